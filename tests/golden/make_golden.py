@@ -1,0 +1,319 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ from the reference itself.
+
+Runs ONLY in the build container, where the reference checkout is mounted at
+/root/reference (it does not exist on the GPU box, and nothing in tests/,
+smoke() or bench.py reads it).  The reference's three hot-path files are
+imported unmodified; the PyG package they import is absent here, so this script
+registers a minimal stand-in first:
+
+* ``torch_geometric.data.Data``        attribute bag (``kernels.py:50,693`` use it
+  only as a kwargs container);
+* ``torch_geometric.nn.MessagePassing`` add-aggregation source -> target, which is
+  PyG's documented ``aggr='add'``, ``flow='source_to_target'`` behaviour;
+* ``global_add_pool`` (index_add over ``batch``) and ``swish`` (x * sigmoid(x)).
+
+What is written is data only: inputs, parameters and the reference's outputs
+and gradients, as compressed ``.npz`` files.
+
+Usage:  python tests/golden/make_golden.py
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = "/root/reference"
+sys.path.insert(0, REPO)
+
+
+def install_pyg_stand_in():
+    tg = types.ModuleType("torch_geometric")
+    tg_data = types.ModuleType("torch_geometric.data")
+    tg_nn = types.ModuleType("torch_geometric.nn")
+    tg_acts = types.ModuleType("torch_geometric.nn.acts")
+
+    class Data:
+        def __init__(self, **kw):
+            for k, v in kw.items():
+                setattr(self, k, v)
+
+    class MessagePassing(torch.nn.Module):
+        def __init__(self, aggr="add", **kw):
+            super().__init__()
+            assert aggr == "add"
+
+        def propagate(self, edge_index, **kw):
+            (name, v), = kw.items()
+            msg = self.message(**{name + "_j": v[edge_index[0]]})
+            out = torch.zeros_like(v)
+            return out.index_add_(0, edge_index[1], msg)
+
+    def global_add_pool(x, batch):
+        n = int(batch.max().item()) + 1
+        return torch.zeros(n, x.shape[1], dtype=x.dtype).index_add_(0, batch, x)
+
+    def swish(x):
+        return x * torch.sigmoid(x)
+
+    tg_data.Data = Data
+    tg_nn.MessagePassing = MessagePassing
+    tg_nn.global_add_pool = global_add_pool
+    tg_acts.swish = swish
+    tg.data, tg.nn = tg_data, tg_nn
+    tg_nn.acts = tg_acts
+    sys.modules.update({"torch_geometric": tg, "torch_geometric.data": tg_data,
+                        "torch_geometric.nn": tg_nn, "torch_geometric.nn.acts": tg_acts})
+    return Data
+
+
+def import_reference():
+    Data = install_pyg_stand_in()
+    sys.path.insert(0, REFERENCE)
+    kernels = importlib.import_module("models.MolKGNN.kernels")
+    layer = importlib.import_module("models.MolKGNN.KernelLayer")
+    net = importlib.import_module("models.MolKGNN.MolKGNNNet")
+    return Data, kernels, layer, net
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrays)} arrays")
+
+
+PARAMS = ("x_center", "x_support", "edge_attr_support", "p_support",
+          "support_attr_sc_weight", "center_attr_sc_weight", "edge_attr_support_sc_weight")
+
+
+def kernelconv_case(kernels, d, F, L, n, last, seed, tie=False, chir_mode=None):
+    """One KernelConv fwd/bwd case; returns dict of arrays (reference outputs)."""
+    E, D = 7, 3
+    torch.manual_seed(seed)
+    conv = kernels.KernelConv(L=L, D=D, num_supports=d, node_attr_dim=F, edge_attr_dim=E)
+    g = torch.Generator().manual_seed(seed + 1)
+    x_focal = torch.randn(n, F, generator=g)
+    x_nei = torch.randn(n, d, F, generator=g)
+    p_focal = torch.randn(n, D, generator=g)
+    p_nei = torch.randn(n, d, D, generator=g)
+    e_nei = (torch.rand(n, d, E, generator=g) < 0.4).float()
+    e_nei[..., 0] = 1.0  # never an all-zero bond vector
+    if tie and d >= 2:
+        # duplicated neighbour rows with different bond attributes
+        x_nei[: n // 2, 1] = x_nei[: n // 2, 0]
+        if d >= 3:
+            x_nei[: n // 4, 2] = x_nei[: n // 4, 0]
+    if chir_mode is not None:
+        assert d == 4
+        # small integers: every determinant below is exact in fp32
+        p_focal = torch.randint(-2, 3, (n, D), generator=g).float()
+        p_nei = torch.randint(-3, 4, (n, d, D), generator=g).float()
+        with torch.no_grad():
+            conv.p_support.copy_(torch.randint(-3, 4, (L, d, D), generator=g).float())
+        # atom 0: two bit-identical neighbour rows -> +1 for every kernel
+        x_nei[0, 3] = x_nei[0, 1]
+        # atom 1: coplanar neighbours -> sign 0 on the atom side
+        p_nei[1] = p_focal[1].unsqueeze(0) + torch.tensor([[1., 0, 0], [0, 1., 0], [1., 1., 0], [2., 1., 0]])
+        # atom 2 and 3: mirror images of each other
+        p_focal[3] = p_focal[2]
+        x_nei[3] = x_nei[2]
+        x_focal[3] = x_focal[2]
+        e_nei[3] = e_nei[2]
+        rel = p_nei[2] - p_focal[2].unsqueeze(0)
+        rel = rel * torch.tensor([1., 1., -1.])
+        p_nei[3] = rel + p_focal[3].unsqueeze(0)
+        # kernel 0: coplanar supports -> sign 0 on the kernel side
+        with torch.no_grad():
+            conv.p_support[0, :, 2] = 0.0
+    x_focal.requires_grad_(True)
+    x_nei.requires_grad_(True)
+    out = {}
+    for k in PARAMS + ("length_sc_weight", "angle_sc_weight"):
+        out["param_" + k] = npy(getattr(conv, k))
+    out.update(x_focal=npy(x_focal), x_neighbor=npy(x_nei), p_focal=npy(p_focal),
+               p_neighbor=npy(p_nei), edge_attr_neighbor=npy(e_nei),
+               is_last_layer=np.array(int(last)), degree=np.array(d))
+    sc = conv(is_last_layer=last, x_focal=x_focal, p_focal=p_focal, x_neighbor=x_nei,
+              p_neighbor=p_nei, edge_attr_neighbor=e_nei)
+    out["sc"] = npy(sc)
+    # the reference's own permutation score table and argmax (kernels.py:368-373)
+    with torch.no_grad():
+        table = conv.get_support_attribute_score(x_nei, conv.permute(conv.x_support))
+        best, idx = torch.max(table, dim=1)
+    out["support_table"] = npy(table)
+    out["best_index"] = npy(idx).astype(np.int64)
+    # gradients: sum() and a random cotangent
+    cot = torch.randn(sc.shape, generator=g)
+    out["cotangent"] = npy(cot)
+    for tag, loss in (("sum", sc.sum()), ("cot", (sc * cot).sum())):
+        grads = torch.autograd.grad(loss, [x_focal, x_nei] + [getattr(conv, k) for k in PARAMS],
+                                    retain_graph=True, allow_unused=True)
+        names = ["x_focal", "x_neighbor"] + list(PARAMS)
+        for nm, gr in zip(names, grads):
+            if gr is None:
+                out[f"grad_{tag}_{nm}_is_none"] = np.array(1)
+            else:
+                out[f"grad_{tag}_{nm}"] = npy(gr)
+    return out
+
+
+def batch_arrays(batch):
+    out = {}
+    for k in batch.keys():
+        v = getattr(batch, k)
+        if torch.is_tensor(v):
+            out["in_" + k] = npy(v)
+    return out
+
+
+def data_from_batch(Data, batch, x=None):
+    kw = {k: getattr(batch, k) for k in batch.keys() if torch.is_tensor(getattr(batch, k))}
+    if x is not None:
+        kw["x"] = x
+    return Data(**kw)
+
+
+def main():
+    Data, kernels, layer, net = import_reference()
+    from molkgnn_amd.synthetic import make_batch
+
+    # ---- G6: docstring known answer (kernels.py:161-170) + permutation tables
+    conv = kernels.KernelConv(L=1, D=3, num_supports=1, node_attr_dim=3, edge_attr_dim=1)
+    t1 = torch.tensor([[[1, 2, 3], [3, 2, 1]], [[1, 2, 3], [3, 2, 1]]], dtype=torch.double)
+    t2 = torch.tensor([[[1, 2, 3], [3, 2, 1]], [[1, 2, 1], [1, 2, 1]]], dtype=torch.double)
+    kat = conv.calculate_average_similarity_score(t1, t2, sim_dim=-1, avg_dim=-2)
+    perm_tables = {}
+    for d in range(1, 5):
+        probe = torch.arange(d, dtype=torch.float32).reshape(1, d, 1)
+        perm_tables[f"perm_deg{d}"] = npy(conv.permute(probe))[0, :, :, 0].astype(np.int64)
+    # cosine edge cases of the container's torch
+    cs = torch.nn.CosineSimilarity(dim=-1)
+    tiny = torch.tensor([1e-6, 0.0])
+    zero = torch.zeros(2)
+    one = torch.tensor([0.6, 0.8])
+    save("g6_kat.npz", kat_t1=npy(t1), kat_t2=npy(t2), kat_out=npy(kat),
+         cos_tiny=npy(cs(tiny, tiny)), cos_zero=npy(cs(zero, one)), **perm_tables)
+
+    # ---- G1: per-degree KernelConv, forward + backward
+    full_L = {1: 10, 2: 20, 3: 30, 4: 50}
+    small_L = {1: 3, 2: 5, 3: 6, 4: 7}
+    g1 = {}
+    for d in range(1, 5):
+        for F, Ls in ((28, full_L), (110, small_L)):
+            for last in ((False, True) if d == 4 else (False,)):
+                tag = f"d{d}_F{F}_last{int(last)}"
+                case = kernelconv_case(kernels, d, F, Ls[d], 8, last, seed=1000 + 10 * d + F)
+                g1.update({f"{tag}/{k}": v for k, v in case.items()})
+    save("g1_kernelconv.npz", **g1)
+
+    # ---- G4: tie cases (duplicated neighbour rows, different bond attrs)
+    g4 = {}
+    for d in (2, 3, 4):
+        case = kernelconv_case(kernels, d, 28, small_L[d] + 3, 16, False, seed=4000 + d, tie=True)
+        g4.update({f"d{d}/{k}": v for k, v in case.items()})
+    save("g4_ties.npz", **g4)
+
+    # ---- G5: chirality cases (degree 4, last layer)
+    case = kernelconv_case(kernels, 4, 28, 9, 8, True, seed=5000, chir_mode="exact")
+    save("g5_chirality.npz", **{f"d4/{k}": v for k, v in case.items()})
+
+    # ---- G2: KernelSetConv on a 3-molecule batch; all degrees / degree 4 absent
+    g2 = {}
+    batch = make_batch(3, seed=22)
+    for tag, b in (("all", batch), ("nodeg4", None)):
+        if b is None:
+            # search a seed whose batch has no degree-4 atom
+            for s in range(100, 200):
+                b = make_batch(3, seed=s)
+                if b.selected_index_deg4.numel() == 0 and b.selected_index_deg3.numel() > 0:
+                    break
+            assert b.selected_index_deg4.numel() == 0
+        for F, Ls, ltag in ((28, (10, 20, 30, 50), "F28"), (110, (3, 5, 6, 7), "F110")):
+            torch.manual_seed(77)
+            ksc = kernels.KernelSetConv(*Ls, D=3, node_attr_dim=F, edge_attr_dim=7)
+            g = torch.Generator().manual_seed(78)
+            x = torch.randn(b.x.shape[0], F, generator=g).requires_grad_(True)
+            for last in (False, True):
+                sc = ksc(is_last_layer=last, data=data_from_batch(Data, b, x=x), save_score=False)
+                g2[f"{tag}_{ltag}/sc_last{int(last)}"] = npy(sc)
+            cot = torch.randn(sc.shape, generator=g)
+            grads = torch.autograd.grad((sc * cot).sum(), [x] + list(ksc.parameters()), allow_unused=True)
+            g2[f"{tag}_{ltag}/cotangent"] = npy(cot)
+            g2[f"{tag}_{ltag}/x"] = npy(x)
+            g2[f"{tag}_{ltag}/grad_x"] = npy(grads[0])
+            for (nm, prm), gr in zip(ksc.named_parameters(), grads[1:]):
+                g2[f"{tag}_{ltag}/param/{nm}"] = npy(prm)
+                if gr is not None:
+                    g2[f"{tag}_{ltag}/grad/{nm}"] = npy(gr)
+            g2[f"{tag}_{ltag}/L"] = np.array(Ls)
+        g2.update({f"{tag}/{k}": v for k, v in batch_arrays(b).items()})
+    save("g2_kernelsetconv.npz", **g2)
+
+    # ---- G3: 3-layer MolGCN / MolKGNNNet, reduced kernel counts, fwd + bwd
+    g3 = {}
+    b = make_batch(3, seed=33)
+    Ls = dict(num_kernel1_1hop=4, num_kernel2_1hop=5, num_kernel3_1hop=6, num_kernel4_1hop=7,
+              num_kernel1_Nhop=4, num_kernel2_Nhop=5, num_kernel3_Nhop=6, num_kernel4_Nhop=7)
+    torch.manual_seed(303)
+    model = net.MolKGNNNet(num_layers=3, x_dim=28, p_dim=3, edge_attr_dim=7,
+                           drop_ratio=0.0, graph_embedding_dim=32, **Ls)
+    model.eval()  # eval-mode BatchNorm (running stats 0/1), dropout off
+    data = data_from_batch(Data, b)
+    # per-layer sim_sc / h by replaying MolGCN.forward's loop (KernelLayer.py:109-119)
+    with torch.no_grad():
+        h = model.node_batch_norm(b.x)
+        for i, lyr in enumerate(model.gnn.layers):
+            sim = lyr(is_last_layer=(i == 2), data=data_from_batch(Data, b, x=h), save_score=False)
+            h = model.gnn.propagate(edge_index=b.edge_index, sim_sc=sim)
+            g3[f"layer{i}_sim_sc"] = npy(sim)
+            g3[f"layer{i}_h"] = npy(h)
+    emb = model(data)
+    g3["graph_embedding"] = npy(emb)
+    gcot = torch.randn(emb.shape, generator=torch.Generator().manual_seed(304))
+    g3["cotangent"] = npy(gcot)
+    (emb * gcot).sum().backward()
+    for nm, prm in model.named_parameters():
+        g3["param/" + nm] = npy(prm)
+        if prm.grad is not None:
+            g3["grad/" + nm] = npy(prm.grad)
+    for nm, buf in model.named_buffers():
+        g3["buffer/" + nm] = npy(buf)
+    g3.update(batch_arrays(b))
+    g3["kernel_counts"] = np.array([4, 5, 6, 7, 4, 5, 6, 7])
+    save("g3_molkgnnnet.npz", **g3)
+
+    # ---- G7: full-size model (10/20/30/50, hidden 32): parameter-init order and
+    #          forward output under a recorded seed (parameters are NOT stored;
+    #          the build's modules must regenerate them from the same seed)
+    Lf = dict(num_kernel1_1hop=10, num_kernel2_1hop=20, num_kernel3_1hop=30, num_kernel4_1hop=50,
+              num_kernel1_Nhop=10, num_kernel2_Nhop=20, num_kernel3_Nhop=30, num_kernel4_Nhop=50)
+    torch.manual_seed(1798)
+    model = net.MolKGNNNet(num_layers=3, x_dim=28, p_dim=3, edge_attr_dim=7,
+                           drop_ratio=0.0, graph_embedding_dim=32, **Lf)
+    model.eval()
+    b = make_batch(4, seed=44)
+    emb = model(data_from_batch(Data, b))
+    g7 = {"graph_embedding": npy(emb), "seed": np.array(1798),
+          "num_params": np.array(sum(p.numel() for p in model.parameters()))}
+    names, sums = [], []
+    for nm, prm in model.named_parameters():
+        names.append(nm)
+        sums.append(float(prm.double().sum()))
+    g7["param_names"] = np.array(names)
+    g7["param_sums"] = np.array(sums)
+    g7["param_shapes"] = np.array([str(tuple(p.shape)) for p in model.parameters()])
+    g7.update(batch_arrays(b))
+    save("g7_fullsize.npz", **g7)
+
+
+if __name__ == "__main__":
+    main()

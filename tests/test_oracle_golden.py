@@ -1,0 +1,163 @@
+"""The CPU oracle against the reference's own outputs (tests/golden/*.npz) -- CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kgnn_oracle as O
+from tests import _golden as G
+
+TOL = 1e-5
+
+
+def test_docstring_known_answer_and_perm_tables():
+    g = G.load("g6_kat.npz")
+    out = O.average_similarity(torch.from_numpy(g["kat_t1"]), torch.from_numpy(g["kat_t2"]), -1, -2)
+    # reference kernels.py:161-170: tensor([1.000, 0.8729])
+    assert torch.allclose(out, torch.tensor([1.0, 0.8729], dtype=torch.double), atol=5e-5)
+    assert np.allclose(out.numpy(), g["kat_out"], atol=1e-12)
+    for d in range(1, 5):
+        assert np.array_equal(np.array(O.perm_table(d)), g[f"perm_deg{d}"])
+    assert len(O.perm_table(4)) == 12
+    # container-torch cosine semantics
+    tiny = torch.tensor([1e-6, 0.0])
+    assert float(O.cosine(tiny, tiny)) == pytest.approx(float(g["cos_tiny"]))
+    assert float(O.cosine(torch.zeros(2), torch.tensor([0.6, 0.8]))) == float(g["cos_zero"]) == 0.0
+
+
+def _check_case(case, tie_free):
+    prm = {k: v.clone().requires_grad_(v.dtype.is_floating_point) for k, v in G.kc_params(case).items()}
+    x_focal, p_focal, x_nei, p_nei, e_nei, last = G.kc_inputs(case)
+    x_focal = x_focal.clone().requires_grad_(True)
+    x_nei = x_nei.clone().requires_grad_(True)
+    sc = O.kernelconv_faithful(prm, x_focal, p_focal, x_nei, p_nei, e_nei, last)
+    assert sc.shape == case["sc"].shape
+    assert torch.allclose(sc, case["sc"], atol=TOL, rtol=0)
+    sc2, table, idx, parts = O.kernelconv_cosmat(prm, x_focal, p_focal, x_nei, p_nei, e_nei, last)
+    assert torch.allclose(table, case["support_table"], atol=2e-6, rtol=0)
+    if tie_free:
+        assert torch.equal(idx, case["best_index"])
+        assert torch.allclose(sc2, case["sc"], atol=TOL, rtol=0)
+    else:
+        bad = O.tie_aware_mismatch(case["sc"], case["best_index"], G.kc_params(case), *G.kc_inputs(case))
+        assert bad == 0
+    # gradients of the faithful form against the reference's autograd
+    names = ["x_focal", "x_neighbor"] + list(G.PARAMS)
+    tensors = [x_focal, x_nei] + [prm[k] for k in G.PARAMS]
+    for tag, loss in (("sum", sc.sum()), ("cot", (sc * case["cotangent"]).sum())):
+        grads = torch.autograd.grad(loss, tensors, retain_graph=True, allow_unused=True)
+        for nm, gr in zip(names, grads):
+            if f"grad_{tag}_{nm}_is_none" in case:
+                assert gr is None, nm            # p_support never receives a gradient (8 a-9)
+            else:
+                ref = case[f"grad_{tag}_{nm}"]
+                assert torch.allclose(gr, ref, atol=2e-5, rtol=1e-4), (tag, nm, (gr - ref).abs().max())
+
+
+def test_kernelconv_per_degree():
+    flat = G.load("g1_kernelconv.npz")
+    names = G.case_names(flat)
+    assert len(names) == 10
+    for nm in names:
+        _check_case(G.group(flat, nm), tie_free=True)
+
+
+def test_kernelconv_ties():
+    flat = G.load("g4_ties.npz")
+    for nm in G.case_names(flat):
+        _check_case(G.group(flat, nm), tie_free=False)
+
+
+def test_kernelconv_chirality():
+    flat = G.load("g5_chirality.npz")
+    case = G.group(flat, "d4")
+    _check_case(case, tie_free=True)
+    sc, table, idx, parts = O.kernelconv_cosmat(G.kc_params(case), *G.kc_inputs(case))
+    chir = parts["chirality"]
+    assert torch.all(chir[:, 0] == 1)                    # bit-identical neighbour rows
+    assert set(chir.unique().tolist()) == {-1.0, 1.0}
+    # atoms 2 and 3 are mirror images: every kernel whose own sign is non-zero flips
+    flipped = (chir[:, 2] != chir[:, 3])
+    assert flipped.sum() >= chir.shape[0] - 2
+
+
+@pytest.mark.parametrize("form", ["faithful", "cosmat"])
+def test_kernelsetconv_batches(form):
+    flat = G.load("g2_kernelsetconv.npz")
+    for tag in ("all", "nodeg4"):
+        b = G.Bag(**{k[len("in_"):]: v for k, v in G.group(flat, tag).items() if k.startswith("in_")})
+        if tag == "nodeg4":
+            assert b.selected_index_deg4.numel() == 0
+        for ltag in ("F28", "F110"):
+            sub = G.group(flat, f"{tag}_{ltag}")
+            state = {k[len("param/"):]: v for k, v in sub.items() if k.startswith("param/")}
+            per_degree = O.kernelset_params(state)
+            x = sub["x"].clone().requires_grad_(True)
+            for p in per_degree:
+                for v in p.values():
+                    v.requires_grad_(True)
+            for last in (False, True):
+                sc = O.kernelsetconv(per_degree, x, b, last, form=form)
+                assert sc.shape == sub[f"sc_last{int(last)}"].shape == (x.shape[0], int(sub["L"].sum()))
+                assert torch.allclose(sc, sub[f"sc_last{int(last)}"], atol=TOL, rtol=0)
+            (sc * sub["cotangent"]).sum().backward()
+            assert torch.allclose(x.grad, sub["grad_x"], atol=2e-5, rtol=1e-4)
+            for d in range(4):
+                for k, v in per_degree[d].items():
+                    key = f"grad/trainable_kernelconv_set.{d}.{k}"
+                    if key in sub:
+                        assert torch.allclose(v.grad, sub[key], atol=2e-5, rtol=1e-4), key
+                    else:
+                        assert v.grad is None or float(v.grad.abs().max()) == 0.0, key
+
+
+def _state(flat):
+    state = {k[len("param/"):]: torch.from_numpy(v).requires_grad_(True) for k, v in flat.items() if k.startswith("param/")}
+    state.update({k[len("buffer/"):]: torch.from_numpy(v) for k, v in flat.items() if k.startswith("buffer/")})
+    return state
+
+
+def test_three_layer_network_faithful():
+    flat = G.load("g3_molkgnnnet.npz")
+    b = G.batch_from(flat)
+    state = _state(flat)
+    collect = []
+    emb = O.molkgnnnet(state, b, num_layers=3, training_bn=False, form="faithful", collect=collect)
+    for i, (sim, h) in enumerate(collect):
+        assert torch.allclose(sim, torch.from_numpy(flat[f"layer{i}_sim_sc"]), atol=TOL, rtol=0)
+        assert torch.allclose(h, torch.from_numpy(flat[f"layer{i}_h"]), atol=2e-5, rtol=0)
+    assert torch.allclose(emb, torch.from_numpy(flat["graph_embedding"]), atol=5e-5, rtol=1e-5)
+    (emb * torch.from_numpy(flat["cotangent"])).sum().backward()
+    n_checked = 0
+    for k, v in state.items():
+        if not v.requires_grad:
+            continue
+        key = "grad/" + k
+        if key in flat:
+            ref = torch.from_numpy(flat[key])
+            assert torch.allclose(v.grad, ref, atol=5e-5, rtol=1e-3), (k, (v.grad - ref).abs().max())
+            n_checked += 1
+        else:
+            assert v.grad is None or float(v.grad.abs().max()) == 0.0, k
+    assert n_checked > 40
+
+
+def test_three_layer_network_cosmat_is_tie_aware_equal():
+    """Layers >= 1 see bit-identical neighbour rows (sibling leaves share
+    h = sim_sc[parent]), so the cos-matrix form may pick another of the tied
+    permutations; it must still satisfy the tie-aware criterion layer by layer
+    when fed the reference's own layer inputs."""
+    flat = G.load("g3_molkgnnnet.npz")
+    b = G.batch_from(flat)
+    state = {k: v.detach() for k, v in _state(flat).items()}
+    x = O.batch_norm(b.x, state["node_batch_norm.weight"], state["node_batch_norm.bias"],
+                     state["node_batch_norm.running_mean"], state["node_batch_norm.running_var"], False)
+    n_ties = 0
+    for i in range(3):
+        per_degree = O.kernelset_params(state, f"gnn.layers.{i}.")
+        idx = []
+        sim = O.kernelsetconv(per_degree, x, b, i == 2, form="cosmat", idx_out=idx)
+        ref = torch.from_numpy(flat[f"layer{i}_sim_sc"])
+        n_ties += int(((sim - ref).abs() > TOL).sum())
+        assert O.kernelset_tie_aware_mismatch(per_degree, x, b, i == 2, sim, idx) == 0
+        x = torch.from_numpy(flat[f"layer{i}_h"])
+    assert n_ties > 0   # the case really exercises the tie rule
