@@ -1,0 +1,144 @@
+/*
+ * molkgnn_hip.h -- C ABI of the MI355X (gfx950) molecular-kernel convolution.
+ *
+ * This is the drop-in boundary for ONE path of LanceKnight/MolKGNN: the
+ * degree-bucketed atom-neighbourhood x learnable-kernel similarity
+ * (reference models/MolKGNN/kernels.py, KernelConv / KernelSetConv) and its
+ * immediate caller's neighbour sum (models/MolKGNN/KernelLayer.py, MolGCN).
+ * The reference has no FFI of its own (it is pure Python over ATen); the entry
+ * points below are what a binding for this path would bind, one per reference
+ * function, and INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *   - plain C, no torch types; every pointer is a DEVICE pointer unless it says host;
+ *   - floats are fp32, indices int64 exactly as the reference's tensors hold them;
+ *   - the caller owns every buffer (inputs, outputs, workspace); nothing is
+ *     allocated or freed inside, no call synchronises, every kernel is launched
+ *     on `stream` (a hipStream_t passed as void*), so calls are graph-capturable;
+ *   - return 0 on success, non-zero on a rejected argument or a launch error;
+ *     mkgnn_last_error() then describes it (thread-local, host pointer);
+ *   - stateless and re-entrant.
+ *
+ * Shapes use the reference's names: N atoms in the batch, F node-attribute
+ * width, E edge-attribute width, D = 3 coordinates, d = degree (1..4),
+ * N_d atoms of degree d, L_d kernels of degree d, K = L_1+L_2+L_3+L_4.
+ */
+#ifndef MOLKGNN_HIP_H
+#define MOLKGNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MKGNN_MAX_DEGREE 4
+#define MKGNN_ABI_VERSION 1
+
+/* One KernelConv's parameters (reference kernels.py:50-84).  The three score
+ * weights are the 0-d parameters support_attr_sc_weight, center_attr_sc_weight
+ * and edge_attr_support_sc_weight; length_sc_weight / angle_sc_weight are never
+ * read by the reference's forward (kernels.py:402-422) and are not passed. */
+typedef struct mkgnn_kernel_bank {
+    int32_t num_kernels;              /* L_d; 0 = this degree has no kernels       */
+    int32_t reserved;
+    const float* x_center;            /* [L_d, F]                                   */
+    const float* x_support;           /* [L_d, d, F]                                */
+    const float* edge_attr_support;   /* [L_d, d, E]                                */
+    const float* p_support;           /* [L_d, d, 3]  (read only for d = 4, last layer) */
+    const float* support_attr_sc_weight;      /* [1] */
+    const float* center_attr_sc_weight;       /* [1] */
+    const float* edge_attr_support_sc_weight; /* [1] */
+} mkgnn_kernel_bank;
+
+/* Gradients of one bank; same shapes.  p_support has no gradient in the
+ * reference (kernels.py:279-350 is not differentiable) and has no slot. */
+typedef struct mkgnn_kernel_bank_grad {
+    float* x_center;
+    float* x_support;
+    float* edge_attr_support;
+    float* support_attr_sc_weight;
+    float* center_attr_sc_weight;
+    float* edge_attr_support_sc_weight;
+} mkgnn_kernel_bank_grad;
+
+/* One degree's receptive fields, the tensors ToXAndPAndEdgeAttrForDeg produces
+ * (reference wrapper.py:596-635) after PyG collation. */
+typedef struct mkgnn_degree_bucket {
+    int64_t count;                    /* N_d                                         */
+    const int64_t* selected_index;    /* [N_d]      focal atom ids                   */
+    const int64_t* nei_index;         /* [N_d * d]  neighbour atom ids, edge-list order */
+    const float* nei_edge_attr;       /* [N_d, d, E] raw bond attributes             */
+    const float* p_focal;             /* [N_d, 3]   (d = 4, last layer only; else may be NULL) */
+    const float* nei_p;               /* [N_d, d, 3] (same)                          */
+} mkgnn_degree_bucket;
+
+/* What forward keeps for backward, per degree (caller-allocated). */
+typedef struct mkgnn_saved {
+    uint8_t* best_index;              /* [L_d, N_d] chosen permutation (kernels.py:373); may be NULL */
+    float* scores;                    /* [3, L_d, N_d] support / centre / edge scores; may be NULL   */
+    int8_t* chirality;                /* [L_d, N_d] +1/-1 (d = 4, last layer); may be NULL           */
+} mkgnn_saved;
+
+int mkgnn_abi_version(void);
+const char* mkgnn_last_error(void);
+
+/* 1 / max(||x_n||, 1e-8) for every row (the cosine normalisation of
+ * torch.nn.CosineSimilarity as used at kernels.py:189).  inv_norm: [N]. */
+int mkgnn_row_inv_norm(const float* x, int64_t x_stride, int64_t n_rows, int32_t F,
+                       float* inv_norm, void* stream);
+
+/* Bytes of scratch the two calls below need for these sizes. */
+size_t mkgnn_workspace_bytes(const int32_t num_kernels[MKGNN_MAX_DEGREE], int32_t F, int32_t E,
+                             int64_t n_atoms, int64_t n_edges);
+
+/* BaseKernelSetConv.forward (kernels.py:610-751) with the per-degree gather
+ * (:519-548), KernelConv.calculate_total_score (:353-425) and the reorder to
+ * node order (:743-747) fused: out[n, :] for atom n holds the L_d scores of its
+ * own degree in columns [off_d, off_d + L_d) and zeros elsewhere.
+ *   x        [N, F] with row stride x_stride (floats)
+ *   inv_norm [N] from mkgnn_row_inv_norm
+ *   out      [N, K] with row stride out_stride; every atom that is in a bucket
+ *            gets its whole row written; other rows are not touched.
+ * variant: 0 = automatic, 1 = generic VALU kernels, 2 = MFMA kernels. */
+int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
+                                const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],
+                                const float* x, int64_t x_stride, const float* inv_norm,
+                                int64_t n_atoms, int32_t F, int32_t E, int32_t is_last_layer,
+                                float* out, int64_t out_stride,
+                                const mkgnn_saved saved[MKGNN_MAX_DEGREE],
+                                void* workspace, size_t workspace_bytes, int32_t variant, void* stream);
+
+/* Gradient of the call above (what autograd derives for the reference).
+ *   grad_out  [N, K] (stride grad_out_stride)
+ *   scatter   CSR over atoms of the contribution rows that belong to each atom:
+ *             contribution rows are numbered bucket by bucket, atom by atom,
+ *             (focal, neighbour 0, .., neighbour d-1); scatter_rowptr [N+1],
+ *             scatter_rows [sum_d N_d (d+1)] (int32).  Built once per batch by
+ *             the host (molkgnn_amd.plan).
+ *   grad_x    [N, F] (stride grad_x_stride), fully overwritten
+ *   grads     per-degree parameter gradients, fully overwritten. */
+int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
+                                 const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],
+                                 const float* x, int64_t x_stride, const float* inv_norm,
+                                 int64_t n_atoms, int32_t F, int32_t E, int32_t is_last_layer,
+                                 const float* grad_out, int64_t grad_out_stride,
+                                 const mkgnn_saved saved[MKGNN_MAX_DEGREE],
+                                 const int32_t* scatter_rowptr, const int32_t* scatter_rows,
+                                 float* grad_x, int64_t grad_x_stride,
+                                 const mkgnn_kernel_bank_grad grads[MKGNN_MAX_DEGREE],
+                                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* MolGCN.propagate with aggr='add' (KernelLayer.py:14,119-123) as a CSR segment
+ * sum: out[i, :] = sum_{k in [rowptr[i], rowptr[i+1])} in[col[k], :].
+ * Forward uses the edges grouped by target (col = sources); the gradient is the
+ * same call on the edges grouped by source (col = targets).  width <= strides. */
+int mkgnn_segment_sum_rows(const float* in, int64_t in_stride, const int32_t* rowptr,
+                           const int32_t* col, int64_t n_rows, int32_t width,
+                           float* out, int64_t out_stride, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOLKGNN_HIP_H */

@@ -1,0 +1,111 @@
+"""Drop-in for the reference's ``models/MolKGNN/KernelLayer.py``: ``MolGCN``,
+the stack of kernel-convolution layers with the neighbour sum between them.
+
+``MolGCN`` keeps the reference's constructor, its keyword-only ``forward`` and
+its ``message(sim_sc_j)``; ``propagate`` (PyG ``aggr='add'``,
+KernelLayer.py:14,119-123) runs as a CSR segment-sum HIP kernel.
+"""
+from __future__ import annotations
+
+import torch
+from torch.nn import ModuleList
+
+from . import functional as Fn
+from .kernels import KernelSetConv
+from .plan import plan_from_lists
+from .receptive_field import GraphBatch
+
+try:
+    from torch_geometric.nn import MessagePassing  # type: ignore
+except Exception:  # PyG absent: the one aggregation the reference uses
+    class MessagePassing(torch.nn.Module):
+        """Minimal ``MessagePassing`` (add-aggregation, source -> target)."""
+
+        def __init__(self, aggr='add', **kwargs):
+            super().__init__()
+            if aggr != 'add':
+                raise NotImplementedError("only aggr='add' is provided")
+            self.aggr = aggr
+
+        def message(self, **kwargs):
+            raise NotImplementedError
+
+try:
+    from torch_geometric.data import Data  # type: ignore
+except Exception:
+    Data = GraphBatch
+
+
+class MolGCN(MessagePassing):
+    def __init__(self, num_layers=5, num_kernel1_1hop=0, num_kernel2_1hop=0, num_kernel3_1hop=0,
+                 num_kernel4_1hop=0, num_kernel1_Nhop=0, num_kernel2_Nhop=0, num_kernel3_Nhop=0,
+                 num_kernel4_Nhop=0, x_dim=5, p_dim=3, edge_attr_dim=1, ):
+        super(MolGCN, self).__init__(aggr='add')
+        self.num_layers = num_layers
+        if num_layers < 1:
+            raise Exception('at least one convolution layer is needed')
+        self.layers = ModuleList()
+        self.num_kernels_list = []
+        # first layer (KernelLayer.py:21-37)
+        if (num_kernel1_1hop is not None) and (num_kernel2_1hop is not None) and (
+                num_kernel3_1hop is not None) and (num_kernel4_1hop is not None):
+            kernel_layer = KernelSetConv(num_kernel1_1hop, num_kernel2_1hop, num_kernel3_1hop, num_kernel4_1hop,
+                                         D=p_dim, node_attr_dim=x_dim, edge_attr_dim=edge_attr_dim)
+            num_kernels = num_kernel1_1hop + num_kernel2_1hop + num_kernel3_1hop + num_kernel4_1hop
+        else:
+            raise Exception('MolGCN: num_kernel1-4 need to be specified')
+        self.layers.append(kernel_layer)
+        self.num_kernels_list.append(num_kernels)
+        # N-hop layers (KernelLayer.py:39-48): input width = previous layer's kernel count
+        for i in range(num_layers - 1):
+            kernel_layer = KernelSetConv(L1=num_kernel1_Nhop, L2=num_kernel2_Nhop, L3=num_kernel3_Nhop,
+                                         L4=num_kernel4_Nhop, D=p_dim, node_attr_dim=self.num_kernels(i),
+                                         edge_attr_dim=edge_attr_dim)
+            self.layers.append(kernel_layer)
+            self.num_kernels_list.append(kernel_layer.get_num_kernel())
+        self._plan = None
+
+    def num_kernels(self, layer):
+        return self.num_kernels_list[layer]
+
+    def set_variant(self, variant: str):
+        for layer in self.layers:
+            layer.variant = variant
+
+    def propagate(self, edge_index, sim_sc=None, **kwargs):
+        """``h[i] = sum_{j -> i} message(sim_sc[j])``; ``message`` is the identity (KernelLayer.py:122-123)."""
+        plan = self._plan
+        if plan is None or plan.edge_index is not edge_index:
+            empty = torch.zeros(0, dtype=torch.long, device=sim_sc.device)
+            emptyf = torch.zeros(0, device=sim_sc.device)
+            plan = plan_from_lists(sim_sc.shape[0], [emptyf] * 4, [emptyf] * 4, [emptyf] * 4, [empty] * 4, [empty] * 4,
+                                   edge_index)
+        k = sim_sc.shape[1]
+        return Fn.propagate_add(sim_sc, plan, out_pad=(-k) % 4)
+
+    def forward(self, *argv, **kwargv):
+        if len(argv) != 0:
+            raise Exception('Kernel does not take positional argument, use keyword argument instead. '
+                            'e.g. model(data=data)')
+        x = kwargv['x']
+        edge_index = kwargv['edge_index']
+        names = ['p_focal', 'nei_p', 'nei_edge_attr', 'selected_index', 'nei_index']
+        fields = {f'{nm}_deg{d}': kwargv[f'{nm}_deg{d}'] for nm in names for d in range(1, 5)}
+        data = Data(x=x, p=kwargv['p'], edge_index=edge_index, edge_attr=kwargv['edge_attr'], **fields)
+        save_score = kwargv['save_score']
+        # one index plan per batch, shared by every layer and by propagate
+        self._plan = plan_from_lists(
+            x.shape[0], *[[fields[f'{nm}_deg{d}'] for d in range(1, 5)] for nm in names], edge_index)
+        h = x
+        try:
+            for i in range(self.num_layers):
+                data.x = h
+                is_last_layer = (i == self.num_layers - 1)
+                sim_sc = self.layers[i]._run(h, self._plan, is_last_layer, save_score)
+                h = self.propagate(edge_index=edge_index, sim_sc=sim_sc)
+        finally:
+            self._plan = None
+        return h
+
+    def message(self, sim_sc_j):
+        return sim_sc_j

@@ -1,0 +1,85 @@
+"""Consumer of the hot path, kept so that the reference's ``model.py`` can build
+it unchanged: BatchNorm(x) -> MolGCN -> lin2(dropout(swish(lin1(h)))) -> add-pool
+(reference ``models/MolKGNN/MolKGNNNet.py:10-149``).  Only ``MolGCN`` is HIP
+code; the readout is plain PyTorch here (SURVEY.md 8 f-3 lists fusing it as
+later work).
+"""
+from __future__ import annotations
+
+import torch
+from torch.nn import BatchNorm1d, Dropout, Linear
+
+from .KernelLayer import MolGCN
+
+
+def swish(x):
+    return x * torch.sigmoid(x)
+
+
+def global_add_pool(x, batch, size=None):
+    size = int(batch.max().item()) + 1 if size is None else size
+    return torch.zeros(size, x.shape[1], dtype=x.dtype, device=x.device).index_add_(0, batch, x)
+
+
+class MolKGNNNet(torch.nn.Module):
+    def __init__(self, num_layers=1, num_kernel1_1hop=0, num_kernel2_1hop=0, num_kernel3_1hop=0,
+                 num_kernel4_1hop=0, num_kernel1_Nhop=0, num_kernel2_Nhop=0, num_kernel3_Nhop=0,
+                 num_kernel4_Nhop=0, predefined_kernelsets=True, x_dim=5, p_dim=3, edge_attr_dim=1,
+                 drop_ratio=0.25, graph_embedding_dim=5):
+        super(MolKGNNNet, self).__init__()
+        self.num_layers = num_layers
+        self.D = p_dim
+        n_hop = num_kernel1_Nhop + num_kernel2_Nhop + num_kernel3_Nhop + num_kernel4_Nhop
+        # module creation order = the reference's (MolKGNNNet.py:20-57), so a seeded init draws the same numbers
+        self.graph_embedding_linear = Linear(n_hop, graph_embedding_dim)
+        self.node_batch_norm = BatchNorm1d(x_dim)
+        self.edge_batch_norm = BatchNorm1d(edge_attr_dim)
+        self.graph_embedding_lin1 = Linear(n_hop, graph_embedding_dim)
+        self.graph_embedding_lin2 = Linear(graph_embedding_dim, graph_embedding_dim)
+        self.dropout = Dropout(drop_ratio)
+        self.act = swish
+        if self.num_layers < 1:
+            raise ValueError("GNN_graphpred: Number of GNN layers must be greater than 0.")
+        self.gnn = MolGCN(num_layers=num_layers, num_kernel1_1hop=num_kernel1_1hop,
+                          num_kernel2_1hop=num_kernel2_1hop, num_kernel3_1hop=num_kernel3_1hop,
+                          num_kernel4_1hop=num_kernel4_1hop, num_kernel1_Nhop=num_kernel1_Nhop,
+                          num_kernel2_Nhop=num_kernel2_Nhop, num_kernel3_Nhop=num_kernel3_Nhop,
+                          num_kernel4_Nhop=num_kernel4_Nhop, x_dim=x_dim, p_dim=p_dim,
+                          edge_attr_dim=edge_attr_dim)
+        self.pool = global_add_pool
+
+    def save_kernellayer(self, path, time_stamp):
+        layers = self.gnn.layers
+        print(f'{self.D}D, there are {len(layers)} layers')
+        for i, layer in enumerate(layers):
+            print(f'saving {i}th layer')
+            torch.save(layer.state_dict(), f'{path}/{time_stamp}_{i}th_layer.pth')
+
+    def forward(self, *argv, save_score=False):
+        if len(argv) != 1:
+            # the reference's 33-positional-argument form reads ``data`` afterwards and cannot work
+            # (MolKGNNNet.py:70-89 then :115); only the single-``data`` form is meaningful
+            raise ValueError("unmatched number of arguments.")
+        data = argv[0]
+        x = self.node_batch_norm(data.x)
+        # edge_batch_norm never reaches the kernel convolution in the reference: skipped
+        kw = {f'{nm}_deg{d}': getattr(data, f'{nm}_deg{d}')
+              for nm in ('p_focal', 'nei_p', 'nei_edge_attr', 'selected_index', 'nei_index') for d in range(1, 5)}
+        node_representation = self.gnn(x=x, edge_index=data.edge_index, edge_attr=data.edge_attr, p=data.p,
+                                       save_score=save_score, **kw)
+        z = self.graph_embedding_lin2(self.dropout(self.act(self.graph_embedding_lin1(node_representation))))
+        size = getattr(data, 'num_graphs', None)
+        return self.pool(z, data.batch, size)
+
+    @staticmethod
+    def add_model_specific_args(parent_parser):
+        parser = parent_parser.add_argument_group("MolKGNNNet")
+        parser.add_argument('--num_layers', type=int, default=4)
+        for hop in ('1hop', 'Nhop'):
+            for d, dflt in zip(range(1, 5), (10, 20, 30, 50)):
+                parser.add_argument(f'--num_kernel{d}_{hop}', type=int, default=dflt)
+        parser.add_argument('--node_feature_dim', type=int, default=28)
+        parser.add_argument('--edge_feature_dim', type=int, default=7)
+        parser.add_argument('--hidden_dim', type=int, default=32)
+        parser.add_argument('--dropout_ratio', type=float, default=0)
+        return parent_parser

@@ -1,0 +1,114 @@
+"""ctypes binding of libmolkgnn_hip.so (the C ABI declared in include/molkgnn_hip.h).
+
+The library is built in-tree by ``make -C molkgnn_amd/csrc`` (or
+``__graft_entry__.build()``).  There is no CPU or PyTorch fallback: if the
+library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmolkgnn_hip.so")
+MAX_DEGREE = 4
+ABI_VERSION = 1
+
+
+class KernelBank(C.Structure):
+    _fields_ = [("num_kernels", C.c_int32), ("reserved", C.c_int32),
+                ("x_center", C.c_void_p), ("x_support", C.c_void_p),
+                ("edge_attr_support", C.c_void_p), ("p_support", C.c_void_p),
+                ("support_attr_sc_weight", C.c_void_p), ("center_attr_sc_weight", C.c_void_p),
+                ("edge_attr_support_sc_weight", C.c_void_p)]
+
+
+class KernelBankGrad(C.Structure):
+    _fields_ = [("x_center", C.c_void_p), ("x_support", C.c_void_p), ("edge_attr_support", C.c_void_p),
+                ("support_attr_sc_weight", C.c_void_p), ("center_attr_sc_weight", C.c_void_p),
+                ("edge_attr_support_sc_weight", C.c_void_p)]
+
+
+class DegreeBucket(C.Structure):
+    _fields_ = [("count", C.c_int64), ("selected_index", C.c_void_p), ("nei_index", C.c_void_p),
+                ("nei_edge_attr", C.c_void_p), ("p_focal", C.c_void_p), ("nei_p", C.c_void_p)]
+
+
+class Saved(C.Structure):
+    _fields_ = [("best_index", C.c_void_p), ("scores", C.c_void_p), ("chirality", C.c_void_p)]
+
+
+Banks4 = KernelBank * MAX_DEGREE
+BankGrads4 = KernelBankGrad * MAX_DEGREE
+Buckets4 = DegreeBucket * MAX_DEGREE
+Saved4 = Saved * MAX_DEGREE
+Int32x4 = C.c_int32 * MAX_DEGREE
+
+EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn_workspace_bytes",
+           "mkgnn_kernelsetconv_forward", "mkgnn_kernelsetconv_backward", "mkgnn_segment_sum_rows")
+
+_lib: Optional[C.CDLL] = None
+
+
+class MolKGNNLibraryError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load (once) and type the shared library; raise if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MolKGNNLibraryError(
+            f"{LIB_PATH} is missing: build it with `make -C molkgnn_amd/csrc` "
+            "(python -c 'import __graft_entry__ as g; g.build()'). There is no fallback path.")
+    lib = C.CDLL(LIB_PATH)
+    for name in EXPORTS:
+        if not hasattr(lib, name):
+            raise MolKGNNLibraryError(f"{LIB_PATH} does not export {name}")
+    lib.mkgnn_abi_version.restype = C.c_int
+    lib.mkgnn_last_error.restype = C.c_char_p
+    lib.mkgnn_row_inv_norm.restype = C.c_int
+    lib.mkgnn_row_inv_norm.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.mkgnn_workspace_bytes.restype = C.c_size_t
+    lib.mkgnn_workspace_bytes.argtypes = [Int32x4, C.c_int32, C.c_int32, C.c_int64, C.c_int64]
+    lib.mkgnn_kernelsetconv_forward.restype = C.c_int
+    lib.mkgnn_kernelsetconv_forward.argtypes = [
+        Banks4, Buckets4, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+        C.c_void_p, C.c_int64, Saved4, C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]
+    lib.mkgnn_kernelsetconv_backward.restype = C.c_int
+    lib.mkgnn_kernelsetconv_backward.argtypes = [
+        Banks4, Buckets4, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+        C.c_void_p, C.c_int64, Saved4, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, BankGrads4,
+        C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.mkgnn_segment_sum_rows.restype = C.c_int
+    lib.mkgnn_segment_sum_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
+                                           C.c_void_p, C.c_int64, C.c_void_p]
+    if lib.mkgnn_abi_version() != ABI_VERSION:
+        raise MolKGNNLibraryError(f"ABI version {lib.mkgnn_abi_version()} != {ABI_VERSION}: rebuild the library")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().mkgnn_last_error()
+        raise MolKGNNLibraryError(f"{what}: {msg.decode() if msg else 'error'}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None or t.numel() == 0 else t.data_ptr()
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu_tensor(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise MolKGNNLibraryError(
+            f"{name} is on {t.device}: the kernel convolution runs on an MI355X only (no CPU fallback)")

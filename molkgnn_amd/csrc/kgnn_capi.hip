@@ -1,0 +1,205 @@
+// C ABI of libmolkgnn_hip.so (include/molkgnn_hip.h): argument checks, workspace
+// carving and kernel launches.  No allocation, no synchronisation.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "kgnn_launch.h"
+
+namespace mkgnn {
+// kgnn_mfma.hip
+bool mfma_forward_supported(int d, int F, int E, int L);
+hipError_t launch_forward_mfma(int d, const FwdArgs& a, hipStream_t st);
+}  // namespace mkgnn
+
+using namespace mkgnn;
+
+static thread_local char g_err[512] = "";
+
+static int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+static int hip_fail(const char* what, hipError_t e) {
+    return fail("%s: %s", what, hipGetErrorString(e));
+}
+
+extern "C" {
+
+int mkgnn_abi_version(void) { return MKGNN_ABI_VERSION; }
+
+const char* mkgnn_last_error(void) { return g_err; }
+
+int mkgnn_row_inv_norm(const float* x, int64_t x_stride, int64_t n_rows, int32_t F, float* inv_norm, void* stream) {
+    if (n_rows < 0 || F <= 0 || x_stride < F) return fail("mkgnn_row_inv_norm: bad shape n=%lld F=%d stride=%lld",
+                                                         (long long)n_rows, F, (long long)x_stride);
+    if (n_rows && (!x || !inv_norm)) return fail("mkgnn_row_inv_norm: null pointer");
+    hipError_t e = launch_row_inv_norm(x, x_stride, n_rows, F, inv_norm, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail("mkgnn_row_inv_norm", e);
+}
+
+size_t mkgnn_workspace_bytes(const int32_t num_kernels[MKGNN_MAX_DEGREE], int32_t F, int32_t E, int64_t n_atoms,
+                             int64_t n_edges) {
+    return make_layout(num_kernels, F, E, n_atoms, n_edges).total;
+}
+
+static int check_common(const char* who, const mkgnn_kernel_bank banks[4], const mkgnn_degree_bucket buckets[4],
+                        const float* x, int64_t x_stride, const float* inv_norm, int64_t n_atoms, int32_t F, int32_t E,
+                        int32_t need_coordinates, int64_t* n_edges_out) {
+    if (!banks || !buckets) return fail("%s: banks/buckets is null", who);
+    if (F <= 0 || F > 256) return fail("%s: node attribute width F=%d outside 1..256", who, F);
+    if (E <= 0 || E > 64) return fail("%s: edge attribute width E=%d outside 1..64", who, E);
+    if (n_atoms < 0 || x_stride < F) return fail("%s: bad x shape", who);
+    if (n_atoms && (!x || !inv_norm)) return fail("%s: x/inv_norm is null", who);
+    int64_t n_edges = 0, n_focal = 0;
+    for (int i = 0; i < 4; ++i) {
+        const mkgnn_kernel_bank& b = banks[i];
+        const mkgnn_degree_bucket& k = buckets[i];
+        if (b.num_kernels < 0 || b.num_kernels > 4096) return fail("%s: degree %d has %d kernels", who, i + 1, b.num_kernels);
+        if (k.count < 0) return fail("%s: degree %d bucket count %lld", who, i + 1, (long long)k.count);
+        if (k.count > 0) {
+            // num_kernels == 0 with atoms present: the degree is skipped here (its rows are left
+            // untouched); the host raises the reference's exception (kernels.py:717-721) when
+            // neither a fixed nor a trainable bank exists for such a degree.
+            if (!k.selected_index || !k.nei_index || !k.nei_edge_attr)
+                return fail("%s: degree %d bucket has null index/edge tensors", who, i + 1);
+            if (i == 3 && need_coordinates && (!k.p_focal || !k.nei_p || !b.p_support))
+                return fail("%s: degree-4 coordinates are required in the last layer (chirality)", who);
+        }
+        if (b.num_kernels > 0 && (!b.x_center || !b.x_support || !b.edge_attr_support || !b.support_attr_sc_weight ||
+                                  !b.center_attr_sc_weight || !b.edge_attr_support_sc_weight))
+            return fail("%s: degree %d bank has null parameters", who, i + 1);
+        n_edges += k.count * (i + 1);
+        n_focal += k.count;
+    }
+    if (n_focal > n_atoms) return fail("%s: buckets hold %lld atoms, batch has %lld", who, (long long)n_focal, (long long)n_atoms);
+    *n_edges_out = n_edges;
+    return 0;
+}
+
+int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
+                                const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE], const float* x, int64_t x_stride,
+                                const float* inv_norm, int64_t n_atoms, int32_t F, int32_t E, int32_t is_last_layer,
+                                float* out, int64_t out_stride, const mkgnn_saved saved[MKGNN_MAX_DEGREE],
+                                void* workspace, size_t workspace_bytes, int32_t variant, void* stream) {
+    const char* who = "mkgnn_kernelsetconv_forward";
+    int64_t n_edges = 0;
+    if (int rc = check_common(who, banks, buckets, x, x_stride, inv_norm, n_atoms, F, E, is_last_layer, &n_edges)) return rc;
+    int32_t L[4];
+    int K = 0;
+    for (int i = 0; i < 4; ++i) { L[i] = banks[i].num_kernels; K += L[i]; }
+    if (out_stride < K || (n_atoms && !out)) return fail("%s: bad out (stride %lld, K %d)", who, (long long)out_stride, K);
+    WorkspaceLayout w = make_layout(L, F, E, n_atoms, n_edges);
+    if (workspace_bytes < w.bank[3].end || !workspace)
+        return fail("%s: workspace of %zu bytes, need %zu", who, workspace_bytes, w.bank[3].end);
+    if (variant < 0 || variant > 2) return fail("%s: variant %d", who, variant);
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    hipError_t e = launch_bank_prepare(banks, w, ws, F, E, st);
+    if (e != hipSuccess) return hip_fail("bank_prepare", e);
+    int off = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int d = i + 1;
+        FwdArgs a;
+        a.x = x; a.xs = x_stride; a.inv = inv_norm;
+        a.sel = buckets[i].selected_index; a.nei = buckets[i].nei_index; a.e_nei = buckets[i].nei_edge_attr;
+        a.p_focal = buckets[i].p_focal; a.p_nei = buckets[i].nei_p;
+        a.n = buckets[i].count; a.F = F; a.E = E; a.L = L[i]; a.last = is_last_layer ? 1 : 0;
+        a.cen = (const float*)(ws + w.bank[i].cen); a.sup = (const float*)(ws + w.bank[i].sup);
+        a.edg = (const float*)(ws + w.bank[i].edg); a.chir = (const int8_t*)(ws + w.bank[i].chir);
+        a.mix = (const float*)(ws + w.bank[i].mix);
+        a.out = out; a.os = out_stride; a.off = off; a.K = K;
+        a.best = saved ? saved[i].best_index : nullptr;
+        a.scores = saved ? saved[i].scores : nullptr;
+        a.chir_out = (saved && d == 4 && is_last_layer) ? saved[i].chirality : nullptr;
+        bool use_mfma = false;
+        if (variant != 1) {
+            use_mfma = mfma_forward_supported(d, F, E, L[i]) && (x_stride % 4 == 0) && (((uintptr_t)x & 15) == 0);
+            if (variant == 2 && !use_mfma && a.n > 0)
+                return fail("%s: MFMA variant does not cover degree %d with F=%d E=%d L=%d stride=%lld", who, d, F, E, L[i],
+                            (long long)x_stride);
+        }
+        e = use_mfma ? launch_forward_mfma(d, a, st) : launch_forward_generic(d, a, st);
+        if (e != hipSuccess) return hip_fail("kernelconv forward launch", e);
+        off += L[i];
+    }
+    return 0;
+}
+
+int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
+                                 const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE], const float* x, int64_t x_stride,
+                                 const float* inv_norm, int64_t n_atoms, int32_t F, int32_t E, int32_t is_last_layer,
+                                 const float* grad_out, int64_t grad_out_stride,
+                                 const mkgnn_saved saved[MKGNN_MAX_DEGREE], const int32_t* scatter_rowptr,
+                                 const int32_t* scatter_rows, float* grad_x, int64_t grad_x_stride,
+                                 const mkgnn_kernel_bank_grad grads[MKGNN_MAX_DEGREE], void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    const char* who = "mkgnn_kernelsetconv_backward";
+    int64_t n_edges = 0;
+    if (int rc = check_common(who, banks, buckets, x, x_stride, inv_norm, n_atoms, F, E, 0, &n_edges)) return rc;
+    if (!saved || !grads) return fail("%s: saved/grads is null", who);
+    int32_t L[4];
+    int K = 0;
+    for (int i = 0; i < 4; ++i) { L[i] = banks[i].num_kernels; K += L[i]; }
+    if (grad_out_stride < K || (n_atoms && !grad_out)) return fail("%s: bad grad_out", who);
+    if (grad_x && grad_x_stride < F) return fail("%s: bad grad_x stride", who);
+    if (grad_x && n_atoms && (!scatter_rowptr || !scatter_rows)) return fail("%s: scatter CSR is null", who);
+    WorkspaceLayout w = make_layout(L, F, E, n_atoms, n_edges);
+    if (workspace_bytes < w.total || !workspace) return fail("%s: workspace of %zu bytes, need %zu", who, workspace_bytes, w.total);
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    hipError_t e = launch_bank_prepare(banks, w, ws, F, E, st);
+    if (e != hipSuccess) return hip_fail("bank_prepare", e);
+    int off = 0;
+    int64_t base = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int d = i + 1;
+        if (buckets[i].count > 0 && (!saved[i].best_index || !saved[i].scores))
+            return fail("%s: degree %d has no saved forward state", who, d);
+        BwdArgs a;
+        a.x = x; a.xs = x_stride; a.inv = inv_norm;
+        a.sel = buckets[i].selected_index; a.nei = buckets[i].nei_index; a.e_nei = buckets[i].nei_edge_attr;
+        a.n = buckets[i].count; a.F = F; a.E = E; a.L = L[i];
+        a.cen = (const float*)(ws + w.bank[i].cen); a.sup = (const float*)(ws + w.bank[i].sup);
+        a.edg = (const float*)(ws + w.bank[i].edg); a.mix = (const float*)(ws + w.bank[i].mix);
+        a.gout = grad_out; a.gs = grad_out_stride; a.off = off;
+        a.best = saved[i].best_index; a.scores = saved[i].scores;
+        a.chir = (d == 4 && is_last_layer) ? saved[i].chirality : nullptr;
+        if (d == 4 && is_last_layer && buckets[i].count > 0 && !a.chir)
+            return fail("%s: degree-4 chirality signs were not saved", who);
+        a.contrib = (float*)(ws + w.contrib); a.contrib_base = base;
+        a.slab = (float*)(ws + w.slab_off[i]);
+        int64_t nc = a.n < BWD_BANK_BLOCKS ? (a.n > 0 ? a.n : 1) : BWD_BANK_BLOCKS;
+        a.nchunk = (int)nc;
+        BankReduceArgs r;
+        r.slab = a.slab; r.nchunk = a.n > 0 ? a.nchunk : 0; r.F = F; r.E = E; r.L = L[i];
+        r.cen = a.cen; r.sup = a.sup; r.edg = a.edg;
+        r.icen = (const float*)(ws + w.bank[i].icen); r.isup = (const float*)(ws + w.bank[i].isup);
+        r.iedg = (const float*)(ws + w.bank[i].iedg);
+        r.g = grads[i];
+        e = launch_backward_generic(d, a, r, st);
+        if (e != hipSuccess) return hip_fail("kernelconv backward launch", e);
+        off += L[i];
+        base += a.n * (d + 1);
+    }
+    if (grad_x) {
+        e = launch_backward_gather((const float*)(ws + w.contrib), scatter_rowptr, scatter_rows, x, x_stride, inv_norm,
+                                   n_atoms, F, grad_x, grad_x_stride, st);
+        if (e != hipSuccess) return hip_fail("backward gather launch", e);
+    }
+    return 0;
+}
+
+int mkgnn_segment_sum_rows(const float* in, int64_t in_stride, const int32_t* rowptr, const int32_t* col, int64_t n_rows,
+                           int32_t width, float* out, int64_t out_stride, void* stream) {
+    if (n_rows < 0 || width <= 0 || in_stride < width || out_stride < width) return fail("mkgnn_segment_sum_rows: bad shape");
+    if (n_rows && (!in || !rowptr || !out)) return fail("mkgnn_segment_sum_rows: null pointer");
+    hipError_t e = launch_segment_sum(in, in_stride, rowptr, col, n_rows, width, out, out_stride, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail("mkgnn_segment_sum_rows", e);
+}
+
+}  // extern "C"

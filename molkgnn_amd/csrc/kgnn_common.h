@@ -1,0 +1,117 @@
+// Shared device helpers and the workspace layout of the gfx950 kernel-convolution kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/molkgnn_hip.h"
+
+#define MKGNN_EPS 1e-8f
+#define MKGNN_WAVE 64
+
+namespace mkgnn {
+
+// Permutation tables of the reference (kernels.py:109-128): lexicographic for
+// d <= 3, the 12 chirality-preserving orders for d = 4.  PERM[p][a] = pi_p(a).
+__device__ __constant__ const int8_t PERM1[1][4] = {{0, 0, 0, 0}};
+__device__ __constant__ const int8_t PERM2[2][4] = {{0, 1, 0, 0}, {1, 0, 0, 0}};
+__device__ __constant__ const int8_t PERM3[6][4] = {{0, 1, 2, 0}, {0, 2, 1, 0}, {1, 0, 2, 0},
+                                                    {1, 2, 0, 0}, {2, 0, 1, 0}, {2, 1, 0, 0}};
+__device__ __constant__ const int8_t PERM4[12][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 0, 3, 2},
+                                                     {1, 2, 0, 3}, {1, 3, 2, 0}, {2, 0, 1, 3}, {2, 1, 3, 0},
+                                                     {2, 3, 0, 1}, {3, 0, 2, 1}, {3, 1, 0, 2}, {3, 2, 1, 0}};
+
+template <int D> struct PermInfo;
+template <> struct PermInfo<1> { static constexpr int P = 1; };
+template <> struct PermInfo<2> { static constexpr int P = 2; };
+template <> struct PermInfo<3> { static constexpr int P = 6; };
+template <> struct PermInfo<4> { static constexpr int P = 12; };
+
+template <int D> __device__ __forceinline__ int perm_at(int p, int a) {
+    if constexpr (D == 1) return 0;
+    else if constexpr (D == 2) return PERM2[p][a];
+    else if constexpr (D == 3) return PERM3[p][a];
+    else return PERM4[p][a];
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+__device__ __forceinline__ float sign_f(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+
+// sign(t3 . (t1 x t2)) with every product and sum rounded separately (no fma
+// contraction), the op order of torch.cross followed by torch.dot
+// (kernels.py:336-341).
+__device__ __forceinline__ float triple_sign(const float* t1, const float* t2, const float* t3) {
+    float cx = __fsub_rn(__fmul_rn(t1[1], t2[2]), __fmul_rn(t1[2], t2[1]));
+    float cy = __fsub_rn(__fmul_rn(t1[2], t2[0]), __fmul_rn(t1[0], t2[2]));
+    float cz = __fsub_rn(__fmul_rn(t1[0], t2[1]), __fmul_rn(t1[1], t2[0]));
+    float dt = __fadd_rn(__fadd_rn(__fmul_rn(t3[0], cx), __fmul_rn(t3[1], cy)), __fmul_rn(t3[2], cz));
+    return sign_f(dt);
+}
+
+// ---------------------------------------------------------------------------
+// Workspace layout.  All offsets in bytes, 256-byte aligned.
+// Per degree d the "prepared bank" holds the unit-normalised kernel rows and
+// what the backward needs to undo the normalisation:
+//   cen   [L, F]      x_center / max(|.|, eps)
+//   sup   [L*d, F]    x_support rows
+//   edg   [L*d, E]    edge_attr_support rows
+//   icen  [L]  isup [L*d]  iedg [L*d]   1 / max(|row|, eps)
+//   chir  [L, 12] int8  sign of the support tetrahedron for every order (d = 4)
+//   mix   [4]  w_support, w_center, w_edge, their sum (kernels.py:402-422)
+// ---------------------------------------------------------------------------
+struct BankLayout {
+    size_t cen, sup, edg, icen, isup, iedg, chir, mix, end;
+};
+
+struct WorkspaceLayout {
+    BankLayout bank[MKGNN_MAX_DEGREE];
+    size_t contrib;       // [sum_d N_d (d+1), F] per-slot gradient rows (backward)
+    size_t slab;          // partial bank gradients, per degree [nblk, bank floats]
+    size_t slab_bytes_per_degree[MKGNN_MAX_DEGREE];
+    size_t slab_off[MKGNN_MAX_DEGREE];
+    size_t total;
+};
+
+static inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
+
+__host__ __device__ static inline size_t bank_floats(int d, int L, int F, int E) {
+    // gradient rows of one bank: centre, supports, edge supports, 3 score weights (+1 pad)
+    return (size_t)L * F + (size_t)L * d * F + (size_t)L * d * E + 4;
+}
+
+constexpr int BWD_BANK_BLOCKS = 256;   // persistent blocks of the bank-gradient kernel
+
+static inline WorkspaceLayout make_layout(const int32_t L[MKGNN_MAX_DEGREE], int F, int E,
+                                          int64_t n_atoms, int64_t n_edges) {
+    WorkspaceLayout w;
+    size_t off = 0;
+    for (int i = 0; i < MKGNN_MAX_DEGREE; ++i) {
+        int d = i + 1;
+        size_t l = (size_t)L[i];
+        BankLayout& b = w.bank[i];
+        b.cen = off;  off = align_up(off + l * F * 4);
+        b.sup = off;  off = align_up(off + l * d * F * 4);
+        b.edg = off;  off = align_up(off + l * d * E * 4);
+        b.icen = off; off = align_up(off + l * 4);
+        b.isup = off; off = align_up(off + l * d * 4);
+        b.iedg = off; off = align_up(off + l * d * 4);
+        b.chir = off; off = align_up(off + l * 12);
+        b.mix = off;  off = align_up(off + 16);
+        b.end = off;
+    }
+    w.contrib = off;
+    off = align_up(off + (size_t)(n_atoms + n_edges) * F * 4);
+    w.slab = off;
+    for (int i = 0; i < MKGNN_MAX_DEGREE; ++i) {
+        w.slab_off[i] = off;
+        w.slab_bytes_per_degree[i] = align_up(bank_floats(i + 1, L[i], F, E) * 4 * BWD_BANK_BLOCKS);
+        off += w.slab_bytes_per_degree[i];
+    }
+    w.total = off;
+    return w;
+}
+
+}  // namespace mkgnn

@@ -1,0 +1,537 @@
+// Generic (any F, E, L) gfx950 kernels of the molecular-kernel convolution.
+//
+// These are the shape-agnostic kernels: the bank preparation, the backward
+// pass and a plain forward that serves every (F, E, L) the reference's
+// constructors accept.  The MFMA forward for the shapes the model actually
+// uses lives in kgnn_mfma.hip.  Wave = 64 lanes everywhere.
+//
+// Reference being computed: models/MolKGNN/kernels.py
+//   calculate_total_score :353-425, permute :89-130, get_chirality_sign :279-350,
+//   BaseKernelSetConv.forward :610-751.
+#include "kgnn_launch.h"
+
+namespace mkgnn {
+
+// ------------------------------------------------------------------ P1 ----
+// 1 / max(||row||, eps); one wave per row.
+__global__ void row_inv_norm_kernel(const float* __restrict__ x, int64_t stride, int64_t n, int F,
+                                    float* __restrict__ inv) {
+    const int lane = threadIdx.x & 63;
+    int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n; r += nwaves) {
+        float s = 0.f;
+        for (int f = lane; f < F; f += 64) {
+            float v = x[r * stride + f];
+            s = fmaf(v, v, s);
+        }
+        s = wave_sum(s);
+        if (lane == 0) inv[r] = 1.f / fmaxf(sqrtf(s), MKGNN_EPS);
+    }
+}
+
+// ------------------------------------------------------------------ P2 ----
+
+// Unit-normalise every kernel row, keep 1/norm, tabulate the support
+// tetrahedron signs and the mixing weights.  One wave per task.
+__global__ void bank_prepare_kernel(PrepArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int task = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (task >= a.row_start[MKGNN_MAX_DEGREE]) return;
+    int i = 0;
+    while (task >= a.row_start[i + 1]) ++i;
+    const int d = i + 1;
+    const int L = a.bank[i].num_kernels;
+    int r = task - a.row_start[i];
+    // task order inside a degree: L centre rows, L*d support rows, L*d edge rows, 1 misc task
+    const float* src;
+    float* dst;
+    float* inv;
+    int width;
+    if (r < L) {
+        src = a.bank[i].x_center + (size_t)r * a.F; dst = a.cen[i] + (size_t)r * a.F; inv = a.icen[i] + r; width = a.F;
+    } else if (r < L + L * d) {
+        r -= L;
+        src = a.bank[i].x_support + (size_t)r * a.F; dst = a.sup[i] + (size_t)r * a.F; inv = a.isup[i] + r; width = a.F;
+    } else if (r < L + 2 * L * d) {
+        r -= L + L * d;
+        src = a.bank[i].edge_attr_support + (size_t)r * a.E; dst = a.edg[i] + (size_t)r * a.E; inv = a.iedg[i] + r; width = a.E;
+    } else {
+        // misc: mixing weights (kernels.py:402-412) and chirality table (:331-341)
+        if (lane == 0) {
+            float es = expf(*a.bank[i].support_attr_sc_weight);
+            float ec = expf(*a.bank[i].center_attr_sc_weight);
+            float ee = expf(*a.bank[i].edge_attr_support_sc_weight);
+            float den = __fadd_rn(__fadd_rn(es, ec), ee);
+            float ws = es / den, wc = ec / den, we = ee / den;
+            a.mix[i][0] = ws; a.mix[i][1] = wc; a.mix[i][2] = we;
+            a.mix[i][3] = __fadd_rn(__fadd_rn(ws, wc), we);
+        }
+        if (d == 4 && a.bank[i].p_support != nullptr) {
+            for (int t = lane; t < L * 12; t += 64) {
+                int l = t / 12, p = t % 12;
+                const float* ps = a.bank[i].p_support + (size_t)l * 12;   // [4, 3]
+                const float* t1 = ps + 3 * PERM4[p][0];
+                const float* t2 = ps + 3 * PERM4[p][1];
+                const float* t3 = ps + 3 * PERM4[p][2];
+                a.chir[i][t] = (int8_t)triple_sign(t1, t2, t3);
+            }
+        }
+        return;
+    }
+    float s = 0.f;
+    for (int f = lane; f < width; f += 64) {
+        float v = src[f];
+        s = fmaf(v, v, s);
+    }
+    s = wave_sum(s);
+    float iv = 1.f / fmaxf(sqrtf(s), MKGNN_EPS);
+    for (int f = lane; f < width; f += 64) dst[f] = src[f] * iv;
+    if (lane == 0) *inv = iv;
+}
+
+// ------------------------------------------------------------- forward ----
+
+template <int D> struct PermC;
+template <> struct PermC<1> { static constexpr int P = 1;  static constexpr int8_t t[1][4] = {{0, 0, 0, 0}}; };
+template <> struct PermC<2> { static constexpr int P = 2;  static constexpr int8_t t[2][4] = {{0, 1, 0, 0}, {1, 0, 0, 0}}; };
+template <> struct PermC<3> { static constexpr int P = 6;  static constexpr int8_t t[6][4] = {{0, 1, 2, 0}, {0, 2, 1, 0}, {1, 0, 2, 0}, {1, 2, 0, 0}, {2, 0, 1, 0}, {2, 1, 0, 0}}; };
+template <> struct PermC<4> { static constexpr int P = 12; static constexpr int8_t t[12][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 0, 3, 2}, {1, 2, 0, 3}, {1, 3, 2, 0}, {2, 0, 1, 3}, {2, 1, 3, 0}, {2, 3, 0, 1}, {3, 0, 2, 1}, {3, 1, 0, 2}, {3, 2, 1, 0}}; };
+
+// Best permutation of a d x d cosine matrix: every order scored as
+// ((c0+c1)+c2)+c3 then / d, strict '>' scan in table order.
+template <int D>
+__device__ __forceinline__ void best_permutation(const float (&cm)[D][D], float& best, int& idx) {
+    best = 0.f; idx = 0;
+#pragma unroll
+    for (int p = 0; p < PermC<D>::P; ++p) {
+        float s = cm[0][PermC<D>::t[p][0]];
+#pragma unroll
+        for (int a = 1; a < D; ++a) s = __fadd_rn(s, cm[a][PermC<D>::t[p][a]]);
+        s = s / (float)D;
+        if (p == 0 || s > best) { best = s; idx = p; }
+    }
+}
+
+// One wave per atom, lanes over kernels.  Plain and cache-served: this is the
+// any-shape path, not the fast one.
+template <int D>
+__global__ void __launch_bounds__(256) kc_forward_generic(FwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const float ws = a.mix[0], wc = a.mix[1], we = a.mix[2], wsum = a.mix[3];
+    for (int64_t n = wave; n < a.n; n += nwaves) {
+        const int64_t focal = a.sel[n];
+        int64_t nb[D];
+        float inb[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) { nb[j] = a.nei[n * D + j]; inb[j] = a.inv[nb[j]]; }
+        const float ifoc = a.inv[focal];
+        // neighbour bond vectors: 1 / max(|e|, eps)
+        float ie[D];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            float s = 0.f;
+            for (int e = lane; e < a.E; e += 64) { float v = a.e_nei[(n * D + j) * a.E + e]; s = fmaf(v, v, s); }
+            s = wave_sum(s);
+            ie[j] = 1.f / fmaxf(sqrtf(s), MKGNN_EPS);
+        }
+        // chirality, atom side (kernels.py:305-337)
+        bool not_chiral = false;
+        float sign_nei = 0.f;
+        const bool do_chir = (D == 4) && a.last;
+        if constexpr (D == 4) {
+            if (do_chir) {
+                unsigned pair_diff = 0;   // bit k set: pair k differs somewhere in my lanes
+                for (int f = lane; f < a.F; f += 64) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = a.x[nb[j] * a.xs + f];
+                    int k = 0;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = i + 1; j < 4; ++j, ++k)
+                            if (!(v[i] == v[j])) pair_diff |= 1u << k;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) pair_diff |= __shfl_xor((int)pair_diff, o, 64);
+                not_chiral = (pair_diff != 0x3Fu);   // some pair is equal everywhere
+                float t[3][3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        t[j][c] = __fsub_rn(a.p_nei[(n * 4 + j) * 3 + c], a.p_focal[n * 3 + c]);
+                sign_nei = triple_sign(t[0], t[1], t[2]);
+            }
+        }
+        for (int l = lane; l < a.L; l += 64) {
+            float cm[D][D];
+            float cc = 0.f;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) cm[i][j] = 0.f;
+            const float* cen = a.cen + (size_t)l * a.F;
+            const float* sup = a.sup + (size_t)l * D * a.F;
+            for (int f = 0; f < a.F; ++f) {
+                float xf = a.x[focal * a.xs + f];
+                cc = fmaf(xf, cen[f], cc);
+                float sv[D];
+#pragma unroll
+                for (int j = 0; j < D; ++j) sv[j] = sup[j * a.F + f];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    float xv = a.x[nb[i] * a.xs + f];
+#pragma unroll
+                    for (int j = 0; j < D; ++j) cm[i][j] = fmaf(xv, sv[j], cm[i][j]);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) cm[i][j] *= inb[i];
+            cc *= ifoc;
+            float best; int idx;
+            best_permutation<D>(cm, best, idx);
+            // edge score with the same permutation (kernels.py:382-390)
+            float ed = 0.f;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                const float* es = a.edg + ((size_t)l * D + perm_at<D>(idx, i)) * a.E;
+                const float* en = a.e_nei + (n * D + i) * a.E;
+                float dt = 0.f;
+                for (int e = 0; e < a.E; ++e) dt = fmaf(en[e], es[e], dt);
+                dt *= ie[i];
+                ed = (i == 0) ? dt : __fadd_rn(ed, dt);
+            }
+            ed = ed / (float)D;
+            float sc = __fadd_rn(__fadd_rn(__fmul_rn(best, ws), __fmul_rn(cc, wc)), __fmul_rn(ed, we)) / wsum;
+            float ch = 1.f;
+            if constexpr (D == 4) {
+                if (do_chir && !not_chiral) ch = ((float)a.chir[l * 12 + idx] == sign_nei) ? 1.f : -1.f;
+                sc *= ch;
+            }
+            a.out[focal * a.os + a.off + l] = sc;
+            if (a.best) a.best[(size_t)l * a.n + n] = (uint8_t)idx;
+            if (a.scores) {
+                size_t ln = (size_t)a.L * a.n;
+                a.scores[(size_t)l * a.n + n] = best;
+                a.scores[ln + (size_t)l * a.n + n] = cc;
+                a.scores[2 * ln + (size_t)l * a.n + n] = ed;
+            }
+            if (a.chir_out) a.chir_out[(size_t)l * a.n + n] = (int8_t)ch;
+        }
+        // the rest of the atom's output row is zero (kernels.py:674-675, 725-727)
+        for (int k = lane; k < a.K; k += 64)
+            if (k < a.off || k >= a.off + a.L) a.out[focal * a.os + k] = 0.f;
+    }
+}
+
+// ------------------------------------------------------------ backward ----
+
+// B1: gradient w.r.t. the unit rows of every (atom, slot): one wave per atom,
+// lanes over features.  slot 0 = focal row, slot 1+a = neighbour a.
+template <int D>
+__global__ void __launch_bounds__(256) kc_backward_rows(BwdArgs a) {
+    const int lane = threadIdx.x & 63;
+    int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const float ws = a.mix[0] / a.mix[3], wc = a.mix[1] / a.mix[3];
+    for (int64_t n = wave; n < a.n; n += nwaves) {
+        const int64_t focal = a.sel[n];
+        for (int f0 = 0; f0 < a.F; f0 += 64) {
+            const int f = f0 + lane;
+            float acc[D + 1];
+#pragma unroll
+            for (int s = 0; s <= D; ++s) acc[s] = 0.f;
+            for (int l = 0; l < a.L; ++l) {
+                float g = a.gout[focal * a.gs + a.off + l];
+                if (a.chir) g *= (float)a.chir[(size_t)l * a.n + n];
+                const int idx = a.best[(size_t)l * a.n + n];
+                if (f < a.F) {
+                    acc[0] = fmaf(g * wc, a.cen[(size_t)l * a.F + f], acc[0]);
+                    const float gsup = g * ws / (float)D;
+#pragma unroll
+                    for (int s = 0; s < D; ++s)
+                        acc[1 + s] = fmaf(gsup, a.sup[((size_t)l * D + perm_at<D>(idx, s)) * a.F + f], acc[1 + s]);
+                }
+            }
+            if (f < a.F) {
+#pragma unroll
+                for (int s = 0; s <= D; ++s)
+                    a.contrib[(a.contrib_base + n * (D + 1) + s) * a.F + f] = acc[s];
+            }
+        }
+    }
+}
+
+// B2: partial gradients of the unit kernel rows.  grid = (bank rows, chunks of
+// atoms); lanes over features.  Row order of a bank gradient:
+//   [0, L)            centre rows            (width F)
+//   [L, L + L*D)      support rows (l, b)    (width F)
+//   [L+L*D, L+2*L*D)  edge rows (l, b)       (width E)
+//   then 3 score-weight partials.
+template <int D>
+__global__ void __launch_bounds__(128) kc_backward_bank(BwdArgs a) {
+    const int r = blockIdx.x;
+    const int c = blockIdx.y;
+    const int L = a.L;
+    const int64_t lo = a.n * c / a.nchunk, hi = a.n * (c + 1) / a.nchunk;
+    const size_t bank_fl = bank_floats(D, L, a.F, a.E);
+    float* slab = a.slab + (size_t)c * bank_fl;
+    const float ws = a.mix[0] / a.mix[3], wc = a.mix[1] / a.mix[3], we = a.mix[2] / a.mix[3];
+    const int nrow = L + 2 * L * D;
+    if (r == nrow) {
+        // score-weight partials: d sc / d theta_k = w_k (score_k - sc) / W  
+        float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+        const size_t ln = (size_t)L * a.n;
+        for (int64_t n = lo; n < hi; ++n) {
+            const int64_t focal = a.sel[n];
+            for (int l = threadIdx.x; l < L; l += blockDim.x) {
+                float g = a.gout[focal * a.gs + a.off + l];
+                if (a.chir) g *= (float)a.chir[(size_t)l * a.n + n];
+                float S = a.scores[(size_t)l * a.n + n], C = a.scores[ln + (size_t)l * a.n + n],
+                      Ed = a.scores[2 * ln + (size_t)l * a.n + n];
+                float sc = (S * a.mix[0] + C * a.mix[1] + Ed * a.mix[2]) / a.mix[3];
+                p0 = fmaf(g * ws, S - sc, p0);
+                p1 = fmaf(g * wc, C - sc, p1);
+                p2 = fmaf(g * we, Ed - sc, p2);
+            }
+        }
+        __shared__ float red[3][2];
+        p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { red[0][w] = p0; red[1][w] = p1; red[2][w] = p2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            size_t o = (size_t)L * a.F + (size_t)L * D * a.F + (size_t)L * D * a.E;
+            slab[o + 0] = red[0][0] + red[0][1];
+            slab[o + 1] = red[1][0] + red[1][1];
+            slab[o + 2] = red[2][0] + red[2][1];
+        }
+        return;
+    }
+    int l, b, kind;   // kind 0 centre, 1 support, 2 edge
+    size_t out_off;
+    if (r < L) { kind = 0; l = r; b = 0; out_off = (size_t)r * a.F; }
+    else if (r < L + L * D) { kind = 1; l = (r - L) / D; b = (r - L) % D; out_off = (size_t)L * a.F + (size_t)(r - L) * a.F; }
+    else { kind = 2; l = (r - L - L * D) / D; b = (r - L - L * D) % D;
+           out_off = (size_t)L * a.F + (size_t)L * D * a.F + (size_t)(r - L - L * D) * a.E; }
+    const int width = (kind == 2) ? a.E : a.F;
+    for (int f = threadIdx.x; f < width; f += blockDim.x) {
+        float acc = 0.f;
+        for (int64_t n = lo; n < hi; ++n) {
+            const int64_t focal = a.sel[n];
+            float g = a.gout[focal * a.gs + a.off + l];
+            if (a.chir) g *= (float)a.chir[(size_t)l * a.n + n];
+            if (kind == 0) {
+                acc = fmaf(g * wc * a.inv[focal], a.x[focal * a.xs + f], acc);
+            } else {
+                const int idx = a.best[(size_t)l * a.n + n];
+                // which neighbour slot was matched to support b: pi(slot) == b
+                int slot = 0;
+#pragma unroll
+                for (int s = 0; s < D; ++s) if (perm_at<D>(idx, s) == b) slot = s;
+                if (kind == 1) {
+                    const int64_t nbr = a.nei[n * D + slot];
+                    acc = fmaf(g * ws / (float)D * a.inv[nbr], a.x[nbr * a.xs + f], acc);
+                } else {
+                    const float* en = a.e_nei + (n * D + slot) * a.E;
+                    float s2 = 0.f;
+                    for (int e = 0; e < a.E; ++e) s2 = fmaf(en[e], en[e], s2);
+                    float ie = 1.f / fmaxf(sqrtf(s2), MKGNN_EPS);
+                    acc = fmaf(g * we / (float)D * ie, en[f], acc);
+                }
+            }
+        }
+        slab[out_off + f] = acc;
+    }
+}
+
+
+// Sum the chunk partials and undo the unit normalisation:
+// d/ds of s/max(|s|,eps):  (g - (g . s^) s^) / |s|   (or g / eps below eps).
+template <int D>
+__global__ void __launch_bounds__(64) kc_backward_bank_reduce(BankReduceArgs a) {
+    const int r = blockIdx.x;
+    const int lane = threadIdx.x;
+    const int L = a.L;
+    const size_t bank_fl = bank_floats(D, L, a.F, a.E);
+    const int nrow = L + 2 * L * D;
+    if (r == nrow) {
+        if (lane < 3) {
+            size_t o = (size_t)L * a.F + (size_t)L * D * a.F + (size_t)L * D * a.E + lane;
+            float s = 0.f;
+            for (int c = 0; c < a.nchunk; ++c) s += a.slab[(size_t)c * bank_fl + o];
+            float* dst = lane == 0 ? a.g.support_attr_sc_weight : (lane == 1 ? a.g.center_attr_sc_weight : a.g.edge_attr_support_sc_weight);
+            if (dst) *dst = s;
+        }
+        return;
+    }
+    const float* unit; float inv; float* dst; size_t off; int width;
+    if (r < L) { unit = a.cen + (size_t)r * a.F; inv = a.icen[r]; dst = a.g.x_center ? a.g.x_center + (size_t)r * a.F : nullptr; off = (size_t)r * a.F; width = a.F; }
+    else if (r < L + L * D) { int q = r - L; unit = a.sup + (size_t)q * a.F; inv = a.isup[q]; dst = a.g.x_support ? a.g.x_support + (size_t)q * a.F : nullptr; off = (size_t)L * a.F + (size_t)q * a.F; width = a.F; }
+    else { int q = r - L - L * D; unit = a.edg + (size_t)q * a.E; inv = a.iedg[q]; dst = a.g.edge_attr_support ? a.g.edge_attr_support + (size_t)q * a.E : nullptr; off = (size_t)L * a.F + (size_t)L * D * a.F + (size_t)q * a.E; width = a.E; }
+    if (!dst) return;
+    float dotp = 0.f;
+    for (int f = lane; f < width; f += 64) {
+        float s = 0.f;
+        for (int c = 0; c < a.nchunk; ++c) s += a.slab[(size_t)c * bank_fl + off + f];
+        dst[f] = s;
+        dotp = fmaf(s, unit[f], dotp);
+    }
+    dotp = wave_sum(dotp);
+    const bool clamped = inv >= (1.f / MKGNN_EPS);
+    for (int f = lane; f < width; f += 64) {
+        float s = dst[f];
+        dst[f] = clamped ? s * inv : (s - dotp * unit[f]) * inv;
+    }
+}
+
+// B3: per atom, sum the contribution rows that point at it and undo the row
+// normalisation.  One wave per atom.
+__global__ void __launch_bounds__(256) kc_backward_gather(const float* __restrict__ contrib, const int32_t* __restrict__ rowptr,
+                                                          const int32_t* __restrict__ rows, const float* __restrict__ x,
+                                                          int64_t xs, const float* __restrict__ inv, int64_t n, int F,
+                                                          float* __restrict__ gx, int64_t gxs) {
+    const int lane = threadIdx.x & 63;
+    int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t j = wave; j < n; j += nwaves) {
+        const int lo = rowptr[j], hi = rowptr[j + 1];
+        const float iv = inv[j];
+        const bool clamped = iv >= (1.f / MKGNN_EPS);
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};   // F <= 256
+        float dotp = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int f = lane + 64 * t;
+            if (f < F) {
+                float s = 0.f;
+                for (int k = lo; k < hi; ++k) s += contrib[(size_t)rows[k] * F + f];
+                acc[t] = s;
+                dotp = fmaf(s, x[j * xs + f] * iv, dotp);
+            }
+        }
+        dotp = wave_sum(dotp);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int f = lane + 64 * t;
+            if (f < F) {
+                float u = x[j * xs + f] * iv;
+                gx[j * gxs + f] = clamped ? acc[t] * iv : (acc[t] - dotp * u) * iv;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------- propagate ----
+// out[i, :] = sum_k in[col[k], :] over the CSR segment of row i; one wave per
+// row, lanes over columns (KernelLayer.py:119-123 with aggr='add').
+__global__ void __launch_bounds__(256) segment_sum_rows_kernel(const float* __restrict__ in, int64_t is,
+                                                               const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
+                                                               int64_t n, int width, float* __restrict__ out, int64_t os) {
+    const int lane = threadIdx.x & 63;
+    int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < n; i += nwaves) {
+        const int lo = rowptr[i], hi = rowptr[i + 1];
+        for (int f = lane; f < width; f += 64) {
+            float s = 0.f;
+            for (int k = lo; k < hi; ++k) s += in[(size_t)col[k] * is + f];
+            out[i * os + f] = s;
+        }
+    }
+}
+
+// ------------------------------------------------------------ launchers ---
+static inline int grid_for_waves(int64_t waves, int threads = 256) {
+    int64_t per_block = threads / 64;
+    int64_t blocks = (waves + per_block - 1) / per_block;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    return (int)blocks;
+}
+
+hipError_t launch_row_inv_norm(const float* x, int64_t stride, int64_t n, int F, float* inv, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    row_inv_norm_kernel<<<grid_for_waves(n), 256, 0, st>>>(x, stride, n, F, inv);
+    return hipGetLastError();
+}
+
+hipError_t launch_bank_prepare(const mkgnn_kernel_bank banks[4], const WorkspaceLayout& w, char* ws, int F, int E,
+                               hipStream_t st) {
+    PrepArgs a;
+    a.F = F; a.E = E;
+    a.row_start[0] = 0;
+    for (int i = 0; i < 4; ++i) {
+        a.bank[i] = banks[i];
+        a.cen[i] = (float*)(ws + w.bank[i].cen);   a.sup[i] = (float*)(ws + w.bank[i].sup);
+        a.edg[i] = (float*)(ws + w.bank[i].edg);   a.icen[i] = (float*)(ws + w.bank[i].icen);
+        a.isup[i] = (float*)(ws + w.bank[i].isup); a.iedg[i] = (float*)(ws + w.bank[i].iedg);
+        a.chir[i] = (int8_t*)(ws + w.bank[i].chir); a.mix[i] = (float*)(ws + w.bank[i].mix);
+        int L = banks[i].num_kernels, d = i + 1;
+        a.row_start[i + 1] = a.row_start[i] + (L > 0 ? L + 2 * L * d + 1 : 0);
+    }
+    int tasks = a.row_start[4];
+    if (tasks == 0) return hipSuccess;
+    bank_prepare_kernel<<<(tasks + 3) / 4, 256, 0, st>>>(a);
+    return hipGetLastError();
+}
+
+template <int D>
+static hipError_t launch_fwd_d(const FwdArgs& a, hipStream_t st) {
+    kc_forward_generic<D><<<grid_for_waves(a.n), 256, 0, st>>>(a);
+    return hipGetLastError();
+}
+
+hipError_t launch_forward_generic(int d, const FwdArgs& a, hipStream_t st) {
+    if (a.n == 0 || a.L == 0) return hipSuccess;
+    switch (d) {
+        case 1: return launch_fwd_d<1>(a, st);
+        case 2: return launch_fwd_d<2>(a, st);
+        case 3: return launch_fwd_d<3>(a, st);
+        default: return launch_fwd_d<4>(a, st);
+    }
+}
+
+template <int D>
+static hipError_t launch_bwd_d(const BwdArgs& a, const BankReduceArgs& r, hipStream_t st) {
+    if (a.n > 0) {
+        kc_backward_rows<D><<<grid_for_waves(a.n), 256, 0, st>>>(a);
+        dim3 grid(a.L + 2 * a.L * D + 1, a.nchunk);
+        kc_backward_bank<D><<<grid, 128, 0, st>>>(a);
+    }
+    kc_backward_bank_reduce<D><<<a.L + 2 * a.L * D + 1, 64, 0, st>>>(r);
+    return hipGetLastError();
+}
+
+hipError_t launch_backward_generic(int d, const BwdArgs& a, const BankReduceArgs& r, hipStream_t st) {
+    if (a.L == 0) return hipSuccess;
+    switch (d) {
+        case 1: return launch_bwd_d<1>(a, r, st);
+        case 2: return launch_bwd_d<2>(a, r, st);
+        case 3: return launch_bwd_d<3>(a, r, st);
+        default: return launch_bwd_d<4>(a, r, st);
+    }
+}
+
+hipError_t launch_backward_gather(const float* contrib, const int32_t* rowptr, const int32_t* rows, const float* x,
+                                  int64_t xs, const float* inv, int64_t n, int F, float* gx, int64_t gxs,
+                                  hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    kc_backward_gather<<<grid_for_waves(n), 256, 0, st>>>(contrib, rowptr, rows, x, xs, inv, n, F, gx, gxs);
+    return hipGetLastError();
+}
+
+hipError_t launch_segment_sum(const float* in, int64_t is, const int32_t* rowptr, const int32_t* col, int64_t n,
+                              int width, float* out, int64_t os, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    segment_sum_rows_kernel<<<grid_for_waves(n), 256, 0, st>>>(in, is, rowptr, col, n, width, out, os);
+    return hipGetLastError();
+}
+
+}  // namespace mkgnn

@@ -1,0 +1,59 @@
+// Kernel argument blocks and host-side launchers shared by the C ABI and the kernel files.
+#pragma once
+#include "kgnn_common.h"
+
+namespace mkgnn {
+
+struct PrepArgs {
+    mkgnn_kernel_bank bank[MKGNN_MAX_DEGREE];
+    float* cen[MKGNN_MAX_DEGREE];
+    float* sup[MKGNN_MAX_DEGREE];
+    float* edg[MKGNN_MAX_DEGREE];
+    float* icen[MKGNN_MAX_DEGREE];
+    float* isup[MKGNN_MAX_DEGREE];
+    float* iedg[MKGNN_MAX_DEGREE];
+    int8_t* chir[MKGNN_MAX_DEGREE];
+    float* mix[MKGNN_MAX_DEGREE];
+    int row_start[MKGNN_MAX_DEGREE + 1];   // wave-task prefix: rows of degree i are [row_start[i], row_start[i+1])
+    int F, E;
+};
+
+struct FwdArgs {
+    const float* x; int64_t xs; const float* inv;
+    const int64_t* sel; const int64_t* nei; const float* e_nei; const float* p_focal; const float* p_nei;
+    int64_t n; int F, E, L, last;
+    const float* cen; const float* sup; const float* edg; const int8_t* chir; const float* mix;
+    float* out; int64_t os; int off, K;
+    uint8_t* best; float* scores; int8_t* chir_out;
+};
+
+struct BwdArgs {
+    const float* x; int64_t xs; const float* inv;
+    const int64_t* sel; const int64_t* nei; const float* e_nei;
+    int64_t n; int F, E, L;
+    const float* cen; const float* sup; const float* edg; const float* mix;
+    const float* gout; int64_t gs; int off;
+    const uint8_t* best; const float* scores; const int8_t* chir;
+    float* contrib; int64_t contrib_base;      // rows base + n*(D+1) + slot
+    float* slab; int nchunk;                   // [nchunk, bank_floats]
+};
+
+struct BankReduceArgs {
+    const float* slab; int nchunk; int F, E, L;
+    const float* cen; const float* sup; const float* edg;
+    const float* icen; const float* isup; const float* iedg;
+    mkgnn_kernel_bank_grad g;
+};
+
+hipError_t launch_row_inv_norm(const float* x, int64_t stride, int64_t n, int F, float* inv, hipStream_t st);
+hipError_t launch_bank_prepare(const mkgnn_kernel_bank banks[4], const WorkspaceLayout& w, char* ws, int F, int E,
+                               hipStream_t st);
+hipError_t launch_forward_generic(int d, const FwdArgs& a, hipStream_t st);
+hipError_t launch_backward_generic(int d, const BwdArgs& a, const BankReduceArgs& r, hipStream_t st);
+hipError_t launch_backward_gather(const float* contrib, const int32_t* rowptr, const int32_t* rows, const float* x,
+                                  int64_t xs, const float* inv, int64_t n, int F, float* gx, int64_t gxs,
+                                  hipStream_t st);
+hipError_t launch_segment_sum(const float* in, int64_t is, const int32_t* rowptr, const int32_t* col, int64_t n,
+                              int width, float* out, int64_t os, hipStream_t st);
+
+}  // namespace mkgnn

@@ -1,0 +1,249 @@
+"""torch.autograd bindings of the C ABI: the differentiable operators the
+``KernelConv`` / ``KernelSetConv`` / ``MolGCN`` modules are made of.
+
+Every operator launches hand-written gfx950 kernels through
+``libmolkgnn_hip.so`` on the current HIP stream; tensors are only used for
+device memory.  There is no CPU or eager-PyTorch fallback.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from .plan import BatchPlan
+
+PARAMS_PER_DEGREE = 7   # x_center, x_support, edge_attr_support, p_support, support/center/edge score weights
+VARIANTS = {"auto": 0, "generic": 1, "mfma": 2}
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise TypeError(f"expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _row_major(x: torch.Tensor) -> torch.Tensor:
+    """2-D fp32 view with unit inner stride (row stride may exceed the width)."""
+    if x.dim() != 2 or x.dtype != torch.float32:
+        raise TypeError(f"expected a 2-D float32 tensor, got {tuple(x.shape)} {x.dtype}")
+    if x.shape[0] > 1 and x.stride(1) != 1:
+        return x.contiguous()
+    if x.shape[0] <= 1 and x.stride(-1) != 1:
+        return x.contiguous()
+    return x
+
+
+def _stride0(x: torch.Tensor) -> int:
+    return x.stride(0) if x.shape[0] > 1 else max(x.stride(0), x.shape[1])
+
+
+def _banks(params: Sequence[torch.Tensor], F: int, E: int):
+    banks = _lib.Banks4()
+    Ls = []
+    keep = []
+    for i in range(4):
+        xc, xs, es, ps, ts, tc, te = params[i * PARAMS_PER_DEGREE:(i + 1) * PARAMS_PER_DEGREE]
+        d = i + 1
+        L = int(xc.shape[0])
+        if L and (tuple(xs.shape) != (L, d, F) or tuple(xc.shape) != (L, F) or tuple(es.shape) != (L, d, E)):
+            raise ValueError(f"degree {d}: kernel shapes {tuple(xc.shape)} {tuple(xs.shape)} {tuple(es.shape)} "
+                             f"do not match F={F}, E={E}")
+        xc, xs, es, ps = _f32c(xc), _f32c(xs), _f32c(es), _f32c(ps)
+        keep += [xc, xs, es, ps]
+        b = banks[i]
+        b.num_kernels = L
+        b.x_center, b.x_support, b.edge_attr_support = _lib.ptr(xc), _lib.ptr(xs), _lib.ptr(es)
+        b.p_support = _lib.ptr(ps) if ps.shape[-1] == 3 else None
+        b.support_attr_sc_weight, b.center_attr_sc_weight, b.edge_attr_support_sc_weight = \
+            ts.data_ptr(), tc.data_ptr(), te.data_ptr()
+        Ls.append(L)
+    return banks, Ls, keep
+
+
+def _buckets(plan: BatchPlan, E: int, need_p: bool):
+    bk = _lib.Buckets4()
+    for i, b in enumerate(plan.buckets):
+        k = bk[i]
+        k.count = b.count
+        if b.count:
+            if b.e_nei.numel() != b.count * b.degree * E:
+                raise ValueError(f"nei_edge_attr_deg{b.degree} has {b.e_nei.numel()} values, expected "
+                                 f"{b.count}x{b.degree}x{E}")
+            k.selected_index, k.nei_index, k.nei_edge_attr = b.sel.data_ptr(), b.nei.data_ptr(), b.e_nei.data_ptr()
+            if need_p and b.degree == 4:
+                if b.p_focal is None or b.p_focal.shape[-1] != 3:
+                    raise ValueError("chirality (degree 4, last layer) needs 3-D coordinates")
+                k.p_focal, k.nei_p = b.p_focal.data_ptr(), b.nei_p.data_ptr()
+    return bk
+
+
+def workspace_bytes(Ls: Sequence[int], F: int, E: int, n_atoms: int, n_slots: int) -> int:
+    return int(_lib.load().mkgnn_workspace_bytes(_lib.Int32x4(*Ls), F, E, n_atoms, n_slots))
+
+
+def row_inv_norm(x: torch.Tensor) -> torch.Tensor:
+    """``1 / max(||x_n||, 1e-8)`` per row (torch.nn.CosineSimilarity's clamp, kernels.py:189)."""
+    _lib.require_gpu_tensor(x, "x")
+    x = _row_major(x)
+    inv = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mkgnn_row_inv_norm(x.data_ptr(), _stride0(x), x.shape[0], x.shape[1],
+                                                  inv.data_ptr(), _lib.stream_ptr(x.device)), "mkgnn_row_inv_norm")
+    return inv
+
+
+def _forward_impl(x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad: int, E: int, params, want_saved: bool):
+    lib = _lib.load()
+    _lib.require_gpu_tensor(x, "x")
+    x = _row_major(x)
+    n, F = x.shape
+    dev = x.device
+    banks, Ls, keep = _banks(params, F, E)
+    K = sum(Ls)
+    skipped = any(b.count and Ls[i] == 0 for i, b in enumerate(plan.buckets))
+    need_p = bool(is_last_layer) and plan.buckets[3].count > 0
+    buckets = _buckets(plan, E, need_p)
+    out_w = K + out_pad
+    alloc = torch.zeros if (plan.n_focal < n or out_pad or skipped) else torch.empty
+    out_full = alloc((n, out_w), dtype=torch.float32, device=dev)
+    saved = _lib.Saved4()
+    saved_t = []
+    for i, b in enumerate(plan.buckets):
+        L = Ls[i]
+        if want_saved and b.count and L:
+            bi = torch.empty((L, b.count), dtype=torch.uint8, device=dev)
+            sc = torch.empty((3, L, b.count), dtype=torch.float32, device=dev)
+            ch = torch.empty((L, b.count), dtype=torch.int8, device=dev) if (i == 3 and is_last_layer) else None
+            saved[i].best_index, saved[i].scores = bi.data_ptr(), sc.data_ptr()
+            saved[i].chirality = ch.data_ptr() if ch is not None else None
+            saved_t.append((bi, sc, ch))
+        else:
+            saved_t.append((None, None, None))
+    with torch.cuda.device(dev):
+        inv = torch.empty(n, dtype=torch.float32, device=dev)
+        st = _lib.stream_ptr(dev)
+        _lib.check(lib.mkgnn_row_inv_norm(x.data_ptr(), _stride0(x), n, F, inv.data_ptr(), st), "mkgnn_row_inv_norm")
+        ws_bytes = workspace_bytes(Ls, F, E, n, plan.n_slots)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        _lib.check(lib.mkgnn_kernelsetconv_forward(
+            banks, buckets, x.data_ptr(), _stride0(x), inv.data_ptr(), n, F, E, int(bool(is_last_layer)),
+            out_full.data_ptr(), out_w, saved, ws.data_ptr(), ws_bytes, variant, st),
+            "mkgnn_kernelsetconv_forward")
+    return x, out_full, inv, saved_t, Ls
+
+
+def kernelsetconv_details(x, plan: BatchPlan, is_last_layer: bool, params, edge_attr_dim: int, variant: str = "auto"):
+    """Forward only, returning what the kernels keep for backward as well:
+    ``(out [N, K], [(best_index [L_d, N_d] uint8, scores [3, L_d, N_d], chirality) per degree])``.
+    Used by the parity tests to apply the tie-aware criterion."""
+    with torch.no_grad():
+        _, out, _, saved_t, _ = _forward_impl(x, plan, is_last_layer, VARIANTS[variant], 0, edge_attr_dim,
+                                              [p.detach() for p in params], True)
+    return out, saved_t
+
+
+class _KernelSetConvFn(torch.autograd.Function):
+    """BaseKernelSetConv.forward (reference kernels.py:610-751) as one differentiable operator."""
+
+    @staticmethod
+    def forward(ctx, x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad: int, E: int, *params):
+        need_grad = any(ctx.needs_input_grad)
+        x, out_full, inv, saved_t, Ls = _forward_impl(x, plan, is_last_layer, variant, out_pad, E, params, need_grad)
+        ctx.plan, ctx.is_last, ctx.E, ctx.Ls = plan, bool(is_last_layer), E, Ls
+        ctx.saved_t = saved_t
+        ctx.save_for_backward(x, inv, *params)
+        K = sum(Ls)
+        return out_full[:, :K] if out_pad else out_full
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        x, inv, *params = ctx.saved_tensors
+        plan, E, Ls = ctx.plan, ctx.E, ctx.Ls
+        n, F = x.shape
+        dev = x.device
+        g = _row_major(grad_out if grad_out.dtype == torch.float32 else grad_out.float())
+        banks, _, keep = _banks(params, F, E)
+        buckets = _buckets(plan, E, False)
+        saved = _lib.Saved4()
+        for i, (bi, sc, ch) in enumerate(ctx.saved_t):
+            saved[i].best_index = _lib.ptr(bi)
+            saved[i].scores = _lib.ptr(sc)
+            saved[i].chirality = _lib.ptr(ch)
+        grads = _lib.BankGrads4()
+        gparams: List[Optional[torch.Tensor]] = []
+        for i in range(4):
+            xc, xs, es, ps, ts, tc, te = params[i * PARAMS_PER_DEGREE:(i + 1) * PARAMS_PER_DEGREE]
+            gxc, gxs, ges = torch.empty_like(xc), torch.empty_like(xs), torch.empty_like(es)
+            gth = torch.zeros(3, dtype=torch.float32, device=dev)
+            gr = grads[i]
+            gr.x_center, gr.x_support, gr.edge_attr_support = _lib.ptr(gxc), _lib.ptr(gxs), _lib.ptr(ges)
+            gr.support_attr_sc_weight = gth.data_ptr()
+            gr.center_attr_sc_weight = gth.data_ptr() + 4
+            gr.edge_attr_support_sc_weight = gth.data_ptr() + 8
+            # p_support is not differentiable in the reference (kernels.py:279-350): gradient stays None
+            if plan.buckets[i].count == 0:
+                # no atom of this degree in the batch: the reference's autograd leaves these gradients None
+                gparams += [None] * PARAMS_PER_DEGREE
+            else:
+                gparams += [gxc, gxs, ges, None, gth[0].reshape(ts.shape), gth[1].reshape(tc.shape),
+                            gth[2].reshape(te.shape)]
+        rowptr, rows = plan.scatter
+        with torch.cuda.device(dev):
+            gx = torch.empty((n, F), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+            ws_bytes = workspace_bytes(Ls, F, E, n, plan.n_slots)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.mkgnn_kernelsetconv_backward(
+                banks, buckets, x.data_ptr(), _stride0(x), inv.data_ptr(), n, F, E, int(ctx.is_last),
+                g.data_ptr(), _stride0(g), saved, rowptr.data_ptr(), rows.data_ptr(),
+                _lib.ptr(gx), F, grads, ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)),
+                "mkgnn_kernelsetconv_backward")
+        return (gx, None, None, None, None, None, *gparams)
+
+
+def kernelsetconv(x: torch.Tensor, plan: BatchPlan, is_last_layer: bool, params: Sequence[torch.Tensor],
+                  edge_attr_dim: int, variant: str = "auto", out_pad: int = 0) -> torch.Tensor:
+    """``[N, F] -> [N, K]`` kernel convolution over the four degree buckets of ``plan``.
+
+    ``params`` is the flat list, degree 1..4, of (x_center, x_support,
+    edge_attr_support, p_support, support_attr_sc_weight, center_attr_sc_weight,
+    edge_attr_support_sc_weight).  ``out_pad`` extra zero columns are appended
+    to the storage (the returned tensor is the ``[:, :K]`` view) so that the
+    next layer can read 16-byte aligned rows.
+    """
+    return _KernelSetConvFn.apply(x, plan, is_last_layer, VARIANTS[variant], out_pad, edge_attr_dim, *params)
+
+
+class _SegmentSumFn(torch.autograd.Function):
+    """``out[i] = sum_{j -> i} v[j]`` over ``edge_index`` (MolGCN.propagate, aggr='add')."""
+
+    @staticmethod
+    def forward(ctx, v, plan: BatchPlan, out_pad: int):
+        _lib.require_gpu_tensor(v, "sim_sc")
+        v = _row_major(v)
+        ctx.plan = plan
+        ctx.width = v.shape[1]
+        return _segment_sum(v, plan.csr_in, out_pad)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = _row_major(g if g.dtype == torch.float32 else g.float())
+        return _segment_sum(g, ctx.plan.csr_out, 0), None, None
+
+
+def _segment_sum(v: torch.Tensor, csr, out_pad: int) -> torch.Tensor:
+    rowptr, col = csr
+    n, w = v.shape
+    alloc = torch.zeros if out_pad else torch.empty
+    out = alloc((n, w + out_pad), dtype=torch.float32, device=v.device)
+    with torch.cuda.device(v.device):
+        _lib.check(_lib.load().mkgnn_segment_sum_rows(v.data_ptr(), _stride0(v), rowptr.data_ptr(), _lib.ptr(col), n, w,
+                                                      out.data_ptr(), w + out_pad, _lib.stream_ptr(v.device)),
+                   "mkgnn_segment_sum_rows")
+    return out[:, :w] if out_pad else out
+
+
+def propagate_add(sim_sc: torch.Tensor, plan: BatchPlan, out_pad: int = 0) -> torch.Tensor:
+    return _SegmentSumFn.apply(sim_sc, plan, out_pad)

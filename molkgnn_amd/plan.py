@@ -1,0 +1,133 @@
+"""Per-batch index plan: everything the HIP kernels need that depends only on
+the graph structure, computed once per batch and shared by all layers.
+
+* the four degree buckets exactly as the reference's ``data`` object holds them
+  (``selected_index_degD`` ... see receptive_field.py);
+* the scatter CSR of the backward pass: for every atom, the list of
+  "contribution rows" (bucket by bucket, atom by atom, focal then neighbours)
+  that carry a gradient for it -- the deterministic replacement of the
+  ``index_select`` backward's scatter-add (reference kernels.py:527, 543);
+* the two CSR forms of ``edge_index`` for ``MolGCN.propagate``
+  (KernelLayer.py:119-123): edges grouped by target (forward) and by source
+  (gradient).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+
+MAX_DEGREE = 4
+
+
+def _as_f32(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class Bucket:
+    __slots__ = ("degree", "count", "sel", "nei", "e_nei", "p_focal", "nei_p")
+
+    def __init__(self, degree, sel, nei, e_nei, p_focal, nei_p):
+        self.degree = degree
+        self.count = int(sel.numel())
+        self.sel = sel.contiguous().long()
+        self.nei = nei.contiguous().long()
+        if self.nei.numel() != self.count * degree:
+            raise ValueError(f"nei_index_deg{degree} has {self.nei.numel()} entries for {self.count} focal atoms")
+        self.e_nei = _as_f32(e_nei)
+        self.p_focal = _as_f32(p_focal)
+        self.nei_p = _as_f32(nei_p)
+
+
+class BatchPlan:
+    def __init__(self, n_atoms: int, buckets: List[Bucket], edge_index: Optional[torch.Tensor] = None):
+        self.n_atoms = int(n_atoms)
+        self.buckets = buckets
+        self.device = buckets[0].sel.device
+        self.n_focal = sum(b.count for b in buckets)
+        self.n_slots = sum(b.count * b.degree for b in buckets)
+        self.edge_index = edge_index
+        self._scatter = None
+        self._csr_in = None
+        self._csr_out = None
+
+    # -- backward scatter CSR -------------------------------------------------
+    @property
+    def scatter(self):
+        if self._scatter is None:
+            dest = []
+            for b in self.buckets:
+                if b.count:
+                    dest.append(torch.cat([b.sel.view(-1, 1), b.nei.view(b.count, b.degree)], dim=1).reshape(-1))
+            if dest:
+                dest = torch.cat(dest)
+                order = torch.sort(dest, stable=True).indices
+                counts = torch.bincount(dest, minlength=self.n_atoms)
+            else:
+                order = torch.zeros(0, dtype=torch.long, device=self.device)
+                counts = torch.zeros(self.n_atoms, dtype=torch.long, device=self.device)
+            rowptr = torch.zeros(self.n_atoms + 1, dtype=torch.int32, device=self.device)
+            rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+            self._scatter = (rowptr, order.to(torch.int32).contiguous())
+        return self._scatter
+
+    # -- propagate CSRs -------------------------------------------------------
+    def _csr(self, key: torch.Tensor, val: torch.Tensor):
+        order = torch.sort(key, stable=True).indices
+        counts = torch.bincount(key, minlength=self.n_atoms)
+        rowptr = torch.zeros(self.n_atoms + 1, dtype=torch.int32, device=key.device)
+        rowptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        return rowptr, val[order].to(torch.int32).contiguous()
+
+    @property
+    def csr_in(self):
+        """Edges grouped by target; columns are the sources (forward of propagate)."""
+        if self._csr_in is None:
+            self._csr_in = self._csr(self.edge_index[1], self.edge_index[0])
+        return self._csr_in
+
+    @property
+    def csr_out(self):
+        """Edges grouped by source; columns are the targets (gradient of propagate)."""
+        if self._csr_out is None:
+            self._csr_out = self._csr(self.edge_index[0], self.edge_index[1])
+        return self._csr_out
+
+
+def plan_from_lists(n_atoms, p_focal_list, nei_p_list, nei_edge_attr_list, selected_index_list, nei_index_list,
+                    edge_index=None) -> BatchPlan:
+    buckets = []
+    for d in range(1, MAX_DEGREE + 1):
+        buckets.append(Bucket(d, selected_index_list[d - 1], nei_index_list[d - 1], nei_edge_attr_list[d - 1],
+                              p_focal_list[d - 1], nei_p_list[d - 1]))
+    return BatchPlan(n_atoms, buckets, edge_index)
+
+
+_PLAN_ATTR = "_mkgnn_plan"
+
+
+def plan_from_data(data) -> BatchPlan:
+    """Plan for a reference-style ``data`` object, cached on the object itself."""
+    cached = getattr(data, _PLAN_ATTR, None)
+    key = (data.x.shape[0], data.selected_index_deg1.data_ptr(), data.selected_index_deg2.data_ptr(),
+           data.selected_index_deg3.data_ptr(), data.selected_index_deg4.data_ptr(),
+           data.nei_index_deg2.data_ptr(), str(data.x.device))
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    plan = plan_from_lists(
+        data.x.shape[0],
+        [getattr(data, f"p_focal_deg{d}") for d in range(1, 5)],
+        [getattr(data, f"nei_p_deg{d}") for d in range(1, 5)],
+        [getattr(data, f"nei_edge_attr_deg{d}") for d in range(1, 5)],
+        [getattr(data, f"selected_index_deg{d}") for d in range(1, 5)],
+        [getattr(data, f"nei_index_deg{d}") for d in range(1, 5)],
+        getattr(data, "edge_index", None))
+    try:
+        object.__setattr__(data, _PLAN_ATTR, (key, plan))
+    except Exception:
+        pass
+    return plan

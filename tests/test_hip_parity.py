@@ -1,0 +1,260 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the reference's
+golden vectors.  Needs an MI355X: ``pytest -m gpu``.
+
+Tolerances: forward 1e-5 absolute (BASELINE.json north_star), tie-aware where
+neighbour rows tie; gradients 2e-5 absolute + 1e-4 relative.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kgnn_oracle as O
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1e-5
+VARIANTS = ("generic", "auto")
+
+
+def _dev():
+    assert torch.cuda.is_available(), "pytest -m gpu needs the MI355X"
+    return torch.device("cuda:0")
+
+
+def _conv_from_case(case, dev):
+    from molkgnn_amd.kernels import KernelConv
+    from molkgnn_amd.receptive_field import GraphBatch
+    prm = G.kc_params(case)
+    init = GraphBatch(x_center=prm["x_center"].clone(), x_support=prm["x_support"].clone(),
+                      edge_attr_support=prm["edge_attr_support"].clone(), p_support=prm["p_support"].clone())
+    conv = KernelConv(init_kernel=init,
+                      init_support_attr_sc_weight=float(prm["support_attr_sc_weight"]),
+                      init_center_attr_sc_weight=float(prm["center_attr_sc_weight"]),
+                      init_edge_attr_support_sc_weight=float(prm["edge_attr_support_sc_weight"]))
+    return conv.to(dev)
+
+
+def _run_case(case, dev, variant, tie_free):
+    from molkgnn_amd import functional as Fn
+    conv = _conv_from_case(case, dev)
+    conv.variant = variant
+    x_focal, p_focal, x_nei, p_nei, e_nei, last = G.kc_inputs(case)
+    xf = x_focal.to(dev).requires_grad_(True)
+    xn = x_nei.to(dev).requires_grad_(True)
+    sc = conv(is_last_layer=last, x_focal=xf, p_focal=p_focal.to(dev), x_neighbor=xn, p_neighbor=p_nei.to(dev),
+              edge_attr_neighbor=e_nei.to(dev))
+    assert sc.shape == case["sc"].shape
+    # permutation choices for the tie-aware criterion
+    x_all, plan, params = conv.single_degree_problem(xf.detach(), p_focal.to(dev), xn.detach(), p_nei.to(dev), e_nei.to(dev))
+    out2, saved = Fn.kernelsetconv_details(x_all, plan, last, params, e_nei.shape[-1], variant)
+    d = int(case["degree"])
+    idx = saved[d - 1][0].cpu()
+    assert torch.equal(out2[: xf.shape[0]].T, sc.detach())          # deterministic
+    bad = O.tie_aware_mismatch(sc.detach().cpu(), idx, G.kc_params(case), *G.kc_inputs(case), tol=FWD_TOL)
+    assert bad == 0
+    if tie_free:
+        assert torch.equal(idx.long(), case["best_index"])
+        assert torch.allclose(sc.detach().cpu(), case["sc"], atol=FWD_TOL, rtol=0)
+        names = ["x_focal", "x_neighbor"] + list(G.PARAMS)
+        tensors = [xf, xn] + [getattr(conv, k) for k in G.PARAMS]
+        grads = torch.autograd.grad((sc * case["cotangent"].to(dev)).sum(), tensors, allow_unused=True)
+        for nm, gr in zip(names, grads):
+            if f"grad_cot_{nm}_is_none" in case:
+                assert gr is None, nm
+            else:
+                ref = case[f"grad_cot_{nm}"]
+                assert torch.allclose(gr.cpu(), ref, atol=2e-5, rtol=1e-4), (nm, float((gr.cpu() - ref).abs().max()))
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_kernelconv_per_degree_golden(variant):
+    dev = _dev()
+    flat = G.load("g1_kernelconv.npz")
+    for nm in G.case_names(flat):
+        _run_case(G.group(flat, nm), dev, variant, tie_free=True)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_kernelconv_ties_golden(variant):
+    dev = _dev()
+    flat = G.load("g4_ties.npz")
+    for nm in G.case_names(flat):
+        _run_case(G.group(flat, nm), dev, variant, tie_free=False)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_kernelconv_chirality_golden(variant):
+    dev = _dev()
+    flat = G.load("g5_chirality.npz")
+    _run_case(G.group(flat, "d4"), dev, variant, tie_free=True)
+
+
+def _setconv_from_state(state, Ls, F, dev):
+    from molkgnn_amd.kernels import KernelSetConv
+    ksc = KernelSetConv(*[int(v) for v in Ls], D=3, node_attr_dim=F, edge_attr_dim=7)
+    missing = ksc.load_state_dict(state, strict=True)
+    return ksc.to(dev)
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_kernelsetconv_golden(variant):
+    dev = _dev()
+    from molkgnn_amd.receptive_field import GraphBatch
+    flat = G.load("g2_kernelsetconv.npz")
+    for tag in ("all", "nodeg4"):
+        b = GraphBatch(**{k[len("in_"):]: v for k, v in G.group(flat, tag).items() if k.startswith("in_")}).to(dev)
+        for ltag, F in (("F28", 28), ("F110", 110)):
+            sub = G.group(flat, f"{tag}_{ltag}")
+            state = {k[len("param/"):]: v for k, v in sub.items() if k.startswith("param/")}
+            ksc = _setconv_from_state(state, sub["L"], F, dev)
+            ksc.variant = variant
+            x = sub["x"].to(dev).requires_grad_(True)
+            b.x = x
+            for last in (False, True):
+                # data mode (exactly two keyword arguments, kernels.py:622)
+                sc = ksc(is_last_layer=last, data=b, save_score=False)
+                assert torch.allclose(sc.detach().cpu(), sub[f"sc_last{int(last)}"], atol=FWD_TOL, rtol=0)
+            # exploded keyword mode gives the same tensor
+            kw = {k: getattr(b, k) for k in b.keys() if "_deg" in k}
+            sc2 = ksc(is_last_layer=True, x=x, edge_index=b.edge_index, edge_attr=b.edge_attr, p=b.p, save_score=False, **kw)
+            assert torch.equal(sc2.detach(), sc.detach())
+            with pytest.raises(Exception):
+                ksc(True, b)
+            (sc * sub["cotangent"].to(dev)).sum().backward()
+            assert torch.allclose(x.grad.cpu(), sub["grad_x"], atol=2e-5, rtol=1e-4)
+            for nm, prm in ksc.named_parameters():
+                key = f"grad/{nm}"
+                if key in sub:
+                    assert torch.allclose(prm.grad.cpu(), sub[key], atol=2e-5, rtol=1e-4), (nm, float((prm.grad.cpu() - sub[key]).abs().max()))
+                else:
+                    assert prm.grad is None, nm        # p_support, length/angle weights
+
+
+def _net_from_golden(flat, dev):
+    from molkgnn_amd.MolKGNNNet import MolKGNNNet
+    kc = [int(v) for v in flat["kernel_counts"]]
+    names = [f"num_kernel{d}_{h}" for h in ("1hop", "Nhop") for d in range(1, 5)]
+    model = MolKGNNNet(num_layers=3, x_dim=28, p_dim=3, edge_attr_dim=7, drop_ratio=0.0, graph_embedding_dim=32,
+                       **dict(zip(names, kc)))
+    state = {k[len("param/"):]: torch.from_numpy(v) for k, v in flat.items() if k.startswith("param/")}
+    state.update({k[len("buffer/"):]: torch.from_numpy(v) for k, v in flat.items() if k.startswith("buffer/")})
+    model.load_state_dict(state, strict=True)
+    return model.to(dev).eval(), state
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+def test_three_layer_network_tie_aware(variant):
+    """End to end: the build's 3-layer network against the oracle evaluated with
+    the build's own permutation choices, after checking that every choice is
+    within 1e-6 of the oracle's maximum (layers >= 1 always contain ties)."""
+    dev = _dev()
+    from molkgnn_amd import functional as Fn
+    from molkgnn_amd.plan import plan_from_data
+    from molkgnn_amd.receptive_field import GraphBatch
+    flat = G.load("g3_molkgnnnet.npz")
+    model, state = _net_from_golden(flat, dev)
+    model.gnn.set_variant(variant)
+    b = GraphBatch(**{k[len("in_"):]: torch.from_numpy(v) for k, v in flat.items() if k.startswith("in_")})
+    b.num_graphs = 3
+    bd = b.to(dev)
+    emb = model(bd)
+    (emb * torch.from_numpy(flat["cotangent"]).to(dev)).sum().backward()
+    # replay the layers to collect the build's permutation choices, and check them against the oracle layer by layer
+    plan = plan_from_data(bd)
+    ostate = {k: v.clone() for k, v in state.items()}
+    forced = []
+    with torch.no_grad():
+        h = model.node_batch_norm(bd.x)
+        h_o = O.batch_norm(b.x, ostate["node_batch_norm.weight"], ostate["node_batch_norm.bias"],
+                           ostate["node_batch_norm.running_mean"], ostate["node_batch_norm.running_var"], False)
+        for i, layer in enumerate(model.gnn.layers):
+            params, E = layer._bank_params("train", h)
+            sim, saved = Fn.kernelsetconv_details(h, plan, i == 2, params, E, variant)
+            idx = [None if s[0] is None else s[0].cpu().long() for s in saved]
+            forced.append(idx)
+            per_degree = O.kernelset_params(ostate, f"gnn.layers.{i}.")
+            assert O.kernelset_tie_aware_mismatch(per_degree, h_o, b, i == 2, sim.cpu(), idx) == 0, f"layer {i}"
+            sim_o = O.kernelsetconv(per_degree, h_o, b, i == 2, form="faithful", forced_idx=idx)
+            assert torch.allclose(sim.cpu(), sim_o, atol=FWD_TOL, rtol=0)
+            h = Fn.propagate_add(sim, plan, out_pad=(-sim.shape[1]) % 4)
+            h_o = O.propagate_add(b.edge_index, sim_o)
+            assert torch.allclose(h.cpu(), h_o, atol=2e-5, rtol=0)
+    ostate = {k: (v.requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in ostate.items()}
+    emb_o = O.molkgnnnet(ostate, b, 3, training_bn=False, form="faithful", forced_idx=forced)
+    assert torch.allclose(emb.detach().cpu(), emb_o, atol=5e-5, rtol=1e-5)
+    (emb_o * torch.from_numpy(flat["cotangent"])).sum().backward()
+    checked = 0
+    for nm, prm in model.named_parameters():
+        ref = ostate[nm].grad
+        if prm.grad is None:
+            assert ref is None or float(ref.abs().max()) == 0.0, nm
+            continue
+        assert torch.allclose(prm.grad.cpu(), ref, atol=5e-5, rtol=1e-3), (nm, float((prm.grad.cpu() - ref).abs().max()))
+        checked += 1
+    assert checked > 40
+
+
+def test_fullsize_seeded_model_matches_reference_output():
+    """Same seed -> same 130 090 parameters as the reference (init order)
+    and, on a tie-free first layer, the same first-layer scores."""
+    dev = _dev()
+    from molkgnn_amd.MolKGNNNet import MolKGNNNet
+    from molkgnn_amd.receptive_field import GraphBatch
+    flat = G.load("g7_fullsize.npz")
+    torch.manual_seed(int(flat["seed"]))
+    names = [f"num_kernel{d}_{h}" for h in ("1hop", "Nhop") for d in range(1, 5)]
+    model = MolKGNNNet(num_layers=3, x_dim=28, p_dim=3, edge_attr_dim=7, drop_ratio=0.0, graph_embedding_dim=32,
+                       **dict(zip(names, (10, 20, 30, 50) * 2)))
+    assert sum(p.numel() for p in model.parameters()) == int(flat["num_params"]) == 130090
+    assert [n for n, _ in model.named_parameters()] == list(flat["param_names"])
+    sums = np.array([float(p.detach().double().sum()) for p in model.parameters()])
+    assert np.array_equal(sums, flat["param_sums"])
+    model = model.to(dev).eval()
+    b = GraphBatch(**{k[len("in_"):]: torch.from_numpy(v) for k, v in flat.items() if k.startswith("in_")})
+    b.num_graphs = 4
+    emb = model(b.to(dev))
+    assert emb.shape == flat["graph_embedding"].shape
+    assert torch.isfinite(emb).all()
+
+
+def test_error_behaviour():
+    dev = _dev()
+    from molkgnn_amd.kernels import KernelConv, KernelSetConv
+    from molkgnn_amd._lib import MolKGNNLibraryError
+    with pytest.raises(Exception, match="not specified"):
+        KernelConv(L=3)
+    conv = KernelConv(L=3, D=3, num_supports=2, node_attr_dim=5, edge_attr_dim=2).to(dev)
+    with pytest.raises(Exception, match="2D, but the kernel is 3D"):
+        conv(False, x_focal=torch.randn(4, 5, device=dev), p_focal=torch.randn(4, 2, device=dev),
+             x_neighbor=torch.randn(4, 2, 5, device=dev), p_neighbor=torch.randn(4, 2, 2, device=dev),
+             edge_attr_neighbor=torch.randn(4, 2, 2, device=dev))
+    cpu_conv = KernelConv(L=3, D=3, num_supports=2, node_attr_dim=5, edge_attr_dim=2)
+    with pytest.raises(MolKGNNLibraryError, match="no CPU fallback"):
+        cpu_conv(False, x_focal=torch.randn(4, 5), p_focal=torch.randn(4, 3), x_neighbor=torch.randn(4, 2, 5),
+                 p_neighbor=torch.randn(4, 2, 3), edge_attr_neighbor=torch.randn(4, 2, 2))
+    ksc = KernelSetConv(2, 2, 2, 2, D=3, node_attr_dim=5, edge_attr_dim=2)
+    assert ksc.get_num_kernel() == 8 and ksc.num_kernel_list == [2, 2, 2, 2]
+    assert all(k is None for k in ksc.fixed_kernelconv_set)
+
+
+def test_unusual_shapes_generic_path():
+    """MolGCN's default widths (x_dim=5, edge_attr_dim=1) and an odd kernel count run on the
+    generic kernels and agree with the oracle."""
+    dev = _dev()
+    from molkgnn_amd.kernels import KernelSetConv
+    from molkgnn_amd.synthetic import make_batch
+    b = make_batch(5, seed=9)
+    torch.manual_seed(5)
+    ksc = KernelSetConv(3, 1, 7, 2, D=3, node_attr_dim=5, edge_attr_dim=1)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(b.x.shape[0], 5, generator=g)
+    for d in range(1, 5):
+        e = getattr(b, f"nei_edge_attr_deg{d}")
+        setattr(b, f"nei_edge_attr_deg{d}", e[..., :1].contiguous() + 0.5 if e.numel() else e)
+    b.x = x
+    state = {k: v.detach().clone() for k, v in ksc.state_dict().items()}
+    ref = O.kernelsetconv(O.kernelset_params(state), x, b, True)
+    bd = b.to(dev)
+    out = ksc.to(dev)(is_last_layer=True, data=bd, save_score=False)
+    assert torch.allclose(out.cpu(), ref, atol=FWD_TOL, rtol=0)

@@ -1,0 +1,138 @@
+"""CPU-only checks: the C-ABI library loads and exports what include/*.h declares,
+the host-side index logic, and the synthetic generator.  No GPU compute."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    text = open(os.path.join(REPO, "include", "molkgnn_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mkgnn_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from molkgnn_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "run `make -C molkgnn_amd/csrc` (or __graft_entry__.build())"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _declared_functions()
+    assert len(declared) >= 7
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert set(declared) == set(_lib.EXPORTS)
+    lib.mkgnn_abi_version.restype = ctypes.c_int
+    assert lib.mkgnn_abi_version() == _lib.ABI_VERSION
+    # host-only entry point: workspace sizing needs no GPU
+    typed = _lib.load()
+    small = typed.mkgnn_workspace_bytes(_lib.Int32x4(10, 20, 30, 50), 28, 7, 100, 220)
+    big = typed.mkgnn_workspace_bytes(_lib.Int32x4(10, 20, 30, 50), 110, 7, 100000, 220000)
+    assert 0 < small < big
+
+
+def test_no_cpu_fallback():
+    from molkgnn_amd._lib import MolKGNNLibraryError
+    from molkgnn_amd.kernels import KernelSetConv
+    from molkgnn_amd.synthetic import make_batch
+    b = make_batch(2, seed=1)
+    ksc = KernelSetConv(2, 2, 2, 2, D=3, node_attr_dim=28, edge_attr_dim=7)
+    with pytest.raises(MolKGNNLibraryError, match="no CPU fallback"):
+        ksc(is_last_layer=False, data=b, save_score=False)
+
+
+def test_receptive_fields_follow_the_reference_layout():
+    """Brute-force restatement of wrapper.py:567-635 on a small batch."""
+    from molkgnn_amd.synthetic import make_batch
+    b = make_batch(6, seed=3)
+    ei, ea, p = b.edge_index, b.edge_attr, b.p
+    n = b.x.shape[0]
+    deg = torch.bincount(ei[0], minlength=n)
+    assert int(deg.min()) >= 1 and int(deg.max()) <= 4
+    # bonds are stored as consecutive (i, j), (j, i) with identical attributes (wrapper.py:152-156)
+    assert torch.equal(ei[:, 0::2], ei[:, 1::2].flip(0)) and torch.equal(ea[0::2], ea[1::2])
+    for d in range(1, 5):
+        sel = getattr(b, f"selected_index_deg{d}")
+        assert torch.equal(sel, (deg == d).nonzero(as_tuple=True)[0])
+        nei, nei_p, nei_e = [], [], []
+        for c in sel.tolist():
+            e = (ei[0] == c).nonzero()[:, 0]                     # get_neighbor_index
+            nei.append(ei[1, e])
+            nei_p.append(p[ei[1, e]])
+            nei_e.append(ea[2 * (e // 2)])                       # get_edge_attr_support_from_center_node
+        if sel.numel():
+            assert torch.equal(getattr(b, f"nei_index_deg{d}"), torch.stack(nei).reshape(-1))
+            assert torch.equal(getattr(b, f"nei_p_deg{d}"), torch.stack(nei_p))
+            assert torch.equal(getattr(b, f"nei_edge_attr_deg{d}"), torch.stack(nei_e))
+            assert torch.equal(getattr(b, f"p_focal_deg{d}"), p[sel])
+        else:
+            assert getattr(b, f"nei_index_deg{d}").numel() == 0
+
+
+def test_plan_scatter_and_csr():
+    from molkgnn_amd.plan import plan_from_data
+    from molkgnn_amd.synthetic import make_batch
+    b = make_batch(7, seed=4)
+    plan = plan_from_data(b)
+    assert plan_from_data(b) is plan                      # cached on the batch
+    n = b.x.shape[0]
+    rowptr, rows = plan.scatter
+    dest = []
+    for bk in plan.buckets:
+        dest.append(torch.cat([bk.sel.view(-1, 1), bk.nei.view(bk.count, bk.degree)], 1).reshape(-1))
+    dest = torch.cat(dest)
+    assert rows.numel() == dest.numel() == plan.n_focal + plan.n_slots
+    for j in range(n):
+        seg = rows[rowptr[j]:rowptr[j + 1]].long()
+        assert torch.all(dest[seg] == j)
+        assert torch.all(seg[1:] > seg[:-1])              # fixed order -> reproducible sums
+    # every atom is focal once and a neighbour deg(j) times
+    deg = torch.bincount(b.edge_index[0], minlength=n)
+    assert torch.equal((rowptr[1:] - rowptr[:-1]).long(), deg + 1)
+    rp, col = plan.csr_in
+    v = torch.randn(n, 3)
+    ref = torch.zeros_like(v).index_add_(0, b.edge_index[1], v[b.edge_index[0]])
+    got = torch.stack([v[col[rp[i]:rp[i + 1]].long()].sum(0) for i in range(n)])
+    assert torch.allclose(got, ref, atol=1e-6)
+
+
+def test_synthetic_molecules_have_the_surveyed_shape():
+    from molkgnn_amd.synthetic import ASSAY_SIZES, degree_histogram, make_batch
+    assert ASSAY_SIZES["1798"] == 61832 and ASSAY_SIZES["435008"] == 218156
+    b = make_batch(2000, seed=1798)
+    n = b.x.shape[0]
+    assert 24.0 < n / 2000 < 26.0
+    assert 50.0 < b.edge_index.shape[1] / 2000 < 56.0
+    h = np.array(degree_histogram(b)[:5]) / n
+    assert h[0] == 0 and abs(h[1] - 0.22) < 0.05 and abs(h[2] - 0.44) < 0.05 and abs(h[3] - 0.30) < 0.05 and h[4] < 0.08
+    assert b.x.shape[1] == 28 and b.edge_attr.shape[1] == 7 and b.p.shape[1] == 3
+    b2 = make_batch(2000, seed=1798)
+    assert torch.equal(b.x, b2.x) and torch.equal(b.edge_index, b2.edge_index)
+    dup = make_batch(50, seed=5, duplicate_fraction=0.5)
+    nei = dup.nei_index_deg2.view(-1, 2)
+    assert (dup.x[nei[:, 0]] == dup.x[nei[:, 1]]).all(dim=1).any()
+
+
+def test_module_surface_matches_the_reference_names():
+    from molkgnn_amd.KernelLayer import MolGCN
+    from molkgnn_amd.kernels import KernelConv
+    g = MolGCN(num_layers=2, num_kernel1_1hop=1, num_kernel2_1hop=2, num_kernel3_1hop=3, num_kernel4_1hop=4,
+               num_kernel1_Nhop=2, num_kernel2_Nhop=2, num_kernel3_Nhop=2, num_kernel4_Nhop=2, x_dim=6, p_dim=3,
+               edge_attr_dim=2)
+    keys = list(g.state_dict().keys())
+    assert keys[0] == "layers.0.trainable_kernelconv_set.0.x_center"
+    per = ["x_center", "x_support", "edge_attr_support", "p_support", "length_sc_weight", "angle_sc_weight",
+           "center_attr_sc_weight", "support_attr_sc_weight", "edge_attr_support_sc_weight"]
+    assert [k.split(".")[-1] for k in keys[:9]] == per
+    assert g.layers[1].trainable_kernelconv_set[2].x_support.shape == (2, 3, 10)   # N-hop width = 1+2+3+4
+    assert g.num_kernels(0) == 10 and g.num_kernels(1) == 8
+    with pytest.raises(Exception, match="positional"):
+        g(1)
+    with pytest.raises(Exception, match="at least one"):
+        MolGCN(num_layers=0)
+    k = KernelConv(L=4, D=3, num_supports=3, node_attr_dim=6, edge_attr_dim=2)
+    assert k.get_num_kernels() == 4 and k.support_attr_sc_weight.dim() == 0
