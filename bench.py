@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""Throughput of the 3-layer MolKGNN training step on AID-1798-shaped synthetic molecules.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One JSON line on rank 0.  ``value`` = molecules/s of forward + backward (+ gradient all-reduce for
+N > 1, + AdamW step) over all ranks, batches already resident in HBM.  ``roofline`` prices the
+kernel-convolution forward of one N-hop layer (F = 110, the dominant kernels) against the HBM
+roofline with the algorithmic byte count of SURVEY.md 8(d); ``cpu_baseline`` times the
+reference-faithful CPU restatement (oracle/) on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+FP32_VECTOR_PEAK_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch-size", type=int, default=4096, help="molecules per step per GPU")
+    ap.add_argument("--assay", default="1798")
+    ap.add_argument("--variant", default="auto", choices=["auto", "generic", "mfma"])
+    ap.add_argument("--distinct-batches", type=int, default=4, help="distinct resident batches cycled through")
+    ap.add_argument("--no-optimizer", action="store_true", help="time forward+backward(+all-reduce) only")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--roofline-reps", type=int, default=20)
+    return ap.parse_args()
+
+
+def layer_algorithmic(plan, F, E, Ls, last):
+    """Strict algorithmic bytes and flops of one KernelSetConv forward:
+    x read once, the output written once, bond attributes, the index tensors (int64, as the ABI
+    takes them), the kernel bank once, and the degree-4 coordinates in the last layer."""
+    n = plan.n_atoms
+    m = plan.n_slots
+    K = sum(Ls)
+    bank = sum(L * (F + d * F + d * E + 3 * d) for d, L in zip(range(1, 5), Ls))
+    by = 4 * n * F + 4 * n * K + 4 * m * E + 8 * m + 8 * n + 4 * bank
+    if last:
+        by += 4 * plan.buckets[3].count * 15
+    fl = 0
+    for d, L in zip(range(1, 5), Ls):
+        fl += plan.buckets[d - 1].count * L * (2 * F * (d * d + 1) + 2 * E * d * d)
+    return by, fl
+
+
+def host_cores():
+    """CPU cores this process may actually use: the cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(seconds, assay):
+    """Reference-faithful CPU restatement (oracle), forward + backward, batch 16 (README.md:81),
+    on all host cores; bounded to about `seconds` of work."""
+    from molkgnn_amd.synthetic import make_batch
+    from molkgnn_amd.train import GNNModel
+    from oracle import kgnn_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = GNNModel()
+    state = {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and "running" not in k)
+             for k, v in model.state_dict().items()}
+    gstate = {k[len("gnn_model."):]: v for k, v in state.items() if k.startswith("gnn_model.")}
+    batches = [make_batch(16, seed=100 + i, assay=assay) for i in range(4)]
+    done = 0
+    t0 = time.perf_counter()
+    while True:
+        b = batches[done % len(batches)]
+        emb = O.molkgnnnet(gstate, b, num_layers=3, training_bn=True, form="faithful")
+        pred = emb @ state["ffn.weight"].T + state["ffn.bias"]
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(pred.view(-1), b.y)
+        loss.backward()
+        for v in state.values():
+            v.grad = None
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= seconds and done >= 2:
+            break
+    return {"value": round(16 * done / el, 2), "unit": "molecules/s", "cores": cores, "kind": "port",
+            "sample": f"{done} steps of batch 16 ({16 * done} molecules), fwd+bwd, oracle/kgnn_oracle.py faithful form, "
+                      f"torch {torch.__version__} CPU, {cores} threads"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path for the HIP kernels)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    from molkgnn_amd import _lib, dp
+    from molkgnn_amd import functional as Fn
+    from molkgnn_amd.plan import plan_from_data
+    from molkgnn_amd.synthetic import ASSAY_SIZES, make_batch
+    from molkgnn_amd.train import GNNModel, configure_optimizer
+    _lib.load()
+    dp.init_process_group_from_env("nccl")
+
+    torch.manual_seed(1798)                       # same initial weights on every rank
+    model = GNNModel().to(dev)
+    model.gnn_model.gnn.set_variant(args.variant)
+    model.train()
+    opt = None if args.no_optimizer else configure_optimizer(model, lr=1e-3)
+    reducer = dp.FlatGradAllReduce(model.parameters(), dp.NEVER_TRAINED + ("lin1", "lin2"),
+                                   [n for n, _ in model.named_parameters()])
+
+    # resident batches: rank r owns batches r, r + world, ... of the global stream (weak scaling)
+    n_mol_assay = ASSAY_SIZES.get(args.assay, 61832)
+    nb = max(1, min(args.distinct_batches, math.ceil(n_mol_assay / args.batch_size)))
+    batches = []
+    for i in range(nb):
+        b = make_batch(args.batch_size, seed=int(args.assay) * 1000 + i * world + rank, assay=args.assay).to(dev)
+        plan = plan_from_data(b)
+        _ = plan.scatter, plan.csr_in, plan.csr_out      # index plans are part of the resident input
+        batches.append(b)
+    atoms = sum(b.x.shape[0] for b in batches) / nb
+    torch.cuda.synchronize()
+
+    def step(i):
+        b = batches[i % nb]
+        model.zero_grad(set_to_none=True)
+        loss = model.loss(b)
+        loss.backward()
+        reducer.reduce()
+        if opt is not None:
+            opt.step()
+        return loss
+
+    def log(msg):
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+    log(f"{nb} resident batches of {args.batch_size} molecules ({atoms:.0f} atoms each); warmup")
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    log("timing")
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    mols = args.batch_size * args.steps * world
+    value = mols / elapsed
+
+    log(f"{value:.0f} molecules/s; measuring the forward kernels")
+    out = None
+    if rank == 0:
+        # ---- roofline of the kernel-convolution forward, N-hop layer (F = 110), live HIP events on this stream
+        b = batches[0]
+        plan = plan_from_data(b)
+        layer = model.gnn_model.gnn.layers[1]
+        params, E = layer._bank_params("train", b.x)
+        Ls = layer.L
+        K_in = model.gnn_model.gnn.num_kernels(0)
+        g = torch.Generator(device=dev).manual_seed(1)
+        h_store = torch.zeros(b.x.shape[0], K_in + (-K_in) % 4, device=dev)
+        h_store[:, :K_in] = torch.rand(b.x.shape[0], K_in, generator=g, device=dev) * 2 - 1
+        h = h_store[:, :K_in]
+        for _ in range(3):
+            Fn.kernelsetconv_details(h, plan, False, params, E, args.variant)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(args.roofline_reps):
+            Fn.kernelsetconv_details(h, plan, False, params, E, args.variant)
+        ev1.record()
+        torch.cuda.synchronize()
+        ms = ev0.elapsed_time(ev1) / args.roofline_reps
+        by, fl = layer_algorithmic(plan, K_in, E, Ls, False)
+        gbs = by / (ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": None,
+                    "kernel": "kernelsetconv forward, one N-hop layer (F=110, K=110): bank_prepare + row_inv_norm + "
+                              "4 degree kernels",
+                    "ms_per_launch": round(ms, 5), "algorithmic_bytes": by, "algorithmic_flops": fl,
+                    "fp32_tflops": round(fl / (ms * 1e-3) / 1e12, 3),
+                    "fp32_vector_frac": round(fl / (ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 5)}
+        out = {"metric": "molecules/sec fwd+bwd, 3-layer MolKGNN on AID 1798", "value": round(value, 1),
+               "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"AID {args.assay} full set shape ({n_mol_assay} molecules, ~25 atoms / ~53 directed "
+                                      f"edges each), 3 layers, hidden_dim 32, kernels 10/20/30/50 per degree, "
+                                      f"batch {args.batch_size} molecules per GPU ({atoms:.0f} atoms), "
+                                      f"{nb} resident batches cycled, fwd+bwd"
+                                      + ("" if args.no_optimizer else "+AdamW") + (", grad all-reduce" if world > 1 else ""),
+                          "variant": args.variant, "batch_size_per_gpu": args.batch_size,
+                          "parallelism": f"dp{world}"},
+               "roofline": roofline}
+        log(f"forward layer {ms:.4f} ms, {gbs:.1f} GB/s algorithmic; cpu baseline")
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.assay)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

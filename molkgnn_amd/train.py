@@ -1,0 +1,61 @@
+"""The training step the throughput metric is quoted on: the reference's ``GNNModel``
+(``model.py:127-198``) around the HIP kernel convolution, without Lightning.
+
+Only what a forward + backward (+ optimiser) step needs is restated here: the module tree with the
+reference's parameter names (``gnn_model.*``, ``lin1``, ``lin2``, ``ffn``; 132 300 parameters), the
+``BCEWithLogitsLoss`` the data module selects (``data.py:37``) and the AdamW groups chosen by parameter
+name (``model.py:373-382``).  Logging, checkpoints, metrics and the LR schedule are out of scope.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch.nn import BCEWithLogitsLoss, Dropout, Linear, ReLU
+
+from .MolKGNNNet import MolKGNNNet
+
+KERNEL_COUNTS = (10, 20, 30, 50)    # paper / README kernels per degree
+
+
+class GNNModel(torch.nn.Module):
+    def __init__(self, num_layers=3, kernels_1hop=KERNEL_COUNTS, kernels_Nhop=KERNEL_COUNTS, node_feature_dim=28,
+                 edge_feature_dim=7, hidden_dim=32, dropout_ratio=0.0, ffn_dropout_rate=0.25, ffn_hidden_dim=64,
+                 task_dim=1):
+        super().__init__()
+        kw = {f"num_kernel{d}_1hop": k for d, k in zip(range(1, 5), kernels_1hop)}
+        kw.update({f"num_kernel{d}_Nhop": k for d, k in zip(range(1, 5), kernels_Nhop)})
+        self.gnn_model = MolKGNNNet(num_layers=num_layers, x_dim=node_feature_dim, edge_attr_dim=edge_feature_dim,
+                                    graph_embedding_dim=hidden_dim, drop_ratio=dropout_ratio, **kw)
+        self.lin1 = Linear(hidden_dim, ffn_hidden_dim)     # unused by forward, as in the reference (model.py:147-148)
+        self.lin2 = Linear(ffn_hidden_dim, task_dim)
+        self.ffn = Linear(hidden_dim, task_dim)
+        self.dropout = Dropout(p=ffn_dropout_rate)
+        self.activate_func = ReLU()
+        self.loss_func = BCEWithLogitsLoss()
+
+    def forward(self, data):
+        graph_embedding = self.dropout(self.gnn_model(data))
+        return self.ffn(graph_embedding), graph_embedding
+
+    def loss(self, data):
+        pred, _ = self(data)
+        return self.loss_func(pred.view(-1), data.y.view(-1).float())
+
+
+def configure_optimizer(model: torch.nn.Module, weight_decay: float = 0.0, lr: float = 1e-3, fused: Optional[bool] = None):
+    """AdamW with the kernel parameters exempt from weight decay, selected by name (model.py:373-382)."""
+    decay, nodecay = [], []
+    for name, p in model.named_parameters():
+        if ('x_center' in name) or ('p_support' in name) or (
+                ('edge_attr_support' in name) and ('edge_attr_support_sc' not in name)) or ('x_support' in name):
+            nodecay.append(p)
+        else:
+            decay.append(p)
+    groups = [{'params': nodecay, 'weight_decay': 0}, {'params': decay, 'weight_decay': weight_decay}]
+    kw = {}
+    if fused is None:
+        fused = all(p.is_cuda for p in model.parameters())
+    if fused:
+        kw["fused"] = True
+    return torch.optim.AdamW(groups, lr=lr, **kw)
