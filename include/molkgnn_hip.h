@@ -76,9 +76,9 @@ typedef struct mkgnn_degree_bucket {
 
 /* What forward keeps for backward, per degree (caller-allocated). */
 typedef struct mkgnn_saved {
-    uint8_t* best_index;              /* [L_d, N_d] chosen permutation (kernels.py:373); may be NULL */
-    float* scores;                    /* [3, L_d, N_d] support / centre / edge scores; may be NULL   */
-    int8_t* chirality;                /* [L_d, N_d] +1/-1 (d = 4, last layer); may be NULL           */
+    uint8_t* best_index;              /* [N_d, L_d] chosen permutation (kernels.py:373); may be NULL */
+    float* scores;                    /* [3, N_d, L_d] support / centre / edge scores; may be NULL   */
+    int8_t* chirality;                /* [N_d, L_d] +1/-1 (d = 4, last layer); may be NULL           */
 } mkgnn_saved;
 
 int mkgnn_abi_version(void);

@@ -112,6 +112,8 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
         a.cen = (const float*)(ws + w.bank[i].cen); a.sup = (const float*)(ws + w.bank[i].sup);
         a.edg = (const float*)(ws + w.bank[i].edg); a.chir = (const int8_t*)(ws + w.bank[i].chir);
         a.mix = (const float*)(ws + w.bank[i].mix);
+        a.padded = (const float*)(ws + w.bank[i].padded); a.edge_padded = (const float*)(ws + w.bank[i].edge_padded);
+        a.n_atoms = n_atoms;
         a.out = out; a.os = out_stride; a.off = off; a.K = K;
         a.best = saved ? saved[i].best_index : nullptr;
         a.scores = saved ? saved[i].scores : nullptr;

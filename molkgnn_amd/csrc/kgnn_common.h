@@ -32,6 +32,27 @@ template <int D> __device__ __forceinline__ int perm_at(int p, int a) {
     else return PERM4[p][a];
 }
 
+template <int D> struct PermC;
+template <> struct PermC<1> { static constexpr int P = 1;  static constexpr int8_t t[1][4] = {{0, 0, 0, 0}}; };
+template <> struct PermC<2> { static constexpr int P = 2;  static constexpr int8_t t[2][4] = {{0, 1, 0, 0}, {1, 0, 0, 0}}; };
+template <> struct PermC<3> { static constexpr int P = 6;  static constexpr int8_t t[6][4] = {{0, 1, 2, 0}, {0, 2, 1, 0}, {1, 0, 2, 0}, {1, 2, 0, 0}, {2, 0, 1, 0}, {2, 1, 0, 0}}; };
+template <> struct PermC<4> { static constexpr int P = 12; static constexpr int8_t t[12][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 0, 3, 2}, {1, 2, 0, 3}, {1, 3, 2, 0}, {2, 0, 1, 3}, {2, 1, 3, 0}, {2, 3, 0, 1}, {3, 0, 2, 1}, {3, 1, 0, 2}, {3, 2, 1, 0}}; };
+
+// Best permutation of a d x d cosine matrix: every order scored as
+// ((c0+c1)+c2)+c3 then / d, strict '>' scan in table order.
+template <int D>
+__device__ __forceinline__ void best_permutation(const float (&cm)[D][D], float& best, int& idx) {
+    best = 0.f; idx = 0;
+#pragma unroll
+    for (int p = 0; p < PermC<D>::P; ++p) {
+        float s = cm[0][PermC<D>::t[p][0]];
+#pragma unroll
+        for (int a = 1; a < D; ++a) s = __fadd_rn(s, cm[a][PermC<D>::t[p][a]]);
+        s = s / (float)D;
+        if (p == 0 || s > best) { best = s; idx = p; }
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -63,8 +84,15 @@ __device__ __forceinline__ float triple_sign(const float* t1, const float* t2, c
 //   mix   [4]  w_support, w_center, w_edge, their sum (kernels.py:402-422)
 // ---------------------------------------------------------------------------
 struct BankLayout {
-    size_t cen, sup, edg, icen, isup, iedg, chir, mix, end;
+    size_t cen, sup, edg, icen, isup, iedg, chir, mix;
+    size_t padded;      // [(d+1)*L, FP] unit rows for the MFMA kernels: row b*L + l = support b of kernel l,
+                        // row d*L + l = centre of kernel l; zero beyond F
+    size_t edge_padded; // [d*L, 8] unit edge rows, row b*L + l, zero beyond E
+    size_t end;
 };
+
+// Feature width the MFMA kernels pad to (0 = shape not covered by them).
+__host__ __device__ static inline int mfma_padded_width(int F) { return F <= 32 ? 32 : (F <= 112 ? 112 : 0); }
 
 struct WorkspaceLayout {
     BankLayout bank[MKGNN_MAX_DEGREE];
@@ -100,6 +128,9 @@ static inline WorkspaceLayout make_layout(const int32_t L[MKGNN_MAX_DEGREE], int
         b.iedg = off; off = align_up(off + l * d * 4);
         b.chir = off; off = align_up(off + l * 12);
         b.mix = off;  off = align_up(off + 16);
+        const int FP = mfma_padded_width(F);
+        b.padded = off;      off = align_up(off + (size_t)(d + 1) * l * FP * 4);
+        b.edge_padded = off; off = align_up(off + (size_t)d * l * 8 * 4);
         b.end = off;
     }
     w.contrib = off;

@@ -48,14 +48,20 @@ __global__ void bank_prepare_kernel(PrepArgs a) {
     float* dst;
     float* inv;
     int width;
+    float* pad_dst = nullptr;
+    int pad_width = 0;
+    const int FP = mfma_padded_width(a.F);
     if (r < L) {
         src = a.bank[i].x_center + (size_t)r * a.F; dst = a.cen[i] + (size_t)r * a.F; inv = a.icen[i] + r; width = a.F;
+        if (FP) { pad_dst = a.padded[i] + ((size_t)d * L + r) * FP; pad_width = FP; }
     } else if (r < L + L * d) {
         r -= L;
         src = a.bank[i].x_support + (size_t)r * a.F; dst = a.sup[i] + (size_t)r * a.F; inv = a.isup[i] + r; width = a.F;
+        if (FP) { pad_dst = a.padded[i] + ((size_t)(r % d) * L + r / d) * FP; pad_width = FP; }
     } else if (r < L + 2 * L * d) {
         r -= L + L * d;
         src = a.bank[i].edge_attr_support + (size_t)r * a.E; dst = a.edg[i] + (size_t)r * a.E; inv = a.iedg[i] + r; width = a.E;
+        if (a.E <= 8) { pad_dst = a.edge_padded[i] + ((size_t)(r % d) * L + r / d) * 8; pad_width = 8; }
     } else {
         // misc: mixing weights (kernels.py:402-412) and chirality table (:331-341)
         if (lane == 0) {
@@ -88,30 +94,13 @@ __global__ void bank_prepare_kernel(PrepArgs a) {
     float iv = 1.f / fmaxf(sqrtf(s), MKGNN_EPS);
     for (int f = lane; f < width; f += 64) dst[f] = src[f] * iv;
     if (lane == 0) *inv = iv;
+    // padded, support-major copies for the MFMA kernels
+    if (pad_dst) {
+        for (int f = lane; f < pad_width; f += 64) pad_dst[f] = f < width ? src[f] * iv : 0.f;
+    }
 }
 
 // ------------------------------------------------------------- forward ----
-
-template <int D> struct PermC;
-template <> struct PermC<1> { static constexpr int P = 1;  static constexpr int8_t t[1][4] = {{0, 0, 0, 0}}; };
-template <> struct PermC<2> { static constexpr int P = 2;  static constexpr int8_t t[2][4] = {{0, 1, 0, 0}, {1, 0, 0, 0}}; };
-template <> struct PermC<3> { static constexpr int P = 6;  static constexpr int8_t t[6][4] = {{0, 1, 2, 0}, {0, 2, 1, 0}, {1, 0, 2, 0}, {1, 2, 0, 0}, {2, 0, 1, 0}, {2, 1, 0, 0}}; };
-template <> struct PermC<4> { static constexpr int P = 12; static constexpr int8_t t[12][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 0, 3, 2}, {1, 2, 0, 3}, {1, 3, 2, 0}, {2, 0, 1, 3}, {2, 1, 3, 0}, {2, 3, 0, 1}, {3, 0, 2, 1}, {3, 1, 0, 2}, {3, 2, 1, 0}}; };
-
-// Best permutation of a d x d cosine matrix: every order scored as
-// ((c0+c1)+c2)+c3 then / d, strict '>' scan in table order.
-template <int D>
-__device__ __forceinline__ void best_permutation(const float (&cm)[D][D], float& best, int& idx) {
-    best = 0.f; idx = 0;
-#pragma unroll
-    for (int p = 0; p < PermC<D>::P; ++p) {
-        float s = cm[0][PermC<D>::t[p][0]];
-#pragma unroll
-        for (int a = 1; a < D; ++a) s = __fadd_rn(s, cm[a][PermC<D>::t[p][a]]);
-        s = s / (float)D;
-        if (p == 0 || s > best) { best = s; idx = p; }
-    }
-}
 
 // One wave per atom, lanes over kernels.  Plain and cache-served: this is the
 // any-shape path, not the fast one.
@@ -215,14 +204,14 @@ __global__ void __launch_bounds__(256) kc_forward_generic(FwdArgs a) {
                 sc *= ch;
             }
             a.out[focal * a.os + a.off + l] = sc;
-            if (a.best) a.best[(size_t)l * a.n + n] = (uint8_t)idx;
+            if (a.best) a.best[(size_t)n * a.L + l] = (uint8_t)idx;
             if (a.scores) {
                 size_t ln = (size_t)a.L * a.n;
-                a.scores[(size_t)l * a.n + n] = best;
-                a.scores[ln + (size_t)l * a.n + n] = cc;
-                a.scores[2 * ln + (size_t)l * a.n + n] = ed;
+                a.scores[(size_t)n * a.L + l] = best;
+                a.scores[ln + (size_t)n * a.L + l] = cc;
+                a.scores[2 * ln + (size_t)n * a.L + l] = ed;
             }
-            if (a.chir_out) a.chir_out[(size_t)l * a.n + n] = (int8_t)ch;
+            if (a.chir_out) a.chir_out[(size_t)n * a.L + l] = (int8_t)ch;
         }
         // the rest of the atom's output row is zero (kernels.py:674-675, 725-727)
         for (int k = lane; k < a.K; k += 64)
@@ -249,8 +238,8 @@ __global__ void __launch_bounds__(256) kc_backward_rows(BwdArgs a) {
             for (int s = 0; s <= D; ++s) acc[s] = 0.f;
             for (int l = 0; l < a.L; ++l) {
                 float g = a.gout[focal * a.gs + a.off + l];
-                if (a.chir) g *= (float)a.chir[(size_t)l * a.n + n];
-                const int idx = a.best[(size_t)l * a.n + n];
+                if (a.chir) g *= (float)a.chir[(size_t)n * a.L + l];
+                const int idx = a.best[(size_t)n * a.L + l];
                 if (f < a.F) {
                     acc[0] = fmaf(g * wc, a.cen[(size_t)l * a.F + f], acc[0]);
                     const float gsup = g * ws / (float)D;
@@ -292,9 +281,9 @@ __global__ void __launch_bounds__(128) kc_backward_bank(BwdArgs a) {
             const int64_t focal = a.sel[n];
             for (int l = threadIdx.x; l < L; l += blockDim.x) {
                 float g = a.gout[focal * a.gs + a.off + l];
-                if (a.chir) g *= (float)a.chir[(size_t)l * a.n + n];
-                float S = a.scores[(size_t)l * a.n + n], C = a.scores[ln + (size_t)l * a.n + n],
-                      Ed = a.scores[2 * ln + (size_t)l * a.n + n];
+                if (a.chir) g *= (float)a.chir[(size_t)n * a.L + l];
+                float S = a.scores[(size_t)n * L + l], C = a.scores[ln + (size_t)n * L + l],
+                      Ed = a.scores[2 * ln + (size_t)n * L + l];
                 float sc = (S * a.mix[0] + C * a.mix[1] + Ed * a.mix[2]) / a.mix[3];
                 p0 = fmaf(g * ws, S - sc, p0);
                 p1 = fmaf(g * wc, C - sc, p1);
@@ -326,11 +315,11 @@ __global__ void __launch_bounds__(128) kc_backward_bank(BwdArgs a) {
         for (int64_t n = lo; n < hi; ++n) {
             const int64_t focal = a.sel[n];
             float g = a.gout[focal * a.gs + a.off + l];
-            if (a.chir) g *= (float)a.chir[(size_t)l * a.n + n];
+            if (a.chir) g *= (float)a.chir[(size_t)n * a.L + l];
             if (kind == 0) {
                 acc = fmaf(g * wc * a.inv[focal], a.x[focal * a.xs + f], acc);
             } else {
-                const int idx = a.best[(size_t)l * a.n + n];
+                const int idx = a.best[(size_t)n * a.L + l];
                 // which neighbour slot was matched to support b: pi(slot) == b
                 int slot = 0;
 #pragma unroll
@@ -473,6 +462,7 @@ hipError_t launch_bank_prepare(const mkgnn_kernel_bank banks[4], const Workspace
         a.edg[i] = (float*)(ws + w.bank[i].edg);   a.icen[i] = (float*)(ws + w.bank[i].icen);
         a.isup[i] = (float*)(ws + w.bank[i].isup); a.iedg[i] = (float*)(ws + w.bank[i].iedg);
         a.chir[i] = (int8_t*)(ws + w.bank[i].chir); a.mix[i] = (float*)(ws + w.bank[i].mix);
+        a.padded[i] = (float*)(ws + w.bank[i].padded); a.edge_padded[i] = (float*)(ws + w.bank[i].edge_padded);
         int L = banks[i].num_kernels, d = i + 1;
         a.row_start[i + 1] = a.row_start[i] + (L > 0 ? L + 2 * L * d + 1 : 0);
     }

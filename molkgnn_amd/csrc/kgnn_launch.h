@@ -14,6 +14,8 @@ struct PrepArgs {
     float* iedg[MKGNN_MAX_DEGREE];
     int8_t* chir[MKGNN_MAX_DEGREE];
     float* mix[MKGNN_MAX_DEGREE];
+    float* padded[MKGNN_MAX_DEGREE];        // see BankLayout::padded
+    float* edge_padded[MKGNN_MAX_DEGREE];
     int row_start[MKGNN_MAX_DEGREE + 1];   // wave-task prefix: rows of degree i are [row_start[i], row_start[i+1])
     int F, E;
 };
@@ -24,7 +26,9 @@ struct FwdArgs {
     int64_t n; int F, E, L, last;
     const float* cen; const float* sup; const float* edg; const int8_t* chir; const float* mix;
     float* out; int64_t os; int off, K;
-    uint8_t* best; float* scores; int8_t* chir_out;
+    uint8_t* best; float* scores; int8_t* chir_out;      // saved state, atom-major [N_d, L]
+    const float* padded; const float* edge_padded;       // MFMA kernels only
+    int64_t n_atoms;
 };
 
 struct BwdArgs {

@@ -35,6 +35,19 @@ def _row_major(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def _aligned_rows(x: torch.Tensor) -> torch.Tensor:
+    """Row-major view whose rows start on 16-byte boundaries (row stride a multiple of 4 floats, zero
+    padded), which is what the MFMA kernels load with 128-bit accesses.  A no-op for tensors that are
+    already laid out that way (everything MolGCN produces); otherwise one padded copy."""
+    x = _row_major(x)
+    if x.shape[0] == 0 or (_stride0(x) % 4 == 0 and x.data_ptr() % 16 == 0):
+        return x
+    n, f = x.shape
+    store = torch.zeros((n, f + (-f) % 4), dtype=x.dtype, device=x.device)
+    store[:, :f] = x
+    return store[:, :f]
+
+
 def _stride0(x: torch.Tensor) -> int:
     return x.stride(0) if x.shape[0] > 1 else max(x.stride(0), x.shape[1])
 
@@ -97,7 +110,7 @@ def row_inv_norm(x: torch.Tensor) -> torch.Tensor:
 def _forward_impl(x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad: int, E: int, params, want_saved: bool):
     lib = _lib.load()
     _lib.require_gpu_tensor(x, "x")
-    x = _row_major(x)
+    x = _row_major(x) if variant == VARIANTS["generic"] else _aligned_rows(x)
     n, F = x.shape
     dev = x.device
     banks, Ls, keep = _banks(params, F, E)
@@ -113,9 +126,9 @@ def _forward_impl(x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad
     for i, b in enumerate(plan.buckets):
         L = Ls[i]
         if want_saved and b.count and L:
-            bi = torch.empty((L, b.count), dtype=torch.uint8, device=dev)
-            sc = torch.empty((3, L, b.count), dtype=torch.float32, device=dev)
-            ch = torch.empty((L, b.count), dtype=torch.int8, device=dev) if (i == 3 and is_last_layer) else None
+            bi = torch.empty((b.count, L), dtype=torch.uint8, device=dev)
+            sc = torch.empty((3, b.count, L), dtype=torch.float32, device=dev)
+            ch = torch.empty((b.count, L), dtype=torch.int8, device=dev) if (i == 3 and is_last_layer) else None
             saved[i].best_index, saved[i].scores = bi.data_ptr(), sc.data_ptr()
             saved[i].chirality = ch.data_ptr() if ch is not None else None
             saved_t.append((bi, sc, ch))
@@ -136,12 +149,13 @@ def _forward_impl(x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad
 
 def kernelsetconv_details(x, plan: BatchPlan, is_last_layer: bool, params, edge_attr_dim: int, variant: str = "auto"):
     """Forward only, returning what the kernels keep for backward as well:
-    ``(out [N, K], [(best_index [L_d, N_d] uint8, scores [3, L_d, N_d], chirality) per degree])``.
-    Used by the parity tests to apply the tie-aware criterion."""
+    ``(out [N, K], [(best_index [L_d, N_d] uint8, scores [3, L_d, N_d], chirality [L_d, N_d]) per degree])``
+    (transposed views of the atom-major buffers).  Used by the parity tests for the tie-aware criterion."""
     with torch.no_grad():
         _, out, _, saved_t, _ = _forward_impl(x, plan, is_last_layer, VARIANTS[variant], 0, edge_attr_dim,
                                               [p.detach() for p in params], True)
-    return out, saved_t
+    tr = lambda t: None if t is None else t.transpose(-1, -2)
+    return out, [(tr(bi), tr(sc), tr(ch)) for bi, sc, ch in saved_t]
 
 
 class _KernelSetConvFn(torch.autograd.Function):

@@ -14,7 +14,7 @@ from tests import _golden as G
 pytestmark = pytest.mark.gpu
 
 FWD_TOL = 1e-5
-VARIANTS = ("generic", "auto")
+VARIANTS = ("generic", "mfma")
 
 
 def _dev():
