@@ -1,0 +1,290 @@
+// LDS-tiled backward kernels of the kernel convolution for the shapes the model uses (gfx950).
+//
+// The backward is sparse where the forward is dense: only the d entries of each d x d cosine
+// matrix that the chosen permutation used carry a gradient, so both gradient products
+//   rows:  g_xhat[n, slot, :]  = sum_l  coef[n, l] * unit_kernel_row[l, pi_{l,n}(slot), :]
+//   bank:  g_unit[l, b, :]     = sum_n  coef[n, l] * xhat[n, pi^-1_{l,n}(b), :]
+// are AXPYs with a data-dependent source row.  They run on the vector ALUs with the source rows
+// in LDS (one 8-byte read per two FMAs, lanes across the feature axis, conflict-free), the
+// per-(atom, kernel) coefficient and its 2-bit-packed permutation broadcast from LDS.  The
+// bank product keeps its accumulators in registers across all tiles of a persistent block and
+// writes one partial slab per block; kc_backward_bank_reduce sums the slabs in a fixed order,
+// so the result is reproducible bit for bit.
+#include "kgnn_launch.h"
+
+namespace mkgnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ rows ---
+template <int D, int KC>
+__global__ void __launch_bounds__(256) kc_backward_rows_lds(BwdArgs a) {
+    constexpr int FP = 16 * KC;
+    constexpr int TA = 32;
+    extern __shared__ __align__(16) float lds[];
+    const int L = a.L;
+    float* bank = lds;                                   // [(D+1)*L][FP]
+    float2* coef = (float2*)(lds + (size_t)(D + 1) * L * FP);   // [TA][L]  {g*ws/(W*D), packed pi}
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int q = tid; q < (D + 1) * L * FP / 4; q += 256)
+        *(f32x4*)(bank + 4 * q) = *(const f32x4*)(a.padded + 4 * q);
+    const float ws_n = a.mix[0] / a.mix[3] / (float)D;
+    const float ratio_c = a.mix[1] * (float)D / a.mix[0];
+    const int64_t ntiles = (a.n + TA - 1) / TA;
+    const bool act = 2 * lane < FP;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+        for (int q = tid; q < TA * L; q += 256) {
+            const int i = q / L, l = q - i * L;
+            const int64_t n = tile * TA + i;
+            float2 c = {0.f, 0.f};
+            if (n < a.n) {
+                float g = a.gout[a.sel[n] * a.gs + a.off + l];
+                if (a.chir) g *= (float)a.chir[(size_t)n * L + l];
+                const int idx = a.best[(size_t)n * L + l];
+                int pk = 0;
+#pragma unroll
+                for (int s = 0; s < D; ++s) pk |= perm_at<D>(idx, s) << (2 * s);
+                c.x = g * ws_n;
+                c.y = __int_as_float(pk);
+            }
+            coef[q] = c;
+        }
+        __syncthreads();
+        for (int i = wave; i < TA; i += 4) {
+            const int64_t n = tile * TA + i;
+            if (n >= a.n) break;
+            float2 acc[D + 1];
+#pragma unroll
+            for (int s = 0; s <= D; ++s) acc[s] = float2{0.f, 0.f};
+            if (act) {
+                const float2* cf = coef + (size_t)i * L;
+                const float* bl = bank + 2 * lane;
+                for (int l = 0; l < L; ++l) {
+                    const float2 c = cf[l];
+                    const int pk = __float_as_int(c.y);
+                    const float2 vc = *(const float2*)(bl + (size_t)(D * L + l) * FP);
+                    const float gc = c.x * ratio_c;
+                    acc[0].x = fmaf(gc, vc.x, acc[0].x);
+                    acc[0].y = fmaf(gc, vc.y, acc[0].y);
+#pragma unroll
+                    for (int s = 0; s < D; ++s) {
+                        const int b = (pk >> (2 * s)) & 3;
+                        const float2 v = *(const float2*)(bl + (size_t)(b * L + l) * FP);
+                        acc[1 + s].x = fmaf(c.x, v.x, acc[1 + s].x);
+                        acc[1 + s].y = fmaf(c.x, v.y, acc[1 + s].y);
+                    }
+                }
+            }
+            if (2 * lane < a.F) {
+#pragma unroll
+                for (int s = 0; s <= D; ++s)
+                    *(float2*)(a.contrib + (size_t)(a.contrib_base + n * (D + 1) + s) * a.F + 2 * lane) = acc[s];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ bank ---
+template <int D, int KC, int LI>
+__global__ void __launch_bounds__(256) kc_backward_bank_lds(BwdArgs a) {
+    constexpr int FP = 16 * KC;
+    constexpr int RS = FP + 8;                      // tile row: FP unit feature floats + 8 unit bond floats
+    constexpr int TA = 16;
+    extern __shared__ __align__(16) float lds[];
+    const int L = a.L;
+    float* xt = lds;                                // [TA][D+1][RS], slot D = focal
+    float2* coef = (float2*)(lds + TA * (D + 1) * RS);     // [TA][L] {g*ws/(W*D), packed inverse pi}
+    __shared__ float red[3][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float w_s = a.mix[0], w_c = a.mix[1], w_e = a.mix[2], w_sum = a.mix[3];
+    const float ws_n = w_s / w_sum / (float)D;
+    const float ratio_c = w_c * (float)D / w_s;
+    const float ratio_e = w_e / w_s;
+    float2 acc[LI][D + 1];
+#pragma unroll
+    for (int li = 0; li < LI; ++li)
+#pragma unroll
+        for (int s = 0; s <= D; ++s) acc[li][s] = float2{0.f, 0.f};
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    const int64_t ntiles = (a.n + TA - 1) / TA;
+    const size_t ln = (size_t)L * a.n;
+    const bool feat = 2 * lane < FP;
+    const bool act = 2 * lane < RS;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        __syncthreads();
+        // unit rows of the tile: x * 1/|x| (features), bond / |bond| (8 trailing floats)
+        for (int q = tid; q < TA * (D + 1) * (RS / 4); q += 256) {
+            const int row = q / (RS / 4), c4 = q - row * (RS / 4);
+            const int i = row / (D + 1), slot = row - i * (D + 1);
+            const int64_t n = tile * TA + i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n < a.n) {
+                if (4 * c4 < FP) {
+                    if (4 * c4 < a.F) {
+                        const int64_t atom = (slot == D) ? a.sel[n] : a.nei[n * D + slot];
+                        v = *(const f32x4*)(a.x + atom * a.xs + 4 * c4);
+                        if (4 * c4 + 1 >= a.F) v.y = 0.f;
+                        if (4 * c4 + 2 >= a.F) v.z = 0.f;
+                        if (4 * c4 + 3 >= a.F) v.w = 0.f;
+                        v *= a.inv[atom];
+                    }
+                } else if (slot < D) {
+                    const float* e = a.e_nei + (n * D + slot) * a.E;
+                    float s2 = 0.f;
+                    for (int k = 0; k < a.E; ++k) s2 = fmaf(e[k], e[k], s2);
+                    const float ie = 1.f / fmaxf(sqrtf(s2), MKGNN_EPS);
+                    const int e0 = 4 * c4 - FP;
+                    v.x = e0 + 0 < a.E ? e[e0 + 0] * ie : 0.f;
+                    v.y = e0 + 1 < a.E ? e[e0 + 1] * ie : 0.f;
+                    v.z = e0 + 2 < a.E ? e[e0 + 2] * ie : 0.f;
+                    v.w = e0 + 3 < a.E ? e[e0 + 3] * ie : 0.f;
+                }
+            }
+            *(f32x4*)(xt + (size_t)row * RS + 4 * c4) = v;
+        }
+        for (int q = tid; q < TA * L; q += 256) {
+            const int i = q / L, l = q - i * L;
+            const int64_t n = tile * TA + i;
+            float2 c = {0.f, 0.f};
+            if (n < a.n) {
+                float g = a.gout[a.sel[n] * a.gs + a.off + l];
+                if (a.chir) g *= (float)a.chir[(size_t)n * L + l];
+                const int idx = a.best[(size_t)n * L + l];
+                int pk = 0;                         // for support b: the neighbour slot matched to it
+#pragma unroll
+                for (int s = 0; s < D; ++s) pk |= s << (2 * perm_at<D>(idx, s));
+                c.x = g * ws_n;
+                c.y = __int_as_float(pk);
+                // d sc / d theta_k = w_k (score_k - sc) / W   
+                const float S = a.scores[(size_t)n * L + l], C = a.scores[ln + (size_t)n * L + l],
+                            Ed = a.scores[2 * ln + (size_t)n * L + l];
+                const float sc = (S * w_s + C * w_c + Ed * w_e) / w_sum;
+                p0 = fmaf(g * (w_s / w_sum), S - sc, p0);
+                p1 = fmaf(g * (w_c / w_sum), C - sc, p1);
+                p2 = fmaf(g * (w_e / w_sum), Ed - sc, p2);
+            }
+            coef[q] = c;
+        }
+        __syncthreads();
+        if (act) {
+            const int64_t left = a.n - tile * TA;
+            const int cnt = left < TA ? (int)left : TA;
+            for (int i = 0; i < cnt; ++i) {
+                const float* xr = xt + (size_t)i * (D + 1) * RS + 2 * lane;
+                const float2 vfocal = *(const float2*)(xr + D * RS);
+#pragma unroll
+                for (int li = 0; li < LI; ++li) {
+                    const int l = wave + 4 * li;
+                    if (l < L) {
+                        const float2 c = coef[(size_t)i * L + l];
+                        const int pk = __float_as_int(c.y);
+                        const float cc = feat ? c.x : c.x * ratio_e;
+                        const float gc = c.x * ratio_c;
+                        acc[li][D].x = fmaf(gc, vfocal.x, acc[li][D].x);
+                        acc[li][D].y = fmaf(gc, vfocal.y, acc[li][D].y);
+#pragma unroll
+                        for (int b = 0; b < D; ++b) {
+                            const int slot = (pk >> (2 * b)) & 3;
+                            const float2 v = *(const float2*)(xr + slot * RS);
+                            acc[li][b].x = fmaf(cc, v.x, acc[li][b].x);
+                            acc[li][b].y = fmaf(cc, v.y, acc[li][b].y);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // ---- one partial slab per block (row order of kc_backward_bank in kgnn_generic.hip)
+    float* slab = a.slab + (size_t)blockIdx.x * bank_floats(D, L, a.F, a.E);
+    const size_t o_sup = (size_t)L * a.F, o_edg = o_sup + (size_t)L * D * a.F, o_th = o_edg + (size_t)L * D * a.E;
+#pragma unroll
+    for (int li = 0; li < LI; ++li) {
+        const int l = wave + 4 * li;
+        if (l < L) {
+            if (2 * lane < a.F) {
+                *(float2*)(slab + (size_t)l * a.F + 2 * lane) = acc[li][D];
+#pragma unroll
+                for (int b = 0; b < D; ++b)
+                    *(float2*)(slab + o_sup + (size_t)(l * D + b) * a.F + 2 * lane) = acc[li][b];
+            } else if (!feat && act) {
+                const int e0 = 2 * lane - FP;
+#pragma unroll
+                for (int b = 0; b < D; ++b) {
+                    if (e0 < a.E) slab[o_edg + (size_t)(l * D + b) * a.E + e0] = acc[li][b].x;
+                    if (e0 + 1 < a.E) slab[o_edg + (size_t)(l * D + b) * a.E + e0 + 1] = acc[li][b].y;
+                }
+            }
+        }
+    }
+    p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
+    if (lane == 0) { red[0][wave] = p0; red[1][wave] = p1; red[2][wave] = p2; }
+    __syncthreads();
+    if (tid < 3) slab[o_th + tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
+}
+
+// ------------------------------------------------------------------ host ---
+static constexpr int bank_li(int d) { return d == 1 ? 3 : (d == 2 ? 5 : (d == 3 ? 8 : 13)); }
+
+bool lds_backward_supported(int d, int F, int E, int L, int64_t xs, const void* x) {
+    if (d < 1 || d > 4 || L < 1 || E > 8 || (F & 1)) return false;
+    const int FP = mfma_padded_width(F);
+    if (!FP || xs % 4 != 0 || ((uintptr_t)x & 15)) return false;
+    if (L > 4 * bank_li(d)) return false;
+    const size_t rows_lds = ((size_t)(d + 1) * L * FP + 2 * 32 * (size_t)L) * 4;
+    return rows_lds <= 160 * 1024;
+}
+
+template <int D, int KC>
+static hipError_t launch_lds_bwd(const BwdArgs& a0, int* nchunk_out, hipStream_t st) {
+    constexpr int FP = 16 * KC;
+    constexpr int LI = bank_li(D);
+    BwdArgs a = a0;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kc_backward_rows_lds<D, KC>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    {   // rows
+        const size_t lds_bytes = ((size_t)(D + 1) * a.L * FP + 2 * 32 * (size_t)a.L) * 4;
+        const int64_t ntiles = (a.n + 31) / 32;
+        int per_cu = (int)((160 * 1024) / lds_bytes);
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 4) per_cu = 4;
+        int64_t blocks = 256 * per_cu;
+        if (blocks > ntiles) blocks = ntiles;
+        kc_backward_rows_lds<D, KC><<<(int)blocks, 256, lds_bytes, st>>>(a);
+    }
+    {   // bank
+        const size_t lds_bytes = ((size_t)16 * (D + 1) * (FP + 8) + 2 * 16 * (size_t)a.L) * 4;
+        const int64_t ntiles = (a.n + 15) / 16;
+        int64_t blocks = BWD_BANK_BLOCKS;
+        if (blocks > ntiles) blocks = ntiles;
+        a.nchunk = (int)blocks;
+        kc_backward_bank_lds<D, KC, LI><<<(int)blocks, 256, lds_bytes, st>>>(a);
+        *nchunk_out = (int)blocks;
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_backward_lds(int d, const BwdArgs& a, int* nchunk_out, hipStream_t st) {
+    const int KC = mfma_padded_width(a.F) / 16;
+    if (KC == 2) {
+        switch (d) {
+            case 1: return launch_lds_bwd<1, 2>(a, nchunk_out, st);
+            case 2: return launch_lds_bwd<2, 2>(a, nchunk_out, st);
+            case 3: return launch_lds_bwd<3, 2>(a, nchunk_out, st);
+            default: return launch_lds_bwd<4, 2>(a, nchunk_out, st);
+        }
+    }
+    switch (d) {
+        case 1: return launch_lds_bwd<1, 7>(a, nchunk_out, st);
+        case 2: return launch_lds_bwd<2, 7>(a, nchunk_out, st);
+        case 3: return launch_lds_bwd<3, 7>(a, nchunk_out, st);
+        default: return launch_lds_bwd<4, 7>(a, nchunk_out, st);
+    }
+}
+
+}  // namespace mkgnn

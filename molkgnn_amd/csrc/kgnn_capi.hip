@@ -175,16 +175,23 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
             return fail("%s: degree-4 chirality signs were not saved", who);
         a.contrib = (float*)(ws + w.contrib); a.contrib_base = base;
         a.slab = (float*)(ws + w.slab_off[i]);
+        a.padded = (const float*)(ws + w.bank[i].padded);
         int64_t nc = a.n < BWD_BANK_BLOCKS ? (a.n > 0 ? a.n : 1) : BWD_BANK_BLOCKS;
         a.nchunk = (int)nc;
+        int nchunk = a.n > 0 ? a.nchunk : 0;
+        if (a.n > 0 && L[i] > 0) {
+            if (lds_backward_supported(d, F, E, L[i], x_stride, x)) e = launch_backward_lds(d, a, &nchunk, st);
+            else e = launch_backward_generic(d, a, st);
+            if (e != hipSuccess) return hip_fail("kernelconv backward launch", e);
+        }
         BankReduceArgs r;
-        r.slab = a.slab; r.nchunk = a.n > 0 ? a.nchunk : 0; r.F = F; r.E = E; r.L = L[i];
+        r.slab = a.slab; r.nchunk = nchunk; r.F = F; r.E = E; r.L = L[i];
         r.cen = a.cen; r.sup = a.sup; r.edg = a.edg;
         r.icen = (const float*)(ws + w.bank[i].icen); r.isup = (const float*)(ws + w.bank[i].isup);
         r.iedg = (const float*)(ws + w.bank[i].iedg);
         r.g = grads[i];
-        e = launch_backward_generic(d, a, r, st);
-        if (e != hipSuccess) return hip_fail("kernelconv backward launch", e);
+        e = launch_bank_reduce(d, r, st);
+        if (e != hipSuccess) return hip_fail("bank gradient reduce launch", e);
         off += L[i];
         base += a.n * (d + 1);
     }

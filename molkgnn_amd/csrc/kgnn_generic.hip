@@ -341,21 +341,24 @@ __global__ void __launch_bounds__(128) kc_backward_bank(BwdArgs a) {
 }
 
 
-// Sum the chunk partials and undo the unit normalisation:
+// Sum the per-block partial slabs in a fixed order and undo the unit normalisation:
 // d/ds of s/max(|s|,eps):  (g - (g . s^) s^) / |s|   (or g / eps below eps).
+// One block per bank row: wave w sums chunks w, w+4, ..., the four partial sums are combined
+// as (p0 + p1) + (p2 + p3) -- the same order on every run.
 template <int D>
-__global__ void __launch_bounds__(64) kc_backward_bank_reduce(BankReduceArgs a) {
+__global__ void __launch_bounds__(256) kc_backward_bank_reduce(BankReduceArgs a) {
     const int r = blockIdx.x;
-    const int lane = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int L = a.L;
     const size_t bank_fl = bank_floats(D, L, a.F, a.E);
     const int nrow = L + 2 * L * D;
+    __shared__ float part[4][256];
     if (r == nrow) {
-        if (lane < 3) {
-            size_t o = (size_t)L * a.F + (size_t)L * D * a.F + (size_t)L * D * a.E + lane;
+        if (tid < 3) {
+            size_t o = (size_t)L * a.F + (size_t)L * D * a.F + (size_t)L * D * a.E + tid;
             float s = 0.f;
             for (int c = 0; c < a.nchunk; ++c) s += a.slab[(size_t)c * bank_fl + o];
-            float* dst = lane == 0 ? a.g.support_attr_sc_weight : (lane == 1 ? a.g.center_attr_sc_weight : a.g.edge_attr_support_sc_weight);
+            float* dst = tid == 0 ? a.g.support_attr_sc_weight : (tid == 1 ? a.g.center_attr_sc_weight : a.g.edge_attr_support_sc_weight);
             if (dst) *dst = s;
         }
         return;
@@ -365,17 +368,28 @@ __global__ void __launch_bounds__(64) kc_backward_bank_reduce(BankReduceArgs a) 
     else if (r < L + L * D) { int q = r - L; unit = a.sup + (size_t)q * a.F; inv = a.isup[q]; dst = a.g.x_support ? a.g.x_support + (size_t)q * a.F : nullptr; off = (size_t)L * a.F + (size_t)q * a.F; width = a.F; }
     else { int q = r - L - L * D; unit = a.edg + (size_t)q * a.E; inv = a.iedg[q]; dst = a.g.edge_attr_support ? a.g.edge_attr_support + (size_t)q * a.E : nullptr; off = (size_t)L * a.F + (size_t)L * D * a.F + (size_t)q * a.E; width = a.E; }
     if (!dst) return;
+    for (int f = lane; f < width; f += 64) {
+        float s0 = 0.f, s1 = 0.f;
+        int c = wave;
+        for (; c + 4 < a.nchunk; c += 8) {
+            s0 += a.slab[(size_t)c * bank_fl + off + f];
+            s1 += a.slab[(size_t)(c + 4) * bank_fl + off + f];
+        }
+        if (c < a.nchunk) s0 += a.slab[(size_t)c * bank_fl + off + f];
+        part[wave][f] = s0 + s1;
+    }
+    __syncthreads();
+    if (wave != 0) return;
     float dotp = 0.f;
     for (int f = lane; f < width; f += 64) {
-        float s = 0.f;
-        for (int c = 0; c < a.nchunk; ++c) s += a.slab[(size_t)c * bank_fl + off + f];
-        dst[f] = s;
+        const float s = (part[0][f] + part[1][f]) + (part[2][f] + part[3][f]);
+        part[0][f] = s;
         dotp = fmaf(s, unit[f], dotp);
     }
     dotp = wave_sum(dotp);
     const bool clamped = inv >= (1.f / MKGNN_EPS);
     for (int f = lane; f < width; f += 64) {
-        float s = dst[f];
+        const float s = part[0][f];
         dst[f] = clamped ? s * inv : (s - dotp * unit[f]) * inv;
     }
 }
@@ -489,23 +503,38 @@ hipError_t launch_forward_generic(int d, const FwdArgs& a, hipStream_t st) {
 }
 
 template <int D>
-static hipError_t launch_bwd_d(const BwdArgs& a, const BankReduceArgs& r, hipStream_t st) {
+static hipError_t launch_bwd_d(const BwdArgs& a, hipStream_t st) {
     if (a.n > 0) {
         kc_backward_rows<D><<<grid_for_waves(a.n), 256, 0, st>>>(a);
         dim3 grid(a.L + 2 * a.L * D + 1, a.nchunk);
         kc_backward_bank<D><<<grid, 128, 0, st>>>(a);
     }
-    kc_backward_bank_reduce<D><<<a.L + 2 * a.L * D + 1, 64, 0, st>>>(r);
     return hipGetLastError();
 }
 
-hipError_t launch_backward_generic(int d, const BwdArgs& a, const BankReduceArgs& r, hipStream_t st) {
+hipError_t launch_backward_generic(int d, const BwdArgs& a, hipStream_t st) {
     if (a.L == 0) return hipSuccess;
     switch (d) {
-        case 1: return launch_bwd_d<1>(a, r, st);
-        case 2: return launch_bwd_d<2>(a, r, st);
-        case 3: return launch_bwd_d<3>(a, r, st);
-        default: return launch_bwd_d<4>(a, r, st);
+        case 1: return launch_bwd_d<1>(a, st);
+        case 2: return launch_bwd_d<2>(a, st);
+        case 3: return launch_bwd_d<3>(a, st);
+        default: return launch_bwd_d<4>(a, st);
+    }
+}
+
+template <int D>
+static hipError_t launch_reduce_d(const BankReduceArgs& r, hipStream_t st) {
+    kc_backward_bank_reduce<D><<<r.L + 2 * r.L * D + 1, 256, 0, st>>>(r);
+    return hipGetLastError();
+}
+
+hipError_t launch_bank_reduce(int d, const BankReduceArgs& r, hipStream_t st) {
+    if (r.L == 0) return hipSuccess;
+    switch (d) {
+        case 1: return launch_reduce_d<1>(r, st);
+        case 2: return launch_reduce_d<2>(r, st);
+        case 3: return launch_reduce_d<3>(r, st);
+        default: return launch_reduce_d<4>(r, st);
     }
 }
 

@@ -40,6 +40,7 @@ struct BwdArgs {
     const uint8_t* best; const float* scores; const int8_t* chir;
     float* contrib; int64_t contrib_base;      // rows base + n*(D+1) + slot
     float* slab; int nchunk;                   // [nchunk, bank_floats]
+    const float* padded;                       // unit bank rows, support-major, padded (LDS kernels)
 };
 
 struct BankReduceArgs {
@@ -53,7 +54,11 @@ hipError_t launch_row_inv_norm(const float* x, int64_t stride, int64_t n, int F,
 hipError_t launch_bank_prepare(const mkgnn_kernel_bank banks[4], const WorkspaceLayout& w, char* ws, int F, int E,
                                hipStream_t st);
 hipError_t launch_forward_generic(int d, const FwdArgs& a, hipStream_t st);
-hipError_t launch_backward_generic(int d, const BwdArgs& a, const BankReduceArgs& r, hipStream_t st);
+hipError_t launch_backward_generic(int d, const BwdArgs& a, hipStream_t st);
+hipError_t launch_bank_reduce(int d, const BankReduceArgs& r, hipStream_t st);
+// kgnn_bwd.hip: LDS-tiled backward for the model's shapes
+bool lds_backward_supported(int d, int F, int E, int L, int64_t xs, const void* x);
+hipError_t launch_backward_lds(int d, const BwdArgs& a, int* nchunk_out, hipStream_t st);
 hipError_t launch_backward_gather(const float* contrib, const int32_t* rowptr, const int32_t* rows, const float* x,
                                   int64_t xs, const float* inv, int64_t n, int F, float* gx, int64_t gxs,
                                   hipStream_t st);
