@@ -6,51 +6,100 @@
 //   bank:  g_unit[l, b, :]     = sum_n  coef[n, l] * xhat[n, pi^-1_{l,n}(b), :]
 // are AXPYs with a data-dependent source row.  They run on the vector ALUs with the source rows
 // in LDS (one 8-byte read per two FMAs, lanes across the feature axis, conflict-free), the
-// per-(atom, kernel) coefficient and its 2-bit-packed permutation broadcast from LDS.  The
-// bank product keeps its accumulators in registers across all tiles of a persistent block and
-// writes one partial slab per block; kc_backward_bank_reduce sums the slabs in a fixed order,
-// so the result is reproducible bit for bit.
+// per-(atom, kernel) coefficient and its 2-bit-packed permutation broadcast from LDS.
+//
+// Both kernels are persistent and software-pipelined: the atom ids of tile t+2 and the global
+// loads (feature rows, output gradients, saved permutation ids) of tile t+1 are issued before
+// tile t is multiplied, so the gather latency is hidden behind the LDS/FMA work.
+//
+// The bank product keeps its accumulators in registers across all tiles of a block and writes
+// one partial slab per block; kc_backward_bank_reduce sums the slabs in a fixed order, so the
+// result is reproducible bit for bit.
 #include "kgnn_launch.h"
 
 namespace mkgnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+__host__ __device__ constexpr int bank_li(int d) { return d == 1 ? 3 : (d == 2 ? 5 : (d == 3 ? 8 : 13)); }   // kernels per wave
+__host__ __device__ constexpr int rows_cq(int d) { return d == 1 ? 2 : (d == 2 ? 3 : (d == 3 ? 4 : 7)); }    // coefficient pairs per thread
+__host__ __device__ constexpr int bank_ta(int d) { return d <= 2 ? 32 : 16; }                                 // atoms per bank tile
+
 // ------------------------------------------------------------------ rows ---
+// Also accumulates the three score-weight partials (d sc / d theta_k = w_k (score_k - sc) / W).
 template <int D, int KC>
 __global__ void __launch_bounds__(256) kc_backward_rows_lds(BwdArgs a) {
     constexpr int FP = 16 * KC;
     constexpr int TA = 32;
+    constexpr int CQ = rows_cq(D);
     extern __shared__ __align__(16) float lds[];
+    __shared__ float red[3][4];
     const int L = a.L;
-    float* bank = lds;                                   // [(D+1)*L][FP]
-    float2* coef = (float2*)(lds + (size_t)(D + 1) * L * FP);   // [TA][L]  {g*ws/(W*D), packed pi}
+    float* bank = lds;                                              // [(D+1)*L][FP]
+    float2* coef = (float2*)(lds + (size_t)(D + 1) * L * FP);       // [TA][L]  {g*ws/(W*D), packed pi}
+    int* idbuf = (int*)(coef + (size_t)TA * L);                     // [2][TA] focal atom ids
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int q = tid; q < (D + 1) * L * FP / 4; q += 256)
         *(f32x4*)(bank + 4 * q) = *(const f32x4*)(a.padded + 4 * q);
-    const float ws_n = a.mix[0] / a.mix[3] / (float)D;
-    const float ratio_c = a.mix[1] * (float)D / a.mix[0];
+    const float w_s = a.mix[0], w_c = a.mix[1], w_e = a.mix[2], w_sum = a.mix[3];
+    const float ws_n = w_s / w_sum / (float)D;
+    const float ratio_c = w_c * (float)D / w_s;
     const int64_t ntiles = (a.n + TA - 1) / TA;
+    const size_t ln = (size_t)L * a.n;
     const bool act = 2 * lane < FP;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        __syncthreads();
-        for (int q = tid; q < TA * L; q += 256) {
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+
+    auto load_ids = [&](int64_t tile, int buf) {
+        if (tid < TA) {
+            int64_t n = tile * TA + tid;
+            if (n >= a.n) n = a.n - 1;
+            idbuf[buf * TA + tid] = (int)a.sel[n];
+        }
+    };
+    float rg[CQ], rS[CQ], rC[CQ], rE[CQ];
+    int ridx[CQ];
+    auto fetch = [&](int64_t tile, int buf) {
+#pragma unroll
+        for (int k = 0; k < CQ; ++k) {
+            const int q = tid + 256 * k;
             const int i = q / L, l = q - i * L;
             const int64_t n = tile * TA + i;
-            float2 c = {0.f, 0.f};
-            if (n < a.n) {
-                float g = a.gout[a.sel[n] * a.gs + a.off + l];
+            rg[k] = 0.f; ridx[k] = 0; rS[k] = rC[k] = rE[k] = 0.f;
+            if (q < TA * L && n < a.n) {
+                float g = a.gout[(int64_t)idbuf[buf * TA + i] * a.gs + a.off + l];
                 if (a.chir) g *= (float)a.chir[(size_t)n * L + l];
-                const int idx = a.best[(size_t)n * L + l];
+                rg[k] = g;
+                ridx[k] = a.best[(size_t)n * L + l];
+                rS[k] = a.scores[(size_t)n * L + l];
+                rC[k] = a.scores[ln + (size_t)n * L + l];
+                rE[k] = a.scores[2 * ln + (size_t)n * L + l];
+            }
+        }
+    };
+    int64_t tile = blockIdx.x;
+    int buf = 0;
+    load_ids(tile, 0);
+    __syncthreads();
+    fetch(tile, 0);
+    if (tile + gridDim.x < ntiles) load_ids(tile + gridDim.x, 1);
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+#pragma unroll
+        for (int k = 0; k < CQ; ++k) {
+            const int q = tid + 256 * k;
+            if (q < TA * L) {
                 int pk = 0;
 #pragma unroll
-                for (int s = 0; s < D; ++s) pk |= perm_at<D>(idx, s) << (2 * s);
-                c.x = g * ws_n;
-                c.y = __int_as_float(pk);
+                for (int s = 0; s < D; ++s) pk |= perm_at<D>(ridx[k], s) << (2 * s);
+                coef[q] = float2{rg[k] * ws_n, __int_as_float(pk)};
+                const float sc = (rS[k] * w_s + rC[k] * w_c + rE[k] * w_e) / w_sum;
+                p0 = fmaf(rg[k] * (w_s / w_sum), rS[k] - sc, p0);
+                p1 = fmaf(rg[k] * (w_c / w_sum), rC[k] - sc, p1);
+                p2 = fmaf(rg[k] * (w_e / w_sum), rE[k] - sc, p2);
             }
-            coef[q] = c;
         }
         __syncthreads();
+        const int64_t nxt = tile + gridDim.x;
+        if (nxt < ntiles) fetch(nxt, buf ^ 1);
         for (int i = wave; i < TA; i += 4) {
             const int64_t n = tile * TA + i;
             if (n >= a.n) break;
@@ -60,6 +109,7 @@ __global__ void __launch_bounds__(256) kc_backward_rows_lds(BwdArgs a) {
             if (act) {
                 const float2* cf = coef + (size_t)i * L;
                 const float* bl = bank + 2 * lane;
+#pragma unroll 2
                 for (int l = 0; l < L; ++l) {
                     const float2 c = cf[l];
                     const int pk = __float_as_int(c.y);
@@ -82,20 +132,30 @@ __global__ void __launch_bounds__(256) kc_backward_rows_lds(BwdArgs a) {
                     *(float2*)(a.contrib + (size_t)(a.contrib_base + n * (D + 1) + s) * a.F + 2 * lane) = acc[s];
             }
         }
+        __syncthreads();
+        if (nxt + gridDim.x < ntiles) load_ids(nxt + gridDim.x, buf);
     }
+    p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
+    if (lane == 0) { red[0][wave] = p0; red[1][wave] = p1; red[2][wave] = p2; }
+    __syncthreads();
+    if (tid < 3) a.theta_slab[(size_t)blockIdx.x * 4 + tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
 }
 
 // ------------------------------------------------------------------ bank ---
-template <int D, int KC, int LI>
+template <int D, int KC, int LI, int TA>
 __global__ void __launch_bounds__(256) kc_backward_bank_lds(BwdArgs a) {
     constexpr int FP = 16 * KC;
     constexpr int RS = FP + 8;                      // tile row: FP unit feature floats + 8 unit bond floats
-    constexpr int TA = 16;
+    constexpr int CH = FP / 4;
+    constexpr int NROW = TA * (D + 1);              // row = atom * (D+1) + slot, slot D = focal
+    constexpr int MAXQ = (NROW * CH + 255) / 256;
+    constexpr int CQ = (TA * 4 * LI + 255) / 256;   // coefficient pairs per thread (L <= 4*LI)
     extern __shared__ __align__(16) float lds[];
     const int L = a.L;
-    float* xt = lds;                                // [TA][D+1][RS], slot D = focal
-    float2* coef = (float2*)(lds + TA * (D + 1) * RS);     // [TA][L] {g*ws/(W*D), packed inverse pi}
-    __shared__ float red[3][4];
+    float* xt = lds;                                        // [NROW][RS]
+    float2* coef = (float2*)(lds + NROW * RS);              // [TA][L] {g*ws/(W*D), packed inverse pi}
+    int* idbuf = (int*)(coef + (size_t)TA * L);             // [2][NROW] atom ids
+    float* invbuf = (float*)(idbuf + 2 * NROW);             // [2][NROW] 1/|x|
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float w_s = a.mix[0], w_c = a.mix[1], w_e = a.mix[2], w_sum = a.mix[3];
     const float ws_n = w_s / w_sum / (float)D;
@@ -106,67 +166,105 @@ __global__ void __launch_bounds__(256) kc_backward_bank_lds(BwdArgs a) {
     for (int li = 0; li < LI; ++li)
 #pragma unroll
         for (int s = 0; s <= D; ++s) acc[li][s] = float2{0.f, 0.f};
-    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
     const int64_t ntiles = (a.n + TA - 1) / TA;
-    const size_t ln = (size_t)L * a.n;
     const bool feat = 2 * lane < FP;
     const bool act = 2 * lane < RS;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        __syncthreads();
-        // unit rows of the tile: x * 1/|x| (features), bond / |bond| (8 trailing floats)
-        for (int q = tid; q < TA * (D + 1) * (RS / 4); q += 256) {
-            const int row = q / (RS / 4), c4 = q - row * (RS / 4);
-            const int i = row / (D + 1), slot = row - i * (D + 1);
-            const int64_t n = tile * TA + i;
+
+    auto load_ids = [&](int64_t tile, int buf) {
+        for (int r = tid; r < NROW; r += 256) {
+            const int i = r / (D + 1), slot = r - i * (D + 1);
+            int64_t n = tile * TA + i;
+            if (n >= a.n) n = a.n - 1;
+            const int64_t atom = (slot == D) ? a.sel[n] : a.nei[n * D + slot];
+            idbuf[buf * NROW + r] = (int)atom;
+            invbuf[buf * NROW + r] = a.inv[atom];
+        }
+    };
+    f32x4 stage[MAXQ];
+    float rg[CQ];
+    int ridx[CQ];
+    float ev[8];
+    auto fetch = [&](int64_t tile, int buf) {
+#pragma unroll
+        for (int k = 0; k < MAXQ; ++k) {
+            const int q = tid + 256 * k;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < a.n) {
-                if (4 * c4 < FP) {
-                    if (4 * c4 < a.F) {
-                        const int64_t atom = (slot == D) ? a.sel[n] : a.nei[n * D + slot];
-                        v = *(const f32x4*)(a.x + atom * a.xs + 4 * c4);
-                        if (4 * c4 + 1 >= a.F) v.y = 0.f;
-                        if (4 * c4 + 2 >= a.F) v.z = 0.f;
-                        if (4 * c4 + 3 >= a.F) v.w = 0.f;
-                        v *= a.inv[atom];
-                    }
-                } else if (slot < D) {
-                    const float* e = a.e_nei + (n * D + slot) * a.E;
-                    float s2 = 0.f;
-                    for (int k = 0; k < a.E; ++k) s2 = fmaf(e[k], e[k], s2);
-                    const float ie = 1.f / fmaxf(sqrtf(s2), MKGNN_EPS);
-                    const int e0 = 4 * c4 - FP;
-                    v.x = e0 + 0 < a.E ? e[e0 + 0] * ie : 0.f;
-                    v.y = e0 + 1 < a.E ? e[e0 + 1] * ie : 0.f;
-                    v.z = e0 + 2 < a.E ? e[e0 + 2] * ie : 0.f;
-                    v.w = e0 + 3 < a.E ? e[e0 + 3] * ie : 0.f;
+            if (q < NROW * CH) {
+                const int row = q / CH, c = q - row * CH;
+                if (4 * c < a.F) {
+                    v = *(const f32x4*)(a.x + (size_t)idbuf[buf * NROW + row] * a.xs + 4 * c);
+                    if (4 * c + 1 >= a.F) v.y = 0.f;
+                    if (4 * c + 2 >= a.F) v.z = 0.f;
+                    if (4 * c + 3 >= a.F) v.w = 0.f;
                 }
             }
-            *(f32x4*)(xt + (size_t)row * RS + 4 * c4) = v;
+            stage[k] = v;
         }
-        for (int q = tid; q < TA * L; q += 256) {
+#pragma unroll
+        for (int k = 0; k < CQ; ++k) {
+            const int q = tid + 256 * k;
             const int i = q / L, l = q - i * L;
             const int64_t n = tile * TA + i;
-            float2 c = {0.f, 0.f};
-            if (n < a.n) {
-                float g = a.gout[a.sel[n] * a.gs + a.off + l];
+            rg[k] = 0.f; ridx[k] = 0;
+            if (q < TA * L && n < a.n) {
+                float g = a.gout[(int64_t)idbuf[buf * NROW + i * (D + 1) + D] * a.gs + a.off + l];
                 if (a.chir) g *= (float)a.chir[(size_t)n * L + l];
-                const int idx = a.best[(size_t)n * L + l];
-                int pk = 0;                         // for support b: the neighbour slot matched to it
-#pragma unroll
-                for (int s = 0; s < D; ++s) pk |= s << (2 * perm_at<D>(idx, s));
-                c.x = g * ws_n;
-                c.y = __int_as_float(pk);
-                // d sc / d theta_k = w_k (score_k - sc) / W   
-                const float S = a.scores[(size_t)n * L + l], C = a.scores[ln + (size_t)n * L + l],
-                            Ed = a.scores[2 * ln + (size_t)n * L + l];
-                const float sc = (S * w_s + C * w_c + Ed * w_e) / w_sum;
-                p0 = fmaf(g * (w_s / w_sum), S - sc, p0);
-                p1 = fmaf(g * (w_c / w_sum), C - sc, p1);
-                p2 = fmaf(g * (w_e / w_sum), Ed - sc, p2);
+                rg[k] = g;
+                ridx[k] = a.best[(size_t)n * L + l];
             }
-            coef[q] = c;
+        }
+        if (tid < TA * D) {                          // bond vectors of (atom, slot)
+            const int i = tid / D, slot = tid - i * D;
+            int64_t n = tile * TA + i;
+            if (n >= a.n) n = a.n - 1;
+            const float* e = a.e_nei + (n * D + slot) * a.E;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) ev[k] = k < a.E ? e[k] : 0.f;
+        }
+    };
+    int64_t tile = blockIdx.x;
+    int buf = 0;
+    load_ids(tile, 0);
+    __syncthreads();
+    fetch(tile, 0);
+    if (tile + gridDim.x < ntiles) load_ids(tile + gridDim.x, 1);
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        // ---- registers -> LDS: unit feature rows, unit bond vectors, coefficients
+#pragma unroll
+        for (int k = 0; k < MAXQ; ++k) {
+            const int q = tid + 256 * k;
+            if (q < NROW * CH) {
+                const int row = q / CH, c = q - row * CH;
+                *(f32x4*)(xt + (size_t)row * RS + 4 * c) = stage[k] * invbuf[buf * NROW + row];
+            }
+        }
+        if (tid < TA * D) {
+            const int i = tid / D, slot = tid - i * D;
+            float s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s2 = fmaf(ev[k], ev[k], s2);
+            const float ie = 1.f / fmaxf(sqrtf(s2), MKGNN_EPS);
+            float* dst = xt + (size_t)(i * (D + 1) + slot) * RS + FP;
+            *(f32x4*)dst = f32x4{ev[0] * ie, ev[1] * ie, ev[2] * ie, ev[3] * ie};
+            *(f32x4*)(dst + 4) = f32x4{ev[4] * ie, ev[5] * ie, ev[6] * ie, ev[7] * ie};
+        } else if (tid < TA * D + TA) {              // focal rows carry no bond vector
+            float* dst = xt + (size_t)((tid - TA * D) * (D + 1) + D) * RS + FP;
+            *(f32x4*)dst = f32x4{0.f, 0.f, 0.f, 0.f};
+            *(f32x4*)(dst + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < CQ; ++k) {
+            const int q = tid + 256 * k;
+            if (q < TA * L) {
+                int pk = 0;                          // for support b: the neighbour slot matched to it
+#pragma unroll
+                for (int s = 0; s < D; ++s) pk |= s << (2 * perm_at<D>(ridx[k], s));
+                coef[q] = float2{rg[k] * ws_n, __int_as_float(pk)};
+            }
         }
         __syncthreads();
+        const int64_t nxt = tile + gridDim.x;
+        if (nxt < ntiles) fetch(nxt, buf ^ 1);
         if (act) {
             const int64_t left = a.n - tile * TA;
             const int cnt = left < TA ? (int)left : TA;
@@ -194,10 +292,12 @@ __global__ void __launch_bounds__(256) kc_backward_bank_lds(BwdArgs a) {
                 }
             }
         }
+        __syncthreads();
+        if (nxt + gridDim.x < ntiles) load_ids(nxt + gridDim.x, buf);
     }
     // ---- one partial slab per block (row order of kc_backward_bank in kgnn_generic.hip)
     float* slab = a.slab + (size_t)blockIdx.x * bank_floats(D, L, a.F, a.E);
-    const size_t o_sup = (size_t)L * a.F, o_edg = o_sup + (size_t)L * D * a.F, o_th = o_edg + (size_t)L * D * a.E;
+    const size_t o_sup = (size_t)L * a.F, o_edg = o_sup + (size_t)L * D * a.F;
 #pragma unroll
     for (int li = 0; li < LI; ++li) {
         const int l = wave + 4 * li;
@@ -217,73 +317,74 @@ __global__ void __launch_bounds__(256) kc_backward_bank_lds(BwdArgs a) {
             }
         }
     }
-    p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
-    if (lane == 0) { red[0][wave] = p0; red[1][wave] = p1; red[2][wave] = p2; }
-    __syncthreads();
-    if (tid < 3) slab[o_th + tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
 }
 
 // ------------------------------------------------------------------ host ---
-static constexpr int bank_li(int d) { return d == 1 ? 3 : (d == 2 ? 5 : (d == 3 ? 8 : 13)); }
+static size_t rows_lds_bytes(int d, int FP, int L) { return ((size_t)(d + 1) * L * FP + 2 * 32 * (size_t)L + 2 * 32) * 4; }
 
 bool lds_backward_supported(int d, int F, int E, int L, int64_t xs, const void* x) {
     if (d < 1 || d > 4 || L < 1 || E > 8 || (F & 1)) return false;
     const int FP = mfma_padded_width(F);
     if (!FP || xs % 4 != 0 || ((uintptr_t)x & 15)) return false;
-    if (L > 4 * bank_li(d)) return false;
-    const size_t rows_lds = ((size_t)(d + 1) * L * FP + 2 * 32 * (size_t)L) * 4;
-    return rows_lds <= 160 * 1024;
+    if (L > 4 * bank_li(d) || 32 * L > 256 * rows_cq(d)) return false;
+    return rows_lds_bytes(d, FP, L) <= 160 * 1024 - 1024;
 }
 
 template <int D, int KC>
-static hipError_t launch_lds_bwd(const BwdArgs& a0, int* nchunk_out, hipStream_t st) {
+static hipError_t launch_lds_bwd(const BwdArgs& a0, int* nchunk_out, int* ntheta_out, hipStream_t st) {
     constexpr int FP = 16 * KC;
     constexpr int LI = bank_li(D);
+    constexpr int TA = bank_ta(D);
     BwdArgs a = a0;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kc_backward_rows_lds<D, KC>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)kc_backward_bank_lds<D, KC, LI, TA>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     {   // rows
-        const size_t lds_bytes = ((size_t)(D + 1) * a.L * FP + 2 * 32 * (size_t)a.L) * 4;
+        const size_t lds_bytes = rows_lds_bytes(D, FP, a.L);
         const int64_t ntiles = (a.n + 31) / 32;
-        int per_cu = (int)((160 * 1024) / lds_bytes);
+        int per_cu = (int)((160 * 1024) / (lds_bytes + 256));
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 4) per_cu = 4;
         int64_t blocks = 256 * per_cu;
+        if (blocks > THETA_SLAB_BLOCKS) blocks = THETA_SLAB_BLOCKS;
         if (blocks > ntiles) blocks = ntiles;
         kc_backward_rows_lds<D, KC><<<(int)blocks, 256, lds_bytes, st>>>(a);
+        *ntheta_out = (int)blocks;
     }
     {   // bank
-        const size_t lds_bytes = ((size_t)16 * (D + 1) * (FP + 8) + 2 * 16 * (size_t)a.L) * 4;
-        const int64_t ntiles = (a.n + 15) / 16;
+        const size_t lds_bytes = ((size_t)TA * (D + 1) * (FP + 8) + 2 * TA * (size_t)a.L + 4 * TA * (D + 1)) * 4;
+        const int64_t ntiles = (a.n + TA - 1) / TA;
         int64_t blocks = BWD_BANK_BLOCKS;
         if (blocks > ntiles) blocks = ntiles;
         a.nchunk = (int)blocks;
-        kc_backward_bank_lds<D, KC, LI><<<(int)blocks, 256, lds_bytes, st>>>(a);
+        kc_backward_bank_lds<D, KC, LI, TA><<<(int)blocks, 256, lds_bytes, st>>>(a);
         *nchunk_out = (int)blocks;
     }
     return hipGetLastError();
 }
 
-hipError_t launch_backward_lds(int d, const BwdArgs& a, int* nchunk_out, hipStream_t st) {
+hipError_t launch_backward_lds(int d, const BwdArgs& a, int* nchunk_out, int* ntheta_out, hipStream_t st) {
     const int KC = mfma_padded_width(a.F) / 16;
     if (KC == 2) {
         switch (d) {
-            case 1: return launch_lds_bwd<1, 2>(a, nchunk_out, st);
-            case 2: return launch_lds_bwd<2, 2>(a, nchunk_out, st);
-            case 3: return launch_lds_bwd<3, 2>(a, nchunk_out, st);
-            default: return launch_lds_bwd<4, 2>(a, nchunk_out, st);
+            case 1: return launch_lds_bwd<1, 2>(a, nchunk_out, ntheta_out, st);
+            case 2: return launch_lds_bwd<2, 2>(a, nchunk_out, ntheta_out, st);
+            case 3: return launch_lds_bwd<3, 2>(a, nchunk_out, ntheta_out, st);
+            default: return launch_lds_bwd<4, 2>(a, nchunk_out, ntheta_out, st);
         }
     }
     switch (d) {
-        case 1: return launch_lds_bwd<1, 7>(a, nchunk_out, st);
-        case 2: return launch_lds_bwd<2, 7>(a, nchunk_out, st);
-        case 3: return launch_lds_bwd<3, 7>(a, nchunk_out, st);
-        default: return launch_lds_bwd<4, 7>(a, nchunk_out, st);
+        case 1: return launch_lds_bwd<1, 7>(a, nchunk_out, ntheta_out, st);
+        case 2: return launch_lds_bwd<2, 7>(a, nchunk_out, ntheta_out, st);
+        case 3: return launch_lds_bwd<3, 7>(a, nchunk_out, ntheta_out, st);
+        default: return launch_lds_bwd<4, 7>(a, nchunk_out, ntheta_out, st);
     }
 }
 

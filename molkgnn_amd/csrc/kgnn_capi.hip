@@ -178,14 +178,21 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         a.padded = (const float*)(ws + w.bank[i].padded);
         int64_t nc = a.n < BWD_BANK_BLOCKS ? (a.n > 0 ? a.n : 1) : BWD_BANK_BLOCKS;
         a.nchunk = (int)nc;
+        a.theta_slab = (float*)(ws + w.theta_off[i]);
         int nchunk = a.n > 0 ? a.nchunk : 0;
+        int ntheta = -1;
         if (a.n > 0 && L[i] > 0) {
-            if (lds_backward_supported(d, F, E, L[i], x_stride, x)) e = launch_backward_lds(d, a, &nchunk, st);
+            if (lds_backward_supported(d, F, E, L[i], x_stride, x)) e = launch_backward_lds(d, a, &nchunk, &ntheta, st);
             else e = launch_backward_generic(d, a, st);
             if (e != hipSuccess) return hip_fail("kernelconv backward launch", e);
         }
         BankReduceArgs r;
         r.slab = a.slab; r.nchunk = nchunk; r.F = F; r.E = E; r.L = L[i];
+        if (ntheta >= 0) { r.theta_src = a.theta_slab; r.theta_stride = 4; r.theta_count = ntheta; }
+        else {
+            r.theta_src = a.slab + (size_t)L[i] * F + (size_t)L[i] * d * F + (size_t)L[i] * d * E;
+            r.theta_stride = bank_floats(d, L[i], F, E); r.theta_count = nchunk;
+        }
         r.cen = a.cen; r.sup = a.sup; r.edg = a.edg;
         r.icen = (const float*)(ws + w.bank[i].icen); r.isup = (const float*)(ws + w.bank[i].isup);
         r.iedg = (const float*)(ws + w.bank[i].iedg);

@@ -100,6 +100,7 @@ struct WorkspaceLayout {
     size_t slab;          // partial bank gradients, per degree [nblk, bank floats]
     size_t slab_bytes_per_degree[MKGNN_MAX_DEGREE];
     size_t slab_off[MKGNN_MAX_DEGREE];
+    size_t theta_off[MKGNN_MAX_DEGREE];
     size_t total;
 };
 
@@ -111,6 +112,7 @@ __host__ __device__ static inline size_t bank_floats(int d, int L, int F, int E)
 }
 
 constexpr int BWD_BANK_BLOCKS = 256;   // persistent blocks of the bank-gradient kernel
+constexpr int THETA_SLAB_BLOCKS = 1024; // most blocks of the rows kernel (score-weight partials)
 
 static inline WorkspaceLayout make_layout(const int32_t L[MKGNN_MAX_DEGREE], int F, int E,
                                           int64_t n_atoms, int64_t n_edges) {
@@ -140,6 +142,8 @@ static inline WorkspaceLayout make_layout(const int32_t L[MKGNN_MAX_DEGREE], int
         w.slab_off[i] = off;
         w.slab_bytes_per_degree[i] = align_up(bank_floats(i + 1, L[i], F, E) * 4 * BWD_BANK_BLOCKS);
         off += w.slab_bytes_per_degree[i];
+        w.theta_off[i] = off;
+        off += align_up((size_t)THETA_SLAB_BLOCKS * 4 * 4);
     }
     w.total = off;
     return w;

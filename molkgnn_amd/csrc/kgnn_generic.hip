@@ -355,9 +355,8 @@ __global__ void __launch_bounds__(256) kc_backward_bank_reduce(BankReduceArgs a)
     __shared__ float part[4][256];
     if (r == nrow) {
         if (tid < 3) {
-            size_t o = (size_t)L * a.F + (size_t)L * D * a.F + (size_t)L * D * a.E + tid;
             float s = 0.f;
-            for (int c = 0; c < a.nchunk; ++c) s += a.slab[(size_t)c * bank_fl + o];
+            for (int c = 0; c < a.theta_count; ++c) s += a.theta_src[(size_t)c * a.theta_stride + tid];
             float* dst = tid == 0 ? a.g.support_attr_sc_weight : (tid == 1 ? a.g.center_attr_sc_weight : a.g.edge_attr_support_sc_weight);
             if (dst) *dst = s;
         }
@@ -369,14 +368,16 @@ __global__ void __launch_bounds__(256) kc_backward_bank_reduce(BankReduceArgs a)
     else { int q = r - L - L * D; unit = a.edg + (size_t)q * a.E; inv = a.iedg[q]; dst = a.g.edge_attr_support ? a.g.edge_attr_support + (size_t)q * a.E : nullptr; off = (size_t)L * a.F + (size_t)L * D * a.F + (size_t)q * a.E; width = a.E; }
     if (!dst) return;
     for (int f = lane; f < width; f += 64) {
-        float s0 = 0.f, s1 = 0.f;
+        // eight loads in flight per lane; the association order is fixed by the code, not by timing
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* base = a.slab + off + f;
         int c = wave;
-        for (; c + 4 < a.nchunk; c += 8) {
-            s0 += a.slab[(size_t)c * bank_fl + off + f];
-            s1 += a.slab[(size_t)(c + 4) * bank_fl + off + f];
+        for (; c + 28 < a.nchunk; c += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s[u] += base[(size_t)(c + 4 * u) * bank_fl];
         }
-        if (c < a.nchunk) s0 += a.slab[(size_t)c * bank_fl + off + f];
-        part[wave][f] = s0 + s1;
+        for (int u = 0; c < a.nchunk; c += 4, ++u) s[u & 7] += base[(size_t)c * bank_fl];
+        part[wave][f] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
     }
     __syncthreads();
     if (wave != 0) return;

@@ -41,10 +41,12 @@ struct BwdArgs {
     float* contrib; int64_t contrib_base;      // rows base + n*(D+1) + slot
     float* slab; int nchunk;                   // [nchunk, bank_floats]
     const float* padded;                       // unit bank rows, support-major, padded (LDS kernels)
+    float* theta_slab;                         // [blocks][4] score-weight partials (LDS rows kernel)
 };
 
 struct BankReduceArgs {
     const float* slab; int nchunk; int F, E, L;
+    const float* theta_src; size_t theta_stride; int theta_count;   // score-weight partials
     const float* cen; const float* sup; const float* edg;
     const float* icen; const float* isup; const float* iedg;
     mkgnn_kernel_bank_grad g;
@@ -58,7 +60,7 @@ hipError_t launch_backward_generic(int d, const BwdArgs& a, hipStream_t st);
 hipError_t launch_bank_reduce(int d, const BankReduceArgs& r, hipStream_t st);
 // kgnn_bwd.hip: LDS-tiled backward for the model's shapes
 bool lds_backward_supported(int d, int F, int E, int L, int64_t xs, const void* x);
-hipError_t launch_backward_lds(int d, const BwdArgs& a, int* nchunk_out, hipStream_t st);
+hipError_t launch_backward_lds(int d, const BwdArgs& a, int* nchunk_out, int* ntheta_out, hipStream_t st);
 hipError_t launch_backward_gather(const float* contrib, const int32_t* rowptr, const int32_t* rows, const float* x,
                                   int64_t xs, const float* inv, int64_t n, int F, float* gx, int64_t gxs,
                                   hipStream_t st);
