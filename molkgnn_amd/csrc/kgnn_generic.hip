@@ -354,11 +354,21 @@ __global__ void __launch_bounds__(256) kc_backward_bank_reduce(BankReduceArgs a)
     const int nrow = L + 2 * L * D;
     __shared__ float part[4][256];
     if (r == nrow) {
-        if (tid < 3) {
+        // score-weight partials: thread t sums entries t, t+256, ...; then a fixed-order tree over the block
+        for (int k = 0; k < 3; ++k) {
             float s = 0.f;
-            for (int c = 0; c < a.theta_count; ++c) s += a.theta_src[(size_t)c * a.theta_stride + tid];
-            float* dst = tid == 0 ? a.g.support_attr_sc_weight : (tid == 1 ? a.g.center_attr_sc_weight : a.g.edge_attr_support_sc_weight);
-            if (dst) *dst = s;
+            for (int c = tid; c < a.theta_count; c += 256) s += a.theta_src[(size_t)c * a.theta_stride + k];
+            part[0][tid] = s;
+            __syncthreads();
+            for (int w = 128; w > 0; w >>= 1) {
+                if (tid < w) part[0][tid] += part[0][tid + w];
+                __syncthreads();
+            }
+            if (tid == 0) {
+                float* dst = k == 0 ? a.g.support_attr_sc_weight : (k == 1 ? a.g.center_attr_sc_weight : a.g.edge_attr_support_sc_weight);
+                if (dst) *dst = part[0][0];
+            }
+            __syncthreads();
         }
         return;
     }
