@@ -39,8 +39,7 @@ __global__ void __launch_bounds__(256) kc_backward_rows_lds(BwdArgs a) {
     float2* coef = (float2*)(lds + (size_t)(D + 1) * L * FP);       // [TA][L]  {g*ws/(W*D), packed pi}
     int* idbuf = (int*)(coef + (size_t)TA * L);                     // [2][TA] focal atom ids
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int q = tid; q < (D + 1) * L * FP / 4; q += 256)
-        *(f32x4*)(bank + 4 * q) = *(const f32x4*)(a.padded + 4 * q);
+    copy_chunks_to_lds(bank, a.padded, (D + 1) * L * FP / 4, tid, [](int q) { return q; });
     const float w_s = a.mix[0], w_c = a.mix[1], w_e = a.mix[2], w_sum = a.mix[3];
     const float ws_n = w_s / w_sum / (float)D;
     const float ratio_c = w_c * (float)D / w_s;

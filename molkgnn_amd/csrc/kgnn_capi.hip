@@ -101,6 +101,12 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
     char* ws = (char*)workspace;
     hipError_t e = launch_bank_prepare(banks, w, ws, F, E, st);
     if (e != hipSuccess) return hip_fail("bank_prepare", e);
+    // every atom's row is zero outside its own degree block (kernels.py:674-675, 725-727): one
+    // streaming memset, the degree kernels then write only their column blocks
+    if (n_atoms > 0 && K > 0) {
+        e = hipMemset2DAsync(out, (size_t)out_stride * 4, 0, (size_t)K * 4, (size_t)n_atoms, st);
+        if (e != hipSuccess) return hip_fail("output memset", e);
+    }
     int off = 0;
     for (int i = 0; i < 4; ++i) {
         const int d = i + 1;
@@ -120,7 +126,8 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
         a.chir_out = (saved && d == 4 && is_last_layer) ? saved[i].chirality : nullptr;
         bool use_mfma = false;
         if (variant != 1) {
-            use_mfma = mfma_forward_supported(d, F, E, L[i]) && (x_stride % 4 == 0) && (((uintptr_t)x & 15) == 0);
+            use_mfma = mfma_forward_supported(d, F, E, L[i]) && (x_stride % 4 == 0) && (((uintptr_t)x & 15) == 0) &&
+                       ((uint64_t)n_atoms * (uint64_t)x_stride < (1ull << 32));
             if (variant == 2 && !use_mfma && a.n > 0)
                 return fail("%s: MFMA variant does not cover degree %d with F=%d E=%d L=%d stride=%lld", who, d, F, E, L[i],
                             (long long)x_stride);

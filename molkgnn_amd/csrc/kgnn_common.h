@@ -38,6 +38,41 @@ template <> struct PermC<2> { static constexpr int P = 2;  static constexpr int8
 template <> struct PermC<3> { static constexpr int P = 6;  static constexpr int8_t t[6][4] = {{0, 1, 2, 0}, {0, 2, 1, 0}, {1, 0, 2, 0}, {1, 2, 0, 0}, {2, 0, 1, 0}, {2, 1, 0, 0}}; };
 template <> struct PermC<4> { static constexpr int P = 12; static constexpr int8_t t[12][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 0, 3, 2}, {1, 2, 0, 3}, {1, 3, 2, 0}, {2, 0, 1, 3}, {2, 1, 3, 0}, {2, 3, 0, 1}, {3, 0, 2, 1}, {3, 1, 0, 2}, {3, 2, 1, 0}}; };
 
+// x / D, correctly rounded, without the hardware division sequence.  Powers of two are exact
+// multiplies; for 3 the residual correction q + fma(-3, q, x) * (1/3) gives the IEEE quotient.
+template <int D> __device__ __forceinline__ float div_by(float x) {
+    if constexpr (D == 1) return x;
+    else if constexpr (D == 2) return x * 0.5f;
+    else if constexpr (D == 4) return x * 0.25f;
+    else {
+        const float c = 1.0f / 3.0f;
+        const float q = x * c;
+        const float r = fmaf(-3.0f, q, x);
+        return fmaf(r, c, q);
+    }
+}
+
+typedef float mkgnn_f32x4 __attribute__((ext_vector_type(4)));
+
+// Copy `n4` 16-byte chunks global -> LDS with `dst_of(q)` giving the destination chunk index;
+// eight loads in flight per thread (a plain one-at-a-time loop serialises on the load latency).
+template <typename DstOf>
+__device__ __forceinline__ void copy_chunks_to_lds(float* lds_base, const float* src, int n4, int tid, DstOf dst_of) {
+    for (int base = 0; base < n4; base += 256 * 8) {
+        mkgnn_f32x4 tmp[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = base + tid + 256 * k;
+            if (q < n4) tmp[k] = *(const mkgnn_f32x4*)(src + 4 * (size_t)q);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = base + tid + 256 * k;
+            if (q < n4) *(mkgnn_f32x4*)(lds_base + 4 * (size_t)dst_of(q)) = tmp[k];
+        }
+    }
+}
+
 // Best permutation of a d x d cosine matrix: every order scored as
 // ((c0+c1)+c2)+c3 then / d, strict '>' scan in table order.
 template <int D>
@@ -48,7 +83,7 @@ __device__ __forceinline__ void best_permutation(const float (&cm)[D][D], float&
         float s = cm[0][PermC<D>::t[p][0]];
 #pragma unroll
         for (int a = 1; a < D; ++a) s = __fadd_rn(s, cm[a][PermC<D>::t[p][a]]);
-        s = s / (float)D;
+        s = div_by<D>(s);
         if (p == 0 || s > best) { best = s; idx = p; }
     }
 }

@@ -196,7 +196,7 @@ __global__ void __launch_bounds__(256) kc_forward_generic(FwdArgs a) {
                 dt *= ie[i];
                 ed = (i == 0) ? dt : __fadd_rn(ed, dt);
             }
-            ed = ed / (float)D;
+            ed = div_by<D>(ed);
             float sc = __fadd_rn(__fadd_rn(__fmul_rn(best, ws), __fmul_rn(cc, wc)), __fmul_rn(ed, we)) / wsum;
             float ch = 1.f;
             if constexpr (D == 4) {
@@ -213,9 +213,6 @@ __global__ void __launch_bounds__(256) kc_forward_generic(FwdArgs a) {
             }
             if (a.chir_out) a.chir_out[(size_t)n * a.L + l] = (int8_t)ch;
         }
-        // the rest of the atom's output row is zero (kernels.py:674-675, 725-727)
-        for (int k = lane; k < a.K; k += 64)
-            if (k < a.off || k >= a.off + a.L) a.out[focal * a.os + k] = 0.f;
     }
 }
 
