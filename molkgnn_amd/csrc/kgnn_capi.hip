@@ -28,6 +28,76 @@ static int hip_fail(const char* what, hipError_t e) {
     return fail("%s: %s", what, hipGetErrorString(e));
 }
 
+// The four degree buckets are independent.  At the batch sizes a molecule model sees, one bucket
+// does not fill 256 CUs for long (a few atom tiles per SIMD, and prologue/tail dominate), so the
+// per-degree kernels of one call run concurrently on three helper streams forked from and joined
+// back into the caller's stream with events (a fork/join that hipGraph capture records as is).
+// Streams and events are created once per device on first use.
+struct DegreeStreams {
+    hipStream_t aux[3];
+    hipEvent_t fork;
+    hipEvent_t join[3];
+    bool ready;
+};
+static DegreeStreams g_streams[16];
+
+static DegreeStreams* degree_streams() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    DegreeStreams& p = g_streams[dev];
+    if (!p.ready) {
+        for (int i = 0; i < 3; ++i) {
+            if (hipStreamCreateWithFlags(&p.aux[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+            if (hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        }
+        if (hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        p.ready = true;
+    }
+    return &p;
+}
+
+// Stream on which degree slot `i` (0 = most work) runs; slot 0 stays on the caller's stream.
+struct ForkJoin {
+    DegreeStreams* p;
+    hipStream_t main;
+    bool used[3];
+    hipError_t begin(hipStream_t st, bool enable) {
+        main = st; p = enable ? degree_streams() : nullptr;
+        used[0] = used[1] = used[2] = false;
+        if (!p) return hipSuccess;
+        return hipEventRecord(p->fork, main);
+    }
+    hipStream_t stream(int slot, hipError_t* e) {
+        *e = hipSuccess;
+        if (!p || slot == 0) return main;
+        const int i = slot - 1;
+        if (!used[i]) { *e = hipStreamWaitEvent(p->aux[i], p->fork, 0); used[i] = true; }
+        return p->aux[i];
+    }
+    hipError_t end() {
+        if (!p) return hipSuccess;
+        for (int i = 0; i < 3; ++i) {
+            if (!used[i]) continue;
+            hipError_t e = hipEventRecord(p->join[i], p->aux[i]);
+            if (e != hipSuccess) return e;
+            e = hipStreamWaitEvent(main, p->join[i], 0);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
+    }
+};
+
+// degree index (0..3) -> concurrency slot, most expensive bucket first (N_d * L_d * (d*d + 1))
+static void degree_slots(const mkgnn_kernel_bank banks[4], const mkgnn_degree_bucket buckets[4], int slot_of[4]) {
+    double cost[4];
+    int order[4] = {0, 1, 2, 3};
+    for (int i = 0; i < 4; ++i) cost[i] = (double)buckets[i].count * banks[i].num_kernels * ((i + 1) * (i + 1) + 1);
+    for (int a = 0; a < 4; ++a)
+        for (int b = a + 1; b < 4; ++b)
+            if (cost[order[b]] > cost[order[a]]) { int t = order[a]; order[a] = order[b]; order[b] = t; }
+    for (int r = 0; r < 4; ++r) slot_of[order[r]] = r;
+}
+
 extern "C" {
 
 int mkgnn_abi_version(void) { return MKGNN_ABI_VERSION; }
@@ -107,9 +177,16 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
         e = hipMemset2DAsync(out, (size_t)out_stride * 4, 0, (size_t)K * 4, (size_t)n_atoms, st);
         if (e != hipSuccess) return hip_fail("output memset", e);
     }
+    int slot_of[4];
+    degree_slots(banks, buckets, slot_of);
+    ForkJoin fj;
+    e = fj.begin(st, true);
+    if (e != hipSuccess) return hip_fail("stream fork", e);
     int off = 0;
     for (int i = 0; i < 4; ++i) {
         const int d = i + 1;
+        hipStream_t dst = fj.stream(slot_of[i], &e);
+        if (e != hipSuccess) return hip_fail("stream fork", e);
         FwdArgs a;
         a.x = x; a.xs = x_stride; a.inv = inv_norm;
         a.sel = buckets[i].selected_index; a.nei = buckets[i].nei_index; a.e_nei = buckets[i].nei_edge_attr;
@@ -132,10 +209,12 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
                 return fail("%s: MFMA variant does not cover degree %d with F=%d E=%d L=%d stride=%lld", who, d, F, E, L[i],
                             (long long)x_stride);
         }
-        e = use_mfma ? launch_forward_mfma(d, a, st) : launch_forward_generic(d, a, st);
+        e = use_mfma ? launch_forward_mfma(d, a, dst) : launch_forward_generic(d, a, dst);
         if (e != hipSuccess) return hip_fail("kernelconv forward launch", e);
         off += L[i];
     }
+    e = fj.end();
+    if (e != hipSuccess) return hip_fail("stream join", e);
     return 0;
 }
 
@@ -163,10 +242,17 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
     char* ws = (char*)workspace;
     hipError_t e = launch_bank_prepare(banks, w, ws, F, E, st);
     if (e != hipSuccess) return hip_fail("bank_prepare", e);
+    int slot_of[4];
+    degree_slots(banks, buckets, slot_of);
+    ForkJoin fj;
+    e = fj.begin(st, true);
+    if (e != hipSuccess) return hip_fail("stream fork", e);
     int off = 0;
     int64_t base = 0;
     for (int i = 0; i < 4; ++i) {
         const int d = i + 1;
+        hipStream_t dst = fj.stream(slot_of[i], &e);
+        if (e != hipSuccess) return hip_fail("stream fork", e);
         if (buckets[i].count > 0 && (!saved[i].best_index || !saved[i].scores))
             return fail("%s: degree %d has no saved forward state", who, d);
         BwdArgs a;
@@ -189,8 +275,8 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         int nchunk = a.n > 0 ? a.nchunk : 0;
         int ntheta = -1;
         if (a.n > 0 && L[i] > 0) {
-            if (lds_backward_supported(d, F, E, L[i], x_stride, x)) e = launch_backward_lds(d, a, &nchunk, &ntheta, st);
-            else e = launch_backward_generic(d, a, st);
+            if (lds_backward_supported(d, F, E, L[i], x_stride, x)) e = launch_backward_lds(d, a, &nchunk, &ntheta, dst);
+            else e = launch_backward_generic(d, a, dst);
             if (e != hipSuccess) return hip_fail("kernelconv backward launch", e);
         }
         BankReduceArgs r;
@@ -204,11 +290,13 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         r.icen = (const float*)(ws + w.bank[i].icen); r.isup = (const float*)(ws + w.bank[i].isup);
         r.iedg = (const float*)(ws + w.bank[i].iedg);
         r.g = grads[i];
-        e = launch_bank_reduce(d, r, st);
+        e = launch_bank_reduce(d, r, dst);
         if (e != hipSuccess) return hip_fail("bank gradient reduce launch", e);
         off += L[i];
         base += a.n * (d + 1);
     }
+    e = fj.end();
+    if (e != hipSuccess) return hip_fail("stream join", e);
     if (grad_x) {
         e = launch_backward_gather((const float*)(ws + w.contrib), scatter_rowptr, scatter_rows, x, x_stride, inv_norm,
                                    n_atoms, F, grad_x, grad_x_stride, st);

@@ -320,7 +320,7 @@ static hipError_t launch_one(const FwdArgs& a, hipStream_t st) {
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 5) per_cu = 5;
     // few atom tiles: let the column tiles of one atom tile run on different waves
-    if (ntiles < 1536) g.cs = g.nct;
+    if (ntiles < 768) g.cs = g.nct;
     int64_t blocks = 256 * per_cu;
     const int64_t need = (ntiles * g.cs + 3) / 4;
     if (blocks > need) blocks = need;
