@@ -6,12 +6,6 @@
 
 #include "kgnn_launch.h"
 
-namespace mkgnn {
-// kgnn_mfma.hip
-bool mfma_forward_supported(int d, int F, int E, int L);
-hipError_t launch_forward_mfma(int d, const FwdArgs& a, hipStream_t st);
-}  // namespace mkgnn
-
 using namespace mkgnn;
 
 static thread_local char g_err[512] = "";
@@ -164,8 +158,8 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
     for (int i = 0; i < 4; ++i) { L[i] = banks[i].num_kernels; K += L[i]; }
     if (out_stride < K || (n_atoms && !out)) return fail("%s: bad out (stride %lld, K %d)", who, (long long)out_stride, K);
     WorkspaceLayout w = make_layout(L, F, E, n_atoms, n_edges);
-    if (workspace_bytes < w.bank[3].end || !workspace)
-        return fail("%s: workspace of %zu bytes, need %zu", who, workspace_bytes, w.bank[3].end);
+    if (workspace_bytes < w.fwd_end || !workspace)
+        return fail("%s: workspace of %zu bytes, need %zu", who, workspace_bytes, w.fwd_end);
     if (variant < 0 || variant > 2) return fail("%s: variant %d", who, variant);
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
@@ -177,16 +171,18 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
         e = hipMemset2DAsync(out, (size_t)out_stride * 4, 0, (size_t)K * 4, (size_t)n_atoms, st);
         if (e != hipSuccess) return hip_fail("output memset", e);
     }
-    int slot_of[4];
-    degree_slots(banks, buckets, slot_of);
-    ForkJoin fj;
-    e = fj.begin(st, true);
-    if (e != hipSuccess) return hip_fail("stream fork", e);
+    // the fused MFMA launch takes every degree whose shape it covers; the rest run on the generic kernels
+    const bool aligned = (x_stride % 4 == 0) && (((uintptr_t)x & 15) == 0) &&
+                         ((uint64_t)n_atoms * (uint64_t)x_stride < (1ull << 32));
+    FusedFwdArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    fa.x = x; fa.xs = x_stride; fa.inv = inv_norm; fa.out = out; fa.os = out_stride;
+    fa.K = K; fa.F = F; fa.E = E; fa.last = is_last_layer ? 1 : 0;
+    bool use[4] = {false, false, false, false};
+    bool any_fused = false;
     int off = 0;
     for (int i = 0; i < 4; ++i) {
         const int d = i + 1;
-        hipStream_t dst = fj.stream(slot_of[i], &e);
-        if (e != hipSuccess) return hip_fail("stream fork", e);
         FwdArgs a;
         a.x = x; a.xs = x_stride; a.inv = inv_norm;
         a.sel = buckets[i].selected_index; a.nei = buckets[i].nei_index; a.e_nei = buckets[i].nei_edge_attr;
@@ -201,20 +197,30 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
         a.best = saved ? saved[i].best_index : nullptr;
         a.scores = saved ? saved[i].scores : nullptr;
         a.chir_out = (saved && d == 4 && is_last_layer) ? saved[i].chirality : nullptr;
-        bool use_mfma = false;
-        if (variant != 1) {
-            use_mfma = mfma_forward_supported(d, F, E, L[i]) && (x_stride % 4 == 0) && (((uintptr_t)x & 15) == 0) &&
-                       ((uint64_t)n_atoms * (uint64_t)x_stride < (1ull << 32));
-            if (variant == 2 && !use_mfma && a.n > 0)
-                return fail("%s: MFMA variant does not cover degree %d with F=%d E=%d L=%d stride=%lld", who, d, F, E, L[i],
-                            (long long)x_stride);
-        }
-        e = use_mfma ? launch_forward_mfma(d, a, dst) : launch_forward_generic(d, a, dst);
-        if (e != hipSuccess) return hip_fail("kernelconv forward launch", e);
         off += L[i];
+        if (a.n == 0 || a.L == 0) continue;
+        const bool can_fuse = variant != 1 && aligned && mfma_forward_supported(d, F, E, L[i]);
+        if (variant == 2 && !can_fuse)
+            return fail("%s: MFMA variant does not cover degree %d with F=%d E=%d L=%d stride=%lld", who, d, F, E, L[i],
+                        (long long)x_stride);
+        if (can_fuse) {
+            FusedDeg& g = fa.deg[i];
+            g.sel = a.sel; g.nei = a.nei; g.e_nei = a.e_nei; g.p_focal = a.p_focal; g.p_nei = a.p_nei;
+            g.padded = a.padded; g.edge_padded = a.edge_padded; g.chir = a.chir; g.mix = a.mix;
+            g.eqflag = (const int8_t*)(ws + w.eqflag);
+            g.best = a.best; g.scores = a.scores; g.chir_out = a.chir_out;
+            g.n = a.n; g.L = a.L; g.off = a.off;
+            use[i] = true;
+            any_fused = true;
+        } else {
+            e = launch_forward_generic(d, a, st);
+            if (e != hipSuccess) return hip_fail("kernelconv forward launch", e);
+        }
     }
-    e = fj.end();
-    if (e != hipSuccess) return hip_fail("stream join", e);
+    if (any_fused) {
+        e = launch_forward_fused(fa, use, st);
+        if (e != hipSuccess) return hip_fail("fused kernelconv forward launch", e);
+    }
     return 0;
 }
 

@@ -131,11 +131,13 @@ __host__ __device__ static inline int mfma_padded_width(int F) { return F <= 32 
 
 struct WorkspaceLayout {
     BankLayout bank[MKGNN_MAX_DEGREE];
+    size_t eqflag;        // [N] int8: degree-4 atom has two identical neighbour rows (last layer)
     size_t contrib;       // [sum_d N_d (d+1), F] per-slot gradient rows (backward)
     size_t slab;          // partial bank gradients, per degree [nblk, bank floats]
     size_t slab_bytes_per_degree[MKGNN_MAX_DEGREE];
     size_t slab_off[MKGNN_MAX_DEGREE];
     size_t theta_off[MKGNN_MAX_DEGREE];
+    size_t fwd_end;       // the forward needs [0, fwd_end)
     size_t total;
 };
 
@@ -170,6 +172,9 @@ static inline WorkspaceLayout make_layout(const int32_t L[MKGNN_MAX_DEGREE], int
         b.edge_padded = off; off = align_up(off + (size_t)d * l * 8 * 4);
         b.end = off;
     }
+    w.eqflag = off;
+    off = align_up(off + (size_t)n_atoms);
+    w.fwd_end = off;
     w.contrib = off;
     off = align_up(off + (size_t)(n_atoms + n_edges) * F * 4);
     w.slab = off;

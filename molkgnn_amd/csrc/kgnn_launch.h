@@ -31,6 +31,34 @@ struct FwdArgs {
     int64_t n_atoms;
 };
 
+// One launch for all degree buckets (kgnn_mfma.hip).
+constexpr int FUSED_MAX_BLOCKS = 512;       // 2 blocks per CU
+constexpr int FUSED_MAX_GROUPS = 16;        // (degree, column part)
+
+struct FusedDeg {
+    const int64_t* sel; const int64_t* nei; const float* e_nei; const float* p_focal; const float* p_nei;
+    const float* padded; const float* edge_padded; const int8_t* chir; const float* mix; const int8_t* eqflag;
+    uint8_t* best; float* scores; int8_t* chir_out;
+    int64_t n;
+    int L, off;
+    int nct;        // column tiles (<= 16 kernels each)
+    int kpt;        // kernels per column tile
+    int cs;         // column split: part cp takes the column tiles cp, cp + cs, ...
+    int nloc;       // column tiles per block = ceil(nct / cs)  (<= 2; 1 for degree 4)
+};
+
+struct FusedFwdArgs {
+    const float* x; int64_t xs; const float* inv;
+    float* out; int64_t os;
+    int K, F, E, last;
+    FusedDeg deg[MKGNN_MAX_DEGREE];
+    uint8_t grp_degree[FUSED_MAX_GROUPS];   // group -> degree index (0..3)
+    uint8_t grp_cp[FUSED_MAX_GROUPS];       // group -> column part
+    uint16_t grp_count[FUSED_MAX_GROUPS];   // blocks in the group
+    uint8_t blk_group[FUSED_MAX_BLOCKS];    // block -> group
+    uint16_t blk_rank[FUSED_MAX_BLOCKS];    // block -> rank inside its group
+};
+
 struct BwdArgs {
     const float* x; int64_t xs; const float* inv;
     const int64_t* sel; const int64_t* nei; const float* e_nei;
@@ -56,6 +84,8 @@ hipError_t launch_row_inv_norm(const float* x, int64_t stride, int64_t n, int F,
 hipError_t launch_bank_prepare(const mkgnn_kernel_bank banks[4], const WorkspaceLayout& w, char* ws, int F, int E,
                                hipStream_t st);
 hipError_t launch_forward_generic(int d, const FwdArgs& a, hipStream_t st);
+bool mfma_forward_supported(int d, int F, int E, int L);
+hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t st);
 hipError_t launch_backward_generic(int d, const BwdArgs& a, hipStream_t st);
 hipError_t launch_bank_reduce(int d, const BankReduceArgs& r, hipStream_t st);
 // kgnn_bwd.hip: LDS-tiled backward for the model's shapes

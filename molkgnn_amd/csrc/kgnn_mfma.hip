@@ -1,4 +1,5 @@
-// MFMA forward of the kernel convolution (gfx950, exact-fp32 v_mfma_f32_16x16x4_f32).
+// Fused MFMA forward of the kernel convolution: ONE launch computes a whole KernelSetConv
+// forward (all four degree buckets) on gfx950 with the exact-fp32 v_mfma_f32_16x16x4_f32.
 //
 // Why MFMA at all: per atom the N-hop layers do ~40 kflop against ~0.95 KB of compulsory
 // traffic -- above the fp32 ridge, so the d x d cosine matrices are the cost,
@@ -9,18 +10,22 @@
 // Tiling ("slot-major"): one MFMA tile = 16 atoms (rows) x 16 kernels (columns) for ONE
 // (a, b) pair, so after the K loop every lane holds, for its kernel (lane & 15) and its four
 // atoms ((lane >> 4) * 4 + j), the complete d x d matrix, the centre dot product and (later)
-// the edge matrix IN REGISTERS: the permutation maximum needs no cross-lane traffic.
+// the bond-cosine matrix IN REGISTERS: the permutation maximum needs no cross-lane traffic.
 //
-// Structure ("wave-autonomous"): the unit-normalised kernel bank of the degree sits in LDS,
-// loaded once per block; after that there is NO block-level synchronisation.  Every wave walks
-// its own 16-atom tiles: it gathers the A fragments of its atoms' feature rows (focal + d
-// neighbours, CSR order) straight from global memory into registers -- lane (row i, k-quarter q)
-// loads the 16-byte chunks 4t + q of row i, which is exactly the MFMA A-operand layout -- keeps
-// them for all column tiles, and writes its atoms' full output rows.  Gather latency is hidden by
-// the other waves of the CU (2-5 waves per SIMD for d <= 3; for d = 4 a tile carries ~60 k MFMA
-// cycles, so the one-wave-per-SIMD exposure is a few percent) and by loading the next tile's atom
-// ids while the current tile is multiplied.  Rows stay RAW (the chirality test compares raw rows
-// bit for bit); 1/|x| multiplies the dot products.  The bank's 16-byte LDS chunks are
+// Work split.  A block belongs to one (degree, column part) group and keeps only ITS share of the
+// unit-normalised kernel bank in LDS (<= 57 KB, so two blocks and 2 waves per SIMD fit on a CU
+// whatever the degree).  The host sizes the groups in proportion to their MFMA work and
+// interleaves them over the block ids, so every CU carries a mix of degrees and all buckets
+// start -- and finish -- together.  Inside a block there is no synchronisation after the bank
+// copy: every wave walks its own 16-atom tiles.
+//
+// Slot-pipelined gather.  A wave needs the rows of slot s (neighbour s of its 16 atoms; the focal
+// row is slot d) only while it multiplies slot s.  It therefore holds just two slots of A
+// fragments: while slot s is multiplied (d * 28 * nloc MFMAs), the 16-byte chunks 4t + kq of
+// slot s+1 -- or of the next tile's slot 0 -- are already in flight straight from global memory
+// into the other register set (lane (row i, k-quarter kq) loads exactly its MFMA A operand).
+// The gather is thus hidden behind the matrix pipe inside each wave, at 56 VGPRs.
+// Rows stay RAW; 1/|x| multiplies the dot products.  The bank's 16-byte LDS chunks are
 // XOR-swizzled so the ds_read_b128 fragment reads are conflict-free (brute-forced against the
 // lane groups of MI355X_MICROARCH.md, LDS section).
 #include "kgnn_launch.h"
@@ -28,6 +33,14 @@
 namespace mkgnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Diagnostic time stamps (tools/stamp_probe.py): per wave {start, bank ready, then per tile
+// start / multiplied / stored}.  Null in normal runs.
+__device__ unsigned long long* g_stamp_buffer = nullptr;
+#define MKGNN_STAMP(slot)                                                                      \
+    do {                                                                                       \
+        if (stamps && lane == 0 && (slot) < 32) stamps[(slot)] = __builtin_readcyclecounter(); \
+    } while (0)
 
 template <int KC> __device__ __forceinline__ int swz(int pos) {
     if constexpr (KC == 7) {                // 112-float rows: rows 4 apart share banks
@@ -37,123 +50,158 @@ template <int KC> __device__ __forceinline__ int swz(int pos) {
     }
 }
 
-struct MfmaGeom {
-    int nct;        // column tiles (<= 16 kernels each)
-    int kpt;        // kernels per column tile
-    int cs;         // waves that share one atom tile, each taking every cs-th column tile
-};
+template <int D> struct BodyTraits { static constexpr int NL = (D == 4) ? 1 : 2; };
 
-__host__ __device__ static inline MfmaGeom mfma_geom(int L) {
-    MfmaGeom g;
-    g.nct = (L + 15) / 16;
-    g.kpt = (L + g.nct - 1) / g.nct;       // balanced: 10, 10, 15, 13 kernels for L = 10, 20, 30, 50
-    g.cs = 1;
-    return g;
-}
-
-// LDS carve (floats).  Everything is a multiple of 4 floats.
-struct MfmaLds {
-    int bank, esup, chirtab, total;
-};
-
-__host__ __device__ static inline MfmaLds mfma_lds(int D, int KC, int L) {
-    const int FP = 16 * KC;
-    MfmaLds o;
-    int off = 0;
-    o.bank = off;    off += (D + 1) * L * FP;
-    o.esup = off;    off += D * L * 8;
-    o.chirtab = off; off += (L * 12 + 15) / 16 * 4;   // int8 table, rounded to 16 bytes
-    o.total = off;
-    return o;
+// LDS floats a (degree, column part) block needs.
+__host__ __device__ static inline int fused_lds_floats(int D, int KC, int L, int nloc, int kpt) {
+    const int srow = nloc * kpt;
+    return (D + 1) * srow * 16 * KC + D * srow * 8 + ((D == 4 ? L * 12 : 0) + 15) / 16 * 4;
 }
 
 template <int D, int KC>
-__global__ void __launch_bounds__(256, (D == 4 ? 1 : 2)) kc_forward_mfma(FwdArgs a, MfmaGeom g) {
+__device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedDeg& dg, const int cp, const int rank,
+                                             const int count, float* lds) {
     constexpr int FP = 16 * KC;
     constexpr int CH = 4 * KC;                       // 16-byte chunks per row
     constexpr int NW = 4;                            // waves per block
-    extern __shared__ __align__(16) float lds[];
-    const int L = a.L;
-    const MfmaLds o = mfma_lds(D, KC, L);
-    float* bank = lds + o.bank;
-    float* esup = lds + o.esup;
-    int8_t* chirtab = (int8_t*)(lds + o.chirtab);
+    constexpr int NL = BodyTraits<D>::NL;            // column tiles per block (static bound)
+    const int L = dg.L, kpt = dg.kpt, cs = dg.cs, nloc = dg.nloc, nct = dg.nct;
+    const int SROW = nloc * kpt;                     // bank rows per slot in this block
+    float* bank = lds;                               // [(D+1)][SROW][FP], slot D = centre rows
+    float* esup = bank + (size_t)(D + 1) * SROW * FP;   // [D][SROW][8]
+    int8_t* chirtab = (int8_t*)(esup + (size_t)D * SROW * 8);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const bool do_chir = (D == 4) && a.last;
+    unsigned long long* stamps = g_stamp_buffer ? g_stamp_buffer + ((size_t)blockIdx.x * NW + wave) * 32 : nullptr;
+    int stamp_slot = 2;
+    MKGNN_STAMP(0);
 
-    // ---- one-time: kernel bank -> LDS (swizzled by position inside its column tile)
-    copy_chunks_to_lds(bank, a.padded, (D + 1) * L * CH, tid, [&](int q) {
-        const int row = q / CH, c = q - row * CH;
-        return row * CH + (c ^ swz<KC>((row % L) % g.kpt));
-    });
-    copy_chunks_to_lds(esup, a.edge_padded, D * L * 2, tid, [](int q) { return q; });
-    if (do_chir)
-        for (int q = tid; q < L * 12; q += 256) chirtab[q] = a.chir[q];
-    __syncthreads();
-
-    const float ws = a.mix[0], wc = a.mix[1], we = a.mix[2], wsum = a.mix[3];
     const int ci = lane & 15, kq = lane >> 4;
-    const int64_t ntiles = (a.n + 15) / 16;
-    // work unit = (atom tile, column part); units are dealt across blocks first so that a small
-    // bucket still spreads over every CU
-    const int64_t nunits = ntiles * g.cs;
-    const int64_t ustride = (int64_t)gridDim.x * NW;
-    int64_t unit = blockIdx.x + (int64_t)gridDim.x * wave;
+    const int64_t ntiles = (dg.n + 15) / 16;
+    const int64_t tstride = (int64_t)count * NW;
+    int64_t tile = (int64_t)rank * NW + wave;
     const uint32_t xs = (uint32_t)a.xs;
 
-    // atom ids of this lane's row (slots 0..D-1 neighbours, slot D focal), one tile ahead
-    uint32_t ids[D + 1];
-    auto load_ids = [&](int64_t u) {
-        int64_t n = (u / g.cs) * 16 + ci;
-        if (n >= a.n) n = a.n - 1;
+    uint32_t ids[D + 1];                             // this tile: slots 0..D-1 neighbours, slot D focal
+    auto load_ids = [&](int64_t t, uint32_t (&dst)[D + 1]) {
+        int64_t n = t * 16 + ci;
+        if (n >= dg.n) n = dg.n - 1;
 #pragma unroll
-        for (int s = 0; s < D; ++s) ids[s] = (uint32_t)a.nei[n * D + s];
-        ids[D] = (uint32_t)a.sel[n];
+        for (int s = 0; s < D; ++s) dst[s] = (uint32_t)dg.nei[n * D + s];
+        dst[D] = (uint32_t)dg.sel[n];
     };
-    if (unit < nunits) load_ids(unit);
+    bool have = tile < ntiles;
+    if (have) load_ids(tile, ids);
 
-    for (; unit < nunits; unit += ustride) {
-        const int64_t tile = unit / g.cs;
-        const int cpart = (int)(unit - tile * g.cs);
-        int64_t nrow = tile * 16 + ci;
-        if (nrow >= a.n) nrow = a.n - 1;
-        // ---- gather the A fragments: rows of (atom ci, slot s), chunks 4t + kq
-        f32x4 af[D + 1][KC];
-        float inv[D + 1];
+    // ---- one-time: this block's kernel rows -> LDS (chunks swizzled by the row's place in its tile)
+    for (int base = 0; base < (D + 1) * SROW * CH; base += 256 * 8) {
+        f32x4 tmp[8];
 #pragma unroll
-        for (int s = 0; s <= D; ++s) {
-            const float* row = a.x + (ids[s] * xs + 4u * kq);      // 32-bit offset (host checks N * stride < 2^32)
-#pragma unroll
-            for (int t = 0; t < KC - 1; ++t) af[s][t] = *(const f32x4*)(row + 16 * t);
-            {   // only the last chunk can reach beyond the row's width (host guarantees FP - 16 < F <= FP)
-                const int f0 = 16 * (KC - 1) + 4 * kq;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (f0 < a.F) {
-                    v = *(const f32x4*)(row + 16 * (KC - 1));
-                    if (f0 + 1 >= a.F) v.y = 0.f;
-                    if (f0 + 2 >= a.F) v.z = 0.f;
-                    if (f0 + 3 >= a.F) v.w = 0.f;
-                }
-                af[s][KC - 1] = v;
+        for (int k = 0; k < 8; ++k) {
+            const int q = base + tid + 256 * k;
+            tmp[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (q < (D + 1) * SROW * CH) {
+                const int row = q / CH, c = q - row * CH;
+                const int s = row / SROW, jr = row - s * SROW;
+                const int j = jr / kpt, r = jr - j * kpt;
+                const int l = (cp + j * cs) * kpt + r;
+                if (l < L && cp + j * cs < nct) tmp[k] = *(const f32x4*)(dg.padded + ((size_t)s * L + l) * FP + 4 * c);
             }
-            inv[s] = a.inv[ids[s]];
         }
-        // unit bond vectors: lane holds components 2kq, 2kq+1 of (atom ci, slot s)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = base + tid + 256 * k;
+            if (q < (D + 1) * SROW * CH) {
+                const int row = q / CH, c = q - row * CH;
+                const int r = (row % SROW) % kpt;
+                *(f32x4*)(bank + (size_t)row * FP + 4 * (c ^ swz<KC>(r))) = tmp[k];
+            }
+        }
+    }
+    for (int q = tid; q < D * SROW * 2; q += 256) {
+        const int row = q >> 1, h = q & 1;
+        const int s = row / SROW, jr = row - s * SROW;
+        const int j = jr / kpt, r = jr - j * kpt;
+        const int l = (cp + j * cs) * kpt + r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (l < L && cp + j * cs < nct) v = *(const f32x4*)(dg.edge_padded + ((size_t)s * L + l) * 8 + 4 * h);
+        *(f32x4*)(esup + (size_t)row * 8 + 4 * h) = v;
+    }
+    if constexpr (D == 4) {
+        if (do_chir)
+            for (int q = tid; q < L * 12; q += 256) chirtab[q] = dg.chir[q];
+    }
+    __syncthreads();
+    MKGNN_STAMP(1);
+    if (!have) return;
+
+    const float ws = dg.mix[0], wc = dg.mix[1], we = dg.mix[2], wsum = dg.mix[3];
+
+    // ---- pipeline registers
+    f32x4 nxt[KC];                                   // rows of the slot in flight
+    float inv_nxt = 0.f;
+    float2 eraw[D];                                  // bond components 2kq, 2kq+1 of (atom ci, slot s)
+    float pvec[(D == 4) ? 15 : 1];
+    int eq_raw = 0;
+    auto issue_small = [&](int64_t t) {
+        int64_t nrow = t * 16 + ci;
+        if (nrow >= dg.n) nrow = dg.n - 1;
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            const float* e = dg.e_nei + (nrow * D + s) * a.E;
+            eraw[s].x = 2 * kq < a.E ? e[2 * kq] : 0.f;
+            eraw[s].y = 2 * kq + 1 < a.E ? e[2 * kq + 1] : 0.f;
+        }
+        if constexpr (D == 4) {
+            if (do_chir) {
+#pragma unroll
+                for (int k = 0; k < 12; ++k) pvec[k] = dg.p_nei[nrow * 12 + k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) pvec[12 + k] = dg.p_focal[nrow * 3 + k];
+                eq_raw = dg.eqflag[nrow];
+            }
+        }
+    };
+    auto issue_slot = [&](uint32_t id) {
+        const float* row = a.x + (id * xs + 4u * kq);            // 32-bit offset (host checks N * stride < 2^32)
+#pragma unroll
+        for (int t = 0; t < KC - 1; ++t) nxt[t] = *(const f32x4*)(row + 16 * t);
+        {   // only the last chunk can reach beyond the row's width (host guarantees FP - 16 < F <= FP)
+            const int f0 = 16 * (KC - 1) + 4 * kq;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (f0 < a.F) {
+                v = *(const f32x4*)(row + 16 * (KC - 1));
+                if (f0 + 1 >= a.F) v.y = 0.f;
+                if (f0 + 2 >= a.F) v.z = 0.f;
+                if (f0 + 3 >= a.F) v.w = 0.f;
+            }
+            nxt[KC - 1] = v;
+        }
+        inv_nxt = a.inv[id];
+    };
+    issue_small(tile);
+    issue_slot(ids[0]);
+
+    for (;;) {
+        MKGNN_STAMP(stamp_slot);
+        const int64_t nxt_tile = tile + tstride;
+        const bool have_next = nxt_tile < ntiles;
+        uint32_t ids_n[D + 1];
+#pragma unroll
+        for (int s = 0; s <= D; ++s) ids_n[s] = 0;
+        if (have_next) load_ids(nxt_tile, ids_n);
+        // ---- per-tile small values (their loads were issued ahead of the rows)
         float2 eu[D];
 #pragma unroll
         for (int s = 0; s < D; ++s) {
-            const float* e = a.e_nei + (nrow * D + s) * a.E;
-            const float e0 = 2 * kq < a.E ? e[2 * kq] : 0.f;
-            const float e1 = 2 * kq + 1 < a.E ? e[2 * kq + 1] : 0.f;
-            float s2 = fmaf(e1, e1, e0 * e0);
+            float s2 = fmaf(eraw[s].y, eraw[s].y, eraw[s].x * eraw[s].x);
             s2 += __shfl_xor(s2, 16, 64);
             s2 += __shfl_xor(s2, 32, 64);
             const float ie = 1.f / fmaxf(sqrtf(s2), MKGNN_EPS);
-            eu[s] = float2{e0 * ie, e1 * ie};
+            eu[s] = float2{eraw[s].x * ie, eraw[s].y * ie};
         }
-        // chirality, atom side (kernels.py:305-337)
         float sign_row = 0.f;
         int eq_row = 0;
         if constexpr (D == 4) {
@@ -162,189 +210,291 @@ __global__ void __launch_bounds__(256, (D == 4 ? 1 : 2)) kc_forward_mfma(FwdArgs
 #pragma unroll
                 for (int j = 0; j < 3; ++j)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        t3[j][c] = __fsub_rn(a.p_nei[(nrow * 4 + j) * 3 + c], a.p_focal[nrow * 3 + c]);
+                    for (int c = 0; c < 3; ++c) t3[j][c] = __fsub_rn(pvec[3 * j + c], pvec[12 + c]);
                 sign_row = triple_sign(t3[0], t3[1], t3[2]);
-                // any two of the four neighbour rows bit-identical -> not chiral (:310-317)
-                int diff = 0;     // bit k: pair k differs in this lane's chunks
-                int k = 0;
+                eq_row = eq_raw;
+            }
+        }
+        const uint32_t focal_row = ids[D];
+        float inv_keep[D + 1];
+
+        // ---- accumulate slot by slot; slot s+1 (or the next tile's slot 0) is in flight meanwhile
+        f32x4 cm[NL][D][D];
+        f32x4 cc[NL];
+        const int rloc = ci < kpt ? ci : kpt - 1;              // padded lanes re-read the tile's last row
+        const int swb = swz<KC>(rloc);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+        for (int s = 0; s <= D; ++s) {
+            f32x4 cur[KC];
 #pragma unroll
-                    for (int j = i + 1; j < 4; ++j, ++k) {
-                        bool same = true;
+            for (int t = 0; t < KC; ++t) cur[t] = nxt[t];
+            inv_keep[s] = inv_nxt;
+            if (s < D) {
+                issue_slot(ids[s + 1 <= D ? s + 1 : D]);
+            } else if (have_next) {
+                issue_small(nxt_tile);
+                issue_slot(ids_n[0]);
+            }
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                if (j < nloc) {
+                    const float* brow = bank + (size_t)(j * kpt + rloc) * FP;
+                    if (s < D) {
+                        constexpr int dummy = 0;
+                        (void)dummy;
+                        const int si = s < D ? s : 0;
+#pragma unroll
+                        for (int b = 0; b < D; ++b) cm[j][si][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int t = 0; t < KC; ++t) {
-                            const f32x4 u = af[i][t], w = af[j][t];
-                            same = same && (u.x == w.x) && (u.y == w.y) && (u.z == w.z) && (u.w == w.w);
+                            const int c = 4 * t + kq;
+                            f32x4 bf[D];
+#pragma unroll
+                            for (int b = 0; b < D; ++b) bf[b] = *(const f32x4*)(brow + (size_t)b * SROW * FP + 4 * (c ^ swb));
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                                for (int b = 0; b < D; ++b)
+                                    cm[j][si][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[t][q4], bf[b][q4], cm[j][si][b], 0, 0, 0);
                         }
-                        if (!same) diff |= 1 << k;
-                    }
-                diff |= __shfl_xor(diff, 16, 64);
-                diff |= __shfl_xor(diff, 32, 64);
-                eq_row = (diff != 0x3F);
-            }
-        }
-        // next tile's ids travel while this tile is multiplied
-        const uint32_t focal_row = ids[D];
-        if (unit + ustride < nunits) load_ids(unit + ustride);
-        // ---- values per accumulator row: atom kq*4 + jj of the tile
-        float inv4[D + 1][4];
-        uint32_t focal4[4];
-        float sign4[4];
-        int eq4[4];
+                    } else {
+                        cc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int src = kq * 4 + jj;
+                        for (int t = 0; t < KC; ++t) {
+                            const int c = 4 * t + kq;
+                            const f32x4 bc = *(const f32x4*)(brow + (size_t)D * SROW * FP + 4 * (c ^ swb));
 #pragma unroll
-            for (int s = 0; s <= D; ++s) inv4[s][jj] = __shfl(inv[s], src, 64);
-            focal4[jj] = (uint32_t)__shfl((int)focal_row, src, 64);
-            sign4[jj] = 0.f;
-            eq4[jj] = 0;
-            if constexpr (D == 4) {
-                sign4[jj] = __shfl(sign_row, src, 64);
-                eq4[jj] = __shfl(eq_row, src, 64);
-            }
-        }
-        // ---- column tiles
-        for (int ct = cpart; ct < g.nct; ct += g.cs) {
-            const int lcol = ct * g.kpt + ci;
-            const bool col_ok = (ci < g.kpt) && (lcol < L);
-            const int lrow = col_ok ? lcol : L - 1;
-            const int swb = swz<KC>(lrow % g.kpt);
-            const float* brow = bank + (size_t)lrow * FP;
-            f32x4 cm[D][D];
-            f32x4 cc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < D; ++i)
-#pragma unroll
-                for (int j = 0; j < D; ++j) cm[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int t = 0; t < KC; ++t) {
-                const int c = 4 * t + kq;
-                f32x4 bf[D + 1];
-#pragma unroll
-                for (int s = 0; s <= D; ++s) bf[s] = *(const f32x4*)(brow + (size_t)s * L * FP + 4 * (c ^ swb));
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-#pragma unroll
-                    for (int i = 0; i < D; ++i)
-#pragma unroll
-                        for (int b = 0; b < D; ++b)
-                            cm[i][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][t][j], bf[b][j], cm[i][b], 0, 0, 0);
-                    cc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[D][t][j], bf[D][j], cc, 0, 0, 0);
-                }
-            }
-            // ---- epilogue: lane = kernel lcol, atoms kq*4 + jj
-            int idx4[4];
-            float best4[4], cen4[4];
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                float m[D][D];
-#pragma unroll
-                for (int s = 0; s < D; ++s)
-#pragma unroll
-                    for (int b = 0; b < D; ++b) m[s][b] = cm[s][b][jj] * inv4[s][jj];
-                best_permutation<D>(m, best4[jj], idx4[jj]);
-                cen4[jj] = cc[jj] * inv4[D][jj];
-            }
-            // bond-cosine matrices, one (a, b) tile at a time; keep the entry the chosen order uses
-            float ed4[4][D];
-            {
-                const float* eb = esup + (size_t)lrow * 8 + 2 * kq;
-#pragma unroll
-                for (int s = 0; s < D; ++s) {
-#pragma unroll
-                    for (int b = 0; b < D; ++b) {
-                        const float2 bv = *(const float2*)(eb + (size_t)b * L * 8);
-                        f32x4 dm = {0.f, 0.f, 0.f, 0.f};
-                        dm = __builtin_amdgcn_mfma_f32_16x16x4f32(eu[s].x, bv.x, dm, 0, 0, 0);
-                        dm = __builtin_amdgcn_mfma_f32_16x16x4f32(eu[s].y, bv.y, dm, 0, 0, 0);
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj)
-                            if (b == 0 || perm_at<D>(idx4[jj], s) == b) ed4[jj][s] = dm[jj];
+                            for (int q4 = 0; q4 < 4; ++q4)
+                                cc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[t][q4], bc[q4], cc[j], 0, 0, 0);
+                        }
                     }
                 }
             }
+        }
+        MKGNN_STAMP(stamp_slot + 1);
+
+        // ---- epilogue per column tile: lane = kernel lcol, atoms kq*4 + jj
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-                const int64_t n = tile * 16 + kq * 4 + jj;
-                float ed = ed4[jj][0];
+        for (int j = 0; j < NL; ++j) {
+            const int ct = cp + j * cs;
+            if (j < nloc && ct < nct) {
+                const int lcol = ct * kpt + ci;
+                const bool col_ok = (ci < kpt) && (lcol < L);
+                int idx4[4];
+                float best4[4], cen4[4];
 #pragma unroll
-                for (int s = 1; s < D; ++s) ed = __fadd_rn(ed, ed4[jj][s]);
-                ed = div_by<D>(ed);
-                float sc = __fadd_rn(__fadd_rn(__fmul_rn(best4[jj], ws), __fmul_rn(cen4[jj], wc)), __fmul_rn(ed, we)) / wsum;
-                float ch = 1.f;
-                if constexpr (D == 4) {
-                    if (do_chir && !eq4[jj]) ch = ((float)chirtab[lrow * 12 + idx4[jj]] == sign4[jj]) ? 1.f : -1.f;
-                    sc *= ch;
-                }
-                if (col_ok && n < a.n) {
-                    a.out[(size_t)focal4[jj] * a.os + a.off + lcol] = sc;
-                    if (a.best) a.best[(size_t)n * L + lcol] = (uint8_t)idx4[jj];
-                    if (a.scores) {
-                        const size_t ln = (size_t)L * a.n;
-                        a.scores[(size_t)n * L + lcol] = best4[jj];
-                        a.scores[ln + (size_t)n * L + lcol] = cen4[jj];
-                        a.scores[2 * ln + (size_t)n * L + lcol] = ed;
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int src = kq * 4 + jj;
+                    float m[D][D];
+#pragma unroll
+                    for (int s = 0; s < D; ++s) {
+                        const float iv = __shfl(inv_keep[s], src, 64);
+#pragma unroll
+                        for (int b = 0; b < D; ++b) m[s][b] = cm[j][s][b][jj] * iv;
                     }
-                    if (a.chir_out) a.chir_out[(size_t)n * L + lcol] = (int8_t)ch;
+                    best_permutation<D>(m, best4[jj], idx4[jj]);
+                    cen4[jj] = cc[j][jj] * __shfl(inv_keep[D], src, 64);
+                }
+                // bond-cosine matrices, one (a, b) tile at a time; keep the entry the chosen order uses
+                float ed4[4][D];
+                {
+                    const float* eb = esup + (size_t)(j * kpt + rloc) * 8 + 2 * kq;
+#pragma unroll
+                    for (int s = 0; s < D; ++s) {
+#pragma unroll
+                        for (int b = 0; b < D; ++b) {
+                            const float2 bv = *(const float2*)(eb + (size_t)b * SROW * 8);
+                            f32x4 dm = {0.f, 0.f, 0.f, 0.f};
+                            dm = __builtin_amdgcn_mfma_f32_16x16x4f32(eu[s].x, bv.x, dm, 0, 0, 0);
+                            dm = __builtin_amdgcn_mfma_f32_16x16x4f32(eu[s].y, bv.y, dm, 0, 0, 0);
+#pragma unroll
+                            for (int jj = 0; jj < 4; ++jj)
+                                if (b == 0 || perm_at<D>(idx4[jj], s) == b) ed4[jj][s] = dm[jj];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int src = kq * 4 + jj;
+                    const int64_t n = tile * 16 + src;
+                    float ed = ed4[jj][0];
+#pragma unroll
+                    for (int s = 1; s < D; ++s) ed = __fadd_rn(ed, ed4[jj][s]);
+                    ed = div_by<D>(ed);
+                    float sc = __fadd_rn(__fadd_rn(__fmul_rn(best4[jj], ws), __fmul_rn(cen4[jj], wc)), __fmul_rn(ed, we)) / wsum;
+                    float ch = 1.f;
+                    if constexpr (D == 4) {
+                        const float sgn = __shfl(sign_row, src, 64);
+                        const int eqv = __shfl(eq_row, src, 64);
+                        if (do_chir && !eqv) ch = ((float)chirtab[(col_ok ? lcol : 0) * 12 + idx4[jj]] == sgn) ? 1.f : -1.f;
+                        sc *= ch;
+                    }
+                    const uint32_t focal = (uint32_t)__shfl((int)focal_row, src, 64);
+                    if (col_ok && n < dg.n) {
+                        a.out[(size_t)focal * a.os + dg.off + lcol] = sc;
+                        if (dg.best) dg.best[(size_t)n * L + lcol] = (uint8_t)idx4[jj];
+                        if (dg.scores) {
+                            const size_t ln = (size_t)L * dg.n;
+                            dg.scores[(size_t)n * L + lcol] = best4[jj];
+                            dg.scores[ln + (size_t)n * L + lcol] = cen4[jj];
+                            dg.scores[2 * ln + (size_t)n * L + lcol] = ed;
+                        }
+                        if (dg.chir_out) dg.chir_out[(size_t)n * L + lcol] = (int8_t)ch;
+                    }
                 }
             }
         }
+        MKGNN_STAMP(stamp_slot + 2);
+        stamp_slot += 3;
+        if (!have_next) break;
+        tile = nxt_tile;
+#pragma unroll
+        for (int s = 0; s <= D; ++s) ids[s] = ids_n[s];
+    }
+}
+
+template <int KC>
+__global__ void __launch_bounds__(256, 2) kc_forward_fused(FusedFwdArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    const int grp = a.blk_group[blockIdx.x];
+    const int rank = a.blk_rank[blockIdx.x];
+    const int di = a.grp_degree[grp];
+    const int cp = a.grp_cp[grp];
+    const int count = a.grp_count[grp];
+    switch (di) {
+        case 0: forward_body<1, KC>(a, a.deg[0], cp, rank, count, lds); break;
+        case 1: forward_body<2, KC>(a, a.deg[1], cp, rank, count, lds); break;
+        case 2: forward_body<3, KC>(a, a.deg[2], cp, rank, count, lds); break;
+        default: forward_body<4, KC>(a, a.deg[3], cp, rank, count, lds); break;
+    }
+}
+
+// eq[n] = 1 if any two of the four neighbour rows of degree-4 atom n are bit-identical
+// (kernels.py:310-317: such an atom is not chiral).  One wave per atom.
+__global__ void __launch_bounds__(256) rows_equal_kernel(const float* __restrict__ x, int64_t xs, const int64_t* __restrict__ nei,
+                                                         int64_t n, int F, int8_t* __restrict__ eq) {
+    const int lane = threadIdx.x & 63;
+    int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t r = wave; r < n; r += nwaves) {
+        int64_t nb[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) nb[j] = nei[r * 4 + j];
+        unsigned diff = 0;
+        for (int f = lane; f < F; f += 64) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = x[nb[j] * xs + f];
+            int k = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = i + 1; j < 4; ++j, ++k)
+                    if (!(v[i] == v[j])) diff |= 1u << k;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor((int)diff, o, 64);
+        if (lane == 0) eq[r] = (diff != 0x3Fu) ? 1 : 0;
     }
 }
 
 // ---------------------------------------------------------------- host ----
+extern "C" int mkgnn_debug_set_stamp_buffer(void* device_ptr) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buffer), &device_ptr, sizeof(void*));
+}
+
 bool mfma_forward_supported(int d, int F, int E, int L) {
     if (d < 1 || d > 4 || L < 1 || E > 8) return false;
     const int FP = mfma_padded_width(F);
     if (!FP || F <= FP - 16) return false;          // only the last 16-float chunk may be partial
-    if ((L + 15) / 16 > 64) return false;
-    return (size_t)mfma_lds(d, FP / 16, L).total * 4 <= 160 * 1024;
+    const int nct = (L + 15) / 16;
+    const int nl = d == 4 ? 1 : 2;
+    if ((nct + nl - 1) / nl > 16) return false;
+    const int kpt = (L + nct - 1) / nct;
+    return (size_t)fused_lds_floats(d, FP / 16, L, nl < nct ? nl : nct, kpt) * 4 <= 64 * 1024;
 }
 
-template <int D, int KC>
-static hipError_t launch_one(const FwdArgs& a, hipStream_t st) {
-    MfmaGeom g = mfma_geom(a.L);
-    const size_t lds_bytes = (size_t)mfma_lds(D, KC, a.L).total * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kc_forward_mfma<D, KC>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    const int64_t ntiles = (a.n + 15) / 16;
-    int per_cu = (int)((160 * 1024) / (lds_bytes + 512));
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 5) per_cu = 5;
-    // few atom tiles: let the column tiles of one atom tile run on different waves
-    if (ntiles < 768) g.cs = g.nct;
-    int64_t blocks = 256 * per_cu;
-    const int64_t need = (ntiles * g.cs + 3) / 4;
-    if (blocks > need) blocks = need;
-    kc_forward_mfma<D, KC><<<(int)blocks, 256, lds_bytes, st>>>(a, g);
-    return hipGetLastError();
-}
-
-hipError_t launch_forward_mfma(int d, const FwdArgs& a, hipStream_t st) {
-    if (a.n == 0 || a.L == 0) return hipSuccess;
-    const int KC = mfma_padded_width(a.F) / 16;
-    if (KC == 2) {
-        switch (d) {
-            case 1: return launch_one<1, 2>(a, st);
-            case 2: return launch_one<2, 2>(a, st);
-            case 3: return launch_one<3, 2>(a, st);
-            default: return launch_one<4, 2>(a, st);
+// Fill geometry, group sizes and the block table; returns the dynamic LDS bytes (0 = nothing to launch).
+static size_t plan_fused(FusedFwdArgs& a, const bool use[4], int KC, int* nblocks_out) {
+    double cost[FUSED_MAX_GROUPS];
+    int64_t cap[FUSED_MAX_GROUPS];
+    int ng = 0;
+    size_t lds_floats = 0;
+    for (int i = 0; i < 4; ++i) {
+        FusedDeg& g = a.deg[i];
+        if (!use[i]) continue;
+        const int d = i + 1, L = g.L;
+        g.nct = (L + 15) / 16;
+        g.kpt = (L + g.nct - 1) / g.nct;            // balanced: 10, 10, 15, 13 kernels for L = 10, 20, 30, 50
+        const int nl = d == 4 ? 1 : 2;
+        g.cs = (g.nct + nl - 1) / nl;                // fewest column parts that respect the register bound
+        const int64_t ntiles = (g.n + 15) / 16;
+        // a small bucket spreads its column tiles over more blocks (each gathers the rows again)
+        if (ntiles * g.cs < 1024 && g.cs < g.nct) g.cs = g.nct;
+        g.nloc = (g.nct + g.cs - 1) / g.cs;
+        const size_t fl = (size_t)fused_lds_floats(d, KC, L, g.nloc, g.kpt);
+        if (fl > lds_floats) lds_floats = fl;
+        for (int cp = 0; cp < g.cs && ng < FUSED_MAX_GROUPS; ++cp) {
+            int mine = 0;                            // column tiles of this part
+            for (int ct = cp; ct < g.nct; ct += g.cs) ++mine;
+            a.grp_degree[ng] = (uint8_t)i;
+            a.grp_cp[ng] = (uint8_t)cp;
+            // MFMAs per tile of this part + a term for the gather (rows are fetched once per part)
+            cost[ng] = (double)ntiles * (mine * ((d * d + 1) * 4.0 * KC + 2.0 * d * d) + 0.35 * (d + 1) * 4.0 * KC);
+            cap[ng] = (ntiles + 3) / 4;
+            ++ng;
         }
     }
-    switch (d) {
-        case 1: return launch_one<1, 7>(a, st);
-        case 2: return launch_one<2, 7>(a, st);
-        case 3: return launch_one<3, 7>(a, st);
-        default: return launch_one<4, 7>(a, st);
+    if (ng == 0) { *nblocks_out = 0; return 0; }
+    double total = 0;
+    for (int g = 0; g < ng; ++g) total += cost[g];
+    int count[FUSED_MAX_GROUPS];
+    int nb = 0;
+    for (int g = 0; g < ng; ++g) {
+        int64_t c = (int64_t)(FUSED_MAX_BLOCKS * cost[g] / total + 0.5);
+        if (c < 1) c = 1;
+        if (c > cap[g]) c = cap[g];
+        count[g] = (int)c;
+        nb += count[g];
     }
+    while (nb > FUSED_MAX_BLOCKS) {                  // rounding overshoot: trim the largest group
+        int big = 0;
+        for (int g = 1; g < ng; ++g) if (count[g] > count[big]) big = g;
+        --count[big]; --nb;
+    }
+    // interleave the groups over the block ids (largest remaining share first), so that
+    // consecutive blocks -- which the dispatcher deals round-robin over the XCDs -- mix degrees
+    int given[FUSED_MAX_GROUPS] = {0};
+    for (int b = 0; b < nb; ++b) {
+        int pick = -1;
+        double best = -1e30;
+        for (int g = 0; g < ng; ++g) {
+            if (given[g] >= count[g]) continue;
+            const double lag = (double)count[g] * (b + 1) / nb - given[g];
+            if (lag > best) { best = lag; pick = g; }
+        }
+        a.blk_group[b] = (uint8_t)pick;
+        a.blk_rank[b] = (uint16_t)given[pick];
+        ++given[pick];
+    }
+    for (int g = 0; g < ng; ++g) a.grp_count[g] = (uint16_t)count[g];
+    *nblocks_out = nb;
+    return lds_floats * 4;
+}
+
+hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t st) {
+    const int KC = mfma_padded_width(a.F) / 16;
+    int nb = 0;
+    const size_t lds_bytes = plan_fused(a, use, KC, &nb);
+    if (nb == 0) return hipSuccess;
+    if (a.last && use[3] && a.deg[3].n > 0) {
+        int64_t blocks = (a.deg[3].n + 3) / 4;
+        if (blocks > 2048) blocks = 2048;
+        rows_equal_kernel<<<(int)blocks, 256, 0, st>>>(a.x, a.xs, a.deg[3].nei, a.deg[3].n, a.F, (int8_t*)a.deg[3].eqflag);
+    }
+    if (KC == 2) kc_forward_fused<2><<<nb, 256, lds_bytes, st>>>(a);
+    else kc_forward_fused<7><<<nb, 256, lds_bytes, st>>>(a);
+    return hipGetLastError();
 }
 
 }  // namespace mkgnn
