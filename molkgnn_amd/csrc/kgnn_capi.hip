@@ -208,6 +208,7 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
             g.sel = a.sel; g.nei = a.nei; g.e_nei = a.e_nei; g.p_focal = a.p_focal; g.p_nei = a.p_nei;
             g.padded = a.padded; g.edge_padded = a.edge_padded; g.chir = a.chir; g.mix = a.mix;
             g.eqflag = (const int8_t*)(ws + w.eqflag);
+            g.signflag = (const int8_t*)(ws + w.signflag);
             g.best = a.best; g.scores = a.scores; g.chir_out = a.chir_out;
             g.n = a.n; g.L = a.L; g.off = a.off;
             use[i] = true;

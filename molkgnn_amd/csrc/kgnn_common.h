@@ -132,6 +132,7 @@ __host__ __device__ static inline int mfma_padded_width(int F) { return F <= 32 
 struct WorkspaceLayout {
     BankLayout bank[MKGNN_MAX_DEGREE];
     size_t eqflag;        // [N] int8: degree-4 atom has two identical neighbour rows (last layer)
+    size_t signflag;      // [N] int8: sign of the degree-4 atom's neighbour tetrahedron (last layer)
     size_t contrib;       // [sum_d N_d (d+1), F] per-slot gradient rows (backward)
     size_t slab;          // partial bank gradients, per degree [nblk, bank floats]
     size_t slab_bytes_per_degree[MKGNN_MAX_DEGREE];
@@ -173,6 +174,8 @@ static inline WorkspaceLayout make_layout(const int32_t L[MKGNN_MAX_DEGREE], int
         b.end = off;
     }
     w.eqflag = off;
+    off = align_up(off + (size_t)n_atoms);
+    w.signflag = off;
     off = align_up(off + (size_t)n_atoms);
     w.fwd_end = off;
     w.contrib = off;

@@ -37,14 +37,15 @@ constexpr int FUSED_MAX_GROUPS = 16;        // (degree, column part)
 
 struct FusedDeg {
     const int64_t* sel; const int64_t* nei; const float* e_nei; const float* p_focal; const float* p_nei;
-    const float* padded; const float* edge_padded; const int8_t* chir; const float* mix; const int8_t* eqflag;
+    const float* padded; const float* edge_padded; const int8_t* chir; const float* mix; const int8_t* eqflag; const int8_t* signflag;
     uint8_t* best; float* scores; int8_t* chir_out;
     int64_t n;
     int L, off;
     int nct;        // column tiles (<= 16 kernels each)
     int kpt;        // kernels per column tile
     int cs;         // column split: part cp takes the column tiles cp, cp + cs, ...
-    int nloc;       // column tiles per block = ceil(nct / cs)  (<= 2; 1 for degree 4)
+    int nloc;       // column tiles resident in a block = ceil(nct / cs)
+    int ics;        // waves of a block that share one atom tile; wave w takes the resident tiles w % ics, + ics, ...
 };
 
 struct FusedFwdArgs {

@@ -39,7 +39,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ unsigned long long* g_stamp_buffer = nullptr;
 #define MKGNN_STAMP(slot)                                                                      \
     do {                                                                                       \
-        if (stamps && lane == 0 && (slot) < 32) stamps[(slot)] = __builtin_readcyclecounter(); \
+        if (stamps && lane == 0 && (slot) < 29) stamps[(slot)] = __builtin_readcyclecounter(); \
     } while (0)
 
 template <int KC> __device__ __forceinline__ int swz(int pos) {
@@ -50,12 +50,13 @@ template <int KC> __device__ __forceinline__ int swz(int pos) {
     }
 }
 
-template <int D> struct BodyTraits { static constexpr int NL = (D == 4) ? 1 : 2; };
+// column tiles one WAVE accumulates at a time (bounds the accumulator registers)
+template <int D> struct BodyTraits { static constexpr int NL = (D >= 3) ? 1 : 2; };
 
 // LDS floats a (degree, column part) block needs.
 __host__ __device__ static inline int fused_lds_floats(int D, int KC, int L, int nloc, int kpt) {
     const int srow = nloc * kpt;
-    return (D + 1) * srow * 16 * KC + D * srow * 8 + ((D == 4 ? L * 12 : 0) + 15) / 16 * 4;
+    return (D + 1) * srow * 16 * KC + D * srow * 8 + ((D == 4 ? L * 12 : 0) + 15) / 16 * 4 + 4 * 16 * 8;
 }
 
 template <int D, int KC>
@@ -73,15 +74,24 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    // per-wave scratch [8][16]: 1/|x| of slots 0..D, focal id, chirality sign, "rows equal" flag of the
+    // wave's 16 atoms, written by the row-owning lanes and read back per accumulator row as one b128
+    float* wscr = (float*)(chirtab + ((D == 4 ? L * 12 : 0) + 15) / 16 * 16) + wave * 16 * 8;
     const bool do_chir = (D == 4) && a.last;
     unsigned long long* stamps = g_stamp_buffer ? g_stamp_buffer + ((size_t)blockIdx.x * NW + wave) * 32 : nullptr;
     int stamp_slot = 2;
     MKGNN_STAMP(0);
+    if (stamps && lane == 0) stamps[31] = (unsigned long long)(D * 16 + cp);
 
     const int ci = lane & 15, kq = lane >> 4;
     const int64_t ntiles = (dg.n + 15) / 16;
-    const int64_t tstride = (int64_t)count * NW;
-    int64_t tile = (int64_t)rank * NW + wave;
+    // `ics` waves of the block share an atom tile (each takes its own column tiles; the second
+    // wave's row loads hit the lines the first one brought in)
+    const int ics = dg.ics;
+    const int wpart = wave % ics;
+    const int tiles_per_block = NW / ics;
+    const int64_t tstride = (int64_t)count * tiles_per_block;
+    int64_t tile = (int64_t)rank * tiles_per_block + wave / ics;
     const uint32_t xs = (uint32_t)a.xs;
 
     uint32_t ids[D + 1];                             // this tile: slots 0..D-1 neighbours, slot D focal
@@ -140,11 +150,14 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
     const float ws = dg.mix[0], wc = dg.mix[1], we = dg.mix[2], wsum = dg.mix[3];
 
     // ---- pipeline registers
-    f32x4 nxt[KC];                                   // rows of the slot in flight
-    float inv_nxt = 0.f;
+    // Two row buffers used alternately: slot s is multiplied out of buf[s & 1] while slot s + 1 (or
+    // the next tile's slot 0) is in flight into the other.  For odd D the parity of slot 0 is the
+    // same in every tile; for even D the next tile's slot 0 lands in buffer 1 and is moved to
+    // buffer 0 once per tile.
+    f32x4 rb0[KC], rb1[KC];
+    float inv0 = 0.f, inv1 = 0.f;
     float2 eraw[D];                                  // bond components 2kq, 2kq+1 of (atom ci, slot s)
-    float pvec[(D == 4) ? 15 : 1];
-    int eq_raw = 0;
+    int eq_raw = 0, sign_raw = 0;
     auto issue_small = [&](int64_t t) {
         int64_t nrow = t * 16 + ci;
         if (nrow >= dg.n) nrow = dg.n - 1;
@@ -156,18 +169,15 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
         }
         if constexpr (D == 4) {
             if (do_chir) {
-#pragma unroll
-                for (int k = 0; k < 12; ++k) pvec[k] = dg.p_nei[nrow * 12 + k];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) pvec[12 + k] = dg.p_focal[nrow * 3 + k];
                 eq_raw = dg.eqflag[nrow];
+                sign_raw = dg.signflag[nrow];
             }
         }
     };
-    auto issue_slot = [&](uint32_t id) {
+    auto issue_slot = [&](uint32_t id, f32x4 (&dst)[KC], float& dinv) {
         const float* row = a.x + (id * xs + 4u * kq);            // 32-bit offset (host checks N * stride < 2^32)
 #pragma unroll
-        for (int t = 0; t < KC - 1; ++t) nxt[t] = *(const f32x4*)(row + 16 * t);
+        for (int t = 0; t < KC - 1; ++t) dst[t] = *(const f32x4*)(row + 16 * t);
         {   // only the last chunk can reach beyond the row's width (host guarantees FP - 16 < F <= FP)
             const int f0 = 16 * (KC - 1) + 4 * kq;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -177,12 +187,12 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
                 if (f0 + 2 >= a.F) v.z = 0.f;
                 if (f0 + 3 >= a.F) v.w = 0.f;
             }
-            nxt[KC - 1] = v;
+            dst[KC - 1] = v;
         }
-        inv_nxt = a.inv[id];
+        dinv = a.inv[id];
     };
     issue_small(tile);
-    issue_slot(ids[0]);
+    issue_slot(ids[0], rb0, inv0);
 
     for (;;) {
         MKGNN_STAMP(stamp_slot);
@@ -206,12 +216,7 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
         int eq_row = 0;
         if constexpr (D == 4) {
             if (do_chir) {
-                float t3[3][3];
-#pragma unroll
-                for (int j = 0; j < 3; ++j)
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) t3[j][c] = __fsub_rn(pvec[3 * j + c], pvec[12 + c]);
-                sign_row = triple_sign(t3[0], t3[1], t3[2]);
+                sign_row = (float)sign_raw;
                 eq_row = eq_raw;
             }
         }
@@ -225,20 +230,20 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
         const int swb = swz<KC>(rloc);
 #pragma unroll
         for (int s = 0; s <= D; ++s) {
-            f32x4 cur[KC];
-#pragma unroll
-            for (int t = 0; t < KC; ++t) cur[t] = nxt[t];
-            inv_keep[s] = inv_nxt;
+            f32x4 (&cur)[KC] = (s & 1) ? rb1 : rb0;
+            f32x4 (&oth)[KC] = (s & 1) ? rb0 : rb1;
+            inv_keep[s] = (s & 1) ? inv1 : inv0;
             if (s < D) {
-                issue_slot(ids[s + 1 <= D ? s + 1 : D]);
+                issue_slot(ids[s + 1 <= D ? s + 1 : D], oth, (s & 1) ? inv0 : inv1);
             } else if (have_next) {
                 issue_small(nxt_tile);
-                issue_slot(ids_n[0]);
+                issue_slot(ids_n[0], oth, (s & 1) ? inv0 : inv1);
             }
 #pragma unroll
             for (int j = 0; j < NL; ++j) {
-                if (j < nloc) {
-                    const float* brow = bank + (size_t)(j * kpt + rloc) * FP;
+                const int jl = wpart + j * ics;                    // resident column tile of this wave
+                if (jl < nloc) {
+                    const float* brow = bank + (size_t)(jl * kpt + rloc) * FP;
                     if (s < D) {
                         constexpr int dummy = 0;
                         (void)dummy;
@@ -272,51 +277,75 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
             }
         }
         MKGNN_STAMP(stamp_slot + 1);
+        // row-owned values -> wave scratch (lanes kq == 0 own rows 0..15), read back 4 atoms at a time
+        if (kq == 0) {
+#pragma unroll
+            for (int s = 0; s <= D; ++s) wscr[s * 16 + ci] = inv_keep[s];
+            wscr[5 * 16 + ci] = __uint_as_float(focal_row);
+            if constexpr (D == 4) {
+                wscr[6 * 16 + ci] = sign_row;
+                wscr[7 * 16 + ci] = __int_as_float(eq_row);
+            }
+        }
+        f32x4 inv4[D + 1];
+#pragma unroll
+        for (int s = 0; s <= D; ++s) inv4[s] = *(const f32x4*)(wscr + s * 16 + kq * 4);
+        const f32x4 focal4 = *(const f32x4*)(wscr + 5 * 16 + kq * 4);
+        f32x4 sign4 = {0.f, 0.f, 0.f, 0.f}, eq4 = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (D == 4) {
+            sign4 = *(const f32x4*)(wscr + 6 * 16 + kq * 4);
+            eq4 = *(const f32x4*)(wscr + 7 * 16 + kq * 4);
+        }
 
         // ---- epilogue per column tile: lane = kernel lcol, atoms kq*4 + jj
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
-            const int ct = cp + j * cs;
-            if (j < nloc && ct < nct) {
+            const int jl = wpart + j * ics;
+            const int ct = cp + jl * cs;
+            if (jl < nloc && ct < nct) {
                 const int lcol = ct * kpt + ci;
                 const bool col_ok = (ci < kpt) && (lcol < L);
                 int idx4[4];
                 float best4[4], cen4[4];
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    const int src = kq * 4 + jj;
                     float m[D][D];
 #pragma unroll
                     for (int s = 0; s < D; ++s) {
-                        const float iv = __shfl(inv_keep[s], src, 64);
+                        const float iv = inv4[s][jj];
 #pragma unroll
                         for (int b = 0; b < D; ++b) m[s][b] = cm[j][s][b][jj] * iv;
                     }
                     best_permutation<D>(m, best4[jj], idx4[jj]);
-                    cen4[jj] = cc[j][jj] * __shfl(inv_keep[D], src, 64);
+                    cen4[jj] = cc[j][jj] * inv4[D][jj];
                 }
+                if (stamps && stamp_slot == 2 && j == 0) { asm volatile("" :: "v"(best4[0]), "v"(best4[3])); MKGNN_STAMP(20); }
                 // bond-cosine matrices, one (a, b) tile at a time; keep the entry the chosen order uses
                 float ed4[4][D];
                 {
-                    const float* eb = esup + (size_t)(j * kpt + rloc) * 8 + 2 * kq;
+                    const float* eb = esup + (size_t)(jl * kpt + rloc) * 8 + 2 * kq;
+                    float2 bv[D];
+#pragma unroll
+                    for (int b = 0; b < D; ++b) bv[b] = *(const float2*)(eb + (size_t)b * SROW * 8);
 #pragma unroll
                     for (int s = 0; s < D; ++s) {
+                        f32x4 dm[D];              // D independent chains: the matrix pipe stays busy
 #pragma unroll
-                        for (int b = 0; b < D; ++b) {
-                            const float2 bv = *(const float2*)(eb + (size_t)b * SROW * 8);
-                            f32x4 dm = {0.f, 0.f, 0.f, 0.f};
-                            dm = __builtin_amdgcn_mfma_f32_16x16x4f32(eu[s].x, bv.x, dm, 0, 0, 0);
-                            dm = __builtin_amdgcn_mfma_f32_16x16x4f32(eu[s].y, bv.y, dm, 0, 0, 0);
+                        for (int b = 0; b < D; ++b)
+                            dm[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(eu[s].x, bv[b].x, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < D; ++b) dm[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(eu[s].y, bv[b].y, dm[b], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < D; ++b)
 #pragma unroll
                             for (int jj = 0; jj < 4; ++jj)
-                                if (b == 0 || perm_at<D>(idx4[jj], s) == b) ed4[jj][s] = dm[jj];
-                        }
+                                if (b == 0 || perm_at<D>(idx4[jj], s) == b) ed4[jj][s] = dm[b][jj];
                     }
                 }
+                if (stamps && stamp_slot == 2 && j == 0) { asm volatile("" :: "v"(ed4[0][0]), "v"(ed4[3][D - 1])); MKGNN_STAMP(21); }
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
-                    const int src = kq * 4 + jj;
-                    const int64_t n = tile * 16 + src;
+                    const int64_t n = tile * 16 + kq * 4 + jj;
                     float ed = ed4[jj][0];
 #pragma unroll
                     for (int s = 1; s < D; ++s) ed = __fadd_rn(ed, ed4[jj][s]);
@@ -324,32 +353,38 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
                     float sc = __fadd_rn(__fadd_rn(__fmul_rn(best4[jj], ws), __fmul_rn(cen4[jj], wc)), __fmul_rn(ed, we)) / wsum;
                     float ch = 1.f;
                     if constexpr (D == 4) {
-                        const float sgn = __shfl(sign_row, src, 64);
-                        const int eqv = __shfl(eq_row, src, 64);
-                        if (do_chir && !eqv) ch = ((float)chirtab[(col_ok ? lcol : 0) * 12 + idx4[jj]] == sgn) ? 1.f : -1.f;
+                        if (do_chir && !__float_as_int(eq4[jj]))
+                            ch = ((float)chirtab[(col_ok ? lcol : 0) * 12 + idx4[jj]] == sign4[jj]) ? 1.f : -1.f;
                         sc *= ch;
                     }
-                    const uint32_t focal = (uint32_t)__shfl((int)focal_row, src, 64);
+                    const uint32_t focal = __float_as_uint(focal4[jj]);
                     if (col_ok && n < dg.n) {
                         a.out[(size_t)focal * a.os + dg.off + lcol] = sc;
-                        if (dg.best) dg.best[(size_t)n * L + lcol] = (uint8_t)idx4[jj];
+                        const uint32_t o = (uint32_t)n * (uint32_t)L + (uint32_t)lcol;   // host checks N_d * L < 2^31
+                        if (dg.best) dg.best[o] = (uint8_t)idx4[jj];
                         if (dg.scores) {
-                            const size_t ln = (size_t)L * dg.n;
-                            dg.scores[(size_t)n * L + lcol] = best4[jj];
-                            dg.scores[ln + (size_t)n * L + lcol] = cen4[jj];
-                            dg.scores[2 * ln + (size_t)n * L + lcol] = ed;
+                            const uint32_t ln = (uint32_t)L * (uint32_t)dg.n;
+                            dg.scores[o] = best4[jj];
+                            dg.scores[ln + o] = cen4[jj];
+                            dg.scores[2u * ln + o] = ed;
                         }
-                        if (dg.chir_out) dg.chir_out[(size_t)n * L + lcol] = (int8_t)ch;
+                        if (dg.chir_out) dg.chir_out[o] = (int8_t)ch;
                     }
                 }
             }
         }
         MKGNN_STAMP(stamp_slot + 2);
+        if (stamp_slot + 3 >= 20) stamp_slot -= 3;      // keep the fine stamps of the first tile
         stamp_slot += 3;
         if (!have_next) break;
         tile = nxt_tile;
 #pragma unroll
         for (int s = 0; s <= D; ++s) ids[s] = ids_n[s];
+        if constexpr ((D & 1) == 0) {       // even D: the new slot 0 was fetched into buffer 1
+#pragma unroll
+            for (int t = 0; t < KC; ++t) rb0[t] = rb1[t];
+            inv0 = inv1;
+        }
     }
 }
 
@@ -372,7 +407,8 @@ __global__ void __launch_bounds__(256, 2) kc_forward_fused(FusedFwdArgs a) {
 // eq[n] = 1 if any two of the four neighbour rows of degree-4 atom n are bit-identical
 // (kernels.py:310-317: such an atom is not chiral).  One wave per atom.
 __global__ void __launch_bounds__(256) rows_equal_kernel(const float* __restrict__ x, int64_t xs, const int64_t* __restrict__ nei,
-                                                         int64_t n, int F, int8_t* __restrict__ eq) {
+                                                         const float* __restrict__ p_focal, const float* __restrict__ p_nei,
+                                                         int64_t n, int F, int8_t* __restrict__ eq, int8_t* __restrict__ sgn) {
     const int lane = threadIdx.x & 63;
     int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -394,7 +430,16 @@ __global__ void __launch_bounds__(256) rows_equal_kernel(const float* __restrict
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor((int)diff, o, 64);
-        if (lane == 0) eq[r] = (diff != 0x3Fu) ? 1 : 0;
+        if (lane == 0) {
+            eq[r] = (diff != 0x3Fu) ? 1 : 0;
+            // sign of the neighbour tetrahedron, coordinates relative to the focal atom (kernels.py:356, 327-337)
+            float t3[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) t3[j][c] = __fsub_rn(p_nei[(r * 4 + j) * 3 + c], p_focal[r * 3 + c]);
+            sgn[r] = (int8_t)triple_sign(t3[0], t3[1], t3[2]);
+        }
     }
 }
 
@@ -408,10 +453,11 @@ bool mfma_forward_supported(int d, int F, int E, int L) {
     const int FP = mfma_padded_width(F);
     if (!FP || F <= FP - 16) return false;          // only the last 16-float chunk may be partial
     const int nct = (L + 15) / 16;
-    const int nl = d == 4 ? 1 : 2;
-    if ((nct + nl - 1) / nl > 16) return false;
+    const int nl = d >= 3 ? 1 : 2;
+    const int need_split = (nct + nl - 1) / nl;
+    if (need_split > 16) return false;                      // <= 4 waves x 4 column parts
     const int kpt = (L + nct - 1) / nct;
-    return (size_t)fused_lds_floats(d, FP / 16, L, nl < nct ? nl : nct, kpt) * 4 <= 64 * 1024;
+    return (size_t)fused_lds_floats(d, FP / 16, L, 1, kpt) * 4 <= 60 * 1024;
 }
 
 // Fill geometry, group sizes and the block table; returns the dynamic LDS bytes (0 = nothing to launch).
@@ -426,22 +472,31 @@ static size_t plan_fused(FusedFwdArgs& a, const bool use[4], int KC, int* nblock
         const int d = i + 1, L = g.L;
         g.nct = (L + 15) / 16;
         g.kpt = (L + g.nct - 1) / g.nct;            // balanced: 10, 10, 15, 13 kernels for L = 10, 20, 30, 50
-        const int nl = d == 4 ? 1 : 2;
-        g.cs = (g.nct + nl - 1) / nl;                // fewest column parts that respect the register bound
         const int64_t ntiles = (g.n + 15) / 16;
-        // a small bucket spreads its column tiles over more blocks (each gathers the rows again)
-        if (ntiles * g.cs < 1024 && g.cs < g.nct) g.cs = g.nct;
+        // Column tiles are spread (a) over the waves of a block that share an atom tile (ics; their
+        // row loads coalesce in L1) and (b) over blocks (cs; each part gathers the rows again), so that
+        // one wave accumulates at most NL column tiles and a block's bank share stays <= ~57 KB.
+        const int nl = d >= 3 ? 1 : 2;
+        const int need_split = (g.nct + nl - 1) / nl;       // waves/blocks a tile's columns must be spread over
+        g.ics = 1;
+        g.cs = need_split;
         g.nloc = (g.nct + g.cs - 1) / g.cs;
+        // the bank share must leave room for two blocks per CU
+        while ((size_t)fused_lds_floats(d, KC, L, g.nloc, g.kpt) * 4 > 60 * 1024 && g.cs < g.nct) {
+            ++g.cs;
+            g.nloc = (g.nct + g.cs - 1) / g.cs;
+        }
         const size_t fl = (size_t)fused_lds_floats(d, KC, L, g.nloc, g.kpt);
         if (fl > lds_floats) lds_floats = fl;
         for (int cp = 0; cp < g.cs && ng < FUSED_MAX_GROUPS; ++cp) {
             int mine = 0;                            // column tiles of this part
             for (int ct = cp; ct < g.nct; ct += g.cs) ++mine;
+            const int tiles_per_block = 4 / g.ics;
             a.grp_degree[ng] = (uint8_t)i;
             a.grp_cp[ng] = (uint8_t)cp;
             // MFMAs per tile of this part + a term for the gather (rows are fetched once per part)
             cost[ng] = (double)ntiles * (mine * ((d * d + 1) * 4.0 * KC + 2.0 * d * d) + 0.35 * (d + 1) * 4.0 * KC);
-            cap[ng] = (ntiles + 3) / 4;
+            cap[ng] = (ntiles + tiles_per_block - 1) / tiles_per_block;
             ++ng;
         }
     }
@@ -490,7 +545,8 @@ hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t 
     if (a.last && use[3] && a.deg[3].n > 0) {
         int64_t blocks = (a.deg[3].n + 3) / 4;
         if (blocks > 2048) blocks = 2048;
-        rows_equal_kernel<<<(int)blocks, 256, 0, st>>>(a.x, a.xs, a.deg[3].nei, a.deg[3].n, a.F, (int8_t*)a.deg[3].eqflag);
+        rows_equal_kernel<<<(int)blocks, 256, 0, st>>>(a.x, a.xs, a.deg[3].nei, a.deg[3].p_focal, a.deg[3].p_nei, a.deg[3].n, a.F,
+                                                      (int8_t*)a.deg[3].eqflag, (int8_t*)a.deg[3].signflag);
     }
     if (KC == 2) kc_forward_fused<2><<<nb, 256, lds_bytes, st>>>(a);
     else kc_forward_fused<7><<<nb, 256, lds_bytes, st>>>(a);
