@@ -21,7 +21,7 @@ namespace mkgnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__host__ __device__ constexpr int bank_li(int d) { return d == 1 ? 3 : (d == 2 ? 5 : (d == 3 ? 8 : 13)); }   // kernels per wave
+__host__ __device__ constexpr int bank_li(int d) { return d == 1 ? 2 : (d == 2 ? 3 : (d == 3 ? 4 : 7)); }     // kernels per wave (8 waves)
 __host__ __device__ constexpr int rows_cq(int d) { return d == 1 ? 2 : (d == 2 ? 3 : (d == 3 ? 4 : 7)); }    // coefficient pairs per thread
 __host__ __device__ constexpr int bank_ta(int d) { return d <= 2 ? 32 : 16; }                                 // atoms per bank tile
 
@@ -99,36 +99,51 @@ __global__ void __launch_bounds__(256) kc_backward_rows_lds(BwdArgs a) {
         __syncthreads();
         const int64_t nxt = tile + gridDim.x;
         if (nxt < ntiles) fetch(nxt, buf ^ 1);
-        for (int i = wave; i < TA; i += 4) {
-            const int64_t n = tile * TA + i;
-            if (n >= a.n) break;
-            float2 acc[D + 1];
+        // each wave owns 8 consecutive atoms of the tile and keeps 4 of them in flight: the chain
+        // coefficient -> permutation bits -> row address -> row -> FMA is LDS-latency bound, four
+        // independent chains hide it
+        constexpr int AU = 4;
+        for (int g4 = 0; g4 < TA / 4 / AU; ++g4) {
+            const int i0 = wave * (TA / 4) + g4 * AU;
+            if (tile * TA + i0 >= a.n) break;
+            float2 acc[AU][D + 1];
 #pragma unroll
-            for (int s = 0; s <= D; ++s) acc[s] = float2{0.f, 0.f};
+            for (int u = 0; u < AU; ++u)
+#pragma unroll
+                for (int s = 0; s <= D; ++s) acc[u][s] = float2{0.f, 0.f};
             if (act) {
-                const float2* cf = coef + (size_t)i * L;
                 const float* bl = bank + 2 * lane;
-#pragma unroll 2
                 for (int l = 0; l < L; ++l) {
-                    const float2 c = cf[l];
-                    const int pk = __float_as_int(c.y);
                     const float2 vc = *(const float2*)(bl + (size_t)(D * L + l) * FP);
-                    const float gc = c.x * ratio_c;
-                    acc[0].x = fmaf(gc, vc.x, acc[0].x);
-                    acc[0].y = fmaf(gc, vc.y, acc[0].y);
+                    float2 c[AU];
 #pragma unroll
-                    for (int s = 0; s < D; ++s) {
-                        const int b = (pk >> (2 * s)) & 3;
-                        const float2 v = *(const float2*)(bl + (size_t)(b * L + l) * FP);
-                        acc[1 + s].x = fmaf(c.x, v.x, acc[1 + s].x);
-                        acc[1 + s].y = fmaf(c.x, v.y, acc[1 + s].y);
+                    for (int u = 0; u < AU; ++u) c[u] = coef[(size_t)(i0 + u) * L + l];    // zero beyond the bucket's end
+#pragma unroll
+                    for (int u = 0; u < AU; ++u) {
+                        const int pk = __float_as_int(c[u].y);
+                        const float gc = c[u].x * ratio_c;
+                        acc[u][0].x = fmaf(gc, vc.x, acc[u][0].x);
+                        acc[u][0].y = fmaf(gc, vc.y, acc[u][0].y);
+#pragma unroll
+                        for (int s = 0; s < D; ++s) {
+                            const int b = (pk >> (2 * s)) & 3;
+                            const float2 v = *(const float2*)(bl + (size_t)(b * L + l) * FP);
+                            acc[u][1 + s].x = fmaf(c[u].x, v.x, acc[u][1 + s].x);
+                            acc[u][1 + s].y = fmaf(c[u].x, v.y, acc[u][1 + s].y);
+                        }
                     }
                 }
             }
             if (2 * lane < a.F) {
 #pragma unroll
-                for (int s = 0; s <= D; ++s)
-                    *(float2*)(a.contrib + (size_t)(a.contrib_base + n * (D + 1) + s) * a.F + 2 * lane) = acc[s];
+                for (int u = 0; u < AU; ++u) {
+                    const int64_t n = tile * TA + i0 + u;
+                    if (n < a.n) {
+#pragma unroll
+                        for (int s = 0; s <= D; ++s)
+                            *(float2*)(a.contrib + (size_t)(a.contrib_base + n * (D + 1) + s) * a.F + 2 * lane) = acc[u][s];
+                    }
+                }
             }
         }
         __syncthreads();
@@ -142,13 +157,14 @@ __global__ void __launch_bounds__(256) kc_backward_rows_lds(BwdArgs a) {
 
 // ------------------------------------------------------------------ bank ---
 template <int D, int KC, int LI, int TA>
-__global__ void __launch_bounds__(256) kc_backward_bank_lds(BwdArgs a) {
+__global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
+    constexpr int NT = 512, NWV = 8;               // 8 waves share one staged tile: 2 waves per SIMD hide the LDS latency
     constexpr int FP = 16 * KC;
     constexpr int RS = FP + 8;                      // tile row: FP unit feature floats + 8 unit bond floats
     constexpr int CH = FP / 4;
     constexpr int NROW = TA * (D + 1);              // row = atom * (D+1) + slot, slot D = focal
-    constexpr int MAXQ = (NROW * CH + 255) / 256;
-    constexpr int CQ = (TA * 4 * LI + 255) / 256;   // coefficient pairs per thread (L <= 4*LI)
+    constexpr int MAXQ = (NROW * CH + NT - 1) / NT;
+    constexpr int CQ = (TA * NWV * LI + NT - 1) / NT;   // coefficient pairs per thread (L <= NWV*LI)
     extern __shared__ __align__(16) float lds[];
     const int L = a.L;
     float* xt = lds;                                        // [NROW][RS]
@@ -170,7 +186,7 @@ __global__ void __launch_bounds__(256) kc_backward_bank_lds(BwdArgs a) {
     const bool act = 2 * lane < RS;
 
     auto load_ids = [&](int64_t tile, int buf) {
-        for (int r = tid; r < NROW; r += 256) {
+        for (int r = tid; r < NROW; r += NT) {
             const int i = r / (D + 1), slot = r - i * (D + 1);
             int64_t n = tile * TA + i;
             if (n >= a.n) n = a.n - 1;
@@ -186,7 +202,7 @@ __global__ void __launch_bounds__(256) kc_backward_bank_lds(BwdArgs a) {
     auto fetch = [&](int64_t tile, int buf) {
 #pragma unroll
         for (int k = 0; k < MAXQ; ++k) {
-            const int q = tid + 256 * k;
+            const int q = tid + NT * k;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (q < NROW * CH) {
                 const int row = q / CH, c = q - row * CH;
@@ -201,7 +217,7 @@ __global__ void __launch_bounds__(256) kc_backward_bank_lds(BwdArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < CQ; ++k) {
-            const int q = tid + 256 * k;
+            const int q = tid + NT * k;
             const int i = q / L, l = q - i * L;
             const int64_t n = tile * TA + i;
             rg[k] = 0.f; ridx[k] = 0;
@@ -231,7 +247,7 @@ __global__ void __launch_bounds__(256) kc_backward_bank_lds(BwdArgs a) {
         // ---- registers -> LDS: unit feature rows, unit bond vectors, coefficients
 #pragma unroll
         for (int k = 0; k < MAXQ; ++k) {
-            const int q = tid + 256 * k;
+            const int q = tid + NT * k;
             if (q < NROW * CH) {
                 const int row = q / CH, c = q - row * CH;
                 *(f32x4*)(xt + (size_t)row * RS + 4 * c) = stage[k] * invbuf[buf * NROW + row];
@@ -253,7 +269,7 @@ __global__ void __launch_bounds__(256) kc_backward_bank_lds(BwdArgs a) {
         }
 #pragma unroll
         for (int k = 0; k < CQ; ++k) {
-            const int q = tid + 256 * k;
+            const int q = tid + NT * k;
             if (q < TA * L) {
                 int pk = 0;                          // for support b: the neighbour slot matched to it
 #pragma unroll
@@ -267,12 +283,13 @@ __global__ void __launch_bounds__(256) kc_backward_bank_lds(BwdArgs a) {
         if (act) {
             const int64_t left = a.n - tile * TA;
             const int cnt = left < TA ? (int)left : TA;
+#pragma unroll 2
             for (int i = 0; i < cnt; ++i) {
                 const float* xr = xt + (size_t)i * (D + 1) * RS + 2 * lane;
                 const float2 vfocal = *(const float2*)(xr + D * RS);
 #pragma unroll
                 for (int li = 0; li < LI; ++li) {
-                    const int l = wave + 4 * li;
+                    const int l = wave + NWV * li;
                     if (l < L) {
                         const float2 c = coef[(size_t)i * L + l];
                         const int pk = __float_as_int(c.y);
@@ -299,7 +316,7 @@ __global__ void __launch_bounds__(256) kc_backward_bank_lds(BwdArgs a) {
     const size_t o_sup = (size_t)L * a.F, o_edg = o_sup + (size_t)L * D * a.F;
 #pragma unroll
     for (int li = 0; li < LI; ++li) {
-        const int l = wave + 4 * li;
+        const int l = wave + NWV * li;
         if (l < L) {
             if (2 * lane < a.F) {
                 *(float2*)(slab + (size_t)l * a.F + 2 * lane) = acc[li][D];
@@ -325,7 +342,7 @@ bool lds_backward_supported(int d, int F, int E, int L, int64_t xs, const void* 
     if (d < 1 || d > 4 || L < 1 || E > 8 || (F & 1)) return false;
     const int FP = mfma_padded_width(F);
     if (!FP || xs % 4 != 0 || ((uintptr_t)x & 15)) return false;
-    if (L > 4 * bank_li(d) || 32 * L > 256 * rows_cq(d)) return false;
+    if (L > 8 * bank_li(d) || 32 * L > 256 * rows_cq(d)) return false;
     return rows_lds_bytes(d, FP, L) <= 160 * 1024 - 1024;
 }
 
@@ -363,7 +380,7 @@ static hipError_t launch_lds_bwd(const BwdArgs& a0, int* nchunk_out, int* ntheta
         int64_t blocks = BWD_BANK_BLOCKS;
         if (blocks > ntiles) blocks = ntiles;
         a.nchunk = (int)blocks;
-        kc_backward_bank_lds<D, KC, LI, TA><<<(int)blocks, 256, lds_bytes, st>>>(a);
+        kc_backward_bank_lds<D, KC, LI, TA><<<(int)blocks, 512, lds_bytes, st>>>(a);
         *nchunk_out = (int)blocks;
     }
     return hipGetLastError();

@@ -2,6 +2,7 @@
 // carving and kernel launches.  No allocation, no synchronisation.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "kgnn_launch.h"
@@ -36,6 +37,8 @@ struct DegreeStreams {
 static DegreeStreams g_streams[16];
 
 static DegreeStreams* degree_streams() {
+    static const bool serial = getenv("MKGNN_SERIAL") != nullptr;    // diagnostics: keep everything on one stream
+    if (serial) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     DegreeStreams& p = g_streams[dev];

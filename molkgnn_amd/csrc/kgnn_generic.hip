@@ -402,8 +402,9 @@ __global__ void __launch_bounds__(256) kc_backward_bank_reduce(BankReduceArgs a)
     }
 }
 
-// B3: per atom, sum the contribution rows that point at it and undo the row
-// normalisation.  One wave per atom.
+// B3: per atom, sum the contribution rows that point at it (fixed CSR order -> reproducible) and
+// undo the row normalisation.  One wave per atom, two floats per lane; the row ids of the segment
+// are fetched first and all row loads issued together, so one atom costs ~2 memory round trips.
 __global__ void __launch_bounds__(256) kc_backward_gather(const float* __restrict__ contrib, const int32_t* __restrict__ rowptr,
                                                           const int32_t* __restrict__ rows, const float* __restrict__ x,
                                                           int64_t xs, const float* __restrict__ inv, int64_t n, int F,
@@ -411,29 +412,55 @@ __global__ void __launch_bounds__(256) kc_backward_gather(const float* __restric
     const int lane = threadIdx.x & 63;
     int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    constexpr int SEG = 8;                 // rows fetched per round (focal + up to 4 neighbour roles fit in one)
     for (int64_t j = wave; j < n; j += nwaves) {
         const int lo = rowptr[j], hi = rowptr[j + 1];
         const float iv = inv[j];
         const bool clamped = iv >= (1.f / MKGNN_EPS);
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};   // F <= 256
-        float dotp = 0.f;
+        for (int f0 = 0; f0 < F; f0 += 128) {
+            const int f = f0 + 2 * lane;
+            const bool two = f + 1 < F, one = f < F;
+            float2 acc = {0.f, 0.f};
+            for (int k0 = lo; k0 < hi; k0 += SEG) {
+                int rid[SEG];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int f = lane + 64 * t;
-            if (f < F) {
-                float s = 0.f;
-                for (int k = lo; k < hi; ++k) s += contrib[(size_t)rows[k] * F + f];
-                acc[t] = s;
-                dotp = fmaf(s, x[j * xs + f] * iv, dotp);
+                for (int u = 0; u < SEG; ++u) rid[u] = k0 + u < hi ? rows[k0 + u] : -1;
+                float2 v[SEG];
+#pragma unroll
+                for (int u = 0; u < SEG; ++u) {
+                    v[u] = float2{0.f, 0.f};
+                    if (rid[u] >= 0 && one) {
+                        const float* src = contrib + (size_t)rid[u] * F + f;
+                        if (two && ((F & 1) == 0)) v[u] = *(const float2*)src;
+                        else { v[u].x = src[0]; if (two) v[u].y = src[1]; }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < SEG; ++u) { acc.x += v[u].x; acc.y += v[u].y; }
             }
-        }
-        dotp = wave_sum(dotp);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int f = lane + 64 * t;
-            if (f < F) {
-                float u = x[j * xs + f] * iv;
-                gx[j * gxs + f] = clamped ? acc[t] * iv : (acc[t] - dotp * u) * iv;
+            float2 xv = {0.f, 0.f};
+            if (one) { xv.x = x[j * xs + f] * iv; if (two) xv.y = x[j * xs + f + 1] * iv; }
+            // the dot product spans the whole row; F <= 256 means at most two passes, handled by accumulating
+            float dotp = acc.x * xv.x + acc.y * xv.y;
+            if (F > 128) {
+                // second half of a wide row contributes to the same dot product: fetch it now
+                const int f2 = (f0 == 0 ? 128 : 0) + 2 * lane;
+                float2 a2 = {0.f, 0.f}, x2 = {0.f, 0.f};
+                if (f2 < F) {
+                    for (int k = lo; k < hi; ++k) {
+                        const float* src = contrib + (size_t)rows[k] * F + f2;
+                        a2.x += src[0];
+                        if (f2 + 1 < F) a2.y += src[1];
+                    }
+                    x2.x = x[j * xs + f2] * iv;
+                    if (f2 + 1 < F) x2.y = x[j * xs + f2 + 1] * iv;
+                }
+                dotp += a2.x * x2.x + a2.y * x2.y;
+            }
+            dotp = wave_sum(dotp);
+            if (one) {
+                gx[j * gxs + f] = clamped ? acc.x * iv : (acc.x - dotp * xv.x) * iv;
+                if (two) gx[j * gxs + f + 1] = clamped ? acc.y * iv : (acc.y - dotp * xv.y) * iv;
             }
         }
     }

@@ -448,6 +448,24 @@ extern "C" int mkgnn_debug_set_stamp_buffer(void* device_ptr) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buffer), &device_ptr, sizeof(void*));
 }
 
+// Measurement hook for bench.py: when enabled, every fused forward launch is bracketed by HIP
+// events on its own stream; the getter waits for the last one and returns its duration.
+static bool g_time_fused = false;
+static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
+extern "C" int mkgnn_debug_time_fused_forward(int enable) {
+    g_time_fused = enable != 0;
+    if (g_time_fused && !g_ev0) {
+        if (hipEventCreate(&g_ev0) != hipSuccess || hipEventCreate(&g_ev1) != hipSuccess) return 1;
+    }
+    return 0;
+}
+extern "C" float mkgnn_debug_last_fused_forward_ms(void) {
+    float ms = -1.f;
+    if (!g_ev0 || hipEventSynchronize(g_ev1) != hipSuccess) return -1.f;
+    if (hipEventElapsedTime(&ms, g_ev0, g_ev1) != hipSuccess) return -1.f;
+    return ms;
+}
+
 bool mfma_forward_supported(int d, int F, int E, int L) {
     if (d < 1 || d > 4 || L < 1 || E > 8) return false;
     const int FP = mfma_padded_width(F);
@@ -548,8 +566,10 @@ hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t 
         rows_equal_kernel<<<(int)blocks, 256, 0, st>>>(a.x, a.xs, a.deg[3].nei, a.deg[3].p_focal, a.deg[3].p_nei, a.deg[3].n, a.F,
                                                       (int8_t*)a.deg[3].eqflag, (int8_t*)a.deg[3].signflag);
     }
+    if (g_time_fused) hipEventRecord(g_ev0, st);
     if (KC == 2) kc_forward_fused<2><<<nb, 256, lds_bytes, st>>>(a);
     else kc_forward_fused<7><<<nb, 256, lds_bytes, st>>>(a);
+    if (g_time_fused) hipEventRecord(g_ev1, st);
     return hipGetLastError();
 }
 
