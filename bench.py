@@ -120,8 +120,9 @@ def main():
     from molkgnn_amd import functional as Fn
     from molkgnn_amd.plan import plan_from_data
     from molkgnn_amd.synthetic import ASSAY_SIZES, make_batch
-    from molkgnn_amd.train import GNNModel, configure_optimizer
+    from molkgnn_amd.train import GNNModel, configure_optimizer, tune_torch_backends
     _lib.load()
+    tune_torch_backends()
     dp.init_process_group_from_env("nccl")
 
     torch.manual_seed(1798)                       # same initial weights on every rank
