@@ -347,7 +347,7 @@ bool lds_backward_supported(int d, int F, int E, int L, int64_t xs, const void* 
 }
 
 template <int D, int KC>
-static hipError_t launch_lds_bwd(const BwdArgs& a0, int* nchunk_out, int* ntheta_out, hipStream_t st) {
+static hipError_t launch_lds_bwd(const BwdArgs& a0, int* nchunk_out, int* ntheta_out, bool rows_too, hipStream_t st) {
     constexpr int FP = 16 * KC;
     constexpr int LI = bank_li(D);
     constexpr int TA = bank_ta(D);
@@ -362,7 +362,7 @@ static hipError_t launch_lds_bwd(const BwdArgs& a0, int* nchunk_out, int* ntheta
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    {   // rows
+    if (rows_too) {   // rows (also the score-weight partials)
         const size_t lds_bytes = rows_lds_bytes(D, FP, a.L);
         const int64_t ntiles = (a.n + 31) / 32;
         int per_cu = (int)((160 * 1024) / (lds_bytes + 256));
@@ -386,21 +386,21 @@ static hipError_t launch_lds_bwd(const BwdArgs& a0, int* nchunk_out, int* ntheta
     return hipGetLastError();
 }
 
-hipError_t launch_backward_lds(int d, const BwdArgs& a, int* nchunk_out, int* ntheta_out, hipStream_t st) {
+hipError_t launch_backward_lds(int d, const BwdArgs& a, int* nchunk_out, int* ntheta_out, bool rows_too, hipStream_t st) {
     const int KC = mfma_padded_width(a.F) / 16;
     if (KC == 2) {
         switch (d) {
-            case 1: return launch_lds_bwd<1, 2>(a, nchunk_out, ntheta_out, st);
-            case 2: return launch_lds_bwd<2, 2>(a, nchunk_out, ntheta_out, st);
-            case 3: return launch_lds_bwd<3, 2>(a, nchunk_out, ntheta_out, st);
-            default: return launch_lds_bwd<4, 2>(a, nchunk_out, ntheta_out, st);
+            case 1: return launch_lds_bwd<1, 2>(a, nchunk_out, ntheta_out, rows_too, st);
+            case 2: return launch_lds_bwd<2, 2>(a, nchunk_out, ntheta_out, rows_too, st);
+            case 3: return launch_lds_bwd<3, 2>(a, nchunk_out, ntheta_out, rows_too, st);
+            default: return launch_lds_bwd<4, 2>(a, nchunk_out, ntheta_out, rows_too, st);
         }
     }
     switch (d) {
-        case 1: return launch_lds_bwd<1, 7>(a, nchunk_out, ntheta_out, st);
-        case 2: return launch_lds_bwd<2, 7>(a, nchunk_out, ntheta_out, st);
-        case 3: return launch_lds_bwd<3, 7>(a, nchunk_out, ntheta_out, st);
-        default: return launch_lds_bwd<4, 7>(a, nchunk_out, ntheta_out, st);
+        case 1: return launch_lds_bwd<1, 7>(a, nchunk_out, ntheta_out, rows_too, st);
+        case 2: return launch_lds_bwd<2, 7>(a, nchunk_out, ntheta_out, rows_too, st);
+        case 3: return launch_lds_bwd<3, 7>(a, nchunk_out, ntheta_out, rows_too, st);
+        default: return launch_lds_bwd<4, 7>(a, nchunk_out, ntheta_out, rows_too, st);
     }
 }
 

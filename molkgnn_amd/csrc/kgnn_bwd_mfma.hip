@@ -1,0 +1,216 @@
+// MFMA backward kernel of the kernel convolution (gfx950, exact-fp32 v_mfma_f32_16x16x4_f32):
+// the gradient with respect to the unit feature rows.
+//
+// It is a contraction with a 0/1-masked coefficient matrix
+//     P_sb[n, l] = coef[n, l]  if the chosen permutation of (kernel l, atom n) matched neighbour
+//                              slot s to support b, else 0          (coef = dL/dsc * w_s / (W d))
+//   rows:  g_xhat[n, slot s, :] = sum_b sum_l P_sb[n, l] * unit_support[l, b, :]     (K = kernels)
+// (plus the centre rows with coef * w_c d / w_s).  Written densely it costs d times the sparse FMA
+// count, but it runs on the matrix pipe with the masked operand built in registers (one v_cndmask
+// per MFMA) instead of one LDS read per two FMAs: measured 130 us against 185 us per N-hop layer
+// (batch 4096) for the LDS/VALU kernel of kgnn_bwd.hip, which stays as the fallback for wider
+// kernel banks.  The transposed product (bank gradients, K = atoms) was built the same way and
+// measured SLOWER than the LDS/VALU bank kernel at these sizes (291 us vs 227 us: its per-tile
+// operand gathers dominate), so the bank gradients stay on kc_backward_bank_lds.
+//
+// Like the forward, the kernel is wave-autonomous: no block barrier after the one-time bank copy;
+// every coefficient comes straight from global memory in MFMA operand layout.  All loads are
+// unconditional on clamped addresses and masked afterwards (a load under a lane-dependent branch
+// ends its basic block with a full wait and serialises the round trips).
+#include "kgnn_launch.h"
+
+namespace mkgnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ constexpr int bwd_lq(int d) { return d == 1 ? 3 : (d == 2 ? 5 : (d == 3 ? 8 : 13)); }   // 4-kernel groups held per lane
+
+// ------------------------------------------------------------------ rows ---
+// M = 16 atoms, N = 16 features (FT tiles), K = kernels.  A = masked coefficients (registers),
+// B = unit kernel rows (LDS, b32 reads, conflict-free), D = contribution rows.
+// Also accumulates the three score-weight partials (d sc / d theta_k = w_k (score_k - sc) / W).
+template <int D, int KC, int NT>
+__global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(BwdArgs a) {
+    constexpr int FP = 16 * KC;
+    constexpr int FT = KC;                           // 16-feature tiles
+    constexpr int LQ = bwd_lq(D);
+    constexpr int NWV = NT / 64;
+    extern __shared__ __align__(16) float lds[];
+    __shared__ float red[3][NWV];
+    const int L = a.L;
+    float* bank = lds;                               // [(D+1)*L][FP], row b*L + l; rows D*L + l = centres
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ci = lane & 15, kq = lane >> 4;
+    for (int base = 0; base < (D + 1) * L * FP / 4; base += NT * 8) {
+        f32x4 tmp[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = base + tid + NT * k;
+            if (q < (D + 1) * L * FP / 4) tmp[k] = *(const f32x4*)(a.padded + 4 * (size_t)q);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = base + tid + NT * k;
+            if (q < (D + 1) * L * FP / 4) *(f32x4*)(bank + 4 * (size_t)q) = tmp[k];
+        }
+    }
+    __syncthreads();
+    const float w_s = a.mix[0], w_c = a.mix[1], w_e = a.mix[2], w_sum = a.mix[3];
+    const float ws_n = w_s / w_sum / (float)D;
+    const float ratio_c = w_c * (float)D / w_s;
+    const int64_t ntiles = (a.n + 15) / 16;
+    const size_t ln = (size_t)L * a.n;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    for (int64_t tile = (int64_t)blockIdx.x * NWV + wave; tile < ntiles; tile += (int64_t)gridDim.x * NWV) {
+        // ---- coefficients of atom row ci, kernels 4*kk + kq
+        const int64_t n = tile * 16 + ci;
+        const bool row_ok = n < a.n;
+        const int64_t focal = a.sel[row_ok ? n : a.n - 1];
+        // Loads are unconditional on clamped addresses and masked afterwards: a load under a lane-dependent
+        // branch ends its own basic block with a full wait, which serialises the round trips.
+        const int64_t nc = row_ok ? n : a.n - 1;
+        float c[LQ];
+        int pk[LQ];
+        float rg[LQ], rS[LQ], rC[LQ], rE[LQ];
+        int ridx[LQ], rch[LQ];
+#pragma unroll
+        for (int kk = 0; kk < LQ; ++kk) {
+            const int l = 4 * kk + kq < L ? 4 * kk + kq : L - 1;
+            rg[kk] = a.gout[focal * a.gs + a.off + l];
+            rch[kk] = 1;
+            ridx[kk] = a.best[(size_t)nc * L + l];
+            rS[kk] = a.scores[(size_t)nc * L + l];
+            rC[kk] = a.scores[ln + (size_t)nc * L + l];
+            rE[kk] = a.scores[2 * ln + (size_t)nc * L + l];
+        }
+        if (a.chir) {                                 // one uniform branch for all the sign loads
+#pragma unroll
+            for (int kk = 0; kk < LQ; ++kk) rch[kk] = (int)a.chir[(size_t)nc * L + (4 * kk + kq < L ? 4 * kk + kq : L - 1)];
+        }
+#pragma unroll
+        for (int kk = 0; kk < LQ; ++kk) {
+            const bool ok = row_ok && (4 * kk + kq < L);
+            const float g = ok ? rg[kk] * (float)rch[kk] : 0.f;
+            int bits = 0;
+#pragma unroll
+            for (int s = 0; s < D; ++s) bits |= perm_at<D>(ridx[kk], s) << (2 * s);
+            pk[kk] = bits;
+            c[kk] = g * ws_n;
+            const float sc = (rS[kk] * w_s + rC[kk] * w_c + rE[kk] * w_e) / w_sum;
+            p0 = fmaf(g * (w_s / w_sum), rS[kk] - sc, p0);
+            p1 = fmaf(g * (w_c / w_sum), rC[kk] - sc, p1);
+            p2 = fmaf(g * (w_e / w_sum), rE[kk] - sc, p2);
+        }
+        f32x4 acc[D + 1][FT];                        // slot 0 = focal, 1 + s = neighbour s
+#pragma unroll
+        for (int s = 0; s <= D; ++s)
+#pragma unroll
+            for (int ft = 0; ft < FT; ++ft) acc[s][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < LQ; ++kk) {
+            if (4 * kk < L) {                        // wave-uniform
+                const int l = 4 * kk + kq < L ? 4 * kk + kq : L - 1;
+                const float* brow = bank + (size_t)l * FP + ci;
+                {   // centre rows -> focal slot
+                    const float av = c[kk] * ratio_c;
+#pragma unroll
+                    for (int ft = 0; ft < FT; ++ft)
+                        acc[0][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, brow[(size_t)D * L * FP + 16 * ft], acc[0][ft], 0, 0, 0);
+                }
+#pragma unroll
+                for (int b = 0; b < D; ++b) {
+                    float av[D];
+#pragma unroll
+                    for (int s = 0; s < D; ++s) av[s] = (((pk[kk] >> (2 * s)) & 3) == b) ? c[kk] : 0.f;
+#pragma unroll
+                    for (int ft = 0; ft < FT; ++ft) {
+                        const float bv = brow[(size_t)b * L * FP + 16 * ft];
+#pragma unroll
+                        for (int s = 0; s < D; ++s)
+                            acc[1 + s][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv, acc[1 + s][ft], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        // ---- contribution rows: lane holds atoms kq*4 + jj, feature 16*ft + ci
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int64_t nn = tile * 16 + kq * 4 + jj;
+            if (nn < a.n) {
+                float* dst = a.contrib + (size_t)(a.contrib_base + nn * (D + 1)) * a.F + ci;
+                const bool last_ok = 16 * (FT - 1) + ci < a.F;     // only the last feature tile can be partial
+#pragma unroll
+                for (int s = 0; s <= D; ++s) {
+#pragma unroll
+                    for (int ft = 0; ft < FT - 1; ++ft) dst[(size_t)s * a.F + 16 * ft] = acc[s][ft][jj];
+                    if (last_ok) dst[(size_t)s * a.F + 16 * (FT - 1)] = acc[s][FT - 1][jj];
+                }
+            }
+        }
+    }
+    p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
+    if (lane == 0) { red[0][wave] = p0; red[1][wave] = p1; red[2][wave] = p2; }
+    __syncthreads();
+    if (tid < 3) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) s += red[tid][w];
+        a.theta_slab[(size_t)blockIdx.x * 4 + tid] = s;
+    }
+}
+
+// ------------------------------------------------------------------ host ---
+bool mfma_backward_supported(int d, int F, int E, int L, int64_t xs, const void* x, int64_t n_atoms) {
+    if (d < 1 || d > 4 || L < 1 || E > 8) return false;
+    const int FP = mfma_padded_width(F);
+    if (!FP || xs % 4 != 0 || ((uintptr_t)x & 15)) return false;
+    if ((uint64_t)n_atoms * (uint64_t)xs >= (1ull << 32)) return false;
+    if (L > 4 * bwd_lq(d)) return false;
+    return ((size_t)(d + 1) * L * FP) * 4 <= 150 * 1024;
+}
+
+template <int D, int KC>
+static hipError_t launch_mfma_rows(const BwdArgs& a, int* ntheta_out, hipStream_t st) {
+    constexpr int FP = 16 * KC;
+    constexpr int NT = 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kc_backward_rows_mfma<D, KC, NT>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int64_t ntiles = (a.n + 15) / 16;
+    const size_t lds_bytes = (size_t)(D + 1) * a.L * FP * 4;
+    int per_cu = (int)((160 * 1024 - 2048) / (lds_bytes + 256));
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 2) per_cu = 2;
+    constexpr int NWV = NT / 64;
+    int64_t blocks = 256 * per_cu;
+    const int64_t need = (ntiles + NWV - 1) / NWV;
+    if (blocks > need) blocks = need;
+    if (blocks > THETA_SLAB_BLOCKS) blocks = THETA_SLAB_BLOCKS;
+    kc_backward_rows_mfma<D, KC, NT><<<(int)blocks, NT, lds_bytes, st>>>(a);
+    *ntheta_out = (int)blocks;
+    return hipGetLastError();
+}
+
+hipError_t launch_backward_rows_mfma(int d, const BwdArgs& a, int* ntheta_out, hipStream_t st) {
+    const int KC = mfma_padded_width(a.F) / 16;
+    if (KC == 2) {
+        switch (d) {
+            case 1: return launch_mfma_rows<1, 2>(a, ntheta_out, st);
+            case 2: return launch_mfma_rows<2, 2>(a, ntheta_out, st);
+            case 3: return launch_mfma_rows<3, 2>(a, ntheta_out, st);
+            default: return launch_mfma_rows<4, 2>(a, ntheta_out, st);
+        }
+    }
+    switch (d) {
+        case 1: return launch_mfma_rows<1, 7>(a, ntheta_out, st);
+        case 2: return launch_mfma_rows<2, 7>(a, ntheta_out, st);
+        case 3: return launch_mfma_rows<3, 7>(a, ntheta_out, st);
+        default: return launch_mfma_rows<4, 7>(a, ntheta_out, st);
+    }
+}
+
+}  // namespace mkgnn

@@ -285,7 +285,15 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         int nchunk = a.n > 0 ? a.nchunk : 0;
         int ntheta = -1;
         if (a.n > 0 && L[i] > 0) {
-            if (lds_backward_supported(d, F, E, L[i], x_stride, x)) e = launch_backward_lds(d, a, &nchunk, &ntheta, dst);
+            static const bool no_mfma_bwd = getenv("MKGNN_NO_MFMA_BWD") != nullptr;     // diagnostics: A/B against the LDS rows kernel
+            if (lds_backward_supported(d, F, E, L[i], x_stride, x)) {
+                const bool rows_mfma = !no_mfma_bwd && mfma_backward_supported(d, F, E, L[i], x_stride, x, n_atoms);
+                if (rows_mfma) {
+                    e = launch_backward_rows_mfma(d, a, &ntheta, dst);
+                    if (e != hipSuccess) return hip_fail("kernelconv backward launch", e);
+                }
+                e = launch_backward_lds(d, a, &nchunk, &ntheta, !rows_mfma, dst);
+            }
             else e = launch_backward_generic(d, a, dst);
             if (e != hipSuccess) return hip_fail("kernelconv backward launch", e);
         }

@@ -91,7 +91,10 @@ hipError_t launch_backward_generic(int d, const BwdArgs& a, hipStream_t st);
 hipError_t launch_bank_reduce(int d, const BankReduceArgs& r, hipStream_t st);
 // kgnn_bwd.hip: LDS-tiled backward for the model's shapes
 bool lds_backward_supported(int d, int F, int E, int L, int64_t xs, const void* x);
-hipError_t launch_backward_lds(int d, const BwdArgs& a, int* nchunk_out, int* ntheta_out, hipStream_t st);
+hipError_t launch_backward_lds(int d, const BwdArgs& a, int* nchunk_out, int* ntheta_out, bool rows_too, hipStream_t st);
+// kgnn_bwd_mfma.hip: MFMA backward for the model's shapes
+bool mfma_backward_supported(int d, int F, int E, int L, int64_t xs, const void* x, int64_t n_atoms);
+hipError_t launch_backward_rows_mfma(int d, const BwdArgs& a, int* ntheta_out, hipStream_t st);
 hipError_t launch_backward_gather(const float* contrib, const int32_t* rowptr, const int32_t* rows, const float* x,
                                   int64_t xs, const float* inv, int64_t n, int F, float* gx, int64_t gxs,
                                   hipStream_t st);

@@ -164,8 +164,12 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
 #pragma unroll
         for (int s = 0; s < D; ++s) {
             const float* e = dg.e_nei + (nrow * D + s) * a.E;
-            eraw[s].x = 2 * kq < a.E ? e[2 * kq] : 0.f;
-            eraw[s].y = 2 * kq + 1 < a.E ? e[2 * kq + 1] : 0.f;
+            // unconditional loads on clamped indices, masked afterwards (a load under a lane-dependent
+            // branch would end its basic block with a full wait)
+            const float r0 = e[2 * kq < a.E ? 2 * kq : a.E - 1];
+            const float r1 = e[2 * kq + 1 < a.E ? 2 * kq + 1 : a.E - 1];
+            eraw[s].x = 2 * kq < a.E ? r0 : 0.f;
+            eraw[s].y = 2 * kq + 1 < a.E ? r1 : 0.f;
         }
         if constexpr (D == 4) {
             if (do_chir) {
@@ -180,13 +184,12 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
         for (int t = 0; t < KC - 1; ++t) dst[t] = *(const f32x4*)(row + 16 * t);
         {   // only the last chunk can reach beyond the row's width (host guarantees FP - 16 < F <= FP)
             const int f0 = 16 * (KC - 1) + 4 * kq;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (f0 < a.F) {
-                v = *(const f32x4*)(row + 16 * (KC - 1));
-                if (f0 + 1 >= a.F) v.y = 0.f;
-                if (f0 + 2 >= a.F) v.z = 0.f;
-                if (f0 + 3 >= a.F) v.w = 0.f;
-            }
+            // clamped (the chunk before) so that the load itself is unconditional
+            f32x4 v = *(const f32x4*)(row + (f0 < a.F ? 16 * (KC - 1) : 16 * (KC - 1) - 4 * kq));
+            if (f0 >= a.F) v.x = 0.f;
+            if (f0 + 1 >= a.F) v.y = 0.f;
+            if (f0 + 2 >= a.F) v.z = 0.f;
+            if (f0 + 3 >= a.F) v.w = 0.f;
             dst[KC - 1] = v;
         }
         dinv = a.inv[id];
