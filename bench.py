@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--variant", default="auto", choices=["auto", "generic", "mfma"])
     ap.add_argument("--distinct-batches", type=int, default=4, help="distinct resident batches cycled through")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+backward(+all-reduce) only")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying one hipGraph per resident batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--roofline-reps", type=int, default=20)
@@ -122,14 +123,15 @@ def main():
     from molkgnn_amd.synthetic import ASSAY_SIZES, make_batch
     from molkgnn_amd.train import GNNModel, configure_optimizer, tune_torch_backends
     _lib.load()
-    tune_torch_backends()
+    if not os.environ.get("MKGNN_NO_TUNE"):
+        tune_torch_backends()
     dp.init_process_group_from_env("nccl")
 
     torch.manual_seed(1798)                       # same initial weights on every rank
     model = GNNModel().to(dev)
     model.gnn_model.gnn.set_variant(args.variant)
     model.train()
-    opt = None if args.no_optimizer else configure_optimizer(model, lr=1e-3)
+    opt = None if args.no_optimizer else configure_optimizer(model, lr=1e-3, capturable=not args.no_graph)
     reducer = dp.FlatGradAllReduce(model.parameters(), dp.NEVER_TRAINED + ("lin1", "lin2"),
                                    [n for n, _ in model.named_parameters()])
 
@@ -139,10 +141,11 @@ def main():
     batches = []
     for i in range(nb):
         b = make_batch(args.batch_size, seed=int(args.assay) * 1000 + i * world + rank, assay=args.assay).to(dev)
-        plan = plan_from_data(b)
-        _ = plan.scatter, plan.csr_in, plan.csr_out      # index plans are part of the resident input
         batches.append(b)
     atoms = sum(b.x.shape[0] for b in batches) / nb
+    with torch.no_grad():                                 # index plans (sorted CSRs) are part of the resident input
+        for b in batches:
+            model(b)
     torch.cuda.synchronize()
 
     def step(i):
@@ -159,7 +162,50 @@ def main():
         if rank == 0:
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
-    log(f"{nb} resident batches of {args.batch_size} molecules ({atoms:.0f} atoms each); warmup")
+    # One hipGraph per resident batch: forward + backward + optimiser are launch-bound at this model size
+    # (~250 kernels of 5-100 us), so the step is captured once and replayed.  The gradient all-reduce
+    # (N > 1) stays outside the graph, between the backward graph and the optimiser.
+    graphs = None
+    if not args.no_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for i in range(3):                   # warm every lazy initialisation on the capture stream
+                    step(i)
+                graphs = []
+                for i in range(nb):
+                    model.zero_grad(set_to_none=True)
+                    g_fb = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g_fb, stream=side):
+                        static_loss = model.loss(batches[i])
+                        static_loss.backward()
+                        if opt is not None and world == 1:
+                            opt.step()
+                    g_opt = None
+                    if opt is not None and world > 1:    # the all-reduce sits between backward and optimiser
+                        g_opt = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g_opt, stream=side):
+                            opt.step()
+                    graphs.append((g_fb, g_opt, static_loss))
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+        except Exception as exc:                     # capture is an optimisation, never a requirement
+            log(f"hipGraph capture unavailable ({type(exc).__name__}: {str(exc).splitlines()[0]}); running eagerly")
+            graphs = None
+            torch.cuda.synchronize()
+
+    if graphs is not None:
+        def step(i):                                 # noqa: F811  (replay form of the same step)
+            g_fb, g_opt, loss = graphs[i % nb]
+            g_fb.replay()
+            reducer.reduce()
+            if g_opt is not None:
+                g_opt.replay()
+            return loss
+
+    log(f"{nb} resident batches of {args.batch_size} molecules ({atoms:.0f} atoms each); "
+        f"{'hipGraph replay' if graphs is not None else 'eager launches'}; warmup")
     for i in range(args.warmup):
         step(i)
     torch.cuda.synchronize()
@@ -241,7 +287,8 @@ def main():
                                       f"edges each), 3 layers, hidden_dim 32, kernels 10/20/30/50 per degree, "
                                       f"batch {args.batch_size} molecules per GPU ({atoms:.0f} atoms), "
                                       f"{nb} resident batches cycled, fwd+bwd"
-                                      + ("" if args.no_optimizer else "+AdamW") + (", grad all-reduce" if world > 1 else ""),
+                                      + ("" if args.no_optimizer else "+AdamW") + (", grad all-reduce" if world > 1 else "")
+                                      + (", one hipGraph per batch" if graphs is not None else ", eager launches"),
                           "variant": args.variant, "batch_size_per_gpu": args.batch_size,
                           "parallelism": f"dp{world}"},
                "roofline": roofline}

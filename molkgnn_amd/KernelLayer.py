@@ -12,7 +12,7 @@ from torch.nn import ModuleList
 
 from . import functional as Fn
 from .kernels import KernelSetConv
-from .plan import plan_from_lists
+from .plan import plan_from_lists, plan_from_lists_cached
 from .receptive_field import GraphBatch
 
 try:
@@ -94,7 +94,7 @@ class MolGCN(MessagePassing):
         data = Data(x=x, p=kwargv['p'], edge_index=edge_index, edge_attr=kwargv['edge_attr'], **fields)
         save_score = kwargv['save_score']
         # one index plan per batch, shared by every layer and by propagate
-        self._plan = plan_from_lists(
+        self._plan = plan_from_lists_cached(
             x.shape[0], *[[fields[f'{nm}_deg{d}'] for d in range(1, 5)] for nm in names], edge_index)
         h = x
         try:

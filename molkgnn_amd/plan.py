@@ -108,6 +108,37 @@ def plan_from_lists(n_atoms, p_focal_list, nei_p_list, nei_edge_attr_list, selec
 
 
 _PLAN_ATTR = "_mkgnn_plan"
+_PLAN_CACHE: "dict" = {}
+_PLAN_CACHE_MAX = 32
+
+
+def plan_from_lists_cached(n_atoms, p_focal_list, nei_p_list, nei_edge_attr_list, selected_index_list, nei_index_list,
+                           edge_index=None) -> BatchPlan:
+    """``plan_from_lists`` memoised on the identity (storage address, length, device) of the index tensors.
+
+    ``MolGCN.forward`` receives the per-degree tensors as separate keyword arguments (the reference's
+    signature, KernelLayer.py:53-87), so the batch object that would carry a cached plan is not
+    visible there; resident batches keep their tensors alive, which makes the addresses a stable key.
+    The plan's sorts run once per batch instead of once per step, and a step contains no
+    host-synchronising call any more (required for hipGraph capture).
+    """
+    def ident(t):
+        return None if t is None else (t.data_ptr(), t.numel(), str(t.device))
+    key = (int(n_atoms), tuple(ident(t) for t in selected_index_list), tuple(ident(t) for t in nei_index_list),
+           tuple(ident(t) for t in nei_edge_attr_list), ident(edge_index))
+    plan = _PLAN_CACHE.get(key)
+    if plan is None:
+        plan = plan_from_lists(n_atoms, p_focal_list, nei_p_list, nei_edge_attr_list, selected_index_list,
+                               nei_index_list, edge_index)
+        # build every index structure now: the lazy properties sort (and synchronise), which must not
+        # happen inside a later backward pass or a hipGraph capture
+        _ = plan.scatter
+        if edge_index is not None:
+            _ = plan.csr_in, plan.csr_out
+        if len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
+            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+        _PLAN_CACHE[key] = plan
+    return plan
 
 
 def plan_from_data(data) -> BatchPlan:

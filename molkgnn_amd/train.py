@@ -52,7 +52,8 @@ def tune_torch_backends() -> None:
         pass
 
 
-def configure_optimizer(model: torch.nn.Module, weight_decay: float = 0.0, lr: float = 1e-3, fused: Optional[bool] = None):
+def configure_optimizer(model: torch.nn.Module, weight_decay: float = 0.0, lr: float = 1e-3, fused: Optional[bool] = None,
+                        capturable: bool = False):
     """AdamW with the kernel parameters exempt from weight decay, selected by name (model.py:373-382)."""
     decay, nodecay = [], []
     for name, p in model.named_parameters():
@@ -67,4 +68,6 @@ def configure_optimizer(model: torch.nn.Module, weight_decay: float = 0.0, lr: f
         fused = all(p.is_cuda for p in model.parameters())
     if fused:
         kw["fused"] = True
+    if capturable:
+        kw["capturable"] = True          # step counters live on the device: the step can be replayed from a hipGraph
     return torch.optim.AdamW(groups, lr=lr, **kw)
