@@ -114,6 +114,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path for the HIP kernels)")
+    local_rank %= max(1, torch.cuda.device_count())      # (rehearsals put several ranks on one card)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -125,7 +126,7 @@ def main():
     _lib.load()
     if not os.environ.get("MKGNN_NO_TUNE"):
         tune_torch_backends()
-    dp.init_process_group_from_env("nccl")
+    dp.init_process_group_from_env(os.environ.get("MKGNN_DIST_BACKEND", "nccl"))   # nccl = RCCL over xGMI
 
     torch.manual_seed(1798)                       # same initial weights on every rank
     model = GNNModel().to(dev)
@@ -166,6 +167,11 @@ def main():
     # (~250 kernels of 5-100 us), so the step is captured once and replayed.  The gradient all-reduce
     # (N > 1) stays outside the graph, between the backward graph and the optimiser.
     graphs = None
+    all_degrees = all(getattr(b, f"selected_index_deg{d}").numel() > 0 for b in batches for d in range(1, 5))
+    if world > 1 and not all_degrees:
+        # a rank whose batch lacks a degree gets that bank's gradients from the all-reduce only; a captured
+        # optimiser step would not see them, so such (tiny) batches run eagerly
+        args.no_graph = True
     if not args.no_graph:
         try:
             side = torch.cuda.Stream()

@@ -56,6 +56,7 @@ class FlatGradAllReduce:
             self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self._filled: List[torch.nn.Parameter] = []
 
     @property
     def nbytes(self) -> int:
@@ -65,17 +66,21 @@ class FlatGradAllReduce:
         """Call after backward: afterwards every ``p.grad`` holds the mean over ranks."""
         if self.world == 1:
             return
+        for p in self._filled:                       # gradients this object created last time are not this step's
+            p.grad = None
+        self._filled = []
         have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
         self.flat.zero_()
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
         self.flat.mul_(1.0 / self.world)
+        if have:                                     # back into the (possibly graph-static) gradient tensors
+            torch._foreach_copy_([g for _, g in have], [v for v, _ in have])
         for v, p in zip(self.views, self.params):
-            if p.grad is None:
+            if p.grad is None:                       # e.g. a degree absent from this rank's batch
                 p.grad = v.clone()
-            else:
-                p.grad.copy_(v)
+                self._filled.append(p)
 
 
 # parameter-name fragments that never receive a gradient in the reference's model (SURVEY 8 a-9)
