@@ -20,6 +20,7 @@
 namespace mkgnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __host__ __device__ constexpr int bank_li(int d) { return d == 1 ? 2 : (d == 2 ? 3 : (d == 3 ? 4 : 7)); }     // kernels per wave (8 waves)
 __host__ __device__ constexpr int rows_cq(int d) { return d == 1 ? 2 : (d == 2 ? 3 : (d == 3 ? 4 : 7)); }    // coefficient pairs per thread
@@ -168,19 +169,25 @@ __global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int L = a.L;
     float* xt = lds;                                        // [NROW][RS]
-    float2* coef = (float2*)(lds + NROW * RS);              // [TA][L] {g*ws/(W*D), packed inverse pi}
-    int* idbuf = (int*)(coef + (size_t)TA * L);             // [2][NROW] atom ids
+    // per (atom, kernel): {g*ws/(W*D), byte offset of the tile row matched to support 0, 1, ..}; the offsets
+    // are precomputed here so that the accumulate loop is add + ds_read + packed FMA per support
+    constexpr int CW = (D == 1) ? 2 : ((D == 4) ? 8 : 4);   // floats per entry (D + 1 rounded up for aligned wide reads)
+    // kernels padded to LP = NWV*LI per atom; the padding entries stay zero, so the accumulate loop needs no
+    // bounds branch (a branch inside the unrolled loop would end each block with a full LDS wait)
+    constexpr int LP = NWV * LI;
+    float* coef = lds + NROW * RS;                          // [TA][LP][CW]
+    int* idbuf = (int*)(coef + (size_t)TA * LP * CW);       // [2][NROW] atom ids
     float* invbuf = (float*)(idbuf + 2 * NROW);             // [2][NROW] 1/|x|
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float w_s = a.mix[0], w_c = a.mix[1], w_e = a.mix[2], w_sum = a.mix[3];
     const float ws_n = w_s / w_sum / (float)D;
     const float ratio_c = w_c * (float)D / w_s;
     const float ratio_e = w_e / w_s;
-    float2 acc[LI][D + 1];
+    f32x2 acc[LI][D + 1];                           // two features per lane, packed-FMA friendly
 #pragma unroll
     for (int li = 0; li < LI; ++li)
 #pragma unroll
-        for (int s = 0; s <= D; ++s) acc[li][s] = float2{0.f, 0.f};
+        for (int s = 0; s <= D; ++s) acc[li][s] = f32x2{0.f, 0.f};
     const int64_t ntiles = (a.n + TA - 1) / TA;
     const bool feat = 2 * lane < FP;
     const bool act = 2 * lane < RS;
@@ -201,42 +208,64 @@ __global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
     float ev[8];
     auto fetch = [&](int64_t tile, int buf) {
 #pragma unroll
+        // every load below is unconditional on a clamped address and masked afterwards: a load under a
+        // lane-dependent branch ends its basic block with a full wait and serialises the round trips
         for (int k = 0; k < MAXQ; ++k) {
             const int q = tid + NT * k;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (q < NROW * CH) {
-                const int row = q / CH, c = q - row * CH;
-                if (4 * c < a.F) {
-                    v = *(const f32x4*)(a.x + (size_t)idbuf[buf * NROW + row] * a.xs + 4 * c);
-                    if (4 * c + 1 >= a.F) v.y = 0.f;
-                    if (4 * c + 2 >= a.F) v.z = 0.f;
-                    if (4 * c + 3 >= a.F) v.w = 0.f;
-                }
-            }
+            const int qc = q < NROW * CH ? q : NROW * CH - 1;
+            const int row = qc / CH, c = qc - row * CH;
+            const int cc = 4 * c < a.F ? c : 0;
+            f32x4 v = *(const f32x4*)(a.x + (size_t)idbuf[buf * NROW + row] * a.xs + 4 * cc);
+            if (4 * c >= a.F) v.x = 0.f;
+            if (4 * c + 1 >= a.F) v.y = 0.f;
+            if (4 * c + 2 >= a.F) v.z = 0.f;
+            if (4 * c + 3 >= a.F) v.w = 0.f;
             stage[k] = v;
+        }
+        float rch[CQ];
+#pragma unroll
+        for (int k = 0; k < CQ; ++k) {
+            const int q = tid + NT * k;
+            const int qc = q < TA * L ? q : TA * L - 1;
+            const int i = qc / L, l = qc - i * L;
+            int64_t n = tile * TA + i;
+            if (n >= a.n) n = a.n - 1;
+            rg[k] = a.gout[(int64_t)idbuf[buf * NROW + i * (D + 1) + D] * a.gs + a.off + l];
+            ridx[k] = a.best[(size_t)n * L + l];
+            rch[k] = 1.f;
+        }
+        if (a.chir) {                                // one uniform branch for all the sign loads
+#pragma unroll
+            for (int k = 0; k < CQ; ++k) {
+                const int q = tid + NT * k;
+                const int qc = q < TA * L ? q : TA * L - 1;
+                const int i = qc / L, l = qc - i * L;
+                int64_t n = tile * TA + i;
+                if (n >= a.n) n = a.n - 1;
+                rch[k] = (float)a.chir[(size_t)n * L + l];
+            }
         }
 #pragma unroll
         for (int k = 0; k < CQ; ++k) {
             const int q = tid + NT * k;
-            const int i = q / L, l = q - i * L;
-            const int64_t n = tile * TA + i;
-            rg[k] = 0.f; ridx[k] = 0;
-            if (q < TA * L && n < a.n) {
-                float g = a.gout[(int64_t)idbuf[buf * NROW + i * (D + 1) + D] * a.gs + a.off + l];
-                if (a.chir) g *= (float)a.chir[(size_t)n * L + l];
-                rg[k] = g;
-                ridx[k] = a.best[(size_t)n * L + l];
-            }
+            const int i = q / L;
+            const bool ok = q < TA * L && tile * TA + i < a.n;
+            rg[k] = ok ? rg[k] * rch[k] : 0.f;
         }
-        if (tid < TA * D) {                          // bond vectors of (atom, slot)
-            const int i = tid / D, slot = tid - i * D;
+        {                                            // bond vectors of (atom, slot); threads beyond TA*D re-read the last one
+            const int t = tid < TA * D ? tid : TA * D - 1;
+            const int i = t / D, slot = t - i * D;
             int64_t n = tile * TA + i;
             if (n >= a.n) n = a.n - 1;
             const float* e = a.e_nei + (n * D + slot) * a.E;
 #pragma unroll
-            for (int k = 0; k < 8; ++k) ev[k] = k < a.E ? e[k] : 0.f;
+            for (int k = 0; k < 8; ++k) {
+                const float r = e[k < a.E ? k : a.E - 1];
+                ev[k] = k < a.E ? r : 0.f;
+            }
         }
     };
+    for (int q = tid; q < TA * LP * CW; q += NT) coef[q] = 0.f;
     int64_t tile = blockIdx.x;
     int buf = 0;
     load_ids(tile, 0);
@@ -271,10 +300,11 @@ __global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
         for (int k = 0; k < CQ; ++k) {
             const int q = tid + NT * k;
             if (q < TA * L) {
-                int pk = 0;                          // for support b: the neighbour slot matched to it
+                float* ce = coef + ((size_t)(q / L) * LP + (q % L)) * CW;
+                ce[0] = rg[k] * ws_n;
 #pragma unroll
-                for (int s = 0; s < D; ++s) pk |= s << (2 * perm_at<D>(ridx[k], s));
-                coef[q] = float2{rg[k] * ws_n, __int_as_float(pk)};
+                for (int s = 0; s < D; ++s)          // support pi(s) takes the row of neighbour slot s
+                    ce[1 + perm_at<D>(ridx[k], s)] = __int_as_float(s * RS * 4);
             }
         }
         __syncthreads();
@@ -283,28 +313,34 @@ __global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
         if (act) {
             const int64_t left = a.n - tile * TA;
             const int cnt = left < TA ? (int)left : TA;
-#pragma unroll 2
+            const float lane_mul = feat ? 1.f : ratio_e;       // bond columns carry w_e / w_s
+#pragma unroll 1
             for (int i = 0; i < cnt; ++i) {
-                const float* xr = xt + (size_t)i * (D + 1) * RS + 2 * lane;
-                const float2 vfocal = *(const float2*)(xr + D * RS);
+                const char* xr = (const char*)(xt + (size_t)i * (D + 1) * RS + 2 * lane);
+                // phase 1: every coefficient entry of this atom (LI broadcast reads in flight together)
+                float cv[LI][D + 1];
 #pragma unroll
                 for (int li = 0; li < LI; ++li) {
-                    const int l = wave + NWV * li;
-                    if (l < L) {
-                        const float2 c = coef[(size_t)i * L + l];
-                        const int pk = __float_as_int(c.y);
-                        const float cc = feat ? c.x : c.x * ratio_e;
-                        const float gc = c.x * ratio_c;
-                        acc[li][D].x = fmaf(gc, vfocal.x, acc[li][D].x);
-                        acc[li][D].y = fmaf(gc, vfocal.y, acc[li][D].y);
+                    const float* ce = coef + ((size_t)i * LP + wave + NWV * li) * CW;
+                    if constexpr (D == 1) { const f32x2 t = *(const f32x2*)ce; cv[li][0] = t.x; cv[li][1] = t.y; }
+                    else if constexpr (D == 3) { const f32x4 t = *(const f32x4*)ce; cv[li][0] = t.x; cv[li][1] = t.y; cv[li][2] = t.z; cv[li][3] = t.w; }
+                    else if constexpr (D == 2) { const f32x4 t = *(const f32x4*)ce; cv[li][0] = t.x; cv[li][1] = t.y; cv[li][2] = t.z; }
+                    else { const f32x4 t = *(const f32x4*)ce; const float t4 = ce[4]; cv[li][0] = t.x; cv[li][1] = t.y; cv[li][2] = t.z; cv[li][3] = t.w; cv[li][4] = t4; }
+                }
+                const f32x2 vfocal = *(const f32x2*)(xr + D * RS * 4);
+                // phase 2: all LI * D row reads, addresses straight from the entries
+                f32x2 vv[LI][D];
 #pragma unroll
-                        for (int b = 0; b < D; ++b) {
-                            const int slot = (pk >> (2 * b)) & 3;
-                            const float2 v = *(const float2*)(xr + slot * RS);
-                            acc[li][b].x = fmaf(cc, v.x, acc[li][b].x);
-                            acc[li][b].y = fmaf(cc, v.y, acc[li][b].y);
-                        }
-                    }
+                for (int li = 0; li < LI; ++li)
+#pragma unroll
+                    for (int b = 0; b < D; ++b) vv[li][b] = *(const f32x2*)(xr + __float_as_int(cv[li][1 + b]));
+                // phase 3: packed FMAs
+#pragma unroll
+                for (int li = 0; li < LI; ++li) {
+                    const float cc = cv[li][0] * lane_mul;
+                    acc[li][D] += vfocal * (cv[li][0] * ratio_c);
+#pragma unroll
+                    for (int b = 0; b < D; ++b) acc[li][b] += vv[li][b] * cc;
                 }
             }
         }
@@ -319,10 +355,10 @@ __global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
         const int l = wave + NWV * li;
         if (l < L) {
             if (2 * lane < a.F) {
-                *(float2*)(slab + (size_t)l * a.F + 2 * lane) = acc[li][D];
+                *(f32x2*)(slab + (size_t)l * a.F + 2 * lane) = acc[li][D];
 #pragma unroll
                 for (int b = 0; b < D; ++b)
-                    *(float2*)(slab + o_sup + (size_t)(l * D + b) * a.F + 2 * lane) = acc[li][b];
+                    *(f32x2*)(slab + o_sup + (size_t)(l * D + b) * a.F + 2 * lane) = acc[li][b];
             } else if (!feat && act) {
                 const int e0 = 2 * lane - FP;
 #pragma unroll
@@ -375,7 +411,8 @@ static hipError_t launch_lds_bwd(const BwdArgs& a0, int* nchunk_out, int* ntheta
         *ntheta_out = (int)blocks;
     }
     {   // bank
-        const size_t lds_bytes = ((size_t)TA * (D + 1) * (FP + 8) + 2 * TA * (size_t)a.L + 4 * TA * (D + 1)) * 4;
+        constexpr int CW = (D == 1) ? 2 : ((D == 4) ? 8 : 4);
+        const size_t lds_bytes = ((size_t)TA * (D + 1) * (FP + 8) + CW * TA * (size_t)(8 * LI) + 4 * TA * (D + 1)) * 4;
         const int64_t ntiles = (a.n + TA - 1) / TA;
         int64_t blocks = BWD_BANK_BLOCKS;
         if (blocks > ntiles) blocks = ntiles;
