@@ -111,11 +111,17 @@ __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(Bw
             if (4 * kk < L) {                        // wave-uniform
                 const int l = 4 * kk + kq < L ? 4 * kk + kq : L - 1;
                 const float* brow = bank + (size_t)l * FP + ci;
+                // all B values of this kernel group first (their LDS reads travel together), then the MFMAs
+                float bv[D + 1][FT];
+#pragma unroll
+                for (int b = 0; b <= D; ++b)
+#pragma unroll
+                    for (int ft = 0; ft < FT; ++ft) bv[b][ft] = brow[(size_t)b * L * FP + 16 * ft];
                 {   // centre rows -> focal slot
                     const float av = c[kk] * ratio_c;
 #pragma unroll
                     for (int ft = 0; ft < FT; ++ft)
-                        acc[0][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, brow[(size_t)D * L * FP + 16 * ft], acc[0][ft], 0, 0, 0);
+                        acc[0][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[D][ft], acc[0][ft], 0, 0, 0);
                 }
 #pragma unroll
                 for (int b = 0; b < D; ++b) {
@@ -123,12 +129,10 @@ __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(Bw
 #pragma unroll
                     for (int s = 0; s < D; ++s) av[s] = (((pk[kk] >> (2 * s)) & 3) == b) ? c[kk] : 0.f;
 #pragma unroll
-                    for (int ft = 0; ft < FT; ++ft) {
-                        const float bv = brow[(size_t)b * L * FP + 16 * ft];
+                    for (int ft = 0; ft < FT; ++ft)
 #pragma unroll
                         for (int s = 0; s < D; ++s)
-                            acc[1 + s][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv, acc[1 + s][ft], 0, 0, 0);
-                    }
+                            acc[1 + s][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[b][ft], acc[1 + s][ft], 0, 0, 0);
                 }
             }
         }
