@@ -133,10 +133,12 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
 /* MolGCN.propagate with aggr='add' (KernelLayer.py:14,119-123) as a CSR segment
  * sum: out[i, :] = sum_{k in [rowptr[i], rowptr[i+1])} in[col[k], :].
  * Forward uses the edges grouped by target (col = sources); the gradient is the
- * same call on the edges grouped by source (col = targets).  width <= strides. */
+ * same call on the edges grouped by source (col = targets).  width <= strides.
+ * inv_norm (may be NULL): also write 1 / max(||out[i]||, 1e-8) -- the next layer's cosine needs it,
+ * so the producer of h hands it over instead of a separate pass over h. */
 int mkgnn_segment_sum_rows(const float* in, int64_t in_stride, const int32_t* rowptr,
                            const int32_t* col, int64_t n_rows, int32_t width,
-                           float* out, int64_t out_stride, void* stream);
+                           float* out, int64_t out_stride, float* inv_norm, void* stream);
 
 #ifdef __cplusplus
 }

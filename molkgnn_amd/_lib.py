@@ -87,7 +87,7 @@ def load() -> C.CDLL:
         C.c_void_p, C.c_size_t, C.c_void_p]
     lib.mkgnn_segment_sum_rows.restype = C.c_int
     lib.mkgnn_segment_sum_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
-                                           C.c_void_p, C.c_int64, C.c_void_p]
+                                           C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     if lib.mkgnn_abi_version() != ABI_VERSION:
         raise MolKGNNLibraryError(f"ABI version {lib.mkgnn_abi_version()} != {ABI_VERSION}: rebuild the library")
     _lib = lib

@@ -328,10 +328,11 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
 }
 
 int mkgnn_segment_sum_rows(const float* in, int64_t in_stride, const int32_t* rowptr, const int32_t* col, int64_t n_rows,
-                           int32_t width, float* out, int64_t out_stride, void* stream) {
-    if (n_rows < 0 || width <= 0 || in_stride < width || out_stride < width) return fail("mkgnn_segment_sum_rows: bad shape");
+                           int32_t width, float* out, int64_t out_stride, float* inv_norm, void* stream) {
+    if (n_rows < 0 || width <= 0 || width > 16384 || in_stride < width || out_stride < width)
+        return fail("mkgnn_segment_sum_rows: bad shape");
     if (n_rows && (!in || !rowptr || !out)) return fail("mkgnn_segment_sum_rows: null pointer");
-    hipError_t e = launch_segment_sum(in, in_stride, rowptr, col, n_rows, width, out, out_stride, (hipStream_t)stream);
+    hipError_t e = launch_segment_sum(in, in_stride, rowptr, col, n_rows, width, out, out_stride, inv_norm, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail("mkgnn_segment_sum_rows", e);
 }
 

@@ -13,7 +13,10 @@
 namespace mkgnn {
 
 // ------------------------------------------------------------------ P1 ----
-// 1 / max(||row||, eps); one wave per row.
+// 1 / max(||row||, eps); one wave per row.  Lane l owns columns 128 j + 2 l, + 1: the same
+// assignment and summation order as segment_sum_rows_kernel's fused norm, so a norm handed over
+// by the producer of x is bit-identical to the one computed here.
+template <bool VEC2>
 __global__ void row_inv_norm_kernel(const float* __restrict__ x, int64_t stride, int64_t n, int F,
                                     float* __restrict__ inv) {
     const int lane = threadIdx.x & 63;
@@ -21,9 +24,12 @@ __global__ void row_inv_norm_kernel(const float* __restrict__ x, int64_t stride,
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t r = wave; r < n; r += nwaves) {
         float s = 0.f;
-        for (int f = lane; f < F; f += 64) {
-            float v = x[r * stride + f];
-            s = fmaf(v, v, s);
+        for (int f = 2 * lane; f < F; f += 128) {
+            float2 v;
+            if constexpr (VEC2) v = *(const float2*)(x + r * stride + f);
+            else { v.x = x[r * stride + f]; v.y = f + 1 < F ? x[r * stride + f + 1] : 0.f; }
+            s = fmaf(v.x, v.x, s);
+            if (f + 1 < F) s = fmaf(v.y, v.y, s);
         }
         s = wave_sum(s);
         if (lane == 0) inv[r] = 1.f / fmaxf(sqrtf(s), MKGNN_EPS);
@@ -467,20 +473,52 @@ __global__ void __launch_bounds__(256) kc_backward_gather(const float* __restric
 }
 
 // ---------------------------------------------------------- propagate ----
-// out[i, :] = sum_k in[col[k], :] over the CSR segment of row i; one wave per
-// row, lanes over columns (KernelLayer.py:119-123 with aggr='add').
+// out[i, :] = sum_k in[col[k], :] over the CSR segment of row i (KernelLayer.py:119-123 with
+// aggr='add'); optionally also 1 / max(|out[i]|, eps), which the next layer's cosine needs anyway.
+// One wave per row, two floats per lane; the segment's column ids are fetched first and all row
+// loads issued together.  Sums run in CSR order: reproducible.
+template <bool VEC2>
 __global__ void __launch_bounds__(256) segment_sum_rows_kernel(const float* __restrict__ in, int64_t is,
                                                                const int32_t* __restrict__ rowptr, const int32_t* __restrict__ col,
-                                                               int64_t n, int width, float* __restrict__ out, int64_t os) {
+                                                               int64_t n, int width, float* __restrict__ out, int64_t os,
+                                                               float* __restrict__ inv_norm) {
     const int lane = threadIdx.x & 63;
     int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    constexpr int SEG = 8;
     for (int64_t i = wave; i < n; i += nwaves) {
         const int lo = rowptr[i], hi = rowptr[i + 1];
-        for (int f = lane; f < width; f += 64) {
-            float s = 0.f;
-            for (int k = lo; k < hi; ++k) s += in[(size_t)col[k] * is + f];
-            out[i * os + f] = s;
+        float ss = 0.f;
+        for (int f0 = 0; f0 < width; f0 += 128) {
+            const int f = f0 + 2 * lane;
+            const bool one = f < width, two = f + 1 < width;
+            const int fc = one ? f : 0;                      // clamped: loads stay unconditional
+            float2 acc = {0.f, 0.f};
+            for (int k0 = lo; k0 < hi; k0 += SEG) {
+                int cid[SEG];
+#pragma unroll
+                for (int u = 0; u < SEG; ++u) cid[u] = col[k0 + u < hi ? k0 + u : hi - 1];
+                float2 v[SEG];
+#pragma unroll
+                for (int u = 0; u < SEG; ++u) {
+                    const float* src = in + (size_t)cid[u] * is + fc;
+                    if constexpr (VEC2) v[u] = *(const float2*)src;
+                    else { v[u].x = src[0]; v[u].y = two ? src[1] : 0.f; }
+                }
+#pragma unroll
+                for (int u = 0; u < SEG; ++u)
+                    if (k0 + u < hi) { acc.x += v[u].x; acc.y += v[u].y; }
+            }
+            if (one) {
+                if constexpr (VEC2) { if (two) *(float2*)(out + i * os + f) = acc; else out[i * os + f] = acc.x; }
+                else { out[i * os + f] = acc.x; if (two) out[i * os + f + 1] = acc.y; }
+                ss = fmaf(acc.x, acc.x, ss);
+                if (two) ss = fmaf(acc.y, acc.y, ss);
+            }
+        }
+        if (inv_norm) {
+            ss = wave_sum(ss);
+            if (lane == 0) inv_norm[i] = 1.f / fmaxf(sqrtf(ss), MKGNN_EPS);
         }
     }
 }
@@ -496,7 +534,10 @@ static inline int grid_for_waves(int64_t waves, int threads = 256) {
 
 hipError_t launch_row_inv_norm(const float* x, int64_t stride, int64_t n, int F, float* inv, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    row_inv_norm_kernel<<<grid_for_waves(n), 256, 0, st>>>(x, stride, n, F, inv);
+    if (stride % 2 == 0 && F % 2 == 0 && (uintptr_t)x % 8 == 0)
+        row_inv_norm_kernel<true><<<grid_for_waves(n), 256, 0, st>>>(x, stride, n, F, inv);
+    else
+        row_inv_norm_kernel<false><<<grid_for_waves(n), 256, 0, st>>>(x, stride, n, F, inv);
     return hipGetLastError();
 }
 
@@ -582,9 +623,12 @@ hipError_t launch_backward_gather(const float* contrib, const int32_t* rowptr, c
 }
 
 hipError_t launch_segment_sum(const float* in, int64_t is, const int32_t* rowptr, const int32_t* col, int64_t n,
-                              int width, float* out, int64_t os, hipStream_t st) {
+                              int width, float* out, int64_t os, float* inv_norm, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    segment_sum_rows_kernel<<<grid_for_waves(n), 256, 0, st>>>(in, is, rowptr, col, n, width, out, os);
+    // 8-byte accesses need even strides / width and 8-byte aligned bases
+    const bool vec2 = (is % 2 == 0) && (os % 2 == 0) && (width % 2 == 0) && (((uintptr_t)in | (uintptr_t)out) % 8 == 0);
+    if (vec2) segment_sum_rows_kernel<true><<<grid_for_waves(n), 256, 0, st>>>(in, is, rowptr, col, n, width, out, os, inv_norm);
+    else segment_sum_rows_kernel<false><<<grid_for_waves(n), 256, 0, st>>>(in, is, rowptr, col, n, width, out, os, inv_norm);
     return hipGetLastError();
 }
 

@@ -99,6 +99,6 @@ hipError_t launch_backward_gather(const float* contrib, const int32_t* rowptr, c
                                   int64_t xs, const float* inv, int64_t n, int F, float* gx, int64_t gxs,
                                   hipStream_t st);
 hipError_t launch_segment_sum(const float* in, int64_t is, const int32_t* rowptr, const int32_t* col, int64_t n,
-                              int width, float* out, int64_t os, hipStream_t st);
+                              int width, float* out, int64_t os, float* inv_norm, hipStream_t st);
 
 }  // namespace mkgnn

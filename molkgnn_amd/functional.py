@@ -107,7 +107,8 @@ def row_inv_norm(x: torch.Tensor) -> torch.Tensor:
     return inv
 
 
-def _forward_impl(x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad: int, E: int, params, want_saved: bool):
+def _forward_impl(x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad: int, E: int, params, want_saved: bool,
+                  inv=None):
     lib = _lib.load()
     _lib.require_gpu_tensor(x, "x")
     x = _row_major(x) if variant == VARIANTS["generic"] else _aligned_rows(x)
@@ -135,9 +136,10 @@ def _forward_impl(x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad
         else:
             saved_t.append((None, None, None))
     with torch.cuda.device(dev):
-        inv = torch.empty(n, dtype=torch.float32, device=dev)
         st = _lib.stream_ptr(dev)
-        _lib.check(lib.mkgnn_row_inv_norm(x.data_ptr(), _stride0(x), n, F, inv.data_ptr(), st), "mkgnn_row_inv_norm")
+        if inv is None:                      # the producer of x did not hand its row norms over
+            inv = torch.empty(n, dtype=torch.float32, device=dev)
+            _lib.check(lib.mkgnn_row_inv_norm(x.data_ptr(), _stride0(x), n, F, inv.data_ptr(), st), "mkgnn_row_inv_norm")
         ws_bytes = workspace_bytes(Ls, F, E, n, plan.n_slots)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         _lib.check(lib.mkgnn_kernelsetconv_forward(
@@ -153,7 +155,7 @@ def kernelsetconv_details(x, plan: BatchPlan, is_last_layer: bool, params, edge_
     (transposed views of the atom-major buffers).  Used by the parity tests for the tie-aware criterion."""
     with torch.no_grad():
         _, out, _, saved_t, _ = _forward_impl(x, plan, is_last_layer, VARIANTS[variant], 0, edge_attr_dim,
-                                              [p.detach() for p in params], True)
+                                              [p.detach() for p in params], True, _handed_inv_norm(x))
     tr = lambda t: None if t is None else t.transpose(-1, -2)
     return out, [(tr(bi), tr(sc), tr(ch)) for bi, sc, ch in saved_t]
 
@@ -162,9 +164,9 @@ class _KernelSetConvFn(torch.autograd.Function):
     """BaseKernelSetConv.forward (reference kernels.py:610-751) as one differentiable operator."""
 
     @staticmethod
-    def forward(ctx, x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad: int, E: int, *params):
+    def forward(ctx, x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad: int, E: int, inv, *params):
         need_grad = any(ctx.needs_input_grad)
-        x, out_full, inv, saved_t, Ls = _forward_impl(x, plan, is_last_layer, variant, out_pad, E, params, need_grad)
+        x, out_full, inv, saved_t, Ls = _forward_impl(x, plan, is_last_layer, variant, out_pad, E, params, need_grad, inv)
         ctx.plan, ctx.is_last, ctx.E, ctx.Ls = plan, bool(is_last_layer), E, Ls
         ctx.saved_t = saved_t
         ctx.save_for_backward(x, inv, *params)
@@ -214,7 +216,7 @@ class _KernelSetConvFn(torch.autograd.Function):
                 g.data_ptr(), _stride0(g), saved, rowptr.data_ptr(), rows.data_ptr(),
                 _lib.ptr(gx), F, grads, ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)),
                 "mkgnn_kernelsetconv_backward")
-        return (gx, None, None, None, None, None, *gparams)
+        return (gx, None, None, None, None, None, None, *gparams)
 
 
 def kernelsetconv(x: torch.Tensor, plan: BatchPlan, is_last_layer: bool, params: Sequence[torch.Tensor],
@@ -227,7 +229,22 @@ def kernelsetconv(x: torch.Tensor, plan: BatchPlan, is_last_layer: bool, params:
     to the storage (the returned tensor is the ``[:, :K]`` view) so that the
     next layer can read 16-byte aligned rows.
     """
-    return _KernelSetConvFn.apply(x, plan, is_last_layer, VARIANTS[variant], out_pad, edge_attr_dim, *params)
+    return _KernelSetConvFn.apply(x, plan, is_last_layer, VARIANTS[variant], out_pad, edge_attr_dim, _handed_inv_norm(x),
+                                  *params)
+
+
+_INV_ATTR = "_mkgnn_inv_norm"
+
+
+def _handed_inv_norm(x: torch.Tensor):
+    """Row norms a previous operator attached to ``x`` (see propagate_add), if ``x`` is still that tensor's data."""
+    tag = getattr(x, _INV_ATTR, None)
+    if tag is None:
+        return None
+    inv, version = tag
+    if version != x._version or inv.shape[0] != x.shape[0] or inv.device != x.device:
+        return None                               # modified in place since: recompute
+    return inv
 
 
 class _SegmentSumFn(torch.autograd.Function):
@@ -239,25 +256,33 @@ class _SegmentSumFn(torch.autograd.Function):
         v = _row_major(v)
         ctx.plan = plan
         ctx.width = v.shape[1]
-        return _segment_sum(v, plan.csr_in, out_pad)
+        inv = torch.empty(v.shape[0], dtype=torch.float32, device=v.device)
+        out = _segment_sum(v, plan.csr_in, out_pad, inv)
+        ctx.mark_non_differentiable(inv)
+        return out, inv
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, _g_inv):
         g = _row_major(g if g.dtype == torch.float32 else g.float())
         return _segment_sum(g, ctx.plan.csr_out, 0), None, None
 
 
-def _segment_sum(v: torch.Tensor, csr, out_pad: int) -> torch.Tensor:
+def _segment_sum(v: torch.Tensor, csr, out_pad: int, inv: Optional[torch.Tensor] = None) -> torch.Tensor:
     rowptr, col = csr
     n, w = v.shape
     alloc = torch.zeros if out_pad else torch.empty
     out = alloc((n, w + out_pad), dtype=torch.float32, device=v.device)
     with torch.cuda.device(v.device):
         _lib.check(_lib.load().mkgnn_segment_sum_rows(v.data_ptr(), _stride0(v), rowptr.data_ptr(), _lib.ptr(col), n, w,
-                                                      out.data_ptr(), w + out_pad, _lib.stream_ptr(v.device)),
+                                                      out.data_ptr(), w + out_pad, _lib.ptr(inv),
+                                                      _lib.stream_ptr(v.device)),
                    "mkgnn_segment_sum_rows")
     return out[:, :w] if out_pad else out
 
 
 def propagate_add(sim_sc: torch.Tensor, plan: BatchPlan, out_pad: int = 0) -> torch.Tensor:
-    return _SegmentSumFn.apply(sim_sc, plan, out_pad)
+    """MolGCN.propagate with aggr='add'.  The kernel also emits ``1 / max(||h_n||, 1e-8)``; it rides on the
+    returned tensor so that the next kernel convolution does not make another pass over ``h`` for it."""
+    h, inv = _SegmentSumFn.apply(sim_sc, plan, out_pad)
+    setattr(h, _INV_ATTR, (inv, h._version))
+    return h

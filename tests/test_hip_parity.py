@@ -258,3 +258,24 @@ def test_unusual_shapes_generic_path():
     bd = b.to(dev)
     out = ksc.to(dev)(is_last_layer=True, data=bd, save_score=False)
     assert torch.allclose(out.cpu(), ref, atol=FWD_TOL, rtol=0)
+
+
+def test_propagate_hands_row_norms_to_next_layer():
+    """propagate_add emits 1/max(|h_n|, eps) with h; the next convolution uses it only while h is unmodified."""
+    from molkgnn_amd import functional as Fn
+    from molkgnn_amd.plan import plan_from_data
+    from molkgnn_amd.synthetic import make_batch
+    batch = make_batch(24, seed=5, device="cuda")
+    plan = plan_from_data(batch)
+    g = torch.Generator().manual_seed(3)
+    for width in (110, 37):                       # even width: 8-byte path; odd width: scalar path
+        v = torch.randn(batch.x.shape[0], width, generator=g).cuda()
+        h = Fn.propagate_add(v, plan, out_pad=(-width) % 4)
+        ref = torch.zeros_like(v).index_add_(0, batch.edge_index[1], v[batch.edge_index[0]])
+        assert torch.allclose(h, ref, atol=1e-5)
+        inv = Fn._handed_inv_norm(h)
+        assert inv is not None
+        assert torch.allclose(inv, 1.0 / h.norm(dim=1).clamp_min(1e-8), rtol=1e-5)
+        assert torch.equal(inv, Fn.row_inv_norm(h))          # same summation order in both kernels
+        h.mul_(2.0)
+        assert Fn._handed_inv_norm(h) is None
