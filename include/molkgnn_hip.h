@@ -140,6 +140,62 @@ int mkgnn_segment_sum_rows(const float* in, int64_t in_stride, const int32_t* ro
                            const int32_t* col, int64_t n_rows, int32_t width,
                            float* out, int64_t out_stride, float* inv_norm, void* stream);
 
+/* ---- the consumers either side of the convolution stack -------------------
+ *
+ * Readout, reference MolKGNNNet.py:144-146:
+ *     out[g] = sum_{n in molecule g} lin2( keep[n] * swish( lin1(h[n]) ) )
+ * evaluated as  W2 (sum_n keep[n] * swish(W1 h[n] + b1)) + |g| b2  (lin2 and the add-pool commute).
+ * Atoms of one molecule are contiguous (PyG batches): mol_ptr[g] .. mol_ptr[g+1].
+ * Limits: F <= 128, H <= 64, G <= 64; h rows 16-byte aligned, h_stride a multiple of 4 and
+ * >= F rounded up to 4. */
+typedef struct mkgnn_readout_params {
+    const float* lin1_weight;   /* [H, F] graph_embedding_lin1.weight */
+    const float* lin1_bias;     /* [H] or NULL */
+    const float* lin2_weight;   /* [G, H] graph_embedding_lin2.weight */
+    const float* lin2_bias;     /* [G] or NULL */
+    int32_t F, H, G;
+} mkgnn_readout_params;
+
+/* Row stride (floats) of the `pre` and `pooled` buffers below: H rounded up to 32 or 64. */
+int32_t mkgnn_readout_hidden_stride(int32_t H);
+size_t mkgnn_readout_workspace_bytes(int32_t F, int32_t H, int32_t G, int64_t n_atoms, int64_t n_mols);
+
+/* keep_scale: [n_atoms, H] dropout multipliers (0 or 1/(1-p)), NULL = no dropout.
+ * Writes pre [n_atoms, HS] (lin1 output, kept for backward), pooled [n_mols, HS], out [n_mols, G]. */
+int mkgnn_readout_forward(const mkgnn_readout_params* params, const float* h, int64_t h_stride,
+                          int64_t n_atoms, const int32_t* mol_ptr, int64_t n_mols,
+                          const float* keep_scale, float* pre, float* pooled,
+                          float* out, int64_t out_stride, void* stream);
+
+/* atom_mol: [n_atoms] molecule id of every atom.  grad_h (may be NULL) is fully overwritten; the four
+ * parameter gradients (each may be NULL) are fully overwritten, summed in a fixed order. */
+int mkgnn_readout_backward(const mkgnn_readout_params* params, const float* h, int64_t h_stride,
+                           int64_t n_atoms, const int32_t* mol_ptr, const int32_t* atom_mol, int64_t n_mols,
+                           const float* keep_scale, const float* pre, const float* pooled,
+                           const float* grad_out, int64_t grad_out_stride,
+                           float* grad_h, int64_t grad_h_stride,
+                           float* grad_lin1_weight, float* grad_lin1_bias,
+                           float* grad_lin2_weight, float* grad_lin2_bias,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
+/* BatchNorm1d over atom rows, reference MolKGNNNet.py:115 (torch.nn.BatchNorm1d semantics: biased
+ * variance for the normalisation, unbiased for running_var, running <- running + momentum (batch - running)).
+ * training != 0: batch statistics, running_* (may be NULL) updated in place, save_* written.
+ * training == 0: running statistics; save_* (may be NULL) receive mean and 1/sqrt(var + eps). */
+size_t mkgnn_batchnorm_workspace_bytes(int32_t C);
+int mkgnn_batchnorm_forward(const float* x, int64_t x_stride, int64_t n_rows, int32_t C,
+                            const float* weight, const float* bias,
+                            float* running_mean, float* running_var, float momentum, float eps,
+                            int32_t training, float* out, int64_t out_stride,
+                            float* save_mean, float* save_invstd,
+                            void* workspace, size_t workspace_bytes, void* stream);
+/* grad_x (may be NULL), grad_weight, grad_bias (may be NULL) are fully overwritten. */
+int mkgnn_batchnorm_backward(const float* grad_out, int64_t grad_out_stride, const float* x, int64_t x_stride,
+                             int64_t n_rows, int32_t C, const float* weight,
+                             const float* save_mean, const float* save_invstd, int32_t training,
+                             float* grad_x, int64_t grad_x_stride, float* grad_weight, float* grad_bias,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

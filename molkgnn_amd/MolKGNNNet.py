@@ -1,8 +1,8 @@
 """Consumer of the hot path, kept so that the reference's ``model.py`` can build
 it unchanged: BatchNorm(x) -> MolGCN -> lin2(dropout(swish(lin1(h)))) -> add-pool
-(reference ``models/MolKGNN/MolKGNNNet.py:10-149``).  Only ``MolGCN`` is HIP
-code; the readout is plain PyTorch here (SURVEY.md 8 f-3 lists fusing it as
-later work).
+(reference ``models/MolKGNN/MolKGNNNet.py:10-149``).  ``MolGCN`` is the hot
+path; the batch norm in front of it and the readout behind it run as HIP
+operators too (``readout.py``).
 """
 from __future__ import annotations
 
@@ -10,6 +10,7 @@ import torch
 from torch.nn import BatchNorm1d, Dropout, Linear
 
 from .KernelLayer import MolGCN
+from . import readout as R
 
 
 def swish(x):
@@ -61,15 +62,15 @@ class MolKGNNNet(torch.nn.Module):
             # (MolKGNNNet.py:70-89 then :115); only the single-``data`` form is meaningful
             raise ValueError("unmatched number of arguments.")
         data = argv[0]
-        x = self.node_batch_norm(data.x)
+        x = R.batch_norm(data.x, self.node_batch_norm)
         # edge_batch_norm never reaches the kernel convolution in the reference: skipped
         kw = {f'{nm}_deg{d}': getattr(data, f'{nm}_deg{d}')
               for nm in ('p_focal', 'nei_p', 'nei_edge_attr', 'selected_index', 'nei_index') for d in range(1, 5)}
         node_representation = self.gnn(x=x, edge_index=data.edge_index, edge_attr=data.edge_attr, p=data.p,
                                        save_score=save_score, **kw)
-        z = self.graph_embedding_lin2(self.dropout(self.act(self.graph_embedding_lin1(node_representation))))
-        size = getattr(data, 'num_graphs', None)
-        return self.pool(z, data.batch, size)
+        # pool(lin2(dropout(act(lin1(h)))), batch) -- MolKGNNNet.py:144-146 -- as one operator
+        return R.readout(node_representation, self.graph_embedding_lin1, self.graph_embedding_lin2, self.dropout,
+                         data.batch, getattr(data, 'num_graphs', None))
 
     @staticmethod
     def add_model_specific_args(parent_parser):

@@ -41,6 +41,11 @@ class Saved(C.Structure):
     _fields_ = [("best_index", C.c_void_p), ("scores", C.c_void_p), ("chirality", C.c_void_p)]
 
 
+class ReadoutParams(C.Structure):
+    _fields_ = [("lin1_weight", C.c_void_p), ("lin1_bias", C.c_void_p), ("lin2_weight", C.c_void_p),
+                ("lin2_bias", C.c_void_p), ("F", C.c_int32), ("H", C.c_int32), ("G", C.c_int32)]
+
+
 Banks4 = KernelBank * MAX_DEGREE
 BankGrads4 = KernelBankGrad * MAX_DEGREE
 Buckets4 = DegreeBucket * MAX_DEGREE
@@ -48,7 +53,10 @@ Saved4 = Saved * MAX_DEGREE
 Int32x4 = C.c_int32 * MAX_DEGREE
 
 EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn_workspace_bytes",
-           "mkgnn_kernelsetconv_forward", "mkgnn_kernelsetconv_backward", "mkgnn_segment_sum_rows")
+           "mkgnn_kernelsetconv_forward", "mkgnn_kernelsetconv_backward", "mkgnn_segment_sum_rows",
+           "mkgnn_readout_hidden_stride", "mkgnn_readout_workspace_bytes", "mkgnn_readout_forward",
+           "mkgnn_readout_backward", "mkgnn_batchnorm_workspace_bytes", "mkgnn_batchnorm_forward",
+           "mkgnn_batchnorm_backward")
 
 _lib: Optional[C.CDLL] = None
 
@@ -88,6 +96,22 @@ def load() -> C.CDLL:
     lib.mkgnn_segment_sum_rows.restype = C.c_int
     lib.mkgnn_segment_sum_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                            C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    P, I64, I32, F32 = C.c_void_p, C.c_int64, C.c_int32, C.c_float
+    lib.mkgnn_readout_hidden_stride.restype = I32
+    lib.mkgnn_readout_hidden_stride.argtypes = [I32]
+    lib.mkgnn_readout_workspace_bytes.restype = C.c_size_t
+    lib.mkgnn_readout_workspace_bytes.argtypes = [I32, I32, I32, I64, I64]
+    lib.mkgnn_readout_forward.restype = C.c_int
+    lib.mkgnn_readout_forward.argtypes = [C.POINTER(ReadoutParams), P, I64, I64, P, I64, P, P, P, P, I64, P]
+    lib.mkgnn_readout_backward.restype = C.c_int
+    lib.mkgnn_readout_backward.argtypes = [C.POINTER(ReadoutParams), P, I64, I64, P, P, I64, P, P, P, P, I64, P, I64,
+                                           P, P, P, P, P, C.c_size_t, P]
+    lib.mkgnn_batchnorm_workspace_bytes.restype = C.c_size_t
+    lib.mkgnn_batchnorm_workspace_bytes.argtypes = [I32]
+    lib.mkgnn_batchnorm_forward.restype = C.c_int
+    lib.mkgnn_batchnorm_forward.argtypes = [P, I64, I64, I32, P, P, P, P, F32, F32, I32, P, I64, P, P, P, C.c_size_t, P]
+    lib.mkgnn_batchnorm_backward.restype = C.c_int
+    lib.mkgnn_batchnorm_backward.argtypes = [P, I64, P, I64, I64, I32, P, P, P, I32, P, I64, P, P, P, C.c_size_t, P]
     if lib.mkgnn_abi_version() != ABI_VERSION:
         raise MolKGNNLibraryError(f"ABI version {lib.mkgnn_abi_version()} != {ABI_VERSION}: rebuild the library")
     _lib = lib

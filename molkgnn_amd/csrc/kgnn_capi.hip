@@ -23,6 +23,17 @@ static int hip_fail(const char* what, hipError_t e) {
     return fail("%s: %s", what, hipGetErrorString(e));
 }
 
+namespace mkgnn {
+int api_fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+int api_hip_fail(const char* what, hipError_t e) { return fail("%s: %s", what, hipGetErrorString(e)); }
+}  // namespace mkgnn
+
 // The four degree buckets are independent.  At the batch sizes a molecule model sees, one bucket
 // does not fill 256 CUs for long (a few atom tiles per SIMD, and prologue/tail dominate), so the
 // per-degree kernels of one call run concurrently on three helper streams forked from and joined

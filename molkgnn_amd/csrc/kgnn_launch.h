@@ -101,4 +101,8 @@ hipError_t launch_backward_gather(const float* contrib, const int32_t* rowptr, c
 hipError_t launch_segment_sum(const float* in, int64_t is, const int32_t* rowptr, const int32_t* col, int64_t n,
                               int width, float* out, int64_t os, float* inv_norm, hipStream_t st);
 
+// error reporting shared by the C-ABI translation units (kgnn_capi.hip owns the thread-local message)
+int api_fail(const char* fmt, ...);
+int api_hip_fail(const char* what, hipError_t e);
+
 }  // namespace mkgnn

@@ -1,0 +1,756 @@
+// The two consumers either side of the kernel-convolution stack:
+//
+//   readout     pool_g( lin2( dropout( swish( lin1(h) ) ) ) )      reference MolKGNNNet.py:144-146
+//   batch norm  BatchNorm1d over the atom rows                      reference MolKGNNNet.py:115
+//
+// Readout.  lin2 and the add-pool are both linear, so the molecule sum is taken first and lin2 is
+// applied to one row per molecule: out_g = W2 (sum_{n in g} keep_n * swish(W1 h_n + b1)) + |g| b2.
+// That removes the [N, H] x [H, G] product and its two gradients; what is left per atom is the
+// [16 atoms x F] x [F x H] tile product, which runs on the fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32), fed straight from global memory with 16-byte loads: an MFMA's k index may
+// be any permutation as long as both operands use the same one, so lane (row r, k-slot q) takes the
+// four consecutive columns 16 j + 4 q .. + 3 of its row for the four k-steps of chunk j.
+//
+// Backward per 16-atom tile: dpre = dA[mol] * keep * swish'(pre) in registers, then two tile products,
+// dh = dpre W1 (stored) and dW1 += dpre^T h (kept in accumulators for the whole kernel), followed by a
+// fixed-order reduction block -> slab -> parameter.  No float atomics anywhere: results are reproducible.
+//
+// Batch norm.  Tall and skinny ([1e5, 28]): three short launches (column sums, centred squares, apply),
+// every block re-deriving the column statistics from the per-block partials in a fixed order.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include "kgnn_common.h"
+#include "kgnn_launch.h"
+#include "../../include/molkgnn_hip.h"
+
+namespace mkgnn {
+
+typedef mkgnn_f32x4 f32x4;
+
+struct ReadoutArgs {
+    const float* h; int64_t hs; int64_t n;
+    const int32_t* mol_ptr; const int32_t* atom_mol; int64_t nmol;
+    const float *w1, *b1, *w2, *b2;
+    int F, H, G;
+    const float* keep;             // [n, H] dropout multipliers or null
+    float* pre;                    // [n, HP]
+    float* pooled;                 // [nmol, HP]
+    float* out; int64_t os;
+    const float* gout; int64_t gos;
+    float* dA;                     // [nmol, HP]
+    float* gh; int64_t ghs;
+    float* slab_atoms; int slab_atoms_stride; int nblk_atoms;
+    float* slab_mol; int slab_mol_stride; int nblk_mol;
+};
+
+__device__ __forceinline__ float sigmoid_f(float p) { return 1.f / (1.f + expf(-p)); }
+
+// ------------------------------------------------------------------ forward: pre = h W1^T + b1 ----
+template <int NT, int NJ>
+__global__ void __launch_bounds__(256) readout_pre_kernel(ReadoutArgs a) {
+    constexpr int HP = 16 * NT, FP = 16 * NJ, LDW = FP + 4;
+    __shared__ __attribute__((aligned(16))) float w1s[HP * LDW];
+    for (int i = threadIdx.x; i < HP * LDW; i += 256) {
+        const int r = i / LDW, c = i - r * LDW;
+        w1s[i] = (r < a.H && c < a.F) ? a.w1[r * a.F + c] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    float bias[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) bias[t] = (a.b1 && 16 * t + r < a.H) ? a.b1[16 * t + r] : 0.f;
+    const int64_t ntiles = (a.n + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        int64_t atom = tile * 16 + r;
+        if (atom >= a.n) atom = a.n - 1;
+        const float* row = a.h + atom * a.hs;
+        f32x4 v[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int col = 16 * j + 4 * q;
+            v[j] = *(const f32x4*)(row + (col < a.F ? col : 0));
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int col = 16 * j + 4 * q;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[j][c] = (col + c < a.F) ? v[j][c] : 0.f;   // row padding may hold anything
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 w = *(const f32x4*)&w1s[(16 * t + r) * LDW + 16 * j + 4 * q];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j][c], w[c], acc[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int64_t ao = tile * 16 + 4 * q + i;
+                if (ao < a.n) a.pre[ao * HP + 16 * t + r] = acc[t][i] + bias[t];
+            }
+        }
+    }
+}
+
+// -------------------------------------- forward: pooled_g = sum keep*swish(pre); out_g = W2 pooled_g + |g| b2 ----
+__global__ void __launch_bounds__(256) readout_pool_kernel(ReadoutArgs a, int HP) {
+    __shared__ float w2s[64 * 65];
+    __shared__ float scr[4][64];
+    const int H = a.H, G = a.G;
+    for (int i = threadIdx.x; i < G * H; i += 256) { const int o = i / H, c = i - o * H; w2s[o * (H + 1) + c] = a.w2[i]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int groups = 64 / HP, c = lane & (HP - 1), gid = lane / HP;
+    const bool kc = a.keep && c < H;
+    for (int64_t mol = (int64_t)blockIdx.x * 4 + wave; mol < a.nmol; mol += (int64_t)gridDim.x * 4) {
+        const int lo = a.mol_ptr[mol], hi = a.mol_ptr[mol + 1];
+        float s = 0.f;
+        for (int at0 = lo + gid; at0 < hi; at0 += 4 * groups) {
+            float p[4], k[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int at = at0 + u * groups;
+                const int atc = at < hi ? at : hi - 1;
+                p[u] = a.pre[(int64_t)atc * HP + c];
+                k[u] = kc ? a.keep[(int64_t)atc * H + c] : 1.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float v = p[u] * sigmoid_f(p[u]) * k[u];
+                if (at0 + u * groups < hi) s += v;
+            }
+        }
+        if (groups == 2) s += __shfl_xor(s, 32, 64);
+        else if (groups == 4) { s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64); }
+        if (gid == 0) { a.pooled[mol * HP + c] = s; scr[wave][c] = s; }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < G) {
+            float z = 0.f;
+            for (int cc = 0; cc < H; ++cc) z = fmaf(w2s[lane * (H + 1) + cc], scr[wave][cc], z);
+            if (a.b2) z = fmaf((float)(hi - lo), a.b2[lane], z);
+            a.out[mol * a.os + lane] = z;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// ------------------- backward, per molecule: dA_g = dz_g W2; partial dW2 = dz^T pooled, db2 = sum |g| dz_g ----
+__global__ void __launch_bounds__(256) readout_bwd_mol_kernel(ReadoutArgs a, int HP) {
+    constexpr int MC = 16;
+    __shared__ float w2s[64 * 65];
+    __shared__ float dzs[MC][64];
+    __shared__ float As[MC][64];
+    __shared__ float nat[MC];
+    const int H = a.H, G = a.G, tid = threadIdx.x;
+    for (int i = tid; i < G * H; i += 256) { const int o = i / H, c = i - o * H; w2s[o * (H + 1) + c] = a.w2[i]; }
+    const int64_t per = (a.nmol + gridDim.x - 1) / gridDim.x;
+    const int64_t m_lo = per * blockIdx.x, m_hi = (m_lo + per < a.nmol) ? m_lo + per : a.nmol;
+    float accw[16];
+    int po[16], pc[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        accw[k] = 0.f;
+        int p = tid + 256 * k;
+        if (p >= G * H) p = 0;
+        po[k] = p / H; pc[k] = p - po[k] * H;
+    }
+    float accb = 0.f;
+    for (int64_t m0 = m_lo; m0 < m_hi; m0 += MC) {
+        __syncthreads();
+        for (int i = tid; i < MC * 64; i += 256) {
+            const int m = i >> 6, o = i & 63;
+            const bool ok = m0 + m < m_hi;
+            dzs[m][o] = (ok && o < G) ? a.gout[(m0 + m) * a.gos + o] : 0.f;
+            As[m][o] = (ok && o < H) ? a.pooled[(m0 + m) * HP + o] : 0.f;
+            if (o == 0) nat[m] = ok ? (float)(a.mol_ptr[m0 + m + 1] - a.mol_ptr[m0 + m]) : 0.f;
+        }
+        __syncthreads();
+        for (int m = 0; m < MC; ++m) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) accw[k] = fmaf(dzs[m][po[k]], As[m][pc[k]], accw[k]);
+            if (tid < G) accb = fmaf(nat[m], dzs[m][tid], accb);
+        }
+        for (int i = tid; i < MC * HP; i += 256) {
+            const int m = i / HP, c = i - m * HP;
+            if (m0 + m < m_hi) {
+                float v = 0.f;
+                if (c < H)
+                    for (int o = 0; o < G; ++o) v = fmaf(dzs[m][o], w2s[o * (H + 1) + c], v);
+                a.dA[(m0 + m) * HP + c] = v;
+            }
+        }
+    }
+    float* slab = a.slab_mol + (int64_t)blockIdx.x * a.slab_mol_stride;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { const int p = tid + 256 * k; if (p < G * H) slab[p] = accw[k]; }
+    if (tid < G) slab[G * H + tid] = accb;
+}
+
+// ----------------------------------- backward, per atom tile: dpre, dh = dpre W1, dW1 += dpre^T h, db1 += dpre ----
+template <int NT, int NU>
+__global__ void __launch_bounds__(256) readout_bwd_atoms_kernel(ReadoutArgs a) {
+    constexpr int NJ = 4 * NU, HP = 16 * NT, FP = 16 * NJ, LDW = FP + 4, LDP = HP + 4;
+    __shared__ __attribute__((aligned(16))) float w1s[HP * LDW];      // [hidden][feature]; reused for the block reduction
+    __shared__ __attribute__((aligned(16))) float dps[4][16 * LDP];   // per wave: dpre tile [atom][hidden]
+    for (int i = threadIdx.x; i < HP * LDW; i += 256) {
+        const int r = i / LDW, c = i - r * LDW;
+        w1s[i] = (r < a.H && c < a.F) ? a.w1[r * a.F + c] : 0.f;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 15, q = lane >> 4;
+    float* dpw = dps[wave];
+    f32x4 accw[NT][NJ];
+    f32x4 colsum[NT];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        colsum[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < NJ; ++t) accw[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const int64_t ntiles = (a.n + 15) / 16;
+    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+        // operand of the weight product: h rows 4 s + q, columns 64 u + 4 r .. + 3 (issued first: longest latency)
+        f32x4 hv[4][NU];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            int64_t ra = tile * 16 + 4 * s + q;
+            if (ra >= a.n) ra = a.n - 1;
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int col = 64 * u + 4 * r;
+                hv[s][u] = *(const f32x4*)(a.h + ra * a.hs + (col < a.F ? col : 0));
+            }
+        }
+        const int64_t atom = tile * 16 + r;
+        const bool valid = atom < a.n;
+        const int64_t atomc = valid ? atom : a.n - 1;
+        const int mol = a.atom_mol[atomc];
+        f32x4 dp[NT];
+#pragma unroll
+        for (int jj = 0; jj < NT; ++jj) {
+            const int c0 = 16 * jj + 4 * q;
+            const f32x4 p = *(const f32x4*)(a.pre + atomc * HP + c0);
+            const f32x4 g = *(const f32x4*)(a.dA + (int64_t)mol * HP + c0);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float sg = sigmoid_f(p[c]);
+                float d = g[c] * (sg * fmaf(p[c], 1.f - sg, 1.f));
+                if (a.keep) d *= (c0 + c < a.H) ? a.keep[atomc * a.H + c0 + c] : 0.f;
+                dp[jj][c] = valid ? d : 0.f;
+            }
+            colsum[jj] += dp[jj];
+            *(f32x4*)&dpw[r * LDP + c0] = dp[jj];
+        }
+        // dh tile = dpre [16 x HP] . W1 [HP x FP]
+        if (a.gh) {
+            f32x4 acch[NJ];
+#pragma unroll
+            for (int t = 0; t < NJ; ++t) acch[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jj = 0; jj < NT; ++jj) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float* wrow = &w1s[(16 * jj + 4 * q + c) * LDW + r];
+#pragma unroll
+                    for (int t = 0; t < NJ; ++t)
+                        acch[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(dp[jj][c], wrow[16 * t], acch[t], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NJ; ++t) {
+                const int col = 16 * t + r;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t ao = tile * 16 + 4 * q + i;
+                    if (ao < a.n && col < a.F) a.gh[ao * a.ghs + col] = acch[t][i];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // dW1 += dpre^T [HP x 16 atoms] . h [16 atoms x FP]
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int col = 64 * u + 4 * r;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) hv[s][u][c] = (col + c < a.F) ? hv[s][u][c] : 0.f;
+            }
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) {
+                const float at = dpw[(4 * s + q) * LDP + 16 * mt + r];
+#pragma unroll
+                for (int u = 0; u < NU; ++u)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        accw[mt][4 * u + c] = __builtin_amdgcn_mfma_f32_16x16x4f32(at, hv[s][u][c], accw[mt][4 * u + c], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // block reduction in wave order, then one slab row per block
+    float* red = w1s;
+#pragma unroll
+    for (int jj = 0; jj < NT; ++jj)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float v = colsum[jj][c];
+            v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+            colsum[jj][c] = v;
+        }
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                for (int t = 0; t < NJ; ++t)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int hid = 16 * mt + 4 * q + i, feat = 64 * (t >> 2) + 4 * r + (t & 3);
+                        const int idx = hid * FP + feat;
+                        red[idx] = (w == 0) ? accw[mt][t][i] : red[idx] + accw[mt][t][i];
+                    }
+            if (r == 0) {
+#pragma unroll
+                for (int jj = 0; jj < NT; ++jj)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int idx = HP * FP + 16 * jj + 4 * q + c;
+                        red[idx] = (w == 0) ? colsum[jj][c] : red[idx] + colsum[jj][c];
+                    }
+            }
+        }
+    }
+    __syncthreads();
+    float* slab = a.slab_atoms + (int64_t)blockIdx.x * a.slab_atoms_stride;
+    for (int i = threadIdx.x; i < HP * FP + HP; i += 256) slab[i] = red[i];
+}
+
+// ------------------------------------------------ fixed-order sum of per-block slabs into the parameters ----
+struct SlabSeg {
+    const float* src; int stride; int count;    // count slabs, `stride` floats apart
+    int src_cols, dst_rows, dst_cols;           // 2-D window [dst_rows, dst_cols] of a [*, src_cols] slab image
+    float* dst;
+    int blk_start;
+};
+struct SlabReduceArgs { SlabSeg seg[4]; int nseg; };
+
+__global__ void __launch_bounds__(256) slab_reduce_kernel(SlabReduceArgs a) {
+    __shared__ float part[8][32];
+    int si = 0;
+    for (int s = 1; s < a.nseg; ++s) if ((int)blockIdx.x >= a.seg[s].blk_start) si = s;
+    const SlabSeg g = a.seg[si];
+    const int e = (blockIdx.x - g.blk_start) * 32 + (threadIdx.x & 31), p = threadIdx.x >> 5;
+    const int total = g.dst_rows * g.dst_cols;
+    const int ec = e < total ? e : total - 1;
+    const int row = ec / g.dst_cols, col = ec - row * g.dst_cols;
+    const float* src = g.src + row * g.src_cols + col;
+    const int per = (g.count + 7) / 8;
+    const int b0 = p * per, b1 = (b0 + per < g.count) ? b0 + per : g.count;
+    float s = 0.f;
+    for (int b = b0; b < b1; b += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(b + u < b1 ? b + u : b1 - 1) * g.stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) if (b + u < b1) s += v[u];
+    }
+    part[p][threadIdx.x & 31] = s;
+    __syncthreads();
+    if (p == 0 && e < total) {
+        float t = part[0][threadIdx.x];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += part[k][threadIdx.x];
+        g.dst[e] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------ batch norm ----
+struct BnArgs {
+    const float* x; int64_t xs; int64_t n; int C;
+    const float *weight, *bias;
+    float *running_mean, *running_var;
+    float momentum, eps; int training;
+    float* out; int64_t os;
+    float *save_mean, *save_invstd;
+    float* part1; float* part2;    // [nblk, C] each
+    // backward
+    const float* gout; int64_t gos;
+    float* gx; int64_t gxs;
+    float *gweight, *gbias;
+};
+
+// rows of this block: [lo, hi)
+__device__ __forceinline__ void bn_rows(const BnArgs& a, int64_t& lo, int64_t& hi) {
+    const int64_t per = (a.n + gridDim.x - 1) / gridDim.x;
+    lo = per * blockIdx.x;
+    hi = lo + per < a.n ? lo + per : a.n;
+    if (lo > hi) lo = hi;
+}
+
+// column sums of f(row) over the block's rows into dst[blockIdx.x][c]; CL = padded column count (power of two)
+template <int MODE>   // 0: x   1: (x - mean)^2   2: (dy, dy * xhat) -> part1, part2
+__device__ __forceinline__ void bn_block_colsum(const BnArgs& a, int CL, const float* mean, const float* invstd, float* sh) {
+    const int c = threadIdx.x & (CL - 1), rsub = threadIdx.x / CL, RS = 256 / CL;
+    int64_t lo, hi;
+    bn_rows(a, lo, hi);
+    const bool act = c < a.C;
+    const int cc = act ? c : 0;
+    const float mu = (MODE >= 1) ? mean[cc] : 0.f, is = (MODE == 2) ? invstd[cc] : 0.f;
+    float s0 = 0.f, s1 = 0.f;
+    for (int64_t r0 = lo + rsub; r0 < hi; r0 += 4 * RS) {
+        float v[4], g[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t rr = r0 + u * RS < hi ? r0 + u * RS : hi - 1;
+            v[u] = a.x[rr * a.xs + cc];
+            if (MODE == 2) g[u] = a.gout[rr * a.gos + cc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (r0 + u * RS < hi) {
+                if (MODE == 0) s0 += v[u];
+                if (MODE == 1) { const float d = v[u] - mu; s0 = fmaf(d, d, s0); }
+                if (MODE == 2) { s0 += g[u]; s1 = fmaf(g[u], (v[u] - mu) * is, s1); }
+            }
+        }
+    }
+    // combine the RS row-lanes of each column in a fixed order
+    sh[threadIdx.x] = s0;
+    if (MODE == 2) sh[256 + threadIdx.x] = s1;
+    __syncthreads();
+    if (rsub == 0 && act) {
+        float t0 = 0.f, t1 = 0.f;
+        for (int k = 0; k < RS; ++k) { t0 += sh[k * CL + c]; if (MODE == 2) t1 += sh[256 + k * CL + c]; }
+        float* p1 = (MODE == 1) ? a.part2 : a.part1;
+        p1[(int64_t)blockIdx.x * a.C + c] = t0;
+        if (MODE == 2) a.part2[(int64_t)blockIdx.x * a.C + c] = t1;
+    }
+}
+
+// sum over blocks of part[b][c] for every column, identically in every block (fixed order), result in sh_out[c]
+__device__ __forceinline__ void bn_total(const float* part, int nblk, int C, int CL, float* sh, float* sh_out) {
+    const int c = threadIdx.x & (CL - 1), rsub = threadIdx.x / CL, RS = 256 / CL;
+    float s = 0.f;
+    if (c < C)
+        for (int b = rsub; b < nblk; b += RS) s += part[(int64_t)b * C + c];
+    __syncthreads();
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (rsub == 0 && c < C) {
+        float t = 0.f;
+        for (int k = 0; k < RS; ++k) t += sh[k * CL + c];
+        sh_out[c] = t;
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) bn_sum_kernel(BnArgs a, int CL) {
+    __shared__ float sh[512];
+    bn_block_colsum<0>(a, CL, nullptr, nullptr, sh);
+}
+
+__global__ void __launch_bounds__(256) bn_var_kernel(BnArgs a, int CL) {
+    __shared__ float sh[512];
+    __shared__ float mean[256];
+    bn_total(a.part1, gridDim.x, a.C, CL, sh, mean);
+    if (threadIdx.x < a.C) mean[threadIdx.x] = mean[threadIdx.x] / (float)a.n;
+    __syncthreads();
+    bn_block_colsum<1>(a, CL, mean, nullptr, sh);
+}
+
+__global__ void __launch_bounds__(256) bn_apply_kernel(BnArgs a, int CL) {
+    __shared__ float sh[512];
+    __shared__ float mean[256], invstd[256], scale[256], shift[256];
+    const int t = threadIdx.x;
+    if (a.training) {
+        bn_total(a.part1, gridDim.x, a.C, CL, sh, mean);
+        bn_total(a.part2, gridDim.x, a.C, CL, sh, invstd);
+        if (t < a.C) {
+            const float mu = mean[t] / (float)a.n, var = invstd[t] / (float)a.n;
+            mean[t] = mu;
+            invstd[t] = 1.f / sqrtf(var + a.eps);
+            if (blockIdx.x == 0) {
+                a.save_mean[t] = mu;
+                a.save_invstd[t] = invstd[t];
+                if (a.running_mean) a.running_mean[t] = fmaf(a.momentum, mu - a.running_mean[t], a.running_mean[t]);
+                if (a.running_var) {
+                    const float unbiased = a.n > 1 ? var * ((float)a.n / (float)(a.n - 1)) : var;
+                    a.running_var[t] = fmaf(a.momentum, unbiased - a.running_var[t], a.running_var[t]);
+                }
+            }
+        }
+    } else if (t < a.C) {
+        mean[t] = a.running_mean[t];
+        invstd[t] = 1.f / sqrtf(a.running_var[t] + a.eps);
+        if (blockIdx.x == 0 && a.save_mean) { a.save_mean[t] = mean[t]; a.save_invstd[t] = invstd[t]; }
+    }
+    __syncthreads();
+    if (t < a.C) {
+        const float w = a.weight ? a.weight[t] : 1.f, b = a.bias ? a.bias[t] : 0.f;
+        scale[t] = invstd[t] * w;
+        shift[t] = b;
+    }
+    __syncthreads();
+    int64_t lo, hi;
+    bn_rows(a, lo, hi);
+    const int64_t cnt = (hi - lo) * a.C;
+    for (int64_t i = t; i < cnt; i += 256) {
+        const int64_t rr = lo + i / a.C;
+        const int c = (int)(i % a.C);
+        a.out[rr * a.os + c] = fmaf(a.x[rr * a.xs + c] - mean[c], scale[c], shift[c]);
+    }
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_partial_kernel(BnArgs a, int CL) {
+    __shared__ float sh[512];
+    bn_block_colsum<2>(a, CL, a.save_mean, a.save_invstd, sh);
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_final_kernel(BnArgs a, int CL, int nblk_part) {
+    __shared__ float sh[512];
+    __shared__ float sdy[256], sdyx[256];
+    bn_total(a.part1, nblk_part, a.C, CL, sh, sdy);
+    bn_total(a.part2, nblk_part, a.C, CL, sh, sdyx);
+    const int t = threadIdx.x;
+    if (blockIdx.x == 0 && t < a.C) {
+        if (a.gbias) a.gbias[t] = sdy[t];
+        if (a.gweight) a.gweight[t] = sdyx[t];
+    }
+    if (!a.gx) return;
+    int64_t lo, hi;
+    bn_rows(a, lo, hi);
+    const int64_t cnt = (hi - lo) * a.C;
+    const float invn = 1.f / (float)a.n;
+    for (int64_t i = t; i < cnt; i += 256) {
+        const int64_t rr = lo + i / a.C;
+        const int c = (int)(i % a.C);
+        const float w = a.weight ? a.weight[c] : 1.f;
+        const float is = a.save_invstd[c];
+        const float dy = a.gout[rr * a.gos + c];
+        float g;
+        if (a.training) {
+            const float xh = (a.x[rr * a.xs + c] - a.save_mean[c]) * is;
+            g = w * is * (dy - invn * (sdy[c] + xh * sdyx[c]));
+        } else {
+            g = w * is * dy;
+        }
+        a.gx[rr * a.gxs + c] = g;
+    }
+}
+
+}  // namespace mkgnn
+
+using namespace mkgnn;
+
+// ================================================================== C ABI ==========================
+namespace {
+
+struct ReadoutDims { int NT, NU, HP, FP; };
+
+bool readout_dims(int F, int H, int G, ReadoutDims& d) {
+    if (F < 1 || F > 128 || H < 1 || H > 64 || G < 1 || G > 64) return false;
+    d.NT = H <= 32 ? 2 : 4;
+    d.NU = F <= 64 ? 1 : 2;
+    d.HP = 16 * d.NT;
+    d.FP = 64 * d.NU;
+    return true;
+}
+
+constexpr int RO_ATOM_BLOCKS = 256;
+constexpr int RO_MOL_BLOCKS = 64;
+constexpr int BN_BLOCKS = 256;
+
+struct ReadoutWs { size_t dA, slab_atoms, slab_mol, total; int slab_atoms_stride, slab_mol_stride; };
+
+ReadoutWs readout_ws(const ReadoutDims& d, int H, int G, int64_t nmol) {
+    ReadoutWs w;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    w.slab_atoms_stride = d.HP * d.FP + d.HP;
+    w.slab_mol_stride = G * H + G;
+    w.dA = 0;
+    w.slab_atoms = up(w.dA + (size_t)nmol * d.HP * 4);
+    w.slab_mol = up(w.slab_atoms + (size_t)RO_ATOM_BLOCKS * w.slab_atoms_stride * 4);
+    w.total = up(w.slab_mol + (size_t)RO_MOL_BLOCKS * w.slab_mol_stride * 4);
+    return w;
+}
+
+int check_readout(const char* who, const mkgnn_readout_params* p, const float* h, int64_t h_stride, int64_t n_atoms,
+                  const int32_t* mol_ptr, int64_t n_mols, ReadoutDims& d) {
+    if (!p) return api_fail("%s: params is null", who);
+    if (!readout_dims(p->F, p->H, p->G, d))
+        return api_fail("%s: shape F=%d H=%d G=%d outside F<=128, H<=64, G<=64", who, p->F, p->H, p->G);
+    if (!p->lin1_weight || !p->lin2_weight) return api_fail("%s: weight pointer is null", who);
+    if (n_atoms < 0 || n_mols < 0 || n_atoms >= (int64_t)1 << 31) return api_fail("%s: bad sizes", who);
+    if (h_stride < (p->F + 3) / 4 * 4 || h_stride % 4 || ((uintptr_t)h & 15))
+        return api_fail("%s: h rows must be 16-byte aligned with stride >= F rounded up to 4 (stride %lld)", who,
+                        (long long)h_stride);
+    if (n_atoms && (!h || !mol_ptr)) return api_fail("%s: h/mol_ptr is null", who);
+    return 0;
+}
+
+ReadoutArgs readout_args(const mkgnn_readout_params* p, const float* h, int64_t hs, int64_t n, const int32_t* mol_ptr,
+                         const int32_t* atom_mol, int64_t nmol, const float* keep, float* pre, float* pooled) {
+    ReadoutArgs a{};
+    a.h = h; a.hs = hs; a.n = n; a.mol_ptr = mol_ptr; a.atom_mol = atom_mol; a.nmol = nmol;
+    a.w1 = p->lin1_weight; a.b1 = p->lin1_bias; a.w2 = p->lin2_weight; a.b2 = p->lin2_bias;
+    a.F = p->F; a.H = p->H; a.G = p->G;
+    a.keep = keep; a.pre = pre; a.pooled = pooled;
+    return a;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t mkgnn_readout_hidden_stride(int32_t H) { return H <= 32 ? 32 : 64; }
+
+size_t mkgnn_readout_workspace_bytes(int32_t F, int32_t H, int32_t G, int64_t n_atoms, int64_t n_mols) {
+    ReadoutDims d;
+    if (!readout_dims(F, H, G, d) || n_mols < 0) return 0;
+    (void)n_atoms;
+    return readout_ws(d, H, G, n_mols).total;
+}
+
+int mkgnn_readout_forward(const mkgnn_readout_params* p, const float* h, int64_t h_stride, int64_t n_atoms,
+                          const int32_t* mol_ptr, int64_t n_mols, const float* keep_scale, float* pre, float* pooled,
+                          float* out, int64_t out_stride, void* stream) {
+    ReadoutDims d;
+    if (int rc = check_readout("mkgnn_readout_forward", p, h, h_stride, n_atoms, mol_ptr, n_mols, d)) return rc;
+    if (n_mols && (!out || !pooled || out_stride < p->G)) return api_fail("mkgnn_readout_forward: bad out/pooled");
+    if (n_atoms && !pre) return api_fail("mkgnn_readout_forward: pre is null");
+    hipStream_t st = (hipStream_t)stream;
+    ReadoutArgs a = readout_args(p, h, h_stride, n_atoms, mol_ptr, nullptr, n_mols, keep_scale, pre, pooled);
+    a.out = out; a.os = out_stride;
+    if (n_atoms) {
+        const int64_t ntiles = (n_atoms + 15) / 16;
+        const int grid = (int)((ntiles + 3) / 4 < 1024 ? (ntiles + 3) / 4 : 1024);
+        if (d.NT == 2 && d.NU == 1) readout_pre_kernel<2, 4><<<grid, 256, 0, st>>>(a);
+        else if (d.NT == 2) readout_pre_kernel<2, 8><<<grid, 256, 0, st>>>(a);
+        else if (d.NU == 1) readout_pre_kernel<4, 4><<<grid, 256, 0, st>>>(a);
+        else readout_pre_kernel<4, 8><<<grid, 256, 0, st>>>(a);
+    }
+    if (n_mols) {
+        const int grid = (int)((n_mols + 3) / 4 < 2048 ? (n_mols + 3) / 4 : 2048);
+        readout_pool_kernel<<<grid, 256, 0, st>>>(a, d.HP);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : api_hip_fail("mkgnn_readout_forward", e);
+}
+
+int mkgnn_readout_backward(const mkgnn_readout_params* p, const float* h, int64_t h_stride, int64_t n_atoms,
+                           const int32_t* mol_ptr, const int32_t* atom_mol, int64_t n_mols, const float* keep_scale,
+                           const float* pre, const float* pooled, const float* grad_out, int64_t grad_out_stride,
+                           float* grad_h, int64_t grad_h_stride, float* grad_lin1_weight, float* grad_lin1_bias,
+                           float* grad_lin2_weight, float* grad_lin2_bias, void* ws, size_t ws_bytes, void* stream) {
+    ReadoutDims d;
+    if (int rc = check_readout("mkgnn_readout_backward", p, h, h_stride, n_atoms, mol_ptr, n_mols, d)) return rc;
+    if (n_atoms == 0 || n_mols == 0) return api_fail("mkgnn_readout_backward: empty batch");
+    if (!atom_mol || !pre || !pooled || !grad_out || grad_out_stride < p->G)
+        return api_fail("mkgnn_readout_backward: null pointer or bad grad_out stride");
+    if (grad_h && grad_h_stride < p->F) return api_fail("mkgnn_readout_backward: bad grad_h stride");
+    const ReadoutWs w = readout_ws(d, p->H, p->G, n_mols);
+    if (!ws || ws_bytes < w.total) return api_fail("mkgnn_readout_backward: workspace too small (%zu < %zu)", ws_bytes, w.total);
+    hipStream_t st = (hipStream_t)stream;
+    ReadoutArgs a = readout_args(p, h, h_stride, n_atoms, mol_ptr, atom_mol, n_mols, keep_scale, (float*)pre, (float*)pooled);
+    a.gout = grad_out; a.gos = grad_out_stride;
+    a.dA = (float*)((char*)ws + w.dA);
+    a.gh = grad_h; a.ghs = grad_h_stride;
+    a.slab_atoms = (float*)((char*)ws + w.slab_atoms); a.slab_atoms_stride = w.slab_atoms_stride;
+    a.slab_mol = (float*)((char*)ws + w.slab_mol); a.slab_mol_stride = w.slab_mol_stride;
+    const int64_t ntiles = (n_atoms + 15) / 16;
+    a.nblk_atoms = (int)((ntiles + 3) / 4 < RO_ATOM_BLOCKS ? (ntiles + 3) / 4 : RO_ATOM_BLOCKS);
+    a.nblk_mol = (int)((n_mols + 15) / 16 < RO_MOL_BLOCKS ? (n_mols + 15) / 16 : RO_MOL_BLOCKS);
+    readout_bwd_mol_kernel<<<a.nblk_mol, 256, 0, st>>>(a, d.HP);
+    if (d.NT == 2 && d.NU == 1) readout_bwd_atoms_kernel<2, 1><<<a.nblk_atoms, 256, 0, st>>>(a);
+    else if (d.NT == 2) readout_bwd_atoms_kernel<2, 2><<<a.nblk_atoms, 256, 0, st>>>(a);
+    else if (d.NU == 1) readout_bwd_atoms_kernel<4, 1><<<a.nblk_atoms, 256, 0, st>>>(a);
+    else readout_bwd_atoms_kernel<4, 2><<<a.nblk_atoms, 256, 0, st>>>(a);
+    SlabReduceArgs r{};
+    int blk = 0;
+    auto add = [&](const float* src, int stride, int count, int src_cols, int rows, int cols, float* dst) {
+        if (!dst) return;
+        SlabSeg& s = r.seg[r.nseg++];
+        s.src = src; s.stride = stride; s.count = count; s.src_cols = src_cols; s.dst_rows = rows; s.dst_cols = cols;
+        s.dst = dst; s.blk_start = blk;
+        blk += (rows * cols + 31) / 32;
+    };
+    add(a.slab_atoms, a.slab_atoms_stride, a.nblk_atoms, d.FP, p->H, p->F, grad_lin1_weight);
+    add(a.slab_atoms + d.HP * d.FP, a.slab_atoms_stride, a.nblk_atoms, d.HP, 1, p->H, grad_lin1_bias);
+    add(a.slab_mol, a.slab_mol_stride, a.nblk_mol, p->H, p->G, p->H, grad_lin2_weight);
+    add(a.slab_mol + p->G * p->H, a.slab_mol_stride, a.nblk_mol, p->G, 1, p->G, grad_lin2_bias);
+    if (blk) slab_reduce_kernel<<<blk, 256, 0, st>>>(r);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : api_hip_fail("mkgnn_readout_backward", e);
+}
+
+size_t mkgnn_batchnorm_workspace_bytes(int32_t C) { return C > 0 ? (size_t)2 * BN_BLOCKS * C * 4 : 0; }
+
+static int bn_common(const char* who, int64_t n, int32_t C, int& CL) {
+    if (C < 1 || C > 256) return api_fail("%s: channel count C=%d outside 1..256", who, C);
+    if (n < 1) return api_fail("%s: batch norm needs at least one row", who);
+    CL = 1;
+    while (CL < C) CL <<= 1;
+    return 0;
+}
+
+int mkgnn_batchnorm_forward(const float* x, int64_t x_stride, int64_t n_rows, int32_t C, const float* weight,
+                            const float* bias, float* running_mean, float* running_var, float momentum, float eps,
+                            int32_t training, float* out, int64_t out_stride, float* save_mean, float* save_invstd,
+                            void* ws, size_t ws_bytes, void* stream) {
+    int CL;
+    if (int rc = bn_common("mkgnn_batchnorm_forward", n_rows, C, CL)) return rc;
+    if (!x || !out || x_stride < C || out_stride < C) return api_fail("mkgnn_batchnorm_forward: bad x/out");
+    if (training && (!save_mean || !save_invstd)) return api_fail("mkgnn_batchnorm_forward: save_mean/save_invstd is null");
+    if (!training && (!running_mean || !running_var)) return api_fail("mkgnn_batchnorm_forward: eval mode needs running statistics");
+    if (training && (!ws || ws_bytes < mkgnn_batchnorm_workspace_bytes(C))) return api_fail("mkgnn_batchnorm_forward: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    BnArgs a{};
+    a.x = x; a.xs = x_stride; a.n = n_rows; a.C = C; a.weight = weight; a.bias = bias;
+    a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum; a.eps = eps; a.training = training;
+    a.out = out; a.os = out_stride; a.save_mean = save_mean; a.save_invstd = save_invstd;
+    a.part1 = (float*)ws; a.part2 = a.part1 ? a.part1 + (size_t)BN_BLOCKS * C : nullptr;
+    if (training) {
+        bn_sum_kernel<<<BN_BLOCKS, 256, 0, st>>>(a, CL);
+        bn_var_kernel<<<BN_BLOCKS, 256, 0, st>>>(a, CL);
+    }
+    bn_apply_kernel<<<BN_BLOCKS, 256, 0, st>>>(a, CL);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : api_hip_fail("mkgnn_batchnorm_forward", e);
+}
+
+int mkgnn_batchnorm_backward(const float* grad_out, int64_t grad_out_stride, const float* x, int64_t x_stride,
+                             int64_t n_rows, int32_t C, const float* weight, const float* save_mean,
+                             const float* save_invstd, int32_t training, float* grad_x, int64_t grad_x_stride, float* grad_weight, float* grad_bias, void* ws,
+                             size_t ws_bytes, void* stream) {
+    int CL;
+    if (int rc = bn_common("mkgnn_batchnorm_backward", n_rows, C, CL)) return rc;
+    if (!grad_out || !x || grad_out_stride < C || x_stride < C) return api_fail("mkgnn_batchnorm_backward: bad grad_out/x");
+    if (!save_mean || !save_invstd) return api_fail("mkgnn_batchnorm_backward: saved statistics are null");
+    if (grad_x && grad_x_stride < C) return api_fail("mkgnn_batchnorm_backward: bad grad_x stride");
+    if (!ws || ws_bytes < mkgnn_batchnorm_workspace_bytes(C)) return api_fail("mkgnn_batchnorm_backward: workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    BnArgs a{};
+    a.x = x; a.xs = x_stride; a.n = n_rows; a.C = C; a.weight = weight;
+    a.training = training;
+    a.save_mean = (float*)save_mean; a.save_invstd = (float*)save_invstd;
+    a.part1 = (float*)ws; a.part2 = a.part1 + (size_t)BN_BLOCKS * C;
+    a.gout = grad_out; a.gos = grad_out_stride; a.gx = grad_x; a.gxs = grad_x_stride;
+    a.gweight = grad_weight; a.gbias = grad_bias;
+    bn_bwd_partial_kernel<<<BN_BLOCKS, 256, 0, st>>>(a, CL);
+    bn_bwd_final_kernel<<<grad_x ? BN_BLOCKS : 1, 256, 0, st>>>(a, CL, BN_BLOCKS);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : api_hip_fail("mkgnn_batchnorm_backward", e);
+}
+
+}  // extern "C"

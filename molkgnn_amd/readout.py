@@ -1,0 +1,212 @@
+"""The two consumers either side of the kernel-convolution stack as HIP operators:
+
+* ``batch_norm(x, bn)``  -- ``self.node_batch_norm(data.x)`` (reference ``MolKGNNNet.py:115``) for a
+  ``torch.nn.BatchNorm1d`` module ``bn`` (its parameters, running statistics and flags are used as is);
+* ``readout(h, lin1, lin2, dropout, batch, size)`` -- ``pool(lin2(dropout(swish(lin1(h)))), batch)``
+  (reference ``MolKGNNNet.py:144-146``).
+
+Both call ``libmolkgnn_hip.so`` through the C ABI (``mkgnn_batchnorm_*``, ``mkgnn_readout_*``); shapes
+outside the kernels' limits (hidden width > 64, node width > 128, an unsorted ``batch`` vector,
+``momentum=None``) take the same formula through PyTorch operators on the GPU instead.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .functional import _aligned_rows, _row_major, _stride0
+
+_SEG_CACHE: dict = {}
+_SEG_CACHE_MAX = 32
+
+
+class MoleculeSegments:
+    """``batch`` (atom -> molecule id) as contiguous segments: ``mol_ptr [B+1]``, ``atom_mol [N]`` (int32)."""
+
+    def __init__(self, batch: torch.Tensor, size: int):
+        self.size = int(size)
+        b = batch.long()
+        self.sorted = bool((b[1:] >= b[:-1]).all().item()) if b.numel() > 1 else True
+        counts = torch.bincount(b, minlength=self.size)
+        if counts.numel() > self.size:
+            raise ValueError(f"batch holds molecule ids >= size ({counts.numel()} > {self.size})")
+        ptr = torch.zeros(self.size + 1, dtype=torch.int32, device=batch.device)
+        ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+        self.mol_ptr = ptr
+        self.atom_mol = b.to(torch.int32).contiguous()
+
+
+def molecule_segments(batch: torch.Tensor, size: Optional[int]) -> MoleculeSegments:
+    """Cached on the identity of ``batch`` (resident batches keep their tensors alive): built once per
+    batch, so a step contains no host synchronisation for it (hipGraph capture)."""
+    if size is None:
+        size = int(batch.max().item()) + 1 if batch.numel() else 0
+    key = (batch.data_ptr(), batch.numel(), str(batch.device), int(size))
+    seg = _SEG_CACHE.get(key)
+    if seg is None:
+        seg = MoleculeSegments(batch, size)
+        if len(_SEG_CACHE) >= _SEG_CACHE_MAX:
+            _SEG_CACHE.pop(next(iter(_SEG_CACHE)))
+        _SEG_CACHE[key] = seg
+    return seg
+
+
+def swish(x):
+    return x * torch.sigmoid(x)
+
+
+def readout_supported(F: int, H: int, G: int) -> bool:
+    return 1 <= F <= 128 and 1 <= H <= 64 and 1 <= G <= 64
+
+
+def _params(w1, b1, w2, b2):
+    p = _lib.ReadoutParams()
+    p.lin1_weight, p.lin1_bias = w1.data_ptr(), _lib.ptr(b1)
+    p.lin2_weight, p.lin2_bias = w2.data_ptr(), _lib.ptr(b2)
+    p.H, p.F = w1.shape
+    p.G = w2.shape[0]
+    return p
+
+
+class _ReadoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, w1, b1, w2, b2, keep, seg: MoleculeSegments):
+        lib = _lib.load()
+        _lib.require_gpu_tensor(h, "node_representation")
+        h = _aligned_rows(h if h.dtype == torch.float32 else h.float())
+        w1c, w2c = w1.contiguous(), w2.contiguous()
+        n, F = h.shape
+        H, G = w1c.shape[0], w2c.shape[0]
+        dev = h.device
+        hs = lib.mkgnn_readout_hidden_stride(H)
+        pre = torch.empty((n, hs), dtype=torch.float32, device=dev)
+        pooled = torch.empty((seg.size, hs), dtype=torch.float32, device=dev)
+        out = torch.empty((seg.size, G), dtype=torch.float32, device=dev)
+        keepc = None if keep is None else keep.contiguous()
+        p = _params(w1c, b1, w2c, b2)
+        with torch.cuda.device(dev):
+            _lib.check(lib.mkgnn_readout_forward(p, h.data_ptr(), _stride0(h), n, seg.mol_ptr.data_ptr(), seg.size,
+                                                 _lib.ptr(keepc), _lib.ptr(pre), _lib.ptr(pooled), _lib.ptr(out), G,
+                                                 _lib.stream_ptr(dev)), "mkgnn_readout_forward")
+        ctx.seg = seg
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        ctx.save_for_backward(h, w1c, b1, w2c, b2, keepc, pre, pooled)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        h, w1, b1, w2, b2, keep, pre, pooled = ctx.saved_tensors
+        seg = ctx.seg
+        n, F = h.shape
+        H, G = w1.shape[0], w2.shape[0]
+        dev = h.device
+        g = _row_major(grad_out if grad_out.dtype == torch.float32 else grad_out.float())
+        gh = torch.empty((n, F), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        gw1, gw2 = torch.empty_like(w1), torch.empty_like(w2)
+        gb1 = torch.empty_like(b1) if b1 is not None else None
+        gb2 = torch.empty_like(b2) if b2 is not None else None
+        if n == 0 or seg.size == 0:
+            for t in (gh, gw1, gw2, gb1, gb2):
+                if t is not None:
+                    t.zero_()
+            return gh, gw1, gb1, gw2, gb2, None, None
+        p = _params(w1, b1, w2, b2)
+        with torch.cuda.device(dev):
+            ws_bytes = int(lib.mkgnn_readout_workspace_bytes(F, H, G, n, seg.size))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.mkgnn_readout_backward(
+                p, h.data_ptr(), _stride0(h), n, seg.mol_ptr.data_ptr(), seg.atom_mol.data_ptr(), seg.size,
+                _lib.ptr(keep), pre.data_ptr(), pooled.data_ptr(), g.data_ptr(), _stride0(g),
+                _lib.ptr(gh), F, gw1.data_ptr(), _lib.ptr(gb1), gw2.data_ptr(), _lib.ptr(gb2),
+                ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)), "mkgnn_readout_backward")
+        return gh, gw1, gb1, gw2, gb2, None, None
+
+
+def readout(h: torch.Tensor, lin1: torch.nn.Linear, lin2: torch.nn.Linear, dropout: Optional[torch.nn.Dropout],
+            batch: torch.Tensor, size: Optional[int] = None) -> torch.Tensor:
+    """``global_add_pool(lin2(dropout(swish(lin1(h)))), batch, size)`` -> ``[size, G]``."""
+    _lib.require_gpu_tensor(h, "node_representation")
+    seg = molecule_segments(batch, size)
+    H, F = lin1.weight.shape
+    G = lin2.weight.shape[0]
+    p_drop = dropout.p if (dropout is not None and dropout.training) else 0.0
+    if not (seg.sorted and readout_supported(F, H, G) and h.shape[0] > 0 and seg.size > 0):
+        z = swish(lin1(h))
+        if dropout is not None:
+            z = dropout(z)
+        z = lin2(z)
+        return torch.zeros(seg.size, G, dtype=z.dtype, device=z.device).index_add_(0, batch, z)
+    keep = None
+    if p_drop > 0.0:
+        # the multipliers torch's dropout would apply: 0 with probability p, else 1 / (1 - p)
+        keep = torch.empty((h.shape[0], H), dtype=torch.float32, device=h.device)
+        if p_drop >= 1.0:
+            keep.zero_()
+        else:
+            keep.bernoulli_(1.0 - p_drop).mul_(1.0 / (1.0 - p_drop))
+    return _ReadoutFn.apply(h, lin1.weight, lin1.bias, lin2.weight, lin2.bias, keep, seg)
+
+
+# ------------------------------------------------------------------------------------------ batch norm --
+class _BatchNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, bn: torch.nn.BatchNorm1d, use_batch_stats: bool):
+        lib = _lib.load()
+        x = _row_major(x if x.dtype == torch.float32 else x.float())
+        n, C = x.shape
+        dev = x.device
+        out = torch.empty((n, C), dtype=torch.float32, device=dev)
+        save_mean = torch.empty(C, dtype=torch.float32, device=dev)
+        save_invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        update = bn.training and bn.track_running_stats and bn.running_mean is not None
+        rm = bn.running_mean if (update or not use_batch_stats) else None
+        rv = bn.running_var if (update or not use_batch_stats) else None
+        with torch.cuda.device(dev):
+            ws_bytes = int(lib.mkgnn_batchnorm_workspace_bytes(C))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.mkgnn_batchnorm_forward(
+                x.data_ptr(), _stride0(x), n, C, _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(rm), _lib.ptr(rv),
+                float(bn.momentum if bn.momentum is not None else 0.0), float(bn.eps), int(use_batch_stats),
+                out.data_ptr(), C, save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(), ws_bytes,
+                _lib.stream_ptr(dev)), "mkgnn_batchnorm_forward")
+        if update and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked.add_(1)
+        ctx.use_batch_stats = use_batch_stats
+        ctx.save_for_backward(x, weight, save_mean, save_invstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        x, weight, save_mean, save_invstd = ctx.saved_tensors
+        n, C = x.shape
+        dev = x.device
+        g = _row_major(grad_out if grad_out.dtype == torch.float32 else grad_out.float())
+        gx = torch.empty((n, C), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        gw = torch.empty(C, dtype=torch.float32, device=dev) if (weight is not None and ctx.needs_input_grad[1]) else None
+        gb = torch.empty(C, dtype=torch.float32, device=dev) if ctx.needs_input_grad[2] else None
+        with torch.cuda.device(dev):
+            ws_bytes = int(lib.mkgnn_batchnorm_workspace_bytes(C))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.mkgnn_batchnorm_backward(
+                g.data_ptr(), _stride0(g), x.data_ptr(), _stride0(x), n, C, _lib.ptr(weight), save_mean.data_ptr(),
+                save_invstd.data_ptr(), int(ctx.use_batch_stats), _lib.ptr(gx), C, _lib.ptr(gw), _lib.ptr(gb),
+                ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)), "mkgnn_batchnorm_backward")
+        return gx, gw, gb, None, None
+
+
+def batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm1d) -> torch.Tensor:
+    """``bn(x)`` for a 2-D input on the GPU, with ``torch.nn.BatchNorm1d``'s semantics (batch statistics in
+    training mode or when no running statistics are tracked; running statistics updated in place)."""
+    _lib.require_gpu_tensor(x, "x")
+    if x.dim() != 2 or x.shape[1] != bn.num_features:
+        raise ValueError(f"expected a [N, {bn.num_features}] input, got {tuple(x.shape)}")
+    use_batch_stats = bn.training or bn.running_mean is None
+    if x.shape[1] > 256 or x.shape[0] == 0 or (bn.training and bn.track_running_stats and bn.momentum is None):
+        return bn(x)
+    if use_batch_stats and bn.training and x.shape[0] == 1:
+        raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
+    return _BatchNormFn.apply(x, bn.weight, bn.bias, bn, use_batch_stats)

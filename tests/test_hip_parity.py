@@ -279,3 +279,96 @@ def test_propagate_hands_row_norms_to_next_layer():
         assert torch.equal(inv, Fn.row_inv_norm(h))          # same summation order in both kernels
         h.mul_(2.0)
         assert Fn._handed_inv_norm(h) is None
+
+
+def _torch_readout(h, w1, b1, w2, b2, keep, batch, size):
+    z = torch.nn.functional.linear(h, w1, b1)
+    z = z * torch.sigmoid(z)
+    if keep is not None:
+        z = z * keep
+    z = torch.nn.functional.linear(z, w2, b2)
+    return torch.zeros(size, w2.shape[0], device=h.device).index_add_(0, batch, z)
+
+
+@pytest.mark.parametrize("F,H,G,bias,drop", [(110, 32, 32, True, False), (110, 32, 32, True, True), (28, 5, 7, False, False),
+                                              (70, 64, 3, True, True), (128, 33, 64, True, False)])
+def test_readout_matches_torch_formula(F, H, G, bias, drop):
+    """pool(lin2(dropout(swish(lin1(h))))) (reference MolKGNNNet.py:144-146) against the same formula in
+    PyTorch fp32 operators: forward 1e-5 relative to the output scale, all five gradients."""
+    from molkgnn_amd import readout as R
+    from molkgnn_amd.synthetic import make_batch
+    dev = _dev()
+    b = make_batch(37, seed=F + H, device=dev, with_receptive_fields=False)
+    n, size = b.x.shape[0], 37
+    g = torch.Generator().manual_seed(F * 1000 + H)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    h = rnd(n, F).to(dev).requires_grad_(True)
+    w1 = (rnd(H, F) * F ** -0.5).to(dev).requires_grad_(True)
+    w2 = (rnd(G, H) * H ** -0.5).to(dev).requires_grad_(True)
+    b1 = rnd(H).to(dev).requires_grad_(True) if bias else None
+    b2 = rnd(G).to(dev).requires_grad_(True) if bias else None
+    keep = ((torch.rand(n, H, generator=g) > 0.25).float() / 0.75).to(dev) if drop else None
+    cot = rnd(size, G).to(dev)
+    seg = R.molecule_segments(b.batch, size)
+    assert seg.sorted
+    out = R._ReadoutFn.apply(h, w1, b1, w2, b2, keep, seg)
+    leaves = [t for t in (h, w1, b1, w2, b2) if t is not None]
+    got = torch.autograd.grad((out * cot).sum(), leaves)
+    ref = _torch_readout(h, w1, b1, w2, b2, keep, b.batch, size)
+    want = torch.autograd.grad((ref * cot).sum(), leaves)
+    scale = float(ref.detach().abs().max())
+    assert float((out - ref).abs().max()) <= 1e-5 * max(scale, 1.0)
+    for a, w in zip(got, want):
+        assert float((a - w).abs().max()) <= 2e-5 * max(float(w.abs().max()), 1.0), (a.shape, float((a - w).abs().max()))
+
+
+def test_readout_module_paths():
+    """The module-level entry point: fused path, dropout in eval mode, an unsorted batch vector (PyTorch
+    operators on the GPU) and an empty molecule in the middle of the batch."""
+    from molkgnn_amd import readout as R
+    dev = _dev()
+    torch.manual_seed(0)
+    lin1, lin2, drop = torch.nn.Linear(110, 32).to(dev), torch.nn.Linear(32, 32).to(dev), torch.nn.Dropout(0.25).eval()
+    batch = torch.tensor([0] * 5 + [1] * 20 + [3] * 7, device=dev)          # molecule 2 has no atoms
+    h = torch.randn(32, 110, device=dev)
+    ref = _torch_readout(h, lin1.weight, lin1.bias, lin2.weight, lin2.bias, None, batch, 4)
+    out = R.readout(h, lin1, lin2, drop, batch, 4)
+    assert torch.allclose(out, ref, atol=1e-5, rtol=1e-5)
+    assert float(out[2].abs().max()) == 0.0
+    perm = torch.randperm(32, device=dev)
+    out_p = R.readout(h[perm], lin1, lin2, drop, batch[perm].contiguous(), 4)
+    assert torch.allclose(out_p, ref, atol=1e-5, rtol=1e-5)
+    drop.train()
+    torch.manual_seed(1)
+    o1 = R.readout(h, lin1, lin2, drop, batch, 4)
+    assert not torch.allclose(o1, ref, atol=1e-3)                            # multipliers were applied
+
+
+@pytest.mark.parametrize("C,n,affine", [(28, 1000, True), (28, 37, True), (7, 513, True), (130, 300, False)])
+def test_batch_norm_matches_torch(C, n, affine):
+    """node_batch_norm (reference MolKGNNNet.py:115): training and eval forward, running statistics and all
+    three gradients against torch.nn.BatchNorm1d."""
+    from molkgnn_amd import readout as R
+    dev = _dev()
+    torch.manual_seed(C)
+    x = (torch.randn(n, C, device=dev) * 3 + 1.5)
+    cot = torch.randn(n, C, device=dev)
+    mine, ref = torch.nn.BatchNorm1d(C, affine=affine).to(dev), torch.nn.BatchNorm1d(C, affine=affine).to(dev)
+    if affine:
+        with torch.no_grad():
+            mine.weight.uniform_(0.5, 1.5); mine.bias.normal_()
+            ref.weight.copy_(mine.weight); ref.bias.copy_(mine.bias)
+    for mode in ("train", "train", "eval"):
+        mine.train(mode == "train"); ref.train(mode == "train")
+        xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        ya, yb = R.batch_norm(xa, mine), ref(xb)
+        assert torch.allclose(ya, yb, atol=2e-5, rtol=1e-5)
+        (ya * cot).sum().backward(); (yb * cot).sum().backward()
+        assert torch.allclose(xa.grad, xb.grad, atol=2e-5, rtol=1e-4)
+        if affine:
+            assert torch.allclose(mine.weight.grad, ref.weight.grad, atol=1e-3, rtol=1e-4)
+            assert torch.allclose(mine.bias.grad, ref.bias.grad, atol=1e-3, rtol=1e-4)
+            mine.zero_grad(); ref.zero_grad()
+        assert torch.allclose(mine.running_mean, ref.running_mean, atol=1e-6, rtol=1e-5)
+        assert torch.allclose(mine.running_var, ref.running_var, atol=1e-5, rtol=1e-5)
+        assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked)

@@ -136,3 +136,20 @@ def test_module_surface_matches_the_reference_names():
         MolGCN(num_layers=0)
     k = KernelConv(L=4, D=3, num_supports=3, node_attr_dim=6, edge_attr_dim=2)
     assert k.get_num_kernels() == 4 and k.support_attr_sc_weight.dim() == 0
+
+
+def test_molecule_segments_and_readout_refuses_cpu():
+    from molkgnn_amd import readout as R
+    from molkgnn_amd._lib import MolKGNNLibraryError
+    batch = torch.tensor([0, 0, 1, 1, 1, 3])
+    seg = R.MoleculeSegments(batch, 5)
+    assert seg.sorted and seg.mol_ptr.tolist() == [0, 2, 5, 5, 6, 6] and seg.atom_mol.tolist() == batch.tolist()
+    assert not R.MoleculeSegments(torch.tensor([1, 0, 1]), 2).sorted
+    with pytest.raises(ValueError):
+        R.MoleculeSegments(torch.tensor([0, 4]), 3)
+    assert R.readout_supported(110, 32, 32) and not R.readout_supported(200, 32, 32)
+    lin = torch.nn.Linear(4, 4)
+    with pytest.raises(MolKGNNLibraryError):
+        R.readout(torch.zeros(6, 4), lin, lin, None, batch, 5)
+    with pytest.raises(MolKGNNLibraryError):
+        R.batch_norm(torch.zeros(6, 4), torch.nn.BatchNorm1d(4))
