@@ -99,8 +99,9 @@ size_t mkgnn_workspace_bytes(const int32_t num_kernels[MKGNN_MAX_DEGREE], int32_
  * own degree in columns [off_d, off_d + L_d) and zeros elsewhere.
  *   x        [N, F] with row stride x_stride (floats)
  *   inv_norm [N] from mkgnn_row_inv_norm
- *   out      [N, K] with row stride out_stride; every atom that is in a bucket
- *            gets its whole row written; other rows are not touched.
+ *   out      [N, K] with row stride out_stride, fully overwritten (rows of atoms in no bucket
+ *            are zero).  If out_stride holds K rounded up to a multiple of 4, that alignment
+ *            padding is zeroed too, so the next layer can read 16-byte rows.
  * variant: 0 = automatic, 1 = generic VALU kernels, 2 = MFMA kernels. */
 int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
                                 const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],
@@ -134,6 +135,8 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
  * sum: out[i, :] = sum_{k in [rowptr[i], rowptr[i+1])} in[col[k], :].
  * Forward uses the edges grouped by target (col = sources); the gradient is the
  * same call on the edges grouped by source (col = targets).  width <= strides.
+ * 16-byte aligned rows (bases, strides % 4 == 0 and >= width rounded up to 4, width <= 256) take the
+ * pipelined kernel, which also writes the alignment padding of `out` as zero.
  * inv_norm (may be NULL): also write 1 / max(||out[i]||, 1e-8) -- the next layer's cosine needs it,
  * so the producer of h hands it over instead of a separate pass over h. */
 int mkgnn_segment_sum_rows(const float* in, int64_t in_stride, const int32_t* rowptr,

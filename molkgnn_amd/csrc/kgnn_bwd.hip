@@ -142,7 +142,7 @@ __global__ void __launch_bounds__(256) kc_backward_rows_lds(BwdArgs a) {
                     if (n < a.n) {
 #pragma unroll
                         for (int s = 0; s <= D; ++s)
-                            *(float2*)(a.contrib + (size_t)(a.contrib_base + n * (D + 1) + s) * a.F + 2 * lane) = acc[u][s];
+                            *(float2*)(a.contrib + (size_t)(a.contrib_base + n * (D + 1) + s) * a.CS + 2 * lane) = acc[u][s];
                     }
                 }
             }

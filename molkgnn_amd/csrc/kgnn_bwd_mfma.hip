@@ -141,13 +141,13 @@ __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(Bw
         for (int jj = 0; jj < 4; ++jj) {
             const int64_t nn = tile * 16 + kq * 4 + jj;
             if (nn < a.n) {
-                float* dst = a.contrib + (size_t)(a.contrib_base + nn * (D + 1)) * a.F + ci;
+                float* dst = a.contrib + (size_t)(a.contrib_base + nn * (D + 1)) * a.CS + ci;
                 const bool last_ok = 16 * (FT - 1) + ci < a.F;     // only the last feature tile can be partial
 #pragma unroll
                 for (int s = 0; s <= D; ++s) {
 #pragma unroll
-                    for (int ft = 0; ft < FT - 1; ++ft) dst[(size_t)s * a.F + 16 * ft] = acc[s][ft][jj];
-                    if (last_ok) dst[(size_t)s * a.F + 16 * (FT - 1)] = acc[s][FT - 1][jj];
+                    for (int ft = 0; ft < FT - 1; ++ft) dst[(size_t)s * a.CS + 16 * ft] = acc[s][ft][jj];
+                    if (last_ok) dst[(size_t)s * a.CS + 16 * (FT - 1)] = acc[s][FT - 1][jj];
                 }
             }
         }

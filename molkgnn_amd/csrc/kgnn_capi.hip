@@ -185,8 +185,10 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
     if (e != hipSuccess) return hip_fail("bank_prepare", e);
     // every atom's row is zero outside its own degree block (kernels.py:674-675, 725-727): one
     // streaming memset, the degree kernels then write only their column blocks
+    // (alignment padding up to the next multiple of four columns is zeroed with it when the stride holds it)
     if (n_atoms > 0 && K > 0) {
-        e = hipMemset2DAsync(out, (size_t)out_stride * 4, 0, (size_t)K * 4, (size_t)n_atoms, st);
+        const int64_t K4 = (K + 3) / 4 * 4;
+        e = hipMemset2DAsync(out, (size_t)out_stride * 4, 0, (size_t)(K4 <= out_stride ? K4 : K) * 4, (size_t)n_atoms, st);
         if (e != hipSuccess) return hip_fail("output memset", e);
     }
     // the fused MFMA launch takes every degree whose shape it covers; the rest run on the generic kernels
@@ -291,7 +293,7 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         a.chir = (d == 4 && is_last_layer) ? saved[i].chirality : nullptr;
         if (d == 4 && is_last_layer && buckets[i].count > 0 && !a.chir)
             return fail("%s: degree-4 chirality signs were not saved", who);
-        a.contrib = (float*)(ws + w.contrib); a.contrib_base = base;
+        a.contrib = (float*)(ws + w.contrib); a.contrib_base = base; a.CS = (F + 3) / 4 * 4;
         a.slab = (float*)(ws + w.slab_off[i]);
         a.padded = (const float*)(ws + w.bank[i].padded);
         int64_t nc = a.n < BWD_BANK_BLOCKS ? (a.n > 0 ? a.n : 1) : BWD_BANK_BLOCKS;
@@ -331,8 +333,8 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
     e = fj.end();
     if (e != hipSuccess) return hip_fail("stream join", e);
     if (grad_x) {
-        e = launch_backward_gather((const float*)(ws + w.contrib), scatter_rowptr, scatter_rows, x, x_stride, inv_norm,
-                                   n_atoms, F, grad_x, grad_x_stride, st);
+        e = launch_backward_gather((const float*)(ws + w.contrib), (F + 3) / 4 * 4, base, scatter_rowptr, scatter_rows, x,
+                                   x_stride, inv_norm, n_atoms, F, grad_x, grad_x_stride, st);
         if (e != hipSuccess) return hip_fail("backward gather launch", e);
     }
     return 0;

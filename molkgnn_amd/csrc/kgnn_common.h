@@ -179,7 +179,7 @@ static inline WorkspaceLayout make_layout(const int32_t L[MKGNN_MAX_DEGREE], int
     off = align_up(off + (size_t)n_atoms);
     w.fwd_end = off;
     w.contrib = off;
-    off = align_up(off + (size_t)(n_atoms + n_edges) * F * 4);
+    off = align_up(off + (size_t)(n_atoms + n_edges) * ((F + 3) / 4 * 4) * 4);
     w.slab = off;
     for (int i = 0; i < MKGNN_MAX_DEGREE; ++i) {
         w.slab_off[i] = off;

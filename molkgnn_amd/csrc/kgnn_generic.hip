@@ -254,7 +254,7 @@ __global__ void __launch_bounds__(256) kc_backward_rows(BwdArgs a) {
             if (f < a.F) {
 #pragma unroll
                 for (int s = 0; s <= D; ++s)
-                    a.contrib[(a.contrib_base + n * (D + 1) + s) * a.F + f] = acc[s];
+                    a.contrib[(a.contrib_base + n * (D + 1) + s) * a.CS + f] = acc[s];
             }
         }
     }
@@ -411,7 +411,7 @@ __global__ void __launch_bounds__(256) kc_backward_bank_reduce(BankReduceArgs a)
 // B3: per atom, sum the contribution rows that point at it (fixed CSR order -> reproducible) and
 // undo the row normalisation.  One wave per atom, two floats per lane; the row ids of the segment
 // are fetched first and all row loads issued together, so one atom costs ~2 memory round trips.
-__global__ void __launch_bounds__(256) kc_backward_gather(const float* __restrict__ contrib, const int32_t* __restrict__ rowptr,
+__global__ void __launch_bounds__(256) kc_backward_gather(const float* __restrict__ contrib, int64_t cs, const int32_t* __restrict__ rowptr,
                                                           const int32_t* __restrict__ rows, const float* __restrict__ x,
                                                           int64_t xs, const float* __restrict__ inv, int64_t n, int F,
                                                           float* __restrict__ gx, int64_t gxs) {
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(256) kc_backward_gather(const float* __restric
                 for (int u = 0; u < SEG; ++u) {
                     v[u] = float2{0.f, 0.f};
                     if (rid[u] >= 0 && one) {
-                        const float* src = contrib + (size_t)rid[u] * F + f;
+                        const float* src = contrib + (size_t)rid[u] * cs + f;
                         if (two && ((F & 1) == 0)) v[u] = *(const float2*)src;
                         else { v[u].x = src[0]; if (two) v[u].y = src[1]; }
                     }
@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(256) kc_backward_gather(const float* __restric
                 float2 a2 = {0.f, 0.f}, x2 = {0.f, 0.f};
                 if (f2 < F) {
                     for (int k = lo; k < hi; ++k) {
-                        const float* src = contrib + (size_t)rows[k] * F + f2;
+                        const float* src = contrib + (size_t)rows[k] * cs + f2;
                         a2.x += src[0];
                         if (f2 + 1 < F) a2.y += src[1];
                     }
@@ -534,6 +534,8 @@ static inline int grid_for_waves(int64_t waves, int threads = 256) {
 
 hipError_t launch_row_inv_norm(const float* x, int64_t stride, int64_t n, int F, float* inv, hipStream_t st) {
     if (n == 0) return hipSuccess;
+    hipError_t e = hipSuccess;
+    if (try_row_inv_norm_aligned(x, stride, n, F, inv, st, &e)) return e;
     if (stride % 2 == 0 && F % 2 == 0 && (uintptr_t)x % 8 == 0)
         row_inv_norm_kernel<true><<<grid_for_waves(n), 256, 0, st>>>(x, stride, n, F, inv);
     else
@@ -614,22 +616,30 @@ hipError_t launch_bank_reduce(int d, const BankReduceArgs& r, hipStream_t st) {
     }
 }
 
-hipError_t launch_backward_gather(const float* contrib, const int32_t* rowptr, const int32_t* rows, const float* x,
-                                  int64_t xs, const float* inv, int64_t n, int F, float* gx, int64_t gxs,
-                                  hipStream_t st) {
+hipError_t launch_backward_gather(const float* contrib, int64_t cs, int64_t n_contrib_rows, const int32_t* rowptr,
+                                  const int32_t* rows, const float* x, int64_t xs, const float* inv, int64_t n, int F,
+                                  float* gx, int64_t gxs, hipStream_t st) {
     if (n == 0) return hipSuccess;
-    kc_backward_gather<<<grid_for_waves(n), 256, 0, st>>>(contrib, rowptr, rows, x, xs, inv, n, F, gx, gxs);
+    hipError_t e = hipSuccess;
+    if (n_contrib_rows > 0 && try_backward_gather_aligned(contrib, cs, rowptr, rows, x, xs, inv, n, F, gx, gxs, st, &e)) return e;
+    kc_backward_gather<<<grid_for_waves(n), 256, 0, st>>>(contrib, cs, rowptr, rows, x, xs, inv, n, F, gx, gxs);
     return hipGetLastError();
 }
 
 hipError_t launch_segment_sum(const float* in, int64_t is, const int32_t* rowptr, const int32_t* col, int64_t n,
                               int width, float* out, int64_t os, float* inv_norm, hipStream_t st) {
     if (n == 0) return hipSuccess;
+    hipError_t e = hipSuccess;
+    if (try_segment_sum_aligned(in, is, rowptr, col, n, width, out, os, inv_norm, st, &e)) return e;
     // 8-byte accesses need even strides / width and 8-byte aligned bases
     const bool vec2 = (is % 2 == 0) && (os % 2 == 0) && (width % 2 == 0) && (((uintptr_t)in | (uintptr_t)out) % 8 == 0);
-    if (vec2) segment_sum_rows_kernel<true><<<grid_for_waves(n), 256, 0, st>>>(in, is, rowptr, col, n, width, out, os, inv_norm);
-    else segment_sum_rows_kernel<false><<<grid_for_waves(n), 256, 0, st>>>(in, is, rowptr, col, n, width, out, os, inv_norm);
-    return hipGetLastError();
+    if (vec2) segment_sum_rows_kernel<true><<<grid_for_waves(n), 256, 0, st>>>(in, is, rowptr, col, n, width, out, os, nullptr);
+    else segment_sum_rows_kernel<false><<<grid_for_waves(n), 256, 0, st>>>(in, is, rowptr, col, n, width, out, os, nullptr);
+    e = hipGetLastError();
+    // the norm handed to the next layer must be the one mkgnn_row_inv_norm would compute on `out`
+    // (same kernel choice, same summation order), whatever layout `in` had
+    if (e == hipSuccess && inv_norm) e = launch_row_inv_norm(out, os, n, width, inv_norm, st);
+    return e;
 }
 
 }  // namespace mkgnn

@@ -68,6 +68,7 @@ struct BwdArgs {
     const float* gout; int64_t gs; int off;
     const uint8_t* best; const float* scores; const int8_t* chir;
     float* contrib; int64_t contrib_base;      // rows base + n*(D+1) + slot
+    int CS;                                    // contrib row stride: F rounded up to 4 (16-byte rows for the gather)
     float* slab; int nchunk;                   // [nchunk, bank_floats]
     const float* padded;                       // unit bank rows, support-major, padded (LDS kernels)
     float* theta_slab;                         // [blocks][4] score-weight partials (LDS rows kernel)
@@ -95,9 +96,16 @@ hipError_t launch_backward_lds(int d, const BwdArgs& a, int* nchunk_out, int* nt
 // kgnn_bwd_mfma.hip: MFMA backward for the model's shapes
 bool mfma_backward_supported(int d, int F, int E, int L, int64_t xs, const void* x, int64_t n_atoms);
 hipError_t launch_backward_rows_mfma(int d, const BwdArgs& a, int* ntheta_out, hipStream_t st);
-hipError_t launch_backward_gather(const float* contrib, const int32_t* rowptr, const int32_t* rows, const float* x,
-                                  int64_t xs, const float* inv, int64_t n, int F, float* gx, int64_t gxs,
-                                  hipStream_t st);
+hipError_t launch_backward_gather(const float* contrib, int64_t cs, int64_t n_contrib_rows, const int32_t* rowptr,
+                                  const int32_t* rows, const float* x, int64_t xs, const float* inv, int64_t n, int F,
+                                  float* gx, int64_t gxs, hipStream_t st);
+// kgnn_csr.hip: pipelined variants for 16-byte aligned rows of <= 256 floats; false = not applicable
+bool try_segment_sum_aligned(const float* in, int64_t is, const int32_t* rowptr, const int32_t* col, int64_t n, int width,
+                             float* out, int64_t os, float* inv_norm, hipStream_t st, hipError_t* err);
+bool try_backward_gather_aligned(const float* contrib, int64_t cs, const int32_t* rowptr, const int32_t* rows, const float* x,
+                                 int64_t xs, const float* inv, int64_t n, int F, float* gx, int64_t gxs, hipStream_t st,
+                                 hipError_t* err);
+bool try_row_inv_norm_aligned(const float* x, int64_t xs, int64_t n, int width, float* inv, hipStream_t st, hipError_t* err);
 hipError_t launch_segment_sum(const float* in, int64_t is, const int32_t* rowptr, const int32_t* col, int64_t n,
                               int width, float* out, int64_t os, float* inv_norm, hipStream_t st);
 

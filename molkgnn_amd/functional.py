@@ -120,8 +120,9 @@ def _forward_impl(x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad
     need_p = bool(is_last_layer) and plan.buckets[3].count > 0
     buckets = _buckets(plan, E, need_p)
     out_w = K + out_pad
-    alloc = torch.zeros if (plan.n_focal < n or out_pad or skipped) else torch.empty
-    out_full = alloc((n, out_w), dtype=torch.float32, device=dev)
+    if out_pad and (out_w != (K + 3) // 4 * 4):
+        raise ValueError("out_pad must round the output width up to a multiple of 4 (the library zeroes exactly that padding)")
+    out_full = torch.empty((n, out_w), dtype=torch.float32, device=dev)      # the forward call zeroes it (and the padding)
     saved = _lib.Saved4()
     saved_t = []
     for i, b in enumerate(plan.buckets):
@@ -193,7 +194,8 @@ class _KernelSetConvFn(torch.autograd.Function):
         for i in range(4):
             xc, xs, es, ps, ts, tc, te = params[i * PARAMS_PER_DEGREE:(i + 1) * PARAMS_PER_DEGREE]
             gxc, gxs, ges = torch.empty_like(xc), torch.empty_like(xs), torch.empty_like(es)
-            gth = torch.zeros(3, dtype=torch.float32, device=dev)
+            gth = torch.zeros(3, dtype=torch.float32, device=dev) if plan.buckets[i].count == 0 else \
+                torch.empty(3, dtype=torch.float32, device=dev)
             gr = grads[i]
             gr.x_center, gr.x_support, gr.edge_attr_support = _lib.ptr(gxc), _lib.ptr(gxs), _lib.ptr(ges)
             gr.support_attr_sc_weight = gth.data_ptr()
@@ -208,13 +210,15 @@ class _KernelSetConvFn(torch.autograd.Function):
                             gth[2].reshape(te.shape)]
         rowptr, rows = plan.scatter
         with torch.cuda.device(dev):
-            gx = torch.empty((n, F), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+            # 16-byte rows: the gather and whatever consumes the gradient next use 128-bit accesses
+            F4 = F + (-F) % 4
+            gx = torch.empty((n, F4), dtype=torch.float32, device=dev)[:, :F] if ctx.needs_input_grad[0] else None
             ws_bytes = workspace_bytes(Ls, F, E, n, plan.n_slots)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             _lib.check(lib.mkgnn_kernelsetconv_backward(
                 banks, buckets, x.data_ptr(), _stride0(x), inv.data_ptr(), n, F, E, int(ctx.is_last),
                 g.data_ptr(), _stride0(g), saved, rowptr.data_ptr(), rows.data_ptr(),
-                _lib.ptr(gx), F, grads, ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)),
+                _lib.ptr(gx), F4, grads, ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)),
                 "mkgnn_kernelsetconv_backward")
         return (gx, None, None, None, None, None, None, *gparams)
 
@@ -264,13 +268,17 @@ class _SegmentSumFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g, _g_inv):
         g = _row_major(g if g.dtype == torch.float32 else g.float())
-        return _segment_sum(g, ctx.plan.csr_out, 0), None, None
+        return _segment_sum(g, ctx.plan.csr_out, (-g.shape[1]) % 4), None, None
 
 
 def _segment_sum(v: torch.Tensor, csr, out_pad: int, inv: Optional[torch.Tensor] = None) -> torch.Tensor:
     rowptr, col = csr
     n, w = v.shape
-    alloc = torch.zeros if out_pad else torch.empty
+    if out_pad and (w + out_pad) != (w + 3) // 4 * 4:
+        raise ValueError("out_pad must round the width up to a multiple of 4")
+    # padded storage is written in full by the aligned kernel; other layouts get their padding zeroed here
+    aligned = (w + out_pad) % 4 == 0 and _stride0(v) % 4 == 0 and v.data_ptr() % 16 == 0 and w <= 256 and col.numel() > 0
+    alloc = torch.zeros if (out_pad and not aligned) else torch.empty
     out = alloc((n, w + out_pad), dtype=torch.float32, device=v.device)
     with torch.cuda.device(v.device):
         _lib.check(_lib.load().mkgnn_segment_sum_rows(v.data_ptr(), _stride0(v), rowptr.data_ptr(), _lib.ptr(col), n, w,

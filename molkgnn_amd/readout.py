@@ -104,7 +104,8 @@ class _ReadoutFn(torch.autograd.Function):
         H, G = w1.shape[0], w2.shape[0]
         dev = h.device
         g = _row_major(grad_out if grad_out.dtype == torch.float32 else grad_out.float())
-        gh = torch.empty((n, F), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        F4 = F + (-F) % 4                       # 16-byte rows for the consumer of the gradient (propagate's backward)
+        gh = torch.empty((n, F4), dtype=torch.float32, device=dev)[:, :F] if ctx.needs_input_grad[0] else None
         gw1, gw2 = torch.empty_like(w1), torch.empty_like(w2)
         gb1 = torch.empty_like(b1) if b1 is not None else None
         gb2 = torch.empty_like(b2) if b2 is not None else None
@@ -120,7 +121,7 @@ class _ReadoutFn(torch.autograd.Function):
             _lib.check(lib.mkgnn_readout_backward(
                 p, h.data_ptr(), _stride0(h), n, seg.mol_ptr.data_ptr(), seg.atom_mol.data_ptr(), seg.size,
                 _lib.ptr(keep), pre.data_ptr(), pooled.data_ptr(), g.data_ptr(), _stride0(g),
-                _lib.ptr(gh), F, gw1.data_ptr(), _lib.ptr(gb1), gw2.data_ptr(), _lib.ptr(gb2),
+                _lib.ptr(gh), F4, gw1.data_ptr(), _lib.ptr(gb1), gw2.data_ptr(), _lib.ptr(gb2),
                 ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)), "mkgnn_readout_backward")
         return gh, gw1, gb1, gw2, gb2, None, None
 
