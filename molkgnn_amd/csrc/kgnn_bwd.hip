@@ -156,6 +156,18 @@ __global__ void __launch_bounds__(256) kc_backward_rows_lds(BwdArgs a) {
     if (tid < 3) a.theta_slab[(size_t)blockIdx.x * 4 + tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
 }
 
+// Diagnostic cycle stamps of the bank kernel (tools/bwd_stamp_probe.py): per block, wave 0.
+__device__ unsigned long long* g_bwd_stamp_buffer = nullptr;
+// Compiled in only with -DMKGNN_BWD_STAMPS: the conditional stores perturb the wait-count placement.
+#ifdef MKGNN_BWD_STAMPS
+#define BWD_STAMP(slot)                                                                              \
+    do {                                                                                             \
+        if (stamps && tid == 0 && (slot) < 64) stamps[(slot)] = __builtin_readcyclecounter();        \
+    } while (0)
+#else
+#define BWD_STAMP(slot) do { (void)stamps; (void)(slot); } while (0)
+#endif
+
 // ------------------------------------------------------------------ bank ---
 template <int D, int KC, int LI, int TA>
 __global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
@@ -192,37 +204,49 @@ __global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
     const bool feat = 2 * lane < FP;
     const bool act = 2 * lane < RS;
 
-    auto load_ids = [&](int64_t tile, int buf) {
-        for (int r = tid; r < NROW; r += NT) {
-            const int i = r / (D + 1), slot = r - i * (D + 1);
-            int64_t n = tile * TA + i;
-            if (n >= a.n) n = a.n - 1;
-            const int64_t atom = (slot == D) ? a.sel[n] : a.nei[n * D + slot];
-            idbuf[buf * NROW + r] = (int)atom;
-            invbuf[buf * NROW + r] = a.inv[atom];
-        }
+    // Atom ids and row norms of a tile, one row per thread (NROW <= NT), pipelined over three tiles: ids are
+    // loaded two tiles ahead, the norms (addressed by those ids) one tile ahead; both loads are issued BEFORE
+    // the tile's other prefetch loads and the accumulate loop and land in LDS after it.  (Issued after the
+    // loop they were exposed global round trips; issued after fetch() the in-order vmcnt wait for them
+    // also waited for the whole next-tile row gather.)
+    static_assert(NROW <= NT, "one id per thread");
+    auto issue_inv = [&](int buf) -> float { return a.inv[idbuf[buf * NROW + (tid < NROW ? tid : NROW - 1)]]; };
+    auto store_inv = [&](float v, int buf) {
+        if (tid < NROW) invbuf[buf * NROW + tid] = v;
+    };
+    auto issue_id = [&](int64_t tile) -> int {
+        const int r = tid < NROW ? tid : NROW - 1;
+        const int i = r / (D + 1), slot = r - i * (D + 1);
+        int64_t n = tile * TA + i;
+        if (n >= a.n) n = a.n - 1;
+        const int64_t* src = (slot == D) ? (a.sel + n) : (a.nei + n * D + slot);
+        return (int)*src;
+    };
+    auto store_id = [&](int id, int buf) {
+        if (tid < NROW) idbuf[buf * NROW + tid] = id;
     };
     f32x4 stage[MAXQ];
-    float rg[CQ];
-    int ridx[CQ];
-    float ev[8];
+    float rg[CQ], rS[CQ], rC[CQ], rE[CQ];
+    int ridx[CQ], rch[CQ];
+    const size_t ln = (size_t)L * a.n;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;              // score-weight partials (when the rows kernel leaves them to us)
+    float ev;                                        // one bond component per thread: (atom, slot) = tid / 8, k = tid % 8
+    static_assert(TA * D * 8 <= NT, "one bond component per thread");
+    const int8_t* chp = a.chir ? a.chir : (const int8_t*)a.best;      // always loadable; ignored when there are no signs
+    // fetch() only ISSUES loads (unconditional, clamped addresses) and leaves the raw values in registers;
+    // every use of a loaded value -- column masks, validity masks, products -- is in the staging code at the
+    // top of the next iteration, and there is no branch in here: a use, or the end of a conditional block
+    // that contains loads, makes the compiler wait for them on the spot -- a full global round trip per
+    // tile, exposed.  Past the last tile the (clamped) loads are simply not used.
     auto fetch = [&](int64_t tile, int buf) {
 #pragma unroll
-        // every load below is unconditional on a clamped address and masked afterwards: a load under a
-        // lane-dependent branch ends its basic block with a full wait and serialises the round trips
         for (int k = 0; k < MAXQ; ++k) {
             const int q = tid + NT * k;
             const int qc = q < NROW * CH ? q : NROW * CH - 1;
             const int row = qc / CH, c = qc - row * CH;
             const int cc = 4 * c < a.F ? c : 0;
-            f32x4 v = *(const f32x4*)(a.x + (size_t)idbuf[buf * NROW + row] * a.xs + 4 * cc);
-            if (4 * c >= a.F) v.x = 0.f;
-            if (4 * c + 1 >= a.F) v.y = 0.f;
-            if (4 * c + 2 >= a.F) v.z = 0.f;
-            if (4 * c + 3 >= a.F) v.w = 0.f;
-            stage[k] = v;
+            stage[k] = *(const f32x4*)(a.x + (size_t)idbuf[buf * NROW + row] * a.xs + 4 * cc);
         }
-        float rch[CQ];
 #pragma unroll
         for (int k = 0; k < CQ; ++k) {
             const int q = tid + NT * k;
@@ -232,46 +256,34 @@ __global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
             if (n >= a.n) n = a.n - 1;
             rg[k] = a.gout[(int64_t)idbuf[buf * NROW + i * (D + 1) + D] * a.gs + a.off + l];
             ridx[k] = a.best[(size_t)n * L + l];
-            rch[k] = 1.f;
+            rch[k] = chp[(size_t)n * L + l];
+            // the three cosine scores feed d sc / d theta_k = w_k (score_k - sc) / W  (SURVEY 8 a-9); this kernel visits
+            // every (atom, kernel) pair exactly once, with one thread per pair: the cheapest place to sum them
+            rS[k] = a.scores[(size_t)n * L + l];
+            rC[k] = a.scores[ln + (size_t)n * L + l];
+            rE[k] = a.scores[2 * ln + (size_t)n * L + l];
         }
-        if (a.chir) {                                // one uniform branch for all the sign loads
-#pragma unroll
-            for (int k = 0; k < CQ; ++k) {
-                const int q = tid + NT * k;
-                const int qc = q < TA * L ? q : TA * L - 1;
-                const int i = qc / L, l = qc - i * L;
-                int64_t n = tile * TA + i;
-                if (n >= a.n) n = a.n - 1;
-                rch[k] = (float)a.chir[(size_t)n * L + l];
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < CQ; ++k) {
-            const int q = tid + NT * k;
-            const int i = q / L;
-            const bool ok = q < TA * L && tile * TA + i < a.n;
-            rg[k] = ok ? rg[k] * rch[k] : 0.f;
-        }
-        {                                            // bond vectors of (atom, slot); threads beyond TA*D re-read the last one
-            const int t = tid < TA * D ? tid : TA * D - 1;
+        {
+            const int t = (tid >> 3) < TA * D ? (tid >> 3) : TA * D - 1, k = tid & 7;
             const int i = t / D, slot = t - i * D;
             int64_t n = tile * TA + i;
             if (n >= a.n) n = a.n - 1;
-            const float* e = a.e_nei + (n * D + slot) * a.E;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const float r = e[k < a.E ? k : a.E - 1];
-                ev[k] = k < a.E ? r : 0.f;
-            }
+            ev = a.e_nei[(n * D + slot) * a.E + (k < a.E ? k : a.E - 1)];
         }
     };
+    unsigned long long* stamps = g_bwd_stamp_buffer ? g_bwd_stamp_buffer + ((size_t)(D - 1) * 256 + blockIdx.x) * 64 : nullptr;
+    int slot = 2;
+    BWD_STAMP(0);
     for (int q = tid; q < TA * LP * CW; q += NT) coef[q] = 0.f;
     int64_t tile = blockIdx.x;
     int buf = 0;
-    load_ids(tile, 0);
+    store_id(issue_id(tile), 0);
+    store_id(issue_id(tile + gridDim.x), 1);         // (clamped past the end: harmless)
     __syncthreads();
+    store_inv(issue_inv(0), 0);
     fetch(tile, 0);
-    if (tile + gridDim.x < ntiles) load_ids(tile + gridDim.x, 1);
+    __syncthreads();                                 // the first staging reads other threads' norms
+    BWD_STAMP(1);
     for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
         // ---- registers -> LDS: unit feature rows, unit bond vectors, coefficients
 #pragma unroll
@@ -279,46 +291,55 @@ __global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
             const int q = tid + NT * k;
             if (q < NROW * CH) {
                 const int row = q / CH, c = q - row * CH;
-                *(f32x4*)(xt + (size_t)row * RS + 4 * c) = stage[k] * invbuf[buf * NROW + row];
+                f32x4 v = stage[k];
+                if (4 * c >= a.F) v.x = 0.f;
+                if (4 * c + 1 >= a.F) v.y = 0.f;
+                if (4 * c + 2 >= a.F) v.z = 0.f;
+                if (4 * c + 3 >= a.F) v.w = 0.f;
+                *(f32x4*)(xt + (size_t)row * RS + 4 * c) = v * invbuf[buf * NROW + row];
             }
         }
-        if (tid < TA * D) {
-            const int i = tid / D, slot = tid - i * D;
-            float s2 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) s2 = fmaf(ev[k], ev[k], s2);
+        {   // unit bond vectors: eight lanes per (atom, slot), norm by an xor tree over them
+            const float e = (tid & 7) < a.E ? ev : 0.f;
+            float s2 = e * e;
+            s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64); s2 += __shfl_xor(s2, 4, 64);
             const float ie = 1.f / fmaxf(sqrtf(s2), MKGNN_EPS);
-            float* dst = xt + (size_t)(i * (D + 1) + slot) * RS + FP;
-            *(f32x4*)dst = f32x4{ev[0] * ie, ev[1] * ie, ev[2] * ie, ev[3] * ie};
-            *(f32x4*)(dst + 4) = f32x4{ev[4] * ie, ev[5] * ie, ev[6] * ie, ev[7] * ie};
-        } else if (tid < TA * D + TA) {              // focal rows carry no bond vector
-            float* dst = xt + (size_t)((tid - TA * D) * (D + 1) + D) * RS + FP;
-            *(f32x4*)dst = f32x4{0.f, 0.f, 0.f, 0.f};
-            *(f32x4*)(dst + 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            if ((tid >> 3) < TA * D) {
+                const int t = tid >> 3, i = t / D, slot = t - i * D;
+                xt[(size_t)(i * (D + 1) + slot) * RS + FP + (tid & 7)] = e * ie;
+            }
+            if (tid < TA * 8) xt[(size_t)((tid >> 3) * (D + 1) + D) * RS + FP + (tid & 7)] = 0.f;   // focal rows carry no bond vector
         }
 #pragma unroll
         for (int k = 0; k < CQ; ++k) {
             const int q = tid + NT * k;
             if (q < TA * L) {
                 float* ce = coef + ((size_t)(q / L) * LP + (q % L)) * CW;
-                ce[0] = rg[k] * ws_n;
+                const float sgn = a.chir ? (float)(int8_t)rch[k] : 1.f;
+                const float g = (tile * TA + q / L < a.n) ? rg[k] * sgn : 0.f;        // atoms past the end contribute nothing
+                ce[0] = g * ws_n;
+                const float sc = (rS[k] * w_s + rC[k] * w_c + rE[k] * w_e) / w_sum;
+                p0 = fmaf(g * (w_s / w_sum), rS[k] - sc, p0);
+                p1 = fmaf(g * (w_c / w_sum), rC[k] - sc, p1);
+                p2 = fmaf(g * (w_e / w_sum), rE[k] - sc, p2);
 #pragma unroll
                 for (int s = 0; s < D; ++s)          // support pi(s) takes the row of neighbour slot s
                     ce[1 + perm_at<D>(ridx[k], s)] = __int_as_float(s * RS * 4);
             }
         }
+        BWD_STAMP(slot);
         __syncthreads();
+        BWD_STAMP(slot + 1);
         const int64_t nxt = tile + gridDim.x;
-        if (nxt < ntiles) fetch(nxt, buf ^ 1);
+        const int id_ahead = issue_id(nxt + gridDim.x);      // these two first: the waits for them must not
+        const float inv_ahead = issue_inv(buf ^ 1);          // cover the row gather issued next
+        fetch(nxt < ntiles ? nxt : tile, buf ^ 1);
+        BWD_STAMP(slot + 2);
         if (act) {
             const int64_t left = a.n - tile * TA;
             const int cnt = left < TA ? (int)left : TA;
             const float lane_mul = feat ? 1.f : ratio_e;       // bond columns carry w_e / w_s
-#pragma unroll 1
-            for (int i = 0; i < cnt; ++i) {
-                const char* xr = (const char*)(xt + (size_t)i * (D + 1) * RS + 2 * lane);
-                // phase 1: every coefficient entry of this atom (LI broadcast reads in flight together)
-                float cv[LI][D + 1];
+            auto read_coef = [&](int i, float (&cv)[LI][D + 1]) {
 #pragma unroll
                 for (int li = 0; li < LI; ++li) {
                     const float* ce = coef + ((size_t)i * LP + wave + NWV * li) * CW;
@@ -327,25 +348,55 @@ __global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
                     else if constexpr (D == 2) { const f32x4 t = *(const f32x4*)ce; cv[li][0] = t.x; cv[li][1] = t.y; cv[li][2] = t.z; }
                     else { const f32x4 t = *(const f32x4*)ce; const float t4 = ce[4]; cv[li][0] = t.x; cv[li][1] = t.y; cv[li][2] = t.z; cv[li][3] = t.w; cv[li][4] = t4; }
                 }
+            };
+            // The coefficient entries of atom i + 1 are read while atom i's rows are in flight, so an atom costs
+            // one LDS round trip (its row reads) instead of two dependent ones.
+            float cv[LI][D + 1];
+            read_coef(0, cv);
+#pragma unroll 1
+            for (int i = 0; i < cnt; ++i) {
+                const char* xr = (const char*)(xt + (size_t)i * (D + 1) * RS + 2 * lane);
                 const f32x2 vfocal = *(const f32x2*)(xr + D * RS * 4);
-                // phase 2: all LI * D row reads, addresses straight from the entries
+                // all LI * D row reads, addresses straight from the entries
                 f32x2 vv[LI][D];
 #pragma unroll
                 for (int li = 0; li < LI; ++li)
 #pragma unroll
                     for (int b = 0; b < D; ++b) vv[li][b] = *(const f32x2*)(xr + __float_as_int(cv[li][1 + b]));
-                // phase 3: packed FMAs
+                float c0[LI];
+#pragma unroll
+                for (int li = 0; li < LI; ++li) c0[li] = cv[li][0];
+                read_coef(i + 1 < TA ? i + 1 : i, cv);
+                // packed FMAs
 #pragma unroll
                 for (int li = 0; li < LI; ++li) {
-                    const float cc = cv[li][0] * lane_mul;
-                    acc[li][D] += vfocal * (cv[li][0] * ratio_c);
+                    const float cc = c0[li] * lane_mul;
+                    acc[li][D] += vfocal * (c0[li] * ratio_c);
 #pragma unroll
                     for (int b = 0; b < D; ++b) acc[li][b] += vv[li][b] * cc;
                 }
             }
         }
+        BWD_STAMP(slot + 3);
+        store_inv(inv_ahead, buf ^ 1);                       // read by the next tile's staging, after its barrier... and
+        __syncthreads();                                     // ...this one orders it before that staging
+        store_id(id_ahead, buf);
+        BWD_STAMP(slot + 4);
+        slot += 5;
+    }
+    BWD_STAMP(62);
+    if (a.theta_in_bank) {                           // fixed-order block sum of the score-weight partials
         __syncthreads();
-        if (nxt + gridDim.x < ntiles) load_ids(nxt + gridDim.x, buf);
+        float* red = coef;                           // the coefficient image is free now
+        p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
+        if (lane == 0) { red[wave] = p0; red[NWV + wave] = p1; red[2 * NWV + wave] = p2; }
+        __syncthreads();
+        if (tid < 3) {
+            float t = 0.f;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) t += red[tid * NWV + w];
+            a.theta_slab[(size_t)blockIdx.x * 4 + tid] = t;
+        }
     }
     // ---- one partial slab per block (row order of kc_backward_bank in kgnn_generic.hip)
     float* slab = a.slab + (size_t)blockIdx.x * bank_floats(D, L, a.F, a.E);
@@ -417,6 +468,8 @@ static hipError_t launch_lds_bwd(const BwdArgs& a0, int* nchunk_out, int* ntheta
         int64_t blocks = BWD_BANK_BLOCKS;
         if (blocks > ntiles) blocks = ntiles;
         a.nchunk = (int)blocks;
+        a.theta_in_bank = rows_too ? 0 : 1;          // the LDS rows kernel sums the score-weight partials itself
+        if (!rows_too) *ntheta_out = (int)blocks;
         kc_backward_bank_lds<D, KC, LI, TA><<<(int)blocks, 512, lds_bytes, st>>>(a);
         *nchunk_out = (int)blocks;
     }
@@ -442,3 +495,7 @@ hipError_t launch_backward_lds(int d, const BwdArgs& a, int* nchunk_out, int* nt
 }
 
 }  // namespace mkgnn
+
+extern "C" int mkgnn_debug_set_bwd_stamp_buffer(void* device_ptr) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(mkgnn::g_bwd_stamp_buffer), &device_ptr, sizeof(void*));
+}

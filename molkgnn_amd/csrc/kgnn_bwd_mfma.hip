@@ -28,7 +28,8 @@ __host__ __device__ constexpr int bwd_lq(int d) { return d == 1 ? 3 : (d == 2 ? 
 // ------------------------------------------------------------------ rows ---
 // M = 16 atoms, N = 16 features (FT tiles), K = kernels.  A = masked coefficients (registers),
 // B = unit kernel rows (LDS, b32 reads, conflict-free), D = contribution rows.
-// Also accumulates the three score-weight partials (d sc / d theta_k = w_k (score_k - sc) / W).
+// (The three score-weight partials d sc / d theta_k are summed by the bank kernel, which visits every
+// (atom, kernel) pair with one thread and has registers to spare; here they cost 3 LQ prefetch registers.)
 template <int D, int KC, int NT>
 __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(BwdArgs a) {
     constexpr int FP = 16 * KC;
@@ -36,7 +37,6 @@ __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(Bw
     constexpr int LQ = bwd_lq(D);
     constexpr int NWV = NT / 64;
     extern __shared__ __align__(16) float lds[];
-    __shared__ float red[3][NWV];
     const int L = a.L;
     float* bank = lds;                               // [(D+1)*L][FP], row b*L + l; rows D*L + l = centres
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -55,52 +55,58 @@ __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(Bw
         }
     }
     __syncthreads();
-    const float w_s = a.mix[0], w_c = a.mix[1], w_e = a.mix[2], w_sum = a.mix[3];
+    const float w_s = a.mix[0], w_c = a.mix[1], w_sum = a.mix[3];
     const float ws_n = w_s / w_sum / (float)D;
     const float ratio_c = w_c * (float)D / w_s;
     const int64_t ntiles = (a.n + 15) / 16;
-    const size_t ln = (size_t)L * a.n;
-    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
-    for (int64_t tile = (int64_t)blockIdx.x * NWV + wave; tile < ntiles; tile += (int64_t)gridDim.x * NWV) {
-        // ---- coefficients of atom row ci, kernels 4*kk + kq
+    // Coefficient inputs of a tile, software pipelined one tile ahead: the loads of tile t + 1 are issued
+    // before the MFMA loop of tile t and its focal ids (the address of the grad_out gather) one tile before
+    // that, so the two dependent global round trips per tile overlap the matrix work instead of preceding it.
+    const int64_t tstep = (int64_t)gridDim.x * NWV;
+    float rg[LQ];
+    int ridx[LQ], rch[LQ];
+    auto focal_of = [&](int64_t tile) -> int64_t {
         const int64_t n = tile * 16 + ci;
-        const bool row_ok = n < a.n;
-        const int64_t focal = a.sel[row_ok ? n : a.n - 1];
+        return a.sel[n < a.n ? n : a.n - 1];
+    };
+    const int8_t* chp = a.chir ? a.chir : (const int8_t*)a.best;      // always loadable; ignored when there are no signs
+    auto issue = [&](int64_t tile, int64_t focal, float (&g)[LQ], int (&ix)[LQ], int (&ch)[LQ]) {
+        const int64_t n = tile * 16 + ci;
+        const int64_t nc = n < a.n ? n : a.n - 1;
         // Loads are unconditional on clamped addresses and masked afterwards: a load under a lane-dependent
         // branch ends its own basic block with a full wait, which serialises the round trips.
-        const int64_t nc = row_ok ? n : a.n - 1;
-        float c[LQ];
-        int pk[LQ];
-        float rg[LQ], rS[LQ], rC[LQ], rE[LQ];
-        int ridx[LQ], rch[LQ];
 #pragma unroll
         for (int kk = 0; kk < LQ; ++kk) {
             const int l = 4 * kk + kq < L ? 4 * kk + kq : L - 1;
-            rg[kk] = a.gout[focal * a.gs + a.off + l];
-            rch[kk] = 1;
-            ridx[kk] = a.best[(size_t)nc * L + l];
-            rS[kk] = a.scores[(size_t)nc * L + l];
-            rC[kk] = a.scores[ln + (size_t)nc * L + l];
-            rE[kk] = a.scores[2 * ln + (size_t)nc * L + l];
+            g[kk] = a.gout[focal * a.gs + a.off + l];
+            ix[kk] = a.best[(size_t)nc * L + l];
+            ch[kk] = chp[(size_t)nc * L + l];
         }
-        if (a.chir) {                                 // one uniform branch for all the sign loads
-#pragma unroll
-            for (int kk = 0; kk < LQ; ++kk) rch[kk] = (int)a.chir[(size_t)nc * L + (4 * kk + kq < L ? 4 * kk + kq : L - 1)];
-        }
+    };
+    int64_t tile = (int64_t)blockIdx.x * NWV + wave;
+    int64_t focal_next = 0;
+    if (tile < ntiles) {
+        issue(tile, focal_of(tile), rg, ridx, rch);
+        focal_next = focal_of(tile + tstep);
+    }
+    for (; tile < ntiles; tile += tstep) {
+        const int64_t n = tile * 16 + ci;
+        const bool row_ok = n < a.n;
+        float c[LQ];
+        int pk[LQ];
 #pragma unroll
         for (int kk = 0; kk < LQ; ++kk) {
             const bool ok = row_ok && (4 * kk + kq < L);
-            const float g = ok ? rg[kk] * (float)rch[kk] : 0.f;
+            const float g = ok ? (a.chir ? rg[kk] * (float)rch[kk] : rg[kk]) : 0.f;
             int bits = 0;
 #pragma unroll
             for (int s = 0; s < D; ++s) bits |= perm_at<D>(ridx[kk], s) << (2 * s);
             pk[kk] = bits;
             c[kk] = g * ws_n;
-            const float sc = (rS[kk] * w_s + rC[kk] * w_c + rE[kk] * w_e) / w_sum;
-            p0 = fmaf(g * (w_s / w_sum), rS[kk] - sc, p0);
-            p1 = fmaf(g * (w_c / w_sum), rC[kk] - sc, p1);
-            p2 = fmaf(g * (w_e / w_sum), rE[kk] - sc, p2);
         }
+        // next tile's inputs: in flight during this tile's MFMAs (tiles past the end read clamped rows, unused)
+        issue(tile + tstep, focal_next, rg, ridx, rch);
+        focal_next = focal_of(tile + 2 * tstep);
         f32x4 acc[D + 1][FT];                        // slot 0 = focal, 1 + s = neighbour s
 #pragma unroll
         for (int s = 0; s <= D; ++s)
@@ -152,15 +158,6 @@ __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(Bw
             }
         }
     }
-    p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
-    if (lane == 0) { red[0][wave] = p0; red[1][wave] = p1; red[2][wave] = p2; }
-    __syncthreads();
-    if (tid < 3) {
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < NWV; ++w) s += red[tid][w];
-        a.theta_slab[(size_t)blockIdx.x * 4 + tid] = s;
-    }
 }
 
 // ------------------------------------------------------------------ host ---
@@ -195,7 +192,7 @@ static hipError_t launch_mfma_rows(const BwdArgs& a, int* ntheta_out, hipStream_
     if (blocks > need) blocks = need;
     if (blocks > THETA_SLAB_BLOCKS) blocks = THETA_SLAB_BLOCKS;
     kc_backward_rows_mfma<D, KC, NT><<<(int)blocks, NT, lds_bytes, st>>>(a);
-    *ntheta_out = (int)blocks;
+    (void)ntheta_out;                                // the bank kernel sums the score-weight partials
     return hipGetLastError();
 }
 

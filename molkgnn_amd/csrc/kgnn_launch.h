@@ -71,7 +71,8 @@ struct BwdArgs {
     int CS;                                    // contrib row stride: F rounded up to 4 (16-byte rows for the gather)
     float* slab; int nchunk;                   // [nchunk, bank_floats]
     const float* padded;                       // unit bank rows, support-major, padded (LDS kernels)
-    float* theta_slab;                         // [blocks][4] score-weight partials (LDS rows kernel)
+    float* theta_slab;                         // [blocks][4] score-weight partials (LDS rows kernel, or the bank kernel)
+    int theta_in_bank;                         // bank kernel sums the score-weight partials (MFMA rows kernel in use)
 };
 
 struct BankReduceArgs {

@@ -569,10 +569,10 @@ hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t 
         rows_equal_kernel<<<(int)blocks, 256, 0, st>>>(a.x, a.xs, a.deg[3].nei, a.deg[3].p_focal, a.deg[3].p_nei, a.deg[3].n, a.F,
                                                       (int8_t*)a.deg[3].eqflag, (int8_t*)a.deg[3].signflag);
     }
-    if (g_time_fused) hipEventRecord(g_ev0, st);
+    if (g_time_fused) (void)hipEventRecord(g_ev0, st);
     if (KC == 2) kc_forward_fused<2><<<nb, 256, lds_bytes, st>>>(a);
     else kc_forward_fused<7><<<nb, 256, lds_bytes, st>>>(a);
-    if (g_time_fused) hipEventRecord(g_ev1, st);
+    if (g_time_fused) (void)hipEventRecord(g_ev1, st);
     return hipGetLastError();
 }
 

@@ -119,6 +119,8 @@ def _forward_impl(x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad
     skipped = any(b.count and Ls[i] == 0 for i, b in enumerate(plan.buckets))
     need_p = bool(is_last_layer) and plan.buckets[3].count > 0
     buckets = _buckets(plan, E, need_p)
+    if out_pad is None:                      # default: storage rows padded to 16 bytes, the result is the [:, :K] view
+        out_pad = (-K) % 4
     out_w = K + out_pad
     if out_pad and (out_w != (K + 3) // 4 * 4):
         raise ValueError("out_pad must round the output width up to a multiple of 4 (the library zeroes exactly that padding)")
@@ -172,7 +174,7 @@ class _KernelSetConvFn(torch.autograd.Function):
         ctx.saved_t = saved_t
         ctx.save_for_backward(x, inv, *params)
         K = sum(Ls)
-        return out_full[:, :K] if out_pad else out_full
+        return out_full[:, :K] if out_full.shape[1] != K else out_full
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -224,14 +226,15 @@ class _KernelSetConvFn(torch.autograd.Function):
 
 
 def kernelsetconv(x: torch.Tensor, plan: BatchPlan, is_last_layer: bool, params: Sequence[torch.Tensor],
-                  edge_attr_dim: int, variant: str = "auto", out_pad: int = 0) -> torch.Tensor:
+                  edge_attr_dim: int, variant: str = "auto", out_pad: Optional[int] = None) -> torch.Tensor:
     """``[N, F] -> [N, K]`` kernel convolution over the four degree buckets of ``plan``.
 
     ``params`` is the flat list, degree 1..4, of (x_center, x_support,
     edge_attr_support, p_support, support_attr_sc_weight, center_attr_sc_weight,
-    edge_attr_support_sc_weight).  ``out_pad`` extra zero columns are appended
-    to the storage (the returned tensor is the ``[:, :K]`` view) so that the
-    next layer can read 16-byte aligned rows.
+    edge_attr_support_sc_weight).  The storage rows are padded with zero columns
+    to a multiple of 4 floats (``out_pad=None``; the returned tensor is the
+    ``[:, :K]`` view) so that whatever reads the result next gets 16-byte rows;
+    ``out_pad=0`` gives contiguous storage.
     """
     return _KernelSetConvFn.apply(x, plan, is_last_layer, VARIANTS[variant], out_pad, edge_attr_dim, _handed_inv_norm(x),
                                   *params)

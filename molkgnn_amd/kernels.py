@@ -132,7 +132,7 @@ class BaseKernelSetConv(Module):
         self.num_kernel_list = [(f or 0) + (t or 0) for f, t in
                                 zip(self.num_fixed_kernel_list, self.num_trainable_kernel_list)]
         self.variant = "auto"     # "auto" | "generic" | "mfma": which HIP kernels serve the forward
-        self.out_pad = 0          # extra zero columns in the output storage (row alignment for the next layer)
+        self.out_pad = None       # None: output storage rows padded to 16 bytes (the result is a view); 0: contiguous
 
     # -- helpers kept for API parity with the reference ----------------------
     def get_focal_nodes_of_degree(self, x, p, selected_index):
