@@ -119,7 +119,10 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
  *             scatter_rows [sum_d N_d (d+1)] (int32).  Built once per batch by
  *             the host (molkgnn_amd.plan).
  *   grad_x    [N, F] (stride grad_x_stride), fully overwritten
- *   grads     per-degree parameter gradients, fully overwritten. */
+ *   grads     per-degree parameter gradients, fully overwritten.
+ *   workspace_from_forward  non-zero: `workspace` is the buffer the forward call of this layer used,
+ *             untouched since, with the same banks / shapes: the normalised kernel bank in it is reused
+ *             instead of being recomputed. */
 int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
                                  const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],
                                  const float* x, int64_t x_stride, const float* inv_norm,
@@ -129,7 +132,8 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
                                  const int32_t* scatter_rowptr, const int32_t* scatter_rows,
                                  float* grad_x, int64_t grad_x_stride,
                                  const mkgnn_kernel_bank_grad grads[MKGNN_MAX_DEGREE],
-                                 void* workspace, size_t workspace_bytes, void* stream);
+                                 void* workspace, size_t workspace_bytes, int32_t workspace_from_forward,
+                                 void* stream);
 
 /* MolGCN.propagate with aggr='add' (KernelLayer.py:14,119-123) as a CSR segment
  * sum: out[i, :] = sum_{k in [rowptr[i], rowptr[i+1])} in[col[k], :].

@@ -92,7 +92,7 @@ def load() -> C.CDLL:
     lib.mkgnn_kernelsetconv_backward.argtypes = [
         Banks4, Buckets4, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
         C.c_void_p, C.c_int64, Saved4, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, BankGrads4,
-        C.c_void_p, C.c_size_t, C.c_void_p]
+        C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]
     lib.mkgnn_segment_sum_rows.restype = C.c_int
     lib.mkgnn_segment_sum_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                            C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]

@@ -24,6 +24,10 @@ namespace mkgnn {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __host__ __device__ constexpr int bwd_lq(int d) { return d == 1 ? 3 : (d == 2 ? 5 : (d == 3 ? 8 : 13)); }   // 4-kernel groups held per lane
+// Waves that share one 16-atom tile, each taking a slice of the feature tiles (the slices are independent:
+// no reduction).  Degree 4 has few atoms and 17 masked products per kernel group -- one wave per tile left
+// three quarters of the SIMDs idle for 24 us; degrees 2 and 3 gain occupancy (smaller accumulators, no spills).
+__host__ __device__ constexpr int bwd_fsplit(int d, int kc) { return kc < 4 ? 1 : (d == 1 ? 1 : (d == 4 ? 4 : 2)); }
 
 // ------------------------------------------------------------------ rows ---
 // M = 16 atoms, N = 16 features (FT tiles), K = kernels.  A = masked coefficients (registers),
@@ -34,6 +38,8 @@ template <int D, int KC, int NT>
 __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(BwdArgs a) {
     constexpr int FP = 16 * KC;
     constexpr int FT = KC;                           // 16-feature tiles
+    constexpr int FS = bwd_fsplit(D, KC);            // waves per atom tile
+    constexpr int FTW = (FT + FS - 1) / FS;          // feature tiles per wave
     constexpr int LQ = bwd_lq(D);
     constexpr int NWV = NT / 64;
     extern __shared__ __align__(16) float lds[];
@@ -62,7 +68,9 @@ __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(Bw
     // Coefficient inputs of a tile, software pipelined one tile ahead: the loads of tile t + 1 are issued
     // before the MFMA loop of tile t and its focal ids (the address of the grad_out gather) one tile before
     // that, so the two dependent global round trips per tile overlap the matrix work instead of preceding it.
-    const int64_t tstep = (int64_t)gridDim.x * NWV;
+    static_assert(NWV % FS == 0, "the feature slice of a wave is fixed");
+    const int ft0 = (wave % FS) * FTW;               // this wave's feature tiles: ft0 .. ft0 + FTW - 1 (< FT)
+    const int64_t tstep = (int64_t)gridDim.x * (NWV / FS);
     float rg[LQ];
     int ridx[LQ], rch[LQ];
     auto focal_of = [&](int64_t tile) -> int64_t {
@@ -83,7 +91,7 @@ __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(Bw
             ch[kk] = chp[(size_t)nc * L + l];
         }
     };
-    int64_t tile = (int64_t)blockIdx.x * NWV + wave;
+    int64_t tile = (int64_t)blockIdx.x * (NWV / FS) + wave / FS;
     int64_t focal_next = 0;
     if (tile < ntiles) {
         issue(tile, focal_of(tile), rg, ridx, rch);
@@ -107,26 +115,28 @@ __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(Bw
         // next tile's inputs: in flight during this tile's MFMAs (tiles past the end read clamped rows, unused)
         issue(tile + tstep, focal_next, rg, ridx, rch);
         focal_next = focal_of(tile + 2 * tstep);
-        f32x4 acc[D + 1][FT];                        // slot 0 = focal, 1 + s = neighbour s
+        f32x4 acc[D + 1][FTW];                       // slot 0 = focal, 1 + s = neighbour s
 #pragma unroll
         for (int s = 0; s <= D; ++s)
 #pragma unroll
-            for (int ft = 0; ft < FT; ++ft) acc[s][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int ft = 0; ft < FTW; ++ft) acc[s][ft] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < LQ; ++kk) {
             if (4 * kk < L) {                        // wave-uniform
                 const int l = 4 * kk + kq < L ? 4 * kk + kq : L - 1;
                 const float* brow = bank + (size_t)l * FP + ci;
                 // all B values of this kernel group first (their LDS reads travel together), then the MFMAs
-                float bv[D + 1][FT];
+                // (a slice that runs past the last feature tile repeats it; its product is not stored)
+                float bv[D + 1][FTW];
 #pragma unroll
                 for (int b = 0; b <= D; ++b)
 #pragma unroll
-                    for (int ft = 0; ft < FT; ++ft) bv[b][ft] = brow[(size_t)b * L * FP + 16 * ft];
+                    for (int ft = 0; ft < FTW; ++ft)
+                        bv[b][ft] = brow[(size_t)b * L * FP + 16 * (ft0 + ft < FT ? ft0 + ft : FT - 1)];
                 {   // centre rows -> focal slot
                     const float av = c[kk] * ratio_c;
 #pragma unroll
-                    for (int ft = 0; ft < FT; ++ft)
+                    for (int ft = 0; ft < FTW; ++ft)
                         acc[0][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[D][ft], acc[0][ft], 0, 0, 0);
                 }
 #pragma unroll
@@ -135,7 +145,7 @@ __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(Bw
 #pragma unroll
                     for (int s = 0; s < D; ++s) av[s] = (((pk[kk] >> (2 * s)) & 3) == b) ? c[kk] : 0.f;
 #pragma unroll
-                    for (int ft = 0; ft < FT; ++ft)
+                    for (int ft = 0; ft < FTW; ++ft)
 #pragma unroll
                         for (int s = 0; s < D; ++s)
                             acc[1 + s][ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], bv[b][ft], acc[1 + s][ft], 0, 0, 0);
@@ -148,12 +158,12 @@ __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(Bw
             const int64_t nn = tile * 16 + kq * 4 + jj;
             if (nn < a.n) {
                 float* dst = a.contrib + (size_t)(a.contrib_base + nn * (D + 1)) * a.CS + ci;
-                const bool last_ok = 16 * (FT - 1) + ci < a.F;     // only the last feature tile can be partial
 #pragma unroll
                 for (int s = 0; s <= D; ++s) {
 #pragma unroll
-                    for (int ft = 0; ft < FT - 1; ++ft) dst[(size_t)s * a.CS + 16 * ft] = acc[s][ft][jj];
-                    if (last_ok) dst[(size_t)s * a.CS + 16 * (FT - 1)] = acc[s][FT - 1][jj];
+                    for (int ft = 0; ft < FTW; ++ft)
+                        if (ft0 + ft < FT && 16 * (ft0 + ft) + ci < a.F)      // only the last feature tile can be partial
+                            dst[(size_t)s * a.CS + 16 * (ft0 + ft)] = acc[s][ft][jj];
                 }
             }
         }
@@ -187,8 +197,9 @@ static hipError_t launch_mfma_rows(const BwdArgs& a, int* ntheta_out, hipStream_
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 2) per_cu = 2;
     constexpr int NWV = NT / 64;
+    constexpr int TPB = NWV / bwd_fsplit(D, KC);     // atom tiles per block pass
     int64_t blocks = 256 * per_cu;
-    const int64_t need = (ntiles + NWV - 1) / NWV;
+    const int64_t need = (ntiles + TPB - 1) / TPB;
     if (blocks > need) blocks = need;
     if (blocks > THETA_SLAB_BLOCKS) blocks = THETA_SLAB_BLOCKS;
     kc_backward_rows_mfma<D, KC, NT><<<(int)blocks, NT, lds_bytes, st>>>(a);

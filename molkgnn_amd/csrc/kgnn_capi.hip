@@ -252,7 +252,7 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
                                  const mkgnn_saved saved[MKGNN_MAX_DEGREE], const int32_t* scatter_rowptr,
                                  const int32_t* scatter_rows, float* grad_x, int64_t grad_x_stride,
                                  const mkgnn_kernel_bank_grad grads[MKGNN_MAX_DEGREE], void* workspace,
-                                 size_t workspace_bytes, void* stream) {
+                                 size_t workspace_bytes, int32_t workspace_from_forward, void* stream) {
     const char* who = "mkgnn_kernelsetconv_backward";
     int64_t n_edges = 0;
     if (int rc = check_common(who, banks, buckets, x, x_stride, inv_norm, n_atoms, F, E, 0, &n_edges)) return rc;
@@ -267,8 +267,11 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
     if (workspace_bytes < w.total || !workspace) return fail("%s: workspace of %zu bytes, need %zu", who, workspace_bytes, w.total);
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
-    hipError_t e = launch_bank_prepare(banks, w, ws, F, E, st);
-    if (e != hipSuccess) return hip_fail("bank_prepare", e);
+    hipError_t e = hipSuccess;
+    if (!workspace_from_forward) {                   // else the normalised bank of the forward call is still there
+        e = launch_bank_prepare(banks, w, ws, F, E, st);
+        if (e != hipSuccess) return hip_fail("bank_prepare", e);
+    }
     int slot_of[4];
     degree_slots(banks, buckets, slot_of);
     ForkJoin fj;

@@ -196,11 +196,12 @@ __global__ void __launch_bounds__(256) readout_bwd_mol_kernel(ReadoutArgs a, int
 
 // ----------------------------------- backward, per atom tile: dpre, dh = dpre W1, dW1 += dpre^T h, db1 += dpre ----
 template <int NT, int NU>
-__global__ void __launch_bounds__(256) readout_bwd_atoms_kernel(ReadoutArgs a) {
+__global__ void __launch_bounds__(512) readout_bwd_atoms_kernel(ReadoutArgs a) {
     constexpr int NJ = 4 * NU, HP = 16 * NT, FP = 16 * NJ, LDW = FP + 4, LDP = HP + 4;
+    constexpr int NW = NT == 4 ? 4 : 8;                               // two waves per SIMD where the 64 KB of static LDS allow it
     __shared__ __attribute__((aligned(16))) float w1s[HP * LDW];      // [hidden][feature]; reused for the block reduction
-    __shared__ __attribute__((aligned(16))) float dps[4][16 * LDP];   // per wave: dpre tile [atom][hidden]
-    for (int i = threadIdx.x; i < HP * LDW; i += 256) {
+    __shared__ __attribute__((aligned(16))) float dps[NW][16 * LDP];  // per wave: dpre tile [atom][hidden]
+    for (int i = threadIdx.x; i < HP * LDW; i += 64 * NW) {
         const int r = i / LDW, c = i - r * LDW;
         w1s[i] = (r < a.H && c < a.F) ? a.w1[r * a.F + c] : 0.f;
     }
@@ -217,7 +218,7 @@ __global__ void __launch_bounds__(256) readout_bwd_atoms_kernel(ReadoutArgs a) {
         for (int t = 0; t < NJ; ++t) accw[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const int64_t ntiles = (a.n + 15) / 16;
-    for (int64_t tile = (int64_t)blockIdx.x * 4 + wave; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    for (int64_t tile = (int64_t)blockIdx.x * NW + wave; tile < ntiles; tile += (int64_t)gridDim.x * NW) {
         // operand of the weight product: h rows 4 s + q, columns 64 u + 4 r .. + 3 (issued first: longest latency)
         f32x4 hv[4][NU];
 #pragma unroll
@@ -307,7 +308,7 @@ __global__ void __launch_bounds__(256) readout_bwd_atoms_kernel(ReadoutArgs a) {
             v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
             colsum[jj][c] = v;
         }
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
         __syncthreads();
         if (wave == w) {
 #pragma unroll
@@ -333,7 +334,7 @@ __global__ void __launch_bounds__(256) readout_bwd_atoms_kernel(ReadoutArgs a) {
     }
     __syncthreads();
     float* slab = a.slab_atoms + (int64_t)blockIdx.x * a.slab_atoms_stride;
-    for (int i = threadIdx.x; i < HP * FP + HP; i += 256) slab[i] = red[i];
+    for (int i = threadIdx.x; i < HP * FP + HP; i += 64 * NW) slab[i] = red[i];
 }
 
 // ------------------------------------------------ fixed-order sum of per-block slabs into the parameters ----
@@ -504,11 +505,17 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(BnArgs a, int CL) {
     __syncthreads();
     int64_t lo, hi;
     bn_rows(a, lo, hi);
-    const int64_t cnt = (hi - lo) * a.C;
-    for (int64_t i = t; i < cnt; i += 256) {
-        const int64_t rr = lo + i / a.C;
-        const int c = (int)(i % a.C);
-        a.out[rr * a.os + c] = fmaf(a.x[rr * a.xs + c] - mean[c], scale[c], shift[c]);
+    const int c = t & (CL - 1), rsub = t / CL, RS = 256 / CL;       // same thread layout as the column sums
+    if (c < a.C) {
+        const float mu = mean[c], sc = scale[c], sh0 = shift[c];
+        for (int64_t r0 = lo + rsub; r0 < hi; r0 += 4 * RS) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = a.x[(r0 + u * RS < hi ? r0 + u * RS : hi - 1) * a.xs + c];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (r0 + u * RS < hi) a.out[(r0 + u * RS) * a.os + c] = fmaf(v[u] - mu, sc, sh0);
+        }
     }
 }
 
@@ -530,22 +537,23 @@ __global__ void __launch_bounds__(256) bn_bwd_final_kernel(BnArgs a, int CL, int
     if (!a.gx) return;
     int64_t lo, hi;
     bn_rows(a, lo, hi);
-    const int64_t cnt = (hi - lo) * a.C;
     const float invn = 1.f / (float)a.n;
-    for (int64_t i = t; i < cnt; i += 256) {
-        const int64_t rr = lo + i / a.C;
-        const int c = (int)(i % a.C);
+    const int c = t & (CL - 1), rsub = t / CL, RS = 256 / CL;
+    if (c < a.C) {
         const float w = a.weight ? a.weight[c] : 1.f;
-        const float is = a.save_invstd[c];
-        const float dy = a.gout[rr * a.gos + c];
-        float g;
-        if (a.training) {
-            const float xh = (a.x[rr * a.xs + c] - a.save_mean[c]) * is;
-            g = w * is * (dy - invn * (sdy[c] + xh * sdyx[c]));
-        } else {
-            g = w * is * dy;
+        const float is = a.save_invstd[c], mu = a.save_mean[c];
+        const float k0 = w * is, s0 = sdy[c] * invn, s1 = sdyx[c] * invn;
+        for (int64_t rr = lo + rsub; rr < hi; rr += RS) {
+            const float dy = a.gout[rr * a.gos + c];
+            float g;
+            if (a.training) {
+                const float xh = (a.x[rr * a.xs + c] - mu) * is;
+                g = k0 * (dy - (s0 + xh * s1));
+            } else {
+                g = k0 * dy;
+            }
+            a.gx[rr * a.gxs + c] = g;
         }
-        a.gx[rr * a.gxs + c] = g;
     }
 }
 
@@ -568,7 +576,7 @@ bool readout_dims(int F, int H, int G, ReadoutDims& d) {
 }
 
 constexpr int RO_ATOM_BLOCKS = 256;
-constexpr int RO_MOL_BLOCKS = 64;
+constexpr int RO_MOL_BLOCKS = 256;      // 16 molecules per block at batch 4096: one LDS chunk each
 constexpr int BN_BLOCKS = 256;
 
 struct ReadoutWs { size_t dA, slab_atoms, slab_mol, total; int slab_atoms_stride, slab_mol_stride; };
@@ -669,11 +677,12 @@ int mkgnn_readout_backward(const mkgnn_readout_params* p, const float* h, int64_
     a.slab_atoms = (float*)((char*)ws + w.slab_atoms); a.slab_atoms_stride = w.slab_atoms_stride;
     a.slab_mol = (float*)((char*)ws + w.slab_mol); a.slab_mol_stride = w.slab_mol_stride;
     const int64_t ntiles = (n_atoms + 15) / 16;
-    a.nblk_atoms = (int)((ntiles + 3) / 4 < RO_ATOM_BLOCKS ? (ntiles + 3) / 4 : RO_ATOM_BLOCKS);
+    const int nw = d.NT == 4 ? 4 : 8;                // waves per block of readout_bwd_atoms_kernel
+    a.nblk_atoms = (int)((ntiles + nw - 1) / nw < RO_ATOM_BLOCKS ? (ntiles + nw - 1) / nw : RO_ATOM_BLOCKS);
     a.nblk_mol = (int)((n_mols + 15) / 16 < RO_MOL_BLOCKS ? (n_mols + 15) / 16 : RO_MOL_BLOCKS);
     readout_bwd_mol_kernel<<<a.nblk_mol, 256, 0, st>>>(a, d.HP);
-    if (d.NT == 2 && d.NU == 1) readout_bwd_atoms_kernel<2, 1><<<a.nblk_atoms, 256, 0, st>>>(a);
-    else if (d.NT == 2) readout_bwd_atoms_kernel<2, 2><<<a.nblk_atoms, 256, 0, st>>>(a);
+    if (d.NT == 2 && d.NU == 1) readout_bwd_atoms_kernel<2, 1><<<a.nblk_atoms, 512, 0, st>>>(a);
+    else if (d.NT == 2) readout_bwd_atoms_kernel<2, 2><<<a.nblk_atoms, 512, 0, st>>>(a);
     else if (d.NU == 1) readout_bwd_atoms_kernel<4, 1><<<a.nblk_atoms, 256, 0, st>>>(a);
     else readout_bwd_atoms_kernel<4, 2><<<a.nblk_atoms, 256, 0, st>>>(a);
     SlabReduceArgs r{};

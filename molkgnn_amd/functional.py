@@ -149,7 +149,7 @@ def _forward_impl(x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad
             banks, buckets, x.data_ptr(), _stride0(x), inv.data_ptr(), n, F, E, int(bool(is_last_layer)),
             out_full.data_ptr(), out_w, saved, ws.data_ptr(), ws_bytes, variant, st),
             "mkgnn_kernelsetconv_forward")
-    return x, out_full, inv, saved_t, Ls
+    return x, out_full, inv, saved_t, Ls, ws
 
 
 def kernelsetconv_details(x, plan: BatchPlan, is_last_layer: bool, params, edge_attr_dim: int, variant: str = "auto"):
@@ -157,7 +157,7 @@ def kernelsetconv_details(x, plan: BatchPlan, is_last_layer: bool, params, edge_
     ``(out [N, K], [(best_index [L_d, N_d] uint8, scores [3, L_d, N_d], chirality [L_d, N_d]) per degree])``
     (transposed views of the atom-major buffers).  Used by the parity tests for the tie-aware criterion."""
     with torch.no_grad():
-        _, out, _, saved_t, _ = _forward_impl(x, plan, is_last_layer, VARIANTS[variant], 0, edge_attr_dim,
+        _, out, _, saved_t, _, _ = _forward_impl(x, plan, is_last_layer, VARIANTS[variant], 0, edge_attr_dim,
                                               [p.detach() for p in params], True, _handed_inv_norm(x))
     tr = lambda t: None if t is None else t.transpose(-1, -2)
     return out, [(tr(bi), tr(sc), tr(ch)) for bi, sc, ch in saved_t]
@@ -169,8 +169,11 @@ class _KernelSetConvFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad: int, E: int, inv, *params):
         need_grad = any(ctx.needs_input_grad)
-        x, out_full, inv, saved_t, Ls = _forward_impl(x, plan, is_last_layer, variant, out_pad, E, params, need_grad, inv)
+        x, out_full, inv, saved_t, Ls, ws = _forward_impl(x, plan, is_last_layer, variant, out_pad, E, params, need_grad, inv)
         ctx.plan, ctx.is_last, ctx.E, ctx.Ls = plan, bool(is_last_layer), E, Ls
+        # the workspace holds the normalised kernel bank: backward reuses it (and the buffer) instead of redoing it
+        ctx.ws = ws if need_grad else None
+        ctx.param_versions = [p._version for p in params]
         ctx.saved_t = saved_t
         ctx.save_for_backward(x, inv, *params)
         K = sum(Ls)
@@ -216,11 +219,15 @@ class _KernelSetConvFn(torch.autograd.Function):
             F4 = F + (-F) % 4
             gx = torch.empty((n, F4), dtype=torch.float32, device=dev)[:, :F] if ctx.needs_input_grad[0] else None
             ws_bytes = workspace_bytes(Ls, F, E, n, plan.n_slots)
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            ws, ctx.ws = ctx.ws, None
+            reuse = ws is not None and ws.numel() >= ws_bytes and \
+                all(p._version == v for p, v in zip(params, ctx.param_versions))
+            if not reuse:
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             _lib.check(lib.mkgnn_kernelsetconv_backward(
                 banks, buckets, x.data_ptr(), _stride0(x), inv.data_ptr(), n, F, E, int(ctx.is_last),
                 g.data_ptr(), _stride0(g), saved, rowptr.data_ptr(), rows.data_ptr(),
-                _lib.ptr(gx), F4, grads, ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)),
+                _lib.ptr(gx), F4, grads, ws.data_ptr(), ws_bytes, int(reuse), _lib.stream_ptr(dev)),
                 "mkgnn_kernelsetconv_backward")
         return (gx, None, None, None, None, None, None, *gparams)
 
@@ -266,10 +273,13 @@ class _SegmentSumFn(torch.autograd.Function):
         inv = torch.empty(v.shape[0], dtype=torch.float32, device=v.device)
         out = _segment_sum(v, plan.csr_in, out_pad, inv)
         ctx.mark_non_differentiable(inv)
+        ctx.set_materialize_grads(False)             # no zero tensor for the norms' (non-existent) gradient
         return out, inv
 
     @staticmethod
     def backward(ctx, g, _g_inv):
+        if g is None:
+            return None, None, None
         g = _row_major(g if g.dtype == torch.float32 else g.float())
         return _segment_sum(g, ctx.plan.csr_out, (-g.shape[1]) % 4), None, None
 
