@@ -73,7 +73,9 @@ struct ForkJoin {
         // inside a hipGraph capture the buckets stay on the one captured stream: replayed graphs ran the
         // forked branches slower than the plain chain (measured 1.41 M vs 1.59 M molecules/s)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-        if (enable && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) enable = false;
+        static const bool fork_in_graph = getenv("MKGNN_FORK_IN_GRAPH") != nullptr;   // diagnostics: re-measure that choice
+        if (enable && !fork_in_graph && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            enable = false;
         main = st; p = enable ? degree_streams() : nullptr;
         used[0] = used[1] = used[2] = false;
         if (!p) return hipSuccess;

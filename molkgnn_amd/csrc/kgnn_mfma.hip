@@ -37,10 +37,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // Diagnostic time stamps (tools/stamp_probe.py): per wave {start, bank ready, then per tile
 // start / multiplied / stored}.  Null in normal runs.
 __device__ unsigned long long* g_stamp_buffer = nullptr;
+// Compiled in only with -DMKGNN_FWD_STAMPS (make STAMPS=1): the conditional stores split the tile loop
+// into more basic blocks and perturb the wait-count placement of the production kernel.
+#ifdef MKGNN_FWD_STAMPS
 #define MKGNN_STAMP(slot)                                                                      \
     do {                                                                                       \
         if (stamps && lane == 0 && (slot) < 29) stamps[(slot)] = __builtin_readcyclecounter(); \
     } while (0)
+#else
+#define MKGNN_STAMP(slot) do { (void)stamps; (void)(slot); } while (0)
+#endif
 
 template <int KC> __device__ __forceinline__ int swz(int pos) {
     if constexpr (KC == 7) {                // 112-float rows: rows 4 apart share banks
@@ -51,7 +57,16 @@ template <int KC> __device__ __forceinline__ int swz(int pos) {
 }
 
 // column tiles one WAVE accumulates at a time (bounds the accumulator registers)
-template <int D> struct BodyTraits { static constexpr int NL = (D >= 3) ? 1 : 2; };
+template <int D> struct BodyTraits {
+    static constexpr int NL = (D >= 3) ? 1 : 2;
+    // Row buffers.  2: the whole following slot is fetched into the other buffer when a slot starts (prefetch
+    // distance 1 - 2 slots of matrix work).  1: a single buffer rotated in place, chunk t of the following
+    // slot is loaded right after chunk t's MFMAs are issued (distance exactly 1 slot, KC * 4 fewer VGPRs).
+    // Degree 4 takes the single buffer: with two it spilled, and every scratch reload carries a vmcnt(0) that
+    // also waits for the gather.  For degrees 1-3 both fit; the launch time is the same within noise
+    // (77.7 - 78.9 us for all-1 / all-2 / mixed at batch 4096), two buffers keep the longer prefetch distance.
+    static constexpr int NB = (D == 4) ? 1 : 2;
+};
 
 // LDS floats a (degree, column part) block needs.
 __host__ __device__ static inline int fused_lds_floats(int D, int KC, int L, int nloc, int kpt) {
@@ -81,7 +96,9 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
     unsigned long long* stamps = g_stamp_buffer ? g_stamp_buffer + ((size_t)blockIdx.x * NW + wave) * 32 : nullptr;
     int stamp_slot = 2;
     MKGNN_STAMP(0);
+#ifdef MKGNN_FWD_STAMPS
     if (stamps && lane == 0) stamps[31] = (unsigned long long)(D * 16 + cp);
+#endif
 
     const int ci = lane & 15, kq = lane >> 4;
     const int64_t ntiles = (dg.n + 15) / 16;
@@ -150,112 +167,120 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
     const float ws = dg.mix[0], wc = dg.mix[1], we = dg.mix[2], wsum = dg.mix[3];
 
     // ---- pipeline registers
-    // Two row buffers used alternately: slot s is multiplied out of buf[s & 1] while slot s + 1 (or
-    // the next tile's slot 0) is in flight into the other.  For odd D the parity of slot 0 is the
-    // same in every tile; for even D the next tile's slot 0 lands in buffer 1 and is moved to
-    // buffer 0 once per tile.
-    f32x4 rb0[KC], rb1[KC];
-    float inv0 = 0.f, inv1 = 0.f;
+    // ONE row buffer, rotated in place: as soon as the MFMAs of chunk t of a slot are issued, chunk t of the
+    // following slot (the next neighbour, the focal row, or slot 0 of the wave's next tile) is loaded into
+    // the same registers.  Every chunk is therefore in flight for exactly one slot's worth of matrix work --
+    // the same prefetch distance as two alternating buffers -- with KC * 4 fewer VGPRs; with two buffers the
+    // degree 3 / 4 paths spilled, and every scratch reload carries a vmcnt(0) that also waits for the gather.
+    // All loads are unconditional (clamped tile index past the end): a load inside a conditional block makes
+    // the compiler wait for it at the end of the block.
+    constexpr int NB = BodyTraits<D>::NB;
+    f32x4 rb[NB][KC];
+    float inv_cur = 0.f;
     float2 eraw[D];                                  // bond components 2kq, 2kq+1 of (atom ci, slot s)
     int eq_raw = 0, sign_raw = 0;
+    const int8_t* eqp = do_chir ? (const int8_t*)dg.eqflag : (const int8_t*)dg.sel;       // always loadable
+    const int8_t* sgp = do_chir ? (const int8_t*)dg.signflag : (const int8_t*)dg.sel;
     auto issue_small = [&](int64_t t) {
         int64_t nrow = t * 16 + ci;
         if (nrow >= dg.n) nrow = dg.n - 1;
 #pragma unroll
         for (int s = 0; s < D; ++s) {
             const float* e = dg.e_nei + (nrow * D + s) * a.E;
-            // unconditional loads on clamped indices, masked afterwards (a load under a lane-dependent
-            // branch would end its basic block with a full wait)
-            const float r0 = e[2 * kq < a.E ? 2 * kq : a.E - 1];
-            const float r1 = e[2 * kq + 1 < a.E ? 2 * kq + 1 : a.E - 1];
-            eraw[s].x = 2 * kq < a.E ? r0 : 0.f;
-            eraw[s].y = 2 * kq + 1 < a.E ? r1 : 0.f;
+            eraw[s].x = e[2 * kq < a.E ? 2 * kq : a.E - 1];         // masked where they are used
+            eraw[s].y = e[2 * kq + 1 < a.E ? 2 * kq + 1 : a.E - 1];
         }
         if constexpr (D == 4) {
-            if (do_chir) {
-                eq_raw = dg.eqflag[nrow];
-                sign_raw = dg.signflag[nrow];
-            }
+            eq_raw = eqp[nrow];
+            sign_raw = sgp[nrow];
         }
     };
-    auto issue_slot = [&](uint32_t id, f32x4 (&dst)[KC], float& dinv) {
-        const float* row = a.x + (id * xs + 4u * kq);            // 32-bit offset (host checks N * stride < 2^32)
-#pragma unroll
-        for (int t = 0; t < KC - 1; ++t) dst[t] = *(const f32x4*)(row + 16 * t);
-        {   // only the last chunk can reach beyond the row's width (host guarantees FP - 16 < F <= FP)
-            const int f0 = 16 * (KC - 1) + 4 * kq;
-            // clamped (the chunk before) so that the load itself is unconditional
-            f32x4 v = *(const f32x4*)(row + (f0 < a.F ? 16 * (KC - 1) : 16 * (KC - 1) - 4 * kq));
-            if (f0 >= a.F) v.x = 0.f;
-            if (f0 + 1 >= a.F) v.y = 0.f;
-            if (f0 + 2 >= a.F) v.z = 0.f;
-            if (f0 + 3 >= a.F) v.w = 0.f;
-            dst[KC - 1] = v;
-        }
-        dinv = a.inv[id];
+    auto row_of = [&](uint32_t id) -> const float* { return a.x + (id * xs + 4u * kq); };   // 32-bit offset (host checks N * stride < 2^32)
+    const int f_last = 16 * (KC - 1) + 4 * kq;       // only the last chunk can reach beyond the row's width (FP - 16 < F <= FP)
+    auto load_chunk = [&](const float* row, int t) -> f32x4 {
+        // the last chunk is clamped (to the chunk before) so that the load itself is unconditional
+        const int off = (t < KC - 1 || f_last < a.F) ? 16 * t : 16 * t - 4 * kq;
+        return *(const f32x4*)(row + off);
+    };
+    auto mask_last = [&](f32x4 v) -> f32x4 {
+        if (f_last >= a.F) v.x = 0.f;
+        if (f_last + 1 >= a.F) v.y = 0.f;
+        if (f_last + 2 >= a.F) v.z = 0.f;
+        if (f_last + 3 >= a.F) v.w = 0.f;
+        return v;
     };
     issue_small(tile);
-    issue_slot(ids[0], rb0, inv0);
+    {
+        const float* row = row_of(ids[0]);
+#pragma unroll
+        for (int t = 0; t < KC; ++t) rb[0][t] = load_chunk(row, t);
+        inv_cur = a.inv[ids[0]];
+    }
 
     for (;;) {
         MKGNN_STAMP(stamp_slot);
         const int64_t nxt_tile = tile + tstride;
         const bool have_next = nxt_tile < ntiles;
         uint32_t ids_n[D + 1];
-#pragma unroll
-        for (int s = 0; s <= D; ++s) ids_n[s] = 0;
-        if (have_next) load_ids(nxt_tile, ids_n);
+        load_ids(have_next ? nxt_tile : tile, ids_n);
         // ---- per-tile small values (their loads were issued ahead of the rows)
         float2 eu[D];
 #pragma unroll
         for (int s = 0; s < D; ++s) {
-            float s2 = fmaf(eraw[s].y, eraw[s].y, eraw[s].x * eraw[s].x);
+            const float ex = 2 * kq < a.E ? eraw[s].x : 0.f, ey = 2 * kq + 1 < a.E ? eraw[s].y : 0.f;
+            float s2 = fmaf(ey, ey, ex * ex);
             s2 += __shfl_xor(s2, 16, 64);
             s2 += __shfl_xor(s2, 32, 64);
             const float ie = 1.f / fmaxf(sqrtf(s2), MKGNN_EPS);
-            eu[s] = float2{eraw[s].x * ie, eraw[s].y * ie};
+            eu[s] = float2{ex * ie, ey * ie};
         }
         float sign_row = 0.f;
         int eq_row = 0;
         if constexpr (D == 4) {
-            if (do_chir) {
-                sign_row = (float)sign_raw;
-                eq_row = eq_raw;
-            }
+            sign_row = do_chir ? (float)sign_raw : 0.f;
+            eq_row = do_chir ? eq_raw : 0;
         }
         const uint32_t focal_row = ids[D];
         float inv_keep[D + 1];
 
-        // ---- accumulate slot by slot; slot s+1 (or the next tile's slot 0) is in flight meanwhile
+        // ---- accumulate slot by slot; the following slot's rows stream in behind the chunks being consumed
         f32x4 cm[NL][D][D];
         f32x4 cc[NL];
         const int rloc = ci < kpt ? ci : kpt - 1;              // padded lanes re-read the tile's last row
         const int swb = swz<KC>(rloc);
 #pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            cc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s2 = 0; s2 < D; ++s2)
+#pragma unroll
+                for (int b = 0; b < D; ++b) cm[j][s2][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
         for (int s = 0; s <= D; ++s) {
-            f32x4 (&cur)[KC] = (s & 1) ? rb1 : rb0;
-            f32x4 (&oth)[KC] = (s & 1) ? rb0 : rb1;
-            inv_keep[s] = (s & 1) ? inv1 : inv0;
-            if (s < D) {
-                issue_slot(ids[s + 1 <= D ? s + 1 : D], oth, (s & 1) ? inv0 : inv1);
-            } else if (have_next) {
-                issue_small(nxt_tile);
-                issue_slot(ids_n[0], oth, (s & 1) ? inv0 : inv1);
+            const uint32_t nid = (s < D) ? ids[s + 1] : ids_n[0];
+            const float* nrow = row_of(nid);
+            inv_keep[s] = inv_cur;
+            inv_cur = a.inv[nid];
+            if (s == D) issue_small(have_next ? nxt_tile : tile);
+            // two buffers: slot s lives in buffer s & 1 (for even D the tile ends in buffer 0 again, for odd D
+            // the next tile's slot 0 has landed in buffer 1 and is moved once per tile, below)
+            const int bcur = (NB == 2) ? (s & 1) : 0;
+            if constexpr (NB == 2) {
+#pragma unroll
+                for (int t = 0; t < KC; ++t) rb[bcur ^ 1][t] = load_chunk(nrow, t);
             }
 #pragma unroll
-            for (int j = 0; j < NL; ++j) {
-                const int jl = wpart + j * ics;                    // resident column tile of this wave
-                if (jl < nloc) {
-                    const float* brow = bank + (size_t)(jl * kpt + rloc) * FP;
-                    if (s < D) {
-                        constexpr int dummy = 0;
-                        (void)dummy;
-                        const int si = s < D ? s : 0;
+            for (int t = 0; t < KC; ++t) {
+                const f32x4 cur = (t == KC - 1) ? mask_last(rb[bcur][t]) : rb[bcur][t];
+                const int c = 4 * t + kq;
 #pragma unroll
-                        for (int b = 0; b < D; ++b) cm[j][si][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int t = 0; t < KC; ++t) {
-                            const int c = 4 * t + kq;
+                for (int j = 0; j < NL; ++j) {
+                    const int jl = wpart + j * ics;                    // resident column tile of this wave
+                    if (jl < nloc) {
+                        const float* brow = bank + (size_t)(jl * kpt + rloc) * FP;
+                        if (s < D) {
+                            const int si = s < D ? s : 0;
                             f32x4 bf[D];
 #pragma unroll
                             for (int b = 0; b < D; ++b) bf[b] = *(const f32x4*)(brow + (size_t)b * SROW * FP + 4 * (c ^ swb));
@@ -263,20 +288,16 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
                             for (int q4 = 0; q4 < 4; ++q4)
 #pragma unroll
                                 for (int b = 0; b < D; ++b)
-                                    cm[j][si][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[t][q4], bf[b][q4], cm[j][si][b], 0, 0, 0);
-                        }
-                    } else {
-                        cc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int t = 0; t < KC; ++t) {
-                            const int c = 4 * t + kq;
+                                    cm[j][si][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[q4], bf[b][q4], cm[j][si][b], 0, 0, 0);
+                        } else {
                             const f32x4 bc = *(const f32x4*)(brow + (size_t)D * SROW * FP + 4 * (c ^ swb));
 #pragma unroll
                             for (int q4 = 0; q4 < 4; ++q4)
-                                cc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[t][q4], bc[q4], cc[j], 0, 0, 0);
+                                cc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[q4], bc[q4], cc[j], 0, 0, 0);
                         }
                     }
                 }
+                if constexpr (NB == 1) rb[0][t] = load_chunk(nrow, t);  // the same chunk of the following slot
             }
         }
         MKGNN_STAMP(stamp_slot + 1);
@@ -322,7 +343,9 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
                     best_permutation<D>(m, best4[jj], idx4[jj]);
                     cen4[jj] = cc[j][jj] * inv4[D][jj];
                 }
+#ifdef MKGNN_FWD_STAMPS
                 if (stamps && stamp_slot == 2 && j == 0) { asm volatile("" :: "v"(best4[0]), "v"(best4[3])); MKGNN_STAMP(20); }
+#endif
                 // bond-cosine matrices, one (a, b) tile at a time; keep the entry the chosen order uses
                 float ed4[4][D];
                 {
@@ -345,7 +368,9 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
                                 if (b == 0 || perm_at<D>(idx4[jj], s) == b) ed4[jj][s] = dm[b][jj];
                     }
                 }
+#ifdef MKGNN_FWD_STAMPS
                 if (stamps && stamp_slot == 2 && j == 0) { asm volatile("" :: "v"(ed4[0][0]), "v"(ed4[3][D - 1])); MKGNN_STAMP(21); }
+#endif
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj) {
                     const int64_t n = tile * 16 + kq * 4 + jj;
@@ -383,10 +408,9 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
         tile = nxt_tile;
 #pragma unroll
         for (int s = 0; s <= D; ++s) ids[s] = ids_n[s];
-        if constexpr ((D & 1) == 0) {       // even D: the new slot 0 was fetched into buffer 1
+        if constexpr (NB == 2 && (D & 1) == 0) {   // even D: D + 1 slots, the new slot 0 was fetched into buffer 1
 #pragma unroll
-            for (int t = 0; t < KC; ++t) rb0[t] = rb1[t];
-            inv0 = inv1;
+            for (int t = 0; t < KC; ++t) rb[0][t] = rb[1][t];
         }
     }
 }
@@ -483,8 +507,8 @@ bool mfma_forward_supported(int d, int F, int E, int L) {
 
 // Fill geometry, group sizes and the block table; returns the dynamic LDS bytes (0 = nothing to launch).
 static size_t plan_fused(FusedFwdArgs& a, const bool use[4], int KC, int* nblocks_out) {
-    double cost[FUSED_MAX_GROUPS];
-    int64_t cap[FUSED_MAX_GROUPS];
+    double cost[FUSED_MAX_GROUPS];                   // per 16-atom tile
+    int64_t cap[FUSED_MAX_GROUPS], tiles_of[FUSED_MAX_GROUPS];
     int ng = 0;
     size_t lds_floats = 0;
     for (int i = 0; i < 4; ++i) {
@@ -516,27 +540,40 @@ static size_t plan_fused(FusedFwdArgs& a, const bool use[4], int KC, int* nblock
             a.grp_degree[ng] = (uint8_t)i;
             a.grp_cp[ng] = (uint8_t)cp;
             // MFMAs per tile of this part + a term for the gather (rows are fetched once per part)
-            cost[ng] = (double)ntiles * (mine * ((d * d + 1) * 4.0 * KC + 2.0 * d * d) + 0.35 * (d + 1) * 4.0 * KC);
+            // (calibrated against cycle stamps at F = 110: ~100 / 80 / 75 / 97 cycles per unit for degree 1..4)
+            static const double calib[4] = {1.25, 1.0, 0.95, 1.2};
+            cost[ng] = calib[i] * (mine * ((d * d + 1) * 4.0 * KC + 2.0 * d * d) + 0.35 * (d + 1) * 4.0 * KC);
+            tiles_of[ng] = ntiles;
             cap[ng] = (ntiles + tiles_per_block - 1) / tiles_per_block;
             ++ng;
         }
     }
     if (ng == 0) { *nblocks_out = 0; return 0; }
-    double total = 0;
-    for (int g = 0; g < ng; ++g) total += cost[g];
+    // Block counts: all blocks are resident at once (two per CU) and a wave walks its group's tiles round
+    // robin, so the launch lasts as long as its slowest wave: prologue + ceil(tiles / waves) * cost per tile.
+    // A share proportional to the total cost ignores that ceil(): with 2-5 tiles per wave at batch 4096 the
+    // degree-4 groups got 2.4 tiles per wave on average, 3 on the slowest, and set the kernel time (stamps:
+    // 170 k cycles against 135 k for the other groups).  Greedy min-max instead: every block goes to the
+    // group that currently finishes last.
+    const double prologue = 100.0;                   // bank copy + first gather, in the cost unit (~80 cycles)
+    auto finish = [&](int g, int blocks) {
+        const int64_t waves = 4 * (int64_t)blocks;
+        return prologue + (double)((tiles_of[g] + waves - 1) / waves) * cost[g];
+    };
     int count[FUSED_MAX_GROUPS];
     int nb = 0;
-    for (int g = 0; g < ng; ++g) {
-        int64_t c = (int64_t)(FUSED_MAX_BLOCKS * cost[g] / total + 0.5);
-        if (c < 1) c = 1;
-        if (c > cap[g]) c = cap[g];
-        count[g] = (int)c;
-        nb += count[g];
-    }
-    while (nb > FUSED_MAX_BLOCKS) {                  // rounding overshoot: trim the largest group
-        int big = 0;
-        for (int g = 1; g < ng; ++g) if (count[g] > count[big]) big = g;
-        --count[big]; --nb;
+    for (int g = 0; g < ng; ++g) { count[g] = 1; ++nb; }
+    while (nb < FUSED_MAX_BLOCKS) {
+        int worst = -1;
+        double t_worst = -1.0;
+        for (int g = 0; g < ng; ++g) {
+            if (count[g] >= cap[g]) continue;
+            const double t = finish(g, count[g]);
+            if (t > t_worst) { t_worst = t; worst = g; }
+        }
+        if (worst < 0) break;
+        // blocks are only useful up to the next drop of ceil(tiles / waves)
+        ++count[worst]; ++nb;
     }
     // interleave the groups over the block ids (largest remaining share first), so that
     // consecutive blocks -- which the dispatcher deals round-robin over the XCDs -- mix degrees
