@@ -23,6 +23,17 @@ namespace mkgnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic cycle stamps (tools/bwd_stamp_probe.py), compiled in only with make STAMPS=1.
+__device__ unsigned long long* g_rows_stamp_buffer = nullptr;
+#ifdef MKGNN_BWD_STAMPS
+#define ROWS_STAMP(slot)                                                                         \
+    do {                                                                                         \
+        if (stamps && lane == 0 && (slot) < 32) stamps[(slot)] = __builtin_readcyclecounter();   \
+    } while (0)
+#else
+#define ROWS_STAMP(slot) do { (void)stamps; (void)(slot); } while (0)
+#endif
+
 __host__ __device__ constexpr int bwd_lq(int d) { return d == 1 ? 3 : (d == 2 ? 5 : (d == 3 ? 8 : 13)); }   // 4-kernel groups held per lane
 // Waves that share one 16-atom tile, each taking a slice of the feature tiles (the slices are independent:
 // no reduction).  Degree 4 has few atoms and 17 masked products per kernel group -- one wave per tile left
@@ -47,20 +58,10 @@ __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(Bw
     float* bank = lds;                               // [(D+1)*L][FP], row b*L + l; rows D*L + l = centres
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ci = lane & 15, kq = lane >> 4;
-    for (int base = 0; base < (D + 1) * L * FP / 4; base += NT * 8) {
-        f32x4 tmp[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int q = base + tid + NT * k;
-            if (q < (D + 1) * L * FP / 4) tmp[k] = *(const f32x4*)(a.padded + 4 * (size_t)q);
-        }
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int q = base + tid + NT * k;
-            if (q < (D + 1) * L * FP / 4) *(f32x4*)(bank + 4 * (size_t)q) = tmp[k];
-        }
-    }
-    __syncthreads();
+    unsigned long long* stamps = g_rows_stamp_buffer
+        ? g_rows_stamp_buffer + (((size_t)(D - 1) * 1024 + blockIdx.x) * NWV + wave) * 32 : nullptr;
+    int sslot = 2;
+    ROWS_STAMP(0);
     const float w_s = a.mix[0], w_c = a.mix[1], w_sum = a.mix[3];
     const float ws_n = w_s / w_sum / (float)D;
     const float ratio_c = w_c * (float)D / w_s;
@@ -93,10 +94,29 @@ __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(Bw
     };
     int64_t tile = (int64_t)blockIdx.x * (NWV / FS) + wave / FS;
     int64_t focal_next = 0;
-    if (tile < ntiles) {
-        issue(tile, focal_of(tile), rg, ridx, rch);
+    {   // unconditional (clamped past the end): a load inside a conditional block is waited for at its end
+        const int64_t t0 = tile < ntiles ? tile : ntiles - 1;
+        issue(t0, focal_of(t0), rg, ridx, rch);
         focal_next = focal_of(tile + tstep);
     }
+    // ---- one-time: the unit kernel rows -> LDS.  Issued AFTER the first tile's coefficient loads, which then
+    // complete under the copy (they were an exposed double round trip of 4-10 k cycles per wave, and at batch
+    // 4096 a wave has one to three tiles); 16 loads in flight per thread.
+    for (int base = 0; base < (D + 1) * L * FP / 4; base += NT * 16) {
+        f32x4 tmp[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int q = base + tid + NT * k;
+            tmp[k] = *(const f32x4*)(a.padded + 4 * (size_t)(q < (D + 1) * L * FP / 4 ? q : 0));
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int q = base + tid + NT * k;
+            if (q < (D + 1) * L * FP / 4) *(f32x4*)(bank + 4 * (size_t)q) = tmp[k];
+        }
+    }
+    __syncthreads();
+    ROWS_STAMP(1);
     for (; tile < ntiles; tile += tstep) {
         const int64_t n = tile * 16 + ci;
         const bool row_ok = n < a.n;
@@ -112,9 +132,13 @@ __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(Bw
             pk[kk] = bits;
             c[kk] = g * ws_n;
         }
-        // next tile's inputs: in flight during this tile's MFMAs (tiles past the end read clamped rows, unused)
-        issue(tile + tstep, focal_next, rg, ridx, rch);
-        focal_next = focal_of(tile + 2 * tstep);
+        ROWS_STAMP(sslot);
+        // next tile's inputs: in flight during this tile's MFMAs (tiles past the end read clamped rows, unused).
+        constexpr bool PF = true;
+        if constexpr (PF) {
+            issue(tile + tstep, focal_next, rg, ridx, rch);
+            focal_next = focal_of(tile + 2 * tstep);
+        }
         f32x4 acc[D + 1][FTW];                       // slot 0 = focal, 1 + s = neighbour s
 #pragma unroll
         for (int s = 0; s <= D; ++s)
@@ -152,6 +176,7 @@ __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(Bw
                 }
             }
         }
+        ROWS_STAMP(sslot + 1);
         // ---- contribution rows: lane holds atoms kq*4 + jj, feature 16*ft + ci
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
@@ -167,6 +192,11 @@ __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(Bw
                 }
             }
         }
+        if constexpr (!PF) {
+            if (tile + tstep < ntiles) issue(tile + tstep, focal_of(tile + tstep), rg, ridx, rch);
+        }
+        ROWS_STAMP(sslot + 2);
+        sslot += 3;
     }
 }
 
@@ -183,6 +213,8 @@ bool mfma_backward_supported(int d, int F, int E, int L, int64_t xs, const void*
 template <int D, int KC>
 static hipError_t launch_mfma_rows(const BwdArgs& a, int* ntheta_out, hipStream_t st) {
     constexpr int FP = 16 * KC;
+    // (eight waves per block were tried for degree 4 -- 112 KB of bank, one block per CU -- to give every wave a single
+    // unit: at two waves per SIMD its ~300 registers spill 400 VGPRs)
     constexpr int NT = 256;
     static bool attr_set = false;
     if (!attr_set) {
@@ -226,3 +258,7 @@ hipError_t launch_backward_rows_mfma(int d, const BwdArgs& a, int* ntheta_out, h
 }
 
 }  // namespace mkgnn
+
+extern "C" int mkgnn_debug_set_rows_stamp_buffer(void* device_ptr) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(mkgnn::g_rows_stamp_buffer), &device_ptr, sizeof(void*));
+}

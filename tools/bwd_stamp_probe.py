@@ -58,3 +58,34 @@ for d in range(4):
     print(f"degree {d + 1}: blocks {len(w)} span {span} cyc; prologue {pro:.0f}; tiles/block {ntile.mean():.2f}; per tile med: "
           f"stage {med[0]:.0f} | barrier {med[1]:.0f} | prefetch issue {med[2]:.0f} | accumulate {med[3]:.0f} | barrier+ids {med[4]:.0f}"
           f" | sum {sum(med):.0f}; epilogue {np.median(w[:, 62] - w[np.arange(len(w)), 2 + 5 * ntile - 1]):.0f}")
+
+# ---- rows kernel (kc_backward_rows_mfma): per wave {start, bank in LDS, then per tile: inputs ready, MFMAs done, stored}
+rsetter = C.CDLL(_lib.LIB_PATH).mkgnn_debug_set_rows_stamp_buffer
+rsetter.argtypes = [C.c_void_p]
+rbuf = torch.zeros(4 * 1024 * 4 * 32, dtype=torch.int64, device=dev)
+assert rsetter(C.c_void_p(rbuf.data_ptr())) == 0
+out = layer._run(x, plan, False)
+(out * cot).sum().backward()
+torch.cuda.synchronize()
+rsetter(C.c_void_p(0))
+rs = rbuf.cpu().numpy().reshape(4, 1024 * 4, 32)
+for d in range(4):
+    w = rs[d]
+    w = w[w[:, 0] != 0]
+    if not len(w):
+        continue
+    t0 = w[:, 0].min()
+    nt = ((w[:, 2:32] != 0).sum(1) // 3)
+    last = np.array([w[r, 2 + 3 * nt[r] - 1] if nt[r] else w[r, 1] for r in range(len(w))])
+    ph = [[] for _ in range(3)]
+    for r in range(len(w)):
+        prev = w[r, 1]
+        for t in range(nt[r]):
+            for k in range(3):
+                cur = w[r, 2 + 3 * t + k]
+                ph[k].append(cur - prev)
+                prev = cur
+    med = [np.median(p) if p else 0 for p in ph]
+    print(f"rows degree {d + 1}: waves {len(w)} (with tiles: {(nt > 0).sum()}) span {last.max() - t0} cyc; start skew max {(w[:, 0] - t0).max()}; "
+          f"bank copy med {np.median(w[:, 1] - w[:, 0]):.0f}; tiles/wave {nt.mean():.2f} max {nt.max()}; per tile med: inputs {med[0]:.0f} | "
+          f"mfma {med[1]:.0f} | store {med[2]:.0f}")
