@@ -281,6 +281,7 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
     if (e != hipSuccess) return hip_fail("stream fork", e);
     int off = 0;
     int64_t base = 0;
+    BankReduceArgs reduce[4];
     for (int i = 0; i < 4; ++i) {
         const int d = i + 1;
         hipStream_t dst = fj.stream(slot_of[i], &e);
@@ -319,7 +320,7 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
             else e = launch_backward_generic(d, a, dst);
             if (e != hipSuccess) return hip_fail("kernelconv backward launch", e);
         }
-        BankReduceArgs r;
+        BankReduceArgs& r = reduce[i];
         r.slab = a.slab; r.nchunk = nchunk; r.F = F; r.E = E; r.L = L[i];
         if (ntheta >= 0) { r.theta_src = a.theta_slab; r.theta_stride = 4; r.theta_count = ntheta; }
         else {
@@ -330,13 +331,13 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         r.icen = (const float*)(ws + w.bank[i].icen); r.isup = (const float*)(ws + w.bank[i].isup);
         r.iedg = (const float*)(ws + w.bank[i].iedg);
         r.g = grads[i];
-        e = launch_bank_reduce(d, r, dst);
-        if (e != hipSuccess) return hip_fail("bank gradient reduce launch", e);
         off += L[i];
         base += a.n * (d + 1);
     }
     e = fj.end();
     if (e != hipSuccess) return hip_fail("stream join", e);
+    e = launch_bank_reduce_all(reduce, st);          // one launch for the four banks
+    if (e != hipSuccess) return hip_fail("bank gradient reduce launch", e);
     if (grad_x) {
         e = launch_backward_gather((const float*)(ws + w.contrib), (F + 3) / 4 * 4, base, scatter_rowptr, scatter_rows, x,
                                    x_stride, inv_norm, n_atoms, F, grad_x, grad_x_stride, st);

@@ -346,30 +346,37 @@ __global__ void __launch_bounds__(128) kc_backward_bank(BwdArgs a) {
 
 // Sum the per-block partial slabs in a fixed order and undo the unit normalisation:
 // d/ds of s/max(|s|,eps):  (g - (g . s^) s^) / |s|   (or g / eps below eps).
-// One block per bank row: wave w sums chunks w, w+4, ..., the four partial sums are combined
-// as (p0 + p1) + (p2 + p3) -- the same order on every run.
-template <int D>
-__global__ void __launch_bounds__(256) kc_backward_bank_reduce(BankReduceArgs a) {
-    const int r = blockIdx.x;
+// One block per bank row, all four degrees in one launch (four separate launches of this latency-bound
+// kernel cost ~9 us each).  Wave w of 8 sums chunks w, w + 8, ... with 16 loads in flight; the partial sums
+// are combined in an order fixed by the code -- the same on every run.
+__global__ void __launch_bounds__(512) kc_backward_bank_reduce(BankReduceAllArgs all) {
+    int di = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) if ((int)blockIdx.x >= all.blk_start[k]) di = k;
+    const BankReduceArgs& a = all.deg[di];
+    const int D = di + 1;
+    const int r = blockIdx.x - all.blk_start[di];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NWV = 8;
     const int L = a.L;
     const size_t bank_fl = bank_floats(D, L, a.F, a.E);
     const int nrow = L + 2 * L * D;
-    __shared__ float part[4][256];
+    __shared__ float part[NWV][256];
     if (r == nrow) {
-        // score-weight partials: thread t sums entries t, t+256, ...; then a fixed-order tree over the block
+        // score-weight partials: thread t sums entries t, t+512, ...; then a fixed-order tree over the block
+        float* red = &part[0][0];
         for (int k = 0; k < 3; ++k) {
             float s = 0.f;
-            for (int c = tid; c < a.theta_count; c += 256) s += a.theta_src[(size_t)c * a.theta_stride + k];
-            part[0][tid] = s;
+            for (int c = tid; c < a.theta_count; c += 512) s += a.theta_src[(size_t)c * a.theta_stride + k];
+            red[tid] = s;
             __syncthreads();
-            for (int w = 128; w > 0; w >>= 1) {
-                if (tid < w) part[0][tid] += part[0][tid + w];
+            for (int w = 256; w > 0; w >>= 1) {
+                if (tid < w) red[tid] += red[tid + w];
                 __syncthreads();
             }
             if (tid == 0) {
                 float* dst = k == 0 ? a.g.support_attr_sc_weight : (k == 1 ? a.g.center_attr_sc_weight : a.g.edge_attr_support_sc_weight);
-                if (dst) *dst = part[0][0];
+                if (dst) *dst = red[0];
             }
             __syncthreads();
         }
@@ -381,22 +388,31 @@ __global__ void __launch_bounds__(256) kc_backward_bank_reduce(BankReduceArgs a)
     else { int q = r - L - L * D; unit = a.edg + (size_t)q * a.E; inv = a.iedg[q]; dst = a.g.edge_attr_support ? a.g.edge_attr_support + (size_t)q * a.E : nullptr; off = (size_t)L * a.F + (size_t)L * D * a.F + (size_t)q * a.E; width = a.E; }
     if (!dst) return;
     for (int f = lane; f < width; f += 64) {
-        // eight loads in flight per lane; the association order is fixed by the code, not by timing
-        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        const float* base = a.slab + off + f;
-        int c = wave;
-        for (; c + 28 < a.nchunk; c += 32) {
+        float s[16];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) s[u] += base[(size_t)(c + 4 * u) * bank_fl];
+        for (int u = 0; u < 16; ++u) s[u] = 0.f;
+        const float* base = a.slab + off + f;
+        for (int c = wave; c < a.nchunk; c += NWV * 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {       // unconditional clamped loads, masked sums
+                const int cc = c + NWV * u;
+                v[u] = base[(size_t)(cc < a.nchunk ? cc : c) * bank_fl];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (c + NWV * u < a.nchunk) s[u] += v[u];
         }
-        for (int u = 0; c < a.nchunk; c += 4, ++u) s[u & 7] += base[(size_t)c * bank_fl];
-        part[wave][f] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+#pragma unroll
+        for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+            for (int u = 0; u < w; ++u) s[u] += s[u + w];
+        part[wave][f] = s[0];
     }
     __syncthreads();
     if (wave != 0) return;
     float dotp = 0.f;
     for (int f = lane; f < width; f += 64) {
-        const float s = (part[0][f] + part[1][f]) + (part[2][f] + part[3][f]);
+        const float s = ((part[0][f] + part[1][f]) + (part[2][f] + part[3][f])) + ((part[4][f] + part[5][f]) + (part[6][f] + part[7][f]));
         part[0][f] = s;
         dotp = fmaf(s, unit[f], dotp);
     }
@@ -600,20 +616,17 @@ hipError_t launch_backward_generic(int d, const BwdArgs& a, hipStream_t st) {
     }
 }
 
-template <int D>
-static hipError_t launch_reduce_d(const BankReduceArgs& r, hipStream_t st) {
-    kc_backward_bank_reduce<D><<<r.L + 2 * r.L * D + 1, 256, 0, st>>>(r);
-    return hipGetLastError();
-}
-
-hipError_t launch_bank_reduce(int d, const BankReduceArgs& r, hipStream_t st) {
-    if (r.L == 0) return hipSuccess;
-    switch (d) {
-        case 1: return launch_reduce_d<1>(r, st);
-        case 2: return launch_reduce_d<2>(r, st);
-        case 3: return launch_reduce_d<3>(r, st);
-        default: return launch_reduce_d<4>(r, st);
+hipError_t launch_bank_reduce_all(const BankReduceArgs r[4], hipStream_t st) {
+    BankReduceAllArgs all;
+    int blk = 0;
+    for (int i = 0; i < 4; ++i) {
+        all.deg[i] = r[i];
+        all.blk_start[i] = blk;
+        if (r[i].L > 0) blk += r[i].L + 2 * r[i].L * (i + 1) + 1;
     }
+    if (blk == 0) return hipSuccess;
+    kc_backward_bank_reduce<<<blk, 512, 0, st>>>(all);
+    return hipGetLastError();
 }
 
 hipError_t launch_backward_gather(const float* contrib, int64_t cs, int64_t n_contrib_rows, const int32_t* rowptr,

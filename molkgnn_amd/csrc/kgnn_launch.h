@@ -90,7 +90,8 @@ hipError_t launch_forward_generic(int d, const FwdArgs& a, hipStream_t st);
 bool mfma_forward_supported(int d, int F, int E, int L);
 hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t st);
 hipError_t launch_backward_generic(int d, const BwdArgs& a, hipStream_t st);
-hipError_t launch_bank_reduce(int d, const BankReduceArgs& r, hipStream_t st);
+struct BankReduceAllArgs { BankReduceArgs deg[4]; int blk_start[4]; };
+hipError_t launch_bank_reduce_all(const BankReduceArgs r[4], hipStream_t st);   // degrees with L == 0 are skipped
 // kgnn_bwd.hip: LDS-tiled backward for the model's shapes
 bool lds_backward_supported(int d, int F, int E, int L, int64_t xs, const void* x);
 hipError_t launch_backward_lds(int d, const BwdArgs& a, int* nchunk_out, int* ntheta_out, bool rows_too, hipStream_t st);
