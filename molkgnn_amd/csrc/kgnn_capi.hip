@@ -69,13 +69,20 @@ struct ForkJoin {
     DegreeStreams* p;
     hipStream_t main;
     bool used[3];
+    // Inside a hipGraph capture: ONE helper stream.  The x-gradient chain (rows kernels of the four degrees, then
+    // the gather) stays on the caller's stream, the bank-gradient chain (bank kernels, then the reduce) runs on the
+    // helper; they share nothing until the join.  Replayed graphs pay ~25 us per extra branch: one branch gains
+    // (1.575 -> 1.518 ms per step), two more lose (1.634 ms), one per degree lost more.  MKGNN_FORK_MODE=0 disables it.
+    bool two_way = false;
     hipError_t begin(hipStream_t st, bool enable) {
         // inside a hipGraph capture the buckets stay on the one captured stream: replayed graphs ran the
         // forked branches slower than the plain chain (measured 1.41 M vs 1.59 M molecules/s)
         hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
         static const bool fork_in_graph = getenv("MKGNN_FORK_IN_GRAPH") != nullptr;   // diagnostics: re-measure that choice
-        if (enable && !fork_in_graph && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
-            enable = false;
+        static const char* fork_mode = getenv("MKGNN_FORK_MODE");
+        const bool capturing = hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+        if (enable && capturing && !(fork_mode && fork_mode[0] == '0') && !fork_in_graph) two_way = true;
+        else if (enable && !fork_in_graph && capturing) enable = false;
         main = st; p = enable ? degree_streams() : nullptr;
         used[0] = used[1] = used[2] = false;
         if (!p) return hipSuccess;
@@ -282,9 +289,10 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
     int off = 0;
     int64_t base = 0;
     BankReduceArgs reduce[4];
+    bool bank_on_main = false;                       // some bank gradient was computed on the caller's stream
     for (int i = 0; i < 4; ++i) {
         const int d = i + 1;
-        hipStream_t dst = fj.stream(slot_of[i], &e);
+        hipStream_t dst = fj.stream(fj.two_way ? 0 : slot_of[i], &e);
         if (e != hipSuccess) return hip_fail("stream fork", e);
         if (buckets[i].count > 0 && (!saved[i].best_index || !saved[i].scores))
             return fail("%s: degree %d has no saved forward state", who, d);
@@ -311,13 +319,20 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
             static const bool no_mfma_bwd = getenv("MKGNN_NO_MFMA_BWD") != nullptr;     // diagnostics: A/B against the LDS rows kernel
             if (lds_backward_supported(d, F, E, L[i], x_stride, x)) {
                 const bool rows_mfma = !no_mfma_bwd && mfma_backward_supported(d, F, E, L[i], x_stride, x, n_atoms);
+                hipStream_t st_rows = dst, st_bank = dst;
+                if (fj.two_way && !rows_mfma) bank_on_main = true;
+                if (fj.two_way && rows_mfma) {
+                    st_rows = st;
+                    st_bank = fj.stream(1, &e);
+                    if (e != hipSuccess) return hip_fail("stream fork", e);
+                }
                 if (rows_mfma) {
-                    e = launch_backward_rows_mfma(d, a, &ntheta, dst);
+                    e = launch_backward_rows_mfma(d, a, &ntheta, st_rows);
                     if (e != hipSuccess) return hip_fail("kernelconv backward launch", e);
                 }
-                e = launch_backward_lds(d, a, &nchunk, &ntheta, !rows_mfma, dst);
+                e = launch_backward_lds(d, a, &nchunk, &ntheta, !rows_mfma, st_bank);
             }
-            else e = launch_backward_generic(d, a, dst);
+            else { e = launch_backward_generic(d, a, dst); bank_on_main = true; }
             if (e != hipSuccess) return hip_fail("kernelconv backward launch", e);
         }
         BankReduceArgs& r = reduce[i];
@@ -334,14 +349,27 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         off += L[i];
         base += a.n * (d + 1);
     }
-    e = fj.end();
-    if (e != hipSuccess) return hip_fail("stream join", e);
-    e = launch_bank_reduce_all(reduce, st);          // one launch for the four banks
+    // two chains: the reduce follows the bank kernels on the helper, the gather follows the rows kernels here
+    const bool split = fj.two_way && !bank_on_main && fj.used[0];
+    if (!split) {
+        e = fj.end();
+        if (e != hipSuccess) return hip_fail("stream join", e);
+    }
+    hipStream_t st_reduce = st;
+    if (split) {
+        st_reduce = fj.stream(1, &e);
+        if (e != hipSuccess) return hip_fail("stream fork", e);
+    }
+    e = launch_bank_reduce_all(reduce, st_reduce);   // one launch for the four banks
     if (e != hipSuccess) return hip_fail("bank gradient reduce launch", e);
     if (grad_x) {
         e = launch_backward_gather((const float*)(ws + w.contrib), (F + 3) / 4 * 4, base, scatter_rowptr, scatter_rows, x,
                                    x_stride, inv_norm, n_atoms, F, grad_x, grad_x_stride, st);
         if (e != hipSuccess) return hip_fail("backward gather launch", e);
+    }
+    if (split) {
+        e = fj.end();
+        if (e != hipSuccess) return hip_fail("stream join", e);
     }
     return 0;
 }
