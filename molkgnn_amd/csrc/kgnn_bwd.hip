@@ -201,8 +201,15 @@ __global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
 #pragma unroll
         for (int s = 0; s <= D; ++s) acc[li][s] = f32x2{0.f, 0.f};
     const int64_t ntiles = (a.n + TA - 1) / TA;
-    const bool feat = 2 * lane < FP;
-    const bool act = 2 * lane < RS;
+    // A tile row is RS / 2 lanes wide (60 for F = 110, 20 for F = 28).  An LDS read instruction costs the same
+    // whether 20 or 64 lanes are active, and the accumulate loop is bound by exactly those instructions, so narrow
+    // rows are packed: PACK atoms side by side in one wave (lane group g = lane / (RS / 2) takes atoms i + g),
+    // each group accumulating its own partial sums, combined by shuffles in a fixed order at the end.
+    constexpr int LPR = RS / 2;                      // lanes per row
+    constexpr int PACK = 64 / LPR;                   // 1 (F = 110) or 3 (F = 28)
+    const int grp = lane / LPR, ll = lane - grp * LPR;
+    const bool feat = 2 * ll < FP;
+    const bool act = grp < PACK;
 
     // Atom ids and row norms of a tile, one row per thread (NROW <= NT), pipelined over three tiles: ids are
     // loaded two tiles ahead, the norms (addressed by those ids) one tile ahead; both loads are issued BEFORE
@@ -352,10 +359,17 @@ __global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
             // The coefficient entries of atom i + 1 are read while atom i's rows are in flight, so an atom costs
             // one LDS round trip (its row reads) instead of two dependent ones.
             float cv[LI][D + 1];
-            read_coef(0, cv);
+            read_coef(grp < cnt ? grp : cnt - 1, cv);
 #pragma unroll 1
-            for (int i = 0; i < cnt; ++i) {
-                const char* xr = (const char*)(xt + (size_t)i * (D + 1) * RS + 2 * lane);
+            for (int i0 = 0; i0 < cnt; i0 += PACK) {
+                const int i = i0 + grp < cnt ? i0 + grp : cnt - 1;        // this lane group's atom (clamped: masked below)
+                if constexpr (PACK > 1) {
+                    if (i0 + grp >= cnt) {
+#pragma unroll
+                        for (int li = 0; li < LI; ++li) cv[li][0] = 0.f;
+                    }
+                }
+                const char* xr = (const char*)(xt + (size_t)i * (D + 1) * RS + 2 * ll);
                 const f32x2 vfocal = *(const f32x2*)(xr + D * RS * 4);
                 // all LI * D row reads, addresses straight from the entries
                 f32x2 vv[LI][D];
@@ -366,7 +380,7 @@ __global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
                 float c0[LI];
 #pragma unroll
                 for (int li = 0; li < LI; ++li) c0[li] = cv[li][0];
-                read_coef(i + 1 < TA ? i + 1 : i, cv);
+                read_coef(i + PACK < cnt ? i + PACK : cnt - 1, cv);   // (re-read of a clamped atom is zeroed at the loop top)
                 // packed FMAs
 #pragma unroll
                 for (int li = 0; li < LI; ++li) {
@@ -398,6 +412,22 @@ __global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
             a.theta_slab[(size_t)blockIdx.x * 4 + tid] = t;
         }
     }
+    if constexpr (PACK > 1) {                        // lane groups -> group 0, fixed order (g0 + g1) + g2 ...
+#pragma unroll
+        for (int li = 0; li < LI; ++li)
+#pragma unroll
+            for (int s = 0; s <= D; ++s) {
+                f32x2 t = acc[li][s];
+#pragma unroll
+                for (int g = 1; g < PACK; ++g) {
+                    const int src = (lane + g * LPR) & 63;
+                    t.x += __shfl(acc[li][s].x, src, 64);
+                    t.y += __shfl(acc[li][s].y, src, 64);
+                }
+                acc[li][s] = t;
+            }
+    }
+    const bool writer = grp == 0;
     // ---- one partial slab per block (row order of kc_backward_bank in kgnn_generic.hip)
     float* slab = a.slab + (size_t)blockIdx.x * bank_floats(D, L, a.F, a.E);
     const size_t o_sup = (size_t)L * a.F, o_edg = o_sup + (size_t)L * D * a.F;
@@ -405,13 +435,13 @@ __global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
     for (int li = 0; li < LI; ++li) {
         const int l = wave + NWV * li;
         if (l < L) {
-            if (2 * lane < a.F) {
-                *(f32x2*)(slab + (size_t)l * a.F + 2 * lane) = acc[li][D];
+            if (writer && 2 * ll < a.F) {
+                *(f32x2*)(slab + (size_t)l * a.F + 2 * ll) = acc[li][D];
 #pragma unroll
                 for (int b = 0; b < D; ++b)
-                    *(f32x2*)(slab + o_sup + (size_t)(l * D + b) * a.F + 2 * lane) = acc[li][b];
-            } else if (!feat && act) {
-                const int e0 = 2 * lane - FP;
+                    *(f32x2*)(slab + o_sup + (size_t)(l * D + b) * a.F + 2 * ll) = acc[li][b];
+            } else if (writer && !feat) {
+                const int e0 = 2 * ll - FP;
 #pragma unroll
                 for (int b = 0; b < D; ++b) {
                     if (e0 < a.E) slab[o_edg + (size_t)(l * D + b) * a.E + e0] = acc[li][b].x;
