@@ -197,7 +197,8 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
     // (alignment padding up to the next multiple of four columns is zeroed with it when the stride holds it)
     if (n_atoms > 0 && K > 0) {
         const int64_t K4 = (K + 3) / 4 * 4;
-        e = hipMemset2DAsync(out, (size_t)out_stride * 4, 0, (size_t)(K4 <= out_stride ? K4 : K) * 4, (size_t)n_atoms, st);
+        if (K4 == out_stride) e = hipMemsetAsync(out, 0, (size_t)n_atoms * out_stride * 4, st);   // contiguous: one fill kernel, not two
+        else e = hipMemset2DAsync(out, (size_t)out_stride * 4, 0, (size_t)(K4 <= out_stride ? K4 : K) * 4, (size_t)n_atoms, st);
         if (e != hipSuccess) return hip_fail("output memset", e);
     }
     // the fused MFMA launch takes every degree whose shape it covers; the rest run on the generic kernels
