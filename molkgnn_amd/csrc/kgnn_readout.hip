@@ -409,16 +409,16 @@ __device__ __forceinline__ void bn_block_colsum(const BnArgs& a, int CL, const f
     const int cc = act ? c : 0;
     const float mu = (MODE >= 1) ? mean[cc] : 0.f, is = (MODE == 2) ? invstd[cc] : 0.f;
     float s0 = 0.f, s1 = 0.f;
-    for (int64_t r0 = lo + rsub; r0 < hi; r0 += 4 * RS) {
-        float v[4], g[4];
+    for (int64_t r0 = lo + rsub; r0 < hi; r0 += 8 * RS) {
+        float v[8], g[8];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const int64_t rr = r0 + u * RS < hi ? r0 + u * RS : hi - 1;
             v[u] = a.x[rr * a.xs + cc];
             if (MODE == 2) g[u] = a.gout[rr * a.gos + cc];
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < 8; ++u) {
             if (r0 + u * RS < hi) {
                 if (MODE == 0) s0 += v[u];
                 if (MODE == 1) { const float d = v[u] - mu; s0 = fmaf(d, d, s0); }
@@ -443,8 +443,17 @@ __device__ __forceinline__ void bn_block_colsum(const BnArgs& a, int CL, const f
 __device__ __forceinline__ void bn_total(const float* part, int nblk, int C, int CL, float* sh, float* sh_out) {
     const int c = threadIdx.x & (CL - 1), rsub = threadIdx.x / CL, RS = 256 / CL;
     float s = 0.f;
-    if (c < C)
-        for (int b = rsub; b < nblk; b += RS) s += part[(int64_t)b * C + c];
+    if (c < C) {
+        // eight loads in flight (every block repeats this sum: serial loads made it the slowest part of the pass)
+        float v[8], t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int b = rsub; b < nblk; b += 8 * RS) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(b + u * RS < nblk ? b + u * RS : b) * C + c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (b + u * RS < nblk) t[u] += v[u];
+        }
+        s = ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
     __syncthreads();
     sh[threadIdx.x] = s;
     __syncthreads();
@@ -508,12 +517,12 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(BnArgs a, int CL) {
     const int c = t & (CL - 1), rsub = t / CL, RS = 256 / CL;       // same thread layout as the column sums
     if (c < a.C) {
         const float mu = mean[c], sc = scale[c], sh0 = shift[c];
-        for (int64_t r0 = lo + rsub; r0 < hi; r0 += 4 * RS) {
-            float v[4];
+        for (int64_t r0 = lo + rsub; r0 < hi; r0 += 8 * RS) {
+            float v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = a.x[(r0 + u * RS < hi ? r0 + u * RS : hi - 1) * a.xs + c];
+            for (int u = 0; u < 8; ++u) v[u] = a.x[(r0 + u * RS < hi ? r0 + u * RS : hi - 1) * a.xs + c];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < 8; ++u)
                 if (r0 + u * RS < hi) a.out[(r0 + u * RS) * a.os + c] = fmaf(v[u] - mu, sc, sh0);
         }
     }
@@ -543,16 +552,21 @@ __global__ void __launch_bounds__(256) bn_bwd_final_kernel(BnArgs a, int CL, int
         const float w = a.weight ? a.weight[c] : 1.f;
         const float is = a.save_invstd[c], mu = a.save_mean[c];
         const float k0 = w * is, s0 = sdy[c] * invn, s1 = sdyx[c] * invn;
-        for (int64_t rr = lo + rsub; rr < hi; rr += RS) {
-            const float dy = a.gout[rr * a.gos + c];
-            float g;
-            if (a.training) {
-                const float xh = (a.x[rr * a.xs + c] - mu) * is;
-                g = k0 * (dy - (s0 + xh * s1));
-            } else {
-                g = k0 * dy;
+        for (int64_t r0 = lo + rsub; r0 < hi; r0 += 4 * RS) {
+            float dy[4], xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t rr = r0 + u * RS < hi ? r0 + u * RS : hi - 1;
+                dy[u] = a.gout[rr * a.gos + c];
+                xv[u] = a.x[rr * a.xs + c];
             }
-            a.gx[rr * a.gxs + c] = g;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (r0 + u * RS < hi) {
+                    const float xh = (xv[u] - mu) * is;
+                    a.gx[(r0 + u * RS) * a.gxs + c] = a.training ? k0 * (dy[u] - (s0 + xh * s1)) : k0 * dy[u];
+                }
+            }
         }
     }
 }
