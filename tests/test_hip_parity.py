@@ -334,7 +334,7 @@ def test_readout_module_paths():
     ref = _torch_readout(h, lin1.weight, lin1.bias, lin2.weight, lin2.bias, None, batch, 4)
     out = R.readout(h, lin1, lin2, drop, batch, 4)
     assert torch.allclose(out, ref, atol=1e-5, rtol=1e-5)
-    assert float(out[2].abs().max()) == 0.0
+    assert float(out[2].detach().abs().max()) == 0.0
     perm = torch.randperm(32, device=dev)
     out_p = R.readout(h[perm], lin1, lin2, drop, batch[perm].contiguous(), 4)
     assert torch.allclose(out_p, ref, atol=1e-5, rtol=1e-5)
@@ -416,3 +416,53 @@ def test_backward_under_graph_capture_matches_eager():
     assert len(captured) == len(eager)
     for g, e in zip(captured, eager):
         assert torch.equal(g, e)
+
+
+def test_csr_passes_long_and_empty_segments():
+    """The pipelined CSR kernels fetch four rows per segment in the steady state and loop for longer ones: a hub
+    atom with nine bonds (not in any degree bucket, but a neighbour of nine degree-1 atoms and the target of nine
+    edges), isolated atoms and widths that select every lanes-per-row variant."""
+    from molkgnn_amd import functional as Fn
+    from molkgnn_amd.plan import plan_from_lists
+    from molkgnn_amd.receptive_field import build_receptive_fields
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    # atoms 0..8 leaves of hub 9; 10-11 isolated; 12-13-14 a chain; 15..23 a second star around 24 plus a tail 24-25
+    pairs = [(i, 9) for i in range(9)] + [(12, 13), (13, 14)] + [(i, 24) for i in range(15, 24)] + [(24, 25)]
+    ei = torch.tensor([[a, b] for a, b in pairs for (a, b) in ((a, b), (b, a))]).t().contiguous()
+    n = 26
+    for width in (110, 28, 60, 200, 7):
+        w4 = width + (-width) % 4
+        store = torch.zeros(n, w4)
+        store[:, :width] = torch.randn(n, width, generator=g)
+        v = store.to(dev)[:, :width]
+        empty, emptyf = torch.zeros(0, dtype=torch.long, device=dev), torch.zeros(0, device=dev)
+        plan = plan_from_lists(n, [emptyf] * 4, [emptyf] * 4, [emptyf] * 4, [empty] * 4, [empty] * 4, ei.to(dev))
+        h = Fn.propagate_add(v, plan, out_pad=(-width) % 4)
+        ref = torch.zeros(n, width).index_add_(0, ei[1], store[:, :width][ei[0]])
+        assert torch.allclose(h.cpu(), ref, atol=1e-5), width
+        assert float(h[10].abs().max()) == 0.0 and float(h[11].abs().max()) == 0.0
+        inv = Fn._handed_inv_norm(h)
+        assert torch.allclose(inv.cpu(), 1.0 / ref.norm(dim=1).clamp_min(1e-8), rtol=1e-5), width
+    # backward gather: the hubs are neighbours in nine (degree-1 focal) roles each -> scatter segments of length 9
+    x = torch.randn(n, 28, generator=g)
+    p = torch.randn(n, 3, generator=g)
+    ea = torch.rand(ei.shape[1], 7, generator=g)
+    ea[1::2] = ea[0::2]
+    from molkgnn_amd.receptive_field import GraphBatch
+    fields = build_receptive_fields(x, p, ei, ea)
+    b = GraphBatch(x=x, p=p, edge_index=ei, edge_attr=ea, batch=torch.zeros(n, dtype=torch.long), **fields).to(dev)
+    from molkgnn_amd.kernels import KernelSetConv
+    from molkgnn_amd.plan import plan_from_data
+    torch.manual_seed(3)
+    layer = KernelSetConv(4, 3, 2, 2, D=3, node_attr_dim=28, edge_attr_dim=7).to(dev)
+    plan = plan_from_data(b)
+    grads = {}
+    for variant in VARIANTS:
+        layer.variant = variant
+        xg = b.x.clone().requires_grad_(True)
+        out = layer._run(xg, plan, False)
+        (out * torch.arange(out.numel(), device=dev).reshape(out.shape).float().cos()).sum().backward()
+        grads[variant] = xg.grad.clone()
+    assert torch.allclose(grads["generic"], grads["mfma"], atol=2e-5, rtol=1e-4)
+    assert float(grads["mfma"][9].abs().max()) > 0.0          # the hub received its nine contributions
