@@ -203,6 +203,21 @@ int mkgnn_batchnorm_backward(const float* grad_out, int64_t grad_out_stride, con
                              float* grad_x, int64_t grad_x_stride, float* grad_weight, float* grad_bias,
                              void* workspace, size_t workspace_bytes, void* stream);
 
+/* Tail of the training step for a single task (reference model.py:147-148, 190-198 with data.py:37):
+ *     pred = graph_embedding @ ffn.weight[0] + ffn.bias;   loss = mean(BCEWithLogits(pred, target))
+ * forward writes pred [n_rows] and loss [1]; backward takes d loss (one float on the device) and fully overwrites
+ * grad_emb [n_rows, H] (may be NULL), grad_weight [H], grad_bias [1] (may be NULL).  One launch each; sums in a
+ * fixed order.  workspace: mkgnn_bce_head_workspace_bytes bytes whose FIRST 4 BYTES ARE ZERO when a call starts
+ * (a block counter; the kernels leave it zero), not shared by calls that may run concurrently. */
+size_t mkgnn_bce_head_workspace_bytes(int64_t n_rows, int32_t H);
+int mkgnn_bce_head_forward(const float* emb, int64_t emb_stride, int64_t n_rows, int32_t H,
+                           const float* weight, const float* bias, const float* target,
+                           float* pred, float* loss, void* workspace, size_t workspace_bytes, void* stream);
+int mkgnn_bce_head_backward(const float* emb, int64_t emb_stride, int64_t n_rows, int32_t H,
+                            const float* weight, const float* target, const float* pred, const float* grad_loss,
+                            float* grad_emb, int64_t grad_emb_stride, float* grad_weight, float* grad_bias,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

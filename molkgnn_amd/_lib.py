@@ -56,7 +56,8 @@ EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn
            "mkgnn_kernelsetconv_forward", "mkgnn_kernelsetconv_backward", "mkgnn_segment_sum_rows",
            "mkgnn_readout_hidden_stride", "mkgnn_readout_workspace_bytes", "mkgnn_readout_forward",
            "mkgnn_readout_backward", "mkgnn_batchnorm_workspace_bytes", "mkgnn_batchnorm_forward",
-           "mkgnn_batchnorm_backward")
+           "mkgnn_batchnorm_backward", "mkgnn_bce_head_workspace_bytes", "mkgnn_bce_head_forward",
+           "mkgnn_bce_head_backward")
 
 _lib: Optional[C.CDLL] = None
 
@@ -112,6 +113,12 @@ def load() -> C.CDLL:
     lib.mkgnn_batchnorm_forward.argtypes = [P, I64, I64, I32, P, P, P, P, F32, F32, I32, P, I64, P, P, P, C.c_size_t, P]
     lib.mkgnn_batchnorm_backward.restype = C.c_int
     lib.mkgnn_batchnorm_backward.argtypes = [P, I64, P, I64, I64, I32, P, P, P, I32, P, I64, P, P, P, C.c_size_t, P]
+    lib.mkgnn_bce_head_forward.restype = C.c_int
+    lib.mkgnn_bce_head_forward.argtypes = [P, I64, I64, I32, P, P, P, P, P, P, C.c_size_t, P]
+    lib.mkgnn_bce_head_backward.restype = C.c_int
+    lib.mkgnn_bce_head_backward.argtypes = [P, I64, I64, I32, P, P, P, P, P, I64, P, P, P, C.c_size_t, P]
+    lib.mkgnn_bce_head_workspace_bytes.restype = C.c_size_t
+    lib.mkgnn_bce_head_workspace_bytes.argtypes = [I64, I32]
     if lib.mkgnn_abi_version() != ABI_VERSION:
         raise MolKGNNLibraryError(f"ABI version {lib.mkgnn_abi_version()} != {ABI_VERSION}: rebuild the library")
     _lib = lib

@@ -571,6 +571,123 @@ __global__ void __launch_bounds__(256) bn_bwd_final_kernel(BnArgs a, int CL, int
     }
 }
 
+// ------------------------------------------------------------------ single-task head + BCE-with-logits ----
+// The tail of the training step (reference model.py: ffn(graph_embedding) -> BCEWithLogitsLoss, mean reduction),
+// ~20 tiny PyTorch kernels at B = 4096.  One launch per pass: 32 lanes per row, 64 rows per block, per-block
+// partials, and the block that finishes last (device counter, self-resetting) sums them in block order -- every
+// sum has a fixed order, whichever block that is.
+struct HeadArgs {
+    const float* emb; int64_t es; int64_t B; int H;
+    const float* w; const float* b; const float* y;
+    float* pred; float* loss;
+    const float* gloss; float* gemb; int64_t ges; float* gw; float* gb;
+    float* partial; int* counter;
+};
+constexpr int HEAD_ROWS = 64;       // rows per block
+
+__device__ __forceinline__ float half_wave_sum(float v) {   // xor tree over the 32 lanes of a row
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// true in exactly one block: the one whose partials were published last
+__device__ __forceinline__ bool last_block_done(int* counter) {
+    __shared__ int is_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int done = atomicAdd(counter, 1);
+        is_last = done == (int)gridDim.x - 1;
+        if (is_last) *counter = 0;                           // ready for the next launch
+    }
+    __syncthreads();
+    if (is_last) __threadfence();
+    return is_last != 0;
+}
+
+__global__ void __launch_bounds__(256) bce_head_forward_kernel(HeadArgs a) {
+    __shared__ float red[8];
+    const int t = threadIdx.x, h = t & 31, g = t >> 5;          // 8 rows x 32 lanes per pass
+    const float bias = a.b ? a.b[0] : 0.f;
+    float s = 0.f;
+    for (int k = 0; k < HEAD_ROWS / 8; ++k) {
+        const int64_t i = (int64_t)blockIdx.x * HEAD_ROWS + k * 8 + g;
+        const int64_t ic = i < a.B ? i : a.B - 1;
+        float x = 0.f;
+        for (int h0 = 0; h0 < a.H; h0 += 32)
+            if (h0 + h < a.H) x = fmaf(a.emb[ic * a.es + h0 + h], a.w[h0 + h], x);
+        x = half_wave_sum(x) + bias;
+        if (h == 0 && i < a.B) {
+            a.pred[i] = x;
+            s += fmaxf(x, 0.f) - x * a.y[i] + log1pf(expf(-fabsf(x)));   // torch's stable form
+        }
+    }
+    if (h == 0) red[g] = s;
+    __syncthreads();
+    if (t == 0) {
+        float p = 0.f;
+        for (int k = 0; k < 8; ++k) p += red[k];
+        a.partial[blockIdx.x] = p;
+    }
+    if (last_block_done(a.counter) && t == 0) {
+        float tot = 0.f;
+        for (int bk = 0; bk < (int)gridDim.x; ++bk) tot += ((volatile float*)a.partial)[bk];
+        a.loss[0] = tot / (float)a.B;
+    }
+}
+
+__global__ void __launch_bounds__(256) bce_head_backward_kernel(HeadArgs a) {
+    __shared__ float red[8][33];
+    __shared__ float redb[8];
+    const int t = threadIdx.x, h = t & 31, g = t >> 5;
+    const float gl = a.gloss[0] / (float)a.B;
+    const int PW = a.H + 1;                                   // partial row: dW[0..H), db
+    float db = 0.f;
+    for (int h0 = 0; h0 < a.H; h0 += 32) {
+        const int hh = h0 + h;
+        const bool ok = hh < a.H;
+        const float wv = ok ? a.w[hh] : 0.f;
+        float dw = 0.f;
+        for (int k = 0; k < HEAD_ROWS / 8; ++k) {
+            const int64_t i = (int64_t)blockIdx.x * HEAD_ROWS + k * 8 + g;
+            if (i < a.B) {
+                const float x = a.pred[i];
+                const float d = gl * (1.f / (1.f + expf(-x)) - a.y[i]);
+                if (ok) {
+                    dw = fmaf(d, a.emb[i * a.es + hh], dw);
+                    if (a.gemb) a.gemb[i * a.ges + hh] = d * wv;
+                }
+                if (h0 == 0 && h == 0) db += d;
+            }
+        }
+        red[g][h] = dw;
+        __syncthreads();
+        if (g == 0 && ok) {
+            float p = 0.f;
+            for (int k = 0; k < 8; ++k) p += red[k][h];
+            a.partial[(size_t)blockIdx.x * PW + hh] = p;
+        }
+        __syncthreads();
+    }
+    if (h == 0) redb[g] = db;
+    __syncthreads();
+    if (t == 0) {
+        float p = 0.f;
+        for (int k = 0; k < 8; ++k) p += redb[k];
+        a.partial[(size_t)blockIdx.x * PW + a.H] = p;
+    }
+    if (last_block_done(a.counter)) {
+        const volatile float* part = a.partial;
+        for (int c = t; c < PW; c += 256) {
+            float tot = 0.f;
+            for (int bk = 0; bk < (int)gridDim.x; ++bk) tot += part[(size_t)bk * PW + c];
+            if (c < a.H) a.gw[c] = tot;
+            else if (a.gb) a.gb[0] = tot;
+        }
+    }
+}
+
 }  // namespace mkgnn
 
 using namespace mkgnn;
@@ -774,6 +891,48 @@ int mkgnn_batchnorm_backward(const float* grad_out, int64_t grad_out_stride, con
     bn_bwd_final_kernel<<<grad_x ? BN_BLOCKS : 1, 256, 0, st>>>(a, CL, BN_BLOCKS);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : api_hip_fail("mkgnn_batchnorm_backward", e);
+}
+
+size_t mkgnn_bce_head_workspace_bytes(int64_t n_rows, int32_t H) {
+    if (n_rows < 1 || H < 1) return 0;
+    return 16 + (size_t)((n_rows + HEAD_ROWS - 1) / HEAD_ROWS) * (H + 1) * 4;
+}
+
+static int head_ws(const char* who, int64_t n_rows, int32_t H, void* ws, size_t ws_bytes, HeadArgs& a) {
+    if (!ws || ws_bytes < mkgnn_bce_head_workspace_bytes(n_rows, H) || ((uintptr_t)ws & 3))
+        return api_fail("%s: workspace too small or misaligned", who);
+    a.counter = (int*)ws;                   // first word: block counter, zero between launches
+    a.partial = (float*)((char*)ws + 16);
+    return 0;
+}
+
+int mkgnn_bce_head_forward(const float* emb, int64_t emb_stride, int64_t n_rows, int32_t H, const float* weight,
+                           const float* bias, const float* target, float* pred, float* loss, void* ws, size_t ws_bytes,
+                           void* stream) {
+    if (n_rows < 1 || H < 1 || emb_stride < H) return api_fail("mkgnn_bce_head_forward: bad shape");
+    if (!emb || !weight || !target || !pred || !loss) return api_fail("mkgnn_bce_head_forward: null pointer");
+    HeadArgs a{};
+    if (int rc = head_ws("mkgnn_bce_head_forward", n_rows, H, ws, ws_bytes, a)) return rc;
+    a.emb = emb; a.es = emb_stride; a.B = n_rows; a.H = H; a.w = weight; a.b = bias; a.y = target; a.pred = pred; a.loss = loss;
+    bce_head_forward_kernel<<<(int)((n_rows + HEAD_ROWS - 1) / HEAD_ROWS), 256, 0, (hipStream_t)stream>>>(a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : api_hip_fail("mkgnn_bce_head_forward", e);
+}
+
+int mkgnn_bce_head_backward(const float* emb, int64_t emb_stride, int64_t n_rows, int32_t H, const float* weight,
+                            const float* target, const float* pred, const float* grad_loss, float* grad_emb,
+                            int64_t grad_emb_stride, float* grad_weight, float* grad_bias, void* ws, size_t ws_bytes,
+                            void* stream) {
+    if (n_rows < 1 || H < 1 || emb_stride < H) return api_fail("mkgnn_bce_head_backward: bad shape");
+    if (!emb || !weight || !target || !pred || !grad_loss || !grad_weight) return api_fail("mkgnn_bce_head_backward: null pointer");
+    if (grad_emb && grad_emb_stride < H) return api_fail("mkgnn_bce_head_backward: bad grad_emb stride");
+    HeadArgs a{};
+    if (int rc = head_ws("mkgnn_bce_head_backward", n_rows, H, ws, ws_bytes, a)) return rc;
+    a.emb = emb; a.es = emb_stride; a.B = n_rows; a.H = H; a.w = weight; a.y = target; a.pred = (float*)pred;
+    a.gloss = grad_loss; a.gemb = grad_emb; a.ges = grad_emb_stride; a.gw = grad_weight; a.gb = grad_bias;
+    bce_head_backward_kernel<<<(int)((n_rows + HEAD_ROWS - 1) / HEAD_ROWS), 256, 0, (hipStream_t)stream>>>(a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : api_hip_fail("mkgnn_bce_head_backward", e);
 }
 
 }  // extern "C"

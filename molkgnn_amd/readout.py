@@ -211,3 +211,67 @@ def batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm1d) -> torch.Tensor:
     if use_batch_stats and bn.training and x.shape[0] == 1:
         raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
     return _BatchNormFn.apply(x, bn.weight, bn.bias, bn, use_batch_stats)
+
+
+# ------------------------------------------------------------------------------- single-task head + loss --
+_HEAD_WS: dict = {}
+
+
+def _head_workspace(dev, nbytes: int) -> torch.Tensor:
+    """Per-device scratch whose first word is the kernels' block counter: zeroed once here, left zero by every launch.
+    Calls on one device are ordered on the autograd / capture stream, so one buffer per device is enough."""
+    ws = _HEAD_WS.get(str(dev))
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.zeros(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
+        _HEAD_WS[str(dev)] = ws
+    return ws
+
+
+class _BceHeadFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, emb, weight, bias, target):
+        lib = _lib.load()
+        emb = _row_major(emb if emb.dtype == torch.float32 else emb.float())
+        B, H = emb.shape
+        dev = emb.device
+        w = weight.reshape(-1).contiguous()
+        y = target.reshape(-1).float().contiguous()
+        pred = torch.empty(B, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            nbytes = int(lib.mkgnn_bce_head_workspace_bytes(B, H))
+            ws = _head_workspace(dev, nbytes)
+            _lib.check(lib.mkgnn_bce_head_forward(emb.data_ptr(), _stride0(emb), B, H, w.data_ptr(), _lib.ptr(bias),
+                                                  y.data_ptr(), pred.data_ptr(), loss.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                  _lib.stream_ptr(dev)), "mkgnn_bce_head_forward")
+        ctx.save_for_backward(emb, w, y, pred)
+        ctx.wshape = weight.shape
+        ctx.has_bias = bias is not None
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        lib = _lib.load()
+        emb, w, y, pred = ctx.saved_tensors
+        B, H = emb.shape
+        dev = emb.device
+        gl = grad_loss.reshape(1).float().contiguous()
+        gemb = torch.empty((B, H), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        gw = torch.empty(H, dtype=torch.float32, device=dev)
+        gb = torch.empty(1, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        with torch.cuda.device(dev):
+            ws = _head_workspace(dev, int(lib.mkgnn_bce_head_workspace_bytes(B, H)))
+            _lib.check(lib.mkgnn_bce_head_backward(emb.data_ptr(), _stride0(emb), B, H, w.data_ptr(), y.data_ptr(),
+                                                   pred.data_ptr(), gl.data_ptr(), _lib.ptr(gemb), H, gw.data_ptr(),
+                                                   _lib.ptr(gb), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)),
+                       "mkgnn_bce_head_backward")
+        return gemb, gw.reshape(ctx.wshape), gb, None
+
+
+def bce_head_loss(emb: torch.Tensor, ffn: torch.nn.Linear, target: torch.Tensor) -> torch.Tensor:
+    """``BCEWithLogitsLoss()(ffn(emb).view(-1), target.view(-1).float())`` for a one-output ``ffn`` (reference
+    ``model.py:147-148, 190-198``) as one forward and one backward kernel."""
+    _lib.require_gpu_tensor(emb, "graph_embedding")
+    if ffn.out_features != 1 or emb.dim() != 2 or emb.shape[0] == 0 or target.numel() != emb.shape[0]:
+        raise ValueError("bce_head_loss needs a one-output linear layer and one target per row")
+    return _BceHeadFn.apply(emb, ffn.weight, ffn.bias, target)

@@ -466,3 +466,22 @@ def test_csr_passes_long_and_empty_segments():
         grads[variant] = xg.grad.clone()
     assert torch.allclose(grads["generic"], grads["mfma"], atol=2e-5, rtol=1e-4)
     assert float(grads["mfma"][9].abs().max()) > 0.0          # the hub received its nine contributions
+
+
+@pytest.mark.parametrize("B,H", [(4096, 32), (37, 5), (1, 40)])
+def test_bce_head_loss_matches_torch(B, H):
+    """ffn + BCEWithLogitsLoss (reference model.py:147-148, 190-198) against the PyTorch operators."""
+    from molkgnn_amd.readout import bce_head_loss
+    dev = _dev()
+    torch.manual_seed(B + H)
+    ffn = torch.nn.Linear(H, 1).to(dev)
+    emb = (torch.randn(B, H, device=dev) * 2).requires_grad_(True)
+    y = (torch.rand(B, device=dev) < 0.3).long()
+    loss = bce_head_loss(emb, ffn, y)
+    got = torch.autograd.grad(loss * 1.7, [emb, ffn.weight, ffn.bias])
+    ref = torch.nn.BCEWithLogitsLoss()(ffn(emb).view(-1), y.view(-1).float())
+    want = torch.autograd.grad(ref * 1.7, [emb, ffn.weight, ffn.bias])
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-6 * max(1.0, abs(float(ref.detach())))
+    for a, w in zip(got, want):
+        assert a.shape == w.shape
+        assert torch.allclose(a, w, atol=1e-7, rtol=2e-5), float((a - w).abs().max())
