@@ -203,6 +203,22 @@ int mkgnn_batchnorm_backward(const float* grad_out, int64_t grad_out_stride, con
                              float* grad_x, int64_t grad_x_stride, float* grad_weight, float* grad_bias,
                              void* workspace, size_t workspace_bytes, void* stream);
 
+/* Receptive-field builder: the per-degree tensors of a collated batch, reference
+ * wrapper.py:559-672 (ToXAndPAndEdgeAttrForDeg) + PyG collation.  edge_index is [2, M] int64 (row 0 sources, row 1
+ * targets), every bond stored as two consecutive directed edges with identical attributes (wrapper.py:152-156).
+ *   mkgnn_rf_count  computes the out-degrees and writes the four bucket sizes N_1..N_4 to counts (device, int64[4]);
+ *   mkgnn_rf_fill   (same workspace, untouched in between) fills, for d = 1..4, out[d-1]:
+ *       selected_index [N_d] ascending atom ids, nei_index [N_d*d] edge targets in edge-list order,
+ *       nei_edge_attr [N_d*d, E] attributes of bond 2*(e/2), p_focal [N_d, 3], nei_p [N_d*d, 3];
+ *       out[d-1].count = rows allocated (>= N_d).  Atoms of out-degree 0 or > 4 are in no bucket.
+ * Deterministic: integer atomics only choose slots, the <= 4 edge ids of an atom are sorted afterwards. */
+size_t mkgnn_rf_workspace_bytes(int64_t n_atoms);
+int mkgnn_rf_count(const int64_t* edge_index, int64_t n_atoms, int64_t n_edges,
+                   void* workspace, size_t workspace_bytes, int64_t* counts, void* stream);
+int mkgnn_rf_fill(const int64_t* edge_index, const float* p, const float* edge_attr,
+                  int64_t n_atoms, int64_t n_edges, int32_t E, const void* workspace,
+                  const mkgnn_degree_bucket out[MKGNN_MAX_DEGREE], void* stream);
+
 /* Tail of the training step for a single task (reference model.py:147-148, 190-198 with data.py:37):
  *     pred = graph_embedding @ ffn.weight[0] + ffn.bias;   loss = mean(BCEWithLogits(pred, target))
  * forward writes pred [n_rows] and loss [1]; backward takes d loss (one float on the device) and fully overwrites

@@ -57,7 +57,7 @@ EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn
            "mkgnn_readout_hidden_stride", "mkgnn_readout_workspace_bytes", "mkgnn_readout_forward",
            "mkgnn_readout_backward", "mkgnn_batchnorm_workspace_bytes", "mkgnn_batchnorm_forward",
            "mkgnn_batchnorm_backward", "mkgnn_bce_head_workspace_bytes", "mkgnn_bce_head_forward",
-           "mkgnn_bce_head_backward")
+           "mkgnn_bce_head_backward", "mkgnn_rf_workspace_bytes", "mkgnn_rf_count", "mkgnn_rf_fill")
 
 _lib: Optional[C.CDLL] = None
 
@@ -119,6 +119,12 @@ def load() -> C.CDLL:
     lib.mkgnn_bce_head_backward.argtypes = [P, I64, I64, I32, P, P, P, P, P, I64, P, P, P, C.c_size_t, P]
     lib.mkgnn_bce_head_workspace_bytes.restype = C.c_size_t
     lib.mkgnn_bce_head_workspace_bytes.argtypes = [I64, I32]
+    lib.mkgnn_rf_workspace_bytes.restype = C.c_size_t
+    lib.mkgnn_rf_workspace_bytes.argtypes = [I64]
+    lib.mkgnn_rf_count.restype = C.c_int
+    lib.mkgnn_rf_count.argtypes = [P, I64, I64, P, C.c_size_t, P, P]
+    lib.mkgnn_rf_fill.restype = C.c_int
+    lib.mkgnn_rf_fill.argtypes = [P, P, P, I64, I64, I32, P, Buckets4, P]
     if lib.mkgnn_abi_version() != ABI_VERSION:
         raise MolKGNNLibraryError(f"ABI version {lib.mkgnn_abi_version()} != {ABI_VERSION}: rebuild the library")
     _lib = lib

@@ -18,8 +18,11 @@ Building on the batch equals per-molecule build + collate because the edge
 list is block diagonal and PyG offsets every ``*index*`` key by the molecule's
 node offset.
 
-Everything here is torch index arithmetic, so it runs on the CPU or on the
-device the batch lives on; no HIP code is involved.
+``build_receptive_fields`` is torch index arithmetic (sort, bincount, nonzero)
+and runs wherever the batch lives; it is the definition the tests check against
+a per-atom brute force.  ``build_receptive_fields_hip`` builds the same tensors
+with two HIP passes behind the C ABI (``mkgnn_rf_count`` / ``mkgnn_rf_fill``,
+SURVEY.md 8 f-2) and is what ``attach_receptive_fields`` uses for GPU batches.
 """
 from __future__ import annotations
 
@@ -95,8 +98,63 @@ def build_receptive_fields(x: torch.Tensor, p: torch.Tensor,
     return out
 
 
+def build_receptive_fields_hip(x: torch.Tensor, p: torch.Tensor, edge_index: torch.Tensor,
+                               edge_attr: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """Same result as ``build_receptive_fields`` (bit for bit) for a batch on the GPU, through the C ABI."""
+    from . import _lib
+    lib = _lib.load()
+    _lib.require_gpu_tensor(edge_index, "edge_index")
+    dev = edge_index.device
+    n, m = x.shape[0], edge_index.shape[1]
+    ei = edge_index.contiguous().long()
+    pf = p.contiguous().float()
+    ea = edge_attr.contiguous().float()
+    E = ea.shape[1] if ea.dim() == 2 else 1
+    with torch.cuda.device(dev):
+        st = _lib.stream_ptr(dev)
+        ws = torch.empty(int(lib.mkgnn_rf_workspace_bytes(n)), dtype=torch.uint8, device=dev)
+        counts = torch.empty(4, dtype=torch.int64, device=dev)
+        _lib.check(lib.mkgnn_rf_count(_lib.ptr(ei), n, m, ws.data_ptr(), ws.numel(), counts.data_ptr(), st), "mkgnn_rf_count")
+        sizes = counts.tolist()                  # the one host round trip: the outputs have to be allocated
+        out: Dict[str, torch.Tensor] = {}
+        buckets = _lib.Buckets4()
+        raw = {}
+        for d in range(1, MAX_DEGREE + 1):
+            nd = int(sizes[d - 1])
+            if nd == 0:
+                continue
+            sel = torch.empty(nd, dtype=torch.long, device=dev)
+            nei = torch.empty(nd * d, dtype=torch.long, device=dev)
+            nea = torch.empty((nd, d, E), dtype=torch.float32, device=dev)
+            pfo = torch.empty((nd, 3), dtype=torch.float32, device=dev)
+            pne = torch.empty((nd, d, 3), dtype=torch.float32, device=dev)
+            b = buckets[d - 1]
+            b.count = nd
+            b.selected_index, b.nei_index = sel.data_ptr(), nei.data_ptr()
+            b.nei_edge_attr, b.p_focal, b.nei_p = nea.data_ptr(), pfo.data_ptr(), pne.data_ptr()
+            raw[d] = (sel, nei, nea, pfo, pne)
+        _lib.check(lib.mkgnn_rf_fill(_lib.ptr(ei), pf.data_ptr(), _lib.ptr(ea), n, m, E, ws.data_ptr(), buckets, st),
+                   "mkgnn_rf_fill")
+        for d in range(1, MAX_DEGREE + 1):
+            if d not in raw:                     # shapes of the reference's empty fields (wrapper.py:627-630)
+                out[f"p_focal_deg{d}"] = p.new_zeros((0, p.shape[1]))
+                out[f"nei_p_deg{d}"] = p.new_zeros((0,))
+                out[f"nei_edge_attr_deg{d}"] = edge_attr.new_zeros((0,))
+                out[f"selected_index_deg{d}"] = torch.zeros((0,), dtype=torch.long, device=dev)
+                out[f"nei_index_deg{d}"] = torch.zeros((0,), dtype=torch.long, device=dev)
+                continue
+            sel, nei, nea, pfo, pne = raw[d]
+            out[f"p_focal_deg{d}"] = pfo.to(p.dtype)
+            out[f"nei_p_deg{d}"] = pne.to(p.dtype)
+            out[f"nei_edge_attr_deg{d}"] = nea.to(edge_attr.dtype) if ea.dim() == 2 else nea.to(edge_attr.dtype).reshape(sel.numel(), d)
+            out[f"selected_index_deg{d}"] = sel
+            out[f"nei_index_deg{d}"] = nei
+    return out
+
+
 def attach_receptive_fields(batch: GraphBatch) -> GraphBatch:
-    rf = build_receptive_fields(batch.x, batch.p, batch.edge_index, batch.edge_attr)
+    build = build_receptive_fields_hip if (batch.edge_index.is_cuda and batch.p.shape[1] == 3) else build_receptive_fields
+    rf = build(batch.x, batch.p, batch.edge_index, batch.edge_attr)
     for k, v in rf.items():
         setattr(batch, k, v)
     return batch

@@ -522,3 +522,31 @@ def test_large_batch_fast_kernels_match_generic_kernels(width, last):
         assert torch.allclose(res["generic"][1], res["mfma"][1], atol=5e-5, rtol=1e-3)
         for a, c in zip(res["generic"][2], res["mfma"][2]):
             assert torch.allclose(a, c, atol=2e-3, rtol=2e-3), float((a - c).abs().max())
+
+
+def test_receptive_field_builder_hip_matches_torch_builder():
+    """mkgnn_rf_count / mkgnn_rf_fill (reference wrapper.py:559-672) against the torch builder, which the CPU suite
+    checks against a per-atom brute force: exact equality of all 20 tensors, on a synthetic batch, on the same batch
+    with the bonds shuffled (sources no longer contiguous in the edge list), and on a graph with hub atoms
+    (out-degree 9, in no bucket), isolated atoms and an absent degree."""
+    from molkgnn_amd.receptive_field import build_receptive_fields, build_receptive_fields_hip
+    from molkgnn_amd.synthetic import make_batch
+    dev = _dev()
+    b = make_batch(300, seed=4, device=dev, with_receptive_fields=False)
+    cases = [(b.x, b.p, b.edge_index, b.edge_attr)]
+    g = torch.Generator().manual_seed(1)
+    nb = b.edge_index.shape[1] // 2
+    perm = torch.randperm(nb, generator=g).to(dev)
+    eperm = torch.stack([2 * perm, 2 * perm + 1], dim=1).reshape(-1)
+    cases.append((b.x, b.p, b.edge_index[:, eperm].contiguous(), b.edge_attr[eperm].contiguous()))
+    pairs = [(i, 9) for i in range(9)] + [(12, 13), (13, 14)] + [(i, 24) for i in range(15, 24)] + [(24, 25)]
+    ei = torch.tensor([[a, c] for a, c in pairs for (a, c) in ((a, c), (c, a))]).t().contiguous().to(dev)
+    ea = torch.rand(ei.shape[1] // 2, 7, generator=g).repeat_interleave(2, dim=0).to(dev)
+    cases.append((torch.randn(26, 28, device=dev), torch.randn(26, 3, device=dev), ei, ea))
+    for x, p, edge_index, edge_attr in cases:
+        want = build_receptive_fields(x, p, edge_index, edge_attr)
+        got = build_receptive_fields_hip(x, p, edge_index, edge_attr)
+        assert set(want) == set(got)
+        for k in want:
+            assert want[k].shape == got[k].shape and want[k].dtype == got[k].dtype, k
+            assert torch.equal(want[k], got[k]), k
