@@ -153,3 +153,24 @@ def test_molecule_segments_and_readout_refuses_cpu():
         R.readout(torch.zeros(6, 4), lin, lin, None, batch, 5)
     with pytest.raises(MolKGNNLibraryError):
         R.batch_norm(torch.zeros(6, 4), torch.nn.BatchNorm1d(4))
+
+
+def test_evaluation_metrics_match_reference_golden():
+    """evaluation.py:11-127 (logAUC, AUC, PPV, accuracy, F1) against numbers produced by the reference's own
+    functions (tests/golden/make_golden_metrics.py)."""
+    import math
+    import os
+    from molkgnn_amd import evaluation as E
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g8_metrics.npz"))
+    names = sorted({k.split("/")[0] for k in g.files if k.endswith("/y")})
+    assert len(names) == 6
+    for name in names:
+        y, s = torch.from_numpy(g[f"{name}/y"]), torch.from_numpy(g[f"{name}/score"])
+        for key, got in (("logauc", E.calculate_logAUC(y, s)), ("logauc_wide", E.calculate_logAUC(y, s, FPR_range=(0.01, 0.5))),
+                         ("auc", E.calculate_auc(y, s)), ("ppv", E.calculate_ppv(y, s)), ("ppv_cut", E.calculate_ppv(y, s, cutoff=0.8)),
+                         ("accuracy", E.calculate_accuracy(y, s)), ("f1", E.calculate_f1_score(y, s))):
+            want = float(g[f"{name}/{key}"])
+            assert abs(got - want) <= 1e-12 * max(1.0, abs(want)), (name, key, got, want)
+    assert math.isnan(E.calculate_auc(torch.zeros(10), torch.randn(10))) and math.isnan(float(g["oneclass/auc"]))
+    with pytest.raises(Exception):
+        E.calculate_logAUC(torch.tensor([0, 1]), torch.tensor([0.1, 0.9]), FPR_range=(0.1, 0.01))
