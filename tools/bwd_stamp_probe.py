@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Diagnostic: cycle stamps inside the bank-gradient kernel (kc_backward_bank_lds), per degree.
+"""Diagnostic: cycle stamps inside the backward kernels (kc_backward_bank_lds, kc_backward_rows_mfma), per degree.
+Needs a library built with the stamps compiled in: make -C molkgnn_amd/csrc clean && make -C molkgnn_amd/csrc STAMPS=1.
 Per tile the kernel records: staging done, barrier passed, prefetch issued, accumulate loop done, barrier + id store."""
 import ctypes as C
 import os
