@@ -496,7 +496,11 @@ static hipError_t launch_lds_bwd(const BwdArgs& a0, int* nchunk_out, int* ntheta
         const size_t lds_bytes = ((size_t)TA * (D + 1) * (FP + 8) + CW * TA * (size_t)(8 * LI) + 4 * TA * (D + 1)) * 4;
         const int64_t ntiles = (a.n + TA - 1) / TA;
         int64_t blocks = BWD_BANK_BLOCKS;
-        if (blocks > ntiles) blocks = ntiles;
+        // every block ends by writing a full partial slab (115 KB for degree 4): with about one tile per block the
+        // slab traffic costs as much as the tile (stamps: 15 us of work, 41 us of kernel), so a block takes at
+        // least two tiles
+        if (blocks > (ntiles + 1) / 2) blocks = (ntiles + 1) / 2;
+        if (blocks < 1) blocks = 1;
         a.nchunk = (int)blocks;
         a.theta_in_bank = rows_too ? 0 : 1;          // the LDS rows kernel sums the score-weight partials itself
         if (!rows_too) *ntheta_out = (int)blocks;
