@@ -495,7 +495,9 @@ static hipError_t launch_lds_bwd(const BwdArgs& a0, int* nchunk_out, int* ntheta
         constexpr int CW = (D == 1) ? 2 : ((D == 4) ? 8 : 4);
         const size_t lds_bytes = ((size_t)TA * (D + 1) * (FP + 8) + CW * TA * (size_t)(8 * LI) + 4 * TA * (D + 1)) * 4;
         const int64_t ntiles = (a.n + TA - 1) / TA;
-        int64_t blocks = BWD_BANK_BLOCKS;
+        static const char* env_blocks = getenv("MKGNN_BANK_BLOCKS");          // diagnostics
+        int64_t blocks = env_blocks ? atoi(env_blocks) : BWD_BANK_BLOCKS;
+        if (blocks < 1 || blocks > BWD_BANK_BLOCKS) blocks = BWD_BANK_BLOCKS;
         // every block ends by writing a full partial slab (115 KB for degree 4): with about one tile per block the
         // slab traffic costs as much as the tile (stamps: 15 us of work, 41 us of kernel), so a block takes at
         // least two tiles

@@ -630,10 +630,20 @@ __global__ void __launch_bounds__(256) bce_head_forward_kernel(HeadArgs a) {
         for (int k = 0; k < 8; ++k) p += red[k];
         a.partial[blockIdx.x] = p;
     }
-    if (last_block_done(a.counter) && t == 0) {
-        float tot = 0.f;
-        for (int bk = 0; bk < (int)gridDim.x; ++bk) tot += ((volatile float*)a.partial)[bk];
-        a.loss[0] = tot / (float)a.B;
+    if (last_block_done(a.counter)) {
+        // all 256 threads fetch (loads in flight together: a serial loop over the partials by one thread took 24 us),
+        // then a fixed tree
+        __shared__ float fin[256];
+        const volatile float* part = a.partial;
+        float v = 0.f;
+        for (int bk = t; bk < (int)gridDim.x; bk += 256) v += part[bk];
+        fin[t] = v;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (t < w) fin[t] += fin[t + w];
+            __syncthreads();
+        }
+        if (t == 0) a.loss[0] = fin[0] / (float)a.B;
     }
 }
 
@@ -678,12 +688,30 @@ __global__ void __launch_bounds__(256) bce_head_backward_kernel(HeadArgs a) {
         a.partial[(size_t)blockIdx.x * PW + a.H] = p;
     }
     if (last_block_done(a.counter)) {
+        // column c, four row parts per column, eight loads in flight per thread; parts combined in a fixed order
+        __shared__ float fin[4][64];
         const volatile float* part = a.partial;
-        for (int c = t; c < PW; c += 256) {
+        const int nb = (int)gridDim.x;
+        for (int c0 = 0; c0 < PW; c0 += 64) {
+            const int c = c0 + (t & 63), pr = t >> 6;
             float tot = 0.f;
-            for (int bk = 0; bk < (int)gridDim.x; ++bk) tot += part[(size_t)bk * PW + c];
-            if (c < a.H) a.gw[c] = tot;
-            else if (a.gb) a.gb[0] = tot;
+            if (c < PW) {
+                for (int bk = pr; bk < nb; bk += 32) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(bk + 4 * u < nb ? bk + 4 * u : bk) * PW + c];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) if (bk + 4 * u < nb) tot += v[u];
+                }
+            }
+            fin[pr][t & 63] = tot;
+            __syncthreads();
+            if (pr == 0 && c < PW) {
+                const float r = (fin[0][t] + fin[1][t]) + (fin[2][t] + fin[3][t]);
+                if (c < a.H) a.gw[c] = r;
+                else if (a.gb) a.gb[0] = r;
+            }
+            __syncthreads();
         }
     }
 }
