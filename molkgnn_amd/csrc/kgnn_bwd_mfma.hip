@@ -35,10 +35,15 @@ __device__ unsigned long long* g_rows_stamp_buffer = nullptr;
 #endif
 
 __host__ __device__ constexpr int bwd_lq(int d) { return d == 1 ? 3 : (d == 2 ? 5 : (d == 3 ? 8 : 13)); }   // 4-kernel groups held per lane
-// Waves that share one 16-atom tile, each taking a slice of the feature tiles (the slices are independent:
-// no reduction).  Degree 4 has few atoms and 17 masked products per kernel group -- one wave per tile left
-// three quarters of the SIMDs idle for 24 us; degrees 2 and 3 gain occupancy (smaller accumulators, no spills).
+// Feature slices: a BLOCK works on one slice of the feature tiles (the slices are independent: no reduction), its
+// four waves on four different atom tiles.  Degree 4 has few atoms and 17 masked products per kernel group -- one
+// unsliced wave per tile left three quarters of the SIMDs idle; and a block keeps only its slice of the bank in LDS
+// (48 / 38 / 19 KB instead of 112 / 54 / 27 KB for degree 4 / 3 / 2), which shortens the copy and leaves room for
+// the bank-gradient kernel that runs next to this one inside a captured graph.
 __host__ __device__ constexpr int bwd_fsplit(int d, int kc) { return kc < 4 ? 1 : (d == 1 ? 1 : (d == 4 ? 4 : 2)); }
+// LDS row stride of a slice of fpw floats: odd multiple of 16 floats, so that the four kernel rows a wave reads
+// together (64 lanes x 4 bytes) spread over all 32 banks
+__host__ __device__ constexpr int bwd_slice_stride(int fpw) { return (fpw % 32 == 16) ? fpw : fpw + 16; }
 
 // ------------------------------------------------------------------ rows ---
 // M = 16 atoms, N = 16 features (FT tiles), K = kernels.  A = masked coefficients (registers),
@@ -46,16 +51,18 @@ __host__ __device__ constexpr int bwd_fsplit(int d, int kc) { return kc < 4 ? 1 
 // (The three score-weight partials d sc / d theta_k are summed by the bank kernel, which visits every
 // (atom, kernel) pair with one thread and has registers to spare; here they cost 3 LQ prefetch registers.)
 template <int D, int KC, int NT>
-__global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(BwdArgs a) {
+__global__ void __launch_bounds__(NT, 2) kc_backward_rows_mfma(BwdArgs a) {
     constexpr int FP = 16 * KC;
     constexpr int FT = KC;                           // 16-feature tiles
-    constexpr int FS = bwd_fsplit(D, KC);            // waves per atom tile
-    constexpr int FTW = (FT + FS - 1) / FS;          // feature tiles per wave
+    constexpr int FS = bwd_fsplit(D, KC);            // feature slices (blocks per group of atom tiles)
+    constexpr int FTW = (FT + FS - 1) / FS;          // feature tiles per slice
+    constexpr int FPW = 16 * FTW;                    // floats per bank row held in LDS
+    constexpr int SB = bwd_slice_stride(FPW);        // LDS row stride
     constexpr int LQ = bwd_lq(D);
     constexpr int NWV = NT / 64;
     extern __shared__ __align__(16) float lds[];
     const int L = a.L;
-    float* bank = lds;                               // [(D+1)*L][FP], row b*L + l; rows D*L + l = centres
+    float* bank = lds;                               // [(D+1)*L][SB] (this block's feature slice), row b*L + l; rows D*L + l = centres
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ci = lane & 15, kq = lane >> 4;
     unsigned long long* stamps = g_rows_stamp_buffer
@@ -69,9 +76,9 @@ __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(Bw
     // Coefficient inputs of a tile, software pipelined one tile ahead: the loads of tile t + 1 are issued
     // before the MFMA loop of tile t and its focal ids (the address of the grad_out gather) one tile before
     // that, so the two dependent global round trips per tile overlap the matrix work instead of preceding it.
-    static_assert(NWV % FS == 0, "the feature slice of a wave is fixed");
-    const int ft0 = (wave % FS) * FTW;               // this wave's feature tiles: ft0 .. ft0 + FTW - 1 (< FT)
-    const int64_t tstep = (int64_t)gridDim.x * (NWV / FS);
+    const int slice = blockIdx.x % FS;               // (the host launches a multiple of FS blocks)
+    const int ft0 = slice * FTW;                     // this block's feature tiles: ft0 .. ft0 + FTW - 1 (those < FT exist)
+    const int64_t tstep = (int64_t)(gridDim.x / FS) * NWV;
     float rg[LQ];
     int ridx[LQ], rch[LQ];
     auto focal_of = [&](int64_t tile) -> int64_t {
@@ -92,7 +99,7 @@ __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(Bw
             ch[kk] = chp[(size_t)nc * L + l];
         }
     };
-    int64_t tile = (int64_t)blockIdx.x * (NWV / FS) + wave / FS;
+    int64_t tile = (int64_t)(blockIdx.x / FS) * NWV + wave;
     int64_t focal_next = 0;
     {   // unconditional (clamped past the end): a load inside a conditional block is waited for at its end
         const int64_t t0 = tile < ntiles ? tile : ntiles - 1;
@@ -102,17 +109,27 @@ __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(Bw
     // ---- one-time: the unit kernel rows -> LDS.  Issued AFTER the first tile's coefficient loads, which then
     // complete under the copy (they were an exposed double round trip of 4-10 k cycles per wave, and at batch
     // 4096 a wave has one to three tiles); 16 loads in flight per thread.
-    for (int base = 0; base < (D + 1) * L * FP / 4; base += NT * 16) {
-        f32x4 tmp[16];
+    {
+        constexpr int CPR = FPW / 4;                 // 16-byte chunks per slice row
+        const int nchunks = (D + 1) * L * CPR;
+        for (int base = 0; base < nchunks; base += NT * 16) {
+            f32x4 tmp[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int q = base + tid + NT * k;
-            tmp[k] = *(const f32x4*)(a.padded + 4 * (size_t)(q < (D + 1) * L * FP / 4 ? q : 0));
-        }
+            for (int k = 0; k < 16; ++k) {
+                const int q = base + tid + NT * k;
+                const int qc = q < nchunks ? q : 0;
+                const int row = qc / CPR, c = qc - row * CPR;
+                const int col = ft0 * 16 + 4 * c;    // column in the full padded row; a slice may run past FP
+                tmp[k] = *(const f32x4*)(a.padded + (size_t)row * FP + (col < FP ? col : 0));
+            }
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const int q = base + tid + NT * k;
-            if (q < (D + 1) * L * FP / 4) *(f32x4*)(bank + 4 * (size_t)q) = tmp[k];
+            for (int k = 0; k < 16; ++k) {
+                const int q = base + tid + NT * k;
+                if (q < nchunks) {
+                    const int row = q / CPR, c = q - row * CPR;
+                    *(f32x4*)(bank + (size_t)row * SB + 4 * c) = tmp[k];
+                }
+            }
         }
     }
     __syncthreads();
@@ -148,15 +165,15 @@ __global__ void __launch_bounds__(NT, (D == 4 ? 1 : 2)) kc_backward_rows_mfma(Bw
         for (int kk = 0; kk < LQ; ++kk) {
             if (4 * kk < L) {                        // wave-uniform
                 const int l = 4 * kk + kq < L ? 4 * kk + kq : L - 1;
-                const float* brow = bank + (size_t)l * FP + ci;
+                const float* brow = bank + (size_t)l * SB + ci;
                 // all B values of this kernel group first (their LDS reads travel together), then the MFMAs
-                // (a slice that runs past the last feature tile repeats it; its product is not stored)
+                // (a slice that runs past the last feature tile holds a copy of the row's first columns there; the product is not stored)
                 float bv[D + 1][FTW];
 #pragma unroll
                 for (int b = 0; b <= D; ++b)
 #pragma unroll
                     for (int ft = 0; ft < FTW; ++ft)
-                        bv[b][ft] = brow[(size_t)b * L * FP + 16 * (ft0 + ft < FT ? ft0 + ft : FT - 1)];
+                        bv[b][ft] = brow[(size_t)b * L * SB + 16 * ft];
                 {   // centre rows -> focal slot
                     const float av = c[kk] * ratio_c;
 #pragma unroll
@@ -212,7 +229,6 @@ bool mfma_backward_supported(int d, int F, int E, int L, int64_t xs, const void*
 
 template <int D, int KC>
 static hipError_t launch_mfma_rows(const BwdArgs& a, int* ntheta_out, hipStream_t st) {
-    constexpr int FP = 16 * KC;
     // (eight waves per block were tried for degree 4 -- 112 KB of bank, one block per CU -- to give every wave a single
     // unit: at two waves per SIMD its ~300 registers spill 400 VGPRs)
     constexpr int NT = 256;
@@ -224,15 +240,18 @@ static hipError_t launch_mfma_rows(const BwdArgs& a, int* ntheta_out, hipStream_
         attr_set = true;
     }
     const int64_t ntiles = (a.n + 15) / 16;
-    const size_t lds_bytes = (size_t)(D + 1) * a.L * FP * 4;
+    constexpr int FS = bwd_fsplit(D, KC);
+    constexpr int FTW = (KC + FS - 1) / FS;
+    const size_t lds_bytes = (size_t)(D + 1) * a.L * bwd_slice_stride(16 * FTW) * 4;
     int per_cu = (int)((160 * 1024 - 2048) / (lds_bytes + 256));
     if (per_cu < 1) per_cu = 1;
-    if (per_cu > 2) per_cu = 2;
+    if (per_cu > 2) per_cu = 2;                      // registers: two waves per SIMD
     constexpr int NWV = NT / 64;
-    constexpr int TPB = NWV / bwd_fsplit(D, KC);     // atom tiles per block pass
-    int64_t blocks = 256 * per_cu;
-    const int64_t need = (ntiles + TPB - 1) / TPB;
-    if (blocks > need) blocks = need;
+    int64_t groups = 256 * per_cu / FS;              // groups of FS blocks (one per slice) that walk the atom tiles
+    const int64_t need = (ntiles + NWV - 1) / NWV;
+    if (groups > need) groups = need;
+    if (groups < 1) groups = 1;
+    int64_t blocks = groups * FS;
     if (blocks > THETA_SLAB_BLOCKS) blocks = THETA_SLAB_BLOCKS;
     kc_backward_rows_mfma<D, KC, NT><<<(int)blocks, NT, lds_bytes, st>>>(a);
     (void)ntheta_out;                                // the bank kernel sums the score-weight partials
