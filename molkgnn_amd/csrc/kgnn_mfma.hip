@@ -107,8 +107,14 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
     const int ics = dg.ics;
     const int wpart = wave % ics;
     const int tiles_per_block = NW / ics;
-    const int64_t tstride = (int64_t)count * tiles_per_block;
-    int64_t tile = (int64_t)rank * tiles_per_block + wave / ics;
+    // A wave owns a CONTIGUOUS run of its group's tiles, and the host numbers the blocks of a group so that the
+    // blocks sharing an XCD (block id mod 8) own adjacent runs: the buckets are sorted by atom id, so XCD x works on
+    // roughly the x-th eighth of the atoms in every degree group at once and the rows one group gathers as
+    // neighbours are the rows another group on the same L2 gathers as focal atoms.
+    const int64_t nwaves_g = (int64_t)count * tiles_per_block;
+    const int64_t wave_g = (int64_t)rank * tiles_per_block + wave / ics;
+    int64_t tile = wave_g * ntiles / nwaves_g;
+    const int64_t tile_end = (wave_g + 1) * ntiles / nwaves_g;
     const uint32_t xs = (uint32_t)a.xs;
 
     uint32_t ids[D + 1];                             // this tile: slots 0..D-1 neighbours, slot D focal
@@ -119,7 +125,7 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
         for (int s = 0; s < D; ++s) dst[s] = (uint32_t)dg.nei[n * D + s];
         dst[D] = (uint32_t)dg.sel[n];
     };
-    bool have = tile < ntiles;
+    bool have = tile < tile_end;
     if (have) load_ids(tile, ids);
 
     // ---- one-time: this block's kernel rows -> LDS (chunks swizzled by the row's place in its tile)
@@ -219,8 +225,8 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
 
     for (;;) {
         MKGNN_STAMP(stamp_slot);
-        const int64_t nxt_tile = tile + tstride;
-        const bool have_next = nxt_tile < ntiles;
+        const int64_t nxt_tile = tile + 1;
+        const bool have_next = nxt_tile < tile_end;
         uint32_t ids_n[D + 1];
         load_ids(have_next ? nxt_tile : tile, ids_n);
         // ---- per-tile small values (their loads were issued ahead of the rows)
@@ -587,8 +593,19 @@ static size_t plan_fused(FusedFwdArgs& a, const bool use[4], int KC, int* nblock
             if (lag > best) { best = lag; pick = g; }
         }
         a.blk_group[b] = (uint8_t)pick;
-        a.blk_rank[b] = (uint16_t)given[pick];
         ++given[pick];
+    }
+    // ranks: the blocks of a group that land on the same XCD (block id mod 8, round-robin dispatch) get consecutive
+    // ranks, i.e. adjacent tile runs
+    {
+        int per_xcd[FUSED_MAX_GROUPS][8] = {};
+        for (int b = 0; b < nb; ++b) ++per_xcd[a.blk_group[b]][b & 7];
+        int next[FUSED_MAX_GROUPS][8];
+        for (int g = 0; g < ng; ++g) {
+            int run = 0;
+            for (int x = 0; x < 8; ++x) { next[g][x] = run; run += per_xcd[g][x]; }
+        }
+        for (int b = 0; b < nb; ++b) a.blk_rank[b] = (uint16_t)next[a.blk_group[b]][b & 7]++;
     }
     for (int g = 0; g < ng; ++g) a.grp_count[g] = (uint16_t)count[g];
     *nblocks_out = nb;
