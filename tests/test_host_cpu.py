@@ -174,3 +174,18 @@ def test_evaluation_metrics_match_reference_golden():
     assert math.isnan(E.calculate_auc(torch.zeros(10), torch.randn(10))) and math.isnan(float(g["oneclass/auc"]))
     with pytest.raises(Exception):
         E.calculate_logAUC(torch.tensor([0, 1]), torch.tensor([0.1, 0.9]), FPR_range=(0.1, 0.01))
+
+
+def test_oversampling_sampler_matches_reference_construction():
+    """data.py:136-166: same weights and the same index stream as the reference's per-sample construction."""
+    from torch.utils.data import WeightedRandomSampler
+    from molkgnn_amd.sampling import oversampling_sampler, oversampling_weights
+    g = torch.Generator().manual_seed(3)
+    y = (torch.rand(500, generator=g) < 0.05).long()
+    n_active = int(y.sum()); n_inactive = y.numel() - n_active
+    ref_w = torch.tensor([(1. / n_inactive) if int(v) == 0 else (1. / n_active) for v in y])      # the reference's loop
+    assert torch.equal(oversampling_weights(y), ref_w)
+    gen = torch.Generator(); gen.manual_seed(42)
+    ref = list(WeightedRandomSampler(weights=ref_w, num_samples=len(ref_w), generator=gen))
+    assert list(oversampling_sampler(y, 42)) == ref
+    assert abs(y[torch.tensor(ref)].float().mean().item() - 0.5) < 0.1                              # classes come out balanced
