@@ -189,3 +189,19 @@ def test_oversampling_sampler_matches_reference_construction():
     ref = list(WeightedRandomSampler(weights=ref_w, num_samples=len(ref_w), generator=gen))
     assert list(oversampling_sampler(y, 42)) == ref
     assert abs(y[torch.tensor(ref)].float().mean().item() - 0.5) < 0.1                              # classes come out balanced
+
+
+def test_header_is_plain_c_and_cpp(tmp_path):
+    """The drop-in boundary is a C ABI: include/molkgnn_hip.h must compile as C99 and as C++ with nothing but the
+    standard headers (no HIP, no torch types)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "molkgnn_hip.h"\nint main(void) { return (int)sizeof(mkgnn_kernel_bank) == 0; }\n')
+    inc = os.path.join(root, "include")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)], check=True)
+    if shutil.which("g++") is not None:
+        subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, "-x", "c++", str(src)], check=True)
