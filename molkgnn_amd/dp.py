@@ -70,7 +70,8 @@ class FlatGradAllReduce:
             p.grad = None
         self._filled = []
         have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
-        self.flat.zero_()
+        if len(have) != len(self.params):            # slots of parameters without a gradient on this rank contribute zero
+            self.flat.zero_()
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
