@@ -196,11 +196,13 @@ class _KernelSetConvFn(torch.autograd.Function):
             saved[i].chirality = _lib.ptr(ch)
         grads = _lib.BankGrads4()
         gparams: List[Optional[torch.Tensor]] = []
+        alive = []          # every buffer whose address goes to the library stays referenced until the call is enqueued
         for i in range(4):
             xc, xs, es, ps, ts, tc, te = params[i * PARAMS_PER_DEGREE:(i + 1) * PARAMS_PER_DEGREE]
             gxc, gxs, ges = torch.empty_like(xc), torch.empty_like(xs), torch.empty_like(es)
             gth = torch.zeros(3, dtype=torch.float32, device=dev) if plan.buckets[i].count == 0 else \
                 torch.empty(3, dtype=torch.float32, device=dev)
+            alive += [gxc, gxs, ges, gth]     # (an absent degree's buffers are written too -- with zeros -- and dropped afterwards)
             gr = grads[i]
             gr.x_center, gr.x_support, gr.edge_attr_support = _lib.ptr(gxc), _lib.ptr(gxs), _lib.ptr(ges)
             gr.support_attr_sc_weight = gth.data_ptr()
@@ -229,6 +231,7 @@ class _KernelSetConvFn(torch.autograd.Function):
                 g.data_ptr(), _stride0(g), saved, rowptr.data_ptr(), rows.data_ptr(),
                 _lib.ptr(gx), F4, grads, ws.data_ptr(), ws_bytes, int(reuse), _lib.stream_ptr(dev)),
                 "mkgnn_kernelsetconv_backward")
+        del alive           # (freed memory is only handed out again in stream order, after the kernels above)
         return (gx, None, None, None, None, None, None, *gparams)
 
 

@@ -13,6 +13,7 @@ the graph structure, computed once per batch and shared by all layers.
 """
 from __future__ import annotations
 
+import weakref
 from typing import List, Optional
 
 import torch
@@ -114,7 +115,8 @@ _PLAN_CACHE_MAX = 32
 
 def plan_from_lists_cached(n_atoms, p_focal_list, nei_p_list, nei_edge_attr_list, selected_index_list, nei_index_list,
                            edge_index=None) -> BatchPlan:
-    """``plan_from_lists`` memoised on the identity (storage address, length, device) of the index tensors.
+    """``plan_from_lists`` memoised on the identity of the index tensors (address, length, device AND the tensor
+    objects themselves, held weakly).
 
     ``MolGCN.forward`` receives the per-degree tensors as separate keyword arguments (the reference's
     signature, KernelLayer.py:53-87), so the batch object that would carry a cached plan is not
@@ -124,20 +126,28 @@ def plan_from_lists_cached(n_atoms, p_focal_list, nei_p_list, nei_edge_attr_list
     """
     def ident(t):
         return None if t is None else (t.data_ptr(), t.numel(), str(t.device))
+    tensors = [t for t in list(selected_index_list) + list(nei_index_list) + list(nei_edge_attr_list) + [edge_index]
+               if t is not None]
     key = (int(n_atoms), tuple(ident(t) for t in selected_index_list), tuple(ident(t) for t in nei_index_list),
            tuple(ident(t) for t in nei_edge_attr_list), ident(edge_index))
-    plan = _PLAN_CACHE.get(key)
-    if plan is None:
-        plan = plan_from_lists(n_atoms, p_focal_list, nei_p_list, nei_edge_attr_list, selected_index_list,
-                               nei_index_list, edge_index)
-        # build every index structure now: the lazy properties sort (and synchronise), which must not
-        # happen inside a later backward pass or a hipGraph capture
-        _ = plan.scatter
-        if edge_index is not None:
-            _ = plan.csr_in, plan.csr_out
-        if len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
-            _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
-        _PLAN_CACHE[key] = plan
+    hit = _PLAN_CACHE.get(key)
+    if hit is not None:
+        plan, refs = hit
+        # addresses are recycled by the allocator: the entry only counts if these are the very tensor objects it was
+        # built from (a freed tensor's weak reference is dead, a new tensor at the same address is another object)
+        if len(refs) == len(tensors) and all(r() is t for r, t in zip(refs, tensors)):
+            return plan
+        del _PLAN_CACHE[key]
+    plan = plan_from_lists(n_atoms, p_focal_list, nei_p_list, nei_edge_attr_list, selected_index_list,
+                           nei_index_list, edge_index)
+    # build every index structure now: the lazy properties sort (and synchronise), which must not
+    # happen inside a later backward pass or a hipGraph capture
+    _ = plan.scatter
+    if edge_index is not None:
+        _ = plan.csr_in, plan.csr_out
+    if len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
+        _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
+    _PLAN_CACHE[key] = (plan, [weakref.ref(t) for t in tensors])
     return plan
 
 

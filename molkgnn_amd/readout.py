@@ -11,6 +11,7 @@ outside the kernels' limits (hidden width > 64, node width > 128, an unsorted ``
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
@@ -44,12 +45,16 @@ def molecule_segments(batch: torch.Tensor, size: Optional[int]) -> MoleculeSegme
     if size is None:
         size = int(batch.max().item()) + 1 if batch.numel() else 0
     key = (batch.data_ptr(), batch.numel(), str(batch.device), int(size))
-    seg = _SEG_CACHE.get(key)
-    if seg is None:
-        seg = MoleculeSegments(batch, size)
-        if len(_SEG_CACHE) >= _SEG_CACHE_MAX:
-            _SEG_CACHE.pop(next(iter(_SEG_CACHE)))
-        _SEG_CACHE[key] = seg
+    hit = _SEG_CACHE.get(key)
+    if hit is not None:
+        seg, ref = hit
+        if ref() is batch:                       # addresses are recycled: only the very tensor it was built from counts
+            return seg
+        del _SEG_CACHE[key]
+    seg = MoleculeSegments(batch, size)
+    if len(_SEG_CACHE) >= _SEG_CACHE_MAX:
+        _SEG_CACHE.pop(next(iter(_SEG_CACHE)))
+    _SEG_CACHE[key] = (seg, weakref.ref(batch))
     return seg
 
 

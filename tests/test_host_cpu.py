@@ -205,3 +205,23 @@ def test_header_is_plain_c_and_cpp(tmp_path):
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)], check=True)
     if shutil.which("g++") is not None:
         subprocess.run(["g++", "-std=c++11", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, "-x", "c++", str(src)], check=True)
+
+
+def test_plan_cache_is_not_fooled_by_recycled_addresses():
+    """The plan cache is keyed by tensor addresses, which the allocator recycles: an entry must only be returned for
+    the very tensor objects it was built from (other objects at the same address -- here views -- rebuild)."""
+    from molkgnn_amd.plan import plan_from_lists_cached
+    from molkgnn_amd.synthetic import make_batch
+    b = make_batch(6, seed=2)
+    def lists(f):
+        return [[f(getattr(b, f"{nm}_deg{d}")) for d in range(1, 5)]
+                for nm in ("p_focal", "nei_p", "nei_edge_attr", "selected_index", "nei_index")]
+    same = lambda t: t
+    alias = lambda t: t.view_as(t)                   # same address, same length, another tensor object
+    n = b.x.shape[0]
+    p1 = plan_from_lists_cached(n, *lists(same), b.edge_index)
+    assert plan_from_lists_cached(n, *lists(same), b.edge_index) is p1
+    held = lists(alias)
+    p2 = plan_from_lists_cached(n, *held, b.edge_index)
+    assert p2 is not p1
+    assert torch.equal(p2.scatter[0], p1.scatter[0]) and torch.equal(p2.scatter[1], p1.scatter[1])
