@@ -291,8 +291,12 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
     int64_t base = 0;
     BankReduceArgs reduce[4];
     bool bank_on_main = false;                       // some bank gradient was computed on the caller's stream
-    for (int i = 0; i < 4; ++i) {
+    int off_of[4]; int64_t base_of[4];
+    for (int i = 0; i < 4; ++i) { off_of[i] = off; base_of[i] = base; off += L[i]; base += buckets[i].count * (i + 2); }
+    for (int i = 0; i < 4; ++i) {                    // (the launch order of the degrees makes no measurable difference)
         const int d = i + 1;
+        const int off = off_of[i];
+        const int64_t base = base_of[i];
         hipStream_t dst = fj.stream(fj.two_way ? 0 : slot_of[i], &e);
         if (e != hipSuccess) return hip_fail("stream fork", e);
         if (buckets[i].count > 0 && (!saved[i].best_index || !saved[i].scores))
@@ -347,8 +351,6 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         r.icen = (const float*)(ws + w.bank[i].icen); r.isup = (const float*)(ws + w.bank[i].isup);
         r.iedg = (const float*)(ws + w.bank[i].iedg);
         r.g = grads[i];
-        off += L[i];
-        base += a.n * (d + 1);
     }
     // two chains: the reduce follows the bank kernels on the helper, the gather follows the rows kernels here
     const bool split = fj.two_way && !bank_on_main && fj.used[0];
