@@ -74,7 +74,9 @@ __host__ __device__ static inline int fused_lds_floats(int D, int KC, int L, int
     return (D + 1) * srow * 16 * KC + D * srow * 8 + ((D == 4 ? L * 12 : 0) + 15) / 16 * 4 + 4 * 16 * 8;
 }
 
-template <int D, int KC>
+// GEN = false: only the last 16-float chunk of a row can be partial (FP - 16 < F <= FP: the reference's 28 and 110);
+// GEN = true: any F <= FP, every chunk is masked against the row width (a few % more VALU work).
+template <int D, int KC, bool GEN>
 __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedDeg& dg, const int cp, const int rank,
                                              const int count, float* lds) {
     constexpr int FP = 16 * KC;
@@ -202,17 +204,21 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
         }
     };
     auto row_of = [&](uint32_t id) -> const float* { return a.x + (id * xs + 4u * kq); };   // 32-bit offset (host checks N * stride < 2^32)
-    const int f_last = 16 * (KC - 1) + 4 * kq;       // only the last chunk can reach beyond the row's width (FP - 16 < F <= FP)
+    // chunk t of a lane covers columns 16 t + 4 kq .. + 3; a chunk that starts beyond the row's width is fetched
+    // from the row's first columns instead (the load stays unconditional and in bounds) and masked to zero
     auto load_chunk = [&](const float* row, int t) -> f32x4 {
-        // the last chunk is clamped (to the chunk before) so that the load itself is unconditional
-        const int off = (t < KC - 1 || f_last < a.F) ? 16 * t : 16 * t - 4 * kq;
+        const int col = 16 * t + 4 * kq;
+        const bool maybe_out = GEN || t == KC - 1;
+        const int off = (!maybe_out || col < a.F) ? 16 * t : -4 * kq;
         return *(const f32x4*)(row + off);
     };
-    auto mask_last = [&](f32x4 v) -> f32x4 {
-        if (f_last >= a.F) v.x = 0.f;
-        if (f_last + 1 >= a.F) v.y = 0.f;
-        if (f_last + 2 >= a.F) v.z = 0.f;
-        if (f_last + 3 >= a.F) v.w = 0.f;
+    auto mask_chunk = [&](f32x4 v, int t) -> f32x4 {
+        if (!(GEN || t == KC - 1)) return v;
+        const int col = 16 * t + 4 * kq;
+        if (col >= a.F) v.x = 0.f;
+        if (col + 1 >= a.F) v.y = 0.f;
+        if (col + 2 >= a.F) v.z = 0.f;
+        if (col + 3 >= a.F) v.w = 0.f;
         return v;
     };
     issue_small(tile);
@@ -278,7 +284,7 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
             }
 #pragma unroll
             for (int t = 0; t < KC; ++t) {
-                const f32x4 cur = (t == KC - 1) ? mask_last(rb[bcur][t]) : rb[bcur][t];
+                const f32x4 cur = mask_chunk(rb[bcur][t], t);
                 const int c = 4 * t + kq;
 #pragma unroll
                 for (int j = 0; j < NL; ++j) {
@@ -421,7 +427,7 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
     }
 }
 
-template <int KC>
+template <int KC, bool GEN>
 __global__ void __launch_bounds__(256, 2) kc_forward_fused(FusedFwdArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int grp = a.blk_group[blockIdx.x];
@@ -430,10 +436,10 @@ __global__ void __launch_bounds__(256, 2) kc_forward_fused(FusedFwdArgs a) {
     const int cp = a.grp_cp[grp];
     const int count = a.grp_count[grp];
     switch (di) {
-        case 0: forward_body<1, KC>(a, a.deg[0], cp, rank, count, lds); break;
-        case 1: forward_body<2, KC>(a, a.deg[1], cp, rank, count, lds); break;
-        case 2: forward_body<3, KC>(a, a.deg[2], cp, rank, count, lds); break;
-        default: forward_body<4, KC>(a, a.deg[3], cp, rank, count, lds); break;
+        case 0: forward_body<1, KC, GEN>(a, a.deg[0], cp, rank, count, lds); break;
+        case 1: forward_body<2, KC, GEN>(a, a.deg[1], cp, rank, count, lds); break;
+        case 2: forward_body<3, KC, GEN>(a, a.deg[2], cp, rank, count, lds); break;
+        default: forward_body<4, KC, GEN>(a, a.deg[3], cp, rank, count, lds); break;
     }
 }
 
@@ -502,7 +508,7 @@ extern "C" float mkgnn_debug_last_fused_forward_ms(void) {
 bool mfma_forward_supported(int d, int F, int E, int L) {
     if (d < 1 || d > 4 || L < 1 || E > 8) return false;
     const int FP = mfma_padded_width(F);
-    if (!FP || F <= FP - 16) return false;          // only the last 16-float chunk may be partial
+    if (!FP) return false;
     const int nct = (L + 15) / 16;
     const int nl = d >= 3 ? 1 : 2;
     const int need_split = (nct + nl - 1) / nl;
@@ -624,8 +630,9 @@ hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t 
                                                       (int8_t*)a.deg[3].eqflag, (int8_t*)a.deg[3].signflag);
     }
     if (g_time_fused) (void)hipEventRecord(g_ev0, st);
-    if (KC == 2) kc_forward_fused<2><<<nb, 256, lds_bytes, st>>>(a);
-    else kc_forward_fused<7><<<nb, 256, lds_bytes, st>>>(a);
+    const bool gen = a.F <= 16 * (KC - 1);           // more than the last chunk can be partial or empty
+    if (KC == 2) { if (gen) kc_forward_fused<2, true><<<nb, 256, lds_bytes, st>>>(a); else kc_forward_fused<2, false><<<nb, 256, lds_bytes, st>>>(a); }
+    else { if (gen) kc_forward_fused<7, true><<<nb, 256, lds_bytes, st>>>(a); else kc_forward_fused<7, false><<<nb, 256, lds_bytes, st>>>(a); }
     if (g_time_fused) (void)hipEventRecord(g_ev1, st);
     return hipGetLastError();
 }

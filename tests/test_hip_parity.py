@@ -487,7 +487,8 @@ def test_bce_head_loss_matches_torch(B, H):
         assert torch.allclose(a, w, atol=1e-7, rtol=2e-5), float((a - w).abs().max())
 
 
-@pytest.mark.parametrize("width,last", [(28, False), (110, False), (110, True)])
+@pytest.mark.parametrize("width,last", [(28, False), (110, False), (110, True), (55, False), (12, False), (96, True), (40, False),
+                                        (33, False)])
 def test_large_batch_fast_kernels_match_generic_kernels(width, last):
     """Tile boundaries, multi-tile waves, partial last tiles and the two-stream / packed-row code paths only show
     up at scale: on ~13 k atoms the fast path (fused MFMA forward, MFMA rows / LDS bank / pipelined CSR backward)
