@@ -4,6 +4,8 @@ golden vectors.  Needs an MI355X: ``pytest -m gpu``.
 Tolerances: forward 1e-5 absolute (BASELINE.json north_star), tie-aware where
 neighbour rows tie; gradients 2e-5 absolute + 1e-4 relative.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -551,3 +553,48 @@ def test_receptive_field_builder_hip_matches_torch_builder():
         for k in want:
             assert want[k].shape == got[k].shape and want[k].dtype == got[k].dtype, k
             assert torch.equal(want[k], got[k]), k
+
+
+@pytest.mark.parametrize("seed", list(range(int(os.environ.get("MKGNN_FUZZ", "10")))))
+def test_random_shapes_fast_kernels_match_generic_kernels(seed):
+    """Random row widths, bond widths, bank sizes (including one kernel, 17 = two column tiles, 50) and batch sizes,
+    first / last layer: the fast path (forced: an unsupported shape would raise) against the generic kernels."""
+    from molkgnn_amd.kernels import KernelSetConv
+    from molkgnn_amd.plan import plan_from_data
+    from molkgnn_amd.receptive_field import GraphBatch, build_receptive_fields
+    from molkgnn_amd.synthetic import make_batch
+    dev = _dev()
+    rng = np.random.default_rng(1000 + seed)
+    F = int(rng.choice([2, 6, 16, 18, 28, 30, 44, 64, 80, 110, 112]))
+    E = int(rng.integers(1, 9))
+    Ls = [int(rng.choice([1, 3, 10, 16, 17, 20, 30, 50])) for _ in range(4)]
+    nmol = int(rng.choice([1, 3, 20, 90]))
+    last = bool(rng.integers(0, 2))
+    topo = make_batch(nmol, seed=seed, with_receptive_fields=False)
+    g = torch.Generator().manual_seed(seed)
+    n, m = topo.x.shape[0], topo.edge_index.shape[1]
+    x = torch.randn(n, F, generator=g)
+    ea = torch.rand(m // 2, E, generator=g).repeat_interleave(2, dim=0)
+    fields = build_receptive_fields(x, topo.p, topo.edge_index, ea)
+    b = GraphBatch(x=x, p=topo.p, edge_index=topo.edge_index, edge_attr=ea, batch=topo.batch, **fields).to(dev)
+    torch.manual_seed(seed)
+    layer = KernelSetConv(*Ls, D=3, node_attr_dim=F, edge_attr_dim=E).to(dev)
+    plan = plan_from_data(b)
+    cot = torch.randn(n, sum(Ls), generator=g).to(dev)
+    res = {}
+    for variant in VARIANTS:
+        layer.variant = variant
+        for p_ in layer.parameters():
+            p_.grad = None
+        xg = b.x.clone().requires_grad_(True)
+        out = layer._run(xg, plan, last)
+        (out * cot).sum().backward()
+        res[variant] = (out.detach(), xg.grad.clone(), [p_.grad.clone() for p_ in layer.parameters() if p_.grad is not None])
+    og, om = res["generic"][0], res["mfma"][0]
+    assert torch.isfinite(om).all() and torch.isfinite(res["mfma"][1]).all()
+    close = (og - om).abs() <= 1e-5
+    assert float(close.float().mean()) > 0.999, (F, E, Ls, nmol, last, float(close.float().mean()))
+    if bool(close.all()):
+        assert torch.allclose(res["generic"][1], res["mfma"][1], atol=5e-5, rtol=1e-3), (F, E, Ls, nmol, last)
+        for a_, c_ in zip(res["generic"][2], res["mfma"][2]):
+            assert torch.allclose(a_, c_, atol=2e-3, rtol=2e-3), (F, E, Ls, nmol, last, float((a_ - c_).abs().max()))
