@@ -35,7 +35,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-size", type=int, default=4096, help="molecules per step per GPU")
     ap.add_argument("--assay", default="1798")
-    ap.add_argument("--variant", default="auto", choices=["auto", "generic", "mfma"])
+    ap.add_argument("--variant", default="auto", choices=["auto", "generic", "mfma", "bf16"])
     ap.add_argument("--distinct-batches", type=int, default=4, help="distinct resident batches cycled through")
     ap.add_argument("--no-optimizer", action="store_true", help="time forward+backward(+all-reduce) only")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying one hipGraph per resident batch")
@@ -273,7 +273,7 @@ def main():
         gbs = by / (ms * 1e-3) / 1e9
         traffic = None
         try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same workload)
-            if args.batch_size == 4096 and args.variant != "generic":
+            if args.batch_size == 4096 and args.variant in ("auto", "mfma"):
                 traffic = json.load(open(os.path.join(REPO, "profiles", "r01_fused_forward_pmc.json")))["hbm_bytes_per_launch"]
         except Exception:
             traffic = None
@@ -288,7 +288,8 @@ def main():
         out = {"metric": "molecules/sec fwd+bwd, 3-layer MolKGNN on AID 1798", "value": round(value, 1),
                "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "vs_baseline": None, "dtype": "bf16 dot products, f32 otherwise" if args.variant == "bf16" else "f32",
+               "data": "synthetic",
                "config": {"workload": f"AID {args.assay} full set shape ({n_mol_assay} molecules, ~25 atoms / ~53 directed "
                                       f"edges each), 3 layers, hidden_dim 32, kernels 10/20/30/50 per degree, "
                                       f"batch {args.batch_size} molecules per GPU ({atoms:.0f} atoms), "

@@ -102,7 +102,10 @@ size_t mkgnn_workspace_bytes(const int32_t num_kernels[MKGNN_MAX_DEGREE], int32_
  *   out      [N, K] with row stride out_stride, fully overwritten (rows of atoms in no bucket
  *            are zero).  If out_stride holds K rounded up to a multiple of 4, that alignment
  *            padding is zeroed too, so the next layer can read 16-byte rows.
- * variant: 0 = automatic, 1 = generic VALU kernels, 2 = MFMA kernels. */
+ * variant: 0 = automatic, 1 = generic VALU kernels, 2 = MFMA kernels (exact fp32),
+ *          3 = MFMA kernels with bf16 operands for the node-feature dot products (fp32 accumulate; the
+ *              "bf16 similarity path": scores within ~1e-3 of the fp32 ones, the chosen order may differ
+ *              between near-tied permutations).  2 and 3 fail if a degree's shape is not covered. */
 int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
                                 const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],
                                 const float* x, int64_t x_stride, const float* inv_norm,

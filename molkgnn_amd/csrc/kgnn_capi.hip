@@ -187,7 +187,7 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
     WorkspaceLayout w = make_layout(L, F, E, n_atoms, n_edges);
     if (workspace_bytes < w.fwd_end || !workspace)
         return fail("%s: workspace of %zu bytes, need %zu", who, workspace_bytes, w.fwd_end);
-    if (variant < 0 || variant > 2) return fail("%s: variant %d", who, variant);
+    if (variant < 0 || variant > 3) return fail("%s: variant %d", who, variant);
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
     hipError_t e = launch_bank_prepare(banks, w, ws, F, E, st);
@@ -208,6 +208,7 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
     memset(&fa, 0, sizeof(fa));
     fa.x = x; fa.xs = x_stride; fa.inv = inv_norm; fa.out = out; fa.os = out_stride;
     fa.K = K; fa.F = F; fa.E = E; fa.last = is_last_layer ? 1 : 0;
+    fa.bf16 = variant == 3 ? 1 : 0;
     bool use[4] = {false, false, false, false};
     bool any_fused = false;
     int off = 0;
@@ -230,7 +231,7 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
         off += L[i];
         if (a.n == 0 || a.L == 0) continue;
         const bool can_fuse = variant != 1 && aligned && mfma_forward_supported(d, F, E, L[i]);
-        if (variant == 2 && !can_fuse)
+        if (variant >= 2 && !can_fuse)
             return fail("%s: MFMA variant does not cover degree %d with F=%d E=%d L=%d stride=%lld", who, d, F, E, L[i],
                         (long long)x_stride);
         if (can_fuse) {

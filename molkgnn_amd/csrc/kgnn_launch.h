@@ -52,6 +52,7 @@ struct FusedFwdArgs {
     const float* x; int64_t xs; const float* inv;
     float* out; int64_t os;
     int K, F, E, last;
+    int bf16;                                // node-feature dot products with bf16 operands (variant 3)
     FusedDeg deg[MKGNN_MAX_DEGREE];
     uint8_t grp_degree[FUSED_MAX_GROUPS];   // group -> degree index (0..3)
     uint8_t grp_cp[FUSED_MAX_GROUPS];       // group -> column part

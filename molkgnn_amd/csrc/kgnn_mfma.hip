@@ -74,9 +74,24 @@ __host__ __device__ static inline int fused_lds_floats(int D, int KC, int L, int
     return (D + 1) * srow * 16 * KC + D * srow * 8 + ((D == 4 ? L * 12 : 0) + 15) / 16 * 4 + 4 * 16 * 8;
 }
 
+// Four fp32 values -> four bf16 (round to nearest even), the operand of v_mfma_f32_16x16x16_bf16: a lane's four
+// consecutive columns of a chunk are exactly that instruction's k = 4 (lane >> 4) + i.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4 to_bf16x4(f32x4 v) {
+    // (plain conversions: the compiler emits v_cvt_pk_bf16_f32 and knows the VALU -> MFMA operand hazards; the same
+    // instruction in inline asm is opaque to its hazard recogniser and produced NaNs)
+    const bf16x4 r = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    return __builtin_bit_cast(s16x4, r);
+}
+
 // GEN = false: only the last 16-float chunk of a row can be partial (FP - 16 < F <= FP: the reference's 28 and 110);
 // GEN = true: any F <= FP, every chunk is masked against the row width (a few % more VALU work).
-template <int D, int KC, bool GEN>
+// BF = true: the "bf16 similarity path" (BASELINE configs[4]): node-feature dot products with
+// bf16 operands and fp32 accumulation (one 16x16x16 MFMA per chunk instead of four 16x16x4); norms, bond cosines,
+// mixing and everything the backward uses stay fp32.  Scores differ from the fp32 path by ~1e-3 and the chosen
+// permutation may differ where two orders are that close.
+template <int D, int KC, bool GEN, bool BF>
 __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedDeg& dg, const int cp, const int rank,
                                              const int count, float* lds) {
     constexpr int FP = 16 * KC;
@@ -296,16 +311,27 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
                             f32x4 bf[D];
 #pragma unroll
                             for (int b = 0; b < D; ++b) bf[b] = *(const f32x4*)(brow + (size_t)b * SROW * FP + 4 * (c ^ swb));
-#pragma unroll
-                            for (int q4 = 0; q4 < 4; ++q4)
+                            if constexpr (BF) {
+                                const s16x4 a4 = to_bf16x4(cur);
 #pragma unroll
                                 for (int b = 0; b < D; ++b)
-                                    cm[j][si][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[q4], bf[b][q4], cm[j][si][b], 0, 0, 0);
+                                    cm[j][si][b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a4, to_bf16x4(bf[b]), cm[j][si][b], 0, 0, 0);
+                            } else {
+#pragma unroll
+                                for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                                    for (int b = 0; b < D; ++b)
+                                        cm[j][si][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[q4], bf[b][q4], cm[j][si][b], 0, 0, 0);
+                            }
                         } else {
                             const f32x4 bc = *(const f32x4*)(brow + (size_t)D * SROW * FP + 4 * (c ^ swb));
+                            if constexpr (BF) {
+                                cc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(to_bf16x4(cur), to_bf16x4(bc), cc[j], 0, 0, 0);
+                            } else {
 #pragma unroll
-                            for (int q4 = 0; q4 < 4; ++q4)
-                                cc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[q4], bc[q4], cc[j], 0, 0, 0);
+                                for (int q4 = 0; q4 < 4; ++q4)
+                                    cc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[q4], bc[q4], cc[j], 0, 0, 0);
+                            }
                         }
                     }
                 }
@@ -427,7 +453,7 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
     }
 }
 
-template <int KC, bool GEN>
+template <int KC, bool GEN, bool BF>
 __global__ void __launch_bounds__(256, 2) kc_forward_fused(FusedFwdArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int grp = a.blk_group[blockIdx.x];
@@ -436,10 +462,10 @@ __global__ void __launch_bounds__(256, 2) kc_forward_fused(FusedFwdArgs a) {
     const int cp = a.grp_cp[grp];
     const int count = a.grp_count[grp];
     switch (di) {
-        case 0: forward_body<1, KC, GEN>(a, a.deg[0], cp, rank, count, lds); break;
-        case 1: forward_body<2, KC, GEN>(a, a.deg[1], cp, rank, count, lds); break;
-        case 2: forward_body<3, KC, GEN>(a, a.deg[2], cp, rank, count, lds); break;
-        default: forward_body<4, KC, GEN>(a, a.deg[3], cp, rank, count, lds); break;
+        case 0: forward_body<1, KC, GEN, BF>(a, a.deg[0], cp, rank, count, lds); break;
+        case 1: forward_body<2, KC, GEN, BF>(a, a.deg[1], cp, rank, count, lds); break;
+        case 2: forward_body<3, KC, GEN, BF>(a, a.deg[2], cp, rank, count, lds); break;
+        default: forward_body<4, KC, GEN, BF>(a, a.deg[3], cp, rank, count, lds); break;
     }
 }
 
@@ -631,8 +657,13 @@ hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t 
     }
     if (g_time_fused) (void)hipEventRecord(g_ev0, st);
     const bool gen = a.F <= 16 * (KC - 1);           // more than the last chunk can be partial or empty
-    if (KC == 2) { if (gen) kc_forward_fused<2, true><<<nb, 256, lds_bytes, st>>>(a); else kc_forward_fused<2, false><<<nb, 256, lds_bytes, st>>>(a); }
-    else { if (gen) kc_forward_fused<7, true><<<nb, 256, lds_bytes, st>>>(a); else kc_forward_fused<7, false><<<nb, 256, lds_bytes, st>>>(a); }
+    if (a.bf16) {
+        if (KC == 2) { if (gen) kc_forward_fused<2, true, true><<<nb, 256, lds_bytes, st>>>(a); else kc_forward_fused<2, false, true><<<nb, 256, lds_bytes, st>>>(a); }
+        else { if (gen) kc_forward_fused<7, true, true><<<nb, 256, lds_bytes, st>>>(a); else kc_forward_fused<7, false, true><<<nb, 256, lds_bytes, st>>>(a); }
+    } else {
+        if (KC == 2) { if (gen) kc_forward_fused<2, true, false><<<nb, 256, lds_bytes, st>>>(a); else kc_forward_fused<2, false, false><<<nb, 256, lds_bytes, st>>>(a); }
+        else { if (gen) kc_forward_fused<7, true, false><<<nb, 256, lds_bytes, st>>>(a); else kc_forward_fused<7, false, false><<<nb, 256, lds_bytes, st>>>(a); }
+    }
     if (g_time_fused) (void)hipEventRecord(g_ev1, st);
     return hipGetLastError();
 }

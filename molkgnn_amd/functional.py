@@ -15,7 +15,7 @@ from . import _lib
 from .plan import BatchPlan
 
 PARAMS_PER_DEGREE = 7   # x_center, x_support, edge_attr_support, p_support, support/center/edge score weights
-VARIANTS = {"auto": 0, "generic": 1, "mfma": 2}
+VARIANTS = {"auto": 0, "generic": 1, "mfma": 2, "bf16": 3}
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:

@@ -598,3 +598,46 @@ def test_random_shapes_fast_kernels_match_generic_kernels(seed):
         assert torch.allclose(res["generic"][1], res["mfma"][1], atol=5e-5, rtol=1e-3), (F, E, Ls, nmol, last)
         for a_, c_ in zip(res["generic"][2], res["mfma"][2]):
             assert torch.allclose(a_, c_, atol=2e-3, rtol=2e-3), (F, E, Ls, nmol, last, float((a_ - c_).abs().max()))
+
+
+@pytest.mark.parametrize("width,last", [(28, False), (110, False), (110, True), (55, False)])
+def test_bf16_similarity_variant_tracks_fp32(width, last):
+    """variant="bf16" (BASELINE configs[4], SURVEY 8c config 5: bf16 similarity path, fp32 accumulate, parity relaxed to
+    bf16 tolerance, argmax may legitimately differ).  Where both paths choose the same neighbour order the scores agree
+    to 1e-2 (3e-3 on average); a different order is chosen for few (atom, kernel) pairs -- near-ties -- and there the
+    support score still agrees (it is a maximum over orders), only the bond score follows the other order.  The
+    backward (fp32, through the saved order) runs and is finite."""
+    from molkgnn_amd import functional as Fn
+    from molkgnn_amd.kernels import KernelSetConv
+    from molkgnn_amd.plan import plan_from_data
+    from molkgnn_amd.synthetic import make_batch
+    dev = _dev()
+    torch.manual_seed(width)
+    b = make_batch(200, seed=3 + width, device=dev)
+    plan = plan_from_data(b)
+    layer = KernelSetConv(10, 20, 30, 50, D=3, node_attr_dim=width, edge_attr_dim=7).to(dev)
+    n = b.x.shape[0]
+    store = torch.zeros(n, width + (-width) % 4, device=dev)
+    store[:, :width] = torch.randn(n, width, device=dev)
+    params, E = layer._bank_params("train", store[:, :width])
+    det = {v: Fn.kernelsetconv_details(store[:, :width], plan, last, params, E, v) for v in ("mfma", "bf16")}
+    same_total = pairs_total = 0
+    for d in range(4):
+        bi32, sc32, _ = det["mfma"][1][d]
+        bi16, sc16, _ = det["bf16"][1][d]
+        if bi32 is None:
+            continue
+        same = bi32 == bi16                              # [L_d, N_d]
+        same_total += int(same.sum()); pairs_total += same.numel()
+        assert float((sc32[0] - sc16[0]).abs().max()) <= 1e-2          # support score: a maximum, robust to the choice
+        assert float((sc32[1] - sc16[1]).abs().max()) <= 1e-2          # centre score: no choice involved
+        assert float((sc32[2] - sc16[2]).abs()[same].max()) <= 1e-6    # bond score: fp32 in both, equal for equal orders
+    assert same_total / pairs_total > 0.97, same_total / pairs_total
+    diff = (det["mfma"][0] - det["bf16"][0]).abs()
+    assert float(diff.mean()) <= 3e-3 and float(diff.max()) > 0.0
+    layer.variant = "bf16"
+    x = store[:, :width].detach().requires_grad_(True)
+    o = layer._run(x, plan, last)
+    o.square().sum().backward()
+    assert torch.isfinite(o).all() and torch.isfinite(x.grad).all()
+    assert all(torch.isfinite(p_.grad).all() for p_ in layer.parameters() if p_.grad is not None)
