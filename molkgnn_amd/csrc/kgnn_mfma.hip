@@ -56,6 +56,14 @@ template <int KC> __device__ __forceinline__ int swz(int pos) {
     }
 }
 
+// The bf16 variant keeps the bank in LDS as bf16 (8-byte chunks, read with ds_read_b64).  Rows are 56 dwords apart
+// for 112 columns (rows 4 apart share banks): XOR-ing bit 1 of the chunk index with bit 2 of the row spreads a
+// half-wave's 64 dwords evenly over the 32 banks; 32-column rows are 16 dwords apart and take the fp32 swizzle.
+template <int KC> __device__ __forceinline__ int swz_h(int pos) {
+    if constexpr (KC == 7) return ((pos >> 2) & 1) * 2;
+    else return (pos >> 1) & 7;
+}
+
 // column tiles one WAVE accumulates at a time (bounds the accumulator registers)
 template <int D> struct BodyTraits {
     static constexpr int NL = (D >= 3) ? 1 : 2;
@@ -166,7 +174,8 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
             if (q < (D + 1) * SROW * CH) {
                 const int row = q / CH, c = q - row * CH;
                 const int r = (row % SROW) % kpt;
-                *(f32x4*)(bank + (size_t)row * FP + 4 * (c ^ swz<KC>(r))) = tmp[k];
+                if constexpr (BF) *(s16x4*)((short*)bank + (size_t)row * FP + 4 * (c ^ swz_h<KC>(r))) = to_bf16x4(tmp[k]);
+                else *(f32x4*)(bank + (size_t)row * FP + 4 * (c ^ swz<KC>(r))) = tmp[k];
             }
         }
     }
@@ -274,7 +283,7 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
         f32x4 cm[NL][D][D];
         f32x4 cc[NL];
         const int rloc = ci < kpt ? ci : kpt - 1;              // padded lanes re-read the tile's last row
-        const int swb = swz<KC>(rloc);
+        const int swb = BF ? swz_h<KC>(rloc) : swz<KC>(rloc);
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
             cc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -308,15 +317,19 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
                         const float* brow = bank + (size_t)(jl * kpt + rloc) * FP;
                         if (s < D) {
                             const int si = s < D ? s : 0;
-                            f32x4 bf[D];
-#pragma unroll
-                            for (int b = 0; b < D; ++b) bf[b] = *(const f32x4*)(brow + (size_t)b * SROW * FP + 4 * (c ^ swb));
                             if constexpr (BF) {
+                                const short* hrow = (const short*)bank + (size_t)(jl * kpt + rloc) * FP;
+                                s16x4 bh[D];
+#pragma unroll
+                                for (int b = 0; b < D; ++b) bh[b] = *(const s16x4*)(hrow + (size_t)b * SROW * FP + 4 * (c ^ swb));
                                 const s16x4 a4 = to_bf16x4(cur);
 #pragma unroll
                                 for (int b = 0; b < D; ++b)
-                                    cm[j][si][b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a4, to_bf16x4(bf[b]), cm[j][si][b], 0, 0, 0);
+                                    cm[j][si][b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a4, bh[b], cm[j][si][b], 0, 0, 0);
                             } else {
+                            f32x4 bf[D];
+#pragma unroll
+                            for (int b = 0; b < D; ++b) bf[b] = *(const f32x4*)(brow + (size_t)b * SROW * FP + 4 * (c ^ swb));
 #pragma unroll
                                 for (int q4 = 0; q4 < 4; ++q4)
 #pragma unroll
@@ -324,10 +337,12 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
                                         cm[j][si][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[q4], bf[b][q4], cm[j][si][b], 0, 0, 0);
                             }
                         } else {
-                            const f32x4 bc = *(const f32x4*)(brow + (size_t)D * SROW * FP + 4 * (c ^ swb));
                             if constexpr (BF) {
-                                cc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(to_bf16x4(cur), to_bf16x4(bc), cc[j], 0, 0, 0);
+                                const short* hrow = (const short*)bank + (size_t)(jl * kpt + rloc) * FP;
+                                const s16x4 bc = *(const s16x4*)(hrow + (size_t)D * SROW * FP + 4 * (c ^ swb));
+                                cc[j] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(to_bf16x4(cur), bc, cc[j], 0, 0, 0);
                             } else {
+                            const f32x4 bc = *(const f32x4*)(brow + (size_t)D * SROW * FP + 4 * (c ^ swb));
 #pragma unroll
                                 for (int q4 = 0; q4 < 4; ++q4)
                                     cc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[q4], bc[q4], cc[j], 0, 0, 0);
