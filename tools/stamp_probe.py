@@ -19,6 +19,7 @@ from molkgnn_amd.synthetic import make_batch        # noqa: E402
 dev = torch.device("cuda:0")
 lib = _lib.load()
 b = make_batch(int(sys.argv[1]) if len(sys.argv) > 1 else 4096, seed=1798000).to(dev)
+VARIANT = sys.argv[2] if len(sys.argv) > 2 else "mfma"        # "mfma" (fp32) or "bf16"
 plan = plan_from_data(b)
 layer = KernelSetConv(10, 20, 30, 50, D=3, node_attr_dim=110, edge_attr_dim=7).to(dev)
 params, E = layer._bank_params("train", b.x)
@@ -26,10 +27,10 @@ store = torch.zeros(b.x.shape[0], 112, device=dev)
 store[:, :110] = torch.rand(b.x.shape[0], 110, device=dev) * 2 - 1
 x = store[:, :110]
 for _ in range(3):
-    Fn.kernelsetconv_details(x, plan, False, params, E, "mfma")
+    Fn.kernelsetconv_details(x, plan, False, params, E, VARIANT)
 buf = torch.zeros(4096 * 32, dtype=torch.int64, device=dev)
 assert lib.mkgnn_debug_set_stamp_buffer(C.c_void_p(buf.data_ptr())) == 0
-Fn.kernelsetconv_details(x, plan, False, params, E, "mfma")
+Fn.kernelsetconv_details(x, plan, False, params, E, VARIANT)
 torch.cuda.synchronize()
 lib.mkgnn_debug_set_stamp_buffer(C.c_void_p(0))
 st = buf.cpu().numpy().reshape(-1, 32)
