@@ -641,3 +641,55 @@ def test_bf16_similarity_variant_tracks_fp32(width, last):
     o.square().sum().backward()
     assert torch.isfinite(o).all() and torch.isfinite(x.grad).all()
     assert all(torch.isfinite(p_.grad).all() for p_ in layer.parameters() if p_.grad is not None)
+
+
+def test_whole_training_step_under_graph_capture_matches_eager():
+    """The complete step (batch norm, three convolution layers, propagate, readout, head + loss, backward, AdamW) captured
+    into one hipGraph and replayed -- what bench.py measures -- must leave the same parameters as the eager step: every
+    operator is capturable (no host synchronisation, no allocation-dependent state) and deterministic."""
+    import copy
+    from molkgnn_amd.synthetic import make_batch
+    from molkgnn_amd.train import GNNModel, configure_optimizer
+    dev = _dev()
+    torch.manual_seed(5)
+    batch = make_batch(64, seed=8, device=dev)
+    batch.y = (torch.arange(64, device=dev) % 3 == 0).long()
+    eager = GNNModel(num_layers=3, ffn_dropout_rate=0.0).to(dev)
+    graphed = copy.deepcopy(eager)
+    opt_e = configure_optimizer(eager, lr=1e-2, fused=True, capturable=True)
+    opt_g = configure_optimizer(graphed, lr=1e-2, fused=True, capturable=True)
+    with torch.no_grad():
+        eager(batch); graphed(batch)                     # index plans are part of the resident input (built once, outside)
+    # the forwards above ran batch norm in training mode on both models alike
+
+    def step(model, opt):
+        model.zero_grad(set_to_none=True)
+        loss = model.loss(batch)
+        loss.backward()
+        opt.step()
+        return loss
+
+    losses_e = [float(step(eager, opt_e).detach()) for _ in range(4)]    # 2 warm-up-equivalent + 2 replayed-equivalent steps
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            step(graphed, opt_g)
+        graphed.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            static_loss = graphed.loss(batch)
+            static_loss.backward()
+            opt_g.step()
+    torch.cuda.current_stream().wait_stream(side)
+    losses_g = []
+    for _ in range(2):
+        g.replay()
+        losses_g.append(float(static_loss.detach()))
+    torch.cuda.synchronize()
+    # the capture itself does not execute: eager has done 4 steps, graphed 2 eager + 2 replayed
+    assert losses_g == losses_e[2:], (losses_g, losses_e)
+    for (name, pe), (_, pg) in zip(eager.named_parameters(), graphed.named_parameters()):
+        assert torch.equal(pe, pg), name
+    assert torch.equal(eager.gnn_model.node_batch_norm.running_var, graphed.gnn_model.node_batch_norm.running_var)
+    assert int(eager.gnn_model.node_batch_norm.num_batches_tracked) == int(graphed.gnn_model.node_batch_norm.num_batches_tracked)
