@@ -133,8 +133,7 @@ def main():
     model.gnn_model.gnn.set_variant(args.variant)
     model.train()
     opt = None if args.no_optimizer else configure_optimizer(model, lr=1e-3, capturable=not args.no_graph)
-    reducer = dp.FlatGradAllReduce(model.parameters(), dp.NEVER_TRAINED + ("lin1", "lin2"),
-                                   [n for n, _ in model.named_parameters()])
+    reducer = dp.FlatGradAllReduce(model.parameters(), dp.NEVER_TRAINED, [n for n, _ in model.named_parameters()])
 
     # resident batches: rank r owns batches r, r + world, ... of the global stream (weak scaling)
     n_mol_assay = ASSAY_SIZES.get(args.assay, 61832)

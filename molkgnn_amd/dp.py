@@ -45,8 +45,11 @@ class FlatGradAllReduce:
         params = list(params)
         names = list(names) if names is not None else [str(i) for i in range(len(params))]
         skip = tuple(never_trained)
-        self.params: List[torch.nn.Parameter] = [p for p, n in zip(params, names)
-                                                 if p.requires_grad and not any(s in n for s in skip)]
+
+        def skipped(name: str) -> bool:
+            # "^prefix" matches the start of the parameter name, anything else matches anywhere in it
+            return any(name.startswith(s[1:]) if s.startswith("^") else s in name for s in skip)
+        self.params: List[torch.nn.Parameter] = [p for p, n in zip(params, names) if p.requires_grad and not skipped(n)]
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device
         self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -84,5 +87,8 @@ class FlatGradAllReduce:
                 self._filled.append(p)
 
 
-# parameter-name fragments that never receive a gradient in the reference's model
-NEVER_TRAINED = ("p_support", "length_sc_weight", "angle_sc_weight", "edge_batch_norm", "graph_embedding_linear")
+# parameter-name fragments that never receive a gradient in the reference's model; "^" anchors a
+# prefix: GNNModel's own unused heads are lin1 / lin2 (model.py:147-148), while gnn_model.graph_embedding_lin1 / lin2
+# ARE trained and must be reduced
+NEVER_TRAINED = ("p_support", "length_sc_weight", "angle_sc_weight", "edge_batch_norm", "graph_embedding_linear",
+                 "^lin1.", "^lin2.")

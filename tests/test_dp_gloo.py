@@ -22,11 +22,11 @@ def _worker(rank, world, port, out_dir):
     torch.manual_seed(7)                                   # identical replicas
     model = GNNModel(num_layers=2, kernels_1hop=(2, 2, 2, 2), kernels_Nhop=(2, 2, 2, 2), hidden_dim=8, ffn_hidden_dim=8)
     names = [n for n, _ in model.named_parameters()]
-    reducer = dp.FlatGradAllReduce(model.parameters(), dp.NEVER_TRAINED + ("lin1", "lin2"), names)
+    reducer = dp.FlatGradAllReduce(model.parameters(), dp.NEVER_TRAINED, names)
     # the flat buffer covers exactly the parameters that can receive a gradient
     covered = {id(p) for p in reducer.params}
     for n, p in model.named_parameters():
-        never = any(s in n for s in dp.NEVER_TRAINED + ("lin1", "lin2"))
+        never = any(n.startswith(s[1:]) if s.startswith("^") else s in n for s in dp.NEVER_TRAINED)
         assert (id(p) in covered) == (not never), n
     # rank-dependent gradients; rank 1 "has no degree-4 atoms": those gradients stay None there
     g = torch.Generator().manual_seed(100 + rank)
@@ -79,3 +79,19 @@ def test_single_process_is_a_no_op():
     red.reduce()
     assert torch.equal(lin.weight.grad, torch.ones_like(lin.weight)) and lin.bias.grad is None
     assert red.nbytes == 4 * (6 + 2)
+
+
+def test_reducer_covers_the_trained_readout_weights():
+    """gnn_model.graph_embedding_lin1 / lin2 are trained (MolKGNNNet.py:144-146) and must be in the all-reduce; only
+    GNNModel's own lin1 / lin2 (model.py:147-148) are unused.  (A substring match on "lin1" once dropped the former.)"""
+    from molkgnn_amd import dp
+    from molkgnn_amd.train import GNNModel
+    model = GNNModel(num_layers=1, kernels_1hop=(1, 1, 1, 1), kernels_Nhop=(1, 1, 1, 1), hidden_dim=4, ffn_hidden_dim=4)
+    names = [n for n, _ in model.named_parameters()]
+    reducer = dp.FlatGradAllReduce(model.parameters(), dp.NEVER_TRAINED, names)
+    covered = {n for n, p in model.named_parameters() if any(p is q for q in reducer.params)}
+    for n in ("gnn_model.graph_embedding_lin1.weight", "gnn_model.graph_embedding_lin2.bias", "ffn.weight",
+              "gnn_model.node_batch_norm.weight", "gnn_model.gnn.layers.0.trainable_kernelconv_set.1.x_support"):
+        assert n in covered, n
+    for n in ("lin1.weight", "lin2.bias", "gnn_model.graph_embedding_linear.weight", "gnn_model.edge_batch_norm.weight"):
+        assert n in names and n not in covered, n

@@ -693,3 +693,49 @@ def test_whole_training_step_under_graph_capture_matches_eager():
         assert torch.equal(pe, pg), name
     assert torch.equal(eager.gnn_model.node_batch_norm.running_var, graphed.gnn_model.node_batch_norm.running_var)
     assert int(eager.gnn_model.node_batch_norm.num_batches_tracked) == int(graphed.gnn_model.node_batch_norm.num_batches_tracked)
+
+
+def _dp_rank(rank, world, port, out_dir):
+    import os as _os
+    _os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from molkgnn_amd import dp
+    from molkgnn_amd.synthetic import make_batch
+    from molkgnn_amd.train import GNNModel
+    dev = torch.device("cuda:0")                          # both ranks share the one GPU of the test box
+    assert dp.init_process_group_from_env("gloo") == world
+    torch.manual_seed(11)                                 # identical replicas
+    model = GNNModel(num_layers=3, ffn_dropout_rate=0.0).to(dev)
+    names = [n for n, _ in model.named_parameters()]
+    reducer = dp.FlatGradAllReduce(model.parameters(), dp.NEVER_TRAINED, names)
+
+    def grads_of(seed):
+        model.zero_grad(set_to_none=True)
+        b = make_batch(48, seed=seed, device=dev)
+        model.loss(b).backward()
+        return {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    mine = grads_of(300 + rank)
+    reducer.reduce()
+    reduced = {n: p.grad.clone().cpu() for n, p in model.named_parameters() if p.grad is not None}
+    if rank == 0:
+        other = grads_of(301)
+        want = {n: ((mine[n] + other[n]) * 0.5).cpu() for n in mine}
+        torch.save({"reduced": reduced, "want": want}, _os.path.join(out_dir, "dp_gpu.pt"))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_data_parallel_gradients_two_ranks_on_one_gpu(tmp_path):
+    """Two ranks (gloo rendezvous, both on the test box's one GPU) run the HIP backward on different molecules; after the
+    flat all-reduce every rank holds the average of the two gradients."""
+    import socket
+    import torch.multiprocessing as mp
+    _dev()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dp_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    res = torch.load(os.path.join(str(tmp_path), "dp_gpu.pt"))
+    assert len(res["want"]) > 40 and set(res["want"]) == set(res["reduced"])
+    for n, w in res["want"].items():
+        assert torch.allclose(res["reduced"][n], w, atol=1e-7, rtol=1e-6), n
