@@ -300,7 +300,7 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         const int64_t base = base_of[i];
         hipStream_t dst = fj.stream(fj.two_way ? 0 : slot_of[i], &e);
         if (e != hipSuccess) return hip_fail("stream fork", e);
-        if (buckets[i].count > 0 && (!saved[i].best_index || !saved[i].scores))
+        if (buckets[i].count > 0 && L[i] > 0 && (!saved[i].best_index || !saved[i].scores))
             return fail("%s: degree %d has no saved forward state", who, d);
         BwdArgs a;
         a.x = x; a.xs = x_stride; a.inv = inv_norm;
@@ -321,6 +321,12 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         a.theta_slab = (float*)(ws + w.theta_off[i]);
         int nchunk = a.n > 0 ? a.nchunk : 0;
         int ntheta = -1;
+        if (a.n > 0 && L[i] == 0 && grad_x) {
+            // atoms of this degree but no kernels for it in this set (a fixed / trainable split, kernels.py:699-720): the
+            // scatter CSR still points at their contribution rows, which nobody writes -- they contribute zero
+            e = hipMemsetAsync(a.contrib + (size_t)base * a.CS, 0, (size_t)a.n * (d + 1) * a.CS * sizeof(float), dst);
+            if (e != hipSuccess) return hip_fail("contribution rows memset", e);
+        }
         if (a.n > 0 && L[i] > 0) {
             static const bool no_mfma_bwd = getenv("MKGNN_NO_MFMA_BWD") != nullptr;     // diagnostics: A/B against the LDS rows kernel
             if (lds_backward_supported(d, F, E, L[i], x_stride, x)) {

@@ -739,3 +739,48 @@ def test_data_parallel_gradients_two_ranks_on_one_gpu(tmp_path):
     assert len(res["want"]) > 40 and set(res["want"]) == set(res["reduced"])
     for n, w in res["want"].items():
         assert torch.allclose(res["reduced"][n], w, atol=1e-7, rtol=1e-6), n
+
+
+def test_fixed_and_trainable_kernel_sets_compose_like_the_reference():
+    """kernels.py:699-720: inside every degree block the fixed kernels' scores come first, then the trainable ones; a
+    degree may have only one of the two.  Checked against the oracle run on each set separately and composed here."""
+    from molkgnn_amd.kernels import BaseKernelSetConv, KernelConv
+    from molkgnn_amd.plan import plan_from_data
+    from molkgnn_amd.synthetic import make_batch
+    dev = _dev()
+    torch.manual_seed(21)
+    F, E = 28, 7
+    mk = lambda L, d, grad: KernelConv(L=L, D=3, num_supports=d, node_attr_dim=F, edge_attr_dim=E, requires_grad=grad,
+                                       init_support_attr_sc_weight=float(torch.rand(())), init_center_attr_sc_weight=float(torch.rand(())),
+                                       init_edge_attr_support_sc_weight=float(torch.rand(())))
+    fixed = [mk(3, 1, False), None, mk(2, 3, False), mk(4, 4, False)]         # degree 2: trainable only
+    train = [mk(2, 1, True), mk(5, 2, True), None, mk(1, 4, True)]            # degree 3: fixed only
+    layer = BaseKernelSetConv(*fixed, *train).to(dev)
+    batch = make_batch(40, seed=12)
+    bd = batch.to(dev)
+    x = bd.x.clone().requires_grad_(True)
+    out = layer._run(x, plan_from_data(bd), False)
+    sd = lambda k: {n: p.detach().cpu() for n, p in k.named_parameters()}
+    empty = lambda d: {"x_center": torch.zeros(0, F), "x_support": torch.zeros(0, d, F), "edge_attr_support": torch.zeros(0, d, E),
+                       "p_support": torch.zeros(0, d, 3), "support_attr_sc_weight": torch.tensor(0.2),
+                       "center_attr_sc_weight": torch.tensor(0.2), "edge_attr_support_sc_weight": torch.tensor(0.2)}
+    per_f = [sd(k) if k is not None else empty(d + 1) for d, k in enumerate(fixed)]
+    per_t = [sd(k) if k is not None else empty(d + 1) for d, k in enumerate(train)]
+    xo = batch.x.clone().requires_grad_(True)
+    of = O.kernelsetconv(per_f, xo, batch, False)
+    ot = O.kernelsetconv(per_t, xo, batch, False)
+    cols, a, c = [], 0, 0
+    for d in range(4):
+        nf = 0 if fixed[d] is None else fixed[d].num_kernels
+        nt = 0 if train[d] is None else train[d].num_kernels
+        cols += [of[:, a:a + nf], ot[:, c:c + nt]]
+        a += nf; c += nt
+    want = torch.cat(cols, dim=1)
+    assert out.shape == want.shape == (batch.x.shape[0], 17)
+    assert torch.allclose(out.detach().cpu(), want.detach(), atol=FWD_TOL, rtol=0)
+    out.square().sum().backward()
+    assert all(p.grad is None for k in fixed if k is not None for p in k.parameters() if p.dim() > 0)     # fixed banks stay fixed
+    assert all(k.x_support.grad is not None and torch.isfinite(k.x_support.grad).all() for k in train if k is not None)
+    assert torch.isfinite(x.grad).all() and float(x.grad.abs().max()) > 0
+    want.square().sum().backward()
+    assert torch.allclose(x.grad.cpu(), xo.grad, atol=2e-5, rtol=1e-4), float((x.grad.cpu() - xo.grad).abs().max())
