@@ -211,6 +211,23 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
     fa.bf16 = variant == 3 ? 1 : 0;
     bool use[4] = {false, false, false, false};
     bool any_fused = false;
+    // which degrees ride in the fused launch: every covered shape, as long as their (degree, column part) groups fit
+    // the launch's group table -- very wide banks (many 16-kernel column tiles) are demoted to the generic kernels,
+    // largest first
+    bool fuse[4];
+    int groups[4], total_groups = 0;
+    for (int i = 0; i < 4; ++i) {
+        fuse[i] = buckets[i].count > 0 && L[i] > 0 && variant != 1 && aligned && mfma_forward_supported(i + 1, F, E, L[i]);
+        groups[i] = fuse[i] ? fused_group_count(i + 1, F, L[i]) : 0;
+        total_groups += groups[i];
+    }
+    while (total_groups > FUSED_MAX_GROUPS) {
+        int big = 0;
+        for (int i = 1; i < 4; ++i) if (groups[i] > groups[big]) big = i;
+        if (variant >= 2)
+            return fail("%s: the banks need %d column groups, the fused launch holds %d", who, total_groups, FUSED_MAX_GROUPS);
+        total_groups -= groups[big]; groups[big] = 0; fuse[big] = false;
+    }
     int off = 0;
     for (int i = 0; i < 4; ++i) {
         const int d = i + 1;
@@ -230,7 +247,7 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
         a.chir_out = (saved && d == 4 && is_last_layer) ? saved[i].chirality : nullptr;
         off += L[i];
         if (a.n == 0 || a.L == 0) continue;
-        const bool can_fuse = variant != 1 && aligned && mfma_forward_supported(d, F, E, L[i]);
+        const bool can_fuse = fuse[i];
         if (variant >= 2 && !can_fuse)
             return fail("%s: MFMA variant does not cover degree %d with F=%d E=%d L=%d stride=%lld", who, d, F, E, L[i],
                         (long long)x_stride);

@@ -558,6 +558,21 @@ bool mfma_forward_supported(int d, int F, int E, int L) {
     return (size_t)fused_lds_floats(d, FP / 16, L, 1, kpt) * 4 <= 60 * 1024;
 }
 
+// (degree, column part) groups a degree occupies in the fused launch (the same splitting rule as plan_fused)
+int fused_group_count(int d, int F, int L) {
+    const int KC = mfma_padded_width(F) / 16;
+    const int nct = (L + 15) / 16;
+    const int kpt = (L + nct - 1) / nct;
+    const int nl = d >= 3 ? 1 : 2;
+    int cs = (nct + nl - 1) / nl;
+    int nloc = (nct + cs - 1) / cs;
+    while ((size_t)fused_lds_floats(d, KC, L, nloc, kpt) * 4 > 60 * 1024 && cs < nct) {
+        ++cs;
+        nloc = (nct + cs - 1) / cs;
+    }
+    return cs;
+}
+
 // Fill geometry, group sizes and the block table; returns the dynamic LDS bytes (0 = nothing to launch).
 static size_t plan_fused(FusedFwdArgs& a, const bool use[4], int KC, int* nblocks_out) {
     double cost[FUSED_MAX_GROUPS];                   // per 16-atom tile

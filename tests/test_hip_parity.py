@@ -784,3 +784,33 @@ def test_fixed_and_trainable_kernel_sets_compose_like_the_reference():
     assert torch.isfinite(x.grad).all() and float(x.grad.abs().max()) > 0
     want.square().sum().backward()
     assert torch.allclose(x.grad.cpu(), xo.grad, atol=2e-5, rtol=1e-4), float((x.grad.cpu() - xo.grad).abs().max())
+
+
+def test_very_wide_banks_fall_back_without_losing_columns():
+    """100 kernels per degree need 22 (degree, column part) groups, the fused launch holds 16: the automatic variant must
+    demote a degree to the generic kernels rather than drop column parts, and forcing the MFMA variant must say so."""
+    from molkgnn_amd._lib import MolKGNNLibraryError
+    from molkgnn_amd.kernels import KernelSetConv
+    from molkgnn_amd.plan import plan_from_data
+    from molkgnn_amd.synthetic import make_batch
+    dev = _dev()
+    torch.manual_seed(2)
+    b = make_batch(30, seed=44, device=dev)
+    plan = plan_from_data(b)
+    layer = KernelSetConv(100, 100, 100, 100, D=3, node_attr_dim=28, edge_attr_dim=7).to(dev)
+    outs = {}
+    for variant in ("generic", "auto"):
+        layer.variant = variant
+        x = b.x.clone().requires_grad_(True)
+        o = layer._run(x, plan, False)
+        o.square().sum().backward()
+        outs[variant] = (o.detach(), x.grad.clone())
+    assert torch.allclose(outs["generic"][0], outs["auto"][0], atol=FWD_TOL, rtol=0)
+    assert torch.allclose(outs["generic"][1], outs["auto"][1], atol=5e-5, rtol=1e-3)
+    deg = torch.bincount(b.edge_index[0], minlength=b.x.shape[0])
+    for d in range(1, 5):                                    # every degree block carries scores for its atoms
+        blk = outs["auto"][0][deg == d][:, 100 * (d - 1):100 * d]
+        assert blk.numel() == 0 or float(blk.abs().min(dim=1).values.max()) > 0
+    layer.variant = "mfma"
+    with pytest.raises(MolKGNNLibraryError):
+        layer._run(b.x, plan, False)
