@@ -217,7 +217,9 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
     bool fuse[4];
     int groups[4], total_groups = 0;
     for (int i = 0; i < 4; ++i) {
-        fuse[i] = buckets[i].count > 0 && L[i] > 0 && variant != 1 && aligned && mfma_forward_supported(i + 1, F, E, L[i]);
+        // (the fused kernel indexes the saved planes [3, N_d, L] with 32-bit offsets)
+        const bool small = (uint64_t)buckets[i].count * (uint64_t)L[i] * 3ull < (1ull << 32);
+        fuse[i] = buckets[i].count > 0 && L[i] > 0 && variant != 1 && aligned && small && mfma_forward_supported(i + 1, F, E, L[i]);
         groups[i] = fuse[i] ? fused_group_count(i + 1, F, L[i]) : 0;
         total_groups += groups[i];
     }
