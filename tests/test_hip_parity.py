@@ -814,3 +814,35 @@ def test_very_wide_banks_fall_back_without_losing_columns():
     layer.variant = "mfma"
     with pytest.raises(MolKGNNLibraryError):
         layer._run(b.x, plan, False)
+
+
+@pytest.mark.parametrize("F,E,Ls", [(20, 12, (3, 4, 2, 3)), (150, 7, (2, 3, 2, 2)), (27, 3, (4, 4, 4, 4))])
+def test_shapes_outside_the_fast_paths_match_the_oracle(F, E, Ls):
+    """Bond width > 8, row width > 112 or odd: the automatic variant takes the one-wave-per-atom kernels (forward and / or
+    backward) -- forward and the x-gradient against the oracle."""
+    from molkgnn_amd.kernels import KernelSetConv
+    from molkgnn_amd.plan import plan_from_data
+    from molkgnn_amd.receptive_field import GraphBatch, build_receptive_fields
+    from molkgnn_amd.synthetic import make_batch
+    dev = _dev()
+    topo = make_batch(12, seed=F, with_receptive_fields=False)
+    g = torch.Generator().manual_seed(F + E)
+    n, m = topo.x.shape[0], topo.edge_index.shape[1]
+    x = torch.randn(n, F, generator=g)
+    ea = torch.rand(m // 2, E, generator=g).repeat_interleave(2, dim=0)
+    fields = build_receptive_fields(x, topo.p, topo.edge_index, ea)
+    cpu = GraphBatch(x=x, p=topo.p, edge_index=topo.edge_index, edge_attr=ea, batch=topo.batch, **fields)
+    bd = cpu.to(dev)
+    torch.manual_seed(F)
+    layer = KernelSetConv(*Ls, D=3, node_attr_dim=F, edge_attr_dim=E)
+    per_degree = O.kernelset_params({k: v.detach().clone() for k, v in layer.state_dict().items()})
+    layer = layer.to(dev)
+    xg = bd.x.clone().requires_grad_(True)
+    out = layer._run(xg, plan_from_data(bd), False)
+    xo = x.clone().requires_grad_(True)
+    want = O.kernelsetconv(per_degree, xo, cpu, False)
+    assert torch.allclose(out.detach().cpu(), want.detach(), atol=FWD_TOL, rtol=0), float((out.detach().cpu() - want).abs().max())
+    cot = torch.randn(want.shape, generator=g)
+    (out * cot.to(dev)).sum().backward()
+    (want * cot).sum().backward()
+    assert torch.allclose(xg.grad.cpu(), xo.grad, atol=2e-5, rtol=1e-4), float((xg.grad.cpu() - xo.grad).abs().max())
