@@ -376,7 +376,8 @@ def test_batch_norm_matches_torch(C, n, affine):
         assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked)
 
 
-def test_backward_under_graph_capture_matches_eager():
+@pytest.mark.parametrize("banks", [(10, 20, 30, 50), (10, 20, 30, 100), (60, 20, 30, 50)])
+def test_backward_under_graph_capture_matches_eager(banks):
     """Inside a hipGraph capture the backward call runs its x-gradient and bank-gradient chains on two streams
     (kgnn_capi.hip ForkJoin); the replayed graph must reproduce the eager gradients bit for bit."""
     from molkgnn_amd.kernels import KernelSetConv
@@ -387,9 +388,11 @@ def test_backward_under_graph_capture_matches_eager():
     b = make_batch(200, seed=21, device=dev)
     plan = plan_from_data(b)
     _ = plan.scatter
-    layer = KernelSetConv(10, 20, 30, 50, D=3, node_attr_dim=28, edge_attr_dim=7).to(dev)
+    # (a 100- or 60-kernel bank is outside the MFMA / LDS backward kernels: that degree's gradients then come from the
+    # generic kernels on the captured stream while the other degrees use the two-stream split)
+    layer = KernelSetConv(*banks, D=3, node_attr_dim=28, edge_attr_dim=7).to(dev)
     x = b.x.clone().requires_grad_(True)
-    cot = torch.randn(b.x.shape[0], 110, device=dev)
+    cot = torch.randn(b.x.shape[0], sum(banks), device=dev)
 
     def step():
         for p in layer.parameters():
