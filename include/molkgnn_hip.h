@@ -237,6 +237,28 @@ int mkgnn_bce_head_backward(const float* emb, int64_t emb_stride, int64_t n_rows
                             float* grad_emb, int64_t grad_emb_stride, float* grad_weight, float* grad_bias,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* AdamW step over all trainable tensors of the model in one launch (reference model.py:368-385: torch.optim.AdamW,
+ * two parameter groups -- kernel banks without weight decay).  Per tensor: param / grad [numel] fp32 contiguous,
+ * state [2 * numel + 1] = exp_avg, exp_avg_sq, step count (as a float, advanced by this call).  Per group: the
+ * learning rate either by value (lr_device NULL) or read from a device float at run time (so that a captured graph
+ * follows a scheduler), betas, eps, decoupled weight_decay, maximize.  The update is torch's fused AdamW formula
+ * (bias corrections 1 - beta^step).  counter: 4 zero bytes on the device, left zero; not shared by concurrent calls.
+ * At most 4 groups; any number of tensors (96 per launch). */
+typedef struct mkgnn_adamw_tensor {
+    float* param;
+    const float* grad;
+    float* state;
+    int64_t numel;
+    int32_t group;
+} mkgnn_adamw_tensor;
+typedef struct mkgnn_adamw_group {
+    const float* lr_device;
+    float lr, beta1, beta2, eps, weight_decay;
+    int32_t maximize;
+} mkgnn_adamw_group;
+int mkgnn_adamw_step(const mkgnn_adamw_tensor* tensors, int32_t n_tensors, const mkgnn_adamw_group* groups,
+                     int32_t n_groups, int32_t* counter, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -46,6 +46,16 @@ class ReadoutParams(C.Structure):
                 ("lin2_bias", C.c_void_p), ("F", C.c_int32), ("H", C.c_int32), ("G", C.c_int32)]
 
 
+class AdamWTensor(C.Structure):
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("state", C.c_void_p), ("numel", C.c_int64),
+                ("group", C.c_int32)]
+
+
+class AdamWGroup(C.Structure):
+    _fields_ = [("lr_device", C.c_void_p), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
+                ("eps", C.c_float), ("weight_decay", C.c_float), ("maximize", C.c_int32)]
+
+
 Banks4 = KernelBank * MAX_DEGREE
 BankGrads4 = KernelBankGrad * MAX_DEGREE
 Buckets4 = DegreeBucket * MAX_DEGREE
@@ -57,7 +67,7 @@ EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn
            "mkgnn_readout_hidden_stride", "mkgnn_readout_workspace_bytes", "mkgnn_readout_forward",
            "mkgnn_readout_backward", "mkgnn_batchnorm_workspace_bytes", "mkgnn_batchnorm_forward",
            "mkgnn_batchnorm_backward", "mkgnn_bce_head_workspace_bytes", "mkgnn_bce_head_forward",
-           "mkgnn_bce_head_backward", "mkgnn_rf_workspace_bytes", "mkgnn_rf_count", "mkgnn_rf_fill")
+           "mkgnn_bce_head_backward", "mkgnn_rf_workspace_bytes", "mkgnn_rf_count", "mkgnn_rf_fill", "mkgnn_adamw_step")
 
 _lib: Optional[C.CDLL] = None
 
@@ -125,6 +135,8 @@ def load() -> C.CDLL:
     lib.mkgnn_rf_count.argtypes = [P, I64, I64, P, C.c_size_t, P, P]
     lib.mkgnn_rf_fill.restype = C.c_int
     lib.mkgnn_rf_fill.argtypes = [P, P, P, I64, I64, I32, P, Buckets4, P]
+    lib.mkgnn_adamw_step.restype = C.c_int
+    lib.mkgnn_adamw_step.argtypes = [P, I32, P, I32, P, P]
     if lib.mkgnn_abi_version() != ABI_VERSION:
         raise MolKGNNLibraryError(f"ABI version {lib.mkgnn_abi_version()} != {ABI_VERSION}: rebuild the library")
     _lib = lib

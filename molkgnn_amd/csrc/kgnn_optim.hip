@@ -1,0 +1,115 @@
+// AdamW step of the whole model in one launch (gfx950).
+//
+// The reference trains with torch.optim.AdamW over two parameter groups (model.py:368-385: the kernel banks exempt
+// from weight decay).  MolKGNN has ~80 small trainable tensors (132 k floats in all): PyTorch's fused multi-tensor
+// path needs two launches per group plus one per group for the step counters -- five launch-bound kernels, ~40 us
+// of a 1.3 ms training step, for 2 MB of traffic.  Here the tensor table travels in the kernel arguments (pointers
+// are baked into a captured graph exactly like PyTorch's), one block per 1024 elements, and the per-tensor step
+// counters are advanced by whichever block finishes last, after every block has read them.
+//
+// Arithmetic: the update of torch's fused kernel (fused_adam_utils.cuh, ADAMW mode), in the same order:
+//   p -= lr * wd * p;  m += (1 - b1) (g - m);  v = b2 v + (1 - b2) g g;
+//   p -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+#include "kgnn_launch.h"
+#include "../../include/molkgnn_hip.h"
+
+namespace mkgnn {
+
+constexpr int ADAM_MAX_TENSORS = 96;      // per launch: 96 * 32 B of kernel arguments
+constexpr int ADAM_MAX_GROUPS = 4;
+constexpr int ADAM_CHUNK = 1024;          // elements per block
+
+struct AdamTensor { float* p; const float* g; float* state; int32_t n; int32_t group; };
+struct AdamGroup { const float* lr_ptr; float lr, beta1, beta2, eps, wd; int32_t maximize; };
+struct AdamArgs {
+    AdamTensor t[ADAM_MAX_TENSORS];
+    AdamGroup grp[ADAM_MAX_GROUPS];
+    int32_t blk_start[ADAM_MAX_TENSORS + 1];
+    int32_t nt;
+    int* counter;
+};
+
+__global__ void __launch_bounds__(256) adamw_step_kernel(AdamArgs a) {
+    // block -> tensor: the last ti with blk_start[ti] <= blockIdx.x
+    int lo = 0, hi = a.nt - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.blk_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const AdamTensor T = a.t[lo];
+    const AdamGroup G = a.grp[T.group];
+    const float lr = G.lr_ptr ? *G.lr_ptr : G.lr;
+    float* m = T.state;
+    float* v = T.state + T.n;
+    const double t = (double)T.state[2 * (size_t)T.n] + 1.0;
+    const float bc1 = (float)(1.0 - pow((double)G.beta1, t));
+    const float bc2_sqrt = sqrtf((float)(1.0 - pow((double)G.beta2, t)));
+    const float step_size = lr / bc1;
+    const int base = ((int)blockIdx.x - a.blk_start[lo]) * ADAM_CHUNK;
+#pragma unroll
+    for (int k = 0; k < ADAM_CHUNK / 256; ++k) {
+        const int i = base + 256 * k + (int)threadIdx.x;
+        if (i < T.n) {
+            float g = T.g[i];
+            if (G.maximize) g = -g;
+            float p = T.p[i];
+            p -= lr * G.wd * p;
+            float mi = m[i], vi = v[i];
+            mi = fmaf(1.f - G.beta1, g - mi, mi);
+            vi = G.beta2 * vi + (1.f - G.beta2) * g * g;
+            const float denom = sqrtf(vi) / bc2_sqrt + G.eps;
+            p -= step_size * mi / denom;
+            T.p[i] = p; m[i] = mi; v[i] = vi;
+        }
+    }
+    // every block has read its tensor's step counter by the time it gets here; the last one advances them all
+    __shared__ int is_last;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int done = atomicAdd(a.counter, 1);
+        is_last = done == (int)gridDim.x - 1;
+        if (is_last) *a.counter = 0;
+    }
+    __syncthreads();
+    if (is_last)
+        for (int ti = threadIdx.x; ti < a.nt; ti += 256) a.t[ti].state[2 * (size_t)a.t[ti].n] += 1.f;
+}
+
+}  // namespace mkgnn
+
+using namespace mkgnn;
+
+extern "C" int mkgnn_adamw_step(const mkgnn_adamw_tensor* tensors, int32_t n_tensors, const mkgnn_adamw_group* groups,
+                                int32_t n_groups, int32_t* counter, void* stream) {
+    if (n_tensors < 0 || n_groups < 1 || n_groups > ADAM_MAX_GROUPS)
+        return api_fail("mkgnn_adamw_step: %d tensors, %d groups (1..%d groups)", n_tensors, n_groups, ADAM_MAX_GROUPS);
+    if (n_tensors == 0) return 0;
+    if (!tensors || !groups || !counter) return api_fail("mkgnn_adamw_step: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    AdamArgs a{};
+    for (int g = 0; g < n_groups; ++g) {
+        const mkgnn_adamw_group& s = groups[g];
+        if (!(s.beta1 >= 0.f && s.beta1 < 1.f && s.beta2 >= 0.f && s.beta2 < 1.f) || s.eps < 0.f || s.weight_decay < 0.f)
+            return api_fail("mkgnn_adamw_step: group %d has betas (%g, %g), eps %g, weight_decay %g", g, s.beta1, s.beta2, s.eps, s.weight_decay);
+        a.grp[g] = AdamGroup{s.lr_device, s.lr, s.beta1, s.beta2, s.eps, s.weight_decay, s.maximize};
+    }
+    a.counter = counter;
+    for (int32_t first = 0; first < n_tensors; first += ADAM_MAX_TENSORS) {
+        const int nt = n_tensors - first < ADAM_MAX_TENSORS ? n_tensors - first : ADAM_MAX_TENSORS;
+        int blocks = 0;
+        for (int i = 0; i < nt; ++i) {
+            const mkgnn_adamw_tensor& s = tensors[first + i];
+            if (!s.param || !s.grad || !s.state || s.numel < 1 || s.numel > (1 << 30) || s.group < 0 || s.group >= n_groups)
+                return api_fail("mkgnn_adamw_step: tensor %d: null pointer, numel %lld or group %d out of range", first + i, (long long)s.numel, s.group);
+            a.t[i] = AdamTensor{s.param, s.grad, s.state, (int32_t)s.numel, s.group};
+            a.blk_start[i] = blocks;
+            blocks += (int)((s.numel + ADAM_CHUNK - 1) / ADAM_CHUNK);
+        }
+        a.blk_start[nt] = blocks;
+        a.nt = nt;
+        adamw_step_kernel<<<blocks, 256, 0, st>>>(a);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : api_hip_fail("mkgnn_adamw_step", e);
+}

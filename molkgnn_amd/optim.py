@@ -1,0 +1,125 @@
+"""AdamW for the MolKGNN training step, one HIP launch for the whole model (``mkgnn_adamw_step``).
+
+The reference builds ``torch.optim.AdamW`` over two parameter groups (``model.py:368-385``).  This class keeps that
+interface -- ``param_groups`` with ``lr`` / ``betas`` / ``eps`` / ``weight_decay`` / ``maximize``, per-parameter state
+``step`` / ``exp_avg`` / ``exp_avg_sq``, ``state_dict`` round trips, parameters without a gradient skipped -- and the
+same update formula; the ~80 small tensors of the model are updated by one kernel instead of PyTorch's five
+(``csrc/kgnn_optim.hip``).  The step counters live on the device, so a step can be captured in a hipGraph; a
+learning-rate schedule reaches a captured step through ``lr`` given as a 0-dim CUDA tensor that the scheduler fills.
+fp32 CUDA parameters only; no CPU path (``MolKGNNLibraryError`` otherwise).
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+
+from . import _lib
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, maximize: bool = False):
+        if not isinstance(lr, torch.Tensor) and lr < 0.0:
+            raise ValueError(f"Invalid learning rate: {lr}")
+        if not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
+            raise ValueError(f"Invalid betas: {betas}")
+        if eps < 0.0:
+            raise ValueError(f"Invalid epsilon value: {eps}")
+        if weight_decay < 0.0:
+            raise ValueError(f"Invalid weight_decay value: {weight_decay}")
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, maximize=maximize))
+        if len(self.param_groups) > 4:
+            raise ValueError("FusedAdamW takes at most 4 parameter groups")
+        self._counter = None
+        self._table_key = None
+        self._table = None
+
+    # -- state: one buffer per parameter, [exp_avg | exp_avg_sq | step]; the three state entries are views of it --
+    def _packed_state(self, p: torch.Tensor) -> torch.Tensor:
+        st = self.state[p]
+        n = p.numel()
+        buf = st.get("_packed")
+        if buf is not None and st["exp_avg"].data_ptr() == buf.data_ptr() and st["step"].data_ptr() == buf[2 * n:].data_ptr():
+            return buf
+        new = torch.zeros(2 * n + 1, dtype=torch.float32, device=p.device)
+        if "exp_avg" in st:                                  # e.g. loaded from a state_dict (ours or torch.optim.AdamW's)
+            new[:n] = st["exp_avg"].reshape(-1).to(new)
+            new[n:2 * n] = st["exp_avg_sq"].reshape(-1).to(new)
+            new[2 * n] = float(st["step"])
+        st["_packed"] = new
+        st["exp_avg"] = new[:n].view_as(p)
+        st["exp_avg_sq"] = new[n:2 * n].view_as(p)
+        st["step"] = new[2 * n:].view(())
+        self._table_key = None
+        return new
+
+    def state_dict(self):
+        sd = super().state_dict()                            # the packed buffer is an implementation detail: its three views are saved
+        sd["state"] = {k: {kk: vv for kk, vv in v.items() if kk != "_packed"} for k, v in sd["state"].items()}
+        return sd
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        for p in list(self.state):                           # pack now: torch may hand over the caller's tensors uncopied
+            if isinstance(p, torch.Tensor) and "exp_avg" in self.state[p]:
+                self.state[p].pop("_packed", None)
+                self._packed_state(p)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        lib = _lib.load()
+        rows: List[tuple] = []
+        keep = []                                            # tensors the enqueued kernel reads: referenced until the call returns
+        dev = None
+        for gi, group in enumerate(self.param_groups):
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                _lib.require_gpu_tensor(p, "parameter")
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise _lib.MolKGNNLibraryError("FusedAdamW needs contiguous float32 parameters")
+                g = p.grad
+                if g.is_sparse:
+                    raise RuntimeError("FusedAdamW does not support sparse gradients")
+                if g.dtype != torch.float32 or not g.is_contiguous():
+                    g = g.float().contiguous()
+                    keep.append(g)
+                if dev is None:
+                    dev = p.device
+                elif p.device != dev:
+                    raise _lib.MolKGNNLibraryError("FusedAdamW: parameters on more than one device")
+                rows.append((p.data_ptr(), g.data_ptr(), self._packed_state(p).data_ptr(), p.numel(), gi))
+        if not rows:
+            return loss
+        if self._counter is None or self._counter.device != dev:
+            self._counter = torch.zeros(1, dtype=torch.int32, device=dev)
+        key = tuple(rows)
+        if key != self._table_key:                           # pointers are stable from step to step: build the table once
+            table = (_lib.AdamWTensor * len(rows))()
+            for e, r in zip(table, rows):
+                e.param, e.grad, e.state, e.numel, e.group = r
+            self._table, self._table_key = table, key
+        groups = (_lib.AdamWGroup * len(self.param_groups))()
+        for e, group in zip(groups, self.param_groups):
+            lr = group["lr"]
+            if isinstance(lr, torch.Tensor):
+                if lr.is_cuda:
+                    if lr.dtype != torch.float32 or lr.numel() != 1:
+                        raise ValueError("a tensor lr must be one float32 element")
+                    e.lr_device, e.lr = lr.data_ptr(), 0.0
+                else:
+                    e.lr_device, e.lr = None, float(lr)
+            else:
+                e.lr_device, e.lr = None, float(lr)
+            e.beta1, e.beta2 = float(group["betas"][0]), float(group["betas"][1])
+            e.eps, e.weight_decay, e.maximize = float(group["eps"]), float(group["weight_decay"]), int(bool(group["maximize"]))
+        with torch.cuda.device(dev):
+            _lib.check(lib.mkgnn_adamw_step(self._table, len(rows), groups, len(groups), self._counter.data_ptr(),
+                                            _lib.stream_ptr(dev)), "mkgnn_adamw_step")
+        del keep
+        return loss

@@ -74,11 +74,12 @@ def configure_optimizer(model: torch.nn.Module, weight_decay: float = 0.0, lr: f
         else:
             decay.append(p)
     groups = [{'params': nodecay, 'weight_decay': 0}, {'params': decay, 'weight_decay': weight_decay}]
-    kw = {}
     if fused is None:
-        fused = all(p.is_cuda for p in model.parameters())
+        fused = all(p.is_cuda and p.dtype == torch.float32 for p in model.parameters())
     if fused:
-        kw["fused"] = True
+        from .optim import FusedAdamW     # one HIP launch for the whole model; step counters on the device (capturable)
+        return FusedAdamW(groups, lr=lr)
+    kw = {}
     if capturable:
         kw["capturable"] = True          # step counters live on the device: the step can be replayed from a hipGraph
     return torch.optim.AdamW(groups, lr=lr, **kw)

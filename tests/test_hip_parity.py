@@ -849,3 +849,100 @@ def test_shapes_outside_the_fast_paths_match_the_oracle(F, E, Ls):
     (out * cot.to(dev)).sum().backward()
     (want * cot).sum().backward()
     assert torch.allclose(xg.grad.cpu(), xo.grad, atol=2e-5, rtol=1e-4), float((xg.grad.cpu() - xo.grad).abs().max())
+
+
+# ------------------------------------------------------------------------------------------ optimiser --
+def _adamw_models(dev, seed=3):
+    torch.manual_seed(seed)
+    shapes = [(10, 110), (20, 2, 110), (30, 3, 7), (3,), (1,), (32, 110), (32,), (1500, 3), (1, 32)]
+    mine = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    return mine, ref
+
+
+def test_fused_adamw_matches_torch_adamw():
+    """mkgnn_adamw_step against torch.optim.AdamW (single-tensor path): two groups (with / without weight decay, as
+    model.py:368-385 builds them), 12 steps, one parameter without a gradient on some steps (its step counter must
+    lag, as torch's does), a learning rate changed on the way."""
+    from molkgnn_amd.optim import FusedAdamW
+    dev = _dev()
+    mine, ref = _adamw_models(dev)
+    mk = lambda ps, cls, **kw: cls([{"params": ps[:4], "weight_decay": 0.0}, {"params": ps[4:], "weight_decay": 0.05}],   # noqa: E731
+                                   lr=3e-3, betas=(0.9, 0.99), eps=1e-8, **kw)
+    opt_m, opt_r = mk(mine, FusedAdamW), mk(ref, torch.optim.AdamW, foreach=False, fused=False)
+    g = torch.Generator(device=dev).manual_seed(17)
+    for it in range(12):
+        for pm, pr in zip(mine, ref):
+            grad = torch.randn(pm.shape, generator=g, device=dev) * (10.0 ** ((it % 5) - 2))
+            pm.grad, pr.grad = grad.clone(), grad.clone()
+        if it % 3 == 1:
+            mine[2].grad = None; ref[2].grad = None
+        if it == 6:
+            for o in (opt_m, opt_r):
+                for grp in o.param_groups:
+                    grp["lr"] = 1e-3
+        opt_m.step(); opt_r.step()
+    for i, (pm, pr) in enumerate(zip(mine, ref)):
+        torch.testing.assert_close(pm, pr, rtol=2e-5, atol=2e-6, msg=lambda m, i=i: f"param {i}: {m}")
+        sm, sr = opt_m.state[pm], opt_r.state[pr]
+        assert float(sm["step"]) == float(sr["step"]), i
+        # (gradients reach 1e2 and the first moment cancels: absolute tolerance on that scale)
+        torch.testing.assert_close(sm["exp_avg"], sr["exp_avg"], rtol=1e-5, atol=2e-5)
+        torch.testing.assert_close(sm["exp_avg_sq"], sr["exp_avg_sq"], rtol=1e-5, atol=1e-7)
+    assert float(opt_m.state[mine[2]]["step"]) == 8.0
+
+
+def test_fused_adamw_state_dict_round_trip_and_device_lr():
+    """state_dict -> load_state_dict (into a fresh optimiser, and from torch.optim.AdamW's own state) continues the same
+    trajectory; a 0-dim CUDA tensor as lr is read at run time (what a captured step needs for a schedule); maximize."""
+    from molkgnn_amd.optim import FusedAdamW
+    dev = _dev()
+    mine, ref = _adamw_models(dev, seed=4)
+    lr_t = torch.tensor(2e-3, device=dev)
+    opt_m = FusedAdamW(mine, lr=lr_t, weight_decay=0.01, maximize=True)
+    opt_r = torch.optim.AdamW(ref, lr=2e-3, weight_decay=0.01, maximize=True, foreach=False)
+    g = torch.Generator(device=dev).manual_seed(5)
+
+    def both_step(om, orf, pm_list, pr_list):
+        for pm, pr in zip(pm_list, pr_list):
+            grad = torch.randn(pm.shape, generator=g, device=dev)
+            pm.grad, pr.grad = grad.clone(), grad.clone()
+        om.step(); orf.step()
+    for _ in range(3):
+        both_step(opt_m, opt_r, mine, ref)
+    lr_t.fill_(5e-4)                                     # the scheduler's write; no optimiser call involved
+    for grp in opt_r.param_groups:
+        grp["lr"] = 5e-4
+    both_step(opt_m, opt_r, mine, ref)
+    for pm, pr in zip(mine, ref):
+        torch.testing.assert_close(pm, pr, rtol=2e-5, atol=2e-6)
+    sd = opt_m.state_dict()
+    assert all("_packed" not in st for st in sd["state"].values())
+    # (a) our state into a fresh FusedAdamW over copies of the parameters
+    mine2 = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    opt_m2 = FusedAdamW(mine2, lr=5e-4, weight_decay=0.01, maximize=True)
+    opt_m2.load_state_dict(sd)
+    # (b) torch's state into a fresh FusedAdamW
+    mine3 = [torch.nn.Parameter(p.detach().clone()) for p in ref]
+    opt_m3 = FusedAdamW(mine3, lr=5e-4, weight_decay=0.01, maximize=True)
+    opt_m3.load_state_dict(opt_r.state_dict())
+    for _ in range(2):
+        grads = [torch.randn(p.shape, generator=g, device=dev) for p in mine]
+        for plist in (mine, ref, mine2, mine3):
+            for p, gr in zip(plist, grads):
+                p.grad = gr.clone()
+        opt_m.step(); opt_r.step(); opt_m2.step(); opt_m3.step()
+    for pm, pr, p2, p3 in zip(mine, ref, mine2, mine3):
+        torch.testing.assert_close(pm, pr, rtol=2e-5, atol=2e-6)
+        assert torch.equal(pm, p2)
+        torch.testing.assert_close(p3, pr, rtol=2e-5, atol=2e-6)
+    assert float(opt_m3.state[mine3[0]]["step"]) == 6.0
+
+
+def test_fused_adamw_refuses_cpu_parameters():
+    from molkgnn_amd import _lib
+    from molkgnn_amd.optim import FusedAdamW
+    p = torch.nn.Parameter(torch.randn(4))
+    p.grad = torch.randn(4)
+    with pytest.raises(_lib.MolKGNNLibraryError):
+        FusedAdamW([p]).step()
