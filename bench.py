@@ -129,7 +129,7 @@ def main():
     dp.init_process_group_from_env(os.environ.get("MKGNN_DIST_BACKEND", "nccl"))   # nccl = RCCL over xGMI
 
     torch.manual_seed(1798)                       # same initial weights on every rank
-    model = GNNModel().to(dev)
+    model = GNNModel(ffn_dropout_rate=float(os.environ.get("MKGNN_BENCH_FFN_DROPOUT", "0.25"))).to(dev)   # (diagnostics; 0.25 = the reference default)
     model.gnn_model.gnn.set_variant(args.variant)
     model.train()
     opt = None if args.no_optimizer else configure_optimizer(model, lr=1e-3, capturable=not args.no_graph)

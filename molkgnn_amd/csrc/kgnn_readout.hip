@@ -175,7 +175,8 @@ __global__ void __launch_bounds__(256) readout_bwd_mol_kernel(ReadoutArgs a, int
         __syncthreads();
         for (int m = 0; m < MC; ++m) {
 #pragma unroll
-            for (int k = 0; k < 16; ++k) accw[k] = fmaf(dzs[m][po[k]], As[m][pc[k]], accw[k]);
+            for (int k = 0; k < 16; ++k)
+                if (256 * k < G * H) accw[k] = fmaf(dzs[m][po[k]], As[m][pc[k]], accw[k]);      // (uniform: G * H = 1024 uses 4 of 16)
             if (tid < G) accb = fmaf(nat[m], dzs[m][tid], accb);
         }
         for (int i = tid; i < MC * HP; i += 256) {
@@ -611,16 +612,29 @@ __global__ void __launch_bounds__(256) bce_head_forward_kernel(HeadArgs a) {
     const int t = threadIdx.x, h = t & 31, g = t >> 5;          // 8 rows x 32 lanes per pass
     const float bias = a.b ? a.b[0] : 0.f;
     float s = 0.f;
-    for (int k = 0; k < HEAD_ROWS / 8; ++k) {
+    constexpr int NP = HEAD_ROWS / 8;
+    // all loads of the block's 64 rows first (unconditional, clamped), then the arithmetic: one global round trip
+    // per block instead of one per pass
+    float xv[NP], yv[NP];
+    const float w0 = h < a.H ? a.w[h] : 0.f;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
         const int64_t i = (int64_t)blockIdx.x * HEAD_ROWS + k * 8 + g;
         const int64_t ic = i < a.B ? i : a.B - 1;
-        float x = 0.f;
-        for (int h0 = 0; h0 < a.H; h0 += 32)
+        xv[k] = a.emb[ic * a.es + (h < a.H ? h : 0)];
+        yv[k] = a.y[ic];
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int64_t i = (int64_t)blockIdx.x * HEAD_ROWS + k * 8 + g;
+        const int64_t ic = i < a.B ? i : a.B - 1;
+        float x = h < a.H ? xv[k] * w0 : 0.f;
+        for (int h0 = 32; h0 < a.H; h0 += 32)                   // (wider embeddings: the rare path)
             if (h0 + h < a.H) x = fmaf(a.emb[ic * a.es + h0 + h], a.w[h0 + h], x);
         x = half_wave_sum(x) + bias;
         if (h == 0 && i < a.B) {
             a.pred[i] = x;
-            s += fmaxf(x, 0.f) - x * a.y[i] + log1pf(expf(-fabsf(x)));   // torch's stable form
+            s += fmaxf(x, 0.f) - x * yv[k] + log1pf(expf(-fabsf(x)));   // torch's stable form
         }
     }
     if (h == 0) red[g] = s;
@@ -654,21 +668,43 @@ __global__ void __launch_bounds__(256) bce_head_backward_kernel(HeadArgs a) {
     const float gl = a.gloss[0] / (float)a.B;
     const int PW = a.H + 1;                                   // partial row: dW[0..H), db
     float db = 0.f;
+    constexpr int NP = HEAD_ROWS / 8;
+    // d loss / d pred of the block's rows: loads first (unconditional, clamped), then the arithmetic
+    float dv[NP];
+    {
+        float pv[NP], yv[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int64_t i = (int64_t)blockIdx.x * HEAD_ROWS + k * 8 + g;
+            const int64_t ic = i < a.B ? i : a.B - 1;
+            pv[k] = a.pred[ic];
+            yv[k] = a.y[ic];
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int64_t i = (int64_t)blockIdx.x * HEAD_ROWS + k * 8 + g;
+            dv[k] = i < a.B ? gl * (1.f / (1.f + expf(-pv[k])) - yv[k]) : 0.f;
+            if (h == 0) db += dv[k];
+        }
+    }
     for (int h0 = 0; h0 < a.H; h0 += 32) {
         const int hh = h0 + h;
         const bool ok = hh < a.H;
         const float wv = ok ? a.w[hh] : 0.f;
         float dw = 0.f;
-        for (int k = 0; k < HEAD_ROWS / 8; ++k) {
+        float ev[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
             const int64_t i = (int64_t)blockIdx.x * HEAD_ROWS + k * 8 + g;
-            if (i < a.B) {
-                const float x = a.pred[i];
-                const float d = gl * (1.f / (1.f + expf(-x)) - a.y[i]);
-                if (ok) {
-                    dw = fmaf(d, a.emb[i * a.es + hh], dw);
-                    if (a.gemb) a.gemb[i * a.ges + hh] = d * wv;
-                }
-                if (h0 == 0 && h == 0) db += d;
+            const int64_t ic = i < a.B ? i : a.B - 1;
+            ev[k] = a.emb[ic * a.es + (ok ? hh : 0)];
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int64_t i = (int64_t)blockIdx.x * HEAD_ROWS + k * 8 + g;
+            if (i < a.B && ok) {
+                dw = fmaf(dv[k], ev[k], dw);
+                if (a.gemb) a.gemb[i * a.ges + hh] = dv[k] * wv;
             }
         }
         red[g][h] = dw;
