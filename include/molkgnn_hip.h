@@ -237,6 +237,21 @@ int mkgnn_bce_head_backward(const float* emb, int64_t emb_stride, int64_t n_rows
                             float* grad_emb, int64_t grad_emb_stride, float* grad_weight, float* grad_bias,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same with dropout on the embedding ahead of the product (reference model.py:150,169: nn.Dropout(ffn_dropout_rate)
+ * before ffn), generated in the kernels: element (row, h) is zeroed with probability dropout_p in [0, 1), kept values
+ * scaled by 1 / (1 - dropout_p).  Counter-based generator (Philox4x32-10) keyed by rng_state = {seed, offset} on the
+ * device: forward uses the pair, copies it to rng_used (2 x int64, the backward regenerates the mask from it) and
+ * advances offset by one, so a replayed graph draws a fresh mask every time.  dropout_p = 0: the functions above. */
+int mkgnn_bce_head_dropout_forward(const float* emb, int64_t emb_stride, int64_t n_rows, int32_t H,
+                                   const float* weight, const float* bias, const float* target, float dropout_p,
+                                   int64_t* rng_state, int64_t* rng_used, float* pred, float* loss,
+                                   void* workspace, size_t workspace_bytes, void* stream);
+int mkgnn_bce_head_dropout_backward(const float* emb, int64_t emb_stride, int64_t n_rows, int32_t H,
+                                    const float* weight, const float* target, const float* pred,
+                                    const float* grad_loss, float dropout_p, const int64_t* rng_used,
+                                    float* grad_emb, int64_t grad_emb_stride, float* grad_weight, float* grad_bias,
+                                    void* workspace, size_t workspace_bytes, void* stream);
+
 /* AdamW step over all trainable tensors of the model in one launch (reference model.py:368-385: torch.optim.AdamW,
  * two parameter groups -- kernel banks without weight decay).  Per tensor: param / grad [numel] fp32 contiguous,
  * state [2 * numel + 1] = exp_avg, exp_avg_sq, step count (as a float, advanced by this call).  Per group: the

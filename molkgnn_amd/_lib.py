@@ -67,7 +67,8 @@ EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn
            "mkgnn_readout_hidden_stride", "mkgnn_readout_workspace_bytes", "mkgnn_readout_forward",
            "mkgnn_readout_backward", "mkgnn_batchnorm_workspace_bytes", "mkgnn_batchnorm_forward",
            "mkgnn_batchnorm_backward", "mkgnn_bce_head_workspace_bytes", "mkgnn_bce_head_forward",
-           "mkgnn_bce_head_backward", "mkgnn_rf_workspace_bytes", "mkgnn_rf_count", "mkgnn_rf_fill", "mkgnn_adamw_step")
+           "mkgnn_bce_head_backward", "mkgnn_rf_workspace_bytes", "mkgnn_rf_count", "mkgnn_rf_fill", "mkgnn_adamw_step",
+           "mkgnn_bce_head_dropout_forward", "mkgnn_bce_head_dropout_backward")
 
 _lib: Optional[C.CDLL] = None
 
@@ -127,6 +128,10 @@ def load() -> C.CDLL:
     lib.mkgnn_bce_head_forward.argtypes = [P, I64, I64, I32, P, P, P, P, P, P, C.c_size_t, P]
     lib.mkgnn_bce_head_backward.restype = C.c_int
     lib.mkgnn_bce_head_backward.argtypes = [P, I64, I64, I32, P, P, P, P, P, I64, P, P, P, C.c_size_t, P]
+    lib.mkgnn_bce_head_dropout_forward.restype = C.c_int
+    lib.mkgnn_bce_head_dropout_forward.argtypes = [P, I64, I64, I32, P, P, P, C.c_float, P, P, P, P, P, C.c_size_t, P]
+    lib.mkgnn_bce_head_dropout_backward.restype = C.c_int
+    lib.mkgnn_bce_head_dropout_backward.argtypes = [P, I64, I64, I32, P, P, P, P, C.c_float, P, P, I64, P, P, P, C.c_size_t, P]
     lib.mkgnn_bce_head_workspace_bytes.restype = C.c_size_t
     lib.mkgnn_bce_head_workspace_bytes.argtypes = [I64, I32]
     lib.mkgnn_rf_workspace_bytes.restype = C.c_size_t

@@ -583,8 +583,32 @@ struct HeadArgs {
     float* pred; float* loss;
     const float* gloss; float* gemb; int64_t ges; float* gw; float* gb;
     float* partial; int* counter;
+    float drop_p;                  // dropout on emb ahead of the product (model.py:150,169), 0 = none
+    int64_t* rng;                  // forward: {seed, offset}, offset advanced by one per launch
+    int64_t* rng_used;             // forward writes / backward reads the {seed, offset} of this call's mask
 };
 constexpr int HEAD_ROWS = 64;       // rows per block
+
+// Philox4x32-10 (Salmon et al., SC'11): counter-based, so the backward regenerates the forward's mask instead of
+// storing it.  counter = (element / 4, offset), key = seed; element e takes word e % 4.
+__device__ __forceinline__ uint32_t philox_word(uint64_t seed, uint64_t offset, uint64_t element) {
+    uint32_t c0 = (uint32_t)(element >> 2), c1 = (uint32_t)(element >> 34), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const uint32_t w[4] = {c0, c1, c2, c3};
+    return w[element & 3];
+}
+// dropout multiplier of element e: 0 with probability p, else 1 / (1 - p)
+__device__ __forceinline__ float keep_scale_of(uint64_t seed, uint64_t offset, uint64_t element, float p) {
+    const float u = (float)(philox_word(seed, offset, element) >> 8) * (1.f / 16777216.f);     // [0, 1)
+    return u >= p ? 1.f / (1.f - p) : 0.f;
+}
 
 __device__ __forceinline__ float half_wave_sum(float v) {   // xor tree over the 32 lanes of a row
 #pragma unroll
@@ -617,6 +641,8 @@ __global__ void __launch_bounds__(256) bce_head_forward_kernel(HeadArgs a) {
     // per block instead of one per pass
     float xv[NP], yv[NP];
     const float w0 = h < a.H ? a.w[h] : 0.f;
+    const bool drop = a.drop_p > 0.f;
+    const uint64_t seed = drop ? (uint64_t)a.rng[0] : 0, offset = drop ? (uint64_t)a.rng[1] : 0;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int64_t i = (int64_t)blockIdx.x * HEAD_ROWS + k * 8 + g;
@@ -629,8 +655,13 @@ __global__ void __launch_bounds__(256) bce_head_forward_kernel(HeadArgs a) {
         const int64_t i = (int64_t)blockIdx.x * HEAD_ROWS + k * 8 + g;
         const int64_t ic = i < a.B ? i : a.B - 1;
         float x = h < a.H ? xv[k] * w0 : 0.f;
+        if (drop) x *= keep_scale_of(seed, offset, (uint64_t)ic * a.H + (h < a.H ? h : 0), a.drop_p);
         for (int h0 = 32; h0 < a.H; h0 += 32)                   // (wider embeddings: the rare path)
-            if (h0 + h < a.H) x = fmaf(a.emb[ic * a.es + h0 + h], a.w[h0 + h], x);
+            if (h0 + h < a.H) {
+                float e = a.emb[ic * a.es + h0 + h];
+                if (drop) e *= keep_scale_of(seed, offset, (uint64_t)ic * a.H + h0 + h, a.drop_p);
+                x = fmaf(e, a.w[h0 + h], x);
+            }
         x = half_wave_sum(x) + bias;
         if (h == 0 && i < a.B) {
             a.pred[i] = x;
@@ -657,7 +688,13 @@ __global__ void __launch_bounds__(256) bce_head_forward_kernel(HeadArgs a) {
             if (t < w) fin[t] += fin[t + w];
             __syncthreads();
         }
-        if (t == 0) a.loss[0] = fin[0] / (float)a.B;
+        if (t == 0) {
+            a.loss[0] = fin[0] / (float)a.B;
+            if (drop) {                              // every block has read the state by now
+                a.rng_used[0] = (int64_t)seed; a.rng_used[1] = (int64_t)offset;
+                a.rng[1] = (int64_t)(offset + 1);
+            }
+        }
     }
 }
 
@@ -669,6 +706,8 @@ __global__ void __launch_bounds__(256) bce_head_backward_kernel(HeadArgs a) {
     const int PW = a.H + 1;                                   // partial row: dW[0..H), db
     float db = 0.f;
     constexpr int NP = HEAD_ROWS / 8;
+    const bool drop = a.drop_p > 0.f;
+    const uint64_t seed = drop ? (uint64_t)a.rng_used[0] : 0, offset = drop ? (uint64_t)a.rng_used[1] : 0;
     // d loss / d pred of the block's rows: loads first (unconditional, clamped), then the arithmetic
     float dv[NP];
     {
@@ -703,8 +742,9 @@ __global__ void __launch_bounds__(256) bce_head_backward_kernel(HeadArgs a) {
         for (int k = 0; k < NP; ++k) {
             const int64_t i = (int64_t)blockIdx.x * HEAD_ROWS + k * 8 + g;
             if (i < a.B && ok) {
-                dw = fmaf(dv[k], ev[k], dw);
-                if (a.gemb) a.gemb[i * a.ges + hh] = dv[k] * wv;
+                const float ks = drop ? keep_scale_of(seed, offset, (uint64_t)i * a.H + hh, a.drop_p) : 1.f;
+                dw = fmaf(dv[k], ev[k] * ks, dw);
+                if (a.gemb) a.gemb[i * a.ges + hh] = dv[k] * wv * ks;
             }
         }
         red[g][h] = dw;
@@ -970,33 +1010,69 @@ static int head_ws(const char* who, int64_t n_rows, int32_t H, void* ws, size_t 
     return 0;
 }
 
+static int head_forward(const char* who, const float* emb, int64_t emb_stride, int64_t n_rows, int32_t H, const float* weight,
+                        const float* bias, const float* target, float p, int64_t* rng_state, int64_t* rng_used, float* pred,
+                        float* loss, void* ws, size_t ws_bytes, void* stream) {
+    if (n_rows < 1 || H < 1 || emb_stride < H) return api_fail("%s: bad shape", who);
+    if (!emb || !weight || !target || !pred || !loss) return api_fail("%s: null pointer", who);
+    if (!(p >= 0.f && p < 1.f)) return api_fail("%s: dropout probability %g outside [0, 1)", who, p);
+    if (p > 0.f && (!rng_state || !rng_used)) return api_fail("%s: dropout needs rng_state and rng_used", who);
+    HeadArgs a{};
+    if (int rc = head_ws(who, n_rows, H, ws, ws_bytes, a)) return rc;
+    a.emb = emb; a.es = emb_stride; a.B = n_rows; a.H = H; a.w = weight; a.b = bias; a.y = target; a.pred = pred; a.loss = loss;
+    a.drop_p = p; a.rng = rng_state; a.rng_used = rng_used;
+    bce_head_forward_kernel<<<(int)((n_rows + HEAD_ROWS - 1) / HEAD_ROWS), 256, 0, (hipStream_t)stream>>>(a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : api_hip_fail(who, e);
+}
+
+static int head_backward(const char* who, const float* emb, int64_t emb_stride, int64_t n_rows, int32_t H, const float* weight,
+                         const float* target, const float* pred, const float* grad_loss, float p, const int64_t* rng_used,
+                         float* grad_emb, int64_t grad_emb_stride, float* grad_weight, float* grad_bias, void* ws,
+                         size_t ws_bytes, void* stream) {
+    if (n_rows < 1 || H < 1 || emb_stride < H) return api_fail("%s: bad shape", who);
+    if (!emb || !weight || !target || !pred || !grad_loss || !grad_weight) return api_fail("%s: null pointer", who);
+    if (grad_emb && grad_emb_stride < H) return api_fail("%s: bad grad_emb stride", who);
+    if (!(p >= 0.f && p < 1.f)) return api_fail("%s: dropout probability %g outside [0, 1)", who, p);
+    if (p > 0.f && !rng_used) return api_fail("%s: dropout needs the forward's rng_used", who);
+    HeadArgs a{};
+    if (int rc = head_ws(who, n_rows, H, ws, ws_bytes, a)) return rc;
+    a.emb = emb; a.es = emb_stride; a.B = n_rows; a.H = H; a.w = weight; a.y = target; a.pred = (float*)pred;
+    a.gloss = grad_loss; a.gemb = grad_emb; a.ges = grad_emb_stride; a.gw = grad_weight; a.gb = grad_bias;
+    a.drop_p = p; a.rng_used = (int64_t*)rng_used;
+    bce_head_backward_kernel<<<(int)((n_rows + HEAD_ROWS - 1) / HEAD_ROWS), 256, 0, (hipStream_t)stream>>>(a);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : api_hip_fail(who, e);
+}
+
 int mkgnn_bce_head_forward(const float* emb, int64_t emb_stride, int64_t n_rows, int32_t H, const float* weight,
                            const float* bias, const float* target, float* pred, float* loss, void* ws, size_t ws_bytes,
                            void* stream) {
-    if (n_rows < 1 || H < 1 || emb_stride < H) return api_fail("mkgnn_bce_head_forward: bad shape");
-    if (!emb || !weight || !target || !pred || !loss) return api_fail("mkgnn_bce_head_forward: null pointer");
-    HeadArgs a{};
-    if (int rc = head_ws("mkgnn_bce_head_forward", n_rows, H, ws, ws_bytes, a)) return rc;
-    a.emb = emb; a.es = emb_stride; a.B = n_rows; a.H = H; a.w = weight; a.b = bias; a.y = target; a.pred = pred; a.loss = loss;
-    bce_head_forward_kernel<<<(int)((n_rows + HEAD_ROWS - 1) / HEAD_ROWS), 256, 0, (hipStream_t)stream>>>(a);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : api_hip_fail("mkgnn_bce_head_forward", e);
+    return head_forward("mkgnn_bce_head_forward", emb, emb_stride, n_rows, H, weight, bias, target, 0.f, nullptr, nullptr,
+                        pred, loss, ws, ws_bytes, stream);
 }
 
 int mkgnn_bce_head_backward(const float* emb, int64_t emb_stride, int64_t n_rows, int32_t H, const float* weight,
                             const float* target, const float* pred, const float* grad_loss, float* grad_emb,
                             int64_t grad_emb_stride, float* grad_weight, float* grad_bias, void* ws, size_t ws_bytes,
                             void* stream) {
-    if (n_rows < 1 || H < 1 || emb_stride < H) return api_fail("mkgnn_bce_head_backward: bad shape");
-    if (!emb || !weight || !target || !pred || !grad_loss || !grad_weight) return api_fail("mkgnn_bce_head_backward: null pointer");
-    if (grad_emb && grad_emb_stride < H) return api_fail("mkgnn_bce_head_backward: bad grad_emb stride");
-    HeadArgs a{};
-    if (int rc = head_ws("mkgnn_bce_head_backward", n_rows, H, ws, ws_bytes, a)) return rc;
-    a.emb = emb; a.es = emb_stride; a.B = n_rows; a.H = H; a.w = weight; a.y = target; a.pred = (float*)pred;
-    a.gloss = grad_loss; a.gemb = grad_emb; a.ges = grad_emb_stride; a.gw = grad_weight; a.gb = grad_bias;
-    bce_head_backward_kernel<<<(int)((n_rows + HEAD_ROWS - 1) / HEAD_ROWS), 256, 0, (hipStream_t)stream>>>(a);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : api_hip_fail("mkgnn_bce_head_backward", e);
+    return head_backward("mkgnn_bce_head_backward", emb, emb_stride, n_rows, H, weight, target, pred, grad_loss, 0.f, nullptr,
+                         grad_emb, grad_emb_stride, grad_weight, grad_bias, ws, ws_bytes, stream);
+}
+
+int mkgnn_bce_head_dropout_forward(const float* emb, int64_t emb_stride, int64_t n_rows, int32_t H, const float* weight,
+                                   const float* bias, const float* target, float dropout_p, int64_t* rng_state,
+                                   int64_t* rng_used, float* pred, float* loss, void* ws, size_t ws_bytes, void* stream) {
+    return head_forward("mkgnn_bce_head_dropout_forward", emb, emb_stride, n_rows, H, weight, bias, target, dropout_p, rng_state,
+                        rng_used, pred, loss, ws, ws_bytes, stream);
+}
+
+int mkgnn_bce_head_dropout_backward(const float* emb, int64_t emb_stride, int64_t n_rows, int32_t H, const float* weight,
+                                    const float* target, const float* pred, const float* grad_loss, float dropout_p,
+                                    const int64_t* rng_used, float* grad_emb, int64_t grad_emb_stride, float* grad_weight,
+                                    float* grad_bias, void* ws, size_t ws_bytes, void* stream) {
+    return head_backward("mkgnn_bce_head_dropout_backward", emb, emb_stride, n_rows, H, weight, target, pred, grad_loss, dropout_p,
+                         rng_used, grad_emb, grad_emb_stride, grad_weight, grad_bias, ws, ws_bytes, stream);
 }
 
 }  // extern "C"

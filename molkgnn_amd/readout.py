@@ -232,9 +232,32 @@ def _head_workspace(dev, nbytes: int) -> torch.Tensor:
     return ws
 
 
+_HEAD_RNG: dict = {}
+
+
+def head_rng_state(dev) -> torch.Tensor:
+    """Per-device ``{seed, offset}`` (int64) of the head kernels' dropout generator.  The seed is drawn from PyTorch's
+    default CPU generator the first time a device needs it, so ``torch.manual_seed`` fixes the sequence; every forward
+    with dropout advances ``offset`` on the device (also inside a replayed graph)."""
+    st = _HEAD_RNG.get(str(dev))
+    if st is None:
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+        st = torch.tensor([seed, 0], dtype=torch.int64, device=dev)
+        _HEAD_RNG[str(dev)] = st
+    return st
+
+
+def reset_head_rng(dev=None, seed=None) -> None:
+    """Forget the generator state (of one device, or all): the next use draws a new seed, or uses ``seed``."""
+    for k in ([str(dev)] if dev is not None else list(_HEAD_RNG)):
+        _HEAD_RNG.pop(k, None)
+        if seed is not None:
+            _HEAD_RNG[k] = torch.tensor([int(seed), 0], dtype=torch.int64, device=torch.device(k))
+
+
 class _BceHeadFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, emb, weight, bias, target):
+    def forward(ctx, emb, weight, bias, target, p_drop):
         lib = _lib.load()
         emb = _row_major(emb if emb.dtype == torch.float32 else emb.float())
         B, H = emb.shape
@@ -243,21 +266,25 @@ class _BceHeadFn(torch.autograd.Function):
         y = target.reshape(-1).float().contiguous()
         pred = torch.empty(B, dtype=torch.float32, device=dev)
         loss = torch.empty((), dtype=torch.float32, device=dev)
+        rng = head_rng_state(dev) if p_drop > 0.0 else None
+        used = torch.empty(2, dtype=torch.int64, device=dev) if p_drop > 0.0 else None
         with torch.cuda.device(dev):
             nbytes = int(lib.mkgnn_bce_head_workspace_bytes(B, H))
             ws = _head_workspace(dev, nbytes)
-            _lib.check(lib.mkgnn_bce_head_forward(emb.data_ptr(), _stride0(emb), B, H, w.data_ptr(), _lib.ptr(bias),
-                                                  y.data_ptr(), pred.data_ptr(), loss.data_ptr(), ws.data_ptr(), ws.numel(),
-                                                  _lib.stream_ptr(dev)), "mkgnn_bce_head_forward")
-        ctx.save_for_backward(emb, w, y, pred)
+            _lib.check(lib.mkgnn_bce_head_dropout_forward(
+                emb.data_ptr(), _stride0(emb), B, H, w.data_ptr(), _lib.ptr(bias), y.data_ptr(), float(p_drop),
+                _lib.ptr(rng), _lib.ptr(used), pred.data_ptr(), loss.data_ptr(), ws.data_ptr(), ws.numel(),
+                _lib.stream_ptr(dev)), "mkgnn_bce_head_dropout_forward")
+        ctx.save_for_backward(emb, w, y, pred, used)
         ctx.wshape = weight.shape
         ctx.has_bias = bias is not None
+        ctx.p_drop = float(p_drop)
         return loss
 
     @staticmethod
     def backward(ctx, grad_loss):
         lib = _lib.load()
-        emb, w, y, pred = ctx.saved_tensors
+        emb, w, y, pred, used = ctx.saved_tensors
         B, H = emb.shape
         dev = emb.device
         gl = grad_loss.reshape(1).float().contiguous()
@@ -266,17 +293,21 @@ class _BceHeadFn(torch.autograd.Function):
         gb = torch.empty(1, dtype=torch.float32, device=dev) if ctx.has_bias else None
         with torch.cuda.device(dev):
             ws = _head_workspace(dev, int(lib.mkgnn_bce_head_workspace_bytes(B, H)))
-            _lib.check(lib.mkgnn_bce_head_backward(emb.data_ptr(), _stride0(emb), B, H, w.data_ptr(), y.data_ptr(),
-                                                   pred.data_ptr(), gl.data_ptr(), _lib.ptr(gemb), H, gw.data_ptr(),
-                                                   _lib.ptr(gb), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)),
-                       "mkgnn_bce_head_backward")
-        return gemb, gw.reshape(ctx.wshape), gb, None
+            _lib.check(lib.mkgnn_bce_head_dropout_backward(
+                emb.data_ptr(), _stride0(emb), B, H, w.data_ptr(), y.data_ptr(), pred.data_ptr(), gl.data_ptr(),
+                ctx.p_drop, _lib.ptr(used), _lib.ptr(gemb), H, gw.data_ptr(), _lib.ptr(gb), ws.data_ptr(), ws.numel(),
+                _lib.stream_ptr(dev)), "mkgnn_bce_head_dropout_backward")
+        return gemb, gw.reshape(ctx.wshape), gb, None, None
 
 
-def bce_head_loss(emb: torch.Tensor, ffn: torch.nn.Linear, target: torch.Tensor) -> torch.Tensor:
-    """``BCEWithLogitsLoss()(ffn(emb).view(-1), target.view(-1).float())`` for a one-output ``ffn`` (reference
-    ``model.py:147-148, 190-198``) as one forward and one backward kernel."""
+def bce_head_loss(emb: torch.Tensor, ffn: torch.nn.Linear, target: torch.Tensor, dropout_p: float = 0.0) -> torch.Tensor:
+    """``BCEWithLogitsLoss()(ffn(dropout(emb)).view(-1), target.view(-1).float())`` for a one-output ``ffn`` (reference
+    ``model.py:147-150, 169, 190-198``) as one forward and one backward kernel; ``dropout_p`` is the probability of
+    zeroing an element of ``emb`` (``nn.Dropout(ffn_dropout_rate)`` in training mode; 0 otherwise), its mask drawn
+    inside the kernels from ``head_rng_state``."""
     _lib.require_gpu_tensor(emb, "graph_embedding")
     if ffn.out_features != 1 or emb.dim() != 2 or emb.shape[0] == 0 or target.numel() != emb.shape[0]:
         raise ValueError("bce_head_loss needs a one-output linear layer and one target per row")
-    return _BceHeadFn.apply(emb, ffn.weight, ffn.bias, target)
+    if not 0.0 <= dropout_p < 1.0:
+        raise ValueError(f"dropout probability {dropout_p} outside [0, 1)")
+    return _BceHeadFn.apply(emb, ffn.weight, ffn.bias, target, float(dropout_p))

@@ -946,3 +946,92 @@ def test_fused_adamw_refuses_cpu_parameters():
     p.grad = torch.randn(4)
     with pytest.raises(_lib.MolKGNNLibraryError):
         FusedAdamW([p]).step()
+
+
+def test_head_dropout_mask_is_consistent_between_forward_and_backward():
+    """Dropout inside the head kernels (model.py:150,169 ahead of ffn): the backward regenerates the forward's mask from
+    the saved {seed, offset}.  The mask is read off grad_emb (zero exactly where an element was dropped); with it the
+    loss and every gradient must equal the PyTorch formula; the keep rate is 1 - p; the state advances by one per
+    forward, a fixed seed reproduces the masks, and a replayed graph draws a new mask each time."""
+    from molkgnn_amd import readout as R
+    dev = _dev()
+    torch.manual_seed(9)
+    B, H, p = 3000, 32, 0.25
+    emb = torch.randn(B, H, device=dev, requires_grad=True)
+    ffn = torch.nn.Linear(H, 1).to(dev)
+    with torch.no_grad():
+        ffn.weight.abs_().add_(0.1)                       # no zero weight: grad_emb == 0 means "dropped"
+    y = (torch.rand(B, device=dev) < 0.3).long()
+
+    def run():
+        emb.grad = None; ffn.zero_grad()
+        loss = R.bce_head_loss(emb, ffn, y, dropout_p=p)
+        loss.backward()
+        return loss.detach().clone(), emb.grad.clone(), ffn.weight.grad.clone(), ffn.bias.grad.clone()
+
+    R.reset_head_rng(dev, seed=1234)
+    loss1, ge1, gw1, gb1 = run()
+    assert int(R.head_rng_state(dev)[1]) == 1
+    mask = (ge1 != 0).float()
+    keep = float(mask.mean())
+    assert abs(keep - (1 - p)) < 4 * (p * (1 - p) / (B * H)) ** 0.5 + 1e-3, keep
+    assert 0.5 < float(mask[:, 0].mean()) < 0.95 and 0.5 < float(mask[0].mean()) <= 1.0      # no row / column structure
+    e2 = emb.detach().clone().requires_grad_(True)
+    w2, b2 = ffn.weight.detach().clone().requires_grad_(True), ffn.bias.detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(((e2 * mask / (1 - p)) @ w2.t() + b2).view(-1), y.float())
+    ref.backward()
+    torch.testing.assert_close(loss1, ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(ge1, e2.grad, rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(gw1, w2.grad, rtol=1e-4, atol=1e-6)
+    torch.testing.assert_close(gb1, b2.grad, rtol=1e-4, atol=1e-6)
+    _, ge2, _, _ = run()                                   # next offset: another mask
+    assert int(R.head_rng_state(dev)[1]) == 2
+    assert float(((ge2 != 0) != (ge1 != 0)).float().mean()) > 0.2
+    R.reset_head_rng(dev, seed=1234)                       # same seed, offset 0: the first mask again
+    loss3, ge3, gw3, _ = run()
+    assert torch.equal(ge3, ge1) and torch.equal(loss3, loss1) and torch.equal(gw3, gw1)
+    # p = 0 through the same entry points is the plain head
+    emb.grad = None
+    l0 = R.bce_head_loss(emb, ffn, y, dropout_p=0.0)
+    torch.testing.assert_close(l0.detach(), torch.nn.functional.binary_cross_entropy_with_logits(
+        ffn(emb.detach()).view(-1), y.float()), rtol=1e-5, atol=1e-6)
+    R.reset_head_rng(dev)
+
+
+def test_head_dropout_draws_a_new_mask_on_every_graph_replay():
+    """The generator's offset lives on the device and is advanced by the forward kernel: a captured step replayed
+    twice uses two different masks (a captured torch dropout needs two extra fill kernels per replay for the same).
+    (Its own test function on purpose: with any un-freed autograd graph over the same leaf alive at capture time --
+    pure-PyTorch ones included -- ``capture_end`` of this PyTorch/ROCm build segfaults.)"""
+    from molkgnn_amd import readout as R
+    dev = _dev()
+    torch.manual_seed(10)
+    B, H, p = 3000, 32, 0.25
+    emb = torch.randn(B, H, device=dev, requires_grad=True)
+    ffn = torch.nn.Linear(H, 1).to(dev)
+    with torch.no_grad():
+        ffn.weight.abs_().add_(0.1)
+    y = (torch.rand(B, device=dev) < 0.3).long()
+
+    def run():
+        emb.grad = None; ffn.zero_grad(set_to_none=True)
+        R.bce_head_loss(emb, ffn, y, dropout_p=p).backward()
+
+    R.reset_head_rng(dev, seed=77)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        run()
+        emb.grad = None; ffn.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            static_loss = R.bce_head_loss(emb, ffn, y, dropout_p=p)
+            static_loss.backward()
+    torch.cuda.current_stream().wait_stream(side)
+    before = int(R.head_rng_state(dev)[1])
+    g.replay(); a_mask = (emb.grad != 0).clone()
+    g.replay(); b_mask = (emb.grad != 0).clone()
+    torch.cuda.synchronize()
+    assert int(R.head_rng_state(dev)[1]) == before + 2
+    assert float((a_mask != b_mask).float().mean()) > 0.2
+    R.reset_head_rng(dev)
