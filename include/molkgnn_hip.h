@@ -225,9 +225,9 @@ int mkgnn_rf_fill(const int64_t* edge_index, const float* p, const float* edge_a
 /* Tail of the training step for a single task (reference model.py:147-148, 190-198 with data.py:37):
  *     pred = graph_embedding @ ffn.weight[0] + ffn.bias;   loss = mean(BCEWithLogits(pred, target))
  * forward writes pred [n_rows] and loss [1]; backward takes d loss (one float on the device) and fully overwrites
- * grad_emb [n_rows, H] (may be NULL), grad_weight [H], grad_bias [1] (may be NULL).  One launch each; sums in a
- * fixed order.  workspace: mkgnn_bce_head_workspace_bytes bytes whose FIRST 4 BYTES ARE ZERO when a call starts
- * (a block counter; the kernels leave it zero), not shared by calls that may run concurrently. */
+ * grad_emb [n_rows, H] (may be NULL), grad_weight [H], grad_bias [1] (may be NULL).  Two launches each (block
+ * partials, then their sum in a fixed order).  workspace: mkgnn_bce_head_workspace_bytes bytes, not shared by calls
+ * that may run concurrently. */
 size_t mkgnn_bce_head_workspace_bytes(int64_t n_rows, int32_t H);
 int mkgnn_bce_head_forward(const float* emb, int64_t emb_stride, int64_t n_rows, int32_t H,
                            const float* weight, const float* bias, const float* target,
@@ -254,11 +254,10 @@ int mkgnn_bce_head_dropout_backward(const float* emb, int64_t emb_stride, int64_
 
 /* AdamW step over all trainable tensors of the model in one launch (reference model.py:368-385: torch.optim.AdamW,
  * two parameter groups -- kernel banks without weight decay).  Per tensor: param / grad [numel] fp32 contiguous,
- * state [2 * numel + 1] = exp_avg, exp_avg_sq, step count (as a float, advanced by this call).  Per group: the
+ * state [2 * numel + 3] = exp_avg, exp_avg_sq, step count (as a float, advanced by this call), two scratch floats.  Per group: the
  * learning rate either by value (lr_device NULL) or read from a device float at run time (so that a captured graph
  * follows a scheduler), betas, eps, decoupled weight_decay, maximize.  The update is torch's fused AdamW formula
- * (bias corrections 1 - beta^step).  counter: 4 zero bytes on the device, left zero; not shared by concurrent calls.
- * At most 4 groups; any number of tensors (96 per launch). */
+ * (bias corrections 1 - beta^step).  At most 4 groups; any number of tensors (96 per launch pair). */
 typedef struct mkgnn_adamw_tensor {
     float* param;
     const float* grad;
@@ -272,7 +271,7 @@ typedef struct mkgnn_adamw_group {
     int32_t maximize;
 } mkgnn_adamw_group;
 int mkgnn_adamw_step(const mkgnn_adamw_tensor* tensors, int32_t n_tensors, const mkgnn_adamw_group* groups,
-                     int32_t n_groups, int32_t* counter, void* stream);
+                     int32_t n_groups, void* stream);
 
 #ifdef __cplusplus
 }

@@ -141,7 +141,7 @@ def load() -> C.CDLL:
     lib.mkgnn_rf_fill.restype = C.c_int
     lib.mkgnn_rf_fill.argtypes = [P, P, P, I64, I64, I32, P, Buckets4, P]
     lib.mkgnn_adamw_step.restype = C.c_int
-    lib.mkgnn_adamw_step.argtypes = [P, I32, P, I32, P, P]
+    lib.mkgnn_adamw_step.argtypes = [P, I32, P, I32, P]
     if lib.mkgnn_abi_version() != ABI_VERSION:
         raise MolKGNNLibraryError(f"ABI version {lib.mkgnn_abi_version()} != {ABI_VERSION}: rebuild the library")
     _lib = lib

@@ -4,8 +4,9 @@
 // from weight decay).  MolKGNN has ~80 small trainable tensors (132 k floats in all): PyTorch's fused multi-tensor
 // path needs two launches per group plus one per group for the step counters -- five launch-bound kernels, ~40 us
 // of a 1.3 ms training step, for 2 MB of traffic.  Here the tensor table travels in the kernel arguments (pointers
-// are baked into a captured graph exactly like PyTorch's), one block per 1024 elements, and the per-tensor step
-// counters are advanced by whichever block finishes last, after every block has read them.
+// are baked into a captured graph exactly like PyTorch's), one block per 1024 elements.  A one-block kernel ahead of
+// it advances the per-tensor step counters and computes the bias corrections (a "last block done" counter inside
+// the update kernel was measured at 27 us for the pair of device-scope fences it needs; two plain launches take 10).
 //
 // Arithmetic: the update of torch's fused kernel (fused_adam_utils.cuh, ADAMW mode), in the same order:
 //   p -= lr * wd * p;  m += (1 - b1) (g - m);  v = b2 v + (1 - b2) g g;
@@ -26,8 +27,21 @@ struct AdamArgs {
     AdamGroup grp[ADAM_MAX_GROUPS];
     int32_t blk_start[ADAM_MAX_TENSORS + 1];
     int32_t nt;
-    int* counter;
 };
+
+// One thread per tensor: advance its step counter and leave the two bias-correction factors next to it
+// (double-precision pow once per tensor instead of once per thread of the update kernel).
+__global__ void __launch_bounds__(128) adamw_count_kernel(AdamArgs a) {
+    const int ti = threadIdx.x;
+    if (ti >= a.nt) return;
+    const AdamTensor T = a.t[ti];
+    const AdamGroup G = a.grp[T.group];
+    float* tail = T.state + 2 * (size_t)T.n;
+    const double t = (double)tail[0] + 1.0;
+    tail[0] = (float)t;
+    tail[1] = (float)(1.0 - pow((double)G.beta1, t));
+    tail[2] = sqrtf((float)(1.0 - pow((double)G.beta2, t)));
+}
 
 __global__ void __launch_bounds__(256) adamw_step_kernel(AdamArgs a) {
     // block -> tensor: the last ti with blk_start[ti] <= blockIdx.x
@@ -41,39 +55,30 @@ __global__ void __launch_bounds__(256) adamw_step_kernel(AdamArgs a) {
     const float lr = G.lr_ptr ? *G.lr_ptr : G.lr;
     float* m = T.state;
     float* v = T.state + T.n;
-    const double t = (double)T.state[2 * (size_t)T.n] + 1.0;
-    const float bc1 = (float)(1.0 - pow((double)G.beta1, t));
-    const float bc2_sqrt = sqrtf((float)(1.0 - pow((double)G.beta2, t)));
+    const float bc1 = T.state[2 * (size_t)T.n + 1], bc2_sqrt = T.state[2 * (size_t)T.n + 2];
     const float step_size = lr / bc1;
     const int base = ((int)blockIdx.x - a.blk_start[lo]) * ADAM_CHUNK;
+    float g[ADAM_CHUNK / 256], p[ADAM_CHUNK / 256], mi[ADAM_CHUNK / 256], vi[ADAM_CHUNK / 256];
+#pragma unroll
+    for (int k = 0; k < ADAM_CHUNK / 256; ++k) {          // all loads first (clamped), then the arithmetic
+        const int i = base + 256 * k + (int)threadIdx.x;
+        const int ic = i < T.n ? i : T.n - 1;
+        g[k] = T.g[ic]; p[k] = T.p[ic]; mi[k] = m[ic]; vi[k] = v[ic];
+    }
 #pragma unroll
     for (int k = 0; k < ADAM_CHUNK / 256; ++k) {
         const int i = base + 256 * k + (int)threadIdx.x;
         if (i < T.n) {
-            float g = T.g[i];
-            if (G.maximize) g = -g;
-            float p = T.p[i];
-            p -= lr * G.wd * p;
-            float mi = m[i], vi = v[i];
-            mi = fmaf(1.f - G.beta1, g - mi, mi);
-            vi = G.beta2 * vi + (1.f - G.beta2) * g * g;
-            const float denom = sqrtf(vi) / bc2_sqrt + G.eps;
-            p -= step_size * mi / denom;
-            T.p[i] = p; m[i] = mi; v[i] = vi;
+            const float gg = G.maximize ? -g[k] : g[k];
+            float pp = p[k];
+            pp -= lr * G.wd * pp;
+            const float mm = fmaf(1.f - G.beta1, gg - mi[k], mi[k]);
+            const float vv = G.beta2 * vi[k] + (1.f - G.beta2) * gg * gg;
+            const float denom = sqrtf(vv) / bc2_sqrt + G.eps;
+            pp -= step_size * mm / denom;
+            T.p[i] = pp; m[i] = mm; v[i] = vv;
         }
     }
-    // every block has read its tensor's step counter by the time it gets here; the last one advances them all
-    __shared__ int is_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int done = atomicAdd(a.counter, 1);
-        is_last = done == (int)gridDim.x - 1;
-        if (is_last) *a.counter = 0;
-    }
-    __syncthreads();
-    if (is_last)
-        for (int ti = threadIdx.x; ti < a.nt; ti += 256) a.t[ti].state[2 * (size_t)a.t[ti].n] += 1.f;
 }
 
 }  // namespace mkgnn
@@ -81,11 +86,11 @@ __global__ void __launch_bounds__(256) adamw_step_kernel(AdamArgs a) {
 using namespace mkgnn;
 
 extern "C" int mkgnn_adamw_step(const mkgnn_adamw_tensor* tensors, int32_t n_tensors, const mkgnn_adamw_group* groups,
-                                int32_t n_groups, int32_t* counter, void* stream) {
+                                int32_t n_groups, void* stream) {
     if (n_tensors < 0 || n_groups < 1 || n_groups > ADAM_MAX_GROUPS)
         return api_fail("mkgnn_adamw_step: %d tensors, %d groups (1..%d groups)", n_tensors, n_groups, ADAM_MAX_GROUPS);
     if (n_tensors == 0) return 0;
-    if (!tensors || !groups || !counter) return api_fail("mkgnn_adamw_step: null pointer");
+    if (!tensors || !groups) return api_fail("mkgnn_adamw_step: null pointer");
     hipStream_t st = (hipStream_t)stream;
     AdamArgs a{};
     for (int g = 0; g < n_groups; ++g) {
@@ -94,7 +99,6 @@ extern "C" int mkgnn_adamw_step(const mkgnn_adamw_tensor* tensors, int32_t n_ten
             return api_fail("mkgnn_adamw_step: group %d has betas (%g, %g), eps %g, weight_decay %g", g, s.beta1, s.beta2, s.eps, s.weight_decay);
         a.grp[g] = AdamGroup{s.lr_device, s.lr, s.beta1, s.beta2, s.eps, s.weight_decay, s.maximize};
     }
-    a.counter = counter;
     for (int32_t first = 0; first < n_tensors; first += ADAM_MAX_TENSORS) {
         const int nt = n_tensors - first < ADAM_MAX_TENSORS ? n_tensors - first : ADAM_MAX_TENSORS;
         int blocks = 0;
@@ -108,6 +112,7 @@ extern "C" int mkgnn_adamw_step(const mkgnn_adamw_tensor* tensors, int32_t n_ten
         }
         a.blk_start[nt] = blocks;
         a.nt = nt;
+        adamw_count_kernel<<<1, 128, 0, st>>>(a);
         adamw_step_kernel<<<blocks, 256, 0, st>>>(a);
     }
     hipError_t e = hipGetLastError();

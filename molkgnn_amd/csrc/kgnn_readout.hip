@@ -574,15 +574,14 @@ __global__ void __launch_bounds__(256) bn_bwd_final_kernel(BnArgs a, int CL, int
 
 // ------------------------------------------------------------------ single-task head + BCE-with-logits ----
 // The tail of the training step (reference model.py: ffn(graph_embedding) -> BCEWithLogitsLoss, mean reduction),
-// ~20 tiny PyTorch kernels at B = 4096.  One launch per pass: 32 lanes per row, 64 rows per block, per-block
-// partials, and the block that finishes last (device counter, self-resetting) sums them in block order -- every
-// sum has a fixed order, whichever block that is.
+// ~20 tiny PyTorch kernels at B = 4096.  Two launches per pass: 32 lanes per row, 64 rows per block, per-block
+// partials; a one-block kernel sums them in a fixed order.
 struct HeadArgs {
     const float* emb; int64_t es; int64_t B; int H;
     const float* w; const float* b; const float* y;
     float* pred; float* loss;
     const float* gloss; float* gemb; int64_t ges; float* gw; float* gb;
-    float* partial; int* counter;
+    float* partial;
     float drop_p;                  // dropout on emb ahead of the product (model.py:150,169), 0 = none
     int64_t* rng;                  // forward: {seed, offset}, offset advanced by one per launch
     int64_t* rng_used;             // forward writes / backward reads the {seed, offset} of this call's mask
@@ -614,21 +613,6 @@ __device__ __forceinline__ float half_wave_sum(float v) {   // xor tree over the
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
-}
-
-// true in exactly one block: the one whose partials were published last
-__device__ __forceinline__ bool last_block_done(int* counter) {
-    __shared__ int is_last;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int done = atomicAdd(counter, 1);
-        is_last = done == (int)gridDim.x - 1;
-        if (is_last) *counter = 0;                           // ready for the next launch
-    }
-    __syncthreads();
-    if (is_last) __threadfence();
-    return is_last != 0;
 }
 
 __global__ void __launch_bounds__(256) bce_head_forward_kernel(HeadArgs a) {
@@ -675,25 +659,28 @@ __global__ void __launch_bounds__(256) bce_head_forward_kernel(HeadArgs a) {
         for (int k = 0; k < 8; ++k) p += red[k];
         a.partial[blockIdx.x] = p;
     }
-    if (last_block_done(a.counter)) {
-        // all 256 threads fetch (loads in flight together: a serial loop over the partials by one thread took 24 us),
-        // then a fixed tree
-        __shared__ float fin[256];
-        const volatile float* part = a.partial;
-        float v = 0.f;
-        for (int bk = t; bk < (int)gridDim.x; bk += 256) v += part[bk];
-        fin[t] = v;
+}
+
+// second launch of the forward: the block partials in a fixed tree -> loss; advances the dropout generator.
+// (A "last block done" counter inside the first kernel did this in one launch, but the two device-scope fences it
+// needs cost 10-15 us on this part -- more than a second, dependent launch: 4.7 us.)
+__global__ void __launch_bounds__(256) bce_head_forward_final_kernel(HeadArgs a, int nblk) {
+    __shared__ float fin[256];
+    const int t = threadIdx.x;
+    float v = 0.f;
+    for (int bk = t; bk < nblk; bk += 256) v += a.partial[bk];
+    fin[t] = v;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (t < w) fin[t] += fin[t + w];
         __syncthreads();
-        for (int w = 128; w > 0; w >>= 1) {
-            if (t < w) fin[t] += fin[t + w];
-            __syncthreads();
-        }
-        if (t == 0) {
-            a.loss[0] = fin[0] / (float)a.B;
-            if (drop) {                              // every block has read the state by now
-                a.rng_used[0] = (int64_t)seed; a.rng_used[1] = (int64_t)offset;
-                a.rng[1] = (int64_t)(offset + 1);
-            }
+    }
+    if (t == 0) {
+        a.loss[0] = fin[0] / (float)a.B;
+        if (a.drop_p > 0.f) {
+            const int64_t seed = a.rng[0], offset = a.rng[1];
+            a.rng_used[0] = seed; a.rng_used[1] = offset;
+            a.rng[1] = offset + 1;
         }
     }
 }
@@ -763,32 +750,35 @@ __global__ void __launch_bounds__(256) bce_head_backward_kernel(HeadArgs a) {
         for (int k = 0; k < 8; ++k) p += redb[k];
         a.partial[(size_t)blockIdx.x * PW + a.H] = p;
     }
-    if (last_block_done(a.counter)) {
-        // column c, four row parts per column, eight loads in flight per thread; parts combined in a fixed order
-        __shared__ float fin[4][64];
-        const volatile float* part = a.partial;
-        const int nb = (int)gridDim.x;
-        for (int c0 = 0; c0 < PW; c0 += 64) {
-            const int c = c0 + (t & 63), pr = t >> 6;
-            float tot = 0.f;
-            if (c < PW) {
-                for (int bk = pr; bk < nb; bk += 32) {
-                    float v[8];
+}
+
+// second launch of the backward: column c of the block partials, four row parts per column, eight loads in flight
+// per thread; parts combined in a fixed order
+__global__ void __launch_bounds__(256) bce_head_backward_final_kernel(HeadArgs a, int nb) {
+    __shared__ float fin[4][64];
+    const int t = threadIdx.x;
+    const int PW = a.H + 1;
+    const float* part = a.partial;
+    for (int c0 = 0; c0 < PW; c0 += 64) {
+        const int c = c0 + (t & 63), pr = t >> 6;
+        float tot = 0.f;
+        if (c < PW) {
+            for (int bk = pr; bk < nb; bk += 32) {
+                float v[8];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(bk + 4 * u < nb ? bk + 4 * u : bk) * PW + c];
+                for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(bk + 4 * u < nb ? bk + 4 * u : bk) * PW + c];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) if (bk + 4 * u < nb) tot += v[u];
-                }
+                for (int u = 0; u < 8; ++u) if (bk + 4 * u < nb) tot += v[u];
             }
-            fin[pr][t & 63] = tot;
-            __syncthreads();
-            if (pr == 0 && c < PW) {
-                const float r = (fin[0][t] + fin[1][t]) + (fin[2][t] + fin[3][t]);
-                if (c < a.H) a.gw[c] = r;
-                else if (a.gb) a.gb[0] = r;
-            }
-            __syncthreads();
         }
+        fin[pr][t & 63] = tot;
+        __syncthreads();
+        if (pr == 0 && c < PW) {
+            const float r = (fin[0][t] + fin[1][t]) + (fin[2][t] + fin[3][t]);
+            if (c < a.H) a.gw[c] = r;
+            else if (a.gb) a.gb[0] = r;
+        }
+        __syncthreads();
     }
 }
 
@@ -1005,7 +995,6 @@ size_t mkgnn_bce_head_workspace_bytes(int64_t n_rows, int32_t H) {
 static int head_ws(const char* who, int64_t n_rows, int32_t H, void* ws, size_t ws_bytes, HeadArgs& a) {
     if (!ws || ws_bytes < mkgnn_bce_head_workspace_bytes(n_rows, H) || ((uintptr_t)ws & 3))
         return api_fail("%s: workspace too small or misaligned", who);
-    a.counter = (int*)ws;                   // first word: block counter, zero between launches
     a.partial = (float*)((char*)ws + 16);
     return 0;
 }
@@ -1021,7 +1010,9 @@ static int head_forward(const char* who, const float* emb, int64_t emb_stride, i
     if (int rc = head_ws(who, n_rows, H, ws, ws_bytes, a)) return rc;
     a.emb = emb; a.es = emb_stride; a.B = n_rows; a.H = H; a.w = weight; a.b = bias; a.y = target; a.pred = pred; a.loss = loss;
     a.drop_p = p; a.rng = rng_state; a.rng_used = rng_used;
-    bce_head_forward_kernel<<<(int)((n_rows + HEAD_ROWS - 1) / HEAD_ROWS), 256, 0, (hipStream_t)stream>>>(a);
+    const int nblk = (int)((n_rows + HEAD_ROWS - 1) / HEAD_ROWS);
+    bce_head_forward_kernel<<<nblk, 256, 0, (hipStream_t)stream>>>(a);
+    bce_head_forward_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>(a, nblk);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : api_hip_fail(who, e);
 }
@@ -1040,7 +1031,9 @@ static int head_backward(const char* who, const float* emb, int64_t emb_stride, 
     a.emb = emb; a.es = emb_stride; a.B = n_rows; a.H = H; a.w = weight; a.y = target; a.pred = (float*)pred;
     a.gloss = grad_loss; a.gemb = grad_emb; a.ges = grad_emb_stride; a.gw = grad_weight; a.gb = grad_bias;
     a.drop_p = p; a.rng_used = (int64_t*)rng_used;
-    bce_head_backward_kernel<<<(int)((n_rows + HEAD_ROWS - 1) / HEAD_ROWS), 256, 0, (hipStream_t)stream>>>(a);
+    const int nblk = (int)((n_rows + HEAD_ROWS - 1) / HEAD_ROWS);
+    bce_head_backward_kernel<<<nblk, 256, 0, (hipStream_t)stream>>>(a);
+    bce_head_backward_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>(a, nblk);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : api_hip_fail(who, e);
 }

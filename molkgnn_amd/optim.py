@@ -30,18 +30,17 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, maximize=maximize))
         if len(self.param_groups) > 4:
             raise ValueError("FusedAdamW takes at most 4 parameter groups")
-        self._counter = None
         self._table_key = None
         self._table = None
 
-    # -- state: one buffer per parameter, [exp_avg | exp_avg_sq | step]; the three state entries are views of it --
+    # -- state: one buffer per parameter, [exp_avg | exp_avg_sq | step | 2 scratch]; the three state entries are views of it --
     def _packed_state(self, p: torch.Tensor) -> torch.Tensor:
         st = self.state[p]
         n = p.numel()
         buf = st.get("_packed")
-        if buf is not None and st["exp_avg"].data_ptr() == buf.data_ptr() and st["step"].data_ptr() == buf[2 * n:].data_ptr():
+        if buf is not None and st["exp_avg"].data_ptr() == buf.data_ptr() and st["step"].data_ptr() == buf[2 * n:].data_ptr() and buf.numel() == 2 * n + 3:
             return buf
-        new = torch.zeros(2 * n + 1, dtype=torch.float32, device=p.device)
+        new = torch.zeros(2 * n + 3, dtype=torch.float32, device=p.device)   # + step, two scratch floats of the kernels
         if "exp_avg" in st:                                  # e.g. loaded from a state_dict (ours or torch.optim.AdamW's)
             new[:n] = st["exp_avg"].reshape(-1).to(new)
             new[n:2 * n] = st["exp_avg_sq"].reshape(-1).to(new)
@@ -49,7 +48,7 @@ class FusedAdamW(torch.optim.Optimizer):
         st["_packed"] = new
         st["exp_avg"] = new[:n].view_as(p)
         st["exp_avg_sq"] = new[n:2 * n].view_as(p)
-        st["step"] = new[2 * n:].view(())
+        st["step"] = new[2 * n:2 * n + 1].view(())
         self._table_key = None
         return new
 
@@ -96,8 +95,6 @@ class FusedAdamW(torch.optim.Optimizer):
                 rows.append((p.data_ptr(), g.data_ptr(), self._packed_state(p).data_ptr(), p.numel(), gi))
         if not rows:
             return loss
-        if self._counter is None or self._counter.device != dev:
-            self._counter = torch.zeros(1, dtype=torch.int32, device=dev)
         key = tuple(rows)
         if key != self._table_key:                           # pointers are stable from step to step: build the table once
             table = (_lib.AdamWTensor * len(rows))()
@@ -119,7 +116,7 @@ class FusedAdamW(torch.optim.Optimizer):
             e.beta1, e.beta2 = float(group["betas"][0]), float(group["betas"][1])
             e.eps, e.weight_decay, e.maximize = float(group["eps"]), float(group["weight_decay"]), int(bool(group["maximize"]))
         with torch.cuda.device(dev):
-            _lib.check(lib.mkgnn_adamw_step(self._table, len(rows), groups, len(groups), self._counter.data_ptr(),
-                                            _lib.stream_ptr(dev)), "mkgnn_adamw_step")
+            _lib.check(lib.mkgnn_adamw_step(self._table, len(rows), groups, len(groups), _lib.stream_ptr(dev)),
+                       "mkgnn_adamw_step")
         del keep
         return loss
