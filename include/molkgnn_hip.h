@@ -105,7 +105,10 @@ size_t mkgnn_workspace_bytes(const int32_t num_kernels[MKGNN_MAX_DEGREE], int32_
  * variant: 0 = automatic, 1 = generic VALU kernels, 2 = MFMA kernels (exact fp32),
  *          3 = MFMA kernels with bf16 operands for the node-feature dot products (fp32 accumulate; the
  *              "bf16 similarity path": scores within ~1e-3 of the fp32 ones, the chosen order may differ
- *              between near-tied permutations).  2 and 3 fail if a degree's shape is not covered. */
+ *              between near-tied permutations).  2 and 3 fail if a degree's shape is not covered.
+ *          | MKGNN_VARIANT_BLOCK_ROWS: the caller will read only each atom's own column block (as
+ *              mkgnn_segment_sum_block_rows does): nothing outside the blocks is written, not even zeros. */
+#define MKGNN_VARIANT_BLOCK_ROWS 0x100
 int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
                                 const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],
                                 const float* x, int64_t x_stride, const float* inv_norm,
@@ -149,6 +152,21 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
 int mkgnn_segment_sum_rows(const float* in, int64_t in_stride, const int32_t* rowptr,
                            const int32_t* col, int64_t n_rows, int32_t width,
                            float* out, int64_t out_stride, float* inv_norm, void* stream);
+
+/* The same sum where one side is the [N, K] output of a kernel convolution, whose row n is non-zero only in the
+ * column block of atom n's degree (K = sum of num_kernels, block d = columns [off_d, off_d + num_kernels[d-1])):
+ *   mode 1  the gathered rows `in` are block rows (MolGCN.propagate's forward: h = sum of neighbours' sim_sc).  col
+ *           entries carry the source atom's degree (0 = in no bucket, contributes nothing) in bits 28..30; only the
+ *           source's block is read -- ~K / L_d times fewer bytes per edge -- and memory outside the blocks is never
+ *           looked at (the producer may leave it unwritten: MKGNN_VARIANT_BLOCK_ROWS).  out: dense [n_rows, K],
+ *           inv_norm as above.  Bit-identical to mkgnn_segment_sum_rows on the zero-filled input.
+ *   mode 2  the written rows `out` are block rows (its backward: d sim_sc = sum of the targets' dense d h rows, of
+ *           which the convolution's backward reads only atom n's own block).  degree: [n_rows] int8, 0..4; only
+ *           that block of out[n] is summed and written, the rest of the row is left untouched.  inv_norm unused.
+ * Rows must be 16-byte aligned (strides multiples of 4 floats); K <= 255; n_rows < 2^28. */
+int mkgnn_segment_sum_block_rows(const float* in, int64_t in_stride, const int32_t* rowptr, const int32_t* col,
+                                 const int8_t* degree, int64_t n_rows, const int32_t num_kernels[MKGNN_MAX_DEGREE],
+                                 int32_t mode, float* out, int64_t out_stride, float* inv_norm, void* stream);
 
 /* ---- the consumers either side of the convolution stack -------------------
  *

@@ -7,6 +7,8 @@ KernelLayer.py:14,119-123) runs as a CSR segment-sum HIP kernel.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 from torch.nn import ModuleList
 
@@ -14,6 +16,9 @@ from . import functional as Fn
 from .kernels import KernelSetConv
 from .plan import plan_from_lists, plan_from_lists_cached
 from .receptive_field import GraphBatch
+
+# diagnostics: MKGNN_DENSE_PROPAGATE=1 keeps sim_sc dense (zero-filled rows, dense sums) between convolution and propagate
+_BLOCK_ROWS = os.environ.get("MKGNN_DENSE_PROPAGATE") is None
 
 try:
     from torch_geometric.nn import MessagePassing  # type: ignore
@@ -101,7 +106,8 @@ class MolGCN(MessagePassing):
             for i in range(self.num_layers):
                 data.x = h
                 is_last_layer = (i == self.num_layers - 1)
-                sim_sc = self.layers[i]._run(h, self._plan, is_last_layer, save_score)
+                # sim_sc goes nowhere but into propagate: block rows (no zero fill, block-sparse sums both ways)
+                sim_sc = self.layers[i]._run(h, self._plan, is_last_layer, save_score, block_rows=_BLOCK_ROWS)
                 h = self.propagate(edge_index=edge_index, sim_sc=sim_sc)
         finally:
             self._plan = None

@@ -187,6 +187,8 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
     WorkspaceLayout w = make_layout(L, F, E, n_atoms, n_edges);
     if (workspace_bytes < w.fwd_end || !workspace)
         return fail("%s: workspace of %zu bytes, need %zu", who, workspace_bytes, w.fwd_end);
+    const bool block_rows_only = (variant & MKGNN_VARIANT_BLOCK_ROWS) != 0;     // the caller reads only each atom's own block
+    variant &= ~MKGNN_VARIANT_BLOCK_ROWS;
     if (variant < 0 || variant > 3) return fail("%s: variant %d", who, variant);
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
@@ -195,7 +197,7 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
     // every atom's row is zero outside its own degree block (kernels.py:674-675, 725-727): one
     // streaming memset, the degree kernels then write only their column blocks
     // (alignment padding up to the next multiple of four columns is zeroed with it when the stride holds it)
-    if (n_atoms > 0 && K > 0) {
+    if (n_atoms > 0 && K > 0 && !block_rows_only) {
         const int64_t K4 = (K + 3) / 4 * 4;
         if (K4 == out_stride) e = hipMemsetAsync(out, 0, (size_t)n_atoms * out_stride * 4, st);   // contiguous: one fill kernel, not two
         else e = hipMemset2DAsync(out, (size_t)out_stride * 4, 0, (size_t)(K4 <= out_stride ? K4 : K) * 4, (size_t)n_atoms, st);
@@ -410,6 +412,27 @@ int mkgnn_segment_sum_rows(const float* in, int64_t in_stride, const int32_t* ro
     if (n_rows && (!in || !rowptr || !out)) return fail("mkgnn_segment_sum_rows: null pointer");
     hipError_t e = launch_segment_sum(in, in_stride, rowptr, col, n_rows, width, out, out_stride, inv_norm, (hipStream_t)stream);
     return e == hipSuccess ? 0 : hip_fail("mkgnn_segment_sum_rows", e);
+}
+
+int mkgnn_segment_sum_block_rows(const float* in, int64_t in_stride, const int32_t* rowptr, const int32_t* col,
+                                 const int8_t* degree, int64_t n_rows, const int32_t num_kernels[MKGNN_MAX_DEGREE],
+                                 int32_t mode, float* out, int64_t out_stride, float* inv_norm, void* stream) {
+    const char* who = "mkgnn_segment_sum_block_rows";
+    if (mode != 1 && mode != 2) return fail("%s: mode %d (1 = block-row sources, 2 = block-row destinations)", who, mode);
+    if (!num_kernels) return fail("%s: num_kernels is null", who);
+    int width = 0;
+    for (int i = 0; i < MKGNN_MAX_DEGREE; ++i) {
+        if (num_kernels[i] < 0 || num_kernels[i] > 255) return fail("%s: num_kernels[%d] = %d outside 0..255", who, i, num_kernels[i]);
+        width += num_kernels[i];
+    }
+    if (n_rows < 0 || width <= 0 || in_stride < width || out_stride < width) return fail("%s: bad shape", who);
+    if (n_rows == 0) return 0;
+    if (!in || !rowptr || !col || !out || (mode == 2 && !degree)) return fail("%s: null pointer", who);
+    if (!segment_sum_blocks_supported(in, in_stride, n_rows, width, out, out_stride))
+        return fail("%s: needs 16-byte aligned rows (strides multiples of 4 floats), at most 255 columns and fewer than 2^28 rows", who);
+    hipError_t e = launch_segment_sum_blocks(in, in_stride, rowptr, col, degree, n_rows, width, num_kernels, mode, out, out_stride,
+                                             inv_norm, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(who, e);
 }
 
 }  // extern "C"

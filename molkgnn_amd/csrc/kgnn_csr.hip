@@ -30,6 +30,10 @@ struct CsrArgs {
     float* out; int64_t os;
     float* inv_out;                        // segment sum: optional row norms of out
     const float* x; int64_t xs; const float* inv;   // gather: the forward's rows and their norms
+    // block rows (BLK != 0): a row of a kernel-convolution output is non-zero only in the column block of its atom's
+    // degree d: columns [off(d), off(d) + len(d)), byte d of the two packed tables (len 0 = no block)
+    const int8_t* deg8;                    // BLK == 2: degree of every destination row
+    uint64_t blk_off, blk_len;
 };
 
 template <int LPR>
@@ -39,14 +43,30 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// v where `keep`, else +0 -- as a bit mask, not a branch or a select on the value: the compiler turns "if (c) acc += v"
+// on a freshly loaded v into a conditional block that CONTAINS the load and ends with s_waitcnt vmcnt(0), which waits
+// for every load in flight (the prefetched indices and row pointers of the next groups included).
+__device__ __forceinline__ f32x4 keep_if(f32x4 v, bool keep) {
+    const uint32_t m = keep ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) v[c] = __uint_as_float(__float_as_uint(v[c]) & m);
+    return v;
+}
+
 __device__ __forceinline__ f32x4 mask_cols(f32x4 v, int col, int width) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) v[c] = (col + c < width) ? v[c] : 0.f;
     return v;
 }
 
-template <int LPR, bool GATHER>
+// BLK = 1: the gathered rows are block rows -- an index entry carries its row's degree in bits 28..30, a lane loads
+//          only where its four columns meet that block and keeps only the block's columns (what lies outside the
+//          block in memory is never used: the producer need not zero it);
+// BLK = 2: the written rows are block rows -- only the columns of the destination's own block are summed and stored.
+// The loads stay unconditional: see row_load.
+template <int LPR, bool GATHER, int BLK = 0>
 __global__ void __launch_bounds__(256) csr_rows_kernel(CsrArgs a) {
+    static_assert(!(GATHER && BLK), "block rows: segment sums only");
     constexpr int RPW = 64 / LPR, SEG = 4;
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR, l = lane % LPR;
@@ -60,34 +80,68 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(CsrArgs a) {
     const int32_t* idxp = last >= 0 ? a.idx : a.rowptr;  // an empty index list is never dereferenced
     last = last >= 0 ? last : 0;
 
-    auto segment = [&](int64_t g, int& lo, int& hi) -> int64_t {
+    auto segment = [&](int64_t g, int& lo, int& hi, int& dg) -> int64_t {
         const int64_t j = g * RPW + sub;
         const int64_t jc = j < a.n ? j : a.n - 1;
         lo = a.rowptr[jc];
         hi = a.rowptr[jc + 1];
+        if constexpr (BLK == 2) dg = a.deg8[jc];
         if (j >= a.n || g >= ngroups) hi = lo;
         return jc;
+    };
+    // [b0, b1) = column block of degree d; "meets" = this lane's four columns intersect it
+    auto block_of = [&](int d, int& b0, int& b1) {
+        b0 = (int)((a.blk_off >> (8 * (d & 7))) & 0xFF);
+        b1 = b0 + (int)((a.blk_len >> (8 * (d & 7))) & 0xFF);
+    };
+    // A lane whose four columns miss the block reads the nearest 16 bytes of the block instead -- the same cache
+    // lines the other lanes of its row fetch, so it adds no traffic (a fixed dummy address made one hot spot of a
+    // few lines that every wave hammered) -- and its value is masked / never stored.
+    auto row_load = [&](int rid_raw, int dst_b0, int dst_b1) -> f32x4 {
+        int row = rid_raw, c = colc;
+        if constexpr (BLK != 0) {
+            int b0 = dst_b0, b1 = dst_b1;
+            if constexpr (BLK == 1) {
+                block_of((unsigned)rid_raw >> 28, b0, b1);
+                row = rid_raw & 0x0FFFFFFF;
+            }
+            const int lo4 = b0 & ~3, hi4 = (b1 - 1) & ~3;
+            c = c < lo4 ? lo4 : (c > hi4 ? hi4 : c);
+            if (b1 <= b0) c = 0;                          // no block at all (atom in no bucket): any valid address
+        }
+        return *(const f32x4*)(a.src + (uint64_t)(uint32_t)row * (uint32_t)a.ss + (uint32_t)c);      // one v_mad_u64_u32
+    };
+    auto row_keep = [&](f32x4 v, int rid_raw) -> f32x4 {        // BLK == 1: only the source's own block counts
+        if constexpr (BLK == 1) {
+            int b0, b1;
+            block_of((unsigned)rid_raw >> 28, b0, b1);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = (col + c >= b0 && col + c < b1) ? v[c] : 0.f;
+        }
+        return v;
     };
     auto ids = [&](int lo, int hi, int k0, int (&rid)[SEG]) {
 #pragma unroll
         for (int u = 0; u < SEG; ++u) {
             int k = k0 + u < hi ? k0 + u : lo;
             k = k < last ? k : last;
-            rid[u] = idxp[k];
+            rid[u] = idxp[(uint32_t)k];                  // (non-negative: zero-extension, no 64-bit sign arithmetic)
         }
     };
 
-    int lo_c, hi_c, lo_n, hi_n;
+    int lo_c, hi_c, lo_n, hi_n, dg_c = 0, dg_n = 0;
     int rid_c[SEG], rid_n[SEG];
     int64_t g = wave0;
-    int64_t j_c = segment(g, lo_c, hi_c);
+    int64_t j_c = segment(g, lo_c, hi_c, dg_c);
     ids(lo_c, hi_c, lo_c, rid_c);
-    int64_t j_n = segment(g + nwaves, lo_n, hi_n);
+    int64_t j_n = segment(g + nwaves, lo_n, hi_n, dg_n);
     for (; g < ngroups; g += nwaves) {
         // ---- issue: rows of this group, indices of the next, row pointers of the one after
+        int d0 = 0, d1 = 0;                                // BLK == 2: the destination's block
+        if constexpr (BLK == 2) block_of(dg_c, d0, d1);
         f32x4 v[SEG];
 #pragma unroll
-        for (int u = 0; u < SEG; ++u) v[u] = *(const f32x4*)(a.src + (int64_t)rid_c[u] * a.ss + colc);
+        for (int u = 0; u < SEG; ++u) v[u] = row_load(rid_c[u], d0, d1);
         f32x4 xv;
         float iv = 0.f;
         if constexpr (GATHER) {
@@ -95,23 +149,21 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(CsrArgs a) {
             iv = a.inv[j_c];
         }
         ids(lo_n, hi_n, lo_n, rid_n);
-        int lo_nn, hi_nn;
-        const int64_t j_nn = segment(g + 2 * nwaves, lo_nn, hi_nn);
+        int lo_nn, hi_nn, dg_nn = 0;
+        const int64_t j_nn = segment(g + 2 * nwaves, lo_nn, hi_nn, dg_nn);
         // ---- consume
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        f32x4 acc = keep_if(row_keep(v[0], rid_c[0]), lo_c < hi_c);
 #pragma unroll
-        for (int u = 0; u < SEG; ++u)
-            if (lo_c + u < hi_c) acc += v[u];
+        for (int u = 1; u < SEG; ++u) acc += keep_if(row_keep(v[u], rid_c[u]), lo_c + u < hi_c);
         if (__any(hi_c - lo_c > SEG)) {                 // long segments: rare (more than four bonds / five roles)
             for (int k0 = lo_c + SEG; __any(k0 < hi_c); k0 += SEG) {
                 int rid[SEG];
                 ids(lo_c, hi_c, k0, rid);
                 f32x4 w[SEG];
 #pragma unroll
-                for (int u = 0; u < SEG; ++u) w[u] = *(const f32x4*)(a.src + (int64_t)rid[u] * a.ss + colc);
+                for (int u = 0; u < SEG; ++u) w[u] = row_load(rid[u], d0, d1);
 #pragma unroll
-                for (int u = 0; u < SEG; ++u)
-                    if (k0 + u < hi_c) acc += w[u];
+                for (int u = 0; u < SEG; ++u) acc += keep_if(row_keep(w[u], rid[u]), k0 + u < hi_c);
             }
         }
         acc = mask_cols(acc, active ? col : a.width, a.width);
@@ -127,6 +179,17 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(CsrArgs a) {
 #pragma unroll
             for (int c = 0; c < 4; ++c) r[c] = clamped ? acc[c] * iv : (acc[c] - dotp * xh[c]) * iv;
             if (row_ok && active) *(f32x4*)(a.out + j_c * a.os + col) = r;
+        } else if constexpr (BLK == 2) {
+            // only the destination's own block is defined; the rest of its row is left as it is
+            if (row_ok && active && col + 3 >= d0 && col < d1) {
+                float* dst = a.out + j_c * a.os + col;
+                if (col >= d0 && col + 3 < d1) *(f32x4*)dst = acc;
+                else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (col + c >= d0 && col + c < d1) dst[c] = acc[c];
+                }
+            }
         } else {
             if (row_ok && active) *(f32x4*)(a.out + j_c * a.os + col) = acc;     // alignment padding is written as zero
             if (a.inv_out) {
@@ -137,10 +200,10 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(CsrArgs a) {
             }
         }
         // ---- shift the pipeline
-        lo_c = lo_n; hi_c = hi_n; j_c = j_n;
+        lo_c = lo_n; hi_c = hi_n; j_c = j_n; dg_c = dg_n;
 #pragma unroll
         for (int u = 0; u < SEG; ++u) rid_c[u] = rid_n[u];
-        lo_n = lo_nn; hi_n = hi_nn; j_n = j_nn;
+        lo_n = lo_nn; hi_n = hi_nn; j_n = j_nn; dg_n = dg_nn;
     }
 }
 
@@ -198,6 +261,38 @@ static hipError_t launch_csr(const CsrArgs& a, hipStream_t st) {
         default: csr_rows_kernel<64, GATHER><<<csr_grid(a.n, 1), 256, 0, st>>>(a); break;
     }
     return hipGetLastError();
+}
+
+template <int BLK>
+static hipError_t launch_csr_blocks(const CsrArgs& a, hipStream_t st) {
+    switch (lanes_per_row(a.width)) {
+        case 8: csr_rows_kernel<8, false, BLK><<<csr_grid(a.n, 8), 256, 0, st>>>(a); break;
+        case 16: csr_rows_kernel<16, false, BLK><<<csr_grid(a.n, 4), 256, 0, st>>>(a); break;
+        case 32: csr_rows_kernel<32, false, BLK><<<csr_grid(a.n, 2), 256, 0, st>>>(a); break;
+        default: csr_rows_kernel<64, false, BLK><<<csr_grid(a.n, 1), 256, 0, st>>>(a); break;
+    }
+    return hipGetLastError();
+}
+
+// Block-row segment sums (see csr_rows_kernel): no fallback, the caller checks segment_sum_blocks_supported first.
+bool segment_sum_blocks_supported(const float* in, int64_t is, int64_t n, int width, const float* out, int64_t os) {
+    return n > 0 && n < (1 << 28) && width <= 255 && aligned_rows(in, is, width) && aligned_rows(out, os, width);
+}
+
+hipError_t launch_segment_sum_blocks(const float* in, int64_t is, const int32_t* rowptr, const int32_t* col, const int8_t* deg8,
+                                     int64_t n, int width, const int32_t L[4], int mode, float* out, int64_t os,
+                                     float* inv_norm, hipStream_t st) {
+    CsrArgs a{};
+    a.src = in; a.ss = is; a.rowptr = rowptr; a.idx = col; a.n = n; a.width = width; a.out = out; a.os = os;
+    a.inv_out = mode == 1 ? inv_norm : nullptr;
+    a.deg8 = deg8;
+    int off = 0;
+    for (int d = 1; d <= 4; ++d) {
+        a.blk_off |= (uint64_t)off << (8 * d);
+        a.blk_len |= (uint64_t)L[d - 1] << (8 * d);
+        off += L[d - 1];
+    }
+    return mode == 1 ? launch_csr_blocks<1>(a, st) : launch_csr_blocks<2>(a, st);
 }
 
 // Fast paths; the callers fall back to the one-row-per-wave kernels when these decline (return false).

@@ -104,6 +104,10 @@ hipError_t launch_backward_gather(const float* contrib, int64_t cs, int64_t n_co
                                   const int32_t* rows, const float* x, int64_t xs, const float* inv, int64_t n, int F,
                                   float* gx, int64_t gxs, hipStream_t st);
 // kgnn_csr.hip: pipelined variants for 16-byte aligned rows of <= 256 floats; false = not applicable
+bool segment_sum_blocks_supported(const float* in, int64_t is, int64_t n, int width, const float* out, int64_t os);
+hipError_t launch_segment_sum_blocks(const float* in, int64_t is, const int32_t* rowptr, const int32_t* col, const int8_t* deg8,
+                                     int64_t n, int width, const int32_t L[4], int mode, float* out, int64_t os,
+                                     float* inv_norm, hipStream_t st);
 bool try_segment_sum_aligned(const float* in, int64_t is, const int32_t* rowptr, const int32_t* col, int64_t n, int width,
                              float* out, int64_t os, float* inv_norm, hipStream_t st, hipError_t* err);
 bool try_backward_gather_aligned(const float* contrib, int64_t cs, const int32_t* rowptr, const int32_t* rows, const float* x,

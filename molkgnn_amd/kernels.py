@@ -194,7 +194,7 @@ class BaseKernelSetConv(Module):
                 [kwargv[f'nei_index_deg{d}'] for d in range(1, 5)], kwargv['edge_index'])
         return self._run(x, plan, is_last_layer, save_score)
 
-    def _run(self, x, plan: BatchPlan, is_last_layer, save_score=False):
+    def _run(self, x, plan: BatchPlan, is_last_layer, save_score=False, block_rows=False):
         for d in range(1, 5):
             if plan.buckets[d - 1].count and self.fixed_kernelconv_set[d - 1] is None \
                     and self.trainable_kernelconv_set[d - 1] is None:
@@ -204,7 +204,9 @@ class BaseKernelSetConv(Module):
         has_train = any(k is not None for k in self.trainable_kernelconv_set)
         if has_train and not has_fixed:
             params, E = self._bank_params("train", x)
-            sc = Fn.kernelsetconv(x, plan, is_last_layer, params, E, self.variant, self.out_pad)
+            block_rows = (bool(block_rows) and not save_score and self.out_pad is None
+                          and plan.block_rows_ok(sum(int(p.shape[0]) for p in params[0::7])))
+            sc = Fn.kernelsetconv(x, plan, is_last_layer, params, E, self.variant, self.out_pad, block_rows=block_rows)
         else:
             # fixed kernels come first inside every degree block (kernels.py:702-710)
             parts = {}

@@ -55,6 +55,8 @@ class BatchPlan:
         self._scatter = None
         self._csr_in = None
         self._csr_out = None
+        self._deg8 = None
+        self._csr_in_packed = None
 
     # -- backward scatter CSR -------------------------------------------------
     @property
@@ -97,6 +99,33 @@ class BatchPlan:
         if self._csr_out is None:
             self._csr_out = self._csr(self.edge_index[0], self.edge_index[1])
         return self._csr_out
+
+
+    # -- block rows: which column block of a convolution output belongs to an atom -----
+    @property
+    def deg8(self):
+        """[n_atoms] int8: the degree bucket every atom is in (0 = none)."""
+        if self._deg8 is None:
+            d8 = torch.zeros(self.n_atoms, dtype=torch.int8, device=self.device)
+            for b in self.buckets:
+                if b.count:
+                    d8[b.sel] = b.degree
+            self._deg8 = d8
+        return self._deg8
+
+    @property
+    def csr_in_packed(self):
+        """``csr_in`` with the source atom's degree in bits 28..30 of every column entry
+        (``mkgnn_segment_sum_block_rows`` mode 1)."""
+        if self._csr_in_packed is None:
+            rowptr, col = self.csr_in
+            packed = col | (self.deg8[col.long()].to(torch.int32) << 28)
+            self._csr_in_packed = (rowptr, packed.contiguous())
+        return self._csr_in_packed
+
+    def block_rows_ok(self, K: int) -> bool:
+        """Can propagate run on block rows (``functional.propagate_add(..., blocks=...)``) for this batch?"""
+        return (self.edge_index is not None and self.edge_index.numel() > 0 and self.n_atoms < (1 << 28) and 0 < K <= 255)
 
 
 def plan_from_lists(n_atoms, p_focal_list, nei_p_list, nei_edge_attr_list, selected_index_list, nei_index_list,
@@ -144,7 +173,7 @@ def plan_from_lists_cached(n_atoms, p_focal_list, nei_p_list, nei_edge_attr_list
     # happen inside a later backward pass or a hipGraph capture
     _ = plan.scatter
     if edge_index is not None:
-        _ = plan.csr_in, plan.csr_out
+        _ = plan.csr_in, plan.csr_out, plan.csr_in_packed
     if len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
         _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
     _PLAN_CACHE[key] = (plan, [weakref.ref(t) for t in tensors])

@@ -1035,3 +1035,82 @@ def test_head_dropout_draws_a_new_mask_on_every_graph_replay():
     assert int(R.head_rng_state(dev)[1]) == before + 2
     assert float((a_mask != b_mask).float().mean()) > 0.2
     R.reset_head_rng(dev)
+
+
+# ------------------------------------------------------------------------------- block-row propagate --
+def test_block_row_propagate_matches_dense_bitwise():
+    """mkgnn_segment_sum_block_rows against the dense sum: (1) sources as block rows, with NaN everywhere outside the
+    blocks (nothing there may be read) -> bit-identical h and row norms; (2) destinations as block rows -> every atom's
+    own block bit-identical, the rest of the row untouched.  Atoms in no bucket (degree 0 / 9) contribute nothing."""
+    from molkgnn_amd import functional as Fn
+    from molkgnn_amd.plan import plan_from_data
+    from molkgnn_amd.receptive_field import attach_receptive_fields
+    from molkgnn_amd.synthetic import make_batch
+    dev = _dev()
+    for Ls in [(10, 20, 30, 50), (3, 0, 7, 6), (16, 16, 16, 16)]:
+        b = make_batch(40, seed=21, device=dev)
+        # a hub of degree 9 and an isolated atom: in no bucket
+        n = b.x.shape[0]
+        hub, extra = 0, torch.arange(n - 9, n - 1, device=dev)
+        ei = torch.cat([b.edge_index, torch.stack([torch.full_like(extra, hub), extra]), torch.stack([extra, torch.full_like(extra, hub)])], dim=1)
+        keep = (ei[0] != n - 1) & (ei[1] != n - 1)
+        b.edge_index = ei[:, keep]
+        b.edge_attr = torch.rand(b.edge_index.shape[1], 7, device=dev)
+        attach_receptive_fields(b)
+        plan = plan_from_data(b)
+        K = sum(Ls)
+        offs = [0, Ls[0], Ls[0] + Ls[1], Ls[0] + Ls[1] + Ls[2]]
+        deg = plan.deg8.long()
+        assert int((deg == 0).sum()) >= 2
+        col = torch.arange(K, device=dev)[None, :]
+        lo = torch.tensor([0] + offs, device=dev)[deg][:, None]
+        ln = torch.tensor([0] + list(Ls), device=dev)[deg][:, None]
+        inblock = (col >= lo) & (col < lo + ln)
+        pad = (-K) % 4
+        dense = torch.zeros(n, K + pad, device=dev)
+        dense[:, :K] = torch.where(inblock, torch.randn(n, K, device=dev), torch.zeros((), device=dev))
+        sparse = torch.full((n, K + pad), float("nan"), device=dev)
+        sparse[:, :K] = torch.where(inblock, dense[:, :K], sparse[:, :K])
+        h_ref = Fn.propagate_add(dense[:, :K], plan, out_pad=pad)
+        sp = sparse[:, :K]
+        setattr(sp, Fn._BLOCKS_ATTR, tuple(Ls))
+        h_blk = Fn.propagate_add(sp, plan, out_pad=pad)
+        assert torch.equal(h_ref, h_blk)
+        assert torch.equal(getattr(h_ref, Fn._INV_ATTR)[0], getattr(h_blk, Fn._INV_ATTR)[0])
+        # backward
+        g = torch.randn(n, K + pad, device=dev)[:, :K]
+        g_ref = Fn._segment_sum(g, plan.csr_out, pad)
+        g_blk = Fn._segment_sum_blocks(g, plan.csr_out, plan.deg8, tuple(Ls), 2, pad, None)
+        assert torch.equal(torch.where(inblock, g_ref, torch.zeros((), device=dev)),
+                           torch.where(inblock, g_blk, torch.zeros((), device=dev)))
+
+
+def test_molgcn_block_rows_equals_dense_path():
+    """The 3-layer MolGCN with sim_sc kept as block rows between convolution and propagate (the default) against the
+    dense form (zero-filled rows, dense sums; MKGNN_DENSE_PROPAGATE): output and every gradient bit for bit."""
+    import copy
+    from molkgnn_amd import KernelLayer as KL
+    from molkgnn_amd.synthetic import make_batch
+    from molkgnn_amd.MolKGNNNet import MolKGNNNet
+    dev = _dev()
+    torch.manual_seed(3)
+    b = make_batch(64, seed=5, device=dev)
+    net = MolKGNNNet(num_layers=3, num_kernel1_1hop=10, num_kernel2_1hop=20, num_kernel3_1hop=30, num_kernel4_1hop=50,
+                     num_kernel1_Nhop=10, num_kernel2_Nhop=20, num_kernel3_Nhop=30, num_kernel4_Nhop=50,
+                     x_dim=28, edge_attr_dim=7, graph_embedding_dim=32, drop_ratio=0.0).to(dev)
+    net2 = copy.deepcopy(net)
+    cot = torch.randn(64, 32, device=dev)
+    res = []
+    for model, blk in ((net, True), (net2, False)):
+        old = KL._BLOCK_ROWS
+        KL._BLOCK_ROWS = blk
+        try:
+            out = model(b)
+            (out * cot).sum().backward()
+        finally:
+            KL._BLOCK_ROWS = old
+        res.append((out.detach(), {n_: p.grad for n_, p in model.named_parameters() if p.grad is not None}))
+    assert torch.equal(res[0][0], res[1][0])
+    assert res[0][1].keys() == res[1][1].keys() and len(res[0][1]) > 20
+    for k in res[0][1]:
+        assert torch.equal(res[0][1][k], res[1][1][k]), k
