@@ -68,106 +68,140 @@ template <int LPR, bool GATHER, int BLK = 0>
 __global__ void __launch_bounds__(256) csr_rows_kernel(CsrArgs a) {
     static_assert(!(GATHER && BLK), "block rows: segment sums only");
     constexpr int RPW = 64 / LPR, SEG = 4;
+    static_assert(LPR >= SEG, "one index per lane of a row group");
     const int lane = threadIdx.x & 63;
     const int sub = lane / LPR, l = lane % LPR;
     const int col = 4 * l;
     const bool active = col < a.width;                  // this lane holds columns col .. col + 3
     const int colc = active ? col : 0;
-    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    const int64_t ngroups = (a.n + RPW - 1) / RPW;
-    int last = a.rowptr[a.n] - 1;
+    // 32-bit row / group arithmetic throughout (the host launches these kernels for n < 2^31 - 2^20 rows; rowptr is
+    // int32 anyway): the 64-bit compares and multiply-adds of the index bookkeeping were a third of the VALU work,
+    // and the VALU is ~50 % busy in these kernels (PMC: 436 VALU instructions per wave for 3 groups of 2 rows).
+    const int n = (int)a.n;
+    const int wave0 = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+    const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+    const int ngroups = (n + RPW - 1) / RPW;
+    int last = a.rowptr[n] - 1;
     const int32_t* idxp = last >= 0 ? a.idx : a.rowptr;  // an empty index list is never dereferenced
     last = last >= 0 ? last : 0;
 
-    auto segment = [&](int64_t g, int& lo, int& hi, int& dg) -> int64_t {
-        const int64_t j = g * RPW + sub;
-        const int64_t jc = j < a.n ? j : a.n - 1;
-        lo = a.rowptr[jc];
-        hi = a.rowptr[jc + 1];
-        if constexpr (BLK == 2) dg = a.deg8[jc];
-        if (j >= a.n || g >= ngroups) hi = lo;
+    auto segment = [&](int g, int& lo, int& hi, int& dg) -> int {
+        const int j = g * RPW + sub;
+        const int jc = (j < n && g < ngroups) ? j : n - 1;
+        lo = a.rowptr[(uint32_t)jc];
+        hi = a.rowptr[(uint32_t)jc + 1];
+        if constexpr (BLK == 2) dg = a.deg8[(uint32_t)jc];
+        if (j >= n || g >= ngroups) hi = lo;
         return jc;
     };
-    // [b0, b1) = column block of degree d; "meets" = this lane's four columns intersect it
+    // [b0, b1) = column block of degree d
     auto block_of = [&](int d, int& b0, int& b1) {
         b0 = (int)((a.blk_off >> (8 * (d & 7))) & 0xFF);
         b1 = b0 + (int)((a.blk_len >> (8 * (d & 7))) & 0xFF);
     };
+    // BLK == 1: this lane's columns are fixed, so what it does with a source of degree d is too: which of its four
+    // elements lie in block d (4 bits) and which 16 bytes it reads (its own, or the nearest of the block).  Both
+    // tables fit one register each (degrees 0..4, 4 resp. 6 bits per entry).
+    uint32_t keep_tab = 0, col_tab = 0;
+    if constexpr (BLK == 1) {
+#pragma unroll
+        for (int d = 1; d <= 4; ++d) {
+            int b0, b1;
+            block_of(d, b0, b1);
+            uint32_t m = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) m |= (uint32_t)(col + c >= b0 && col + c < b1) << c;
+            const int lo4 = b0 & ~3, hi4 = (b1 - 1) & ~3;
+            int cc = colc < lo4 ? lo4 : (colc > hi4 ? hi4 : colc);
+            if (b1 <= b0) cc = 0;
+            keep_tab |= m << (4 * d);
+            col_tab |= (uint32_t)(cc >> 2) << (6 * d);
+        }
+    }
     // A lane whose four columns miss the block reads the nearest 16 bytes of the block instead -- the same cache
     // lines the other lanes of its row fetch, so it adds no traffic (a fixed dummy address made one hot spot of a
     // few lines that every wave hammered) -- and its value is masked / never stored.
     auto row_load = [&](int rid_raw, int dst_b0, int dst_b1) -> f32x4 {
         int row = rid_raw, c = colc;
-        if constexpr (BLK != 0) {
-            int b0 = dst_b0, b1 = dst_b1;
-            if constexpr (BLK == 1) {
-                block_of((unsigned)rid_raw >> 28, b0, b1);
-                row = rid_raw & 0x0FFFFFFF;
-            }
-            const int lo4 = b0 & ~3, hi4 = (b1 - 1) & ~3;
+        if constexpr (BLK == 1) {
+            const uint32_t d = (uint32_t)rid_raw >> 28;
+            row = rid_raw & 0x0FFFFFFF;
+            c = (int)((col_tab >> (6 * d)) & 63) << 2;
+        } else if constexpr (BLK == 2) {
+            const int lo4 = dst_b0 & ~3, hi4 = (dst_b1 - 1) & ~3;
             c = c < lo4 ? lo4 : (c > hi4 ? hi4 : c);
-            if (b1 <= b0) c = 0;                          // no block at all (atom in no bucket): any valid address
+            if (dst_b1 <= dst_b0) c = 0;                  // no block at all (atom in no bucket): any valid address
         }
         return *(const f32x4*)(a.src + (uint64_t)(uint32_t)row * (uint32_t)a.ss + (uint32_t)c);      // one v_mad_u64_u32
     };
-    auto row_keep = [&](f32x4 v, int rid_raw) -> f32x4 {        // BLK == 1: only the source's own block counts
+    // v where the source is valid and, BLK == 1, inside the source's own block; +0 elsewhere (bit masks: see keep_if)
+    auto row_keep = [&](f32x4 v, int rid_raw, bool valid) -> f32x4 {
         if constexpr (BLK == 1) {
-            int b0, b1;
-            block_of((unsigned)rid_raw >> 28, b0, b1);
+            const int m = valid ? (int)(keep_tab >> (4 * ((uint32_t)rid_raw >> 28))) : 0;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) v[c] = (col + c >= b0 && col + c < b1) ? v[c] : 0.f;
+            for (int c = 0; c < 4; ++c)
+                v[c] = __uint_as_float(__float_as_uint(v[c]) & (uint32_t)__builtin_amdgcn_sbfe(m, c, 1));   // bit c -> 0 / ~0
+            return v;
+        } else {
+            return keep_if(v, valid);
         }
-        return v;
     };
-    auto ids = [&](int lo, int hi, int k0, int (&rid)[SEG]) {
+    // The SEG indices of a row: ONE load instruction per wave -- lane l of the row's group fetches entry
+    // k0 + (l % SEG) -- and a crossbar broadcast (ds_bpermute, no memory pipe) when they are used, one group later.
+    // Every lane loading its own copy of all SEG entries cost SEG address-pipe passes per group for two distinct
+    // cache lines; the address pipe, not HBM, bounds these kernels (the block-row forms, with a fifth of the bytes,
+    // take the same time).
+    auto idx_issue = [&](int lo, int hi, int k0) -> int {
+        const int u_mine = l & (SEG - 1);
+        int k = k0 + u_mine < hi ? k0 + u_mine : lo;
+        k = k < last ? k : last;
+        return idxp[(uint32_t)k];
+    };
+    auto idx_bcast = [&](int mine, int (&rid)[SEG]) {
 #pragma unroll
-        for (int u = 0; u < SEG; ++u) {
-            int k = k0 + u < hi ? k0 + u : lo;
-            k = k < last ? k : last;
-            rid[u] = idxp[(uint32_t)k];                  // (non-negative: zero-extension, no 64-bit sign arithmetic)
-        }
+        for (int u = 0; u < SEG; ++u) rid[u] = __shfl(mine, sub * LPR + u, 64);
     };
 
     int lo_c, hi_c, lo_n, hi_n, dg_c = 0, dg_n = 0;
-    int rid_c[SEG], rid_n[SEG];
-    int64_t g = wave0;
-    int64_t j_c = segment(g, lo_c, hi_c, dg_c);
-    ids(lo_c, hi_c, lo_c, rid_c);
-    int64_t j_n = segment(g + nwaves, lo_n, hi_n, dg_n);
+    int g = wave0;
+    int j_c = segment(g, lo_c, hi_c, dg_c);
+    int mine_c = idx_issue(lo_c, hi_c, lo_c);
+    int j_n = segment(g + nwaves, lo_n, hi_n, dg_n);
     for (; g < ngroups; g += nwaves) {
         // ---- issue: rows of this group, indices of the next, row pointers of the one after
         int d0 = 0, d1 = 0;                                // BLK == 2: the destination's block
         if constexpr (BLK == 2) block_of(dg_c, d0, d1);
+        int rid_c[SEG];
+        idx_bcast(mine_c, rid_c);
         f32x4 v[SEG];
 #pragma unroll
         for (int u = 0; u < SEG; ++u) v[u] = row_load(rid_c[u], d0, d1);
         f32x4 xv;
         float iv = 0.f;
         if constexpr (GATHER) {
-            xv = *(const f32x4*)(a.x + j_c * a.xs + colc);
+            xv = *(const f32x4*)(a.x + (uint64_t)(uint32_t)j_c * (uint32_t)a.xs + colc);
             iv = a.inv[j_c];
         }
-        ids(lo_n, hi_n, lo_n, rid_n);
+        const int mine_n = idx_issue(lo_n, hi_n, lo_n);
         int lo_nn, hi_nn, dg_nn = 0;
-        const int64_t j_nn = segment(g + 2 * nwaves, lo_nn, hi_nn, dg_nn);
+        const int j_nn = segment(g + 2 * nwaves, lo_nn, hi_nn, dg_nn);
         // ---- consume
-        f32x4 acc = keep_if(row_keep(v[0], rid_c[0]), lo_c < hi_c);
+        f32x4 acc = row_keep(v[0], rid_c[0], lo_c < hi_c);
 #pragma unroll
-        for (int u = 1; u < SEG; ++u) acc += keep_if(row_keep(v[u], rid_c[u]), lo_c + u < hi_c);
+        for (int u = 1; u < SEG; ++u) acc += row_keep(v[u], rid_c[u], lo_c + u < hi_c);
         if (__any(hi_c - lo_c > SEG)) {                 // long segments: rare (more than four bonds / five roles)
             for (int k0 = lo_c + SEG; __any(k0 < hi_c); k0 += SEG) {
                 int rid[SEG];
-                ids(lo_c, hi_c, k0, rid);
+                idx_bcast(idx_issue(lo_c, hi_c, k0), rid);
                 f32x4 w[SEG];
 #pragma unroll
                 for (int u = 0; u < SEG; ++u) w[u] = row_load(rid[u], d0, d1);
 #pragma unroll
-                for (int u = 0; u < SEG; ++u) acc += keep_if(row_keep(w[u], rid[u]), k0 + u < hi_c);
+                for (int u = 0; u < SEG; ++u) acc += row_keep(w[u], rid[u], k0 + u < hi_c);
             }
         }
         acc = mask_cols(acc, active ? col : a.width, a.width);
-        const bool row_ok = g * RPW + sub < a.n;
+        const bool row_ok = g * RPW + sub < n;
         if constexpr (GATHER) {
             // d/dx of x / max(|x|, eps): (acc - (acc . xh) xh) * inv, or acc * inv where the clamp is active
             f32x4 xh = mask_cols(xv, active ? col : a.width, a.width) * iv;
@@ -178,11 +212,11 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(CsrArgs a) {
             f32x4 r;
 #pragma unroll
             for (int c = 0; c < 4; ++c) r[c] = clamped ? acc[c] * iv : (acc[c] - dotp * xh[c]) * iv;
-            if (row_ok && active) *(f32x4*)(a.out + j_c * a.os + col) = r;
+            if (row_ok && active) *(f32x4*)(a.out + (uint64_t)(uint32_t)j_c * (uint32_t)a.os + col) = r;
         } else if constexpr (BLK == 2) {
             // only the destination's own block is defined; the rest of its row is left as it is
             if (row_ok && active && col + 3 >= d0 && col < d1) {
-                float* dst = a.out + j_c * a.os + col;
+                float* dst = a.out + (uint64_t)(uint32_t)j_c * (uint32_t)a.os + col;
                 if (col >= d0 && col + 3 < d1) *(f32x4*)dst = acc;
                 else {
 #pragma unroll
@@ -191,7 +225,7 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(CsrArgs a) {
                 }
             }
         } else {
-            if (row_ok && active) *(f32x4*)(a.out + j_c * a.os + col) = acc;     // alignment padding is written as zero
+            if (row_ok && active) *(f32x4*)(a.out + (uint64_t)(uint32_t)j_c * (uint32_t)a.os + col) = acc;     // alignment padding is written as zero
             if (a.inv_out) {
                 float ss = acc[0] * acc[0];
                 ss = fmaf(acc[1], acc[1], ss); ss = fmaf(acc[2], acc[2], ss); ss = fmaf(acc[3], acc[3], ss);
@@ -200,9 +234,7 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(CsrArgs a) {
             }
         }
         // ---- shift the pipeline
-        lo_c = lo_n; hi_c = hi_n; j_c = j_n; dg_c = dg_n;
-#pragma unroll
-        for (int u = 0; u < SEG; ++u) rid_c[u] = rid_n[u];
+        lo_c = lo_n; hi_c = hi_n; j_c = j_n; dg_c = dg_n; mine_c = mine_n;
         lo_n = lo_nn; hi_n = hi_nn; j_n = j_nn; dg_n = dg_nn;
     }
 }
@@ -298,7 +330,7 @@ hipError_t launch_segment_sum_blocks(const float* in, int64_t is, const int32_t*
 // Fast paths; the callers fall back to the one-row-per-wave kernels when these decline (return false).
 bool try_segment_sum_aligned(const float* in, int64_t is, const int32_t* rowptr, const int32_t* col, int64_t n, int width,
                              float* out, int64_t os, float* inv_norm, hipStream_t st, hipError_t* err) {
-    if (n == 0 || !col || width > 256 || !aligned_rows(in, is, width) || !aligned_rows(out, os, width)) return false;
+    if (n == 0 || n >= (1 << 30) || !col || width > 256 || !aligned_rows(in, is, width) || !aligned_rows(out, os, width)) return false;
     CsrArgs a{};
     a.src = in; a.ss = is; a.rowptr = rowptr; a.idx = col; a.n = n; a.width = width; a.out = out; a.os = os;
     a.inv_out = inv_norm;
@@ -309,7 +341,7 @@ bool try_segment_sum_aligned(const float* in, int64_t is, const int32_t* rowptr,
 bool try_backward_gather_aligned(const float* contrib, int64_t cs, const int32_t* rowptr, const int32_t* rows, const float* x,
                                  int64_t xs, const float* inv, int64_t n, int F, float* gx, int64_t gxs, hipStream_t st,
                                  hipError_t* err) {
-    if (n == 0 || !rows || F > 256 || !aligned_rows(contrib, cs, F) || !aligned_rows(x, xs, F) || !aligned_rows(gx, gxs, F))
+    if (n == 0 || n >= (1 << 30) || !rows || F > 256 || !aligned_rows(contrib, cs, F) || !aligned_rows(x, xs, F) || !aligned_rows(gx, gxs, F))
         return false;
     CsrArgs a{};
     a.src = contrib; a.ss = cs; a.rowptr = rowptr; a.idx = rows; a.n = n; a.width = F; a.out = gx; a.os = gxs;
