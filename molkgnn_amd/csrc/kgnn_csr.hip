@@ -16,6 +16,7 @@
 // Sums run in CSR order and the row reductions are fixed xor trees: results are reproducible.
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdlib>
 #include "kgnn_common.h"
 #include "kgnn_launch.h"
 
@@ -274,7 +275,9 @@ static inline int csr_grid(int64_t n, int rpw) {
     int64_t groups = (n + rpw - 1) / rpw;
     int64_t blocks = (groups + 3) / 4;
     if (blocks < 1) blocks = 1;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    static const char* env_cap = getenv("MKGNN_CSR_BLOCKS");          // diagnostics
+    const int64_t cap = env_cap ? atoi(env_cap) : 256 * 16;
+    if (blocks > cap) blocks = cap;
     return (int)blocks;
 }
 
