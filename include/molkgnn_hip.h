@@ -209,13 +209,16 @@ int mkgnn_readout_backward(const mkgnn_readout_params* params, const float* h, i
 /* BatchNorm1d over atom rows, reference MolKGNNNet.py:115 (torch.nn.BatchNorm1d semantics: biased
  * variance for the normalisation, unbiased for running_var, running <- running + momentum (batch - running)).
  * training != 0: batch statistics, running_* (may be NULL) updated in place, save_* written.
- * training == 0: running statistics; save_* (may be NULL) receive mean and 1/sqrt(var + eps). */
+ * training == 0: running statistics; save_* (may be NULL) receive mean and 1/sqrt(var + eps).
+ * inv_norm (may be NULL; 17 <= C <= 32): also 1 / max(||out row||, 1e-8) per row, bit-identical to mkgnn_row_inv_norm
+ * on out -- the first kernel convolution reads the normalised features next (MolKGNNNet.py:115-117).
+ * num_batches_tracked (may be NULL): incremented when training != 0 (BatchNorm1d's counter). */
 size_t mkgnn_batchnorm_workspace_bytes(int32_t C);
 int mkgnn_batchnorm_forward(const float* x, int64_t x_stride, int64_t n_rows, int32_t C,
                             const float* weight, const float* bias,
                             float* running_mean, float* running_var, float momentum, float eps,
                             int32_t training, float* out, int64_t out_stride,
-                            float* save_mean, float* save_invstd,
+                            float* save_mean, float* save_invstd, float* inv_norm, int64_t* num_batches_tracked,
                             void* workspace, size_t workspace_bytes, void* stream);
 /* grad_x (may be NULL), grad_weight, grad_bias (may be NULL) are fully overwritten. */
 int mkgnn_batchnorm_backward(const float* grad_out, int64_t grad_out_stride, const float* x, int64_t x_stride,

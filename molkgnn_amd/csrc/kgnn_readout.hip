@@ -390,6 +390,8 @@ struct BnArgs {
     const float* gout; int64_t gos;
     float* gx; int64_t gxs;
     float *gweight, *gbias;
+    float* inv_out;                // forward: 1 / max(|out row|, eps) for the convolution that reads out next (17 <= C <= 32)
+    int64_t* nbt;                  // forward, training: BatchNorm1d.num_batches_tracked, incremented
 };
 
 // rows of this block: [lo, hi)
@@ -516,7 +518,32 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(BnArgs a, int CL) {
     int64_t lo, hi;
     bn_rows(a, lo, hi);
     const int c = t & (CL - 1), rsub = t / CL, RS = 256 / CL;       // same thread layout as the column sums
-    if (c < a.C) {
+    if (blockIdx.x == 0 && t == 0 && a.nbt && a.training) a.nbt[0] += 1;
+    if (a.inv_out && CL == 32) {
+        // also the row norms of the output, for the kernel convolution that reads it next: the summation order of
+        // row_inv_norm_aligned_kernel<8> (kgnn_csr.hip) on the stored values -- four columns per quad leader by FMAs,
+        // then the xor tree over the eight leaders -- so the result is bit-identical to mkgnn_row_inv_norm on `out`.
+        // Every lane runs the loop (the shuffles need them); columns past C load column 0 and count as zero.
+        const int cc = c < a.C ? c : 0;
+        const float mu = mean[cc], sc = scale[cc], sh0 = shift[cc];
+        for (int64_t r0 = lo + rsub; r0 - rsub < hi; r0 += 8 * RS) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = a.x[(r0 + u * RS < hi ? r0 + u * RS : hi - 1) * a.xs + cc];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool ok = r0 + u * RS < hi;
+                const float o = fmaf(v[u] - mu, sc, sh0);
+                if (ok && c < a.C) a.out[(r0 + u * RS) * a.os + c] = o;
+                const float m0 = c < a.C ? o : 0.f;
+                const float m1 = __shfl_down(m0, 1, 64), m2 = __shfl_down(m0, 2, 64), m3 = __shfl_down(m0, 3, 64);
+                float ss = m0 * m0;
+                ss = fmaf(m1, m1, ss); ss = fmaf(m2, m2, ss); ss = fmaf(m3, m3, ss);
+                ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 8, 64); ss += __shfl_xor(ss, 4, 64);
+                if (ok && c == 0) a.inv_out[r0 + u * RS] = 1.f / fmaxf(sqrtf(ss), MKGNN_EPS);
+            }
+        }
+    } else if (c < a.C) {
         const float mu = mean[c], sc = scale[c], sh0 = shift[c];
         for (int64_t r0 = lo + rsub; r0 < hi; r0 += 8 * RS) {
             float v[8];
@@ -941,7 +968,7 @@ static int bn_common(const char* who, int64_t n, int32_t C, int& CL) {
 int mkgnn_batchnorm_forward(const float* x, int64_t x_stride, int64_t n_rows, int32_t C, const float* weight,
                             const float* bias, float* running_mean, float* running_var, float momentum, float eps,
                             int32_t training, float* out, int64_t out_stride, float* save_mean, float* save_invstd,
-                            void* ws, size_t ws_bytes, void* stream) {
+                            float* inv_norm, int64_t* num_batches_tracked, void* ws, size_t ws_bytes, void* stream) {
     int CL;
     if (int rc = bn_common("mkgnn_batchnorm_forward", n_rows, C, CL)) return rc;
     if (!x || !out || x_stride < C || out_stride < C) return api_fail("mkgnn_batchnorm_forward: bad x/out");
@@ -953,6 +980,8 @@ int mkgnn_batchnorm_forward(const float* x, int64_t x_stride, int64_t n_rows, in
     a.x = x; a.xs = x_stride; a.n = n_rows; a.C = C; a.weight = weight; a.bias = bias;
     a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum; a.eps = eps; a.training = training;
     a.out = out; a.os = out_stride; a.save_mean = save_mean; a.save_invstd = save_invstd;
+    if (inv_norm && (C <= 16 || C > 32)) return api_fail("mkgnn_batchnorm_forward: inv_norm is available for 17 <= C <= 32 only (C=%d)", C);
+    a.inv_out = inv_norm; a.nbt = num_batches_tracked;
     a.part1 = (float*)ws; a.part2 = a.part1 ? a.part1 + (size_t)BN_BLOCKS * C : nullptr;
     if (training) {
         bn_sum_kernel<<<BN_BLOCKS, 256, 0, st>>>(a, CL);

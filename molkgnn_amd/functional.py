@@ -315,9 +315,9 @@ def _segment_sum_blocks(v, csr, deg8, blocks, mode: int, out_pad: int, inv) -> t
     n, w = v.shape
     if sum(blocks) != w or (w + out_pad) % 4 or _stride0(v) % 4 or v.data_ptr() % 16:
         raise _lib.MolKGNNLibraryError("block-row propagate needs 16-byte aligned rows whose width is the sum of the blocks")
+    # mode 1 writes whole rows (alignment padding included); mode 2 leaves everything outside the blocks undefined --
+    # the padding too: its only reader is the convolution's backward, which reads blocks
     out = torch.empty((n, w + out_pad), dtype=torch.float32, device=v.device)
-    if out_pad and mode == 2:
-        out[:, w:].zero_()                           # (mode 1 writes the alignment padding itself)
     with torch.cuda.device(v.device):
         _lib.check(_lib.load().mkgnn_segment_sum_block_rows(
             v.data_ptr(), _stride0(v), rowptr.data_ptr(), col.data_ptr(), _lib.ptr(deg8), n, _lib.Int32x4(*blocks), mode,

@@ -170,23 +170,32 @@ class _BatchNormFn(torch.autograd.Function):
         update = bn.training and bn.track_running_stats and bn.running_mean is not None
         rm = bn.running_mean if (update or not use_batch_stats) else None
         rv = bn.running_var if (update or not use_batch_stats) else None
+        nbt = bn.num_batches_tracked if (update and bn.num_batches_tracked is not None) else None
+        if nbt is not None and (nbt.dtype != torch.int64 or nbt.device != dev):
+            raise _lib.MolKGNNLibraryError("num_batches_tracked must be an int64 tensor on the input's device")
+        # the row norms of the output ride along for the kernel convolution that reads it next (17..32 channels, 16-byte rows)
+        inv = torch.empty(n, dtype=torch.float32, device=dev) if (16 < C <= 32 and C % 4 == 0) else None
         with torch.cuda.device(dev):
             ws_bytes = int(lib.mkgnn_batchnorm_workspace_bytes(C))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             _lib.check(lib.mkgnn_batchnorm_forward(
                 x.data_ptr(), _stride0(x), n, C, _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(rm), _lib.ptr(rv),
                 float(bn.momentum if bn.momentum is not None else 0.0), float(bn.eps), int(use_batch_stats),
-                out.data_ptr(), C, save_mean.data_ptr(), save_invstd.data_ptr(), ws.data_ptr(), ws_bytes,
-                _lib.stream_ptr(dev)), "mkgnn_batchnorm_forward")
-        if update and bn.num_batches_tracked is not None:
-            bn.num_batches_tracked.add_(1)
+                out.data_ptr(), C, save_mean.data_ptr(), save_invstd.data_ptr(), _lib.ptr(inv), _lib.ptr(nbt),
+                ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)), "mkgnn_batchnorm_forward")
         ctx.use_batch_stats = use_batch_stats
         ctx.save_for_backward(x, weight, save_mean, save_invstd)
-        return out
+        if inv is None:
+            inv = torch.empty(0, dtype=torch.float32, device=dev)
+        ctx.mark_non_differentiable(inv)
+        ctx.set_materialize_grads(False)
+        return out, inv
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, _g_inv=None):
         lib = _lib.load()
+        if grad_out is None:
+            return None, None, None, None, None
         x, weight, save_mean, save_invstd = ctx.saved_tensors
         n, C = x.shape
         dev = x.device
@@ -215,7 +224,11 @@ def batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm1d) -> torch.Tensor:
         return bn(x)
     if use_batch_stats and bn.training and x.shape[0] == 1:
         raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
-    return _BatchNormFn.apply(x, bn.weight, bn.bias, bn, use_batch_stats)
+    out, inv = _BatchNormFn.apply(x, bn.weight, bn.bias, bn, use_batch_stats)
+    if inv.numel():
+        from .functional import _INV_ATTR
+        setattr(out, _INV_ATTR, (inv, out._version))
+    return out
 
 
 # ------------------------------------------------------------------------------- single-task head + loss --

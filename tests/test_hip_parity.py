@@ -1114,3 +1114,32 @@ def test_molgcn_block_rows_equals_dense_path():
     assert res[0][1].keys() == res[1][1].keys() and len(res[0][1]) > 20
     for k in res[0][1]:
         assert torch.equal(res[0][1][k], res[1][1][k]), k
+
+
+def test_batch_norm_hands_row_norms_and_counts_batches():
+    """mkgnn_batchnorm_forward also emits 1 / max(||row||, eps) of its output (28 channels: the first convolution reads
+    it next) -- bit-identical to mkgnn_row_inv_norm on the same rows, so tie-breaks do not depend on who computed the
+    norms -- and increments num_batches_tracked inside the kernel (no separate PyTorch kernel in the captured step)."""
+    from molkgnn_amd import functional as Fn
+    from molkgnn_amd import readout as R
+    dev = _dev()
+    torch.manual_seed(12)
+    for n in (1, 7, 1000, 4097):
+        if n == 1:
+            continue                                      # BatchNorm1d refuses a single row in training mode
+        bn = torch.nn.BatchNorm1d(28).to(dev).train()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+        x = torch.randn(n, 28, device=dev) * 3 + 1
+        out = R.batch_norm(x, bn)
+        assert int(bn.num_batches_tracked) == 1
+        handed = Fn._handed_inv_norm(out)
+        assert handed is not None and handed.shape == (n,)
+        assert torch.equal(handed, Fn.row_inv_norm(out.detach()))
+        ref = torch.nn.functional.batch_norm(x, None, None, bn.weight, bn.bias, True, 0.1, bn.eps)
+        torch.testing.assert_close(out, ref, rtol=1e-5, atol=1e-5)
+        R.batch_norm(x, bn)
+        assert int(bn.num_batches_tracked) == 2
+    bn = torch.nn.BatchNorm1d(40).to(dev).train()         # other widths: no norms handed over, same results
+    out = R.batch_norm(torch.randn(50, 40, device=dev), bn)
+    assert Fn._handed_inv_norm(out) is None and int(bn.num_batches_tracked) == 1
