@@ -45,15 +45,36 @@ struct ReadoutArgs {
 
 __device__ __forceinline__ float sigmoid_f(float p) { return 1.f / (1.f + expf(-p)); }
 
+// A [rows, cols] row-major weight matrix -> LDS image [rows_pad][ld] (zero outside), eight loads in flight per thread.
+// (Written as "for (i ...) lds[i] = ok ? w[...] : 0" the compiler keeps one conditional load in flight at a time:
+// 16 dependent round trips ahead of readout_pre_kernel's first tile, ~10 of its 21 us.)
+template <int NTHREADS>
+__device__ __forceinline__ void weights_to_lds(float* lds, int total, int ld, const float* w, int rows, int cols, int tid) {
+    for (int base = 0; base < total; base += NTHREADS * 8) {
+        float tmp[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = base + tid + NTHREADS * k;
+            const int ic = i < total ? i : total - 1;
+            const int r = ic / ld, c = ic - r * ld;
+            const bool ok = r < rows && c < cols;
+            const float v = w[ok ? r * cols + c : 0];          // unconditional load, masked after
+            tmp[k] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int i = base + tid + NTHREADS * k;
+            if (i < total) lds[i] = tmp[k];
+        }
+    }
+}
+
 // ------------------------------------------------------------------ forward: pre = h W1^T + b1 ----
 template <int NT, int NJ>
 __global__ void __launch_bounds__(256) readout_pre_kernel(ReadoutArgs a) {
     constexpr int HP = 16 * NT, FP = 16 * NJ, LDW = FP + 4;
     __shared__ __attribute__((aligned(16))) float w1s[HP * LDW];
-    for (int i = threadIdx.x; i < HP * LDW; i += 256) {
-        const int r = i / LDW, c = i - r * LDW;
-        w1s[i] = (r < a.H && c < a.F) ? a.w1[r * a.F + c] : 0.f;
-    }
+    weights_to_lds<256>(w1s, HP * LDW, LDW, a.w1, a.H, a.F, threadIdx.x);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
@@ -105,7 +126,7 @@ __global__ void __launch_bounds__(256) readout_pool_kernel(ReadoutArgs a, int HP
     __shared__ float w2s[64 * 65];
     __shared__ float scr[4][64];
     const int H = a.H, G = a.G;
-    for (int i = threadIdx.x; i < G * H; i += 256) { const int o = i / H, c = i - o * H; w2s[o * (H + 1) + c] = a.w2[i]; }
+    weights_to_lds<256>(w2s, G * (H + 1), H + 1, a.w2, G, H, threadIdx.x);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int groups = 64 / HP, c = lane & (HP - 1), gid = lane / HP;
@@ -150,7 +171,7 @@ __global__ void __launch_bounds__(256) readout_bwd_mol_kernel(ReadoutArgs a, int
     __shared__ float As[MC][64];
     __shared__ float nat[MC];
     const int H = a.H, G = a.G, tid = threadIdx.x;
-    for (int i = tid; i < G * H; i += 256) { const int o = i / H, c = i - o * H; w2s[o * (H + 1) + c] = a.w2[i]; }
+    weights_to_lds<256>(w2s, G * (H + 1), H + 1, a.w2, G, H, tid);
     const int64_t per = (a.nmol + gridDim.x - 1) / gridDim.x;
     const int64_t m_lo = per * blockIdx.x, m_hi = (m_lo + per < a.nmol) ? m_lo + per : a.nmol;
     float accw[16];
@@ -165,12 +186,25 @@ __global__ void __launch_bounds__(256) readout_bwd_mol_kernel(ReadoutArgs a, int
     float accb = 0.f;
     for (int64_t m0 = m_lo; m0 < m_hi; m0 += MC) {
         __syncthreads();
-        for (int i = tid; i < MC * 64; i += 256) {
-            const int m = i >> 6, o = i & 63;
-            const bool ok = m0 + m < m_hi;
-            dzs[m][o] = (ok && o < G) ? a.gout[(m0 + m) * a.gos + o] : 0.f;
-            As[m][o] = (ok && o < H) ? a.pooled[(m0 + m) * HP + o] : 0.f;
-            if (o == 0) nat[m] = ok ? (float)(a.mol_ptr[m0 + m + 1] - a.mol_ptr[m0 + m]) : 0.f;
+        {   // MC * 64 = 4 * 256 entries: all loads first (unconditional, clamped), then the LDS stores
+            float dz[4], av[4];
+            int p0[4], p1[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = tid + 256 * k, m = i >> 6, o = i & 63;
+                const int64_t mc = m0 + m < m_hi ? m0 + m : m_hi - 1;
+                dz[k] = a.gout[mc * a.gos + (o < G ? o : 0)];
+                av[k] = a.pooled[mc * HP + (o < H ? o : 0)];
+                p0[k] = a.mol_ptr[mc]; p1[k] = a.mol_ptr[mc + 1];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int i = tid + 256 * k, m = i >> 6, o = i & 63;
+                const bool ok = m0 + m < m_hi;
+                dzs[m][o] = (ok && o < G) ? dz[k] : 0.f;
+                As[m][o] = (ok && o < H) ? av[k] : 0.f;
+                if (o == 0) nat[m] = ok ? (float)(p1[k] - p0[k]) : 0.f;
+            }
         }
         __syncthreads();
         for (int m = 0; m < MC; ++m) {
@@ -202,10 +236,7 @@ __global__ void __launch_bounds__(512) readout_bwd_atoms_kernel(ReadoutArgs a) {
     constexpr int NW = NT == 4 ? 4 : 8;                               // two waves per SIMD where the 64 KB of static LDS allow it
     __shared__ __attribute__((aligned(16))) float w1s[HP * LDW];      // [hidden][feature]; reused for the block reduction
     __shared__ __attribute__((aligned(16))) float dps[NW][16 * LDP];  // per wave: dpre tile [atom][hidden]
-    for (int i = threadIdx.x; i < HP * LDW; i += 64 * NW) {
-        const int r = i / LDW, c = i - r * LDW;
-        w1s[i] = (r < a.H && c < a.F) ? a.w1[r * a.F + c] : 0.f;
-    }
+    weights_to_lds<64 * NW>(w1s, HP * LDW, LDW, a.w1, a.H, a.F, threadIdx.x);
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 15, q = lane >> 4;
