@@ -210,7 +210,8 @@ int mkgnn_readout_backward(const mkgnn_readout_params* params, const float* h, i
  * variance for the normalisation, unbiased for running_var, running <- running + momentum (batch - running)).
  * training != 0: batch statistics, running_* (may be NULL) updated in place, save_* written.
  * training == 0: running statistics; save_* (may be NULL) receive mean and 1/sqrt(var + eps).
- * inv_norm (may be NULL; 17 <= C <= 32): also 1 / max(||out row||, 1e-8) per row, bit-identical to mkgnn_row_inv_norm
+ * inv_norm (may be NULL; needs C <= 32, C % 4 == 0 and 16-byte aligned rows of x and out): also
+ * 1 / max(||out row||, 1e-8) per row, bit-identical to mkgnn_row_inv_norm
  * on out -- the first kernel convolution reads the normalised features next (MolKGNNNet.py:115-117).
  * num_batches_tracked (may be NULL): incremented when training != 0 (BatchNorm1d's counter). */
 size_t mkgnn_batchnorm_workspace_bytes(int32_t C);

@@ -91,6 +91,24 @@ __global__ void bank_prepare_kernel(PrepArgs a) {
         }
         return;
     }
+    if (width <= 128) {
+        // the model's rows (F = 28 / 110, E = 7): both halves of the row loaded at once, every output from registers
+        // (the general loop below reads the row three times, one dependent round trip each)
+        const float v0 = src[lane < width ? lane : 0], v1 = src[lane + 64 < width ? lane + 64 : 0];
+        const float m0 = lane < width ? v0 : 0.f, m1 = lane + 64 < width ? v1 : 0.f;
+        float s = fmaf(m0, m0, 0.f);                 // (same order as the loop: element lane, then lane + 64)
+        if (width > 64) s = fmaf(m1, m1, s);
+        s = wave_sum(s);
+        const float iv = 1.f / fmaxf(sqrtf(s), MKGNN_EPS);
+        if (lane < width) dst[lane] = m0 * iv;
+        if (lane + 64 < width) dst[lane + 64] = m1 * iv;
+        if (lane == 0) *inv = iv;
+        if (pad_dst) {
+            if (lane < pad_width) pad_dst[lane] = m0 * iv;
+            if (lane + 64 < pad_width) pad_dst[lane + 64] = m1 * iv;
+        }
+        return;
+    }
     float s = 0.f;
     for (int f = lane; f < width; f += 64) {
         float v = src[f];

@@ -496,17 +496,31 @@ __global__ void __launch_bounds__(256) rows_equal_kernel(const float* __restrict
         int64_t nb[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) nb[j] = nei[r * 4 + j];
-        unsigned diff = 0;
-        for (int f = lane; f < F; f += 64) {
-            float v[4];
+        // the coordinates travel with the ids (they were one more dependent round trip at the end, under lane == 0)
+        float pn[3][3], pf[3];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = x[nb[j] * xs + f];
+        for (int c = 0; c < 3; ++c) {
+            pf[c] = p_focal[r * 3 + c];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) pn[j][c] = p_nei[(r * 4 + j) * 3 + c];
+        }
+        unsigned diff = 0;
+        for (int f0 = 0; f0 < F; f0 += 128) {             // two column blocks per pass, all eight loads in flight
+            const int fa = f0 + lane, fb = f0 + 64 + lane;
+            float va[4], vb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                va[j] = x[nb[j] * xs + (fa < F ? fa : 0)];
+                vb[j] = x[nb[j] * xs + (fb < F ? fb : 0)];
+            }
             int k = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = i + 1; j < 4; ++j, ++k)
-                    if (!(v[i] == v[j])) diff |= 1u << k;
+                for (int j = i + 1; j < 4; ++j, ++k) {
+                    if (fa < F && !(va[i] == va[j])) diff |= 1u << k;
+                    if (fb < F && !(vb[i] == vb[j])) diff |= 1u << k;
+                }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) diff |= __shfl_xor((int)diff, o, 64);
@@ -517,7 +531,7 @@ __global__ void __launch_bounds__(256) rows_equal_kernel(const float* __restrict
 #pragma unroll
             for (int j = 0; j < 3; ++j)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) t3[j][c] = __fsub_rn(p_nei[(r * 4 + j) * 3 + c], p_focal[r * 3 + c]);
+                for (int c = 0; c < 3; ++c) t3[j][c] = __fsub_rn(pn[j][c], pf[c]);
             sgn[r] = (int8_t)triple_sign(t3[0], t3[1], t3[2]);
         }
     }

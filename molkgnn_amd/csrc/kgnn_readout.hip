@@ -550,28 +550,32 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(BnArgs a, int CL) {
     bn_rows(a, lo, hi);
     const int c = t & (CL - 1), rsub = t / CL, RS = 256 / CL;       // same thread layout as the column sums
     if (blockIdx.x == 0 && t == 0 && a.nbt && a.training) a.nbt[0] += 1;
-    if (a.inv_out && CL == 32) {
-        // also the row norms of the output, for the kernel convolution that reads it next: the summation order of
-        // row_inv_norm_aligned_kernel<8> (kgnn_csr.hip) on the stored values -- four columns per quad leader by FMAs,
-        // then the xor tree over the eight leaders -- so the result is bit-identical to mkgnn_row_inv_norm on `out`.
-        // Every lane runs the loop (the shuffles need them); columns past C load column 0 and count as zero.
-        const int cc = c < a.C ? c : 0;
-        const float mu = mean[cc], sc = scale[cc], sh0 = shift[cc];
-        for (int64_t r0 = lo + rsub; r0 - rsub < hi; r0 += 8 * RS) {
-            float v[8];
+    if (a.inv_out) {
+        // also the row norms of the output, for the kernel convolution that reads it next.  Thread layout of
+        // row_inv_norm_aligned_kernel<8> (kgnn_csr.hip): eight lanes per row, four consecutive channels each (16-byte
+        // loads and stores; the host checks the alignment), the same FMA chain and xor tree on the stored values --
+        // bit-identical to mkgnn_row_inv_norm on `out`.
+        const int l = t & 7, rs8 = t >> 3, col = 4 * l;
+        const bool act = col < a.C;                       // (C is a multiple of 4 here: a lane's four channels exist or do not)
+        const int cb = act ? col : 0;
+        f32x4 mu4, sc4, sh4;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = a.x[(r0 + u * RS < hi ? r0 + u * RS : hi - 1) * a.xs + cc];
+        for (int e = 0; e < 4; ++e) { mu4[e] = mean[cb + e]; sc4[e] = scale[cb + e]; sh4[e] = shift[cb + e]; }
+        for (int64_t r0 = lo + rs8; r0 - rs8 < hi; r0 += 4 * 32) {
+            f32x4 v[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool ok = r0 + u * RS < hi;
-                const float o = fmaf(v[u] - mu, sc, sh0);
-                if (ok && c < a.C) a.out[(r0 + u * RS) * a.os + c] = o;
-                const float m0 = c < a.C ? o : 0.f;
-                const float m1 = __shfl_down(m0, 1, 64), m2 = __shfl_down(m0, 2, 64), m3 = __shfl_down(m0, 3, 64);
-                float ss = m0 * m0;
-                ss = fmaf(m1, m1, ss); ss = fmaf(m2, m2, ss); ss = fmaf(m3, m3, ss);
-                ss += __shfl_xor(ss, 16, 64); ss += __shfl_xor(ss, 8, 64); ss += __shfl_xor(ss, 4, 64);
-                if (ok && c == 0) a.inv_out[r0 + u * RS] = 1.f / fmaxf(sqrtf(ss), MKGNN_EPS);
+            for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(a.x + (r0 + u * 32 < hi ? r0 + u * 32 : hi - 1) * a.xs + cb);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const bool ok = r0 + u * 32 < hi;
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = act ? fmaf(v[u][e] - mu4[e], sc4[e], sh4[e]) : 0.f;
+                if (ok && act) *(f32x4*)(a.out + (r0 + u * 32) * a.os + col) = o;
+                float ss = o[0] * o[0];
+                ss = fmaf(o[1], o[1], ss); ss = fmaf(o[2], o[2], ss); ss = fmaf(o[3], o[3], ss);
+                ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 1, 64);
+                if (ok && l == 0) a.inv_out[r0 + u * 32] = 1.f / fmaxf(sqrtf(ss), MKGNN_EPS);
             }
         }
     } else if (c < a.C) {
@@ -1011,7 +1015,8 @@ int mkgnn_batchnorm_forward(const float* x, int64_t x_stride, int64_t n_rows, in
     a.x = x; a.xs = x_stride; a.n = n_rows; a.C = C; a.weight = weight; a.bias = bias;
     a.running_mean = running_mean; a.running_var = running_var; a.momentum = momentum; a.eps = eps; a.training = training;
     a.out = out; a.os = out_stride; a.save_mean = save_mean; a.save_invstd = save_invstd;
-    if (inv_norm && (C <= 16 || C > 32)) return api_fail("mkgnn_batchnorm_forward: inv_norm is available for 17 <= C <= 32 only (C=%d)", C);
+    if (inv_norm && (C > 32 || C % 4 || x_stride % 4 || out_stride % 4 || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)))
+        return api_fail("mkgnn_batchnorm_forward: inv_norm needs C <= 32, a multiple of 4, and 16-byte aligned rows of x and out (C=%d)", C);
     a.inv_out = inv_norm; a.nbt = num_batches_tracked;
     a.part1 = (float*)ws; a.part2 = a.part1 ? a.part1 + (size_t)BN_BLOCKS * C : nullptr;
     if (training) {

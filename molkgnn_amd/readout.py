@@ -173,8 +173,9 @@ class _BatchNormFn(torch.autograd.Function):
         nbt = bn.num_batches_tracked if (update and bn.num_batches_tracked is not None) else None
         if nbt is not None and (nbt.dtype != torch.int64 or nbt.device != dev):
             raise _lib.MolKGNNLibraryError("num_batches_tracked must be an int64 tensor on the input's device")
-        # the row norms of the output ride along for the kernel convolution that reads it next (17..32 channels, 16-byte rows)
-        inv = torch.empty(n, dtype=torch.float32, device=dev) if (16 < C <= 32 and C % 4 == 0) else None
+        # the row norms of the output ride along for the kernel convolution that reads it next (<= 32 channels, 16-byte rows)
+        inv = torch.empty(n, dtype=torch.float32, device=dev) \
+            if (C <= 32 and C % 4 == 0 and _stride0(x) % 4 == 0 and x.data_ptr() % 16 == 0) else None
         with torch.cuda.device(dev):
             ws_bytes = int(lib.mkgnn_batchnorm_workspace_bytes(C))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
