@@ -261,13 +261,14 @@ def main():
         torch.cuda.synchronize()
         ms_call = ev0.elapsed_time(ev1) / args.roofline_reps
         # (b) the dominant kernel alone (kc_forward_fused): HIP events recorded around its launch, on its stream
-        lib.mkgnn_debug_time_fused_forward(1)
         samples = []
-        for _ in range(args.roofline_reps):
-            Fn.kernelsetconv_details(h, plan, False, params, E, args.variant)
-            samples.append(float(lib.mkgnn_debug_last_fused_forward_ms()))
-        lib.mkgnn_debug_time_fused_forward(0)
-        ms = sum(samples) / len(samples) if args.variant != "generic" and min(samples) > 0 else ms_call
+        if args.variant != "generic":                # (the generic kernels have no fused launch to bracket)
+            lib.mkgnn_debug_time_fused_forward(1)
+            for _ in range(args.roofline_reps):
+                Fn.kernelsetconv_details(h, plan, False, params, E, args.variant)
+                samples.append(float(lib.mkgnn_debug_last_fused_forward_ms()))
+            lib.mkgnn_debug_time_fused_forward(0)
+        ms = sum(samples) / len(samples) if samples and min(samples) > 0 else ms_call
         by, fl = layer_algorithmic(plan, K_in, E, Ls, False)
         gbs = by / (ms * 1e-3) / 1e9
         traffic = None
