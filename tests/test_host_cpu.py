@@ -225,3 +225,48 @@ def test_plan_cache_is_not_fooled_by_recycled_addresses():
     p2 = plan_from_lists_cached(n, *held, b.edge_index)
     assert p2 is not p1
     assert torch.equal(p2.scatter[0], p1.scatter[0]) and torch.equal(p2.scatter[1], p1.scatter[1])
+
+
+def test_plan_block_row_tables():
+    """Host side of the block-row propagate: the degree table built from the buckets (0 = in no bucket) and the
+    propagate CSR whose column entries carry the source atom's degree in bits 28..30."""
+    from molkgnn_amd.plan import plan_from_data
+    from molkgnn_amd.synthetic import make_batch
+    b = make_batch(9, seed=6)
+    plan = plan_from_data(b)
+    n = b.x.shape[0]
+    deg = torch.bincount(b.edge_index[0], minlength=n)
+    expect = torch.where(deg <= 4, deg, torch.zeros_like(deg)).to(torch.int8)
+    assert torch.equal(plan.deg8, expect)
+    rowptr, col = plan.csr_in
+    rp2, packed = plan.csr_in_packed
+    assert rp2 is rowptr and packed.dtype == torch.int32
+    assert torch.equal(packed & 0x0FFFFFFF, col)
+    assert torch.equal((packed >> 28) & 7, plan.deg8[col.long()].to(torch.int32))
+    assert plan.block_rows_ok(110) and not plan.block_rows_ok(300) and not plan.block_rows_ok(0)
+
+
+def test_fused_adamw_host_side():
+    """FusedAdamW without a GPU: argument checks, refusal of CPU parameters (no CPU path), and the packed state
+    (exp_avg | exp_avg_sq | step as views of one buffer) built from a torch.optim.AdamW state_dict."""
+    from molkgnn_amd._lib import MolKGNNLibraryError
+    from molkgnn_amd.optim import FusedAdamW
+    p = torch.nn.Parameter(torch.randn(3, 5))
+    with pytest.raises(ValueError):
+        FusedAdamW([p], betas=(1.0, 0.9))
+    with pytest.raises(ValueError):
+        FusedAdamW([{"params": [torch.nn.Parameter(torch.zeros(1))]} for _ in range(5)])
+    opt = FusedAdamW([p], lr=1e-3)
+    p.grad = torch.randn(3, 5)
+    with pytest.raises(MolKGNNLibraryError, match="no CPU fallback"):
+        opt.step()
+    ref = torch.optim.AdamW([p], lr=1e-3)
+    ref.step()
+    opt2 = FusedAdamW([p], lr=1e-3)
+    opt2.load_state_dict(ref.state_dict())
+    st = opt2.state[p]
+    buf = st["_packed"]
+    assert buf.numel() == 2 * 15 + 3 and float(st["step"]) == 1.0
+    assert st["exp_avg"].data_ptr() == buf.data_ptr() and st["exp_avg"].shape == p.shape
+    assert torch.equal(st["exp_avg"], ref.state[p]["exp_avg"]) and torch.equal(st["exp_avg_sq"], ref.state[p]["exp_avg_sq"])
+    assert "_packed" not in next(iter(opt2.state_dict()["state"].values()))
