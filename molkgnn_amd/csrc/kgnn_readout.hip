@@ -340,6 +340,12 @@ __global__ void __launch_bounds__(512) readout_bwd_atoms_kernel(ReadoutArgs a) {
             v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
             colsum[jj][c] = v;
         }
+    // LDS image in lane order -- value k of lane l at red[k * 64 + l]: conflict-free.  (Indexed by (hidden, feature) the
+    // lanes of an access were 512 bytes apart: 8-way bank conflicts.)  Cycle stamps of this kernel at batch 4096: weight
+    // copy 3.5 k, three tiles of 14-20 k each, a fourth for one wave in eight (6412 tiles over 2048 waves) that the
+    // rest of its block waits for at the barrier below, reduction + slab 5 k.
+    // The (hidden, feature) mapping is applied once, on the way to the slab.
+    constexpr int NV = NT * NJ * 4;                    // weight-gradient values per lane
     for (int w = 0; w < NW; ++w) {
         __syncthreads();
         if (wave == w) {
@@ -349,8 +355,7 @@ __global__ void __launch_bounds__(512) readout_bwd_atoms_kernel(ReadoutArgs a) {
                 for (int t = 0; t < NJ; ++t)
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const int hid = 16 * mt + 4 * q + i, feat = 64 * (t >> 2) + 4 * r + (t & 3);
-                        const int idx = hid * FP + feat;
+                        const int idx = ((mt * NJ + t) * 4 + i) * 64 + lane;
                         red[idx] = (w == 0) ? accw[mt][t][i] : red[idx] + accw[mt][t][i];
                     }
             if (r == 0) {
@@ -358,7 +363,7 @@ __global__ void __launch_bounds__(512) readout_bwd_atoms_kernel(ReadoutArgs a) {
                 for (int jj = 0; jj < NT; ++jj)
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
-                        const int idx = HP * FP + 16 * jj + 4 * q + c;
+                        const int idx = NV * 64 + 16 * jj + 4 * q + c;
                         red[idx] = (w == 0) ? colsum[jj][c] : red[idx] + colsum[jj][c];
                     }
             }
@@ -366,7 +371,13 @@ __global__ void __launch_bounds__(512) readout_bwd_atoms_kernel(ReadoutArgs a) {
     }
     __syncthreads();
     float* slab = a.slab_atoms + (int64_t)blockIdx.x * a.slab_atoms_stride;
-    for (int i = threadIdx.x; i < HP * FP + HP; i += 64 * NW) slab[i] = red[i];
+    for (int e = threadIdx.x; e < NV * 64; e += 64 * NW) {
+        const int k = e >> 6, ln = e & 63, rr = ln & 15, qq = ln >> 4;
+        const int i = k & 3, t = (k >> 2) % NJ, mt = (k >> 2) / NJ;
+        const int hid = 16 * mt + 4 * qq + i, feat = 64 * (t >> 2) + 4 * rr + (t & 3);
+        slab[hid * FP + feat] = red[e];
+    }
+    for (int e = threadIdx.x; e < HP; e += 64 * NW) slab[HP * FP + e] = red[NV * 64 + e];
 }
 
 // ------------------------------------------------ fixed-order sum of per-block slabs into the parameters ----
