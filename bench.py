@@ -188,11 +188,14 @@ def main():
                         if opt is not None and world == 1:
                             opt.step()
                     g_opt = None
+                    # this graph's gradient tensors: every captured graph writes into its own (p.grad names only the
+                    # last capture's), and the all-reduce between its two halves must work on exactly these
+                    static_grads = reducer.grads()
                     if opt is not None and world > 1:    # the all-reduce sits between backward and optimiser
                         g_opt = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(g_opt, stream=side):
                             opt.step()
-                    graphs.append((g_fb, g_opt, static_loss))
+                    graphs.append((g_fb, g_opt, static_loss, static_grads))
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
         except Exception as exc:                     # capture is an optimisation, never a requirement
@@ -202,9 +205,9 @@ def main():
 
     if graphs is not None:
         def step(i):                                 # noqa: F811  (replay form of the same step)
-            g_fb, g_opt, loss = graphs[i % nb]
+            g_fb, g_opt, loss, static_grads = graphs[i % nb]
             g_fb.replay()
-            reducer.reduce()
+            reducer.reduce(static_grads)
             if g_opt is not None:
                 g_opt.replay()
             return loss
@@ -231,6 +234,18 @@ def main():
         elapsed = float(t.item())
     mols = args.batch_size * args.steps * world
     value = mols / elapsed
+    # data-parallel sanity, outside the timed region: identical initial weights + averaged gradients + a deterministic
+    # optimiser must leave every replica with the same parameters
+    replicas_diff = None
+    if world > 1 and opt is not None:
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1).float() for p in model.parameters()])
+            ref = flat.clone()
+            dist.broadcast(ref, 0)
+            d = (flat - ref).abs().max().reshape(1)
+            dist.all_reduce(d, op=dist.ReduceOp.MAX)
+            replicas_diff = float(d.item())
+        log(f"replicas: max |parameter - rank 0's| over all ranks after {args.warmup + args.steps} steps = {replicas_diff:g}")
 
     log(f"{value:.0f} molecules/s; measuring the forward kernels")
     out = None
@@ -290,6 +305,7 @@ def main():
                "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16 dot products, f32 otherwise" if args.variant == "bf16" else "f32",
                "data": "synthetic",
+               **({"dp_replicas_max_abs_diff": replicas_diff} if replicas_diff is not None else {}),
                "config": {"workload": f"AID {args.assay} full set shape ({n_mol_assay} molecules, ~25 atoms / ~53 directed "
                                       f"edges each), 3 layers, hidden_dim 32, kernels 10/20/30/50 per degree, "
                                       f"batch {args.batch_size} molecules per GPU ({atoms:.0f} atoms), "

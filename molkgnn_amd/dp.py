@@ -65,9 +65,30 @@ class FlatGradAllReduce:
     def nbytes(self) -> int:
         return self.flat.numel() * 4
 
-    def reduce(self) -> None:
-        """Call after backward: afterwards every ``p.grad`` holds the mean over ranks."""
+    def grads(self) -> List[Optional[torch.Tensor]]:
+        """The current ``p.grad`` tensors of the reduced parameters, in buffer order.  A step replayed from a captured
+        graph writes its gradients into the tensors that were ``p.grad`` *when that graph was captured*; with one graph
+        per resident batch those are different tensors per graph, so the caller keeps this list per graph and hands
+        it to ``reduce`` (``p.grad`` itself only names the last captured graph's tensors)."""
+        return [p.grad for p in self.params]
+
+    def reduce(self, grads: Optional[List[Optional[torch.Tensor]]] = None) -> None:
+        """Call after backward: afterwards every gradient tensor (``p.grad``, or the given list from ``grads()``) holds
+        the mean over ranks."""
         if self.world == 1:
+            return
+        if grads is not None:
+            if len(grads) != len(self.params):
+                raise ValueError("grads must come from FlatGradAllReduce.grads()")
+            have = [(v, g) for v, g in zip(self.views, grads) if g is not None]
+            if len(have) != len(self.params):
+                self.flat.zero_()
+            if have:
+                torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            self.flat.mul_(1.0 / self.world)
+            if have:
+                torch._foreach_copy_([g for _, g in have], [v for v, _ in have])
             return
         for p in self._filled:                       # gradients this object created last time are not this step's
             p.grad = None

@@ -95,3 +95,37 @@ def test_reducer_covers_the_trained_readout_weights():
         assert n in covered, n
     for n in ("lin1.weight", "lin2.bias", "gnn_model.graph_embedding_linear.weight", "gnn_model.edge_batch_norm.weight"):
         assert n in names and n not in covered, n
+
+
+def _worker_static_grads(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from molkgnn_amd import dp
+    assert dp.init_process_group_from_env("gloo") == world
+    torch.manual_seed(3)
+    lin = torch.nn.Linear(4, 3)
+    red = dp.FlatGradAllReduce(lin.parameters())
+    # two captured graphs = two sets of gradient tensors; p.grad names only the last one's
+    g = torch.Generator().manual_seed(10 + rank)
+    sets = []
+    for _ in range(2):
+        for p in lin.parameters():
+            p.grad = torch.randn(p.shape, generator=g)
+        sets.append(red.grads())
+    before = [[t.clone() for t in s] for s in sets]
+    red.reduce(sets[0])                                    # "replay of graph 0": its tensors are averaged ...
+    torch.save({"before": before, "after": [[t.clone() for t in s] for s in sets]}, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reduce_works_on_the_gradients_of_the_replayed_graph(tmp_path):
+    """One hipGraph per resident batch: every graph writes into its own gradient tensors, and ``p.grad`` names the last
+    capture's.  ``reduce(grads)`` must average exactly the given set and leave the other alone (bench.py passes each
+    graph's list; reducing ``p.grad`` instead left the replicas out of sync -- caught by bench.py's replica check)."""
+    port = _free_port()
+    mp.spawn(_worker_static_grads, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "rank0.pt"), torch.load(tmp_path / "rank1.pt")
+    for k in range(2):                                     # weight, bias
+        want = (r0["before"][0][k] + r1["before"][0][k]) / 2
+        assert torch.allclose(r0["after"][0][k], want, atol=1e-7) and torch.equal(r0["after"][0][k], r1["after"][0][k])
+        assert torch.equal(r0["after"][1][k], r0["before"][1][k]) and torch.equal(r1["after"][1][k], r1["before"][1][k])
