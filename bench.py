@@ -179,10 +179,13 @@ def main():
                 for i in range(3):                   # warm every lazy initialisation on the capture stream
                     step(i)
                 graphs = []
+                # N > 1: RCCL's watchdog thread polls its events with HIP calls of its own; in the default ("global")
+                # capture mode such a call from another thread invalidates the capture
+                cap = {"capture_error_mode": "thread_local"} if world > 1 else {}
                 for i in range(nb):
                     model.zero_grad(set_to_none=True)
                     g_fb = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g_fb, stream=side):
+                    with torch.cuda.graph(g_fb, stream=side, **cap):
                         static_loss = model.loss(batches[i])
                         static_loss.backward()
                         if opt is not None and world == 1:
@@ -193,7 +196,7 @@ def main():
                     static_grads = reducer.grads()
                     if opt is not None and world > 1:    # the all-reduce sits between backward and optimiser
                         g_opt = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g_opt, stream=side):
+                        with torch.cuda.graph(g_opt, stream=side, **cap):
                             opt.step()
                     graphs.append((g_fb, g_opt, static_loss, static_grads))
             torch.cuda.current_stream().wait_stream(side)
