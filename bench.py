@@ -163,7 +163,7 @@ def main():
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     # One hipGraph per resident batch: forward + backward + optimiser are launch-bound at this model size
-    # (~250 kernels of 5-100 us), so the step is captured once and replayed.  The gradient all-reduce
+    # (60 kernels of 5-100 us), so the step is captured once and replayed.  The gradient all-reduce
     # (N > 1) stays outside the graph, between the backward graph and the optimiser.
     graphs = None
     all_degrees = all(getattr(b, f"selected_index_deg{d}").numel() > 0 for b in batches for d in range(1, 5))
