@@ -166,6 +166,7 @@ def main():
     # (60 kernels of 5-100 us), so the step is captured once and replayed.  The gradient all-reduce
     # (N > 1) stays outside the graph, between the backward graph and the optimiser.
     graphs = None
+    flat_opt = False
     all_degrees = all(getattr(b, f"selected_index_deg{d}").numel() > 0 for b in batches for d in range(1, 5))
     if world > 1 and not all_degrees:
         # a rank whose batch lacks a degree gets that bank's gradients from the all-reduce only; a captured
@@ -190,28 +191,50 @@ def main():
                         static_loss.backward()
                         if opt is not None and world == 1:
                             opt.step()
-                    g_opt = None
                     # this graph's gradient tensors: every captured graph writes into its own (p.grad names only the
-                    # last capture's), and the all-reduce between its two halves must work on exactly these
-                    static_grads = reducer.grads()
-                    if opt is not None and world > 1:    # the all-reduce sits between backward and optimiser
-                        g_opt = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g_opt, stream=side, **cap):
+                    # last capture's), and the all-reduce after it must work on exactly these
+                    graphs.append([g_fb, None, static_loss, reducer.grads()])
+                if opt is not None and world > 1:
+                    # N > 1: backward graph -> gradients summed over the ranks in the flat buffer -> ONE optimiser graph
+                    # for all batches that reads the flat views and divides by the world size itself
+                    from molkgnn_amd.optim import FusedAdamW
+                    flat_opt = isinstance(opt, FusedAdamW)
+                    for entry in graphs:
+                        if flat_opt and entry is not graphs[0]:
+                            entry[1] = graphs[0][1]
+                            continue
+                        if flat_opt:
+                            for p_, v_ in zip(reducer.params, reducer.views):
+                                p_.grad = v_
+                            for grp in opt.param_groups:
+                                grp["grad_scale"] = 1.0 / world
+                        else:                            # (PyTorch optimiser: averaged gradients copied back, one graph per batch)
+                            for p_, g_ in zip(reducer.params, entry[3]):
+                                p_.grad = g_
+                        entry[1] = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(entry[1], stream=side, **cap):
                             opt.step()
-                    graphs.append((g_fb, g_opt, static_loss, static_grads))
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
         except Exception as exc:                     # capture is an optimisation, never a requirement
             log(f"hipGraph capture unavailable ({type(exc).__name__}: {str(exc).splitlines()[0]}); running eagerly")
             graphs = None
+            flat_opt = False
+            if opt is not None:
+                for grp in opt.param_groups:
+                    if "grad_scale" in grp:
+                        grp["grad_scale"] = 1.0
             torch.cuda.synchronize()
 
     if graphs is not None:
         def step(i):                                 # noqa: F811  (replay form of the same step)
             g_fb, g_opt, loss, static_grads = graphs[i % nb]
             g_fb.replay()
-            reducer.reduce(static_grads)
             if g_opt is not None:
+                if flat_opt:
+                    reducer.sum_into_flat(static_grads)
+                else:
+                    reducer.reduce(static_grads)
                 g_opt.replay()
             return loss
 

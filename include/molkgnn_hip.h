@@ -278,7 +278,7 @@ int mkgnn_bce_head_dropout_backward(const float* emb, int64_t emb_stride, int64_
  * two parameter groups -- kernel banks without weight decay).  Per tensor: param / grad [numel] fp32 contiguous,
  * state [2 * numel + 3] = exp_avg, exp_avg_sq, step count (as a float, advanced by this call), two scratch floats.  Per group: the
  * learning rate either by value (lr_device NULL) or read from a device float at run time (so that a captured graph
- * follows a scheduler), betas, eps, decoupled weight_decay, maximize.  The update is torch's fused AdamW formula
+ * follows a scheduler), betas, eps, decoupled weight_decay, maximize, grad_scale.  The update is torch's fused AdamW formula
  * (bias corrections 1 - beta^step).  At most 4 groups; any number of tensors (96 per launch pair). */
 typedef struct mkgnn_adamw_tensor {
     float* param;
@@ -291,6 +291,7 @@ typedef struct mkgnn_adamw_group {
     const float* lr_device;
     float lr, beta1, beta2, eps, weight_decay;
     int32_t maximize;
+    float grad_scale;      /* every gradient is multiplied by this first (1 / world size after a summing all-reduce; else 1) */
 } mkgnn_adamw_group;
 int mkgnn_adamw_step(const mkgnn_adamw_tensor* tensors, int32_t n_tensors, const mkgnn_adamw_group* groups,
                      int32_t n_groups, void* stream);

@@ -53,7 +53,7 @@ class AdamWTensor(C.Structure):
 
 class AdamWGroup(C.Structure):
     _fields_ = [("lr_device", C.c_void_p), ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float),
-                ("eps", C.c_float), ("weight_decay", C.c_float), ("maximize", C.c_int32)]
+                ("eps", C.c_float), ("weight_decay", C.c_float), ("maximize", C.c_int32), ("grad_scale", C.c_float)]
 
 
 Banks4 = KernelBank * MAX_DEGREE

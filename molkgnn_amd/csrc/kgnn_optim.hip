@@ -21,7 +21,7 @@ constexpr int ADAM_MAX_GROUPS = 4;
 constexpr int ADAM_CHUNK = 1024;          // elements per block
 
 struct AdamTensor { float* p; const float* g; float* state; int32_t n; int32_t group; };
-struct AdamGroup { const float* lr_ptr; float lr, beta1, beta2, eps, wd; int32_t maximize; };
+struct AdamGroup { const float* lr_ptr; float lr, beta1, beta2, eps, wd; int32_t maximize; float gscale; };
 struct AdamArgs {
     AdamTensor t[ADAM_MAX_TENSORS];
     AdamGroup grp[ADAM_MAX_GROUPS];
@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256) adamw_step_kernel(AdamArgs a) {
     for (int k = 0; k < ADAM_CHUNK / 256; ++k) {
         const int i = base + 256 * k + (int)threadIdx.x;
         if (i < T.n) {
-            const float gg = G.maximize ? -g[k] : g[k];
+            const float gg = (G.maximize ? -g[k] : g[k]) * G.gscale;
             float pp = p[k];
             pp -= lr * G.wd * pp;
             const float mm = fmaf(1.f - G.beta1, gg - mi[k], mi[k]);
@@ -97,7 +97,7 @@ extern "C" int mkgnn_adamw_step(const mkgnn_adamw_tensor* tensors, int32_t n_ten
         const mkgnn_adamw_group& s = groups[g];
         if (!(s.beta1 >= 0.f && s.beta1 < 1.f && s.beta2 >= 0.f && s.beta2 < 1.f) || s.eps < 0.f || s.weight_decay < 0.f)
             return api_fail("mkgnn_adamw_step: group %d has betas (%g, %g), eps %g, weight_decay %g", g, s.beta1, s.beta2, s.eps, s.weight_decay);
-        a.grp[g] = AdamGroup{s.lr_device, s.lr, s.beta1, s.beta2, s.eps, s.weight_decay, s.maximize};
+        a.grp[g] = AdamGroup{s.lr_device, s.lr, s.beta1, s.beta2, s.eps, s.weight_decay, s.maximize, s.grad_scale};
     }
     for (int32_t first = 0; first < n_tensors; first += ADAM_MAX_TENSORS) {
         const int nt = n_tensors - first < ADAM_MAX_TENSORS ? n_tensors - first : ADAM_MAX_TENSORS;

@@ -18,7 +18,8 @@ from . import _lib
 
 
 class FusedAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, maximize: bool = False):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, maximize: bool = False,
+                 grad_scale: float = 1.0):
         if not isinstance(lr, torch.Tensor) and lr < 0.0:
             raise ValueError(f"Invalid learning rate: {lr}")
         if not 0.0 <= betas[0] < 1.0 or not 0.0 <= betas[1] < 1.0:
@@ -27,7 +28,10 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError(f"Invalid epsilon value: {eps}")
         if weight_decay < 0.0:
             raise ValueError(f"Invalid weight_decay value: {weight_decay}")
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, maximize=maximize))
+        # grad_scale: every gradient is multiplied by it first -- 1 / world after a summing all-reduce, so that the
+        # averaging costs no kernel of its own (default 1: torch.optim.AdamW's update)
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, maximize=maximize,
+                                      grad_scale=grad_scale))
         if len(self.param_groups) > 4:
             raise ValueError("FusedAdamW takes at most 4 parameter groups")
         self._table_key = None
@@ -115,6 +119,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 e.lr_device, e.lr = None, float(lr)
             e.beta1, e.beta2 = float(group["betas"][0]), float(group["betas"][1])
             e.eps, e.weight_decay, e.maximize = float(group["eps"]), float(group["weight_decay"]), int(bool(group["maximize"]))
+            e.grad_scale = float(group.get("grad_scale", 1.0))
         with torch.cuda.device(dev):
             _lib.check(lib.mkgnn_adamw_step(self._table, len(rows), groups, len(groups), _lib.stream_ptr(dev)),
                        "mkgnn_adamw_step")

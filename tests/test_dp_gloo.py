@@ -113,7 +113,10 @@ def _worker_static_grads(rank, world, port, out_dir):
         sets.append(red.grads())
     before = [[t.clone() for t in s] for s in sets]
     red.reduce(sets[0])                                    # "replay of graph 0": its tensors are averaged ...
-    torch.save({"before": before, "after": [[t.clone() for t in s] for s in sets]}, os.path.join(out_dir, f"rank{rank}.pt"))
+    after = [[t.clone() for t in s] for s in sets]
+    red.sum_into_flat(sets[1])                             # the flat-buffer form: a sum, nothing copied back
+    torch.save({"before": before, "after": after, "flat": [v.clone() for v in red.views],
+                "set1_after_sum": [t.clone() for t in sets[1]]}, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -129,3 +132,6 @@ def test_reduce_works_on_the_gradients_of_the_replayed_graph(tmp_path):
         want = (r0["before"][0][k] + r1["before"][0][k]) / 2
         assert torch.allclose(r0["after"][0][k], want, atol=1e-7) and torch.equal(r0["after"][0][k], r1["after"][0][k])
         assert torch.equal(r0["after"][1][k], r0["before"][1][k]) and torch.equal(r1["after"][1][k], r1["before"][1][k])
+        # sum_into_flat: the views hold the SUM over ranks of the given set, which itself is untouched
+        assert torch.allclose(r0["flat"][k], r0["before"][1][k] + r1["before"][1][k], atol=1e-6)
+        assert torch.equal(r0["flat"][k], r1["flat"][k]) and torch.equal(r0["set1_after_sum"][k], r0["before"][1][k])

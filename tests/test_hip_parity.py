@@ -1143,3 +1143,21 @@ def test_batch_norm_hands_row_norms_and_counts_batches():
     bn = torch.nn.BatchNorm1d(40).to(dev).train()         # other widths: no norms handed over, same results
     out = R.batch_norm(torch.randn(50, 40, device=dev), bn)
     assert Fn._handed_inv_norm(out) is None and int(bn.num_batches_tracked) == 1
+
+
+def test_fused_adamw_grad_scale_is_a_scaled_gradient():
+    """grad_scale = 1 / world (the data-parallel step sums the gradients into the flat buffer and lets the optimiser
+    divide): the same trajectory as torch.optim.AdamW fed with the scaled gradients."""
+    from molkgnn_amd.optim import FusedAdamW
+    dev = _dev()
+    mine, ref = _adamw_models(dev, seed=6)
+    opt_m = FusedAdamW(mine, lr=2e-3, weight_decay=0.02, grad_scale=0.125)
+    opt_r = torch.optim.AdamW(ref, lr=2e-3, weight_decay=0.02, foreach=False)
+    g = torch.Generator(device=dev).manual_seed(8)
+    for _ in range(5):
+        for pm, pr in zip(mine, ref):
+            grad = torch.randn(pm.shape, generator=g, device=dev) * 8
+            pm.grad, pr.grad = grad.clone(), grad * 0.125
+        opt_m.step(); opt_r.step()
+    for pm, pr in zip(mine, ref):
+        torch.testing.assert_close(pm, pr, rtol=2e-5, atol=2e-6)
