@@ -501,7 +501,10 @@ static hipError_t launch_lds_bwd(const BwdArgs& a0, int* nchunk_out, int* ntheta
         // every block ends by writing a full partial slab (115 KB for degree 4): with about one tile per block the
         // slab traffic costs as much as the tile (stamps: 15 us of work, 41 us of kernel), so a block takes at
         // least two tiles
-        if (blocks > (ntiles + 1) / 2) blocks = (ntiles + 1) / 2;
+        // (when there are more tiles than blocks; a small batch -- fewer tiles than CUs -- is latency-bound per tile
+        // and takes one tile per block: degree 4 at batch 256 has 16 tiles, 36 us on 8 blocks)
+        if (ntiles > BWD_BANK_BLOCKS && blocks > (ntiles + 1) / 2) blocks = (ntiles + 1) / 2;
+        if (blocks > ntiles) blocks = ntiles;
         if (blocks < 1) blocks = 1;
         a.nchunk = (int)blocks;
         a.theta_in_bank = rows_too ? 0 : 1;          // the LDS rows kernel sums the score-weight partials itself
