@@ -16,6 +16,7 @@
 // one partial slab per block; kc_backward_bank_reduce sums the slabs in a fixed order, so the
 // result is reproducible bit for bit.
 #include "kgnn_launch.h"
+#include <cstring>
 
 namespace mkgnn {
 
@@ -169,8 +170,9 @@ __device__ unsigned long long* g_bwd_stamp_buffer = nullptr;
 #endif
 
 // ------------------------------------------------------------------ bank ---
+// (device body: the block index and count are parameters, so that one launch can run the four degrees' blocks)
 template <int D, int KC, int LI, int TA>
-__global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
+__device__ __forceinline__ void bank_body(const BwdArgs& a, const int vblock, const int vgrid) {
     constexpr int NT = 512, NWV = 8;               // 8 waves share one staged tile: 2 waves per SIMD hide the LDS latency
     constexpr int FP = 16 * KC;
     constexpr int RS = FP + 8;                      // tile row: FP unit feature floats + 8 unit bond floats
@@ -278,20 +280,20 @@ __global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
             ev = a.e_nei[(n * D + slot) * a.E + (k < a.E ? k : a.E - 1)];
         }
     };
-    unsigned long long* stamps = g_bwd_stamp_buffer ? g_bwd_stamp_buffer + ((size_t)(D - 1) * 256 + blockIdx.x) * 64 : nullptr;
+    unsigned long long* stamps = g_bwd_stamp_buffer ? g_bwd_stamp_buffer + ((size_t)(D - 1) * 256 + vblock) * 64 : nullptr;
     int slot = 2;
     BWD_STAMP(0);
     for (int q = tid; q < TA * LP * CW; q += NT) coef[q] = 0.f;
-    int64_t tile = blockIdx.x;
+    int64_t tile = vblock;
     int buf = 0;
     store_id(issue_id(tile), 0);
-    store_id(issue_id(tile + gridDim.x), 1);         // (clamped past the end: harmless)
+    store_id(issue_id(tile + vgrid), 1);         // (clamped past the end: harmless)
     __syncthreads();
     store_inv(issue_inv(0), 0);
     fetch(tile, 0);
     __syncthreads();                                 // the first staging reads other threads' norms
     BWD_STAMP(1);
-    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+    for (; tile < ntiles; tile += vgrid, buf ^= 1) {
         // ---- registers -> LDS: unit feature rows, unit bond vectors, coefficients
 #pragma unroll
         for (int k = 0; k < MAXQ; ++k) {
@@ -337,8 +339,8 @@ __global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
         BWD_STAMP(slot);
         __syncthreads();
         BWD_STAMP(slot + 1);
-        const int64_t nxt = tile + gridDim.x;
-        const int id_ahead = issue_id(nxt + gridDim.x);      // these two first: the waits for them must not
+        const int64_t nxt = tile + vgrid;
+        const int id_ahead = issue_id(nxt + vgrid);      // these two first: the waits for them must not
         const float inv_ahead = issue_inv(buf ^ 1);          // cover the row gather issued next
         fetch(nxt < ntiles ? nxt : tile, buf ^ 1);
         BWD_STAMP(slot + 2);
@@ -409,7 +411,7 @@ __global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
             float t = 0.f;
 #pragma unroll
             for (int w = 0; w < NWV; ++w) t += red[tid * NWV + w];
-            a.theta_slab[(size_t)blockIdx.x * 4 + tid] = t;
+            a.theta_slab[(size_t)vblock * 4 + tid] = t;
         }
     }
     if constexpr (PACK > 1) {                        // lane groups -> group 0, fixed order (g0 + g1) + g2 ...
@@ -429,7 +431,7 @@ __global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
     }
     const bool writer = grp == 0;
     // ---- one partial slab per block (row order of kc_backward_bank in kgnn_generic.hip)
-    float* slab = a.slab + (size_t)blockIdx.x * bank_floats(D, L, a.F, a.E);
+    float* slab = a.slab + (size_t)vblock * bank_floats(D, L, a.F, a.E);
     const size_t o_sup = (size_t)L * a.F, o_edg = o_sup + (size_t)L * D * a.F;
 #pragma unroll
     for (int li = 0; li < LI; ++li) {
@@ -449,6 +451,36 @@ __global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
                 }
             }
         }
+    }
+}
+
+template <int D, int KC, int LI, int TA>
+__global__ void __launch_bounds__(512) kc_backward_bank_lds(BwdArgs a) {
+    bank_body<D, KC, LI, TA>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The four degrees' bank-gradient blocks in ONE launch: block b belongs to segment s (blk_start[s] <= b <
+// blk_start[s + 1]) = degree order[s], heaviest degree first; the blocks of the next degree start as soon as a CU is
+// free.  133 us alone against 153 us for four launches at batch 4096 (in the replayed graph the step is the same: it is
+// bound by the combined work of the two backward chains); at small batches, where a degree has fewer tiles than the
+// GPU has CUs and four launches of latency-bound blocks ran one after the other, 4-10 % of a step.
+struct BankFusedArgs {
+    BwdArgs d[4];
+    int blk_start[5];
+    int order[4];
+    int nseg;
+};
+
+template <int KC>
+__global__ void __launch_bounds__(512) kc_backward_bank_fused(BankFusedArgs fa) {
+    int sgm = 0;
+    for (int q = 1; q < fa.nseg; ++q) if ((int)blockIdx.x >= fa.blk_start[q]) sgm = q;
+    const int vblock = (int)blockIdx.x - fa.blk_start[sgm], vgrid = fa.blk_start[sgm + 1] - fa.blk_start[sgm];
+    switch (fa.order[sgm]) {
+        case 0: bank_body<1, KC, bank_li(1), bank_ta(1)>(fa.d[0], vblock, vgrid); break;
+        case 1: bank_body<2, KC, bank_li(2), bank_ta(2)>(fa.d[1], vblock, vgrid); break;
+        case 2: bank_body<3, KC, bank_li(3), bank_ta(3)>(fa.d[2], vblock, vgrid); break;
+        default: bank_body<4, KC, bank_li(4), bank_ta(4)>(fa.d[3], vblock, vgrid); break;
     }
 }
 
@@ -512,6 +544,67 @@ static hipError_t launch_lds_bwd(const BwdArgs& a0, int* nchunk_out, int* ntheta
         kc_backward_bank_lds<D, KC, LI, TA><<<(int)blocks, 512, lds_bytes, st>>>(a);
         *nchunk_out = (int)blocks;
     }
+    return hipGetLastError();
+}
+
+static size_t bank_lds_bytes(int d, int FP) {
+    const int TA = bank_ta(d), CW = (d == 1) ? 2 : ((d == 4) ? 8 : 4);
+    return ((size_t)TA * (d + 1) * (FP + 8) + CW * TA * (size_t)(8 * bank_li(d)) + 4 * TA * (d + 1)) * 4;
+}
+
+// blocks the bank kernel of degree d uses for n atoms (the rule of launch_lds_bwd)
+int bank_blocks_for(int d, int64_t n) {
+    const int64_t ntiles = (n + bank_ta(d) - 1) / bank_ta(d);
+    int64_t blocks = BWD_BANK_BLOCKS;
+    if (ntiles > BWD_BANK_BLOCKS && blocks > (ntiles + 1) / 2) blocks = (ntiles + 1) / 2;
+    if (blocks > ntiles) blocks = ntiles;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+// One launch for the bank gradients of every degree in `use` (all with the MFMA rows kernel in front: the bank kernel
+// sums the score-weight partials).  nchunk_out[i] / ntheta_out[i] = slabs written for degree i + 1.
+hipError_t launch_backward_bank_fused(const BwdArgs a4[4], const bool use[4], int nchunk_out[4], int ntheta_out[4], hipStream_t st) {
+    BankFusedArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    int KC = 0;
+    size_t lds_bytes = 0;
+    int order[4], n_use = 0;
+    for (int i = 0; i < 4; ++i) if (use[i]) order[n_use++] = i;
+    for (int x = 0; x < n_use; ++x)                  // heaviest first: work ~ atoms * kernels * (d + 1)
+        for (int y = x + 1; y < n_use; ++y) {
+            const double wx = (double)a4[order[x]].n * a4[order[x]].L * (order[x] + 2), wy = (double)a4[order[y]].n * a4[order[y]].L * (order[y] + 2);
+            if (wy > wx) { const int t = order[x]; order[x] = order[y]; order[y] = t; }
+        }
+    int blk = 0;
+    for (int x = 0; x < n_use; ++x) {
+        const int i = order[x], d = i + 1;
+        fa.d[i] = a4[i];
+        const int blocks = bank_blocks_for(d, a4[i].n);
+        fa.d[i].nchunk = blocks;
+        fa.d[i].theta_in_bank = 1;
+        fa.order[x] = i;
+        fa.blk_start[x] = blk;
+        blk += blocks;
+        nchunk_out[i] = blocks;
+        ntheta_out[i] = blocks;
+        const int FP = mfma_padded_width(a4[i].F);
+        KC = FP / 16;
+        const size_t b = bank_lds_bytes(d, FP);
+        if (b > lds_bytes) lds_bytes = b;
+    }
+    fa.blk_start[n_use] = blk;
+    fa.nseg = n_use;
+    if (n_use == 0) return hipSuccess;
+    static bool attr_set[2] = {false, false};
+    const int which = KC == 2 ? 0 : 1;
+    if (!attr_set[which]) {
+        hipError_t e = KC == 2 ? hipFuncSetAttribute((const void*)kc_backward_bank_fused<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)
+                               : hipFuncSetAttribute((const void*)kc_backward_bank_fused<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
+        if (e != hipSuccess) return e;
+        attr_set[which] = true;
+    }
+    if (KC == 2) kc_backward_bank_fused<2><<<blk, 512, lds_bytes, st>>>(fa);
+    else kc_backward_bank_fused<7><<<blk, 512, lds_bytes, st>>>(fa);
     return hipGetLastError();
 }
 

@@ -315,6 +315,19 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
     bool bank_on_main = false;                       // some bank gradient was computed on the caller's stream
     int off_of[4]; int64_t base_of[4];
     for (int i = 0; i < 4; ++i) { off_of[i] = off; base_of[i] = base; off += L[i]; base += buckets[i].count * (i + 2); }
+    // The bank gradients of all four degrees in one launch when every degree runs the MFMA rows + LDS bank pair: the
+    // blocks of the next degree start as soon as a CU is free.  Neutral at batch 4096 (the replayed graph is bound by the
+    // combined work of its two chains), 4-10 % of a step at batches <= 2048, where four launches of a few latency-bound
+    // blocks each ran one after the other.
+    static const bool no_mfma_bwd = getenv("MKGNN_NO_MFMA_BWD") != nullptr;     // diagnostics: A/B against the LDS rows kernel
+    static const char* env_bank_fused = getenv("MKGNN_BANK_FUSED");             // diagnostics: "0" = one launch per degree
+    bool fuse_bank = !(env_bank_fused && env_bank_fused[0] == '0') && !no_mfma_bwd;
+    for (int i = 0; i < 4 && fuse_bank; ++i)
+        if (buckets[i].count > 0 && L[i] > 0 &&
+            !(lds_backward_supported(i + 1, F, E, L[i], x_stride, x) && mfma_backward_supported(i + 1, F, E, L[i], x_stride, x, n_atoms)))
+            fuse_bank = false;
+    BwdArgs bank_a[4];
+    bool bank_use[4] = {false, false, false, false};
     for (int i = 0; i < 4; ++i) {                    // (the launch order of the degrees makes no measurable difference)
         const int d = i + 1;
         const int off = off_of[i];
@@ -349,7 +362,6 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
             if (e != hipSuccess) return hip_fail("contribution rows memset", e);
         }
         if (a.n > 0 && L[i] > 0) {
-            static const bool no_mfma_bwd = getenv("MKGNN_NO_MFMA_BWD") != nullptr;     // diagnostics: A/B against the LDS rows kernel
             if (lds_backward_supported(d, F, E, L[i], x_stride, x)) {
                 const bool rows_mfma = !no_mfma_bwd && mfma_backward_supported(d, F, E, L[i], x_stride, x, n_atoms);
                 hipStream_t st_rows = dst, st_bank = dst;
@@ -363,7 +375,8 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
                     e = launch_backward_rows_mfma(d, a, &ntheta, st_rows);
                     if (e != hipSuccess) return hip_fail("kernelconv backward launch", e);
                 }
-                e = launch_backward_lds(d, a, &nchunk, &ntheta, !rows_mfma, st_bank);
+                if (fuse_bank) { bank_a[i] = a; bank_use[i] = true; }       // launched below, all degrees together
+                else e = launch_backward_lds(d, a, &nchunk, &ntheta, !rows_mfma, st_bank);
             }
             else { e = launch_backward_generic(d, a, dst); bank_on_main = true; }
             if (e != hipSuccess) return hip_fail("kernelconv backward launch", e);
@@ -379,6 +392,18 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         r.icen = (const float*)(ws + w.bank[i].icen); r.isup = (const float*)(ws + w.bank[i].isup);
         r.iedg = (const float*)(ws + w.bank[i].iedg);
         r.g = grads[i];
+    }
+    if (bank_use[0] || bank_use[1] || bank_use[2] || bank_use[3]) {
+        int nchunk4[4] = {0, 0, 0, 0}, ntheta4[4] = {0, 0, 0, 0};
+        hipStream_t st_bank = fj.stream(1, &e);      // the helper (the caller's stream when nothing is forked)
+        if (e != hipSuccess) return hip_fail("stream fork", e);
+        e = launch_backward_bank_fused(bank_a, bank_use, nchunk4, ntheta4, st_bank);
+        if (e != hipSuccess) return hip_fail("fused bank gradient launch", e);
+        for (int i = 0; i < 4; ++i)
+            if (bank_use[i]) {
+                reduce[i].nchunk = nchunk4[i];
+                reduce[i].theta_src = bank_a[i].theta_slab; reduce[i].theta_stride = 4; reduce[i].theta_count = ntheta4[i];
+            }
     }
     // two chains: the reduce follows the bank kernels on the helper, the gather follows the rows kernels here
     const bool split = fj.two_way && !bank_on_main && fj.used[0];

@@ -97,6 +97,8 @@ hipError_t launch_bank_reduce_all(const BankReduceArgs r[4], hipStream_t st);   
 // kgnn_bwd.hip: LDS-tiled backward for the model's shapes
 bool lds_backward_supported(int d, int F, int E, int L, int64_t xs, const void* x);
 hipError_t launch_backward_lds(int d, const BwdArgs& a, int* nchunk_out, int* ntheta_out, bool rows_too, hipStream_t st);
+int bank_blocks_for(int d, int64_t n);
+hipError_t launch_backward_bank_fused(const BwdArgs a4[4], const bool use[4], int nchunk_out[4], int ntheta_out[4], hipStream_t st);
 // kgnn_bwd_mfma.hip: MFMA backward for the model's shapes
 bool mfma_backward_supported(int d, int F, int E, int L, int64_t xs, const void* x, int64_t n_atoms);
 hipError_t launch_backward_rows_mfma(int d, const BwdArgs& a, int* ntheta_out, hipStream_t st);
