@@ -18,7 +18,6 @@
 // unconditional on clamped addresses and masked afterwards (a load under a lane-dependent branch
 // ends its basic block with a full wait and serialises the round trips).
 #include "kgnn_launch.h"
-#include <cstring>
 
 namespace mkgnn {
 
@@ -51,9 +50,8 @@ __host__ __device__ constexpr int bwd_slice_stride(int fpw) { return (fpw % 32 =
 // B = unit kernel rows (LDS, b32 reads, conflict-free), D = contribution rows.
 // (The three score-weight partials d sc / d theta_k are summed by the bank kernel, which visits every
 // (atom, kernel) pair with one thread and has registers to spare; here they cost 3 LQ prefetch registers.)
-// (device body: the block index and count are parameters, so that one launch can run the four degrees' blocks)
 template <int D, int KC, int NT>
-__device__ __forceinline__ void rows_body(const BwdArgs& a, const int vblock, const int vgrid) {
+__global__ void __launch_bounds__(NT, 2) kc_backward_rows_mfma(BwdArgs a) {
     constexpr int FP = 16 * KC;
     constexpr int FT = KC;                           // 16-feature tiles
     constexpr int FS = bwd_fsplit(D, KC);            // feature slices (blocks per group of atom tiles)
@@ -68,7 +66,7 @@ __device__ __forceinline__ void rows_body(const BwdArgs& a, const int vblock, co
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ci = lane & 15, kq = lane >> 4;
     unsigned long long* stamps = g_rows_stamp_buffer
-        ? g_rows_stamp_buffer + (((size_t)(D - 1) * 1024 + vblock) * NWV + wave) * 32 : nullptr;
+        ? g_rows_stamp_buffer + (((size_t)(D - 1) * 1024 + blockIdx.x) * NWV + wave) * 32 : nullptr;
     int sslot = 2;
     ROWS_STAMP(0);
     const float w_s = a.mix[0], w_c = a.mix[1], w_sum = a.mix[3];
@@ -78,9 +76,9 @@ __device__ __forceinline__ void rows_body(const BwdArgs& a, const int vblock, co
     // Coefficient inputs of a tile, software pipelined one tile ahead: the loads of tile t + 1 are issued
     // before the MFMA loop of tile t and its focal ids (the address of the grad_out gather) one tile before
     // that, so the two dependent global round trips per tile overlap the matrix work instead of preceding it.
-    const int slice = vblock % FS;               // (the host launches a multiple of FS blocks)
+    const int slice = blockIdx.x % FS;               // (the host launches a multiple of FS blocks)
     const int ft0 = slice * FTW;                     // this block's feature tiles: ft0 .. ft0 + FTW - 1 (those < FT exist)
-    const int64_t tstep = (int64_t)(vgrid / FS) * NWV;
+    const int64_t tstep = (int64_t)(gridDim.x / FS) * NWV;
     float rg[LQ];
     int ridx[LQ], rch[LQ];
     auto focal_of = [&](int64_t tile) -> int64_t {
@@ -101,7 +99,7 @@ __device__ __forceinline__ void rows_body(const BwdArgs& a, const int vblock, co
             ch[kk] = chp[(size_t)nc * L + l];
         }
     };
-    int64_t tile = (int64_t)(vblock / FS) * NWV + wave;
+    int64_t tile = (int64_t)(blockIdx.x / FS) * NWV + wave;
     int64_t focal_next = 0;
     {   // unconditional (clamped past the end): a load inside a conditional block is waited for at its end
         const int64_t t0 = tile < ntiles ? tile : ntiles - 1;
@@ -219,33 +217,6 @@ __device__ __forceinline__ void rows_body(const BwdArgs& a, const int vblock, co
     }
 }
 
-template <int D, int KC, int NT>
-__global__ void __launch_bounds__(NT, 2) kc_backward_rows_mfma(BwdArgs a) {
-    rows_body<D, KC, NT>(a, (int)blockIdx.x, (int)gridDim.x);
-}
-
-// The four degrees' x-gradient blocks in ONE launch (segment table as in kc_backward_bank_fused): at small batches the
-// four launches are a few latency-bound blocks each and run one after the other on the x-gradient chain.
-struct RowsFusedArgs {
-    BwdArgs d[4];
-    int blk_start[5];
-    int order[4];
-    int nseg;
-};
-
-template <int KC>
-__global__ void __launch_bounds__(256, 2) kc_backward_rows_fused(RowsFusedArgs fa) {
-    int sgm = 0;
-    for (int q = 1; q < fa.nseg; ++q) if ((int)blockIdx.x >= fa.blk_start[q]) sgm = q;
-    const int vblock = (int)blockIdx.x - fa.blk_start[sgm], vgrid = fa.blk_start[sgm + 1] - fa.blk_start[sgm];
-    switch (fa.order[sgm]) {
-        case 0: rows_body<1, KC, 256>(fa.d[0], vblock, vgrid); break;
-        case 1: rows_body<2, KC, 256>(fa.d[1], vblock, vgrid); break;
-        case 2: rows_body<3, KC, 256>(fa.d[2], vblock, vgrid); break;
-        default: rows_body<4, KC, 256>(fa.d[3], vblock, vgrid); break;
-    }
-}
-
 // ------------------------------------------------------------------ host ---
 bool mfma_backward_supported(int d, int F, int E, int L, int64_t xs, const void* x, int64_t n_atoms) {
     if (d < 1 || d > 4 || L < 1 || E > 8) return false;
@@ -254,71 +225,6 @@ bool mfma_backward_supported(int d, int F, int E, int L, int64_t xs, const void*
     if ((uint64_t)n_atoms * (uint64_t)xs >= (1ull << 32)) return false;
     if (L > 4 * bwd_lq(d)) return false;
     return ((size_t)(d + 1) * L * FP) * 4 <= 150 * 1024;
-}
-
-// grid and dynamic LDS of the rows kernel for degree d (the rule of launch_mfma_rows)
-static void rows_geometry(int d, int KC, int L, int64_t n, int* blocks_out, size_t* lds_out) {
-    const int64_t ntiles = (n + 15) / 16;
-    const int FS = bwd_fsplit(d, KC);
-    const int FTW = (KC + FS - 1) / FS;
-    const size_t lds_bytes = (size_t)(d + 1) * L * bwd_slice_stride(16 * FTW) * 4;
-    int per_cu = (int)((160 * 1024 - 2048) / (lds_bytes + 256));
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 2) per_cu = 2;
-    int64_t groups = 256 * per_cu / FS;
-    const int64_t need = (ntiles + 3) / 4;
-    if (groups > need) groups = need;
-    if (groups < 1) groups = 1;
-    int64_t blocks = groups * FS;
-    if (blocks > THETA_SLAB_BLOCKS) blocks = THETA_SLAB_BLOCKS;
-    *blocks_out = (int)blocks;
-    *lds_out = lds_bytes;
-}
-
-int rows_blocks_for(int d, int F, int L, int64_t n) {
-    int blocks; size_t lb;
-    rows_geometry(d, mfma_padded_width(F) / 16, L, n, &blocks, &lb);
-    return blocks;
-}
-
-hipError_t launch_backward_rows_fused(const BwdArgs a4[4], const bool use[4], hipStream_t st) {
-    RowsFusedArgs fa;
-    memset(&fa, 0, sizeof(fa));
-    int order[4], n_use = 0, KC = 0;
-    for (int i = 0; i < 4; ++i) if (use[i]) order[n_use++] = i;
-    if (n_use == 0) return hipSuccess;
-    for (int x = 0; x < n_use; ++x)                  // heaviest first: masked products ~ atoms * kernels * (d^2 + 1)
-        for (int y = x + 1; y < n_use; ++y) {
-            const int dx = order[x] + 1, dy = order[y] + 1;
-            const double wx = (double)a4[order[x]].n * a4[order[x]].L * (dx * dx + 1), wy = (double)a4[order[y]].n * a4[order[y]].L * (dy * dy + 1);
-            if (wy > wx) { const int t = order[x]; order[x] = order[y]; order[y] = t; }
-        }
-    int blk = 0;
-    size_t lds_bytes = 0;
-    for (int x = 0; x < n_use; ++x) {
-        const int i = order[x];
-        KC = mfma_padded_width(a4[i].F) / 16;
-        int blocks; size_t lb;
-        rows_geometry(i + 1, KC, a4[i].L, a4[i].n, &blocks, &lb);
-        fa.d[i] = a4[i];
-        fa.order[x] = i;
-        fa.blk_start[x] = blk;
-        blk += blocks;
-        if (lb > lds_bytes) lds_bytes = lb;
-    }
-    fa.blk_start[n_use] = blk;
-    fa.nseg = n_use;
-    static bool attr_set[2] = {false, false};
-    const int which = KC == 2 ? 0 : 1;
-    if (!attr_set[which]) {
-        hipError_t e = KC == 2 ? hipFuncSetAttribute((const void*)kc_backward_rows_fused<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)
-                               : hipFuncSetAttribute((const void*)kc_backward_rows_fused<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
-        if (e != hipSuccess) return e;
-        attr_set[which] = true;
-    }
-    if (KC == 2) kc_backward_rows_fused<2><<<blk, 256, lds_bytes, st>>>(fa);
-    else kc_backward_rows_fused<7><<<blk, 256, lds_bytes, st>>>(fa);
-    return hipGetLastError();
 }
 
 template <int D, int KC>

@@ -328,19 +328,6 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
             fuse_bank = false;
     BwdArgs bank_a[4];
     bool bank_use[4] = {false, false, false, false};
-    // The x-gradient (rows) kernels likewise, but only while all their blocks are resident at once (two per CU): the
-    // merged kernel carries the largest degree's registers (40 spilled VGPRs at F = 110), which costs at full size what
-    // the saved launch boundaries gain; at batch <= 1024 the four launches are a few latency-bound blocks each.
-    static const char* env_rows_fused = getenv("MKGNN_ROWS_FUSED");             // diagnostics: "0" never, "1" always
-    bool fuse_rows = fuse_bank && !(env_rows_fused && env_rows_fused[0] == '0');
-    if (fuse_rows && !(env_rows_fused && env_rows_fused[0] == '1')) {
-        int total = 0;
-        for (int i = 0; i < 4; ++i)
-            if (buckets[i].count > 0 && L[i] > 0) total += rows_blocks_for(i + 1, F, L[i], buckets[i].count);
-        if (total > 512) fuse_rows = false;
-    }
-    BwdArgs rows_a[4];
-    bool rows_use[4] = {false, false, false, false};
     for (int i = 0; i < 4; ++i) {                    // (the launch order of the degrees makes no measurable difference)
         const int d = i + 1;
         const int off = off_of[i];
@@ -384,8 +371,7 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
                     st_bank = fj.stream(1, &e);
                     if (e != hipSuccess) return hip_fail("stream fork", e);
                 }
-                if (rows_mfma && fuse_rows) { rows_a[i] = a; rows_use[i] = true; }      // launched below, all degrees together
-                else if (rows_mfma) {
+                if (rows_mfma) {
                     e = launch_backward_rows_mfma(d, a, &ntheta, st_rows);
                     if (e != hipSuccess) return hip_fail("kernelconv backward launch", e);
                 }
@@ -406,10 +392,6 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         r.icen = (const float*)(ws + w.bank[i].icen); r.isup = (const float*)(ws + w.bank[i].isup);
         r.iedg = (const float*)(ws + w.bank[i].iedg);
         r.g = grads[i];
-    }
-    if (rows_use[0] || rows_use[1] || rows_use[2] || rows_use[3]) {
-        e = launch_backward_rows_fused(rows_a, rows_use, st);                   // on the caller's stream: the gather follows it
-        if (e != hipSuccess) return hip_fail("fused x-gradient launch", e);
     }
     if (bank_use[0] || bank_use[1] || bank_use[2] || bank_use[3]) {
         int nchunk4[4] = {0, 0, 0, 0}, ntheta4[4] = {0, 0, 0, 0};

@@ -102,8 +102,6 @@ hipError_t launch_backward_bank_fused(const BwdArgs a4[4], const bool use[4], in
 // kgnn_bwd_mfma.hip: MFMA backward for the model's shapes
 bool mfma_backward_supported(int d, int F, int E, int L, int64_t xs, const void* x, int64_t n_atoms);
 hipError_t launch_backward_rows_mfma(int d, const BwdArgs& a, int* ntheta_out, hipStream_t st);
-hipError_t launch_backward_rows_fused(const BwdArgs a4[4], const bool use[4], hipStream_t st);
-int rows_blocks_for(int d, int F, int L, int64_t n);
 hipError_t launch_backward_gather(const float* contrib, int64_t cs, int64_t n_contrib_rows, const int32_t* rowptr,
                                   const int32_t* rows, const float* x, int64_t xs, const float* inv, int64_t n, int F,
                                   float* gx, int64_t gxs, hipStream_t st);
