@@ -163,7 +163,7 @@ def main():
             print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
     # One hipGraph per resident batch: forward + backward + optimiser are launch-bound at this model size
-    # (60 kernels of 5-100 us), so the step is captured once and replayed.  The gradient all-reduce
+    # (51 kernels of 5-190 us), so the step is captured once and replayed.  The gradient all-reduce
     # (N > 1) stays outside the graph, between the backward graph and the optimiser.
     graphs = None
     flat_opt = False
