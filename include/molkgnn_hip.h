@@ -17,7 +17,11 @@
  *     on `stream` (a hipStream_t passed as void*), so calls are graph-capturable;
  *   - return 0 on success, non-zero on a rejected argument or a launch error;
  *     mkgnn_last_error() then describes it (thread-local, host pointer);
- *   - stateless and re-entrant.
+ *   - no state is kept between calls except lazily created helper streams / events (one set per device,
+ *     created under std::call_once); calls on DIFFERENT devices or different streams of one device may run from
+ *     different host threads, but mkgnn_kernelsetconv_backward forks onto the device's helper streams, so at
+ *     most one host thread per device may be inside it at a time (PyTorch's autograd engine guarantees that:
+ *     one backward thread per device).
  *
  * Shapes use the reference's names: N atoms in the batch, F node-attribute
  * width, E edge-attribute width, D = 3 coordinates, d = degree (1..4),
@@ -34,7 +38,7 @@ extern "C" {
 #endif
 
 #define MKGNN_MAX_DEGREE 4
-#define MKGNN_ABI_VERSION 1
+#define MKGNN_ABI_VERSION 2
 
 /* One KernelConv's parameters (reference kernels.py:50-84).  The three score
  * weights are the 0-d parameters support_attr_sc_weight, center_attr_sc_weight
@@ -128,7 +132,11 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
  *   grads     per-degree parameter gradients, fully overwritten.
  *   workspace_from_forward  non-zero: `workspace` is the buffer the forward call of this layer used,
  *             untouched since, with the same banks / shapes: the normalised kernel bank in it is reused
- *             instead of being recomputed. */
+ *             instead of being recomputed.
+ *   variant   0 = automatic (the MFMA rows / LDS bank / pipelined gather kernels wherever a degree's shape is
+ *             covered, the generic kernels elsewhere), 1 = the generic one-wave-per-atom kernels and the plain
+ *             gather for every degree (the A/B reference of the parity tests), 2 = the fast kernels, failing if a
+ *             degree with atoms and kernels is not covered by them. */
 int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
                                  const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],
                                  const float* x, int64_t x_stride, const float* inv_norm,
@@ -139,7 +147,7 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
                                  float* grad_x, int64_t grad_x_stride,
                                  const mkgnn_kernel_bank_grad grads[MKGNN_MAX_DEGREE],
                                  void* workspace, size_t workspace_bytes, int32_t workspace_from_forward,
-                                 void* stream);
+                                 int32_t variant, void* stream);
 
 /* MolGCN.propagate with aggr='add' (KernelLayer.py:14,119-123) as a CSR segment
  * sum: out[i, :] = sum_{k in [rowptr[i], rowptr[i+1])} in[col[k], :].
@@ -279,13 +287,16 @@ int mkgnn_bce_head_dropout_backward(const float* emb, int64_t emb_stride, int64_
  * state [2 * numel + 3] = exp_avg, exp_avg_sq, step count (as a float, advanced by this call), two scratch floats.  Per group: the
  * learning rate either by value (lr_device NULL) or read from a device float at run time (so that a captured graph
  * follows a scheduler), betas, eps, decoupled weight_decay, maximize, grad_scale.  The update is torch's fused AdamW formula
- * (bias corrections 1 - beta^step).  At most 4 groups; any number of tensors (96 per launch pair). */
+ * (bias corrections 1 - beta^step).  At most 4 groups; any number of tensors (80 per launch pair). */
 typedef struct mkgnn_adamw_tensor {
     float* param;
     const float* grad;
     float* state;
     int64_t numel;
     int32_t group;
+    int32_t reserved;
+    const float* active;   /* NULL, or a device float: the tensor is skipped (no update, step count not advanced) when it
+                              reads 0 -- "no rank had a gradient for it this step" in a captured data-parallel step */
 } mkgnn_adamw_tensor;
 typedef struct mkgnn_adamw_group {
     const float* lr_device;

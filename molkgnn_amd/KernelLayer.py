@@ -73,9 +73,10 @@ class MolGCN(MessagePassing):
     def num_kernels(self, layer):
         return self.num_kernels_list[layer]
 
-    def set_variant(self, variant: str):
+    def set_variant(self, variant: str, backward_variant=None):
         for layer in self.layers:
             layer.variant = variant
+            layer.backward_variant = backward_variant
 
     def propagate(self, edge_index, sim_sc=None, **kwargs):
         """``h[i] = sum_{j -> i} message(sim_sc[j])``; ``message`` is the identity (KernelLayer.py:122-123)."""

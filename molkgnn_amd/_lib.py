@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmolkgnn_hip.so")
 MAX_DEGREE = 4
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class KernelBank(C.Structure):
@@ -48,7 +48,7 @@ class ReadoutParams(C.Structure):
 
 class AdamWTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("state", C.c_void_p), ("numel", C.c_int64),
-                ("group", C.c_int32)]
+                ("group", C.c_int32), ("reserved", C.c_int32), ("active", C.c_void_p)]
 
 
 class AdamWGroup(C.Structure):
@@ -104,7 +104,7 @@ def load() -> C.CDLL:
     lib.mkgnn_kernelsetconv_backward.argtypes = [
         Banks4, Buckets4, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
         C.c_void_p, C.c_int64, Saved4, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, BankGrads4,
-        C.c_void_p, C.c_size_t, C.c_int32, C.c_void_p]
+        C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_void_p]
     lib.mkgnn_segment_sum_rows.restype = C.c_int
     lib.mkgnn_segment_sum_rows.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32,
                                            C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]

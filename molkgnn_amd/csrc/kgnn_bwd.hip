@@ -501,15 +501,15 @@ static hipError_t launch_lds_bwd(const BwdArgs& a0, int* nchunk_out, int* ntheta
     constexpr int LI = bank_li(D);
     constexpr int TA = bank_ta(D);
     BwdArgs a = a0;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (const int slot = attr_set.pending(); slot >= 0) {
         hipError_t e = hipFuncSetAttribute((const void*)kc_backward_rows_lds<D, KC>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void*)kc_backward_bank_lds<D, KC, LI, TA>,
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.set(slot);
     }
     if (rows_too) {   // rows (also the score-weight partials)
         const size_t lds_bytes = rows_lds_bytes(D, FP, a.L);
@@ -595,13 +595,13 @@ hipError_t launch_backward_bank_fused(const BwdArgs a4[4], const bool use[4], in
     fa.blk_start[n_use] = blk;
     fa.nseg = n_use;
     if (n_use == 0) return hipSuccess;
-    static bool attr_set[2] = {false, false};
+    static PerDeviceOnce attr_set[2];
     const int which = KC == 2 ? 0 : 1;
-    if (!attr_set[which]) {
+    if (const int slot = attr_set[which].pending(); slot >= 0) {
         hipError_t e = KC == 2 ? hipFuncSetAttribute((const void*)kc_backward_bank_fused<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024)
                                : hipFuncSetAttribute((const void*)kc_backward_bank_fused<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         if (e != hipSuccess) return e;
-        attr_set[which] = true;
+        attr_set[which].set(slot);
     }
     if (KC == 2) kc_backward_bank_fused<2><<<blk, 512, lds_bytes, st>>>(fa);
     else kc_backward_bank_fused<7><<<blk, 512, lds_bytes, st>>>(fa);

@@ -232,12 +232,12 @@ static hipError_t launch_mfma_rows(const BwdArgs& a, int* ntheta_out, hipStream_
     // (eight waves per block were tried for degree 4 -- 112 KB of bank, one block per CU -- to give every wave a single
     // unit: at two waves per SIMD its ~300 registers spill 400 VGPRs)
     constexpr int NT = 256;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_set;
+    if (const int slot = attr_set.pending(); slot >= 0) {
         hipError_t e = hipFuncSetAttribute((const void*)kc_backward_rows_mfma<D, KC, NT>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set.set(slot);
     }
     const int64_t ntiles = (a.n + 15) / 16;
     constexpr int FS = bwd_fsplit(D, KC);

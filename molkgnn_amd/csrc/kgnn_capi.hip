@@ -5,6 +5,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "kgnn_launch.h"
 
 using namespace mkgnn;
@@ -44,24 +46,29 @@ struct DegreeStreams {
     hipEvent_t fork;
     hipEvent_t join[3];
     bool ready;
+    std::once_flag once;
 };
 static DegreeStreams g_streams[16];
 
+// Created once per device under std::call_once (two host threads making their first call on one device do not race on
+// the table).  The fork / join events are per device: the header's threading rule -- one host thread per device inside
+// the backward call at a time -- is what keeps two callers from recording the same event.
 static DegreeStreams* degree_streams() {
     static const bool serial = getenv("MKGNN_SERIAL") != nullptr;    // diagnostics: keep everything on one stream
     if (serial) return nullptr;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
     DegreeStreams& p = g_streams[dev];
-    if (!p.ready) {
-        for (int i = 0; i < 3; ++i) {
-            if (hipStreamCreateWithFlags(&p.aux[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
-            if (hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+    std::call_once(p.once, [&p]() {
+        bool ok = true;
+        for (int i = 0; i < 3 && ok; ++i) {
+            ok = hipStreamCreateWithFlags(&p.aux[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming) == hipSuccess;
         }
-        if (hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-        p.ready = true;
-    }
-    return &p;
+        ok = ok && hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) == hipSuccess;
+        p.ready = ok;
+    });
+    return p.ready ? &p : nullptr;
 }
 
 // Stream on which degree slot `i` (0 = most work) runs; slot 0 stays on the caller's stream.
@@ -284,8 +291,10 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
                                  const mkgnn_saved saved[MKGNN_MAX_DEGREE], const int32_t* scatter_rowptr,
                                  const int32_t* scatter_rows, float* grad_x, int64_t grad_x_stride,
                                  const mkgnn_kernel_bank_grad grads[MKGNN_MAX_DEGREE], void* workspace,
-                                 size_t workspace_bytes, int32_t workspace_from_forward, void* stream) {
+                                 size_t workspace_bytes, int32_t workspace_from_forward, int32_t variant, void* stream) {
     const char* who = "mkgnn_kernelsetconv_backward";
+    if (variant < 0 || variant > 2) return fail("%s: variant %d (0 = automatic, 1 = generic kernels, 2 = fast kernels)", who, variant);
+    const bool force_generic = variant == 1, force_fast = variant == 2;
     int64_t n_edges = 0;
     if (int rc = check_common(who, banks, buckets, x, x_stride, inv_norm, n_atoms, F, E, 0, &n_edges)) return rc;
     if (!saved || !grads) return fail("%s: saved/grads is null", who);
@@ -321,7 +330,7 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
     // blocks each ran one after the other.
     static const bool no_mfma_bwd = getenv("MKGNN_NO_MFMA_BWD") != nullptr;     // diagnostics: A/B against the LDS rows kernel
     static const char* env_bank_fused = getenv("MKGNN_BANK_FUSED");             // diagnostics: "0" = one launch per degree
-    bool fuse_bank = !(env_bank_fused && env_bank_fused[0] == '0') && !no_mfma_bwd;
+    bool fuse_bank = !(env_bank_fused && env_bank_fused[0] == '0') && !no_mfma_bwd && !force_generic;
     for (int i = 0; i < 4 && fuse_bank; ++i)
         if (buckets[i].count > 0 && L[i] > 0 &&
             !(lds_backward_supported(i + 1, F, E, L[i], x_stride, x) && mfma_backward_supported(i + 1, F, E, L[i], x_stride, x, n_atoms)))
@@ -362,7 +371,11 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
             if (e != hipSuccess) return hip_fail("contribution rows memset", e);
         }
         if (a.n > 0 && L[i] > 0) {
-            if (lds_backward_supported(d, F, E, L[i], x_stride, x)) {
+            const bool fast_ok = lds_backward_supported(d, F, E, L[i], x_stride, x);
+            if (force_fast && !(fast_ok && mfma_backward_supported(d, F, E, L[i], x_stride, x, n_atoms)))
+                return fail("%s: the fast kernels do not cover degree %d with F=%d E=%d L=%d stride=%lld", who, d, F, E, L[i],
+                            (long long)x_stride);
+            if (fast_ok && !force_generic) {
                 const bool rows_mfma = !no_mfma_bwd && mfma_backward_supported(d, F, E, L[i], x_stride, x, n_atoms);
                 hipStream_t st_rows = dst, st_bank = dst;
                 if (fj.two_way && !rows_mfma) bank_on_main = true;
@@ -420,7 +433,7 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
     if (e != hipSuccess) return hip_fail("bank gradient reduce launch", e);
     if (grad_x) {
         e = launch_backward_gather((const float*)(ws + w.contrib), (F + 3) / 4 * 4, base, scatter_rowptr, scatter_rows, x,
-                                   x_stride, inv_norm, n_atoms, F, grad_x, grad_x_stride, st);
+                                   x_stride, inv_norm, n_atoms, F, grad_x, grad_x_stride, !force_generic, st);
         if (e != hipSuccess) return hip_fail("backward gather launch", e);
     }
     if (split) {

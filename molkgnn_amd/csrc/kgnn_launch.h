@@ -2,6 +2,8 @@
 #pragma once
 #include "kgnn_common.h"
 
+#include <atomic>
+
 namespace mkgnn {
 
 struct PrepArgs {
@@ -104,7 +106,7 @@ bool mfma_backward_supported(int d, int F, int E, int L, int64_t xs, const void*
 hipError_t launch_backward_rows_mfma(int d, const BwdArgs& a, int* ntheta_out, hipStream_t st);
 hipError_t launch_backward_gather(const float* contrib, int64_t cs, int64_t n_contrib_rows, const int32_t* rowptr,
                                   const int32_t* rows, const float* x, int64_t xs, const float* inv, int64_t n, int F,
-                                  float* gx, int64_t gxs, hipStream_t st);
+                                  float* gx, int64_t gxs, bool allow_fast, hipStream_t st);
 // kgnn_csr.hip: pipelined variants for 16-byte aligned rows of <= 256 floats; false = not applicable
 bool segment_sum_blocks_supported(const float* in, int64_t is, int64_t n, int width, const float* out, int64_t os);
 hipError_t launch_segment_sum_blocks(const float* in, int64_t is, const int32_t* rowptr, const int32_t* col, const int8_t* deg8,
@@ -118,6 +120,20 @@ bool try_backward_gather_aligned(const float* contrib, int64_t cs, const int32_t
 bool try_row_inv_norm_aligned(const float* x, int64_t xs, int64_t n, int width, float* inv, hipStream_t st, hipError_t* err);
 hipError_t launch_segment_sum(const float* in, int64_t is, const int32_t* rowptr, const int32_t* col, int64_t n,
                               int width, float* out, int64_t os, float* inv_norm, hipStream_t st);
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: remember per device whether
+// it has been set (setting it twice from two threads is harmless, skipping it on a second GPU is a failed launch).
+struct PerDeviceOnce {
+    std::atomic<bool> done[16];
+    PerDeviceOnce() { for (auto& d : done) d.store(false); }
+    // returns the device slot if the attribute still has to be set for the current device, -1 if it is set
+    int pending() {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 0;   // unknown device: set it every time
+        return done[dev].load(std::memory_order_acquire) ? -1 : dev;
+    }
+    void set(int dev) { if (dev >= 0 && dev < 16) done[dev].store(true, std::memory_order_release); }
+};
 
 // error reporting shared by the C-ABI translation units (kgnn_capi.hip owns the thread-local message)
 int api_fail(const char* fmt, ...);

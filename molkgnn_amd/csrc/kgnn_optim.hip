@@ -16,11 +16,11 @@
 
 namespace mkgnn {
 
-constexpr int ADAM_MAX_TENSORS = 96;      // per launch: 96 * 32 B of kernel arguments
+constexpr int ADAM_MAX_TENSORS = 80;      // per launch: 80 * 40 B of kernel arguments
 constexpr int ADAM_MAX_GROUPS = 4;
 constexpr int ADAM_CHUNK = 1024;          // elements per block
 
-struct AdamTensor { float* p; const float* g; float* state; int32_t n; int32_t group; };
+struct AdamTensor { float* p; const float* g; float* state; const float* active; int32_t n; int32_t group; };
 struct AdamGroup { const float* lr_ptr; float lr, beta1, beta2, eps, wd; int32_t maximize; float gscale; };
 struct AdamArgs {
     AdamTensor t[ADAM_MAX_TENSORS];
@@ -36,6 +36,7 @@ __global__ void __launch_bounds__(128) adamw_count_kernel(AdamArgs a) {
     if (ti >= a.nt) return;
     const AdamTensor T = a.t[ti];
     const AdamGroup G = a.grp[T.group];
+    if (T.active && *T.active == 0.f) return;                // no gradient anywhere this step: the step count stands still
     float* tail = T.state + 2 * (size_t)T.n;
     const double t = (double)tail[0] + 1.0;
     tail[0] = (float)t;
@@ -51,6 +52,7 @@ __global__ void __launch_bounds__(256) adamw_step_kernel(AdamArgs a) {
         if (a.blk_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const AdamTensor T = a.t[lo];
+    if (T.active && *T.active == 0.f) return;                // (block-uniform)
     const AdamGroup G = a.grp[T.group];
     const float lr = G.lr_ptr ? *G.lr_ptr : G.lr;
     float* m = T.state;
@@ -106,7 +108,7 @@ extern "C" int mkgnn_adamw_step(const mkgnn_adamw_tensor* tensors, int32_t n_ten
             const mkgnn_adamw_tensor& s = tensors[first + i];
             if (!s.param || !s.grad || !s.state || s.numel < 1 || s.numel > (1 << 30) || s.group < 0 || s.group >= n_groups)
                 return api_fail("mkgnn_adamw_step: tensor %d: null pointer, numel %lld or group %d out of range", first + i, (long long)s.numel, s.group);
-            a.t[i] = AdamTensor{s.param, s.grad, s.state, (int32_t)s.numel, s.group};
+            a.t[i] = AdamTensor{s.param, s.grad, s.state, s.active, (int32_t)s.numel, s.group};
             a.blk_start[i] = blocks;
             blocks += (int)((s.numel + ADAM_CHUNK - 1) / ADAM_CHUNK);
         }

@@ -11,7 +11,8 @@ Some parameters never receive a gradient (``p_support``, the two unused score we
 unused heads) and a degree that is absent from a rank's batch leaves its
 bank's gradients ``None`` on that rank only.  The flat buffer therefore has a fixed slot for
 every parameter that CAN receive a gradient, zero-filled where this rank has none, so all
-ranks always reduce the same layout.
+ranks always reduce the same layout; a flag per parameter rides along so that every rank knows
+which parameters had a gradient somewhere.
 """
 from __future__ import annotations
 
@@ -39,7 +40,13 @@ def shard_indices(n_items: int, rank: int, world: int) -> range:
 
 
 class FlatGradAllReduce:
-    """Sum-then-average the gradients of ``params`` across ranks through one flat buffer."""
+    """Sum-then-average the gradients of ``params`` across ranks through one flat buffer.
+
+    The buffer is ``[gradient slots | one "has a gradient" flag per parameter]``; both halves travel in the same
+    all-reduce, so afterwards ``flags[i]`` is the number of ranks that had a gradient for parameter ``i``.  A parameter
+    without a gradient on this rank (a degree absent from this rank's batch) still receives the reduced gradient of the
+    ranks that had one -- otherwise the replicas drift apart -- and a parameter without a gradient on EVERY rank stays
+    without one, as on one GPU (the reference's AdamW skips it: no step count, no moment decay)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], never_trained: Iterable[str] = (), names=None):
         params = list(params)
@@ -52,7 +59,9 @@ class FlatGradAllReduce:
         self.params: List[torch.nn.Parameter] = [p for p, n in zip(params, names) if p.requires_grad and not skipped(n)]
         total = sum(p.numel() for p in self.params)
         dev = self.params[0].device
-        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self._buf = torch.zeros(total + len(self.params), dtype=torch.float32, device=dev)
+        self.flat = self._buf[:total]                 # the gradient slots
+        self.flags = self._buf[total:]                # ranks that had a gradient, per parameter (after a reduction)
         self.views = []
         off = 0
         for p in self.params:
@@ -60,10 +69,11 @@ class FlatGradAllReduce:
             off += p.numel()
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self._filled: List[torch.nn.Parameter] = []
+        self._flag_cache: dict = {}
 
     @property
     def nbytes(self) -> int:
-        return self.flat.numel() * 4
+        return self._buf.numel() * 4
 
     def grads(self) -> List[Optional[torch.Tensor]]:
         """The current ``p.grad`` tensors of the reduced parameters, in buffer order.  A step replayed from a captured
@@ -72,55 +82,83 @@ class FlatGradAllReduce:
         it to ``reduce`` (``p.grad`` itself only names the last captured graph's tensors)."""
         return [p.grad for p in self.params]
 
-    def sum_into_flat(self, grads: List[Optional[torch.Tensor]]) -> None:
-        """Copy the given gradients (from ``grads()``) into the flat buffer and SUM it over the ranks; nothing is
-        scaled or copied back.  For an optimiser that reads the flat views directly and divides by the world size
-        itself (``FusedAdamW(grad_scale=1 / world)`` captured with ``p.grad = view``): two copy launches and one
-        scaling launch fewer per step than ``reduce``."""
-        if len(grads) != len(self.params):
-            raise ValueError("grads must come from FlatGradAllReduce.grads()")
+    def active_flags(self) -> dict:
+        """``{parameter: 0-dim view of its flag}`` for ``FusedAdamW.set_grad_active``: after ``sum_into_flat`` a flag
+        of zero means no rank had a gradient for that parameter this step, and the optimiser must leave it alone."""
+        return {p: self.flags[i] for i, p in enumerate(self.params)}
+
+    def _fill(self, grads: List[Optional[torch.Tensor]]) -> List[tuple]:
+        """Local gradients and has-gradient flags into the buffer; returns the (view, gradient) pairs present."""
         have = [(v, g) for v, g in zip(self.views, grads) if g is not None]
         if len(have) != len(self.params):
-            self.flat.zero_()
+            self.flat.zero_()                         # slots of parameters without a gradient here contribute zero
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        pattern = tuple(g is not None for g in grads)
+        local = self._flag_cache.get(pattern)
+        if local is None:                             # one small device tensor per None-pattern, built outside any capture
+            local = torch.tensor([1.0 if b else 0.0 for b in pattern], dtype=torch.float32).to(self.flags.device)
+            if len(self._flag_cache) < 64:
+                self._flag_cache[pattern] = local
+        self.flags.copy_(local)
+        return have
+
+    def prepare_patterns(self, grads_lists) -> None:
+        """Build the flag tensors of these gradient lists now (a host-to-device copy cannot happen inside a capture)."""
+        for grads in grads_lists:
+            pattern = tuple(g is not None for g in grads)
+            if pattern not in self._flag_cache:
+                self._flag_cache[pattern] = torch.tensor([1.0 if b else 0.0 for b in pattern],
+                                                         dtype=torch.float32).to(self.flags.device)
+
+    def sum_into_flat(self, grads: List[Optional[torch.Tensor]]) -> None:
+        """Copy the given gradients (from ``grads()``) into the flat buffer and SUM it over the ranks; nothing is
+        scaled or copied back.  For an optimiser that reads the flat views directly, divides by the world size itself
+        and skips the parameters whose flag is zero (``FusedAdamW(grad_scale=1 / world)`` with ``p.grad = view`` and
+        ``set_grad_active(active_flags())``): every rank then applies the same update to every parameter, whatever its
+        own batch lacked, with two copy launches and one scaling launch fewer per step than ``reduce``."""
+        if len(grads) != len(self.params):
+            raise ValueError("grads must come from FlatGradAllReduce.grads()")
+        self._fill(grads)
         if self.world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            dist.all_reduce(self._buf, op=dist.ReduceOp.SUM)
 
     def reduce(self, grads: Optional[List[Optional[torch.Tensor]]] = None) -> None:
         """Call after backward: afterwards every gradient tensor (``p.grad``, or the given list from ``grads()``) holds
-        the mean over ranks."""
+        the mean over ranks.  With an explicit list every entry must be a tensor: a ``None`` entry has nowhere to
+        receive the other ranks' gradient, and skipping it would let the replicas diverge silently (use
+        ``sum_into_flat`` with an optimiser that reads the flat views for that case)."""
         if self.world == 1:
             return
         if grads is not None:
             if len(grads) != len(self.params):
                 raise ValueError("grads must come from FlatGradAllReduce.grads()")
-            have = [(v, g) for v, g in zip(self.views, grads) if g is not None]
-            if len(have) != len(self.params):
-                self.flat.zero_()
-            if have:
-                torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            missing = [i for i, g in enumerate(grads) if g is None]
+            if missing:
+                raise ValueError(f"reduce(grads): {len(missing)} entries are None (first: parameter {missing[0]}); "
+                                 "a rank without a gradient tensor cannot receive the reduced one -- use "
+                                 "sum_into_flat() with an optimiser that reads the flat views")
+            have = self._fill(grads)
+            dist.all_reduce(self._buf, op=dist.ReduceOp.SUM)
             self.flat.mul_(1.0 / self.world)
-            if have:
-                torch._foreach_copy_([g for _, g in have], [v for v, _ in have])
+            torch._foreach_copy_([g for _, g in have], [v for v, _ in have])
             return
         for p in self._filled:                       # gradients this object created last time are not this step's
             p.grad = None
         self._filled = []
-        have = [(v, p.grad) for v, p in zip(self.views, self.params) if p.grad is not None]
-        if len(have) != len(self.params):            # slots of parameters without a gradient on this rank contribute zero
-            self.flat.zero_()
-        if have:
-            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        have = self._fill([p.grad for p in self.params])
+        dist.all_reduce(self._buf, op=dist.ReduceOp.SUM)
         self.flat.mul_(1.0 / self.world)
         if have:                                     # back into the (possibly graph-static) gradient tensors
             torch._foreach_copy_([g for _, g in have], [v for v, _ in have])
-        for v, p in zip(self.views, self.params):
-            if p.grad is None:                       # e.g. a degree absent from this rank's batch
-                p.grad = v.clone()
-                self._filled.append(p)
+        if len(have) != len(self.params):
+            # a degree absent from this rank's batch: take the other ranks' mean; absent everywhere: stay None
+            # (one small device-to-host copy, only on steps where this rank lacks a gradient)
+            counts = self.flags.cpu()
+            for i, (v, p) in enumerate(zip(self.views, self.params)):
+                if p.grad is None and float(counts[i]) > 0.0:
+                    p.grad = v.clone()
+                    self._filled.append(p)
 
 
 # parameter-name fragments that never receive a gradient in the reference's model (SURVEY 8 a-9); "^" anchors a

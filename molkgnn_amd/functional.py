@@ -16,6 +16,10 @@ from .plan import BatchPlan
 
 PARAMS_PER_DEGREE = 7   # x_center, x_support, edge_attr_support, p_support, support/center/edge score weights
 VARIANTS = {"auto": 0, "generic": 1, "mfma": 2, "bf16": 3}
+# mkgnn_kernelsetconv_backward's own switch: "generic" = the one-wave-per-atom kernels + plain gather for every degree,
+# "fast" = the MFMA rows / LDS bank / pipelined gather kernels or an error.  None follows the forward variant
+# ("generic" -> "generic", anything else -> "auto").
+BACKWARD_VARIANTS = {"auto": 0, "generic": 1, "fast": 2}
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -167,8 +171,10 @@ class _KernelSetConvFn(torch.autograd.Function):
     """BaseKernelSetConv.forward (reference kernels.py:610-751) as one differentiable operator."""
 
     @staticmethod
-    def forward(ctx, x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad: int, E: int, inv, *params):
+    def forward(ctx, x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad: int, E: int, inv, bwd_variant: int,
+                *params):
         need_grad = any(ctx.needs_input_grad)
+        ctx.bwd_variant = int(bwd_variant)
         x, out_full, inv, saved_t, Ls, ws = _forward_impl(x, plan, is_last_layer, variant, out_pad, E, params, need_grad, inv)
         ctx.plan, ctx.is_last, ctx.E, ctx.Ls = plan, bool(is_last_layer), E, Ls
         # the workspace holds the normalised kernel bank: backward reuses it (and the buffer) instead of redoing it
@@ -200,8 +206,10 @@ class _KernelSetConvFn(torch.autograd.Function):
         for i in range(4):
             xc, xs, es, ps, ts, tc, te = params[i * PARAMS_PER_DEGREE:(i + 1) * PARAMS_PER_DEGREE]
             gxc, gxs, ges = torch.empty_like(xc), torch.empty_like(xs), torch.empty_like(es)
-            gth = torch.zeros(3, dtype=torch.float32, device=dev) if plan.buckets[i].count == 0 else \
-                torch.empty(3, dtype=torch.float32, device=dev)
+            # a degree without atoms, or without kernels in this set (a fixed / trainable split), launches nothing
+            # that writes the score-weight partials: start from zeros there, the values are dropped below anyway
+            idle = plan.buckets[i].count == 0 or Ls[i] == 0
+            gth = torch.zeros(3, dtype=torch.float32, device=dev) if idle else torch.empty(3, dtype=torch.float32, device=dev)
             alive += [gxc, gxs, ges, gth]     # (an absent degree's buffers are written too -- with zeros -- and dropped afterwards)
             gr = grads[i]
             gr.x_center, gr.x_support, gr.edge_attr_support = _lib.ptr(gxc), _lib.ptr(gxs), _lib.ptr(ges)
@@ -209,8 +217,10 @@ class _KernelSetConvFn(torch.autograd.Function):
             gr.center_attr_sc_weight = gth.data_ptr() + 4
             gr.edge_attr_support_sc_weight = gth.data_ptr() + 8
             # p_support is not differentiable in the reference (kernels.py:279-350): gradient stays None
-            if plan.buckets[i].count == 0:
-                # no atom of this degree in the batch: the reference's autograd leaves these gradients None
+            if idle:
+                # no atom of this degree in the batch, or no kernels of this degree in this set (the score weights
+                # handed in for such a degree belong to ANOTHER degree's KernelConv, kernels._bank_params): the
+                # reference's autograd leaves all of these gradients None
                 gparams += [None] * PARAMS_PER_DEGREE
             else:
                 gparams += [gxc, gxs, ges, None, gth[0].reshape(ts.shape), gth[1].reshape(tc.shape),
@@ -229,10 +239,10 @@ class _KernelSetConvFn(torch.autograd.Function):
             _lib.check(lib.mkgnn_kernelsetconv_backward(
                 banks, buckets, x.data_ptr(), _stride0(x), inv.data_ptr(), n, F, E, int(ctx.is_last),
                 g.data_ptr(), _stride0(g), saved, rowptr.data_ptr(), rows.data_ptr(),
-                _lib.ptr(gx), F4, grads, ws.data_ptr(), ws_bytes, int(reuse), _lib.stream_ptr(dev)),
+                _lib.ptr(gx), F4, grads, ws.data_ptr(), ws_bytes, int(reuse), ctx.bwd_variant, _lib.stream_ptr(dev)),
                 "mkgnn_kernelsetconv_backward")
         del alive           # (freed memory is only handed out again in stream order, after the kernels above)
-        return (gx, None, None, None, None, None, None, *gparams)
+        return (gx, None, None, None, None, None, None, None, *gparams)
 
 
 BLOCK_ROWS = 0x100           # MKGNN_VARIANT_BLOCK_ROWS
@@ -241,7 +251,7 @@ _BLOCKS_ATTR = "_mkgnn_block_rows"
 
 def kernelsetconv(x: torch.Tensor, plan: BatchPlan, is_last_layer: bool, params: Sequence[torch.Tensor],
                   edge_attr_dim: int, variant: str = "auto", out_pad: Optional[int] = None,
-                  block_rows: bool = False) -> torch.Tensor:
+                  block_rows: bool = False, backward_variant: Optional[str] = None) -> torch.Tensor:
     """``[N, F] -> [N, K]`` kernel convolution over the four degree buckets of ``plan``.
 
     ``params`` is the flat list, degree 1..4, of (x_center, x_support,
@@ -257,8 +267,10 @@ def kernelsetconv(x: torch.Tensor, plan: BatchPlan, is_last_layer: bool, params:
     """
     if block_rows and out_pad not in (None, (-sum(int(p.shape[0]) for p in params[0::7])) % 4):
         raise ValueError("block_rows needs the default padded storage")
+    if backward_variant is None:
+        backward_variant = "generic" if variant == "generic" else "auto"
     out = _KernelSetConvFn.apply(x, plan, is_last_layer, VARIANTS[variant] | (BLOCK_ROWS if block_rows else 0), out_pad,
-                                 edge_attr_dim, _handed_inv_norm(x), *params)
+                                 edge_attr_dim, _handed_inv_norm(x), BACKWARD_VARIANTS[backward_variant], *params)
     if block_rows:
         setattr(out, _BLOCKS_ATTR, tuple(int(p.shape[0]) for p in params[0::7]))
     return out

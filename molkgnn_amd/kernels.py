@@ -60,6 +60,7 @@ class KernelConv(Module):
         self.edge_attr_support_sc_weight = Parameter(torch.tensor(init_edge_attr_support_sc_weight),
                                                      requires_grad=weight_requires_grad)
         self.variant = "auto"
+        self.backward_variant = None      # None: follows ``variant`` (functional.BACKWARD_VARIANTS)
 
     def get_num_kernels(self):
         return self.num_kernels
@@ -112,7 +113,8 @@ class KernelConv(Module):
                             f'{self.p_support.shape[-1]}D')
         x_all, plan, params = self.single_degree_problem(x_focal, p_focal, x_neighbor, p_neighbor, edge_attr_neighbor)
         n = x_focal.shape[0]
-        out = Fn.kernelsetconv(x_all, plan, is_last_layer, params, self.edge_attr_support.shape[-1], self.variant)
+        out = Fn.kernelsetconv(x_all, plan, is_last_layer, params, self.edge_attr_support.shape[-1], self.variant,
+                               backward_variant=self.backward_variant)
         return out[:n].T
 
 
@@ -131,7 +133,8 @@ class BaseKernelSetConv(Module):
         self.num_trainable_kernel_list = [k.get_num_kernels() if k is not None else None for k in train]
         self.num_kernel_list = [(f or 0) + (t or 0) for f, t in
                                 zip(self.num_fixed_kernel_list, self.num_trainable_kernel_list)]
-        self.variant = "auto"     # "auto" | "generic" | "mfma": which HIP kernels serve the forward
+        self.variant = "auto"     # "auto" | "generic" | "mfma" | "bf16": which HIP kernels serve the forward
+        self.backward_variant = None   # None (follows variant) | "auto" | "generic" | "fast": ... the backward
         self.out_pad = None       # None: output storage rows padded to 16 bytes (the result is a view); 0: contiguous
 
     # -- helpers kept for API parity with the reference ----------------------
@@ -206,14 +209,16 @@ class BaseKernelSetConv(Module):
             params, E = self._bank_params("train", x)
             block_rows = (bool(block_rows) and not save_score and self.out_pad is None
                           and plan.block_rows_ok(sum(int(p.shape[0]) for p in params[0::7])))
-            sc = Fn.kernelsetconv(x, plan, is_last_layer, params, E, self.variant, self.out_pad, block_rows=block_rows)
+            sc = Fn.kernelsetconv(x, plan, is_last_layer, params, E, self.variant, self.out_pad, block_rows=block_rows,
+                                  backward_variant=self.backward_variant)
         else:
             # fixed kernels come first inside every degree block (kernels.py:702-710)
             parts = {}
             for which, present in (("fixed", has_fixed), ("train", has_train)):
                 if present:
                     params, E = self._bank_params(which, x)
-                    parts[which] = Fn.kernelsetconv(x, plan, is_last_layer, params, E, self.variant)
+                    parts[which] = Fn.kernelsetconv(x, plan, is_last_layer, params, E, self.variant,
+                                                    backward_variant=self.backward_variant)
             cols = []
             of = ot = 0
             for d in range(4):

@@ -36,6 +36,17 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError("FusedAdamW takes at most 4 parameter groups")
         self._table_key = None
         self._table = None
+        self._active: dict = {}
+
+    def set_grad_active(self, flags: dict) -> None:
+        """``{parameter: one-element float32 CUDA tensor}``: a parameter whose flag reads 0 when the step runs is
+        skipped (as if its gradient were ``None``) -- decided on the device, so a captured data-parallel step skips the
+        banks of a degree that no rank's batch contained (``dp.FlatGradAllReduce.active_flags``)."""
+        for p, f in flags.items():
+            if not (isinstance(f, torch.Tensor) and f.is_cuda and f.dtype == torch.float32 and f.numel() == 1):
+                raise ValueError("an active flag must be one float32 element on the GPU")
+        self._active = dict(flags)
+        self._table_key = None
 
     # -- state: one buffer per parameter, [exp_avg | exp_avg_sq | step | 2 scratch]; the three state entries are views of it --
     def _packed_state(self, p: torch.Tensor) -> torch.Tensor:
@@ -81,7 +92,7 @@ class FusedAdamW(torch.optim.Optimizer):
         dev = None
         for gi, group in enumerate(self.param_groups):
             for p in group["params"]:
-                if p.grad is None:
+                if p.grad is None or p.numel() == 0:         # (an empty bank's tensors have nothing to update)
                     continue
                 _lib.require_gpu_tensor(p, "parameter")
                 if p.dtype != torch.float32 or not p.is_contiguous():
@@ -96,14 +107,16 @@ class FusedAdamW(torch.optim.Optimizer):
                     dev = p.device
                 elif p.device != dev:
                     raise _lib.MolKGNNLibraryError("FusedAdamW: parameters on more than one device")
-                rows.append((p.data_ptr(), g.data_ptr(), self._packed_state(p).data_ptr(), p.numel(), gi))
+                act = self._active.get(p)
+                rows.append((p.data_ptr(), g.data_ptr(), self._packed_state(p).data_ptr(), p.numel(), gi,
+                             None if act is None else act.data_ptr()))
         if not rows:
             return loss
         key = tuple(rows)
         if key != self._table_key:                           # pointers are stable from step to step: build the table once
             table = (_lib.AdamWTensor * len(rows))()
             for e, r in zip(table, rows):
-                e.param, e.grad, e.state, e.numel, e.group = r
+                e.param, e.grad, e.state, e.numel, e.group, e.active = r
             self._table, self._table_key = table, key
         groups = (_lib.AdamWGroup * len(self.param_groups))()
         for e, group in zip(groups, self.param_groups):

@@ -144,8 +144,8 @@ _PLAN_CACHE_MAX = 32
 
 def plan_from_lists_cached(n_atoms, p_focal_list, nei_p_list, nei_edge_attr_list, selected_index_list, nei_index_list,
                            edge_index=None) -> BatchPlan:
-    """``plan_from_lists`` memoised on the identity of the index tensors (address, length, device AND the tensor
-    objects themselves, held weakly).
+    """``plan_from_lists`` memoised on the identity of the index, bond-attribute and coordinate tensors (address,
+    length, device, in-place version AND the tensor objects themselves, held weakly).
 
     ``MolGCN.forward`` receives the per-degree tensors as separate keyword arguments (the reference's
     signature, KernelLayer.py:53-87), so the batch object that would carry a cached plan is not
@@ -154,11 +154,12 @@ def plan_from_lists_cached(n_atoms, p_focal_list, nei_p_list, nei_edge_attr_list
     host-synchronising call any more (required for hipGraph capture).
     """
     def ident(t):
-        return None if t is None else (t.data_ptr(), t.numel(), str(t.device))
-    tensors = [t for t in list(selected_index_list) + list(nei_index_list) + list(nei_edge_attr_list) + [edge_index]
-               if t is not None]
-    key = (int(n_atoms), tuple(ident(t) for t in selected_index_list), tuple(ident(t) for t in nei_index_list),
-           tuple(ident(t) for t in nei_edge_attr_list), ident(edge_index))
+        # address, length, device AND the in-place version counter: refilling a static input tensor in place (the usual
+        # hipGraph pattern) changes the graph structure without changing the address
+        return None if t is None else (t.data_ptr(), t.numel(), str(t.device), t._version)
+    groups = (selected_index_list, nei_index_list, nei_edge_attr_list, p_focal_list, nei_p_list)
+    tensors = [t for g in groups for t in g if t is not None] + ([edge_index] if edge_index is not None else [])
+    key = (int(n_atoms),) + tuple(tuple(ident(t) for t in g) for g in groups) + (ident(edge_index),)
     hit = _PLAN_CACHE.get(key)
     if hit is not None:
         plan, refs = hit
@@ -183,9 +184,9 @@ def plan_from_lists_cached(n_atoms, p_focal_list, nei_p_list, nei_edge_attr_list
 def plan_from_data(data) -> BatchPlan:
     """Plan for a reference-style ``data`` object, cached on the object itself."""
     cached = getattr(data, _PLAN_ATTR, None)
-    key = (data.x.shape[0], data.selected_index_deg1.data_ptr(), data.selected_index_deg2.data_ptr(),
-           data.selected_index_deg3.data_ptr(), data.selected_index_deg4.data_ptr(),
-           data.nei_index_deg2.data_ptr(), str(data.x.device))
+    fields = [getattr(data, f"{nm}_deg{d}") for nm in ("selected_index", "nei_index", "nei_edge_attr", "p_focal", "nei_p")
+              for d in range(1, 5)]
+    key = (data.x.shape[0], str(data.x.device)) + tuple((t.data_ptr(), t.numel(), t._version) for t in fields)
     if cached is not None and cached[0] == key:
         return cached[1]
     plan = plan_from_lists(

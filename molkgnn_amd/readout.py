@@ -44,7 +44,7 @@ def molecule_segments(batch: torch.Tensor, size: Optional[int]) -> MoleculeSegme
     batch, so a step contains no host synchronisation for it (hipGraph capture)."""
     if size is None:
         size = int(batch.max().item()) + 1 if batch.numel() else 0
-    key = (batch.data_ptr(), batch.numel(), str(batch.device), int(size))
+    key = (batch.data_ptr(), batch.numel(), str(batch.device), int(size), batch._version)   # (refilled in place: rebuilt)
     hit = _SEG_CACHE.get(key)
     if hit is not None:
         seg, ref = hit
@@ -237,13 +237,13 @@ _HEAD_WS: dict = {}
 
 
 def _head_workspace(dev, nbytes: int) -> torch.Tensor:
-    """Per-device scratch whose first word is the kernels' block counter: zeroed once here, left zero by every launch.
-    Calls on one device are ordered on the autograd / capture stream, so one buffer per device is enough."""
-    ws = _HEAD_WS.get(str(dev))
-    if ws is None or ws.numel() < nbytes:
-        ws = torch.zeros(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev)
-        _HEAD_WS[str(dev)] = ws
-    return ws
+    """Per-device scratch for the head kernels' per-block partials.  Calls on one device are ordered on the autograd /
+    capture stream, so one buffer per device is enough.  A buffer that has been handed out is never released: a
+    captured graph has its address baked in, so when a larger one is needed the old ones stay referenced here."""
+    held = _HEAD_WS.setdefault(str(dev), [])
+    if not held or held[-1].numel() < nbytes:
+        held.append(torch.empty(max(nbytes, 1 << 16), dtype=torch.uint8, device=dev))
+    return held[-1]
 
 
 _HEAD_RNG: dict = {}

@@ -36,6 +36,8 @@ def _worker(rank, world, port, out_dir):
             continue
         if rank == 1 and "trainable_kernelconv_set.3." in n:
             continue
+        if "layers.1.trainable_kernelconv_set.2." in n:       # "no degree-3 atom on ANY rank" in layer 1
+            continue
         p.grad = torch.randn(p.shape, generator=g)
         local[n] = p.grad.clone()
     reducer.reduce()
@@ -65,6 +67,10 @@ def test_flat_gradient_allreduce_two_ranks(tmp_path):
     r0 = torch.load(tmp_path / "rank0.pt")
     r1 = torch.load(tmp_path / "rank1.pt")
     assert set(r0["reduced"]) == set(r1["reduced"]) and len(r0["reduced"]) > 20
+    # a bank without a gradient on every rank keeps none (the 1-GPU optimiser skips it: no step count, no moment decay);
+    # a bank without a gradient on ONE rank receives the other rank's (halved) there too
+    assert not any("layers.1.trainable_kernelconv_set.2." in n for n in r0["reduced"])
+    assert any("trainable_kernelconv_set.3." in n for n in r1["reduced"])
     for n, g0 in r0["reduced"].items():
         assert torch.equal(g0, r1["reduced"][n]), n                      # same result on both ranks
         want = (r0["local"][n] + r1["local"].get(n, torch.zeros_like(g0))) / 2
@@ -78,7 +84,7 @@ def test_single_process_is_a_no_op():
     red = dp.FlatGradAllReduce(lin.parameters())
     red.reduce()
     assert torch.equal(lin.weight.grad, torch.ones_like(lin.weight)) and lin.bias.grad is None
-    assert red.nbytes == 4 * (6 + 2)
+    assert red.nbytes == 4 * (6 + 2) + 4 * 2              # gradient slots + one has-gradient flag per parameter
 
 
 def test_reducer_covers_the_trained_readout_weights():
@@ -115,8 +121,21 @@ def _worker_static_grads(rank, world, port, out_dir):
     red.reduce(sets[0])                                    # "replay of graph 0": its tensors are averaged ...
     after = [[t.clone() for t in s] for s in sets]
     red.sum_into_flat(sets[1])                             # the flat-buffer form: a sum, nothing copied back
-    torch.save({"before": before, "after": after, "flat": [v.clone() for v in red.views],
-                "set1_after_sum": [t.clone() for t in sets[1]]}, os.path.join(out_dir, f"rank{rank}.pt"))
+    saved = {"before": before, "after": after, "flat": [v.clone() for v in red.views],
+             "set1_after_sum": [t.clone() for t in sets[1]], "flags_full": red.flags.clone()}
+    # a gradient list with a hole (this rank's graph has no tensor for the bias on rank 1 only)
+    holed = list(sets[1])
+    if rank == 1:
+        holed[1] = None
+    red.sum_into_flat(holed)
+    saved["flags_holed"] = red.flags.clone()
+    saved["flat_holed"] = [v.clone() for v in red.views]
+    try:
+        red.reduce([sets[0][0], None])
+        saved["raised"] = False
+    except ValueError:
+        saved["raised"] = True
+    torch.save(saved, os.path.join(out_dir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -135,3 +154,10 @@ def test_reduce_works_on_the_gradients_of_the_replayed_graph(tmp_path):
         # sum_into_flat: the views hold the SUM over ranks of the given set, which itself is untouched
         assert torch.allclose(r0["flat"][k], r0["before"][1][k] + r1["before"][1][k], atol=1e-6)
         assert torch.equal(r0["flat"][k], r1["flat"][k]) and torch.equal(r0["set1_after_sum"][k], r0["before"][1][k])
+    # the has-gradient flags ride in the same all-reduce: number of ranks with a gradient, identical on both ranks
+    for r in (r0, r1):
+        assert r["flags_full"].tolist() == [2.0, 2.0] and r["flags_holed"].tolist() == [2.0, 1.0]
+        assert r["raised"]                                 # reduce(grads) refuses a None entry instead of skipping it
+    # rank 1 had no bias gradient: both ranks still see rank 0's in the flat view (and would apply the same update)
+    assert torch.allclose(r0["flat_holed"][1], r0["before"][1][1], atol=1e-6)
+    assert torch.equal(r0["flat_holed"][1], r1["flat_holed"][1])
