@@ -304,6 +304,10 @@ def main():
     emb = model(data_from_batch(Data, b))
     g7 = {"graph_embedding": npy(emb), "seed": np.array(1798),
           "num_params": np.array(sum(p.numel() for p in model.parameters()))}
+    with torch.no_grad():       # the first layer's scores (tie-free on a random batch) and the whole stack's h
+        h0 = model.node_batch_norm(b.x)
+        g7["layer0_sim_sc"] = npy(model.gnn.layers[0](is_last_layer=False, data=data_from_batch(Data, b, x=h0),
+                                                      save_score=False))
     names, sums = [], []
     for nm, prm in model.named_parameters():
         names.append(nm)
@@ -313,6 +317,32 @@ def main():
     g7["param_shapes"] = np.array([str(tuple(p.shape)) for p in model.parameters()])
     g7.update(batch_arrays(b))
     save("g7_fullsize.npz", **g7)
+
+    # ---- G9: the benchmark's own layer shape -- KernelSetConv(10, 20, 30, 50) on 110-wide rows (an N-hop layer of
+    #          the headline model, kernels.py:754-781 with the README kernel counts): forward (last / not last) and
+    #          every gradient, on a 3-molecule batch.  This is the configuration kc_forward_fused<7> and the
+    #          backward's <7> instantiations are timed on.
+    g9 = {}
+    b = make_batch(3, seed=91)
+    assert all(getattr(b, f"selected_index_deg{d}").numel() > 0 for d in range(1, 5))
+    torch.manual_seed(909)
+    ksc = kernels.KernelSetConv(10, 20, 30, 50, D=3, node_attr_dim=110, edge_attr_dim=7)
+    g = torch.Generator().manual_seed(910)
+    x = torch.randn(b.x.shape[0], 110, generator=g).requires_grad_(True)
+    cot = torch.randn(b.x.shape[0], 110, generator=g)
+    g9["x"], g9["cotangent"], g9["L"] = npy(x), npy(cot), np.array([10, 20, 30, 50])
+    for nm, prm in ksc.named_parameters():
+        g9[f"param/{nm}"] = npy(prm)
+    for last in (False, True):
+        sc = ksc(is_last_layer=last, data=data_from_batch(Data, b, x=x), save_score=False)
+        g9[f"sc_last{int(last)}"] = npy(sc)
+        grads = torch.autograd.grad((sc * cot).sum(), [x] + list(ksc.parameters()), allow_unused=True)
+        g9[f"grad_last{int(last)}/x"] = npy(grads[0])
+        for (nm, prm), gr in zip(ksc.named_parameters(), grads[1:]):
+            if gr is not None:
+                g9[f"grad_last{int(last)}/{nm}"] = npy(gr).astype(np.float32)
+    g9.update(batch_arrays(b))
+    save("g9_setconv_fullsize.npz", **g9)
 
 
 if __name__ == "__main__":

@@ -161,3 +161,50 @@ def test_three_layer_network_cosmat_is_tie_aware_equal():
         assert O.kernelset_tie_aware_mismatch(per_degree, x, b, i == 2, sim, idx) == 0
         x = torch.from_numpy(flat[f"layer{i}_h"])
     assert n_ties > 0   # the case really exercises the tie rule
+
+
+@pytest.mark.parametrize("form", ["faithful", "cosmat"])
+def test_kernelsetconv_benchmark_shape(form):
+    """G9: the reference's KernelSetConv(10, 20, 30, 50) on 110-wide rows (the timed N-hop layer shape), forward
+    (last / not last) and every gradient."""
+    flat = G.load("g9_setconv_fullsize.npz")
+    b = G.batch_from(flat)
+    state = {k[len("param/"):]: torch.from_numpy(v) for k, v in flat.items() if k.startswith("param/")}
+    for last in (False, True):
+        per_degree = O.kernelset_params({k: v.clone() for k, v in state.items()})
+        x = torch.from_numpy(flat["x"]).clone().requires_grad_(True)
+        for p in per_degree:
+            for v in p.values():
+                v.requires_grad_(True)
+        sc = O.kernelsetconv(per_degree, x, b, last, form=form)
+        assert torch.allclose(sc, torch.from_numpy(flat[f"sc_last{int(last)}"]), atol=TOL, rtol=0)
+        (sc * torch.from_numpy(flat["cotangent"])).sum().backward()
+        assert torch.allclose(x.grad, torch.from_numpy(flat[f"grad_last{int(last)}/x"]), atol=2e-5, rtol=1e-4)
+        checked = 0
+        for d in range(4):
+            for k, v in per_degree[d].items():
+                key = f"grad_last{int(last)}/trainable_kernelconv_set.{d}.{k}"
+                if key in flat:
+                    assert torch.allclose(v.grad, torch.from_numpy(flat[key]), atol=2e-5, rtol=1e-4), key
+                    checked += 1
+                else:
+                    assert v.grad is None or float(v.grad.abs().max()) == 0.0, key
+        assert checked == 24            # 4 degrees x (3 kernel tensors + 3 score weights)
+
+
+def test_fullsize_seeded_model_oracle_matches_reference():
+    """G7: the full-size model (10/20/30/50, hidden 32) rebuilt from the recorded seed through the package's own
+    modules (same draw order as the reference) and evaluated by the oracle: the reference's first-layer
+    scores and graph embedding."""
+    from molkgnn_amd.MolKGNNNet import MolKGNNNet
+    flat = G.load("g7_fullsize.npz")
+    torch.manual_seed(int(flat["seed"]))
+    names = [f"num_kernel{d}_{h}" for h in ("1hop", "Nhop") for d in range(1, 5)]
+    model = MolKGNNNet(num_layers=3, x_dim=28, p_dim=3, edge_attr_dim=7, drop_ratio=0.0, graph_embedding_dim=32,
+                       **dict(zip(names, (10, 20, 30, 50) * 2)))
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    b = G.batch_from(flat)
+    collect = []
+    emb = O.molkgnnnet(state, b, 3, training_bn=False, form="faithful", collect=collect)
+    assert torch.allclose(collect[0][0], torch.from_numpy(flat["layer0_sim_sc"]), atol=TOL, rtol=0)
+    assert torch.allclose(emb, torch.from_numpy(flat["graph_embedding"]), atol=5e-5, rtol=1e-5)
