@@ -1,0 +1,596 @@
+// Streamed MFMA forward of the kernel convolution (gfx950): ONE launch = one KernelSetConv forward
+// (reference kernels.py:610-751 with :353-425 fused), like kc_forward_fused, restructured so that the inner loop
+// contains nothing but matrix instructions and one LDS read per 4 D of them.
+//
+// What kc_forward_fused (kgnn_mfma.hip) spends its time on besides the matrix pipe: D LDS reads of the bank per chunk
+// (each chunk step its own basic block: the compiler cannot hoist them over the step's branch), gathered rows held in
+// 28 - 56 VGPRs per wave, every degree-3 / 4 tile gathered once per column part.  Here the two operands swap places:
+//
+//   * the BANK is the register-resident operand.  A wave owns one column tile (<= 16 kernels) of its degree and keeps
+//     those kernels' unit rows -- D support slots + the centre, KC 16-byte chunks each -- in (D + 1) * KC * 4 VGPRs for
+//     the whole launch (140 for degree 4).  Nothing about the bank is read inside the loop.
+//   * the gathered ATOM ROWS stream through LDS.  The NS waves that hold the NS column tiles of a degree share one
+//     16-atom tile: its rows are fetched ONCE, by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, asynchronous),
+//     slot by slot (neighbour 0 .. D-1, then the focal row) into a ring of KC KB buffers laid out in exactly the order
+//     the MFMA A-operand lanes read them (lane q of DMA piece t fetches chunk 4 t + (q >> 4) of row q & 15 and lands at
+//     byte 16 q of piece t: the read is the linear ds_read_b128 at 16 * lane, conflict-free by construction).
+//     One ds_read_b128 feeds 4 * D MFMAs; the ring runs RING slots ahead of the multiply.
+//   * per-tile small data (atom ids, 1 / |x| of every slot, focal ids, raw bond attributes, the degree-4 chirality
+//     flags) is DMA'd / written into a small LDS record in the layout its readers use, a tile ahead.
+//
+// Synchronisation (cdna_hip_programming.md section 5, "Pipelining across barriers"): every vector-memory LOAD of the
+// loop is an LDS-DMA with a hand-counted s_waitcnt vmcnt(N) -- the compiler never sees an ordinary load result in the
+// loop, so it never drains the DMA queue with a vmcnt(0) of its own -- and waves meet at a raw s_barrier.  Step k (one
+// slot of one tile):  multiply buffer k % RING;  wait until only the youngest DMA batch is in flight (so the batch for
+// step k + 1 has landed);  barrier (all waves are done reading buffer k % RING, everybody's share of step k + 1 is
+// visible);  issue the DMA batch of step k + RING into buffer k % RING;  after a tile's last slot, the epilogue
+// (permutation maximum, bond cosines, mixing, chirality sign, stores) -- the arithmetic of kc_forward_fused, so the two
+// kernels agree bit for bit.
+//
+// Degree 4 (140 bank registers + 64 accumulators per wave would spill, and a scratch reload is a vector-memory load that
+// drains the DMA queue): a column tile's four support slots are split over TWO waves (supports {0,1} + the centre, and
+// {2,3}); a block holds two column tiles, the degree's four take two blocks (its rows are gathered twice -- 19 MB more
+// of ~140 MB).  At the end of a tile the two waves swap, through LDS, the half of the 4 x 4 cosine matrices the other
+// needs: each finishes two of a lane's four atoms, with the same summation order as everywhere else.
+//
+// Covered shapes: F in (16 (KC - 1), 16 KC] for KC = 2 or 7 (the reference's 28 and 110), E <= 8, 16-byte aligned rows,
+// and per degree exactly NS(d) = 1 / 2 / 2 / 4 column tiles (L <= 16 / 17..32 / 17..32 / 49..64: the reference's
+// 10 / 20 / 30 / 50).  Other shapes keep kc_forward_fused.
+#include <type_traits>
+
+#include "kgnn_launch.h"
+
+namespace mkgnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int D> struct StreamTraits {
+    static constexpr int NS = (D == 1) ? 1 : (D == 4 ? 4 : 2);     // waves sharing an atom tile = column tiles of the degree
+    static constexpr int NSTREAM = 4 / NS;                         // atom-tile streams per 4-wave block
+    static constexpr int RING = (NS == 1) ? 2 : 3;                 // row-slot buffers per stream
+    static constexpr int S1 = D + 1;                               // steps (slots) per tile
+    // per-tile record (floats): ids[S1][16] | inv[S1][16] | focal[16] | sign bytes[16] (4 dwords used) | eq bytes[16] | bond[D][16][8]
+    static constexpr int OFF_INV = 16 * S1, OFF_FOCAL = 32 * S1, OFF_SIGN = OFF_FOCAL + 16, OFF_EQ = OFF_SIGN + 16,
+                         OFF_BOND = OFF_EQ + 16, META = OFF_BOND + 128 * D;
+};
+
+int stream_column_tiles(int d) { return d == 1 ? 1 : (d == 4 ? 4 : 2); }
+
+__host__ __device__ constexpr int stream_lds_floats(int D, int KC) {
+    const int NS = (D == 1) ? 1 : (D == 4 ? 4 : 2);
+    const int RING = (NS == 1) ? 2 : 3;
+    const int META = 32 * (D + 1) + 48 + 128 * D;
+    // degree 4: + chirality sign table (<= 64 x 12 bytes) + the exchange buffer of the support halves (4 waves x 18 KB-rows of 256 B)
+    return (4 / NS) * (RING * KC * 256 + 2 * META) + (D == 4 ? 192 + 4 * 18 * 64 : 0);
+}
+
+template <int I> using IC = std::integral_constant<int, I>;
+template <int B, int E, typename Fn> __device__ __forceinline__ void static_for(Fn&& fn) {
+    if constexpr (B < E) { fn(IC<B>{}); static_for<B + 1, E>(fn); }
+}
+
+// pi_p(a) of the reference's permutation tables (kernels.py:109-128) without a table load: the a-th entries of all
+// orders packed two bits each (a is a compile-time constant wherever this is used; a __constant__ lookup with a
+// per-lane index is an ordinary vector load, which the DMA pipeline of this kernel cannot afford)
+template <int D, int A> __device__ __forceinline__ int perm_entry(int p) {
+    if constexpr (D == 1) return 0;
+    else {
+        constexpr uint32_t packed = [] {
+            uint32_t v = 0;
+            for (int q = 0; q < PermC<D>::P; ++q) v |= (uint32_t)PermC<D>::t[q][A] << (2 * q);
+            return v;
+        }();
+        return (int)((packed >> (2 * p)) & 3u);
+    }
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "s_waitcnt vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// 16 / 4 bytes per lane, global -> LDS, asynchronous; the LDS address is the wave-uniform base + lane * size
+__device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void dma4(const void* src, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+
+// DMA pieces of one row slot that wave `role` (0 .. NS-1) of a stream issues: t = role, role + NS, ...
+template <int KC, int NS> constexpr int pieces_of(int role) { return (KC - role + NS - 1) / NS; }
+
+// vector-memory operations wave `role` issues in the DMA phase whose slot is `sd` (the counted waits rely on it)
+template <int D, int KC> constexpr int batch_size(int sd, int role) {
+    using T = StreamTraits<D>;
+    int n = pieces_of<KC, T::NS>(role);
+    if (role == 0) {
+        if (sd < D) n += 2;                              // bond attributes of the slot
+        if (sd == 0) n += 2 * (T::S1 == 5 ? 2 : 1) + (D == 4 ? 2 : 0);     // following tile's ids, this tile's 1/|x|, flags
+    }
+    return n;
+}
+
+template <int D, int KC>
+__device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDeg& dg, const int cp, const int rank, const int count, float* lds) {
+    using T = StreamTraits<D>;
+    constexpr int NS = T::NS, NSTREAM = T::NSTREAM, RING = T::RING, S1 = T::S1, META = T::META;
+    constexpr int FP = 16 * KC;
+    constexpr int SLOT = KC * 256;                       // floats per row-slot buffer (KC pieces of 1 KB)
+    // HS ("half supports", degree 4): wave = (column tile of the block, support half); see the file comment
+    constexpr bool HS = (D == 4);
+    constexpr int NBS = HS ? 2 : D;                      // support slots this wave multiplies
+    constexpr int NB = NBS + 1;                          // bank slots in registers: the supports + the centre (HS: half 0 only)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int stream = wave / NS, role = wave % NS;
+    const int half = HS ? (role & 1) : 0;                // supports 2 * half, 2 * half + 1
+    const int ct = HS ? cp * 2 + (role >> 1) : role;     // this wave's column tile (the degree has exactly NS: host-checked)
+    const int ci = lane & 15, kq = lane >> 4;
+    const int L = dg.L, kpt = dg.kpt;
+    const int lcol = ct * kpt + ci;
+    const bool col_ok = (ci < kpt) && (lcol < L);
+    const bool do_chir = (D == 4) && a.last;
+    float* const ring = lds + (size_t)stream * (RING * SLOT + 2 * META);
+    float* const meta = ring + RING * SLOT;
+    int8_t* const chirtab = (int8_t*)(lds + (size_t)NSTREAM * (RING * SLOT + 2 * META));
+    float* const xbuf = lds + (size_t)NSTREAM * (RING * SLOT + 2 * META) + 192;      // (HS only) [wave][18][64]
+
+    // ---- tiles of this stream: a contiguous run; every block of the group runs the same number of iterations
+    const int64_t ntiles = (dg.n + 15) / 16;
+    const int64_t nstreams = (int64_t)count * NSTREAM;
+    const int64_t sg = (int64_t)rank * NSTREAM + stream;
+    const int64_t tile_first = sg * ntiles / nstreams;
+    const int64_t tile_end = (sg + 1) * ntiles / nstreams;
+    const int64_t iters = (ntiles + nstreams - 1) / nstreams;
+    const int64_t tile_hi = (tile_end > tile_first ? tile_end : (tile_first + 1 < ntiles ? tile_first + 1 : ntiles)) - 1;
+    auto tile_at = [&](int64_t i) -> int64_t {           // clamped: a stream short of tiles repeats its last one
+        const int64_t t = tile_first + i;
+        return t > tile_hi ? tile_hi : t;
+    };
+
+    // ---- one-time: this wave's share of the bank -> registers (unit rows, zero beyond F; idle columns all zero)
+    f32x4 bk[NB][KC];
+    float2 bv[D];
+    {
+        const int l = col_ok ? lcol : 0;
+#pragma unroll
+        for (int bl = 0; bl < NB; ++bl) {
+            // bank slot behind register slot bl: support 2 * half + bl (HS) or bl, the centre (slot D) last
+            const int b = (bl == NBS) ? D : (HS ? 2 * half + bl : bl);
+            const bool zero = !col_ok || (HS && bl == NBS && half != 0);      // (the second half multiplies no centre)
+#pragma unroll
+            for (int t = 0; t < KC; ++t) {
+                f32x4 v = *(const f32x4*)(dg.padded + ((size_t)b * L + l) * FP + 16 * t + 4 * kq);
+                if (zero) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                bk[bl][t] = v;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+            float2 v = *(const float2*)(dg.edge_padded + ((size_t)b * L + l) * 8 + 2 * kq);
+            if (!col_ok) v = float2{0.f, 0.f};
+            bv[b] = v;
+        }
+    }
+    const float ws = dg.mix[0], wc = dg.mix[1], we = dg.mix[2], wsum = dg.mix[3];
+    if constexpr (D == 4) {
+        if (do_chir)
+            for (int q = tid; q < L * 12; q += 256) chirtab[q] = dg.chir[q];
+    }
+    const int8_t* const eqp = do_chir ? (const int8_t*)dg.eqflag : (const int8_t*)dg.sel;       // always loadable
+    const int8_t* const sgp = do_chir ? (const int8_t*)dg.signflag : (const int8_t*)dg.sel;
+    const uint32_t xs = (uint32_t)a.xs;
+    const int F = a.F, E = a.E;
+
+    uint32_t idsD[S1];                                   // atom ids (of atom ci, every slot) of the tile the DMA pointer is in
+    // source of DMA piece t of a row: chunk 4 t + kq; a chunk entirely beyond the row's width is fetched from the
+    // row's first chunk instead (in bounds, finite whenever the row is) and masked to zero where it is used
+    auto row_src = [&](uint32_t id, int t) -> const float* {
+        const int col = 16 * t + 4 * kq;
+        const uint32_t off = (t == KC - 1 && col >= F) ? 0u : (uint32_t)col;
+        return a.x + ((size_t)id * xs + off);
+    };
+    auto issue_rows = [&](auto sdc, float* buf) {        // this wave's pieces of slot sd of the DMA tile
+        constexpr int sd = decltype(sdc)::value;
+        static_for<0, KC>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            static_for<0, NS>([&](auto rc) {
+                if constexpr (t % NS == decltype(rc)::value) {
+                    if (role == decltype(rc)::value) dma16(row_src(idsD[sd], t), buf + t * 256);
+                }
+            });
+        });
+    };
+    // bond attributes of slot sd: two 64-dword pieces, [atom 0..7 | 8..15][8 components] (component 7 duplicates the
+    // last real one: masked where it is used)
+    auto issue_bonds = [&](int64_t t, int sd, float* mrec) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            int64_t n = t * 16 + h * 8 + (lane >> 3);
+            if (n >= dg.n) n = dg.n - 1;
+            const int comp = (lane & 7) < E ? (lane & 7) : E - 1;
+            dma4(dg.e_nei + (n * D + sd) * E + comp, mrec + T::OFF_BOND + sd * 128 + h * 64);
+        }
+    };
+    // lane q -> (slot q >> 4, atom q & 15): slots 0..3 in one 64-dword piece, slot 4 (degree 4's focal row) in a second
+    auto issue_ids = [&](int64_t t, float* mrec) {       // low dwords of the int64 indices of tile t
+        int64_t n = t * 16 + ci;
+        if (n >= dg.n) n = dg.n - 1;
+        const void* src = (kq < D) ? (const void*)(dg.nei + n * D + kq) : (const void*)(dg.sel + n);    // kq == D: the focal id (D < 4)
+        if (S1 >= 4 || kq < S1) dma4(src, mrec);
+        if constexpr (S1 == 5) {
+            if (kq == 0) dma4(dg.sel + n, mrec + 64);
+        }
+    };
+    auto issue_meta = [&](int64_t t, float* mrec) {      // 1 / |x| of every slot (through the ids in the record), flags, focal ids
+        // lane q needs the id of (slot q >> 4, atom q & 15): read it from the record (idsD[kq] would be a run-time index)
+        const uint32_t idq = __float_as_uint(mrec[16 * ((S1 >= 4 || kq < S1) ? kq : 0) + ci]);
+        if (S1 >= 4 || kq < S1) dma4(a.inv + idq, mrec + T::OFF_INV);
+        if constexpr (S1 == 5) {
+            if (kq == 0) dma4(a.inv + idsD[4], mrec + T::OFF_INV + 64);
+        }
+        if constexpr (D == 4) {                          // 16 flag bytes each = 4 dwords
+            if (lane < 4) {
+                int64_t n4 = t * 4 + lane;               // dword index; the last tile may be partial: clamp into the array
+                const int64_t hi = (dg.n + 3) / 4 - 1;
+                n4 = n4 > hi ? hi : n4;
+                dma4(sgp + 4 * n4, mrec + T::OFF_SIGN);
+                dma4(eqp + 4 * n4, mrec + T::OFF_EQ);
+            }
+        }
+        if (kq == 0) mrec[T::OFF_FOCAL + ci] = __uint_as_float(idsD[D]);     // (a plain LDS store from registers)
+    };
+
+    // ---- prologue: tile 0's ids go through the LDS record like every later tile's (idsD must never be indexed by a
+    // run-time value: the array would live in scratch); then the first RING slots, tile 0's record, tile 1's ids;
+    // everything drained before the loop
+    if (role == 0) issue_ids(tile_at(0), meta);
+    wait_vmcnt<0>();
+    __syncthreads();                                     // (also: chirality table written)
+#pragma unroll
+    for (int q = 0; q < S1; ++q) idsD[q] = __float_as_uint(meta[16 * q + ci]);
+    static_for<0, RING>([&](auto kc) {                   // RING <= S1: all inside tile 0
+        constexpr int k = decltype(kc)::value;
+        issue_rows(kc, ring + k * SLOT);
+        if (role == 0 && k < D) issue_bonds(tile_at(0), k, meta);
+    });
+    if (role == 0) {
+        issue_meta(tile_at(0), meta);
+        issue_ids(tile_at(1), meta + META);
+    }
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+
+    int buf = 0;                                         // ring buffer of the current step
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t tile = tile_at(it);
+        const bool real = tile_first + it < tile_end;    // else: a repeat of the last tile, results discarded
+        float* const mrec = meta + (it & 1) * META;
+        f32x4 cm[D][NBS];
+        f32x4 cc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < D; ++s)
+#pragma unroll
+            for (int b = 0; b < NBS; ++b) cm[s][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        static_for<0, S1>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            // ---- multiply slot s: one LDS read per 4 NBS (or 4) matrix instructions, issued one chunk ahead
+            const float* rb = ring + buf * SLOT + lane * 4;
+            if (s < D || !HS || half == 0) {             // (HS: the centre belongs to half 0)
+                f32x4 nxt = *(const f32x4*)rb;
+#pragma unroll
+                for (int t = 0; t < KC; ++t) {
+                    f32x4 cur = nxt;
+                    if (t + 1 < KC) nxt = *(const f32x4*)(rb + (t + 1) * 256);
+                    if (t == KC - 1) {                   // only the last chunk of a row can be partial or empty
+                        const int col = 16 * t + 4 * kq;
+                        if (col >= F) cur.x = 0.f;
+                        if (col + 1 >= F) cur.y = 0.f;
+                        if (col + 2 >= F) cur.z = 0.f;
+                        if (col + 3 >= F) cur.w = 0.f;
+                    }
+                    if constexpr (s < D) {
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                            for (int b = 0; b < NBS; ++b)
+                                cm[s][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[q4], bk[b][t][q4], cm[s][b], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) cc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[q4], bk[NBS][t][q4], cc, 0, 0, 0);
+                    }
+                    // pin the order: the next chunk's read ahead of this chunk's matrix instructions
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, s < D ? 4 * NBS : 4, 0);
+                }
+            }
+            // ---- retire: only the youngest batch (issued at the end of the previous step, DMA slot sdp) may stay in
+            // flight, so the batch of the NEXT step has landed.  (A 2-buffer ring has just one batch in flight.)
+            if constexpr (RING == 2) {
+                wait_vmcnt<0>();
+            } else {
+                constexpr int sdp = (s + S1 - 1 + RING) % S1;
+                static_for<0, NS>([&](auto rc) {
+                    if (role == decltype(rc)::value) wait_vmcnt<batch_size<D, KC>(sdp, decltype(rc)::value)>();
+                });
+            }
+            if constexpr (NS > 1) __builtin_amdgcn_s_barrier();
+            // ---- issue the batch of step k + RING into the buffer just read
+            constexpr int sd = (s + RING) % S1;
+            const int64_t itd = it + (s + RING) / S1;    // iteration (tile) the DMA pointer is in
+            float* const drec = meta + (itd & 1) * META;
+            if constexpr (sd == 0) {                     // the DMA pointer enters a new tile: its ids were DMA'd a tile ago
+#pragma unroll
+                for (int q = 0; q < S1; ++q) idsD[q] = __float_as_uint(drec[16 * q + ci]);
+            }
+            issue_rows(IC<sd>{}, ring + buf * SLOT);
+            if (role == 0) {
+                if constexpr (sd < D) issue_bonds(tile_at(itd), sd, drec);
+                if constexpr (sd == 0) {
+                    issue_meta(tile_at(itd), drec);
+                    issue_ids(tile_at(itd + 1), meta + ((itd + 1) & 1) * META);
+                }
+            }
+            buf = (buf + 1 == RING) ? 0 : buf + 1;
+        });
+
+        // ---- epilogue: lane = kernel lcol, atoms kq * 4 + jj (the arithmetic of kc_forward_fused).  One atom at a
+        // time, fenced: left to itself the scheduler interleaves the atoms' permutation scans for ILP, and with the
+        // bank resident in registers that is what spills.
+        constexpr int NJ = HS ? 2 : 4;                   // atoms of a lane this wave finishes (HS: 2 * half, 2 * half + 1)
+        [[maybe_unused]] float px[NJ][D][2];             // (HS) the partner's two support columns of my atoms
+        [[maybe_unused]] float pcc[NJ];
+        if constexpr (HS) {
+            // swap: my columns of the PARTNER's atoms out, the partner's columns of MY atoms in
+            float* const mine = xbuf + (size_t)wave * (18 * 64) + lane;
+            const float* const theirs = xbuf + (size_t)(wave ^ 1) * (18 * 64) + lane;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int s = 0; s < D; ++s)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        mine[((j * D + s) * 2 + b) * 64] = half ? cm[s][b][j] : cm[s][b][2 + j];     // partner's atoms: 2 (1 - half) + j
+                mine[(16 + j) * 64] = half ? cc[j] : cc[2 + j];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                for (int s = 0; s < D; ++s)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) px[j][s][b] = theirs[((j * D + s) * 2 + b) * 64];
+                pcc[j] = theirs[(16 + j) * 64];
+            }
+        }
+        int idx4[NJ];
+        float best4[NJ], cen4[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            float m[D][D];
+            const int jj = HS ? 2 * half + j : j;        // atom of the lane (run-time only under HS: selects, never an index)
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+                const float iv = mrec[T::OFF_INV + s * 16 + kq * 4 + jj];
+                if constexpr (HS) {
+                    const float own0 = half ? cm[s][0][2 + j] : cm[s][0][j], own1 = half ? cm[s][1][2 + j] : cm[s][1][j];
+                    m[s][0] = (half ? px[j][s][0] : own0) * iv;
+                    m[s][1] = (half ? px[j][s][1] : own1) * iv;
+                    m[s][2] = (half ? own0 : px[j][s][0]) * iv;
+                    m[s][3] = (half ? own1 : px[j][s][1]) * iv;
+                } else {
+#pragma unroll
+                    for (int b = 0; b < D; ++b) m[s][b] = cm[s][b][j] * iv;
+                }
+            }
+            best_permutation<D>(m, best4[j], idx4[j]);
+            float c;
+            if constexpr (HS) c = half ? pcc[j] : cc[j];
+            else c = cc[j];
+            cen4[j] = c * mrec[T::OFF_INV + D * 16 + kq * 4 + jj];
+            if constexpr (D >= 3) __builtin_amdgcn_sched_barrier(0);
+        }
+        uint32_t signw = 0, eqw = 0;
+        if constexpr (D == 4) {
+            signw = __float_as_uint(mrec[T::OFF_SIGN + kq]);
+            eqw = __float_as_uint(mrec[T::OFF_EQ + kq]);
+        }
+        float2 eu[D];                                    // unit bond components 2 kq, 2 kq + 1 of (atom ci, slot s)
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            const float2 raw = *(const float2*)(mrec + T::OFF_BOND + s * 128 + ci * 8 + 2 * kq);
+            const float ex = 2 * kq < E ? raw.x : 0.f, ey = 2 * kq + 1 < E ? raw.y : 0.f;
+            float s2 = fmaf(ey, ey, ex * ex);
+            s2 += __shfl_xor(s2, 16, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            const float ie = 1.f / fmaxf(sqrtf(s2), MKGNN_EPS);
+            eu[s] = float2{ex * ie, ey * ie};
+        }
+        // bond-cosine matrices, one (a, b) tile at a time; keep the entry the chosen order uses
+        float ed4[NJ][D];
+        static_for<0, D>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            f32x4 dm[D];                                 // D independent chains
+#pragma unroll
+            for (int b = 0; b < D; ++b) dm[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(eu[s].x, bv[b].x, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < D; ++b) dm[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(eu[s].y, bv[b].y, dm[b], 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int pb = perm_entry<D, s>(idx4[j]);
+                float v;
+                if constexpr (HS) {
+                    v = half ? dm[0][2 + j] : dm[0][j];
+#pragma unroll
+                    for (int b = 1; b < D; ++b) v = (pb == b) ? (half ? dm[b][2 + j] : dm[b][j]) : v;
+                } else {
+                    v = dm[0][j];
+#pragma unroll
+                    for (int b = 1; b < D; ++b) v = (pb == b) ? dm[b][j] : v;
+                }
+                ed4[j][s] = v;
+            }
+        });
+        const f32x4 focal4 = *(const f32x4*)(mrec + T::OFF_FOCAL + kq * 4);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int jj = HS ? 2 * half + j : j;
+            const int64_t n = tile * 16 + kq * 4 + jj;
+            float ed = ed4[j][0];
+#pragma unroll
+            for (int s = 1; s < D; ++s) ed = __fadd_rn(ed, ed4[j][s]);
+            ed = div_by<D>(ed);
+            float sc = __fadd_rn(__fadd_rn(__fmul_rn(best4[j], ws), __fmul_rn(cen4[j], wc)), __fmul_rn(ed, we)) / wsum;
+            float ch = 1.f;
+            if constexpr (D == 4) {
+                const int eqb = (int)((eqw >> (8 * jj)) & 0xFFu);
+                const float sgn = (float)(int8_t)((signw >> (8 * jj)) & 0xFFu);
+                if (do_chir && !eqb) ch = ((float)chirtab[(col_ok ? lcol : 0) * 12 + idx4[j]] == sgn) ? 1.f : -1.f;
+                sc *= ch;
+            }
+            uint32_t focal;
+            if constexpr (HS) focal = __float_as_uint(half ? focal4[2 + j] : focal4[j]);
+            else focal = __float_as_uint(focal4[j]);
+            if (real && col_ok && n < dg.n) {
+                a.out[(size_t)focal * a.os + dg.off + lcol] = sc;
+                const uint32_t o = (uint32_t)n * (uint32_t)L + (uint32_t)lcol;   // the host fuses a degree only if 3 * N_d * L < 2^32
+                if (dg.best) dg.best[o] = (uint8_t)idx4[j];
+                if (dg.scores) {
+                    const uint32_t ln = (uint32_t)L * (uint32_t)dg.n;
+                    dg.scores[o] = best4[j];
+                    dg.scores[ln + o] = cen4[j];
+                    dg.scores[2u * ln + o] = ed;
+                }
+                if (dg.chir_out) dg.chir_out[o] = (int8_t)ch;
+            }
+        }
+    }
+    wait_vmcnt<0>();                                     // no DMA may land in this block's LDS after it is gone
+}
+
+template <int KC>
+__global__ void __launch_bounds__(256, 2) kc_forward_stream(FusedFwdArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    const int grp = a.blk_group[blockIdx.x];
+    const int rank = a.blk_rank[blockIdx.x];
+    const int di = a.grp_degree[grp];
+    const int cp = a.grp_cp[grp];
+    const int count = a.grp_count[grp];
+    switch (di) {
+        case 0: stream_body<1, KC>(a, a.deg[0], cp, rank, count, lds); break;
+        case 1: stream_body<2, KC>(a, a.deg[1], cp, rank, count, lds); break;
+        case 2: stream_body<3, KC>(a, a.deg[2], cp, rank, count, lds); break;
+        default: stream_body<4, KC>(a, a.deg[3], cp, rank, count, lds); break;
+    }
+}
+
+// ---------------------------------------------------------------- host ----
+bool stream_forward_supported(int d, int F, int E, int L) {
+    if (d < 1 || d > 4 || L < 1 || E < 1 || E > 8) return false;
+    const int FP = mfma_padded_width(F);
+    if (!FP || F <= FP - 16) return false;               // only the last 16-float chunk of a row may be partial
+    if (d == 4 && L * 12 > 768) return false;            // the chirality sign table's LDS slot
+    return (L + 15) / 16 == stream_column_tiles(d);
+}
+
+// Block table of the streamed launch: one group per degree, block counts by greedy min-max over
+// prologue + iterations * cost per tile (all blocks are resident at once: the launch lasts as long as its slowest wave),
+// groups interleaved over the block ids, the blocks of a group that share an XCD (block id mod 8) given adjacent runs
+// of tiles (the buckets are sorted by atom id: what one group gathers as neighbours another gathers as focal rows).
+static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nblocks_out) {
+    constexpr int MG = 8;                               // groups: degrees 1-3 one each, degree 4 two (its column parts)
+    double cost[MG], bytes_per_tile[MG];
+    int64_t tiles_of[MG], cap[MG];
+    int nstream_of[MG], ng = 0;
+    size_t lds_floats = 0;
+    for (int i = 0; i < 4; ++i) {
+        if (!use[i]) continue;
+        FusedDeg& g = a.deg[i];
+        const int d = i + 1;
+        g.nct = stream_column_tiles(d);
+        g.kpt = (g.L + g.nct - 1) / g.nct;
+        g.cs = (d == 4) ? 2 : 1; g.nloc = g.nct / g.cs; g.ics = g.nloc;
+        const int nstream = (d == 4) ? 1 : 4 / g.nct;
+        const int64_t ntiles = (g.n + 15) / 16;
+        const size_t fl = (size_t)stream_lds_floats(d, KC);
+        if (fl > lds_floats) lds_floats = fl;
+        for (int cp = 0; cp < g.cs; ++cp) {
+            // matrix instructions of the busiest wave per tile + a term for the epilogue (unit: one instruction's 32 cycles)
+            const int nbs = (d == 4) ? 2 : d;
+            cost[ng] = (d * nbs + 1) * 4.0 * KC + 2.0 * d * d + (d == 4 ? 45.0 : d == 3 ? 40.0 : 25.0);
+            // the rows a tile gathers: a stream cannot run faster than its share of the CU's gather rate delivers them
+            bytes_per_tile[ng] = (double)(d + 1) * 16 * 64 * KC;
+            tiles_of[ng] = ntiles;
+            cap[ng] = (ntiles + nstream - 1) / nstream;
+            nstream_of[ng] = nstream;
+            a.grp_degree[ng] = (uint8_t)i;
+            a.grp_cp[ng] = (uint8_t)cp;
+            ++ng;
+        }
+    }
+    if (ng == 0) { *nblocks_out = 0; return 0; }
+    const double prologue = 60.0;
+    // ~16 GB/s of gathered rows per block (half a CU's ~33 GB/s from the Infinity Cache, MI355X_MICROARCH.md "Indexed
+    // rows"), in bytes per unit of 32 cycles at ~2.1 GHz
+    const double block_bytes_per_unit = 16e9 * 32.0 / 2.1e9;
+    auto finish = [&](int g, int blocks) {
+        const int64_t streams = (int64_t)blocks * nstream_of[g];
+        const double per_tile = cost[g] > bytes_per_tile[g] * nstream_of[g] / block_bytes_per_unit
+                                    ? cost[g] : bytes_per_tile[g] * nstream_of[g] / block_bytes_per_unit;
+        return prologue + (double)((tiles_of[g] + streams - 1) / streams) * per_tile;
+    };
+    int count[MG], nb = 0;
+    for (int g = 0; g < ng; ++g) { count[g] = 1; ++nb; }
+    while (nb < FUSED_MAX_BLOCKS) {
+        int worst = -1;
+        double t_worst = -1.0;
+        for (int g = 0; g < ng; ++g) {
+            if (count[g] >= cap[g]) continue;
+            const double t = finish(g, count[g]);
+            if (t > t_worst) { t_worst = t; worst = g; }
+        }
+        if (worst < 0) break;
+        ++count[worst]; ++nb;
+    }
+    int given[MG] = {};
+    for (int b = 0; b < nb; ++b) {
+        int pick = -1;
+        double best = -1e30;
+        for (int g = 0; g < ng; ++g) {
+            if (given[g] >= count[g]) continue;
+            const double lag = (double)count[g] * (b + 1) / nb - given[g];
+            if (lag > best) { best = lag; pick = g; }
+        }
+        a.blk_group[b] = (uint8_t)pick;
+        ++given[pick];
+    }
+    {
+        int per_xcd[MG][8] = {};
+        for (int b = 0; b < nb; ++b) ++per_xcd[a.blk_group[b]][b & 7];
+        int next[MG][8];
+        for (int g = 0; g < ng; ++g) {
+            int run = 0;
+            for (int x = 0; x < 8; ++x) { next[g][x] = run; run += per_xcd[g][x]; }
+        }
+        for (int b = 0; b < nb; ++b) a.blk_rank[b] = (uint16_t)next[a.blk_group[b]][b & 7]++;
+    }
+    for (int g = 0; g < ng; ++g) a.grp_count[g] = (uint16_t)count[g];
+    *nblocks_out = nb;
+    return lds_floats * 4;
+}
+
+hipError_t launch_forward_stream(FusedFwdArgs& a, const bool use[4], hipStream_t st) {
+    const int KC = mfma_padded_width(a.F) / 16;
+    int nb = 0;
+    const size_t lds_bytes = plan_stream(a, use, KC, &nb);
+    if (nb == 0) return hipSuccess;
+    if (KC == 2) kc_forward_stream<2><<<nb, 256, lds_bytes, st>>>(a);
+    else kc_forward_stream<7><<<nb, 256, lds_bytes, st>>>(a);
+    return hipGetLastError();
+}
+
+}  // namespace mkgnn

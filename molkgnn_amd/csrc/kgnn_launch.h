@@ -93,6 +93,9 @@ hipError_t launch_forward_generic(int d, const FwdArgs& a, hipStream_t st);
 bool mfma_forward_supported(int d, int F, int E, int L);
 int fused_group_count(int d, int F, int L);      // groups of the fused launch this degree needs (budget: FUSED_MAX_GROUPS)
 hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t st);
+// kgnn_fwd_stream.hip: bank in registers, atom rows streamed through LDS by DMA (the reference's shapes)
+bool stream_forward_supported(int d, int F, int E, int L);
+hipError_t launch_forward_stream(FusedFwdArgs& a, const bool use[4], hipStream_t st);
 hipError_t launch_backward_generic(int d, const BwdArgs& a, hipStream_t st);
 struct BankReduceAllArgs { BankReduceArgs deg[4]; int blk_start[4]; };
 hipError_t launch_bank_reduce_all(const BankReduceArgs r[4], hipStream_t st);   // degrees with L == 0 are skipped

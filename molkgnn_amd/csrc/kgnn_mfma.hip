@@ -544,13 +544,14 @@ extern "C" int mkgnn_debug_set_stamp_buffer(void* device_ptr) {
 
 // Measurement hook for bench.py: when enabled, every fused forward launch is bracketed by HIP
 // events on its own stream; the getter waits for the last one and returns its duration.
-static bool g_time_fused = false;
+// (a measurement hook for one benchmarking thread: the flag is atomic, the event pair is not per caller)
+static std::atomic<bool> g_time_fused{false};
 static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 extern "C" int mkgnn_debug_time_fused_forward(int enable) {
-    g_time_fused = enable != 0;
-    if (g_time_fused && !g_ev0) {
+    if (enable && !g_ev0) {
         if (hipEventCreate(&g_ev0) != hipSuccess || hipEventCreate(&g_ev1) != hipSuccess) return 1;
     }
+    g_time_fused.store(enable != 0);
     return 0;
 }
 extern "C" float mkgnn_debug_last_fused_forward_ms(void) {
@@ -690,25 +691,44 @@ static size_t plan_fused(FusedFwdArgs& a, const bool use[4], int KC, int* nblock
 
 hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t st) {
     const int KC = mfma_padded_width(a.F) / 16;
-    int nb = 0;
-    const size_t lds_bytes = plan_fused(a, use, KC, &nb);
-    if (nb == 0) return hipSuccess;
     if (a.last && use[3] && a.deg[3].n > 0) {
         int64_t blocks = (a.deg[3].n + 3) / 4;
         if (blocks > 2048) blocks = 2048;
         rows_equal_kernel<<<(int)blocks, 256, 0, st>>>(a.x, a.xs, a.deg[3].nei, a.deg[3].p_focal, a.deg[3].p_nei, a.deg[3].n, a.F,
                                                       (int8_t*)a.deg[3].eqflag, (int8_t*)a.deg[3].signflag);
     }
-    if (g_time_fused) (void)hipEventRecord(g_ev0, st);
-    const bool gen = a.F <= 16 * (KC - 1);           // more than the last chunk can be partial or empty
-    if (a.bf16) {
-        if (KC == 2) { if (gen) kc_forward_fused<2, true, true><<<nb, 256, lds_bytes, st>>>(a); else kc_forward_fused<2, false, true><<<nb, 256, lds_bytes, st>>>(a); }
-        else { if (gen) kc_forward_fused<7, true, true><<<nb, 256, lds_bytes, st>>>(a); else kc_forward_fused<7, false, true><<<nb, 256, lds_bytes, st>>>(a); }
-    } else {
-        if (KC == 2) { if (gen) kc_forward_fused<2, true, false><<<nb, 256, lds_bytes, st>>>(a); else kc_forward_fused<2, false, false><<<nb, 256, lds_bytes, st>>>(a); }
-        else { if (gen) kc_forward_fused<7, true, false><<<nb, 256, lds_bytes, st>>>(a); else kc_forward_fused<7, false, false><<<nb, 256, lds_bytes, st>>>(a); }
+    // The reference's bank shapes take the streamed kernel (kgnn_fwd_stream.hip); every other covered shape, and the
+    // bf16 variant, the LDS-bank kernel below.  MKGNN_FWD_STREAM=0: A/B switch (diagnostics).
+    static const char* env_stream = getenv("MKGNN_FWD_STREAM");
+    const bool stream_on = !(env_stream && env_stream[0] == '0') && !a.bf16;
+    bool use_stream[4], use_bank[4];
+    bool any_bank = false;
+    for (int i = 0; i < 4; ++i) {
+        use_stream[i] = use[i] && stream_on && stream_forward_supported(i + 1, a.F, a.E, a.deg[i].L);
+        use_bank[i] = use[i] && !use_stream[i];
+        any_bank = any_bank || use_bank[i];
     }
-    if (g_time_fused) (void)hipEventRecord(g_ev1, st);
+    if (g_time_fused.load()) (void)hipEventRecord(g_ev0, st);
+    {
+        FusedFwdArgs s = a;
+        hipError_t e = launch_forward_stream(s, use_stream, st);
+        if (e != hipSuccess) return e;
+    }
+    if (any_bank) {
+        int nb = 0;
+        const size_t lds_bytes = plan_fused(a, use_bank, KC, &nb);
+        if (nb > 0) {
+            const bool gen = a.F <= 16 * (KC - 1);           // more than the last chunk can be partial or empty
+            if (a.bf16) {
+                if (KC == 2) { if (gen) kc_forward_fused<2, true, true><<<nb, 256, lds_bytes, st>>>(a); else kc_forward_fused<2, false, true><<<nb, 256, lds_bytes, st>>>(a); }
+                else { if (gen) kc_forward_fused<7, true, true><<<nb, 256, lds_bytes, st>>>(a); else kc_forward_fused<7, false, true><<<nb, 256, lds_bytes, st>>>(a); }
+            } else {
+                if (KC == 2) { if (gen) kc_forward_fused<2, true, false><<<nb, 256, lds_bytes, st>>>(a); else kc_forward_fused<2, false, false><<<nb, 256, lds_bytes, st>>>(a); }
+                else { if (gen) kc_forward_fused<7, true, false><<<nb, 256, lds_bytes, st>>>(a); else kc_forward_fused<7, false, false><<<nb, 256, lds_bytes, st>>>(a); }
+            }
+        }
+    }
+    if (g_time_fused.load()) (void)hipEventRecord(g_ev1, st);
     return hipGetLastError();
 }
 
