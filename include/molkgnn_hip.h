@@ -76,6 +76,10 @@ typedef struct mkgnn_degree_bucket {
     const float* nei_edge_attr;       /* [N_d, d, E] raw bond attributes             */
     const float* p_focal;             /* [N_d, 3]   (d = 4, last layer only; else may be NULL) */
     const float* nei_p;               /* [N_d, d, 3] (same)                          */
+    const float* nei_edge_unit;       /* [N_d, d, 8] nei_edge_attr / max(|.|, 1e-8), zero padded (mkgnn_unit_rows8; E <= 8);
+                                         may be NULL.  The bond attributes of a batch are the same in every layer and every
+                                         step: a caller that keeps them (molkgnn_amd.plan does) saves the forward kernel the
+                                         per-tile normalisation, and lets it take the streamed kernel */
 } mkgnn_degree_bucket;
 
 /* What forward keeps for backward, per degree (caller-allocated). */
@@ -92,6 +96,10 @@ const char* mkgnn_last_error(void);
  * torch.nn.CosineSimilarity as used at kernels.py:189).  inv_norm: [N]. */
 int mkgnn_row_inv_norm(const float* x, int64_t x_stride, int64_t n_rows, int32_t F,
                        float* inv_norm, void* stream);
+
+/* out[r, 0..7] = in[r, 0..E-1] / max(||in[r]||, 1e-8), zero beyond E (E <= 8): the unit bond-attribute rows
+ * mkgnn_degree_bucket.nei_edge_unit holds.  in: [n_rows, E] contiguous, out: [n_rows, 8]. */
+int mkgnn_unit_rows8(const float* in, int64_t n_rows, int32_t E, float* out, void* stream);
 
 /* Bytes of scratch the two calls below need for these sizes. */
 size_t mkgnn_workspace_bytes(const int32_t num_kernels[MKGNN_MAX_DEGREE], int32_t F, int32_t E,

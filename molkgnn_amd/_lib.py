@@ -13,7 +13,8 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmolkgnn_hip.so")
+# MKGNN_LIB: a diagnostic build of the same library (make VARIANT=... in csrc/), e.g. with cycle stamps compiled in
+LIB_PATH = os.environ.get("MKGNN_LIB") or os.path.join(_HERE, "libmolkgnn_hip.so")
 MAX_DEGREE = 4
 ABI_VERSION = 2
 
@@ -34,7 +35,7 @@ class KernelBankGrad(C.Structure):
 
 class DegreeBucket(C.Structure):
     _fields_ = [("count", C.c_int64), ("selected_index", C.c_void_p), ("nei_index", C.c_void_p),
-                ("nei_edge_attr", C.c_void_p), ("p_focal", C.c_void_p), ("nei_p", C.c_void_p)]
+                ("nei_edge_attr", C.c_void_p), ("p_focal", C.c_void_p), ("nei_p", C.c_void_p), ("nei_edge_unit", C.c_void_p)]
 
 
 class Saved(C.Structure):
@@ -62,7 +63,7 @@ Buckets4 = DegreeBucket * MAX_DEGREE
 Saved4 = Saved * MAX_DEGREE
 Int32x4 = C.c_int32 * MAX_DEGREE
 
-EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn_workspace_bytes",
+EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn_unit_rows8", "mkgnn_workspace_bytes",
            "mkgnn_kernelsetconv_forward", "mkgnn_kernelsetconv_backward", "mkgnn_segment_sum_rows",
            "mkgnn_readout_hidden_stride", "mkgnn_readout_workspace_bytes", "mkgnn_readout_forward",
            "mkgnn_readout_backward", "mkgnn_batchnorm_workspace_bytes", "mkgnn_batchnorm_forward",
@@ -94,6 +95,8 @@ def load() -> C.CDLL:
     lib.mkgnn_last_error.restype = C.c_char_p
     lib.mkgnn_row_inv_norm.restype = C.c_int
     lib.mkgnn_row_inv_norm.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.mkgnn_unit_rows8.restype = C.c_int
+    lib.mkgnn_unit_rows8.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]
     lib.mkgnn_workspace_bytes.restype = C.c_size_t
     lib.mkgnn_workspace_bytes.argtypes = [Int32x4, C.c_int32, C.c_int32, C.c_int64, C.c_int64]
     lib.mkgnn_kernelsetconv_forward.restype = C.c_int

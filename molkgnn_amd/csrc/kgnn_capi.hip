@@ -140,6 +140,13 @@ int mkgnn_row_inv_norm(const float* x, int64_t x_stride, int64_t n_rows, int32_t
     return e == hipSuccess ? 0 : hip_fail("mkgnn_row_inv_norm", e);
 }
 
+int mkgnn_unit_rows8(const float* in, int64_t n_rows, int32_t E, float* out, void* stream) {
+    if (n_rows < 0 || E < 1 || E > 8) return fail("mkgnn_unit_rows8: %lld rows of width %d (1..8)", (long long)n_rows, E);
+    if (n_rows && (!in || !out)) return fail("mkgnn_unit_rows8: null pointer");
+    hipError_t e = launch_unit_rows8(in, n_rows, E, out, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail("mkgnn_unit_rows8", e);
+}
+
 size_t mkgnn_workspace_bytes(const int32_t num_kernels[MKGNN_MAX_DEGREE], int32_t F, int32_t E, int64_t n_atoms,
                              int64_t n_edges) {
     return make_layout(num_kernels, F, E, n_atoms, n_edges).total;
@@ -216,7 +223,7 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
     FusedFwdArgs fa;
     memset(&fa, 0, sizeof(fa));
     fa.x = x; fa.xs = x_stride; fa.inv = inv_norm; fa.out = out; fa.os = out_stride;
-    fa.K = K; fa.F = F; fa.E = E; fa.last = is_last_layer ? 1 : 0;
+    fa.K = K; fa.F = F; fa.E = E; fa.last = is_last_layer ? 1 : 0; fa.n_atoms = n_atoms;
     fa.bf16 = variant == 3 ? 1 : 0;
     bool use[4] = {false, false, false, false};
     bool any_fused = false;
@@ -264,7 +271,7 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
                         (long long)x_stride);
         if (can_fuse) {
             FusedDeg& g = fa.deg[i];
-            g.sel = a.sel; g.nei = a.nei; g.e_nei = a.e_nei; g.p_focal = a.p_focal; g.p_nei = a.p_nei;
+            g.sel = a.sel; g.nei = a.nei; g.e_nei = a.e_nei; g.e_unit = buckets[i].nei_edge_unit; g.p_focal = a.p_focal; g.p_nei = a.p_nei;
             g.padded = a.padded; g.edge_padded = a.edge_padded; g.chir = a.chir; g.mix = a.mix;
             g.eqflag = (const int8_t*)(ws + w.eqflag);
             g.signflag = (const int8_t*)(ws + w.signflag);

@@ -36,6 +36,9 @@
 // Covered shapes: F in (16 (KC - 1), 16 KC] for KC = 2 or 7 (the reference's 28 and 110), E <= 8, 16-byte aligned rows,
 // and per degree exactly NS(d) = 1 / 2 / 2 / 4 column tiles (L <= 16 / 17..32 / 17..32 / 49..64: the reference's
 // 10 / 20 / 30 / 50).  Other shapes keep kc_forward_fused.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "kgnn_launch.h"
@@ -47,7 +50,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <int D> struct StreamTraits {
     static constexpr int NS = (D == 1) ? 1 : (D == 4 ? 4 : 2);     // waves sharing an atom tile = column tiles of the degree
     static constexpr int NSTREAM = 4 / NS;                         // atom-tile streams per 4-wave block
-    static constexpr int RING = (NS == 1) ? 2 : 3;                 // row-slot buffers per stream
+    // row-slot buffers per stream (<= S1): the batch of step k + RING is issued when step k has been multiplied, so the
+    // rows of a slot have RING - 1 steps of matrix work (0.9 - 1.7 us each at two waves per SIMD) to arrive
+    static constexpr int RING = (D == 1) ? 2 : (D == 2 ? 3 : (D == 3 ? 4 : 5));
     static constexpr int S1 = D + 1;                               // steps (slots) per tile
     // per-tile record (floats): ids[S1][16] | inv[S1][16] | focal[16] | sign bytes[16] (4 dwords used) | eq bytes[16] | bond[D][16][8]
     static constexpr int OFF_INV = 16 * S1, OFF_FOCAL = 32 * S1, OFF_SIGN = OFF_FOCAL + 16, OFF_EQ = OFF_SIGN + 16,
@@ -58,7 +63,7 @@ int stream_column_tiles(int d) { return d == 1 ? 1 : (d == 4 ? 4 : 2); }
 
 __host__ __device__ constexpr int stream_lds_floats(int D, int KC) {
     const int NS = (D == 1) ? 1 : (D == 4 ? 4 : 2);
-    const int RING = (NS == 1) ? 2 : 3;
+    const int RING = (D == 1) ? 2 : (D == 2 ? 3 : (D == 3 ? 4 : 5));
     const int META = 32 * (D + 1) + 48 + 128 * D;
     // degree 4: + chirality sign table (<= 64 x 12 bytes) + the exchange buffer of the support halves (4 waves x 18 KB-rows of 256 B)
     return (4 / NS) * (RING * KC * 256 + 2 * META) + (D == 4 ? 192 + 4 * 18 * 64 : 0);
@@ -84,6 +89,29 @@ template <int D, int A> __device__ __forceinline__ int perm_entry(int p) {
     }
 }
 
+// Diagnostic build (make STAMPS=1): per-wave cycle totals of the loop's phases -- multiply, counted wait, barrier, DMA issue,
+// epilogue -- in stamps[4..8] (tools/stream_stamps.py).  Each s_memtime read costs an lgkmcnt(0) at a phase boundary.
+#ifdef MKGNN_FWD_STAMPS
+#define MKGNN_PHASE(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); phase[i] += t_ - t_phase; t_phase = t_; } while (0)
+#else
+#define MKGNN_PHASE(i) do { } while (0)
+#endif
+
+// Wave priority of the multiply phase / of everything else (waits, DMA issue, epilogue).  Two waves share a SIMD: the one
+// that is multiplying needs one issue slot per 32 cycles, the other one's VALU-and-latency-bound epilogue decides how soon
+// it multiplies again (MI355X_MICROARCH.md, "Two waves per SIMD", items 2 and 4).  -DMKGNN_STREAM_PRIO=<0|1|2>: A/B builds.
+#ifndef MKGNN_STREAM_PRIO
+#define MKGNN_STREAM_PRIO 1
+#endif
+__device__ __forceinline__ void prio_multiply() {
+    if constexpr (MKGNN_STREAM_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+    else if constexpr (MKGNN_STREAM_PRIO == 2) __builtin_amdgcn_s_setprio(2);
+}
+__device__ __forceinline__ void prio_other() {
+    if constexpr (MKGNN_STREAM_PRIO == 1) __builtin_amdgcn_s_setprio(2);
+    else if constexpr (MKGNN_STREAM_PRIO == 2) __builtin_amdgcn_s_setprio(0);
+}
+
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N <= 63, "s_waitcnt vmcnt is a 6-bit field");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -107,9 +135,17 @@ template <int D, int KC> constexpr int batch_size(int sd, int role) {
     using T = StreamTraits<D>;
     int n = pieces_of<KC, T::NS>(role);
     if (role == 0) {
-        if (sd < D) n += 2;                              // bond attributes of the slot
+        if (sd < D) n += 1;                              // unit bond rows of the slot
         if (sd == 0) n += 2 * (T::S1 == 5 ? 2 : 1) + (D == 4 ? 2 : 0);     // following tile's ids, this tile's 1/|x|, flags
     }
+    return n;
+}
+
+// vector-memory operations of the RING - 2 batches issued at the ends of steps k-1 .. k-(RING-2), k being a step with slot s
+template <int D, int KC> constexpr int young_batches(int s, int role) {
+    using T = StreamTraits<D>;
+    int n = 0;
+    for (int j = 1; j <= T::RING - 2; ++j) n += batch_size<D, KC>((s + 64 * T::S1 - j + T::RING) % T::S1, role);
     return n;
 }
 
@@ -125,6 +161,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
     constexpr int NB = NBS + 1;                          // bank slots in registers: the supports + the centre (HS: half 0 only)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned long long t_start = a.stamps ? __builtin_readcyclecounter() : 0ull;
     const int stream = wave / NS, role = wave % NS;
     const int half = HS ? (role & 1) : 0;                // supports 2 * half, 2 * half + 1
     const int ct = HS ? cp * 2 + (role >> 1) : role;     // this wave's column tile (the degree has exactly NS: host-checked)
@@ -186,33 +223,30 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
     const int F = a.F, E = a.E;
 
     uint32_t idsD[S1];                                   // atom ids (of atom ci, every slot) of the tile the DMA pointer is in
-    // source of DMA piece t of a row: chunk 4 t + kq; a chunk entirely beyond the row's width is fetched from the
-    // row's first chunk instead (in bounds, finite whenever the row is) and masked to zero where it is used
-    auto row_src = [&](uint32_t id, int t) -> const float* {
-        const int col = 16 * t + 4 * kq;
-        const uint32_t off = (t == KC - 1 && col >= F) ? 0u : (uint32_t)col;
-        return a.x + ((size_t)id * xs + off);
-    };
     auto issue_rows = [&](auto sdc, float* buf) {        // this wave's pieces of slot sd of the DMA tile
         constexpr int sd = decltype(sdc)::value;
-        static_for<0, KC>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            static_for<0, NS>([&](auto rc) {
-                if constexpr (t % NS == decltype(rc)::value) {
-                    if (role == decltype(rc)::value) dma16(row_src(idsD[sd], t), buf + t * 256);
-                }
-            });
+        const uint32_t rowbase = idsD[sd] * xs + 4u * kq;     // 32-bit element offset (the host checks n_atoms * stride < 2^30)
+        static_for<0, NS>([&](auto rc) {                 // one wave-uniform branch per step, the role's pieces inside
+            constexpr int r = decltype(rc)::value;
+            if (role == r) {
+                static_for<0, KC>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    if constexpr (t % NS == r) {
+                        // a chunk entirely beyond the row's width is fetched from the row's first chunk instead (in
+                        // bounds, finite whenever the row is) and masked to zero where it is used
+                        const uint32_t off = (t == KC - 1 && 16 * t + 4 * kq >= F) ? idsD[sd] * xs : rowbase + 16u * t;
+                        dma16(a.x + off, buf + t * 256);
+                    }
+                });
+            }
         });
     };
-    // bond attributes of slot sd: two 64-dword pieces, [atom 0..7 | 8..15][8 components] (component 7 duplicates the
-    // last real one: masked where it is used)
+    // unit bond rows of slot sd (mkgnn_degree_bucket.nei_edge_unit, [N_d, d, 8]): 16 atoms x 32 bytes = half a DMA piece
     auto issue_bonds = [&](int64_t t, int sd, float* mrec) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            int64_t n = t * 16 + h * 8 + (lane >> 3);
+        if (lane < 32) {
+            int64_t n = t * 16 + (lane >> 1);
             if (n >= dg.n) n = dg.n - 1;
-            const int comp = (lane & 7) < E ? (lane & 7) : E - 1;
-            dma4(dg.e_nei + (n * D + sd) * E + comp, mrec + T::OFF_BOND + sd * 128 + h * 64);
+            dma16(dg.e_unit + ((uint32_t)(n * D + sd) * 8u + 4u * (lane & 1)), mrec + T::OFF_BOND + sd * 128);
         }
     };
     // lane q -> (slot q >> 4, atom q & 15): slots 0..3 in one 64-dword piece, slot 4 (degree 4's focal row) in a second
@@ -265,6 +299,9 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
     __builtin_amdgcn_s_barrier();
 
     int buf = 0;                                         // ring buffer of the current step
+#ifdef MKGNN_FWD_STAMPS
+    unsigned long long phase[5] = {0, 0, 0, 0, 0}, t_phase = __builtin_readcyclecounter();
+#endif
     for (int64_t it = 0; it < iters; ++it) {
         const int64_t tile = tile_at(it);
         const bool real = tile_first + it < tile_end;    // else: a repeat of the last tile, results discarded
@@ -279,6 +316,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
             constexpr int s = decltype(sc)::value;
             // ---- multiply slot s: one LDS read per 4 NBS (or 4) matrix instructions, issued one chunk ahead
             const float* rb = ring + buf * SLOT + lane * 4;
+            prio_multiply();
             if (s < D || !HS || half == 0) {             // (HS: the centre belongs to half 0)
                 f32x4 nxt = *(const f32x4*)rb;
 #pragma unroll
@@ -307,17 +345,22 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
                     __builtin_amdgcn_sched_group_barrier(0x008, s < D ? 4 * NBS : 4, 0);
                 }
             }
-            // ---- retire: only the youngest batch (issued at the end of the previous step, DMA slot sdp) may stay in
-            // flight, so the batch of the NEXT step has landed.  (A 2-buffer ring has just one batch in flight.)
+            prio_other();
+            MKGNN_PHASE(0);
+            // ---- retire: the batch of the NEXT step must have landed; the RING - 2 batches issued after it may stay in
+            // flight (vmcnt retires in order).  (A 2-buffer ring has just one batch in flight.)
             if constexpr (RING == 2) {
                 wait_vmcnt<0>();
             } else {
-                constexpr int sdp = (s + S1 - 1 + RING) % S1;
                 static_for<0, NS>([&](auto rc) {
-                    if (role == decltype(rc)::value) wait_vmcnt<batch_size<D, KC>(sdp, decltype(rc)::value)>();
+                    constexpr int r = decltype(rc)::value;
+                    constexpr int n_young = young_batches<D, KC>(s, r);
+                    if (role == r) wait_vmcnt<n_young>();
                 });
             }
+            MKGNN_PHASE(1);
             if constexpr (NS > 1) __builtin_amdgcn_s_barrier();
+            MKGNN_PHASE(2);
             // ---- issue the batch of step k + RING into the buffer just read
             constexpr int sd = (s + RING) % S1;
             const int64_t itd = it + (s + RING) / S1;    // iteration (tile) the DMA pointer is in
@@ -335,6 +378,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
                 }
             }
             buf = (buf + 1 == RING) ? 0 : buf + 1;
+            MKGNN_PHASE(3);
         });
 
         // ---- epilogue: lane = kernel lcol, atoms kq * 4 + jj (the arithmetic of kc_forward_fused).  One atom at a
@@ -369,46 +413,53 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
         }
         int idx4[NJ];
         float best4[NJ], cen4[NJ];
+        [[maybe_unused]] f32x4 inv4[S1];
+        if constexpr (!HS) {
+#pragma unroll
+            for (int s = 0; s < S1; ++s) inv4[s] = *(const f32x4*)(mrec + T::OFF_INV + s * 16 + kq * 4);
+        }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             float m[D][D];
             const int jj = HS ? 2 * half + j : j;        // atom of the lane (run-time only under HS: selects, never an index)
 #pragma unroll
             for (int s = 0; s < D; ++s) {
-                const float iv = mrec[T::OFF_INV + s * 16 + kq * 4 + jj];
                 if constexpr (HS) {
+                    const float iv = mrec[T::OFF_INV + s * 16 + kq * 4 + jj];
                     const float own0 = half ? cm[s][0][2 + j] : cm[s][0][j], own1 = half ? cm[s][1][2 + j] : cm[s][1][j];
                     m[s][0] = (half ? px[j][s][0] : own0) * iv;
                     m[s][1] = (half ? px[j][s][1] : own1) * iv;
                     m[s][2] = (half ? own0 : px[j][s][0]) * iv;
                     m[s][3] = (half ? own1 : px[j][s][1]) * iv;
                 } else {
+                    const float iv = inv4[s][j];
 #pragma unroll
                     for (int b = 0; b < D; ++b) m[s][b] = cm[s][b][j] * iv;
                 }
             }
             best_permutation<D>(m, best4[j], idx4[j]);
-            float c;
-            if constexpr (HS) c = half ? pcc[j] : cc[j];
-            else c = cc[j];
-            cen4[j] = c * mrec[T::OFF_INV + D * 16 + kq * 4 + jj];
-            if constexpr (D >= 3) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (HS) cen4[j] = (half ? pcc[j] : cc[j]) * mrec[T::OFF_INV + D * 16 + kq * 4 + jj];
+            else cen4[j] = cc[j] * inv4[D][j];
         }
         uint32_t signw = 0, eqw = 0;
         if constexpr (D == 4) {
             signw = __float_as_uint(mrec[T::OFF_SIGN + kq]);
             eqw = __float_as_uint(mrec[T::OFF_EQ + kq]);
         }
-        float2 eu[D];                                    // unit bond components 2 kq, 2 kq + 1 of (atom ci, slot s)
-#pragma unroll
-        for (int s = 0; s < D; ++s) {
-            const float2 raw = *(const float2*)(mrec + T::OFF_BOND + s * 128 + ci * 8 + 2 * kq);
-            const float ex = 2 * kq < E ? raw.x : 0.f, ey = 2 * kq + 1 < E ? raw.y : 0.f;
-            float s2 = fmaf(ey, ey, ex * ex);
-            s2 += __shfl_xor(s2, 16, 64);
-            s2 += __shfl_xor(s2, 32, 64);
-            const float ie = 1.f / fmaxf(sqrtf(s2), MKGNN_EPS);
-            eu[s] = float2{ex * ie, ey * ie};
+        // unit bond components 2 kq, 2 kq + 1 of (atom ci, slot s).  Read behind the compiler's back: it cannot know that
+        // the counted waits above have retired the DMA that wrote them and would drain the whole DMA queue (vmcnt(0))
+        // in front of an ordinary LDS read of this part of the record
+        float2 eu[D];
+        {
+            const uint32_t ea = (uint32_t)(uintptr_t)(mrec + T::OFF_BOND + ci * 8 + 2 * kq);      // LDS byte address
+            asm volatile("ds_read_b64 %0, %1" : "=v"(eu[0]) : "v"(ea) : "memory");
+            if constexpr (D > 1) asm volatile("ds_read_b64 %0, %1 offset:512" : "=v"(eu[D > 1 ? 1 : 0]) : "v"(ea) : "memory");
+            if constexpr (D > 2) asm volatile("ds_read_b64 %0, %1 offset:1024" : "=v"(eu[D > 2 ? 2 : 0]) : "v"(ea) : "memory");
+            if constexpr (D > 3) asm volatile("ds_read_b64 %0, %1 offset:1536" : "=v"(eu[D > 3 ? 3 : 0]) : "v"(ea) : "memory");
+            if constexpr (D == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(eu[0]) : : "memory");
+            else if constexpr (D == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(eu[0]), "+v"(eu[D > 1 ? 1 : 0]) : : "memory");
+            else if constexpr (D == 3) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(eu[0]), "+v"(eu[D > 1 ? 1 : 0]), "+v"(eu[D > 2 ? 2 : 0]) : : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(eu[0]), "+v"(eu[D > 1 ? 1 : 0]), "+v"(eu[D > 2 ? 2 : 0]), "+v"(eu[D > 3 ? 3 : 0]) : : "memory");
         }
         // bond-cosine matrices, one (a, b) tile at a time; keep the entry the chosen order uses
         float ed4[NJ][D];
@@ -456,7 +507,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
             if constexpr (HS) focal = __float_as_uint(half ? focal4[2 + j] : focal4[j]);
             else focal = __float_as_uint(focal4[j]);
             if (real && col_ok && n < dg.n) {
-                a.out[(size_t)focal * a.os + dg.off + lcol] = sc;
+                a.out[focal * (uint32_t)a.os + (uint32_t)(dg.off + lcol)] = sc;     // (the host checks n_atoms * stride < 2^30)
                 const uint32_t o = (uint32_t)n * (uint32_t)L + (uint32_t)lcol;   // the host fuses a degree only if 3 * N_d * L < 2^32
                 if (dg.best) dg.best[o] = (uint8_t)idx4[j];
                 if (dg.scores) {
@@ -468,8 +519,16 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
                 if (dg.chir_out) dg.chir_out[o] = (int8_t)ch;
             }
         }
+        MKGNN_PHASE(4);
     }
     wait_vmcnt<0>();                                     // no DMA may land in this block's LDS after it is gone
+    if (a.stamps && lane == 0) {
+        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 16;
+        o[0] = t_start; o[1] = __builtin_readcyclecounter(); o[2] = (unsigned long long)(D * 16 + cp); o[3] = (unsigned long long)iters;
+#ifdef MKGNN_FWD_STAMPS
+        for (int i = 0; i < 5; ++i) o[4 + i] = phase[i];
+#endif
+    }
 }
 
 template <int KC>
@@ -489,12 +548,39 @@ __global__ void __launch_bounds__(256, 2) kc_forward_stream(FusedFwdArgs a) {
 }
 
 // ---------------------------------------------------------------- host ----
-bool stream_forward_supported(int d, int F, int E, int L) {
-    if (d < 1 || d > 4 || L < 1 || E < 1 || E > 8) return false;
+bool stream_forward_supported(int d, int F, int E, int L, int64_t n_atoms, int64_t x_stride, int64_t out_stride, const float* e_unit) {
+    if (d < 1 || d > 4 || L < 1 || E < 1 || E > 8 || !e_unit) return false;
     const int FP = mfma_padded_width(F);
     if (!FP || F <= FP - 16) return false;               // only the last 16-float chunk of a row may be partial
     if (d == 4 && L * 12 > 768) return false;            // the chirality sign table's LDS slot
+    // 32-bit element offsets into x, out and the unit bond rows
+    if ((uint64_t)n_atoms * (uint64_t)x_stride >= (1ull << 30) || (uint64_t)n_atoms * (uint64_t)out_stride >= (1ull << 30) ||
+        (uint64_t)n_atoms * 32ull >= (1ull << 30))
+        return false;
     return (L + 15) / 16 == stream_column_tiles(d);
+}
+
+__global__ void unit_rows8_kernel(const float* __restrict__ in, int64_t n, int E, float* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    float e[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e[k] = k < E ? in[r * E + k] : 0.f;
+    // the summation order of the forward kernels' in-register form: pairs (2k, 2k+1), then (p0 + p1) + (p2 + p3)
+    float p[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p[k] = fmaf(e[2 * k + 1], e[2 * k + 1], e[2 * k] * e[2 * k]);
+    const float s2 = __fadd_rn(__fadd_rn(p[0], p[1]), __fadd_rn(p[2], p[3]));
+    const float ie = 1.f / fmaxf(sqrtf(s2), MKGNN_EPS);
+    f32x4 lo = {e[0] * ie, e[1] * ie, e[2] * ie, e[3] * ie}, hi = {e[4] * ie, e[5] * ie, e[6] * ie, e[7] * ie};
+    *(f32x4*)(out + r * 8) = lo;
+    *(f32x4*)(out + r * 8 + 4) = hi;
+}
+
+hipError_t launch_unit_rows8(const float* in, int64_t n_rows, int E, float* out, hipStream_t st) {
+    if (n_rows == 0) return hipSuccess;
+    unit_rows8_kernel<<<(unsigned)((n_rows + 255) / 256), 256, 0, st>>>(in, n_rows, E, out);
+    return hipGetLastError();
 }
 
 // Block table of the streamed launch: one group per degree, block counts by greedy min-max over
@@ -503,7 +589,7 @@ bool stream_forward_supported(int d, int F, int E, int L) {
 // of tiles (the buckets are sorted by atom id: what one group gathers as neighbours another gathers as focal rows).
 static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nblocks_out) {
     constexpr int MG = 8;                               // groups: degrees 1-3 one each, degree 4 two (its column parts)
-    double cost[MG], bytes_per_tile[MG];
+    double cost[MG];
     int64_t tiles_of[MG], cap[MG];
     int nstream_of[MG], ng = 0;
     size_t lds_floats = 0;
@@ -519,11 +605,20 @@ static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nbloc
         const size_t fl = (size_t)stream_lds_floats(d, KC);
         if (fl > lds_floats) lds_floats = fl;
         for (int cp = 0; cp < g.cs; ++cp) {
-            // matrix instructions of the busiest wave per tile + a term for the epilogue (unit: one instruction's 32 cycles)
-            const int nbs = (d == 4) ? 2 : d;
-            cost[ng] = (d * nbs + 1) * 4.0 * KC + 2.0 * d * d + (d == 4 ? 45.0 : d == 3 ? 40.0 : 25.0);
-            // the rows a tile gathers: a stream cannot run faster than its share of the CU's gather rate delivers them
-            bytes_per_tile[ng] = (double)(d + 1) * 16 * 64 * KC;
+            // what a wave takes per tile, everything included (multiply, DMA issue, waits, epilogue), in units of 32
+            // cycles -- measured with tools/stream_stamps.py at two waves per SIMD and all groups resident (F = 110, batch
+            // 4096: 10.2 k / 15.2 k / 27.3 k / 33.8 k cycles for degree 1..4), scaled with the chunk count for F <= 32
+            static double calib7[4] = {319.0, 475.0, 853.0, 1056.0}, calib2[4] = {200.0, 260.0, 420.0, 560.0};
+            static const bool env_read = [] {            // diagnostics: MKGNN_STREAM_COST="c1,c2,c3,c4" (applies to both widths)
+                if (const char* e = getenv("MKGNN_STREAM_COST")) {
+                    double v[4];
+                    if (sscanf(e, "%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3]) == 4)
+                        for (int k = 0; k < 4; ++k) calib7[k] = calib2[k] = v[k];
+                }
+                return true;
+            }();
+            (void)env_read;
+            cost[ng] = KC == 7 ? calib7[i] : calib2[i];
             tiles_of[ng] = ntiles;
             cap[ng] = (ntiles + nstream - 1) / nstream;
             nstream_of[ng] = nstream;
@@ -534,14 +629,9 @@ static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nbloc
     }
     if (ng == 0) { *nblocks_out = 0; return 0; }
     const double prologue = 60.0;
-    // ~16 GB/s of gathered rows per block (half a CU's ~33 GB/s from the Infinity Cache, MI355X_MICROARCH.md "Indexed
-    // rows"), in bytes per unit of 32 cycles at ~2.1 GHz
-    const double block_bytes_per_unit = 16e9 * 32.0 / 2.1e9;
     auto finish = [&](int g, int blocks) {
         const int64_t streams = (int64_t)blocks * nstream_of[g];
-        const double per_tile = cost[g] > bytes_per_tile[g] * nstream_of[g] / block_bytes_per_unit
-                                    ? cost[g] : bytes_per_tile[g] * nstream_of[g] / block_bytes_per_unit;
-        return prologue + (double)((tiles_of[g] + streams - 1) / streams) * per_tile;
+        return prologue + (double)((tiles_of[g] + streams - 1) / streams) * cost[g];
     };
     int count[MG], nb = 0;
     for (int g = 0; g < ng; ++g) { count[g] = 1; ++nb; }
@@ -583,11 +673,25 @@ static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nbloc
     return lds_floats * 4;
 }
 
+static unsigned long long* g_stream_stamps = nullptr;
+extern "C" int mkgnn_debug_set_stream_stamps(void* device_ptr) { g_stream_stamps = (unsigned long long*)device_ptr; return 0; }
+
 hipError_t launch_forward_stream(FusedFwdArgs& a, const bool use[4], hipStream_t st) {
     const int KC = mfma_padded_width(a.F) / 16;
+    a.stamps = g_stream_stamps;
     int nb = 0;
     const size_t lds_bytes = plan_stream(a, use, KC, &nb);
     if (nb == 0) return hipSuccess;
+    if (lds_bytes > 64 * 1024) {                         // (two such blocks still fit a CU's 160 KB)
+        static PerDeviceOnce attr_set[2];
+        const int which = KC == 2 ? 0 : 1;
+        if (const int slot = attr_set[which].pending(); slot >= 0) {
+            hipError_t e = KC == 2 ? hipFuncSetAttribute((const void*)kc_forward_stream<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
+                                   : hipFuncSetAttribute((const void*)kc_forward_stream<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            if (e != hipSuccess) return e;
+            attr_set[which].set(slot);
+        }
+    }
     if (KC == 2) kc_forward_stream<2><<<nb, 256, lds_bytes, st>>>(a);
     else kc_forward_stream<7><<<nb, 256, lds_bytes, st>>>(a);
     return hipGetLastError();

@@ -38,7 +38,7 @@ constexpr int FUSED_MAX_BLOCKS = 512;       // 2 blocks per CU
 constexpr int FUSED_MAX_GROUPS = 16;        // (degree, column part)
 
 struct FusedDeg {
-    const int64_t* sel; const int64_t* nei; const float* e_nei; const float* p_focal; const float* p_nei;
+    const int64_t* sel; const int64_t* nei; const float* e_nei; const float* e_unit; const float* p_focal; const float* p_nei;
     const float* padded; const float* edge_padded; const int8_t* chir; const float* mix; const int8_t* eqflag; const int8_t* signflag;
     uint8_t* best; float* scores; int8_t* chir_out;
     int64_t n;
@@ -54,6 +54,7 @@ struct FusedFwdArgs {
     const float* x; int64_t xs; const float* inv;
     float* out; int64_t os;
     int K, F, E, last;
+    int64_t n_atoms;
     int bf16;                                // node-feature dot products with bf16 operands (variant 3)
     FusedDeg deg[MKGNN_MAX_DEGREE];
     uint8_t grp_degree[FUSED_MAX_GROUPS];   // group -> degree index (0..3)
@@ -61,6 +62,7 @@ struct FusedFwdArgs {
     uint16_t grp_count[FUSED_MAX_GROUPS];   // blocks in the group
     uint8_t blk_group[FUSED_MAX_BLOCKS];    // block -> group
     uint16_t blk_rank[FUSED_MAX_BLOCKS];    // block -> rank inside its group
+    unsigned long long* stamps;             // diagnostics (tools/stream_stamps.py): per wave {start, end, group, iterations}; usually null
 };
 
 struct BwdArgs {
@@ -94,8 +96,9 @@ bool mfma_forward_supported(int d, int F, int E, int L);
 int fused_group_count(int d, int F, int L);      // groups of the fused launch this degree needs (budget: FUSED_MAX_GROUPS)
 hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t st);
 // kgnn_fwd_stream.hip: bank in registers, atom rows streamed through LDS by DMA (the reference's shapes)
-bool stream_forward_supported(int d, int F, int E, int L);
+bool stream_forward_supported(int d, int F, int E, int L, int64_t n_atoms, int64_t x_stride, int64_t out_stride, const float* e_unit);
 hipError_t launch_forward_stream(FusedFwdArgs& a, const bool use[4], hipStream_t st);
+hipError_t launch_unit_rows8(const float* in, int64_t n_rows, int E, float* out, hipStream_t st);
 hipError_t launch_backward_generic(int d, const BwdArgs& a, hipStream_t st);
 struct BankReduceAllArgs { BankReduceArgs deg[4]; int blk_start[4]; };
 hipError_t launch_bank_reduce_all(const BankReduceArgs r[4], hipStream_t st);   // degrees with L == 0 are skipped

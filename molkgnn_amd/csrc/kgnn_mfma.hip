@@ -704,7 +704,7 @@ hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t 
     bool use_stream[4], use_bank[4];
     bool any_bank = false;
     for (int i = 0; i < 4; ++i) {
-        use_stream[i] = use[i] && stream_on && stream_forward_supported(i + 1, a.F, a.E, a.deg[i].L);
+        use_stream[i] = use[i] && stream_on && stream_forward_supported(i + 1, a.F, a.E, a.deg[i].L, a.n_atoms, a.xs, a.os, a.deg[i].e_unit);
         use_bank[i] = use[i] && !use_stream[i];
         any_bank = any_bank || use_bank[i];
     }

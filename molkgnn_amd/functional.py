@@ -89,6 +89,7 @@ def _buckets(plan: BatchPlan, E: int, need_p: bool):
                 raise ValueError(f"nei_edge_attr_deg{b.degree} has {b.e_nei.numel()} values, expected "
                                  f"{b.count}x{b.degree}x{E}")
             k.selected_index, k.nei_index, k.nei_edge_attr = b.sel.data_ptr(), b.nei.data_ptr(), b.e_nei.data_ptr()
+            k.nei_edge_unit = _lib.ptr(b.e_unit(E))
             if need_p and b.degree == 4:
                 if b.p_focal is None or b.p_focal.shape[-1] != 3:
                     raise ValueError("chirality (degree 4, last layer) needs 3-D coordinates")

@@ -30,7 +30,7 @@ def _as_f32(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 
 class Bucket:
-    __slots__ = ("degree", "count", "sel", "nei", "e_nei", "p_focal", "nei_p")
+    __slots__ = ("degree", "count", "sel", "nei", "e_nei", "p_focal", "nei_p", "_e_unit")
 
     def __init__(self, degree, sel, nei, e_nei, p_focal, nei_p):
         self.degree = degree
@@ -42,6 +42,21 @@ class Bucket:
         self.e_nei = _as_f32(e_nei)
         self.p_focal = _as_f32(p_focal)
         self.nei_p = _as_f32(nei_p)
+        self._e_unit = None
+
+    def e_unit(self, E: int):
+        """``[N_d * d, 8]`` unit-normalised bond attributes (``mkgnn_unit_rows8``), built once per batch: the bonds of a
+        batch are the same in every layer and every step.  ``None`` when not applicable (CPU tensors, E > 8)."""
+        if self._e_unit is None and self.count and self.e_nei is not None and self.e_nei.is_cuda and 1 <= E <= 8 \
+                and self.e_nei.numel() == self.count * self.degree * E:
+            from . import _lib
+            rows = self.count * self.degree
+            out = torch.empty((rows, 8), dtype=torch.float32, device=self.e_nei.device)
+            with torch.cuda.device(out.device):
+                _lib.check(_lib.load().mkgnn_unit_rows8(self.e_nei.data_ptr(), rows, E, out.data_ptr(),
+                                                        _lib.stream_ptr(out.device)), "mkgnn_unit_rows8")
+            self._e_unit = out
+        return self._e_unit
 
 
 class BatchPlan:
@@ -175,6 +190,9 @@ def plan_from_lists_cached(n_atoms, p_focal_list, nei_p_list, nei_edge_attr_list
     _ = plan.scatter
     if edge_index is not None:
         _ = plan.csr_in, plan.csr_out, plan.csr_in_packed
+    for b in plan.buckets:
+        if b.count and b.e_nei is not None and b.e_nei.is_cuda:
+            b.e_unit(b.e_nei.numel() // (b.count * b.degree))
     if len(_PLAN_CACHE) >= _PLAN_CACHE_MAX:
         _PLAN_CACHE.pop(next(iter(_PLAN_CACHE)))
     _PLAN_CACHE[key] = (plan, [weakref.ref(t) for t in tensors])

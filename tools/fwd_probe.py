@@ -38,3 +38,17 @@ for _ in range(args.reps):
         Fn.kernelsetconv_details(x, plan, args.last, params, E, args.variant)
 torch.cuda.synchronize()
 print("done", b.x.shape[0], "atoms", [bk.count for bk in plan.buckets])
+if not args.backward and args.variant != "generic":
+    # the fused forward launch alone: HIP events recorded around it on its own stream (several rounds, sorted)
+    import ctypes
+    from molkgnn_amd import _lib
+    lib = _lib.load()
+    lib.mkgnn_debug_last_fused_forward_ms.restype = ctypes.c_float
+    lib.mkgnn_debug_time_fused_forward(1)
+    ms = []
+    for _ in range(max(args.reps, 10)):
+        Fn.kernelsetconv_details(x, plan, args.last, params, E, args.variant)
+        ms.append(float(lib.mkgnn_debug_last_fused_forward_ms()))
+    lib.mkgnn_debug_time_fused_forward(0)
+    ms.sort()
+    print("fused forward launch us: min %.1f median %.1f max %.1f" % (1e3 * ms[0], 1e3 * ms[len(ms) // 2], 1e3 * ms[-1]))
