@@ -1,0 +1,613 @@
+// Streamed MFMA bank-gradient kernel of the kernel convolution (gfx950): the gradient with respect to the
+// unit-normalised kernel rows (autograd of reference kernels.py:353-425 towards x_center / x_support /
+// edge_attr_support), all four degree buckets in ONE launch, on the matrix pipe.
+//
+//   g_unit[l, b, :] = sum_n coef[n, l] * [pi_{n,l}(a) = b] * xhat[nei(n, a), :]          (supports; a = neighbour slot)
+//   g_unit[l, c, :] = sum_n coefc[n, l] * xhat[n, :]                                      (centres)
+//   g_edge[l, b, :] = sum_n coefe[n, l] * [pi_{n,l}(a) = b] * ehat[n, a, :]               (bond supports)
+//
+// Per 16-atom tile and 16-kernel column tile this is P_ab^T [kernels x atoms] . X_a [atoms x F]: the transpose of the
+// forward's product with the 0/1-masked coefficient tile as the A operand.  It runs on the forward's streaming skeleton
+// (kgnn_fwd_stream.hip): a wave owns a column tile and keeps ITS accumulators -- the gradient rows of its kernels, 28
+// VGPRs per bank slot -- in registers for the whole launch; the gathered atom rows stream through an LDS ring filled by
+// LDS-DMA (here in plain row-major order: a DMA piece is 64 consecutive 16-byte chunks of the 16 x 448-byte slot image,
+// whole rows in full cache lines, and the B-operand reads -- one float per lane, atom k, feature j -- are conflict-free
+// in that layout); counted vmcnt waits and raw barriers as in the forward.  There is no per-tile epilogue: a wave writes
+// its accumulators once, at the end, as its slice of a partial slab, and kc_backward_bank_reduce sums the slabs in a
+// fixed order (bit-reproducible; no float atomics).
+//
+// The per-(atom, kernel) inputs -- dL/dsc through the focal ids, the chosen permutation, the chirality sign -- are put
+// into tile order by a small pre-pass (coef_prepare_kernel: one 1 KB + 1 KB record per (atom tile, column tile), so the
+// main kernel fetches them with two DMA pieces per tile); the pre-pass also sums the three score-weight partials
+// d sc / d theta_k = w_k (score_k - sc) / W, which need every pair's three scores exactly once.
+//
+// Degree 4 splits a column tile's supports over two waves like the forward (its accumulators would not fit otherwise);
+// covered shapes are the forward's (stream_forward_supported).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+
+#include "kgnn_launch.h"
+
+namespace mkgnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace bs {
+
+template <int I> using IC = std::integral_constant<int, I>;
+template <int B, int E, typename Fn> __device__ __forceinline__ void static_for(Fn&& fn) {
+    if constexpr (B < E) { fn(IC<B>{}); static_for<B + 1, E>(fn); }
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "s_waitcnt vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void dma16(const void* src, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__device__ __forceinline__ void dma4(const void* src, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+}
+// an LDS dword written by DMA, read behind the compiler's back (it would drain the DMA queue in front of an ordinary
+// read that may alias a pending DMA); valid after lds_fence over the same registers
+__device__ __forceinline__ float lds_read_raw(uint32_t byte_addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(byte_addr) : "memory");
+    return v;
+}
+// ... with a compile-time byte offset in the instruction (one address register for a whole family of reads)
+template <int OFF> __device__ __forceinline__ float lds_read_raw_at(uint32_t byte_addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(byte_addr), "n"(OFF) : "memory");
+    return v;
+}
+
+template <typename V> __device__ __forceinline__ void lds_fence(V& v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) : : "memory"); }
+
+template <int D, int A> __device__ __forceinline__ int perm_entry(int p) {
+    if constexpr (D == 1) return 0;
+    else {
+        constexpr uint32_t packed = [] {
+            uint32_t v = 0;
+            for (int q = 0; q < PermC<D>::P; ++q) v |= (uint32_t)PermC<D>::t[q][A] << (2 * q);
+            return v;
+        }();
+        return (int)((packed >> (2 * p)) & 3u);
+    }
+}
+
+template <int D> struct Traits {
+    static constexpr int NS = (D == 1) ? 1 : (D == 4 ? 4 : 2);     // waves sharing an atom tile
+    static constexpr int NSTREAM = 4 / NS;
+    static constexpr int RING = (D == 1) ? 2 : (D == 2 ? 3 : (D == 3 ? 4 : 5));   // = the forward's (<= S1)
+    static constexpr int S1 = D + 1;
+    // per-tile record (floats): ids[S1][16] | inv[S1][16] | bond[D][16][8]
+    static constexpr int OFF_INV = 16 * S1, OFF_BOND = 32 * S1, META = OFF_BOND + 128 * D;
+    static constexpr int COEF = 512;                               // per wave and tile: g[16][16] floats | idx[16][16] ints
+};
+
+__host__ __device__ constexpr int lds_floats(int D, int KC) {
+    const int NS = (D == 1) ? 1 : (D == 4 ? 4 : 2);
+    const int RING = (D == 1) ? 2 : (D == 2 ? 3 : (D == 3 ? 4 : 5));
+    const int META = 32 * (D + 1) + 128 * D;
+    const int FPC = KC == 7 ? 28 : 8;
+    return (4 / NS) * (RING * 16 * FPC * 4 + 2 * META) + 4 * 512;
+}
+
+template <int KC, int NS> constexpr int pieces_of(int role) { return (KC - role + NS - 1) / NS; }
+
+// vector-memory operations wave `role` issues in the DMA phase whose slot is `sd`
+template <int D, int KC> constexpr int batch_size(int sd, int role) {
+    using T = Traits<D>;
+    int n = pieces_of<KC, T::NS>(role);
+    if (sd == 0) n += 2;                                 // this wave's coefficient record of the tile (g, idx)
+    if (role == 0) {
+        if (sd < D) n += 1;                              // unit bond rows of the slot
+        if (sd == 0) n += 2 * (T::S1 == 5 ? 2 : 1);      // following tile's ids, this tile's 1/|x|
+    }
+    return n;
+}
+template <int D, int KC> constexpr int young_batches(int s, int role) {
+    using T = Traits<D>;
+    int n = 0;
+    for (int j = 1; j <= T::RING - 2; ++j) n += batch_size<D, KC>((s + 64 * T::S1 - j + T::RING) % T::S1, role);
+    return n;
+}
+
+}  // namespace bs
+
+struct BankStreamDeg {
+    const int64_t* sel; const int64_t* nei; const float* e_unit;
+    const uint8_t* best; const float* scores; const int8_t* chir;
+    const float* mix;
+    float* coefq;            // [ntiles][nct][512]: g tile, idx tile
+    float* slab;             // [chunks][bank_floats]
+    float* theta_slab;       // [prepare blocks][4]
+    int64_t n;
+    int L, off, nct, kpt, cs;
+    int prep_blk0, prep_blocks;      // this degree's blocks of the pre-pass
+};
+
+struct BankStreamArgs {
+    const float* x; int64_t xs; const float* inv;
+    const float* gout; int64_t gs;
+    int F, E;
+    BankStreamDeg deg[MKGNN_MAX_DEGREE];
+    uint8_t grp_degree[8];
+    uint8_t grp_cp[8];
+    uint16_t grp_count[8];
+    uint8_t blk_group[FUSED_MAX_BLOCKS];
+    uint16_t blk_rank[FUSED_MAX_BLOCKS];
+};
+
+// ------------------------------------------------------------- pre-pass ---
+// One thread per (atom of a tile, column of a column tile): the pair's dL/dsc (times the chirality sign) and
+// permutation id into tile order, zeros for padding; the three score-weight partials summed per block in a fixed order.
+__global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
+    int di = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) if (a.deg[k].prep_blocks > 0 && (int)blockIdx.x >= a.deg[k].prep_blk0) di = k;
+    const BankStreamDeg& g = a.deg[di];
+    const int tid = threadIdx.x;
+    const int64_t rec = (int64_t)blockIdx.x - g.prep_blk0;          // (tile, column tile) record
+    const int64_t tile = rec / g.nct;
+    const int ct = (int)(rec - tile * g.nct);
+    const int atom = tid >> 4, k = tid & 15;
+    const int64_t n = tile * 16 + atom;
+    const int l = ct * g.kpt + k;
+    const bool ok = n < g.n && k < g.kpt && l < g.L;
+    float gv = 0.f;
+    int idx = 0;
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    if (ok) {
+        const int64_t focal = g.sel[n];
+        const size_t o = (size_t)n * g.L + l, ln = (size_t)g.L * g.n;
+        gv = a.gout[focal * a.gs + g.off + l];
+        if (g.chir) gv *= (float)g.chir[o];
+        idx = g.best[o];
+        const float w_s = g.mix[0], w_c = g.mix[1], w_e = g.mix[2], w_sum = g.mix[3];
+        const float S = g.scores[o], C = g.scores[ln + o], Ed = g.scores[2 * ln + o];
+        const float sc = (S * w_s + C * w_c + Ed * w_e) / w_sum;
+        p0 = gv * (w_s / w_sum) * (S - sc);
+        p1 = gv * (w_c / w_sum) * (C - sc);
+        p2 = gv * (w_e / w_sum) * (Ed - sc);
+    }
+    float* out = g.coefq + (size_t)rec * 512;
+    out[tid] = gv;
+    ((int*)out)[256 + tid] = idx;
+    // fixed-order block sums
+    __shared__ float red[3][4];
+    p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = p0; red[1][tid >> 6] = p1; red[2][tid >> 6] = p2; }
+    __syncthreads();
+    if (tid < 3) g.theta_slab[(size_t)rec * 4 + tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
+}
+
+// ------------------------------------------------------------ main body ---
+template <int D, int KC>
+__device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const BankStreamDeg& dg, const int cp, const int rank,
+                                                 const int count, float* lds) {
+    using namespace bs;
+    using T = Traits<D>;
+    constexpr int NS = T::NS, NSTREAM = T::NSTREAM, RING = T::RING, S1 = T::S1, META = T::META;
+    constexpr int FPC = KC == 7 ? 28 : 8;                // 16-byte chunks per row in the slot image
+    constexpr int RF = 4 * FPC;                          // floats per row (112 / 32)
+    constexpr int SLOT = 16 * RF;                        // floats per slot image
+    constexpr int NP = SLOT / 256;                       // DMA pieces per slot (7 / 2 = KC)
+    static_assert(NP == KC, "piece count");
+    constexpr bool HS = (D == 4);
+    constexpr int NBS = HS ? 2 : D;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int stream = wave / NS, role = wave % NS;
+    const int half = HS ? (role & 1) : 0;
+    const int ct = HS ? cp * 2 + (role >> 1) : role;
+    const int ci = lane & 15, kq = lane >> 4;
+    const int L = dg.L, kpt = dg.kpt;
+    float* const ring = lds + (size_t)stream * (RING * SLOT + 2 * META);
+    float* const meta = ring + RING * SLOT;
+    // (one record per wave is enough: it is read into registers at the top of a tile, the next tile's DMA is issued later)
+    float* const cbuf = lds + (size_t)NSTREAM * (RING * SLOT + 2 * META) + (size_t)wave * T::COEF;
+
+    const int64_t ntiles = (dg.n + 15) / 16;
+    const int64_t nstreams = (int64_t)count * NSTREAM;
+    const int64_t sg = (int64_t)rank * NSTREAM + stream;
+    const int64_t tile_first = sg * ntiles / nstreams;
+    const int64_t tile_end = (sg + 1) * ntiles / nstreams;
+    const int64_t iters = (ntiles + nstreams - 1) / nstreams;
+    const int64_t tile_hi = (tile_end > tile_first ? tile_end : (tile_first + 1 < ntiles ? tile_first + 1 : ntiles)) - 1;
+    auto tile_at = [&](int64_t i) -> int64_t {
+        const int64_t t = tile_first + i;
+        return t > tile_hi ? tile_hi : t;
+    };
+    const float w_s = dg.mix[0], w_c = dg.mix[1], w_e = dg.mix[2], w_sum = dg.mix[3];
+    const float ws_n = w_s / w_sum / (float)D, wc_n = w_c / w_sum, we_n = w_e / w_sum / (float)D;
+    const uint32_t xs = (uint32_t)a.xs;
+    const int F = a.F;
+
+    // DMA piece t of a slot: lane q fetches chunk (64 t + q) of the row-major 16 x FPC image.  (F <= 32: chunk c of
+    // an odd row sits at c ^ 4, which makes the transposed reads below conflict-free for 8-chunk rows too.)
+    auto issue_rows = [&](auto sdc, const float* drec, float* buf) {
+        constexpr int sd = decltype(sdc)::value;
+        const uint32_t ids_b = (uint32_t)(uintptr_t)(drec + 16 * sd);
+        static_for<0, NS>([&](auto rc) {
+            constexpr int r = decltype(rc)::value;
+            constexpr int NMINE = pieces_of<KC, NS>(r);
+            if constexpr (NMINE > 0) if (role == r) {
+                uint32_t id[NMINE];
+                int cc[NMINE];
+                static_for<0, NMINE>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    const int g = 64 * (r + NS * k) + lane;
+                    const int row = g / FPC;
+                    int c = g - row * FPC;
+                    if constexpr (KC == 2) c ^= (row & 1) * 4;
+                    cc[k] = c;
+                    id[k] = __float_as_uint(lds_read_raw(ids_b + 4u * row));
+                });
+                static_for<0, NMINE>([&](auto kc) { lds_fence(id[decltype(kc)::value]); });
+                static_for<0, NMINE>([&](auto kc) {
+                    constexpr int k = decltype(kc)::value;
+                    dma16(a.x + (id[k] * xs + (4 * cc[k] < F ? 4u * cc[k] : 0u)), buf + (r + NS * k) * 256);
+                });
+            }
+        });
+    };
+    auto issue_bonds = [&](int64_t t, int sd, float* mrec) {
+        if (lane < 32) {
+            int64_t n = t * 16 + (lane >> 1);
+            if (n >= dg.n) n = dg.n - 1;
+            dma16(dg.e_unit + ((uint32_t)(n * D + sd) * 8u + 4u * (lane & 1)), mrec + T::OFF_BOND + sd * 128);
+        }
+    };
+    auto issue_ids = [&](int64_t t, float* mrec) {
+        int64_t n = t * 16 + ci;
+        if (n >= dg.n) n = dg.n - 1;
+        const void* src = (kq < D) ? (const void*)(dg.nei + n * D + kq) : (const void*)(dg.sel + n);
+        if (S1 >= 4 || kq < S1) dma4(src, mrec);
+        if constexpr (S1 == 5) {
+            if (kq == 0) dma4(dg.sel + n, mrec + 64);
+        }
+    };
+    auto issue_inv = [&](float* mrec) {                  // 1 / |x| of every slot, through the ids in the record
+        const uint32_t rec_b = (uint32_t)(uintptr_t)mrec;
+        uint32_t idq = __float_as_uint(lds_read_raw(rec_b + 4u * (16 * ((S1 >= 4 || kq < S1) ? kq : 0) + ci)));
+        [[maybe_unused]] uint32_t id4 = 0;
+        if constexpr (S1 == 5) id4 = __float_as_uint(lds_read_raw(rec_b + 4u * (64 + ci)));
+        lds_fence(idq);
+        if constexpr (S1 == 5) lds_fence(id4);
+        if (S1 >= 4 || kq < S1) dma4(a.inv + idq, mrec + T::OFF_INV);
+        if constexpr (S1 == 5) {
+            if (kq == 0) dma4(a.inv + id4, mrec + T::OFF_INV + 64);
+        }
+    };
+    auto issue_coef = [&](int64_t t, float* cb) {        // this wave's (tile, column tile) record: two 1 KB pieces
+        const float* src = dg.coefq + ((size_t)(t * dg.nct + ct) * 512 + 4 * lane);
+        dma16(src, cb);
+        dma16(src + 256, cb + 256);
+    };
+
+    f32x4 acc[NBS][KC];                                  // gradient rows of this wave's kernels: support slots
+    f32x4 accC[KC];                                      // ... centre rows (HS: half 0)
+    f32x4 accE[NBS];                                     // ... bond supports
+#pragma unroll
+    for (int t = 0; t < KC; ++t) {
+        accC[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < NBS; ++b) acc[b][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int b = 0; b < NBS; ++b) accE[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue
+    if (role == 0) issue_ids(tile_at(0), meta);
+    wait_vmcnt<0>();
+    __syncthreads();
+    static_for<0, RING>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        issue_rows(kc, meta, ring + k * SLOT);
+        if (role == 0 && k < D) issue_bonds(tile_at(0), k, meta);
+    });
+    issue_coef(tile_at(0), cbuf);
+    if (role == 0) {
+        issue_inv(meta);
+        issue_ids(tile_at(1), meta + META);
+    }
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+
+    int buf = 0;
+    for (int64_t it = 0; it < iters; ++it) {
+        const bool real = tile_first + it < tile_end;    // a repeated tile must not be accumulated twice
+        const uint32_t mrec_b = (uint32_t)(uintptr_t)(meta + (it & 1) * META);            // LDS byte addresses
+        const uint32_t cb_b = (uint32_t)(uintptr_t)cbuf;
+        // the tile's coefficients for this lane: kernel ci, atoms 4 q + kq
+        float gq[4];
+        int iq[4];
+        {
+            float raw[8];
+            const uint32_t cl_b = cb_b + 4u * (kq * 16 + ci);
+            static_for<0, 4>([&](auto qc) {
+                constexpr int q = decltype(qc)::value;
+                raw[q] = lds_read_raw_at<4 * (4 * q * 16)>(cl_b);
+                raw[4 + q] = lds_read_raw_at<4 * (256 + 4 * q * 16)>(cl_b);
+            });
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(raw[0]), "+v"(raw[1]), "+v"(raw[2]), "+v"(raw[3]), "+v"(raw[4]), "+v"(raw[5]),
+                         "+v"(raw[6]), "+v"(raw[7]) : : "memory");
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                gq[q] = real ? raw[q] : 0.f;
+                iq[q] = __float_as_int(raw[4 + q]);
+            }
+        }
+        static_for<0, S1>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;
+            if (s < D || !HS || half == 0) {
+                const uint32_t rb_b = (uint32_t)(uintptr_t)(ring + buf * SLOT);
+                // 1 / |x| of the slot's rows for this lane's four atoms, the A operands, then the slot's rows as B operands
+                float iv[4];
+                const uint32_t il_b = mrec_b + 4u * kq;
+                static_for<0, 4>([&](auto qc) {
+                    constexpr int q = decltype(qc)::value;
+                    iv[q] = lds_read_raw_at<4 * (T::OFF_INV + s * 16 + 4 * q)>(il_b);
+                });
+                [[maybe_unused]] float eb[4];
+                if constexpr (s < D) {
+                    const uint32_t el_b = mrec_b + 4u * (kq * 8 + (ci & 7));
+                    static_for<0, 4>([&](auto qc) {
+                        constexpr int q = decltype(qc)::value;
+                        eb[q] = lds_read_raw_at<4 * (T::OFF_BOND + (s < D ? s : 0) * 128 + 4 * q * 8)>(el_b);
+                    });
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(iv[0]), "+v"(iv[1]), "+v"(iv[2]), "+v"(iv[3]), "+v"(eb[0]), "+v"(eb[1]),
+                                 "+v"(eb[2]), "+v"(eb[3]) : : "memory");
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(iv[0]), "+v"(iv[1]), "+v"(iv[2]), "+v"(iv[3]) : : "memory");
+                }
+                float av[NBS][4], ae[NBS][4], ac[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if constexpr (s < D) {
+                        const float cf = gq[q] * ws_n * iv[q], ce = gq[q] * we_n;
+                        const int pb = perm_entry<D, s>(iq[q]);
+#pragma unroll
+                        for (int b = 0; b < NBS; ++b) {
+                            const bool hit = pb == (HS ? 2 * half + b : b);
+                            av[b][q] = hit ? cf : 0.f;
+                            ae[b][q] = hit ? ce : 0.f;
+                        }
+                    } else {
+                        ac[q] = gq[q] * wc_n * iv[q];
+                    }
+                }
+                if constexpr (s < D) {
+#pragma unroll
+                    for (int b = 0; b < NBS; ++b)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) accE[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[b][q], eb[q], accE[b], 0, 0, 0);
+                }
+                // feature tiles: lane (k = kq, j = ci) reads row 4 q + kq, feature 16 t + ci of the slot image
+                uint32_t xl_b = rb_b + 4u * (kq * RF + ci);
+                if constexpr (KC == 2) xl_b = rb_b + 4u * (kq * RF + (ci ^ ((kq & 1) * 16)));       // (odd rows: chunk ^ 4; 16 t ^ 16 below)
+                static_for<0, KC>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    float bx[4];
+                    static_for<0, 4>([&](auto qc) {
+                        constexpr int q = decltype(qc)::value;
+                        if constexpr (KC == 2) {
+                            // column (16 t + ci) ^ 16 (kq & 1): the xor of the 16s-bit is t ^ (kq & 1), resolved per lane
+                            const uint32_t tb = (uint32_t)(t ^ (kq & 1));
+                            bx[q] = lds_read_raw(rb_b + 4u * ((4 * q + kq) * RF + 16u * tb + ci));
+                        } else {
+                            bx[q] = lds_read_raw_at<4 * (4 * q * RF + 16 * t)>(xl_b);
+                        }
+                    });
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bx[0]), "+v"(bx[1]), "+v"(bx[2]), "+v"(bx[3]) : : "memory");
+                    if constexpr (s < D) {
+#pragma unroll
+                        for (int b = 0; b < NBS; ++b)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[b][q], bx[q], acc[b][t], 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) accC[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[q], bx[q], accC[t], 0, 0, 0);
+                    }
+                });
+            }
+            // ---- retire / barrier / issue: as in the forward
+            if constexpr (RING == 2) {
+                wait_vmcnt<0>();
+            } else {
+                static_for<0, NS>([&](auto rc) {
+                    constexpr int r = decltype(rc)::value;
+                    constexpr int n_young = young_batches<D, KC>(s, r);
+                    if (role == r) wait_vmcnt<n_young>();
+                });
+            }
+            if constexpr (NS > 1) __builtin_amdgcn_s_barrier();
+            constexpr int sd = (s + RING) % S1;
+            const int64_t itd = it + (s + RING) / S1;
+            float* const drec = meta + (itd & 1) * META;
+            issue_rows(IC<sd>{}, drec, ring + buf * SLOT);
+            if constexpr (sd == 0) issue_coef(tile_at(itd), cbuf);
+            if (role == 0) {
+                if constexpr (sd < D) issue_bonds(tile_at(itd), sd, drec);
+                if constexpr (sd == 0) {
+                    issue_inv(drec);
+                    issue_ids(tile_at(itd + 1), meta + ((itd + 1) & 1) * META);
+                }
+            }
+            buf = (buf + 1 == RING) ? 0 : buf + 1;
+        });
+    }
+    wait_vmcnt<0>();
+
+    // ---- this wave's slice of its stream's partial slab: C layout col = feature 16 t + ci, row = kernel kq * 4 + r
+    float* const slab = dg.slab + (size_t)sg * bank_floats(D, L, F, a.E);
+    const size_t o_sup = (size_t)L * F, o_edg = o_sup + (size_t)L * D * F;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = kq * 4 + r, l = ct * kpt + i;
+        if (i < kpt && l < L) {
+#pragma unroll
+            for (int t = 0; t < KC; ++t) {
+                const int f = 16 * t + ci;
+                if (f < F) {
+                    if (!HS || half == 0) slab[(size_t)l * F + f] = accC[t][r];
+#pragma unroll
+                    for (int b = 0; b < NBS; ++b) slab[o_sup + (size_t)(l * D + (HS ? 2 * half + b : b)) * F + f] = acc[b][t][r];
+                }
+            }
+            if (ci < a.E) {
+#pragma unroll
+                for (int b = 0; b < NBS; ++b) slab[o_edg + (size_t)(l * D + (HS ? 2 * half + b : b)) * a.E + ci] = accE[b][r];
+            }
+        }
+    }
+}
+
+template <int KC>
+__global__ void __launch_bounds__(256, 2) kc_backward_bank_stream(BankStreamArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    const int grp = a.blk_group[blockIdx.x];
+    const int rank = a.blk_rank[blockIdx.x];
+    const int di = a.grp_degree[grp];
+    const int cp = a.grp_cp[grp];
+    const int count = a.grp_count[grp];
+    switch (di) {
+        case 0: bank_stream_body<1, KC>(a, a.deg[0], cp, rank, count, lds); break;
+        case 1: bank_stream_body<2, KC>(a, a.deg[1], cp, rank, count, lds); break;
+        case 2: bank_stream_body<3, KC>(a, a.deg[2], cp, rank, count, lds); break;
+        default: bank_stream_body<4, KC>(a, a.deg[3], cp, rank, count, lds); break;
+    }
+}
+
+// ---------------------------------------------------------------- host ----
+// Same conditions as the forward's streamed kernel (the pre-pass and the slab chunk capacity added).
+bool bank_stream_supported(int d, int F, int E, int L, int64_t n_atoms, int64_t x_stride, const float* e_unit) {
+    return stream_forward_supported(d, F, E, L, n_atoms, x_stride, x_stride, e_unit);
+}
+
+hipError_t launch_backward_bank_stream(const BwdArgs a4[4], const bool use[4], const float* const e_unit[4], float* const coefq[4],
+                                       int nchunk_out[4], int ntheta_out[4], hipStream_t st) {
+    BankStreamArgs a;
+    memset(&a, 0, sizeof(a));
+    int KC = 0, ng = 0, prep_blocks = 0;
+    constexpr int MG = 8;
+    double cost[MG];
+    int64_t tiles_of[MG], cap[MG];
+    int nstream_of[MG], deg_of[MG];
+    size_t lds_fl = 0;
+    for (int i = 0; i < 4; ++i) {
+        nchunk_out[i] = 0; ntheta_out[i] = 0;
+        if (!use[i]) continue;
+        const BwdArgs& s = a4[i];
+        const int d = i + 1;
+        a.x = s.x; a.xs = s.xs; a.inv = s.inv; a.gout = s.gout; a.gs = s.gs; a.F = s.F; a.E = s.E;
+        KC = mfma_padded_width(s.F) / 16;
+        BankStreamDeg& g = a.deg[i];
+        g.sel = s.sel; g.nei = s.nei; g.e_unit = e_unit[i]; g.best = s.best; g.scores = s.scores; g.chir = s.chir; g.mix = s.mix;
+        g.coefq = coefq[i]; g.slab = s.slab; g.theta_slab = s.theta_slab;
+        g.n = s.n; g.L = s.L; g.off = s.off;
+        g.nct = d == 1 ? 1 : (d == 4 ? 4 : 2);
+        g.kpt = (s.L + g.nct - 1) / g.nct;
+        g.cs = d == 4 ? 2 : 1;
+        const int64_t ntiles = (s.n + 15) / 16;
+        g.prep_blk0 = prep_blocks;
+        g.prep_blocks = (int)(ntiles * g.nct);
+        prep_blocks += g.prep_blocks;
+        ntheta_out[i] = g.prep_blocks;
+        const int nstream = d == 4 ? 1 : 4 / g.nct;
+        const size_t fl = (size_t)bs::lds_floats(d, KC);
+        if (fl > lds_fl) lds_fl = fl;
+        for (int cp = 0; cp < g.cs; ++cp) {
+            // a wave's time per tile (units of 32 cycles): matrix work + DMA issue, no per-tile epilogue
+            const int nbs = d == 4 ? 2 : d;
+            cost[ng] = (d * nbs + 1) * 4.0 * KC + 4.0 * d * nbs + 12.0 * d + 60.0;
+            tiles_of[ng] = ntiles;
+            cap[ng] = (ntiles + nstream - 1) / nstream;
+            nstream_of[ng] = nstream;
+            deg_of[ng] = i;
+            a.grp_degree[ng] = (uint8_t)i;
+            a.grp_cp[ng] = (uint8_t)cp;
+            ++ng;
+        }
+    }
+    if (ng == 0) return hipSuccess;
+    // block counts: greedy min-max as in the forward; the two column parts of degree 4 get the same count (they fill the
+    // same slab chunks), and a degree's streams may not outnumber its slab chunks
+    auto finish = [&](int g, int blocks) {
+        const int64_t streams = (int64_t)blocks * nstream_of[g];
+        return 40.0 + (double)((tiles_of[g] + streams - 1) / streams) * cost[g];
+    };
+    int count[MG], nb = 0;
+    for (int g = 0; g < ng; ++g) { count[g] = 1; ++nb; }
+    auto partner = [&](int g) {
+        if (deg_of[g] != 3) return -1;
+        for (int h = 0; h < ng; ++h) if (h != g && deg_of[h] == 3) return h;
+        return -1;
+    };
+    while (nb < FUSED_MAX_BLOCKS) {
+        int worst = -1;
+        double t_worst = -1.0;
+        for (int g = 0; g < ng; ++g) {
+            if (count[g] >= cap[g] || (int64_t)(count[g] + 1) * nstream_of[g] > SLAB_CHUNKS) continue;
+            const double t = finish(g, count[g]);
+            if (t > t_worst) { t_worst = t; worst = g; }
+        }
+        if (worst < 0) break;
+        const int p = partner(worst);
+        if (p >= 0) {
+            if (nb + 2 > FUSED_MAX_BLOCKS) break;
+            ++count[worst]; ++count[p]; nb += 2;
+        } else { ++count[worst]; ++nb; }
+    }
+    int given[MG] = {};
+    for (int b = 0; b < nb; ++b) {
+        int pick = -1;
+        double best = -1e30;
+        for (int g = 0; g < ng; ++g) {
+            if (given[g] >= count[g]) continue;
+            const double lag = (double)count[g] * (b + 1) / nb - given[g];
+            if (lag > best) { best = lag; pick = g; }
+        }
+        a.blk_group[b] = (uint8_t)pick;
+        ++given[pick];
+    }
+    {
+        int per_xcd[MG][8] = {};
+        for (int b = 0; b < nb; ++b) ++per_xcd[a.blk_group[b]][b & 7];
+        int next[MG][8];
+        for (int g = 0; g < ng; ++g) {
+            int run = 0;
+            for (int x = 0; x < 8; ++x) { next[g][x] = run; run += per_xcd[g][x]; }
+        }
+        for (int b = 0; b < nb; ++b) a.blk_rank[b] = (uint16_t)next[a.blk_group[b]][b & 7]++;
+    }
+    for (int g = 0; g < ng; ++g) {
+        a.grp_count[g] = (uint16_t)count[g];
+        nchunk_out[deg_of[g]] = count[g] * nstream_of[g];
+    }
+    coef_prepare_kernel<<<prep_blocks, 256, 0, st>>>(a);
+    const size_t lds_bytes = lds_fl * 4;
+    if (lds_bytes > 64 * 1024) {
+        static PerDeviceOnce attr_set[2];
+        const int which = KC == 2 ? 0 : 1;
+        if (const int slot = attr_set[which].pending(); slot >= 0) {
+            hipError_t e = KC == 2 ? hipFuncSetAttribute((const void*)kc_backward_bank_stream<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
+                                   : hipFuncSetAttribute((const void*)kc_backward_bank_stream<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            if (e != hipSuccess) return e;
+            attr_set[which].set(slot);
+        }
+    }
+    if (KC == 2) kc_backward_bank_stream<2><<<nb, 256, lds_bytes, st>>>(a);
+    else kc_backward_bank_stream<7><<<nb, 256, lds_bytes, st>>>(a);
+    return hipGetLastError();
+}
+
+}  // namespace mkgnn

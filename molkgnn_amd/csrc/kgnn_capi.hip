@@ -417,7 +417,22 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         int nchunk4[4] = {0, 0, 0, 0}, ntheta4[4] = {0, 0, 0, 0};
         hipStream_t st_bank = fj.stream(1, &e);      // the helper (the caller's stream when nothing is forked)
         if (e != hipSuccess) return hip_fail("stream fork", e);
-        e = launch_backward_bank_fused(bank_a, bank_use, nchunk4, ntheta4, st_bank);
+        // the reference's bank shapes: the streamed MFMA kernel (kgnn_bwd_stream.hip); anything else: the LDS / VALU one.
+        // MKGNN_BANK_STREAM=0: A/B switch (diagnostics)
+        static const char* env_bank_stream = getenv("MKGNN_BANK_STREAM");
+        bool streamed = !(env_bank_stream && env_bank_stream[0] == '0');
+        const float* e_unit4[4]; float* coefq4[4];
+        size_t coef_off = w.coefq_off[0];
+        for (int i = 0; i < 4; ++i) {
+            e_unit4[i] = buckets[i].nei_edge_unit; coefq4[i] = nullptr;
+            if (!bank_use[i]) continue;
+            if (!bank_stream_supported(i + 1, F, E, L[i], n_atoms, x_stride, e_unit4[i])) streamed = false;
+            const int nct = (L[i] + 15) / 16;
+            coefq4[i] = (float*)(ws + coef_off);
+            coef_off += (size_t)((buckets[i].count + 15) / 16) * nct * 512 * 4;
+        }
+        if (streamed) e = launch_backward_bank_stream(bank_a, bank_use, e_unit4, coefq4, nchunk4, ntheta4, st_bank);
+        else e = launch_backward_bank_fused(bank_a, bank_use, nchunk4, ntheta4, st_bank);
         if (e != hipSuccess) return hip_fail("fused bank gradient launch", e);
         for (int i = 0; i < 4; ++i)
             if (bank_use[i]) {

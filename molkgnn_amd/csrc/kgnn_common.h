@@ -138,6 +138,7 @@ struct WorkspaceLayout {
     size_t slab_bytes_per_degree[MKGNN_MAX_DEGREE];
     size_t slab_off[MKGNN_MAX_DEGREE];
     size_t theta_off[MKGNN_MAX_DEGREE];
+    size_t coefq_off[MKGNN_MAX_DEGREE];   // coefficient records of the streamed bank-gradient kernel, per degree
     size_t fwd_end;       // the forward needs [0, fwd_end)
     size_t total;
 };
@@ -149,7 +150,8 @@ __host__ __device__ static inline size_t bank_floats(int d, int L, int F, int E)
     return (size_t)L * F + (size_t)L * d * F + (size_t)L * d * E + 4;
 }
 
-constexpr int BWD_BANK_BLOCKS = 256;   // persistent blocks of the bank-gradient kernel
+constexpr int BWD_BANK_BLOCKS = 256;   // persistent blocks of the LDS bank-gradient kernel
+constexpr int SLAB_CHUNKS = 512;       // partial slabs per degree the workspace holds (streamed bank-gradient kernel: one per stream)
 constexpr int THETA_SLAB_BLOCKS = 1024; // most blocks of the rows kernel (score-weight partials)
 
 static inline WorkspaceLayout make_layout(const int32_t L[MKGNN_MAX_DEGREE], int F, int E,
@@ -181,12 +183,23 @@ static inline WorkspaceLayout make_layout(const int32_t L[MKGNN_MAX_DEGREE], int
     w.contrib = off;
     off = align_up(off + (size_t)(n_atoms + n_edges) * ((F + 3) / 4 * 4) * 4);
     w.slab = off;
+    // an upper bound on the (atom tile, column tile) records of a degree whose bucket size is not known here
+    const size_t max_tiles = (size_t)n_atoms / 16 + 4;
     for (int i = 0; i < MKGNN_MAX_DEGREE; ++i) {
         w.slab_off[i] = off;
-        w.slab_bytes_per_degree[i] = align_up(bank_floats(i + 1, L[i], F, E) * 4 * BWD_BANK_BLOCKS);
+        w.slab_bytes_per_degree[i] = align_up(bank_floats(i + 1, L[i], F, E) * 4 * SLAB_CHUNKS);
         off += w.slab_bytes_per_degree[i];
         w.theta_off[i] = off;
-        off += align_up((size_t)THETA_SLAB_BLOCKS * 4 * 4);
+        const size_t nct = L[i] > 0 ? (size_t)(L[i] + 15) / 16 : 0;
+        const size_t theta_entries = max_tiles * nct > (size_t)THETA_SLAB_BLOCKS ? max_tiles * nct : (size_t)THETA_SLAB_BLOCKS;
+        off += align_up(theta_entries * 4 * 4);
+    }
+    {   // the records of all degrees together hold at most max_tiles * max(nct) tiles' worth: sum_d N_d <= n_atoms
+        size_t nct_max = 0;
+        for (int i = 0; i < MKGNN_MAX_DEGREE; ++i) { const size_t c = (size_t)(L[i] + 15) / 16; if (L[i] > 0 && c > nct_max) nct_max = c; }
+        size_t per_degree_cap = (max_tiles + 4) * nct_max * 512 * 4;
+        for (int i = 0; i < MKGNN_MAX_DEGREE; ++i) w.coefq_off[i] = off;      // carved per call from the real bucket sizes
+        off += align_up(per_degree_cap + 4 * 4096);
     }
     w.total = off;
     return w;
