@@ -149,44 +149,73 @@ struct BankStreamArgs {
 // ------------------------------------------------------------- pre-pass ---
 // One thread per (atom of a tile, column of a column tile): the pair's dL/dsc (times the chirality sign) and
 // permutation id into tile order, zeros for padding; the three score-weight partials summed per block in a fixed order.
+constexpr int PREP_RPB = 4;                              // records per block: four independent load chains per thread
 __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
     int di = 0;
 #pragma unroll
     for (int k = 1; k < 4; ++k) if (a.deg[k].prep_blocks > 0 && (int)blockIdx.x >= a.deg[k].prep_blk0) di = k;
     const BankStreamDeg& g = a.deg[di];
     const int tid = threadIdx.x;
-    const int64_t rec = (int64_t)blockIdx.x - g.prep_blk0;          // (tile, column tile) record
-    const int64_t tile = rec / g.nct;
-    const int ct = (int)(rec - tile * g.nct);
+    const int64_t blk = (int64_t)blockIdx.x - g.prep_blk0;
+    const int64_t nrec = ((g.n + 15) / 16) * g.nct;
     const int atom = tid >> 4, k = tid & 15;
-    const int64_t n = tile * 16 + atom;
-    const int l = ct * g.kpt + k;
-    const bool ok = n < g.n && k < g.kpt && l < g.L;
-    float gv = 0.f;
-    int idx = 0;
-    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
-    if (ok) {
-        const int64_t focal = g.sel[n];
-        const size_t o = (size_t)n * g.L + l, ln = (size_t)g.L * g.n;
-        gv = a.gout[focal * a.gs + g.off + l];
-        if (g.chir) gv *= (float)g.chir[o];
-        idx = g.best[o];
-        const float w_s = g.mix[0], w_c = g.mix[1], w_e = g.mix[2], w_sum = g.mix[3];
-        const float S = g.scores[o], C = g.scores[ln + o], Ed = g.scores[2 * ln + o];
-        const float sc = (S * w_s + C * w_c + Ed * w_e) / w_sum;
-        p0 = gv * (w_s / w_sum) * (S - sc);
-        p1 = gv * (w_c / w_sum) * (C - sc);
-        p2 = gv * (w_e / w_sum) * (Ed - sc);
+    const float w_s = g.mix[0], w_c = g.mix[1], w_e = g.mix[2], w_sum = g.mix[3];
+    const size_t ln = (size_t)g.L * g.n;
+    const int8_t* chp = g.chir ? g.chir : (const int8_t*)g.best;      // always loadable
+    // all loads of the block's records first (clamped addresses), then the arithmetic
+    float gv[PREP_RPB], S[PREP_RPB], C[PREP_RPB], Ed[PREP_RPB];
+    int idx[PREP_RPB], ch[PREP_RPB];
+    bool ok[PREP_RPB];
+    int64_t focal[PREP_RPB];
+#pragma unroll
+    for (int r = 0; r < PREP_RPB; ++r) {
+        const int64_t rec = blk * PREP_RPB + r;
+        const int64_t rc = rec < nrec ? rec : nrec - 1;
+        const int64_t tile = rc / g.nct;
+        const int ct = (int)(rc - tile * g.nct);
+        const int64_t n = tile * 16 + atom;
+        const int l = ct * g.kpt + k;
+        ok[r] = rec < nrec && n < g.n && k < g.kpt && l < g.L;
+        focal[r] = g.sel[n < g.n ? n : g.n - 1];
     }
-    float* out = g.coefq + (size_t)rec * 512;
-    out[tid] = gv;
-    ((int*)out)[256 + tid] = idx;
+#pragma unroll
+    for (int r = 0; r < PREP_RPB; ++r) {
+        const int64_t rec = blk * PREP_RPB + r;
+        const int64_t rc = rec < nrec ? rec : nrec - 1;
+        const int64_t tile = rc / g.nct;
+        const int ct = (int)(rc - tile * g.nct);
+        const int64_t n = tile * 16 + atom;
+        const int64_t nc = n < g.n ? n : g.n - 1;
+        const int l = ct * g.kpt + k, lc = l < g.L ? l : g.L - 1;
+        const size_t o = (size_t)nc * g.L + lc;
+        gv[r] = a.gout[focal[r] * a.gs + g.off + lc];
+        idx[r] = g.best[o];
+        ch[r] = chp[o];
+        S[r] = g.scores[o]; C[r] = g.scores[ln + o]; Ed[r] = g.scores[2 * ln + o];
+    }
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < PREP_RPB; ++r) {
+        const int64_t rec = blk * PREP_RPB + r;
+        float gg = ok[r] ? (g.chir ? gv[r] * (float)ch[r] : gv[r]) : 0.f;
+        if (rec < nrec) {
+            float* out = g.coefq + (size_t)rec * 512;
+            out[tid] = gg;
+            ((int*)out)[256 + tid] = ok[r] ? idx[r] : 0;
+        }
+        if (ok[r]) {
+            const float sc = (S[r] * w_s + C[r] * w_c + Ed[r] * w_e) / w_sum;
+            p0 = fmaf(gg * (w_s / w_sum), S[r] - sc, p0);
+            p1 = fmaf(gg * (w_c / w_sum), C[r] - sc, p1);
+            p2 = fmaf(gg * (w_e / w_sum), Ed[r] - sc, p2);
+        }
+    }
     // fixed-order block sums
     __shared__ float red[3][4];
     p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
     if ((tid & 63) == 0) { red[0][tid >> 6] = p0; red[1][tid >> 6] = p1; red[2][tid >> 6] = p2; }
     __syncthreads();
-    if (tid < 3) g.theta_slab[(size_t)rec * 4 + tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
+    if (tid < 3) g.theta_slab[(size_t)blk * 4 + tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
 }
 
 // ------------------------------------------------------------ main body ---
@@ -519,7 +548,7 @@ hipError_t launch_backward_bank_stream(const BwdArgs a4[4], const bool use[4], c
         g.cs = d == 4 ? 2 : 1;
         const int64_t ntiles = (s.n + 15) / 16;
         g.prep_blk0 = prep_blocks;
-        g.prep_blocks = (int)(ntiles * g.nct);
+        g.prep_blocks = (int)((ntiles * g.nct + PREP_RPB - 1) / PREP_RPB);
         prep_blocks += g.prep_blocks;
         ntheta_out[i] = g.prep_blocks;
         const int nstream = d == 4 ? 1 : 4 / g.nct;

@@ -1188,3 +1188,20 @@ def test_fused_adamw_grad_scale_is_a_scaled_gradient():
         opt_m.step(); opt_r.step()
     for pm, pr in zip(mine, ref):
         torch.testing.assert_close(pm, pr, rtol=2e-5, atol=2e-6)
+
+
+def test_receptive_field_builder_hip_matches_the_reference_transform():
+    """G10 (the reference's own ``ToXAndPAndEdgeAttrForDeg`` outputs, collated): mkgnn_rf_count / mkgnn_rf_fill
+    reproduce all 20 tensors exactly."""
+    from molkgnn_amd.receptive_field import build_receptive_fields_hip
+    dev = _dev()
+    z = np.load(os.path.join(G.GOLDEN, "g10_receptive_fields.npz"))
+    t = lambda k: torch.from_numpy(z[k])                  # noqa: E731
+    got = build_receptive_fields_hip(t("batch/x").to(dev), t("batch/p").to(dev), t("batch/edge_index").to(dev),
+                                     t("batch/edge_attr").to(dev))
+    for d in range(1, 5):
+        for nm in ("p_focal", "nei_p", "nei_edge_attr", "selected_index", "nei_index"):
+            k = f"{nm}_deg{d}"
+            want = t("batch/" + k)
+            assert got[k].numel() == want.numel(), k
+            assert torch.equal(got[k].cpu().reshape(want.shape), want.to(got[k].dtype)), k

@@ -270,3 +270,29 @@ def test_fused_adamw_host_side():
     assert st["exp_avg"].data_ptr() == buf.data_ptr() and st["exp_avg"].shape == p.shape
     assert torch.equal(st["exp_avg"], ref.state[p]["exp_avg"]) and torch.equal(st["exp_avg_sq"], ref.state[p]["exp_avg_sq"])
     assert "_packed" not in next(iter(opt2.state_dict()["state"].values()))
+
+
+def test_receptive_field_builder_matches_the_reference_transform():
+    """G10: ``ToXAndPAndEdgeAttrForDeg.__call__`` of the reference itself (wrapper.py:637-672, imported unmodified by
+    tests/golden/make_golden_rf.py) run per molecule, then collated: the batch-level builder must reproduce all 20
+    tensors exactly -- molecules with shuffled bond order, a hub atom of degree 7 (in no bucket), a two-atom molecule
+    (degrees 2-4 absent); and, molecule by molecule, the reference's own per-molecule outputs."""
+    import numpy as np
+    from molkgnn_amd.receptive_field import build_receptive_fields
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g10_receptive_fields.npz"))
+    t = lambda k: torch.from_numpy(z[k])
+    names = [f"{nm}_deg{d}" for d in range(1, 5) for nm in ("p_focal", "nei_p", "nei_edge_attr", "selected_index", "nei_index")]
+    got = build_receptive_fields(t("batch/x"), t("batch/p"), t("batch/edge_index"), t("batch/edge_attr"))
+    deg = torch.bincount(t("batch/edge_index")[0], minlength=t("batch/x").shape[0])
+    assert int(deg.max()) == 7                         # the hub is really there
+    for k in names:
+        want = t("batch/" + k)
+        assert got[k].numel() == want.numel(), k
+        assert torch.equal(got[k].reshape(want.shape), want), k
+    for i in range(int(z["num_molecules"])):
+        g = build_receptive_fields(t(f"mol{i}/in_x"), t(f"mol{i}/in_p"), t(f"mol{i}/in_edge_index"), t(f"mol{i}/in_edge_attr"))
+        for k in names:
+            want = t(f"mol{i}/{k}")
+            assert g[k].numel() == want.numel(), (i, k)
+            if want.numel():
+                assert torch.equal(g[k].reshape(want.shape), want.to(g[k].dtype)), (i, k)
