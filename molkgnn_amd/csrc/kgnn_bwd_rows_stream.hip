@@ -1,0 +1,318 @@
+// Streamed MFMA "rows" kernel of the backward pass (gfx950): the gradient with respect to the unit feature rows,
+// all four degree buckets in ONE launch (autograd of reference kernels.py:353-425 towards x, before the scatter of
+// kernels.py:527, 543 is undone by the gather kernel).
+//
+//   g_xhat[n, slot a, :] = sum_b sum_l coef[n, l] * [pi_{n,l}(a) = b] * unit_support[l, b, :]
+//   g_xhat[n, focal,  :] = sum_l coefc[n, l] * unit_centre[l, :]
+//
+// Per 16-atom tile and neighbour slot this is P_ab [atoms x kernels] . S_b [kernels x F] with the 0/1-masked
+// coefficient tile as the A operand.  kc_backward_rows_mfma (kgnn_bwd_mfma.hip) reads the bank from LDS, one 4-byte
+// read per matrix instruction, and runs once per degree.  Here, as in the forward's streamed kernel, the BANK is the
+// register-resident operand: a wave owns one column tile (<= 16 kernels) of its degree and keeps those kernels' unit
+// rows in B-operand order (kernel k, feature j) in 28 (D + 1) VGPRs for the whole launch; nothing is gathered (the
+// product needs no feature rows at all) and the inner loop is matrix instructions only.  A wave's result is the partial
+// sum over ITS kernels: the NS waves that hold a degree's NS column tiles exchange the partial tiles through LDS
+// (register-order images, conflict-free 16-byte accesses), each adds up a share of the feature tiles in a fixed order
+// and stores it -- bit-reproducible, no float atomics.  The coefficient inputs of a tile (dL/dsc through the focal ids,
+// permutation ids, chirality signs) are ordinary loads issued one tile ahead, the focal ids two.
+//
+// Covered shapes: the streamed forward's (F in (16 (KC - 1), 16 KC], exactly NS(d) = 1 / 2 / 2 / 4 column tiles).
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <type_traits>
+
+#include "kgnn_launch.h"
+
+namespace mkgnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace rs {
+
+template <int I> using IC = std::integral_constant<int, I>;
+template <int B, int E, typename Fn> __device__ __forceinline__ void static_for(Fn&& fn) {
+    if constexpr (B < E) { fn(IC<B>{}); static_for<B + 1, E>(fn); }
+}
+template <int D, int A> __device__ __forceinline__ int perm_entry(int p) {
+    if constexpr (D == 1) return 0;
+    else {
+        constexpr uint32_t packed = [] {
+            uint32_t v = 0;
+            for (int q = 0; q < PermC<D>::P; ++q) v |= (uint32_t)PermC<D>::t[q][A] << (2 * q);
+            return v;
+        }();
+        return (int)((packed >> (2 * p)) & 3u);
+    }
+}
+__host__ __device__ constexpr int column_tiles(int d) { return d == 1 ? 1 : (d == 4 ? 4 : 2); }
+
+}  // namespace rs
+
+struct RowsStreamDeg {
+    const int64_t* sel;
+    const uint8_t* best; const int8_t* chir;
+    const float* padded; const float* mix;
+    float* contrib; int64_t contrib_base;
+    int64_t n;
+    int L, off, kpt;
+};
+
+struct RowsStreamArgs {
+    const float* gout; int64_t gs;
+    int F, CS;
+    RowsStreamDeg deg[MKGNN_MAX_DEGREE];
+    uint8_t grp_degree[4];
+    uint16_t grp_count[4];
+    uint8_t blk_group[FUSED_MAX_BLOCKS];
+    uint16_t blk_rank[FUSED_MAX_BLOCKS];
+};
+
+template <int D, int KC>
+__device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const RowsStreamDeg& dg, const int rank, const int count,
+                                                 float* lds) {
+    using namespace rs;
+    constexpr int NS = column_tiles(D), NSTREAM = 4 / NS, S1 = D + 1;
+    constexpr int FP = 16 * KC;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int stream = wave / NS, role = wave % NS;
+    const int ci = lane & 15, kq = lane >> 4;
+    const int L = dg.L, kpt = dg.kpt;
+    const int ct = role;
+    // exchange images: [stream][parity][role][t][lane] x 16 bytes
+    float* const xbuf = lds + (size_t)stream * (2 * NS * KC * 256);
+
+    const int64_t ntiles = (dg.n + 15) / 16;
+    const int64_t nstreams = (int64_t)count * NSTREAM;
+    const int64_t sg = (int64_t)rank * NSTREAM + stream;
+    const int64_t tile_first = sg * ntiles / nstreams;
+    const int64_t tile_end = (sg + 1) * ntiles / nstreams;
+    const int64_t iters = (ntiles + nstreams - 1) / nstreams;
+    const int64_t tile_hi = (tile_end > tile_first ? tile_end : (tile_first + 1 < ntiles ? tile_first + 1 : ntiles)) - 1;
+    auto tile_at = [&](int64_t i) -> int64_t {
+        const int64_t t = tile_first + i;
+        return t > tile_hi ? tile_hi : t;
+    };
+
+    // ---- one-time: this wave's kernels' unit rows in B-operand order: lane (k = kq, j = ci) -> kernel 4 q + kq, feature 16 t + ci
+    float bk[D + 1][4][KC];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = 4 * q + kq, l = ct * kpt + i;
+        const bool ok = i < kpt && l < L;
+        const int lc = ok ? l : 0;
+#pragma unroll
+        for (int b = 0; b <= D; ++b)
+#pragma unroll
+            for (int t = 0; t < KC; ++t) {
+                const float v = dg.padded[((size_t)b * L + lc) * FP + 16 * t + ci];
+                bk[b][q][t] = ok ? v : 0.f;
+            }
+    }
+    const float w_s = dg.mix[0], w_c = dg.mix[1], w_sum = dg.mix[3];
+    const float ws_n = w_s / w_sum / (float)D;
+    const float ratio_c = w_c * (float)D / w_s;
+    const int8_t* const chp = dg.chir ? dg.chir : (const int8_t*)dg.best;        // always loadable; ignored without signs
+
+    // coefficient inputs of a tile for this lane: atom ci, kernels 4 q + kq of the wave's column tile (clamped, masked later)
+    float rg[4];
+    int ridx[4], rch[4];
+    auto focal_of = [&](int64_t tile) -> int64_t {
+        const int64_t n = tile * 16 + ci;
+        return dg.sel[n < dg.n ? n : dg.n - 1];
+    };
+    auto issue = [&](int64_t tile, int64_t focal) {
+        const int64_t n = tile * 16 + ci;
+        const int64_t nc = n < dg.n ? n : dg.n - 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int l = ct * kpt + 4 * q + kq;
+            const int lc = l < L ? l : L - 1;
+            rg[q] = a.gout[focal * a.gs + dg.off + lc];
+            ridx[q] = dg.best[(size_t)nc * L + lc];
+            rch[q] = chp[(size_t)nc * L + lc];
+        }
+    };
+    issue(tile_at(0), focal_of(tile_at(0)));
+    int64_t focal_next = focal_of(tile_at(1));
+    int par = 0;
+
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t tile = tile_at(it);
+        const bool real = tile_first + it < tile_end;
+        const int64_t n_mine = tile * 16 + ci;
+        float cf[4];
+        int ix[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = 4 * q + kq;
+            const bool ok = real && n_mine < dg.n && i < kpt && ct * kpt + i < L;
+            const float g = dg.chir ? rg[q] * (float)rch[q] : rg[q];
+            cf[q] = ok ? g * ws_n : 0.f;
+            ix[q] = ridx[q];
+        }
+        // next tile's inputs: in flight during this tile's matrix work
+        issue(tile_at(it + 1), focal_next);
+        focal_next = focal_of(tile_at(it + 2));
+
+        static_for<0, S1>([&](auto sc) {
+            constexpr int s = decltype(sc)::value;       // contribution-row slot: 0 = focal (centre rows), 1 + a = neighbour a
+            f32x4 acc[KC];
+#pragma unroll
+            for (int t = 0; t < KC; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if constexpr (s == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float av = cf[q] * ratio_c;
+#pragma unroll
+                    for (int t = 0; t < KC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bk[D][q][t], acc[t], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int pb = perm_entry<D, (s > 0 ? s - 1 : 0)>(ix[q]);
+#pragma unroll
+                    for (int b = 0; b < D; ++b) {
+                        const float av = (pb == b) ? cf[q] : 0.f;
+#pragma unroll
+                        for (int t = 0; t < KC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bk[b][q][t], acc[t], 0, 0, 0);
+                    }
+                }
+            }
+            // ---- sum over the column tiles (waves of the stream), then the contribution rows: lane holds atoms
+            // kq * 4 + r, feature 16 t + ci
+            auto store_tile = [&](int t, const f32x4& v) {
+                if (16 * t + ci < a.F) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t nn = tile * 16 + kq * 4 + r;
+                        if (real && nn < dg.n) dg.contrib[(size_t)(dg.contrib_base + nn * S1 + s) * a.CS + 16 * t + ci] = v[r];
+                    }
+                }
+            };
+            if constexpr (NS == 1) {
+#pragma unroll
+                for (int t = 0; t < KC; ++t) store_tile(t, acc[t]);
+            } else {
+                float* const mine = xbuf + (size_t)((par * NS + role) * KC) * 256 + lane * 4;
+#pragma unroll
+                for (int t = 0; t < KC; ++t) *(f32x4*)(mine + t * 256) = acc[t];
+                __syncthreads();
+                static_for<0, KC>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+                    if (t % NS == role) {                // (wave-uniform)
+                        const float* src = xbuf + (size_t)(par * NS * KC + t) * 256 + lane * 4;
+                        f32x4 v = *(const f32x4*)src;
+#pragma unroll
+                        for (int w = 1; w < NS; ++w) v += *(const f32x4*)(src + (size_t)w * KC * 256);
+                        store_tile(t, v);
+                    }
+                });
+                par ^= 1;
+            }
+        });
+    }
+}
+
+template <int KC>
+__global__ void __launch_bounds__(256, 2) kc_backward_rows_stream(RowsStreamArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    const int grp = a.blk_group[blockIdx.x];
+    const int rank = a.blk_rank[blockIdx.x];
+    const int di = a.grp_degree[grp];
+    const int count = a.grp_count[grp];
+    switch (di) {
+        case 0: rows_stream_body<1, KC>(a, a.deg[0], rank, count, lds); break;
+        case 1: rows_stream_body<2, KC>(a, a.deg[1], rank, count, lds); break;
+        case 2: rows_stream_body<3, KC>(a, a.deg[2], rank, count, lds); break;
+        default: rows_stream_body<4, KC>(a, a.deg[3], rank, count, lds); break;
+    }
+}
+
+// ---------------------------------------------------------------- host ----
+bool rows_stream_supported(int d, int F, int E, int L) {
+    if (d < 1 || d > 4 || L < 1) return false;
+    const int FP = mfma_padded_width(F);
+    if (!FP || F <= FP - 16) return false;
+    return (L + 15) / 16 == rs::column_tiles(d);
+}
+
+hipError_t launch_backward_rows_stream(const BwdArgs a4[4], const bool use[4], hipStream_t st) {
+    RowsStreamArgs a;
+    memset(&a, 0, sizeof(a));
+    int KC = 0, ng = 0;
+    double cost[4];
+    int64_t tiles_of[4], cap[4];
+    int nstream_of[4];
+    for (int i = 0; i < 4; ++i) {
+        if (!use[i]) continue;
+        const BwdArgs& s = a4[i];
+        const int d = i + 1;
+        a.gout = s.gout; a.gs = s.gs; a.F = s.F; a.CS = s.CS;
+        KC = mfma_padded_width(s.F) / 16;
+        RowsStreamDeg& g = a.deg[i];
+        g.sel = s.sel; g.best = s.best; g.chir = s.chir; g.padded = s.padded; g.mix = s.mix;
+        g.contrib = s.contrib; g.contrib_base = s.contrib_base;
+        g.n = s.n; g.L = s.L; g.off = s.off;
+        const int nct = rs::column_tiles(d);
+        g.kpt = (s.L + nct - 1) / nct;
+        const int nstream = 4 / nct;
+        const int64_t ntiles = (s.n + 15) / 16;
+        // a wave's time per tile (units of 32 cycles): matrix instructions + per-slot exchange and stores
+        cost[ng] = (d * d + 1) * 4.0 * KC + (d + 1) * 30.0 + 40.0;
+        tiles_of[ng] = ntiles;
+        cap[ng] = (ntiles + nstream - 1) / nstream;
+        nstream_of[ng] = nstream;
+        a.grp_degree[ng] = (uint8_t)i;
+        ++ng;
+    }
+    if (ng == 0) return hipSuccess;
+    auto finish = [&](int g, int blocks) {
+        const int64_t streams = (int64_t)blocks * nstream_of[g];
+        return 40.0 + (double)((tiles_of[g] + streams - 1) / streams) * cost[g];
+    };
+    int count[4], nb = 0;
+    for (int g = 0; g < ng; ++g) { count[g] = 1; ++nb; }
+    while (nb < FUSED_MAX_BLOCKS) {
+        int worst = -1;
+        double t_worst = -1.0;
+        for (int g = 0; g < ng; ++g) {
+            if (count[g] >= cap[g]) continue;
+            const double t = finish(g, count[g]);
+            if (t > t_worst) { t_worst = t; worst = g; }
+        }
+        if (worst < 0) break;
+        ++count[worst]; ++nb;
+    }
+    int given[4] = {0, 0, 0, 0};
+    for (int b = 0; b < nb; ++b) {
+        int pick = -1;
+        double best = -1e30;
+        for (int g = 0; g < ng; ++g) {
+            if (given[g] >= count[g]) continue;
+            const double lag = (double)count[g] * (b + 1) / nb - given[g];
+            if (lag > best) { best = lag; pick = g; }
+        }
+        a.blk_group[b] = (uint8_t)pick;
+        ++given[pick];
+    }
+    {
+        int per_xcd[4][8] = {};
+        for (int b = 0; b < nb; ++b) ++per_xcd[a.blk_group[b]][b & 7];
+        int next[4][8];
+        for (int g = 0; g < ng; ++g) {
+            int run = 0;
+            for (int x = 0; x < 8; ++x) { next[g][x] = run; run += per_xcd[g][x]; }
+        }
+        for (int b = 0; b < nb; ++b) a.blk_rank[b] = (uint16_t)next[a.blk_group[b]][b & 7]++;
+    }
+    for (int g = 0; g < ng; ++g) a.grp_count[g] = (uint16_t)count[g];
+    const size_t lds_bytes = (size_t)4 * 2 * KC * 256 * 4;       // NSTREAM * NS = 4 wave images, two parities
+    if (KC == 2) kc_backward_rows_stream<2><<<nb, 256, lds_bytes, st>>>(a);
+    else kc_backward_rows_stream<7><<<nb, 256, lds_bytes, st>>>(a);
+    return hipGetLastError();
+}
+
+}  // namespace mkgnn

@@ -342,6 +342,12 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         if (buckets[i].count > 0 && L[i] > 0 &&
             !(lds_backward_supported(i + 1, F, E, L[i], x_stride, x) && mfma_backward_supported(i + 1, F, E, L[i], x_stride, x, n_atoms)))
             fuse_bank = false;
+    // the x-gradient rows of all degrees in one streamed launch when every degree's shape is covered (kgnn_bwd_rows_stream.hip);
+    // MKGNN_ROWS_STREAM=0: one kc_backward_rows_mfma launch per degree (diagnostics)
+    static const char* env_rows_stream = getenv("MKGNN_ROWS_STREAM");
+    bool rows_streamed = fuse_bank && grad_x && !(env_rows_stream && env_rows_stream[0] == '0');
+    for (int i = 0; i < 4 && rows_streamed; ++i)
+        if (buckets[i].count > 0 && L[i] > 0 && !rows_stream_supported(i + 1, F, E, L[i])) rows_streamed = false;
     BwdArgs bank_a[4];
     bool bank_use[4] = {false, false, false, false};
     for (int i = 0; i < 4; ++i) {                    // (the launch order of the degrees makes no measurable difference)
@@ -391,7 +397,7 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
                     st_bank = fj.stream(1, &e);
                     if (e != hipSuccess) return hip_fail("stream fork", e);
                 }
-                if (rows_mfma) {
+                if (rows_mfma && !rows_streamed) {
                     e = launch_backward_rows_mfma(d, a, &ntheta, st_rows);
                     if (e != hipSuccess) return hip_fail("kernelconv backward launch", e);
                 }
@@ -412,6 +418,10 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         r.icen = (const float*)(ws + w.bank[i].icen); r.isup = (const float*)(ws + w.bank[i].isup);
         r.iedg = (const float*)(ws + w.bank[i].iedg);
         r.g = grads[i];
+    }
+    if (rows_streamed && (bank_use[0] || bank_use[1] || bank_use[2] || bank_use[3])) {
+        e = launch_backward_rows_stream(bank_a, bank_use, st);       // (bank_a holds every active degree's arguments)
+        if (e != hipSuccess) return hip_fail("streamed rows launch", e);
     }
     if (bank_use[0] || bank_use[1] || bank_use[2] || bank_use[3]) {
         int nchunk4[4] = {0, 0, 0, 0}, ntheta4[4] = {0, 0, 0, 0};

@@ -111,6 +111,9 @@ hipError_t launch_backward_bank_fused(const BwdArgs a4[4], const bool use[4], in
 bool bank_stream_supported(int d, int F, int E, int L, int64_t n_atoms, int64_t x_stride, const float* e_unit);
 hipError_t launch_backward_bank_stream(const BwdArgs a4[4], const bool use[4], const float* const e_unit[4], float* const coefq[4],
                                        int nchunk_out[4], int ntheta_out[4], hipStream_t st);
+// kgnn_bwd_rows_stream.hip: streamed MFMA rows kernel (bank in registers), all degrees in one launch
+bool rows_stream_supported(int d, int F, int E, int L);
+hipError_t launch_backward_rows_stream(const BwdArgs a4[4], const bool use[4], hipStream_t st);
 // kgnn_bwd_mfma.hip: MFMA backward for the model's shapes
 bool mfma_backward_supported(int d, int F, int E, int L, int64_t xs, const void* x, int64_t n_atoms);
 hipError_t launch_backward_rows_mfma(int d, const BwdArgs& a, int* ntheta_out, hipStream_t st);
