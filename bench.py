@@ -42,6 +42,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--roofline-reps", type=int, default=20)
+    ap.add_argument("--windows", type=int, default=0, help="timed windows of --steps steps each (0: as many as make >= 0.5 s of timed work, at least 5)")
+    ap.add_argument("--fresh-batches", type=int, default=16,
+                    help="also time an epoch of this many distinct batches (one AID-1798 epoch at batch 4096 is 16) with the "
+                         "receptive-field and index-plan build inside the timed region; 0 = skip")
     return ap.parse_args()
 
 
@@ -107,6 +111,39 @@ def cpu_baseline(seconds, assay):
                       f"torch {torch.__version__} CPU, {cores} threads"}
 
 
+def fresh_batches_leg(args, model, opt, dev, log):
+    """An epoch of DISTINCT batches: every step receives a collated batch it has never seen (x, p, edge_index,
+    edge_attr, batch, y resident on the GPU, as a loader would hand it over) and builds the degree buckets
+    (mkgnn_rf_count / mkgnn_rf_fill), the unit bond rows and the index plan (mkgnn_plan_build) INSIDE the timed region,
+    then runs forward + backward + AdamW eagerly (a hipGraph is tied to one batch's sizes; a batch-agnostic captured
+    step is not built yet -- DESIGN.md).  Reported next to the resident-replay value, not instead of it."""
+    from molkgnn_amd.receptive_field import attach_receptive_fields
+    from molkgnn_amd.synthetic import make_batch
+    nb = args.fresh_batches
+    raw = [make_batch(args.batch_size, seed=int(args.assay) * 1000 + 500 + i, assay=args.assay, with_receptive_fields=False).to(dev)
+           for i in range(nb)]
+    torch.cuda.synchronize()
+
+    def one(b):
+        attach_receptive_fields(b)                       # degree buckets on the GPU (one host round trip: four bucket sizes)
+        model.zero_grad(set_to_none=True)
+        loss = model.loss(b)                             # (the index plan and the unit bond rows are built on first use)
+        loss.backward()
+        if opt is not None:
+            opt.step()
+
+    one(raw[0])                                          # warm-up (same batch object again below: its fields are rebuilt)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in raw:
+        one(b)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    log(f"fresh batches: {nb} distinct batches, {1e3 * el / nb:.3f} ms per step")
+    return {"value": round(args.batch_size * nb / el, 1), "unit": "molecules/s", "ms_per_step": round(1e3 * el / nb, 4),
+            "distinct_batches": nb, "in_timed_region": "receptive-field build + unit bond rows + index plan (HIP) + fwd + bwd + AdamW, eager launches"}
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -167,11 +204,8 @@ def main():
     # (N > 1) stays outside the graph, between the backward graph and the optimiser.
     graphs = None
     flat_opt = False
-    all_degrees = all(getattr(b, f"selected_index_deg{d}").numel() > 0 for b in batches for d in range(1, 5))
-    if world > 1 and not all_degrees:
-        # a rank whose batch lacks a degree gets that bank's gradients from the all-reduce only; a captured
-        # optimiser step would not see them, so such (tiny) batches run eagerly
-        args.no_graph = True
+    # (a rank whose batch lacks a degree: its bank's gradient slots stay zero in the flat buffer, the has-gradient flags
+    # that travel with the all-reduce tell every rank's optimiser which banks had a gradient anywhere -- dp.py)
     if not args.no_graph:
         try:
             side = torch.cuda.Stream()
@@ -208,6 +242,8 @@ def main():
                                 p_.grad = v_
                             for grp in opt.param_groups:
                                 grp["grad_scale"] = 1.0 / world
+                            opt.set_grad_active(reducer.active_flags())
+                            reducer.prepare_patterns([e_[3] for e_ in graphs])
                         else:                            # (PyTorch optimiser: averaged gradients copied back, one graph per batch)
                             for p_, g_ in zip(reducer.params, entry[3]):
                                 p_.grad = g_
@@ -244,20 +280,33 @@ def main():
         step(i)
     torch.cuda.synchronize()
     log("timing")
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        step(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+
+    def timed_window():
+        """EXACTLY --steps steps between barrier + synchronize pairs; the maximum over ranks."""
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el
+
+    first = timed_window()
+    n_windows = args.windows if args.windows > 0 else max(5, min(200, int(math.ceil(0.5 / max(first, 1e-6)))))
+    if world > 1:                                        # every rank must run the same number of windows
+        t = torch.tensor([n_windows], dtype=torch.int64, device=dev)
+        dist.broadcast(t, 0)
+        n_windows = int(t.item())
+    windows = sorted([first] + [timed_window() for _ in range(n_windows - 1)])
+    elapsed = windows[len(windows) // 2]                 # the median window is the reported one
     mols = args.batch_size * args.steps * world
     value = mols / elapsed
     # data-parallel sanity, outside the timed region: identical initial weights + averaged gradients + a deterministic
@@ -312,15 +361,17 @@ def main():
         ms = sum(samples) / len(samples) if samples and min(samples) > 0 else ms_call
         by, fl = layer_algorithmic(plan, K_in, E, Ls, False)
         gbs = by / (ms * 1e-3) / 1e9
-        traffic = None
-        try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same workload)
+        traffic, traffic_source = None, None
+        try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same workload; tools/pmc.sh)
             if args.batch_size == 4096 and args.variant in ("auto", "mfma"):
-                traffic = json.load(open(os.path.join(REPO, "profiles", "r01_fused_forward_pmc.json")))["hbm_bytes_per_launch"]
+                pmc = json.load(open(os.path.join(REPO, "profiles", "r02_forward_pmc.json")))
+                traffic = pmc["hbm_bytes_per_launch"]
+                traffic_source = "profiles/r02_forward_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of commit " + pmc.get("commit", "?") + ")"
         except Exception:
             traffic = None
         roofline = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
-                    "kernel": "kc_forward_fused<7>: one launch = KernelSetConv forward of one N-hop layer (F=110, K=110), "
+                    "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
+                    "kernel": "kc_forward_stream<7>: one launch = KernelSetConv forward of one N-hop layer (F=110, K=110), "
                               "all four degree buckets, training configuration (saves permutation ids and scores)",
                     "ms_per_launch": round(ms, 5), "ms_whole_forward_call": round(ms_call, 5),
                     "algorithmic_bytes": by, "algorithmic_flops": fl,
@@ -328,7 +379,12 @@ def main():
                     "fp32_vector_frac": round(fl / (ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 5)}
         out = {"metric": "molecules/sec fwd+bwd, 3-layer MolKGNN on AID 1798", "value": round(value, 1),
                "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(1e3 * elapsed / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+               "windows": {"n": len(windows), "steps_each": args.steps, "statistic": "median",
+                           "ms_per_step_min": round(1e3 * windows[0] / args.steps, 4),
+                           "ms_per_step_max": round(1e3 * windows[-1] / args.steps, 4),
+                           "timed_seconds_total": round(sum(windows), 4)},
+               "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16 dot products, f32 otherwise" if args.variant == "bf16" else "f32",
                "data": "synthetic",
                **({"dp_replicas_max_abs_diff": replicas_diff} if replicas_diff is not None else {}),
@@ -341,7 +397,9 @@ def main():
                           "variant": args.variant, "batch_size_per_gpu": args.batch_size,
                           "parallelism": f"dp{world}"},
                "roofline": roofline}
-        log(f"fused forward kernel {ms:.4f} ms ({ms_call:.4f} ms whole call), {gbs:.1f} GB/s algorithmic; cpu baseline")
+        log(f"forward kernel {ms:.4f} ms ({ms_call:.4f} ms whole call), {gbs:.1f} GB/s algorithmic")
+        if world == 1 and args.fresh_batches > 0:
+            out["fresh_batches"] = fresh_batches_leg(args, model, opt, dev, log)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.assay)
         print(json.dumps(out), flush=True)

@@ -260,6 +260,24 @@ int mkgnn_rf_fill(const int64_t* edge_index, const float* p, const float* edge_a
                   int64_t n_atoms, int64_t n_edges, int32_t E, const void* workspace,
                   const mkgnn_degree_bucket out[MKGNN_MAX_DEGREE], void* stream);
 
+/* Per-batch index plan (the host side keeps it with the batch, molkgnn_amd.plan): for every atom, in ascending original
+ * order inside the atom's segment,
+ *   scatter  the contribution rows of mkgnn_kernelsetconv_backward that point at it (rows numbered bucket by bucket, atom
+ *            by atom, focal then neighbours): scatter_rowptr [N+1], scatter_rows [sum_d N_d (d+1)];
+ *   in       the edges that end in it, by source atom: in_rowptr [N+1], in_col [M] (MolGCN.propagate's forward);
+ *            in_col_packed (may be NULL): the same with the source's degree bucket in bits 28..30
+ *            (mkgnn_segment_sum_block_rows mode 1);
+ *   out      the edges that start from it, by target atom: out_rowptr [N+1], out_col [M] (its gradient);
+ *   deg8     [N] the degree bucket of every atom (0 = in none).
+ * No sort over the batch and no host synchronisation: counts with integer atomics, a scan, slots taken with integer
+ * atomics, every segment sorted by one thread -- the result does not depend on the order the atomics ran in.
+ * buckets: only count, selected_index and nei_index are read.  N < 2^28, M < 2^31. */
+size_t mkgnn_plan_workspace_bytes(int64_t n_atoms, int64_t n_edges, int64_t n_rows);
+int mkgnn_plan_build(const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE], int64_t n_atoms, const int64_t* edge_index,
+                     int64_t n_edges, int32_t* scatter_rowptr, int32_t* scatter_rows, int32_t* in_rowptr, int32_t* in_col,
+                     int32_t* in_col_packed, int32_t* out_rowptr, int32_t* out_col, int8_t* deg8, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 /* Tail of the training step for a single task (reference model.py:147-148, 190-198 with data.py:37):
  *     pred = graph_embedding @ ffn.weight[0] + ffn.bias;   loss = mean(BCEWithLogits(pred, target))
  * forward writes pred [n_rows] and loss [1]; backward takes d loss (one float on the device) and fully overwrites

@@ -69,7 +69,8 @@ EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn
            "mkgnn_readout_backward", "mkgnn_batchnorm_workspace_bytes", "mkgnn_batchnorm_forward",
            "mkgnn_batchnorm_backward", "mkgnn_bce_head_workspace_bytes", "mkgnn_bce_head_forward",
            "mkgnn_bce_head_backward", "mkgnn_rf_workspace_bytes", "mkgnn_rf_count", "mkgnn_rf_fill", "mkgnn_adamw_step",
-           "mkgnn_bce_head_dropout_forward", "mkgnn_bce_head_dropout_backward", "mkgnn_segment_sum_block_rows")
+           "mkgnn_bce_head_dropout_forward", "mkgnn_bce_head_dropout_backward", "mkgnn_segment_sum_block_rows",
+           "mkgnn_plan_workspace_bytes", "mkgnn_plan_build")
 
 _lib: Optional[C.CDLL] = None
 
@@ -145,6 +146,10 @@ def load() -> C.CDLL:
     lib.mkgnn_rf_fill.argtypes = [P, P, P, I64, I64, I32, P, Buckets4, P]
     lib.mkgnn_segment_sum_block_rows.restype = C.c_int
     lib.mkgnn_segment_sum_block_rows.argtypes = [P, I64, P, P, P, I64, Int32x4, I32, P, I64, P, P]
+    lib.mkgnn_plan_workspace_bytes.restype = C.c_size_t
+    lib.mkgnn_plan_workspace_bytes.argtypes = [I64, I64, I64]
+    lib.mkgnn_plan_build.restype = C.c_int
+    lib.mkgnn_plan_build.argtypes = [Buckets4, I64, P, I64, P, P, P, P, P, P, P, P, P, C.c_size_t, P]
     lib.mkgnn_adamw_step.restype = C.c_int
     lib.mkgnn_adamw_step.argtypes = [P, I32, P, I32, P]
     if lib.mkgnn_abi_version() != ABI_VERSION:

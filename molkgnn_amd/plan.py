@@ -13,6 +13,7 @@ the graph structure, computed once per batch and shared by all layers.
 """
 from __future__ import annotations
 
+import os
 import weakref
 from typing import List, Optional
 
@@ -73,9 +74,50 @@ class BatchPlan:
         self._deg8 = None
         self._csr_in_packed = None
 
+    # -- all index structures in one pass on the GPU (mkgnn_plan_build) ----------
+    def build_hip(self) -> bool:
+        """Scatter CSR, both propagate CSRs, ``deg8`` and the packed columns from one call of ``mkgnn_plan_build``
+        (no sort over the batch, no host synchronisation); entry for entry what the torch definitions below give
+        (``tests/test_hip_parity.py::test_plan_builder_hip_matches_torch_builder``).  False when not applicable (CPU)."""
+        if not self.device.type == "cuda" or os.environ.get("MKGNN_TORCH_PLAN"):
+            return False
+        from . import _lib
+        lib = _lib.load()
+        dev, n = self.device, self.n_atoms
+        ei = self.edge_index
+        m = int(ei.shape[1]) if ei is not None else 0
+        r = sum(b.count * (b.degree + 1) for b in self.buckets)
+        if ei is not None:
+            ei = ei.contiguous()
+            if ei.dtype != torch.int64:
+                ei = ei.long()
+        bk = _lib.Buckets4()
+        for i, b in enumerate(self.buckets):
+            bk[i].count = b.count
+            if b.count:
+                bk[i].selected_index, bk[i].nei_index = b.sel.data_ptr(), b.nei.data_ptr()
+        i32 = lambda k: torch.empty(max(k, 1), dtype=torch.int32, device=dev)      # noqa: E731
+        s_ptr, s_rows = i32(n + 1), i32(r)
+        in_ptr, in_col, in_pk, out_ptr, out_col = i32(n + 1), i32(m), i32(m), i32(n + 1), i32(m)
+        deg8 = torch.empty(max(n, 1), dtype=torch.int8, device=dev)
+        with torch.cuda.device(dev):
+            nbytes = int(lib.mkgnn_plan_workspace_bytes(n, m, r))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.mkgnn_plan_build(bk, n, _lib.ptr(ei), m, s_ptr.data_ptr(), s_rows.data_ptr(), in_ptr.data_ptr(),
+                                            in_col.data_ptr(), in_pk.data_ptr(), out_ptr.data_ptr(), out_col.data_ptr(),
+                                            deg8.data_ptr(), ws.data_ptr(), nbytes, _lib.stream_ptr(dev)), "mkgnn_plan_build")
+        self._scatter = (s_ptr, s_rows[:r])
+        self._deg8 = deg8[:n]
+        if self.edge_index is not None:
+            self._csr_in, self._csr_out = (in_ptr, in_col[:m]), (out_ptr, out_col[:m])
+            self._csr_in_packed = (in_ptr, in_pk[:m])
+        return True
+
     # -- backward scatter CSR -------------------------------------------------
     @property
     def scatter(self):
+        if self._scatter is None:
+            self.build_hip()
         if self._scatter is None:
             dest = []
             for b in self.buckets:
@@ -105,12 +147,16 @@ class BatchPlan:
     def csr_in(self):
         """Edges grouped by target; columns are the sources (forward of propagate)."""
         if self._csr_in is None:
+            self.build_hip()
+        if self._csr_in is None:
             self._csr_in = self._csr(self.edge_index[1], self.edge_index[0])
         return self._csr_in
 
     @property
     def csr_out(self):
         """Edges grouped by source; columns are the targets (gradient of propagate)."""
+        if self._csr_out is None:
+            self.build_hip()
         if self._csr_out is None:
             self._csr_out = self._csr(self.edge_index[0], self.edge_index[1])
         return self._csr_out
@@ -120,6 +166,8 @@ class BatchPlan:
     @property
     def deg8(self):
         """[n_atoms] int8: the degree bucket every atom is in (0 = none)."""
+        if self._deg8 is None:
+            self.build_hip()
         if self._deg8 is None:
             d8 = torch.zeros(self.n_atoms, dtype=torch.int8, device=self.device)
             for b in self.buckets:
@@ -132,6 +180,8 @@ class BatchPlan:
     def csr_in_packed(self):
         """``csr_in`` with the source atom's degree in bits 28..30 of every column entry
         (``mkgnn_segment_sum_block_rows`` mode 1)."""
+        if self._csr_in_packed is None:
+            self.build_hip()
         if self._csr_in_packed is None:
             rowptr, col = self.csr_in
             packed = col | (self.deg8[col.long()].to(torch.int32) << 28)

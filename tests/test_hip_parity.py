@@ -1205,3 +1205,42 @@ def test_receptive_field_builder_hip_matches_the_reference_transform():
             want = t("batch/" + k)
             assert got[k].numel() == want.numel(), k
             assert torch.equal(got[k].cpu().reshape(want.shape), want.to(got[k].dtype)), k
+
+
+def test_plan_builder_hip_matches_torch_builder():
+    """mkgnn_plan_build (scatter CSR of the backward, both propagate CSRs, deg8, packed columns) against the torch
+    definition in plan.py (stable sorts): exact equality, on a synthetic batch, with the bonds shuffled, with hub atoms of
+    degree 9 / isolated atoms / an absent degree, and for a plan without an edge list."""
+    from molkgnn_amd.plan import plan_from_lists
+    from molkgnn_amd.receptive_field import build_receptive_fields
+    from molkgnn_amd.synthetic import make_batch
+    dev = _dev()
+    b = make_batch(300, seed=4, device=dev, with_receptive_fields=False)
+    cases = [(b.x, b.p, b.edge_index, b.edge_attr)]
+    g = torch.Generator().manual_seed(1)
+    nb = b.edge_index.shape[1] // 2
+    perm = torch.randperm(nb, generator=g).to(dev)
+    eperm = torch.stack([2 * perm, 2 * perm + 1], dim=1).reshape(-1)
+    cases.append((b.x, b.p, b.edge_index[:, eperm].contiguous(), b.edge_attr[eperm].contiguous()))
+    pairs = [(i, 9) for i in range(9)] + [(12, 13), (13, 14)] + [(i, 24) for i in range(15, 24)] + [(24, 25)]
+    ei = torch.tensor([[a, c] for a, c in pairs for (a, c) in ((a, c), (c, a))]).t().contiguous().to(dev)
+    ea = torch.rand(ei.shape[1] // 2, 7, generator=g).repeat_interleave(2, dim=0).to(dev)
+    cases.append((torch.randn(26, 28, device=dev), torch.randn(26, 3, device=dev), ei, ea))
+    for ci, (x, p, edge_index, edge_attr) in enumerate(cases):
+        f = build_receptive_fields(x, p, edge_index, edge_attr)
+        lists = [[f[f"{nm}_deg{d}"] for d in range(1, 5)] for nm in ("p_focal", "nei_p", "nei_edge_attr", "selected_index", "nei_index")]
+        for with_edges in (True, False):
+            hip = plan_from_lists(x.shape[0], *lists, edge_index if with_edges else None)
+            assert hip.build_hip()
+            ref = plan_from_lists(x.shape[0], *lists, edge_index if with_edges else None)
+            os.environ["MKGNN_TORCH_PLAN"] = "1"
+            try:
+                want = [ref.scatter, ref.deg8] + ([ref.csr_in, ref.csr_out, ref.csr_in_packed] if with_edges else [])
+            finally:
+                del os.environ["MKGNN_TORCH_PLAN"]
+            got = [hip.scatter, hip.deg8] + ([hip.csr_in, hip.csr_out, hip.csr_in_packed] if with_edges else [])
+            for gi, (gv, wv) in enumerate(zip(got, want)):
+                if isinstance(gv, tuple):
+                    assert torch.equal(gv[0], wv[0]) and torch.equal(gv[1], wv[1]), (ci, with_edges, gi)
+                else:
+                    assert torch.equal(gv, wv), (ci, with_edges, gi)
