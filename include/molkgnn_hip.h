@@ -229,20 +229,23 @@ int mkgnn_readout_backward(const mkgnn_readout_params* params, const float* h, i
  * inv_norm (may be NULL; needs C <= 32, C % 4 == 0 and 16-byte aligned rows of x and out): also
  * 1 / max(||out row||, 1e-8) per row, bit-identical to mkgnn_row_inv_norm
  * on out -- the first kernel convolution reads the normalised features next (MolKGNNNet.py:115-117).
- * num_batches_tracked (may be NULL): incremented when training != 0 (BatchNorm1d's counter). */
+ * num_batches_tracked (may be NULL): incremented when training != 0 (BatchNorm1d's counter).
+ * n_valid_rows (device scalar, may be NULL): only rows [0, *n_valid_rows) enter the batch statistics; the rest of the
+ * n_rows rows is padding (normalised like any row, excluded from every sum) -- a batch padded to a fixed shape so that
+ * one captured graph serves every batch (molkgnn_amd.padding) keeps the statistics of its real atoms. */
 size_t mkgnn_batchnorm_workspace_bytes(int32_t C);
 int mkgnn_batchnorm_forward(const float* x, int64_t x_stride, int64_t n_rows, int32_t C,
                             const float* weight, const float* bias,
                             float* running_mean, float* running_var, float momentum, float eps,
                             int32_t training, float* out, int64_t out_stride,
                             float* save_mean, float* save_invstd, float* inv_norm, int64_t* num_batches_tracked,
-                            void* workspace, size_t workspace_bytes, void* stream);
+                            const int64_t* n_valid_rows, void* workspace, size_t workspace_bytes, void* stream);
 /* grad_x (may be NULL), grad_weight, grad_bias (may be NULL) are fully overwritten. */
 int mkgnn_batchnorm_backward(const float* grad_out, int64_t grad_out_stride, const float* x, int64_t x_stride,
                              int64_t n_rows, int32_t C, const float* weight,
                              const float* save_mean, const float* save_invstd, int32_t training,
                              float* grad_x, int64_t grad_x_stride, float* grad_weight, float* grad_bias,
-                             void* workspace, size_t workspace_bytes, void* stream);
+                             const int64_t* n_valid_rows, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Receptive-field builder: the per-degree tensors of a collated batch, reference
  * wrapper.py:559-672 (ToXAndPAndEdgeAttrForDeg) + PyG collation.  edge_index is [2, M] int64 (row 0 sources, row 1

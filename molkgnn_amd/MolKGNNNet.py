@@ -62,15 +62,19 @@ class MolKGNNNet(torch.nn.Module):
             # (MolKGNNNet.py:70-89 then :115); only the single-``data`` form is meaningful
             raise ValueError("unmatched number of arguments.")
         data = argv[0]
-        x = R.batch_norm(data.x, self.node_batch_norm)
+        # (a batch padded to a fixed shape -- molkgnn_amd.padding -- carries its real atom count and its molecule segments)
+        x = R.batch_norm(data.x, self.node_batch_norm, getattr(data, 'n_valid_atoms', None))
         # edge_batch_norm never reaches the kernel convolution in the reference: skipped
         kw = {f'{nm}_deg{d}': getattr(data, f'{nm}_deg{d}')
               for nm in ('p_focal', 'nei_p', 'nei_edge_attr', 'selected_index', 'nei_index') for d in range(1, 5)}
         node_representation = self.gnn(x=x, edge_index=data.edge_index, edge_attr=data.edge_attr, p=data.p,
                                        save_score=save_score, **kw)
         # pool(lin2(dropout(act(lin1(h)))), batch) -- MolKGNNNet.py:144-146 -- as one operator
+        seg = None
+        if getattr(data, 'mol_ptr', None) is not None and getattr(data, 'atom_mol', None) is not None:
+            seg = R.MoleculeSegments.from_tensors(data.mol_ptr, data.atom_mol)
         return R.readout(node_representation, self.graph_embedding_lin1, self.graph_embedding_lin2, self.dropout,
-                         data.batch, getattr(data, 'num_graphs', None))
+                         data.batch, getattr(data, 'num_graphs', None), segments=seg)
 
     @staticmethod
     def add_model_specific_args(parent_parser):

@@ -125,9 +125,9 @@ def load() -> C.CDLL:
     lib.mkgnn_batchnorm_workspace_bytes.restype = C.c_size_t
     lib.mkgnn_batchnorm_workspace_bytes.argtypes = [I32]
     lib.mkgnn_batchnorm_forward.restype = C.c_int
-    lib.mkgnn_batchnorm_forward.argtypes = [P, I64, I64, I32, P, P, P, P, F32, F32, I32, P, I64, P, P, P, P, P, C.c_size_t, P]
+    lib.mkgnn_batchnorm_forward.argtypes = [P, I64, I64, I32, P, P, P, P, F32, F32, I32, P, I64, P, P, P, P, P, P, C.c_size_t, P]
     lib.mkgnn_batchnorm_backward.restype = C.c_int
-    lib.mkgnn_batchnorm_backward.argtypes = [P, I64, P, I64, I64, I32, P, P, P, I32, P, I64, P, P, P, C.c_size_t, P]
+    lib.mkgnn_batchnorm_backward.argtypes = [P, I64, P, I64, I64, I32, P, P, P, I32, P, I64, P, P, P, P, C.c_size_t, P]
     lib.mkgnn_bce_head_forward.restype = C.c_int
     lib.mkgnn_bce_head_forward.argtypes = [P, I64, I64, I32, P, P, P, P, P, P, C.c_size_t, P]
     lib.mkgnn_bce_head_backward.restype = C.c_int

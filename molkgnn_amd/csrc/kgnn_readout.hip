@@ -434,7 +434,16 @@ struct BnArgs {
     float *gweight, *gbias;
     float* inv_out;                // forward: 1 / max(|out row|, eps) for the convolution that reads out next (17 <= C <= 32)
     int64_t* nbt;                  // forward, training: BatchNorm1d.num_batches_tracked, incremented
+    const int64_t* nvalid;         // device scalar or null: only rows [0, *nvalid) enter the batch statistics (padded batches)
 };
+
+// rows that count for the statistics: all of them, or the leading *nvalid (the rest is padding: normalised like any
+// row, excluded from every sum)
+__device__ __forceinline__ int64_t bn_valid(const BnArgs& a) {
+    if (!a.nvalid) return a.n;
+    const int64_t v = *a.nvalid;
+    return v < 1 ? 1 : (v < a.n ? v : a.n);
+}
 
 // rows of this block: [lo, hi)
 __device__ __forceinline__ void bn_rows(const BnArgs& a, int64_t& lo, int64_t& hi) {
@@ -450,6 +459,7 @@ __device__ __forceinline__ void bn_block_colsum(const BnArgs& a, int CL, const f
     const int c = threadIdx.x & (CL - 1), rsub = threadIdx.x / CL, RS = 256 / CL;
     int64_t lo, hi;
     bn_rows(a, lo, hi);
+    const int64_t nv = bn_valid(a);
     const bool act = c < a.C;
     const int cc = act ? c : 0;
     const float mu = (MODE >= 1) ? mean[cc] : 0.f, is = (MODE == 2) ? invstd[cc] : 0.f;
@@ -464,7 +474,7 @@ __device__ __forceinline__ void bn_block_colsum(const BnArgs& a, int CL, const f
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            if (r0 + u * RS < hi) {
+            if (r0 + u * RS < hi && r0 + u * RS < nv) {
                 if (MODE == 0) s0 += v[u];
                 if (MODE == 1) { const float d = v[u] - mu; s0 = fmaf(d, d, s0); }
                 if (MODE == 2) { s0 += g[u]; s1 = fmaf(g[u], (v[u] - mu) * is, s1); }
@@ -519,7 +529,7 @@ __global__ void __launch_bounds__(256) bn_var_kernel(BnArgs a, int CL) {
     __shared__ float sh[512];
     __shared__ float mean[256];
     bn_total(a.part1, gridDim.x, a.C, CL, sh, mean);
-    if (threadIdx.x < a.C) mean[threadIdx.x] = mean[threadIdx.x] / (float)a.n;
+    if (threadIdx.x < a.C) mean[threadIdx.x] = mean[threadIdx.x] / (float)bn_valid(a);
     __syncthreads();
     bn_block_colsum<1>(a, CL, mean, nullptr, sh);
 }
@@ -532,7 +542,8 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(BnArgs a, int CL) {
         bn_total(a.part1, gridDim.x, a.C, CL, sh, mean);
         bn_total(a.part2, gridDim.x, a.C, CL, sh, invstd);
         if (t < a.C) {
-            const float mu = mean[t] / (float)a.n, var = invstd[t] / (float)a.n;
+            const int64_t nv = bn_valid(a);
+            const float mu = mean[t] / (float)nv, var = invstd[t] / (float)nv;
             mean[t] = mu;
             invstd[t] = 1.f / sqrtf(var + a.eps);
             if (blockIdx.x == 0) {
@@ -540,7 +551,7 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(BnArgs a, int CL) {
                 a.save_invstd[t] = invstd[t];
                 if (a.running_mean) a.running_mean[t] = fmaf(a.momentum, mu - a.running_mean[t], a.running_mean[t]);
                 if (a.running_var) {
-                    const float unbiased = a.n > 1 ? var * ((float)a.n / (float)(a.n - 1)) : var;
+                    const float unbiased = nv > 1 ? var * ((float)nv / (float)(nv - 1)) : var;
                     a.running_var[t] = fmaf(a.momentum, unbiased - a.running_var[t], a.running_var[t]);
                 }
             }
@@ -620,7 +631,7 @@ __global__ void __launch_bounds__(256) bn_bwd_final_kernel(BnArgs a, int CL, int
     if (!a.gx) return;
     int64_t lo, hi;
     bn_rows(a, lo, hi);
-    const float invn = 1.f / (float)a.n;
+    const float invn = 1.f / (float)bn_valid(a);
     const int c = t & (CL - 1), rsub = t / CL, RS = 256 / CL;
     if (c < a.C) {
         const float w = a.weight ? a.weight[c] : 1.f;
@@ -1014,7 +1025,8 @@ static int bn_common(const char* who, int64_t n, int32_t C, int& CL) {
 int mkgnn_batchnorm_forward(const float* x, int64_t x_stride, int64_t n_rows, int32_t C, const float* weight,
                             const float* bias, float* running_mean, float* running_var, float momentum, float eps,
                             int32_t training, float* out, int64_t out_stride, float* save_mean, float* save_invstd,
-                            float* inv_norm, int64_t* num_batches_tracked, void* ws, size_t ws_bytes, void* stream) {
+                            float* inv_norm, int64_t* num_batches_tracked, const int64_t* n_valid_rows, void* ws, size_t ws_bytes,
+                            void* stream) {
     int CL;
     if (int rc = bn_common("mkgnn_batchnorm_forward", n_rows, C, CL)) return rc;
     if (!x || !out || x_stride < C || out_stride < C) return api_fail("mkgnn_batchnorm_forward: bad x/out");
@@ -1028,7 +1040,7 @@ int mkgnn_batchnorm_forward(const float* x, int64_t x_stride, int64_t n_rows, in
     a.out = out; a.os = out_stride; a.save_mean = save_mean; a.save_invstd = save_invstd;
     if (inv_norm && (C > 32 || C % 4 || x_stride % 4 || out_stride % 4 || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)))
         return api_fail("mkgnn_batchnorm_forward: inv_norm needs C <= 32, a multiple of 4, and 16-byte aligned rows of x and out (C=%d)", C);
-    a.inv_out = inv_norm; a.nbt = num_batches_tracked;
+    a.inv_out = inv_norm; a.nbt = num_batches_tracked; a.nvalid = n_valid_rows;
     a.part1 = (float*)ws; a.part2 = a.part1 ? a.part1 + (size_t)BN_BLOCKS * C : nullptr;
     if (training) {
         bn_sum_kernel<<<BN_BLOCKS, 256, 0, st>>>(a, CL);
@@ -1041,8 +1053,8 @@ int mkgnn_batchnorm_forward(const float* x, int64_t x_stride, int64_t n_rows, in
 
 int mkgnn_batchnorm_backward(const float* grad_out, int64_t grad_out_stride, const float* x, int64_t x_stride,
                              int64_t n_rows, int32_t C, const float* weight, const float* save_mean,
-                             const float* save_invstd, int32_t training, float* grad_x, int64_t grad_x_stride, float* grad_weight, float* grad_bias, void* ws,
-                             size_t ws_bytes, void* stream) {
+                             const float* save_invstd, int32_t training, float* grad_x, int64_t grad_x_stride, float* grad_weight, float* grad_bias,
+                             const int64_t* n_valid_rows, void* ws, size_t ws_bytes, void* stream) {
     int CL;
     if (int rc = bn_common("mkgnn_batchnorm_backward", n_rows, C, CL)) return rc;
     if (!grad_out || !x || grad_out_stride < C || x_stride < C) return api_fail("mkgnn_batchnorm_backward: bad grad_out/x");
@@ -1056,7 +1068,7 @@ int mkgnn_batchnorm_backward(const float* grad_out, int64_t grad_out_stride, con
     a.save_mean = (float*)save_mean; a.save_invstd = (float*)save_invstd;
     a.part1 = (float*)ws; a.part2 = a.part1 + (size_t)BN_BLOCKS * C;
     a.gout = grad_out; a.gos = grad_out_stride; a.gx = grad_x; a.gxs = grad_x_stride;
-    a.gweight = grad_weight; a.gbias = grad_bias;
+    a.gweight = grad_weight; a.gbias = grad_bias; a.nvalid = n_valid_rows;
     bn_bwd_partial_kernel<<<BN_BLOCKS, 256, 0, st>>>(a, CL);
     bn_bwd_final_kernel<<<grad_x ? BN_BLOCKS : 1, 256, 0, st>>>(a, CL, BN_BLOCKS);
     hipError_t e = hipGetLastError();

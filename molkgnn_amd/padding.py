@@ -1,0 +1,104 @@
+"""Batches padded to one fixed shape, so that ONE captured hipGraph serves every batch of an epoch.
+
+A hipGraph bakes every kernel's sizes in: atoms, atoms per degree, edges, molecules.  Batches of molecules differ in all
+of them, so a step captured on one batch cannot replay another (bench.py's headline cycles resident batches, one graph
+each).  Padding makes the sizes equal: every batch gets ONE extra padding molecule made of as many atoms of each degree
+as the batch is short of the epoch's targets, bonded among themselves (the kernels read indices, not chemistry: multiple
+bonds and self loops are fine there).  Nothing of a real molecule touches it -- the edge list stays block diagonal --
+and it cannot reach the loss:
+
+* the node batch norm takes its statistics over the real atoms only (``n_valid_atoms``, read on the device:
+  ``mkgnn_batchnorm_forward``'s ``n_valid_rows``);
+* the padding molecule is the last row of the graph embedding and is cut off before the head (``n_valid_molecules``),
+  so its atoms receive a zero gradient and add exactly zero to every parameter gradient.
+
+The step then runs from static buffers: ``StaticBatch.load`` copies the next padded batch in place, the captured graph
+rebuilds degree buckets, unit bond rows and the index plan (``mkgnn_rf_*``, ``mkgnn_unit_rows8``, ``mkgnn_plan_build``:
+no host synchronisation) and runs forward, backward and the optimiser.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence
+
+import torch
+
+from .receptive_field import GraphBatch
+
+RAW_FIELDS = ("x", "p", "edge_index", "edge_attr", "batch", "y")
+
+
+def degree_histogram(batch: GraphBatch) -> List[int]:
+    """[atoms, N_1, N_2, N_3, N_4, atoms in no bucket] of a collated batch (host values)."""
+    n = batch.x.shape[0]
+    deg = torch.bincount(batch.edge_index[0], minlength=n)
+    h = torch.bincount(deg.clamp(max=5), minlength=6).tolist()
+    return [n, h[1], h[2], h[3], h[4], h[0] + h[5]]
+
+
+def fixed_shape(histograms: Sequence[Sequence[int]]) -> Dict[str, int]:
+    """The common shape of a set of batches: per-degree targets = the maxima (+ 1 so that every batch receives a
+    non-empty padding molecule, + the parity fix that makes the padding's bond stubs pair up)."""
+    if any(h[5] for h in histograms):
+        raise ValueError("atoms of degree 0 or > 4 are in no bucket: such batches cannot be padded to a bucket shape")
+    t = [max(h[d] for h in histograms) + 1 for d in range(1, 5)]
+    # sum_d d * (t_d - N_d) must be even for every batch; sum_d d * N_d = edges is even (two directed edges per bond),
+    # so sum_d d * t_d must be even: one more degree-1 atom fixes an odd total
+    if sum((d + 1) * t[d] for d in range(4)) % 2:
+        t[0] += 1
+    return {"n1": t[0], "n2": t[1], "n3": t[2], "n4": t[3], "atoms": sum(t), "edges": sum((d + 1) * t[d] for d in range(4))}
+
+
+def pad_batch(batch: GraphBatch, shape: Dict[str, int], num_molecules: int) -> GraphBatch:
+    """``batch`` (raw fields on any device, ``num_molecules`` molecules) + one padding molecule -> a batch of exactly
+    ``shape``.  Returns the raw fields plus ``mol_ptr``, ``atom_mol`` (int32), ``n_valid_atoms`` (int64 scalar tensor),
+    ``n_valid_molecules`` and ``bucket_sizes``."""
+    dev = batch.x.device
+    h = degree_histogram(batch)
+    need = [shape[f"n{d}"] - h[d] for d in range(1, 5)]
+    if min(need) < 0 or h[5]:
+        raise ValueError(f"batch with degree histogram {h[1:5]} does not fit the shape {shape}")
+    n_real, n_pad = h[0], sum(need)
+    # padding atoms in degree order; their bond stubs paired off in sequence (stub k with stub k + 1)
+    deg_of = torch.cat([torch.full((need[d],), d + 1, dtype=torch.long) for d in range(4)])
+    stubs = torch.repeat_interleave(torch.arange(n_pad), deg_of) + n_real
+    if stubs.numel() % 2:
+        raise ValueError("odd number of padding bond stubs: the shape does not come from fixed_shape()")
+    a, b = stubs[0::2], stubs[1::2]
+    pad_ei = torch.stack([torch.stack([a, b], dim=1).reshape(-1), torch.stack([b, a], dim=1).reshape(-1)]).to(dev)
+    E = batch.edge_attr.shape[1]
+    pad_ea = torch.zeros(pad_ei.shape[1], E, dtype=batch.edge_attr.dtype, device=dev)
+    pad_ea[:, 0] = 1.0                                   # (a valid bond vector: no zero-norm rows in the padding)
+    out = GraphBatch()
+    out.x = torch.cat([batch.x, torch.zeros(n_pad, batch.x.shape[1], dtype=batch.x.dtype, device=dev)])
+    out.p = torch.cat([batch.p, torch.zeros(n_pad, batch.p.shape[1], dtype=batch.p.dtype, device=dev)])
+    out.edge_index = torch.cat([batch.edge_index, pad_ei], dim=1)
+    out.edge_attr = torch.cat([batch.edge_attr, pad_ea])
+    out.batch = torch.cat([batch.batch, torch.full((n_pad,), num_molecules, dtype=batch.batch.dtype, device=dev)])
+    out.y = batch.y
+    counts = torch.bincount(out.batch, minlength=num_molecules + 1)
+    ptr = torch.zeros(num_molecules + 2, dtype=torch.int32, device=dev)
+    ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    out.mol_ptr, out.atom_mol = ptr, out.batch.to(torch.int32)
+    out.n_valid_atoms = torch.tensor([n_real], dtype=torch.int64, device=dev)
+    out.n_valid_molecules, out.num_graphs = num_molecules, num_molecules + 1
+    out.bucket_sizes = [shape["n1"], shape["n2"], shape["n3"], shape["n4"]]
+    assert out.x.shape[0] == shape["atoms"] and out.edge_index.shape[1] == shape["edges"]
+    return out
+
+
+class StaticBatch:
+    """Static device buffers of one fixed shape: ``load`` copies a padded batch in place (the tensors keep their addresses,
+    which is what a captured graph refers to); ``data`` is the object the model consumes."""
+
+    FIELDS = ("x", "p", "edge_index", "edge_attr", "batch", "y", "mol_ptr", "atom_mol", "n_valid_atoms")
+
+    def __init__(self, first: GraphBatch):
+        self.data = GraphBatch(**{k: getattr(first, k).clone() for k in self.FIELDS})
+        self.data.n_valid_molecules, self.data.num_graphs = first.n_valid_molecules, first.num_graphs
+        self.data.bucket_sizes = list(first.bucket_sizes)
+
+    def load(self, padded: GraphBatch) -> None:
+        if list(padded.bucket_sizes) != self.data.bucket_sizes or padded.n_valid_molecules != self.data.n_valid_molecules:
+            raise ValueError("batch shape differs from the static buffers'")
+        for k in self.FIELDS:
+            getattr(self.data, k).copy_(getattr(padded, k), non_blocking=True)

@@ -26,6 +26,18 @@ _SEG_CACHE_MAX = 32
 class MoleculeSegments:
     """``batch`` (atom -> molecule id) as contiguous segments: ``mol_ptr [B+1]``, ``atom_mol [N]`` (int32)."""
 
+    @classmethod
+    def from_tensors(cls, mol_ptr: torch.Tensor, atom_mol: torch.Tensor) -> "MoleculeSegments":
+        """Segments handed over by the loader (int32, on the GPU, atoms of a molecule contiguous): no derivation, no
+        host synchronisation; the tensors may be refilled in place between replays of a captured step."""
+        if mol_ptr.dtype != torch.int32 or atom_mol.dtype != torch.int32:
+            raise TypeError("mol_ptr and atom_mol must be int32")
+        seg = cls.__new__(cls)
+        seg.size = int(mol_ptr.numel()) - 1
+        seg.sorted = True
+        seg.mol_ptr, seg.atom_mol = mol_ptr, atom_mol
+        return seg
+
     def __init__(self, batch: torch.Tensor, size: int):
         self.size = int(size)
         b = batch.long()
@@ -132,10 +144,12 @@ class _ReadoutFn(torch.autograd.Function):
 
 
 def readout(h: torch.Tensor, lin1: torch.nn.Linear, lin2: torch.nn.Linear, dropout: Optional[torch.nn.Dropout],
-            batch: torch.Tensor, size: Optional[int] = None) -> torch.Tensor:
-    """``global_add_pool(lin2(dropout(swish(lin1(h)))), batch, size)`` -> ``[size, G]``."""
+            batch: torch.Tensor, size: Optional[int] = None, segments: Optional["MoleculeSegments"] = None) -> torch.Tensor:
+    """``global_add_pool(lin2(dropout(swish(lin1(h)))), batch, size)`` -> ``[size, G]``.  ``segments``: the molecule
+    segments of ``batch`` when the caller already has them (a loader knows the molecule sizes; deriving them from
+    ``batch`` costs a host synchronisation, which a captured step cannot have)."""
     _lib.require_gpu_tensor(h, "node_representation")
-    seg = molecule_segments(batch, size)
+    seg = segments if segments is not None else molecule_segments(batch, size)
     H, F = lin1.weight.shape
     G = lin2.weight.shape[0]
     p_drop = dropout.p if (dropout is not None and dropout.training) else 0.0
@@ -159,8 +173,9 @@ def readout(h: torch.Tensor, lin1: torch.nn.Linear, lin2: torch.nn.Linear, dropo
 # ------------------------------------------------------------------------------------------ batch norm --
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, bn: torch.nn.BatchNorm1d, use_batch_stats: bool):
+    def forward(ctx, x, weight, bias, bn: torch.nn.BatchNorm1d, use_batch_stats: bool, n_valid=None):
         lib = _lib.load()
+        ctx.n_valid = n_valid
         x = _row_major(x if x.dtype == torch.float32 else x.float())
         n, C = x.shape
         dev = x.device
@@ -183,7 +198,7 @@ class _BatchNormFn(torch.autograd.Function):
                 x.data_ptr(), _stride0(x), n, C, _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(rm), _lib.ptr(rv),
                 float(bn.momentum if bn.momentum is not None else 0.0), float(bn.eps), int(use_batch_stats),
                 out.data_ptr(), C, save_mean.data_ptr(), save_invstd.data_ptr(), _lib.ptr(inv), _lib.ptr(nbt),
-                ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)), "mkgnn_batchnorm_forward")
+                _lib.ptr(n_valid), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)), "mkgnn_batchnorm_forward")
         ctx.use_batch_stats = use_batch_stats
         ctx.save_for_backward(x, weight, save_mean, save_invstd)
         if inv is None:
@@ -196,7 +211,7 @@ class _BatchNormFn(torch.autograd.Function):
     def backward(ctx, grad_out, _g_inv=None):
         lib = _lib.load()
         if grad_out is None:
-            return None, None, None, None, None
+            return None, None, None, None, None, None
         x, weight, save_mean, save_invstd = ctx.saved_tensors
         n, C = x.shape
         dev = x.device
@@ -210,22 +225,30 @@ class _BatchNormFn(torch.autograd.Function):
             _lib.check(lib.mkgnn_batchnorm_backward(
                 g.data_ptr(), _stride0(g), x.data_ptr(), _stride0(x), n, C, _lib.ptr(weight), save_mean.data_ptr(),
                 save_invstd.data_ptr(), int(ctx.use_batch_stats), _lib.ptr(gx), C, _lib.ptr(gw), _lib.ptr(gb),
-                ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)), "mkgnn_batchnorm_backward")
-        return gx, gw, gb, None, None
+                _lib.ptr(ctx.n_valid), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)), "mkgnn_batchnorm_backward")
+        return gx, gw, gb, None, None, None
 
 
-def batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm1d) -> torch.Tensor:
+def batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm1d, n_valid: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``bn(x)`` for a 2-D input on the GPU, with ``torch.nn.BatchNorm1d``'s semantics (batch statistics in
-    training mode or when no running statistics are tracked; running statistics updated in place)."""
+    training mode or when no running statistics are tracked; running statistics updated in place).
+
+    ``n_valid`` (a one-element int64 CUDA tensor): only the leading ``n_valid`` rows enter the batch statistics; the
+    remaining rows are padding (``molkgnn_amd.padding``) -- normalised with the same statistics, excluded from every sum.
+    The value is read on the device, so a captured step serves batches with different numbers of real atoms."""
     _lib.require_gpu_tensor(x, "x")
+    if n_valid is not None and not (n_valid.is_cuda and n_valid.dtype == torch.int64 and n_valid.numel() == 1):
+        raise ValueError("n_valid must be a one-element int64 tensor on the GPU")
     if x.dim() != 2 or x.shape[1] != bn.num_features:
         raise ValueError(f"expected a [N, {bn.num_features}] input, got {tuple(x.shape)}")
     use_batch_stats = bn.training or bn.running_mean is None
     if x.shape[1] > 256 or x.shape[0] == 0 or (bn.training and bn.track_running_stats and bn.momentum is None):
+        if n_valid is not None:
+            raise ValueError("n_valid needs the HIP batch norm (<= 256 channels, momentum set)")
         return bn(x)
     if use_batch_stats and bn.training and x.shape[0] == 1:
         raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
-    out, inv = _BatchNormFn.apply(x, bn.weight, bn.bias, bn, use_batch_stats)
+    out, inv = _BatchNormFn.apply(x, bn.weight, bn.bias, bn, use_batch_stats, n_valid)
     if inv.numel():
         from .functional import _INV_ATTR
         setattr(out, _INV_ATTR, (inv, out._version))

@@ -99,8 +99,11 @@ def build_receptive_fields(x: torch.Tensor, p: torch.Tensor,
 
 
 def build_receptive_fields_hip(x: torch.Tensor, p: torch.Tensor, edge_index: torch.Tensor,
-                               edge_attr: torch.Tensor) -> Dict[str, torch.Tensor]:
-    """Same result as ``build_receptive_fields`` (bit for bit) for a batch on the GPU, through the C ABI."""
+                               edge_attr: torch.Tensor, sizes=None) -> Dict[str, torch.Tensor]:
+    """Same result as ``build_receptive_fields`` (bit for bit) for a batch on the GPU, through the C ABI.
+
+    ``sizes`` = the four bucket sizes when the caller knows them (a batch padded to a fixed shape): no host round trip,
+    so the build can run inside a captured graph; the degree counts of the batch must be exactly these."""
     from . import _lib
     lib = _lib.load()
     _lib.require_gpu_tensor(edge_index, "edge_index")
@@ -115,7 +118,8 @@ def build_receptive_fields_hip(x: torch.Tensor, p: torch.Tensor, edge_index: tor
         ws = torch.empty(int(lib.mkgnn_rf_workspace_bytes(n)), dtype=torch.uint8, device=dev)
         counts = torch.empty(4, dtype=torch.int64, device=dev)
         _lib.check(lib.mkgnn_rf_count(_lib.ptr(ei), n, m, ws.data_ptr(), ws.numel(), counts.data_ptr(), st), "mkgnn_rf_count")
-        sizes = counts.tolist()                  # the one host round trip: the outputs have to be allocated
+        if sizes is None:
+            sizes = counts.tolist()              # the one host round trip: the outputs have to be allocated
         out: Dict[str, torch.Tensor] = {}
         buckets = _lib.Buckets4()
         raw = {}
@@ -152,9 +156,11 @@ def build_receptive_fields_hip(x: torch.Tensor, p: torch.Tensor, edge_index: tor
     return out
 
 
-def attach_receptive_fields(batch: GraphBatch) -> GraphBatch:
-    build = build_receptive_fields_hip if (batch.edge_index.is_cuda and batch.p.shape[1] == 3) else build_receptive_fields
-    rf = build(batch.x, batch.p, batch.edge_index, batch.edge_attr)
+def attach_receptive_fields(batch: GraphBatch, sizes=None) -> GraphBatch:
+    if batch.edge_index.is_cuda and batch.p.shape[1] == 3:
+        rf = build_receptive_fields_hip(batch.x, batch.p, batch.edge_index, batch.edge_attr, sizes)
+    else:
+        rf = build_receptive_fields(batch.x, batch.p, batch.edge_index, batch.edge_attr)
     for k, v in rf.items():
         setattr(batch, k, v)
     return batch

@@ -52,6 +52,9 @@ class GNNModel(torch.nn.Module):
             # comes from the kernels' own counter-based generator, see readout.head_rng_state)
             p = self.dropout.p if (self.training and self.dropout.p < 1.0) else 0.0
             graph_embedding = self.gnn_model(data)
+            nreal = getattr(data, 'n_valid_molecules', None)
+            if nreal is not None:                      # a padded batch: the padding molecule's row takes no part in the loss
+                graph_embedding = graph_embedding[:nreal]
             if self.training and self.dropout.p >= 1.0:
                 graph_embedding = self.dropout(graph_embedding)
             return bce_head_loss(graph_embedding, self.ffn, data.y, dropout_p=p)
