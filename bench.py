@@ -123,7 +123,7 @@ def fresh_batches_leg(args, model, opt, dev, log):
     nb, B = args.fresh_batches, args.batch_size
     raws = [make_batch(B, seed=int(args.assay) * 1000 + 500 + i, assay=args.assay, with_receptive_fields=False) for i in range(nb)]
     shape = P.fixed_shape([P.degree_histogram(r) for r in raws])
-    padded = [P.pad_batch(r, shape, B).to(dev) for r in raws]
+    padded = [P.pack(P.pad_batch(r, shape, B).to(dev)) for r in raws]      # (packed: one copy loads a batch)
     pad_atoms = sum(shape["atoms"] - int(p.n_valid_atoms) for p in padded) / nb
     sb = P.StaticBatch(padded[0])
 

@@ -254,6 +254,7 @@ int mkgnn_batchnorm_backward(const float* grad_out, int64_t grad_out_stride, con
  *   mkgnn_rf_fill   (same workspace, untouched in between) fills, for d = 1..4, out[d-1]:
  *       selected_index [N_d] ascending atom ids, nei_index [N_d*d] edge targets in edge-list order,
  *       nei_edge_attr [N_d*d, E] attributes of bond 2*(e/2), p_focal [N_d, 3], nei_p [N_d*d, 3];
+ *       nei_edge_unit [N_d*d, 8] (if not NULL and E <= 8) the same rows unit-normalised, as mkgnn_unit_rows8 gives them;
  *       out[d-1].count = rows allocated (>= N_d).  Atoms of out-degree 0 or > 4 are in no bucket.
  * Deterministic: integer atomics only choose slots, the <= 4 edge ids of an atom are sorted afterwards. */
 size_t mkgnn_rf_workspace_bytes(int64_t n_atoms);

@@ -100,8 +100,11 @@ class MolGCN(MessagePassing):
         data = Data(x=x, p=kwargv['p'], edge_index=edge_index, edge_attr=kwargv['edge_attr'], **fields)
         save_score = kwargv['save_score']
         # one index plan per batch, shared by every layer and by propagate
+        # (not part of the reference's signature: unit bond rows that came with the receptive fields, if any)
+        units = [kwargv.get(f'nei_edge_unit_deg{d}') for d in range(1, 5)]
         self._plan = plan_from_lists_cached(
-            x.shape[0], *[[fields[f'{nm}_deg{d}'] for d in range(1, 5)] for nm in names], edge_index)
+            x.shape[0], *[[fields[f'{nm}_deg{d}'] for d in range(1, 5)] for nm in names], edge_index,
+            units if any(u is not None for u in units) else None)
         h = x
         try:
             for i in range(self.num_layers):

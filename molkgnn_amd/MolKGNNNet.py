@@ -67,6 +67,10 @@ class MolKGNNNet(torch.nn.Module):
         # edge_batch_norm never reaches the kernel convolution in the reference: skipped
         kw = {f'{nm}_deg{d}': getattr(data, f'{nm}_deg{d}')
               for nm in ('p_focal', 'nei_p', 'nei_edge_attr', 'selected_index', 'nei_index') for d in range(1, 5)}
+        for d in range(1, 5):                          # unit bond rows built with the receptive fields (mkgnn_rf_fill), if any
+            u = getattr(data, f'nei_edge_unit_deg{d}', None)
+            if u is not None:
+                kw[f'nei_edge_unit_deg{d}'] = u
         node_representation = self.gnn(x=x, edge_index=data.edge_index, edge_attr=data.edge_attr, p=data.p,
                                        save_score=save_score, **kw)
         # pool(lin2(dropout(act(lin1(h)))), batch) -- MolKGNNNet.py:144-146 -- as one operator

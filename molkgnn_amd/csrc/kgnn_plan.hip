@@ -56,38 +56,72 @@ __global__ void __launch_bounds__(256) plan_count_fill_kernel(PlanArgs a) {
             if (FILL) { a.tmp[1][p1] = (int32_t)i; a.tmp[2][p2] = (int32_t)i; }
         }
     }
-    if (!FILL) {                                        // the degree bucket of every atom (0 = none)
+    // the degree bucket of every atom (0 = none): zeroed by the counting pass, scattered by the fill pass (no memset launch)
+    if (!FILL) {
+        if (i < a.n) a.deg8[i] = 0;
+    } else {
 #pragma unroll
         for (int d = 0; d < 4; ++d)
             if (i < a.count[d]) a.deg8[a.sel[d][i]] = (int8_t)(d + 1);
     }
 }
 
-// exclusive scan of cnt[k][0..n) -> rowptr[k][0..n], cursor (in place) = the same; one block per array
-__global__ void __launch_bounds__(1024) plan_scan_kernel(PlanArgs a) {
-    __shared__ int part[1024];
-    const int k = blockIdx.x, t = threadIdx.x;
-    int32_t* c = a.cnt + (size_t)k * (a.n + 1);
-    const int64_t per = (a.n + 1023) / 1024;
-    const int64_t lo = t * per, hi = lo + per < a.n ? lo + per : a.n;
-    int s = 0;
-    for (int64_t i = lo; i < hi; ++i) s += c[i];
-    part[t] = s;
+// exclusive scan of cnt[k][0..n) -> rowptr[k][0..n] and, in place, the fill pass's cursors.  Two coalesced passes:
+// totals of 2048-element blocks, then every block scans its elements behind the sum of the totals before it.
+constexpr int PLAN_SCAN_ELEMS = 2048;                    // per block: 256 threads x 8 chunks of 256 consecutive elements
+
+__device__ __forceinline__ int plan_block_scan256(int v, int* sh, int& total) {     // exclusive scan over the block's 256 threads
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int u = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += u;
+    }
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {          // Hillis-Steele inclusive scan of the 1024 partials
-        const int v = t >= off ? part[t - off] : 0;
-        __syncthreads();
-        part[t] += v;
+    if (lane == 63) sh[wave] = inc;
+    __syncthreads();
+    int base = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) if (w < wave) base += sh[w];
+    total = sh[0] + sh[1] + sh[2] + sh[3];
+    return base + inc - v;
+}
+
+__global__ void __launch_bounds__(256) plan_blocksum_kernel(PlanArgs a, int32_t* bsum, int nblk) {
+    __shared__ int sh[4];
+    const int k = blockIdx.y;
+    const int32_t* c = a.cnt + (size_t)k * (a.n + 1);
+    const int64_t base = (int64_t)blockIdx.x * PLAN_SCAN_ELEMS;
+    int s = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int64_t i = base + 256 * j + threadIdx.x;
+        s += i < a.n ? c[i] : 0;
+    }
+    int total;
+    (void)plan_block_scan256(s, sh, total);
+    if (threadIdx.x == 0) bsum[k * nblk + blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(256) plan_scan_kernel(PlanArgs a, const int32_t* bsum, int nblk) {
+    __shared__ int sh[4];
+    const int k = blockIdx.y;
+    int32_t* c = a.cnt + (size_t)k * (a.n + 1);
+    // sum of the block totals before this block (a few dozen values; every thread reads them all, broadcast loads)
+    int carry = 0;
+    for (int b = 0; b < (int)blockIdx.x; ++b) carry += bsum[k * nblk + b];
+    const int64_t base = (int64_t)blockIdx.x * PLAN_SCAN_ELEMS;
+    for (int j = 0; j < 8; ++j) {
+        const int64_t i = base + 256 * j + threadIdx.x;
+        const int v = i < a.n ? c[i] : 0;
+        int total;
+        const int ex = plan_block_scan256(v, sh, total);
+        if (i < a.n) { c[i] = carry + ex; a.rowptr[k][i] = carry + ex; }
+        carry += total;
         __syncthreads();
     }
-    int run = t ? part[t - 1] : 0;
-    for (int64_t i = lo; i < hi; ++i) {
-        const int v = c[i];
-        c[i] = run;                                     // cursor for the fill pass
-        a.rowptr[k][i] = run;
-        run += v;
-    }
-    if (t == 1023) a.rowptr[k][a.n] = part[1023];
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) a.rowptr[k][a.n] = carry;
 }
 
 // one thread per (array, atom): sort the segment, then the stored form of every entry
@@ -120,7 +154,7 @@ __global__ void __launch_bounds__(256) plan_sort_kernel(PlanArgs a) {
 using namespace mkgnn;
 
 extern "C" size_t mkgnn_plan_workspace_bytes(int64_t n_atoms, int64_t n_edges, int64_t n_rows) {
-    return (size_t)(3 * (n_atoms + 1) + n_rows + 2 * n_edges) * 4 + 1024;
+    return (size_t)(3 * (n_atoms + 1) + n_rows + 2 * n_edges + 3 * (n_atoms / PLAN_SCAN_ELEMS + 2)) * 4 + 1024;
 }
 
 extern "C" int mkgnn_plan_build(const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE], int64_t n_atoms, const int64_t* edge_index,
@@ -147,19 +181,22 @@ extern "C" int mkgnn_plan_build(const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGR
     a.edge_index = edge_index; a.n = n_atoms; a.m = n_edges; a.r = r;
     int32_t* w = (int32_t*)workspace;
     a.cnt = w; w += 3 * (n_atoms + 1);
+    const int nblk_scan = (int)((n_atoms + PLAN_SCAN_ELEMS - 1) / PLAN_SCAN_ELEMS);
+    int32_t* bsum = w; w += 3 * (nblk_scan > 0 ? nblk_scan : 1);
     a.tmp[0] = w; w += r; a.tmp[1] = w; w += n_edges; a.tmp[2] = w;
     a.rowptr[0] = scatter_rowptr; a.rowptr[1] = in_rowptr; a.rowptr[2] = out_rowptr;
     a.scatter_rows = scatter_rows; a.in_col = in_col; a.in_col_packed = in_col_packed; a.out_col = out_col; a.deg8 = deg8;
     hipStream_t st = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(a.cnt, 0, (size_t)3 * (n_atoms + 1) * 4, st);
-    if (e == hipSuccess && n_atoms > 0) e = hipMemsetAsync(deg8, 0, (size_t)n_atoms, st);
     if (e != hipSuccess) return api_hip_fail(who, e);
     int64_t work = r > n_edges ? r : n_edges;
+    if (n_atoms > work) work = n_atoms;
     for (int d = 0; d < 4; ++d) if (a.count[d] > work) work = a.count[d];
     if (n_atoms == 0) return 0;
     const unsigned grid = (unsigned)((work + 255) / 256);
     if (grid) plan_count_fill_kernel<false><<<grid, 256, 0, st>>>(a);
-    plan_scan_kernel<<<3, 1024, 0, st>>>(a);
+    plan_blocksum_kernel<<<dim3(nblk_scan, 3), 256, 0, st>>>(a, bsum, nblk_scan);
+    plan_scan_kernel<<<dim3(nblk_scan, 3), 256, 0, st>>>(a, bsum, nblk_scan);
     if (grid) plan_count_fill_kernel<true><<<grid, 256, 0, st>>>(a);
     plan_sort_kernel<<<(unsigned)((3 * n_atoms + 255) / 256), 256, 0, st>>>(a);
     e = hipGetLastError();

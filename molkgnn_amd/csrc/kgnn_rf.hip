@@ -103,6 +103,7 @@ __global__ void __launch_bounds__(256) rf_scan_kernel(int64_t nblk, RfWs w, int6
 
 struct RfOut {
     int64_t* sel[4]; int64_t* nei[4]; float* eattr[4]; float* pf[4]; float* pn[4];
+    float* eunit[4];     // optional: [rows, 8] unit-normalised bond rows (mkgnn_degree_bucket.nei_edge_unit), written with the raw ones
     int64_t cap[4];      // rows the caller allocated per bucket (ranks beyond it are dropped, never written)
 };
 
@@ -146,6 +147,20 @@ __global__ void __launch_bounds__(RF_BLOCK) rf_fill_kernel(const int64_t* __rest
         const float* src = eattr + (int64_t)(e[k] & ~1) * E;            // both directions of a bond share edge 2*(e/2)
         float* ea = o.eattr[b] + row * E;
         for (int c = 0; c < E; ++c) ea[c] = src[c];
+        if (o.eunit[b] && E <= 8) {
+            // the arithmetic of mkgnn_unit_rows8 (kgnn_fwd_stream.hip unit_rows8_kernel), so that the two agree bit for bit
+            float ev[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) ev[c] = c < E ? src[c] : 0.f;
+            float pq[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pq[c] = fmaf(ev[2 * c + 1], ev[2 * c + 1], ev[2 * c] * ev[2 * c]);
+            const float s2 = __fadd_rn(__fadd_rn(pq[0], pq[1]), __fadd_rn(pq[2], pq[3]));
+            const float ie = 1.f / fmaxf(sqrtf(s2), MKGNN_EPS);
+            float* eu = o.eunit[b] + row * 8;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) eu[c] = ev[c] * ie;
+        }
     }
 }
 
@@ -191,6 +206,7 @@ int mkgnn_rf_fill(const int64_t* edge_index, const float* p, const float* edge_a
     for (int k = 0; k < 4; ++k) {
         o.sel[k] = (int64_t*)out[k].selected_index; o.nei[k] = (int64_t*)out[k].nei_index;
         o.eattr[k] = (float*)out[k].nei_edge_attr; o.pf[k] = (float*)out[k].p_focal; o.pn[k] = (float*)out[k].nei_p;
+        o.eunit[k] = (float*)out[k].nei_edge_unit;
         o.cap[k] = out[k].count;
         if (out[k].count > 0 && (!o.sel[k] || !o.nei[k] || !o.eattr[k] || !o.pf[k] || !o.pn[k]))
             return api_fail("mkgnn_rf_fill: degree %d has %lld atoms but null outputs", k + 1, (long long)out[k].count);

@@ -25,6 +25,8 @@ import torch
 from .receptive_field import GraphBatch
 
 RAW_FIELDS = ("x", "p", "edge_index", "edge_attr", "batch", "y")
+PAD_MOLECULES = 64      # the padding atoms are dealt to this many padding molecules (a molecule is pooled by one wave: one
+                        # molecule of a thousand atoms would take as long as 40 real ones)
 
 
 def degree_histogram(batch: GraphBatch) -> List[int]:
@@ -73,32 +75,70 @@ def pad_batch(batch: GraphBatch, shape: Dict[str, int], num_molecules: int) -> G
     out.p = torch.cat([batch.p, torch.zeros(n_pad, batch.p.shape[1], dtype=batch.p.dtype, device=dev)])
     out.edge_index = torch.cat([batch.edge_index, pad_ei], dim=1)
     out.edge_attr = torch.cat([batch.edge_attr, pad_ea])
-    out.batch = torch.cat([batch.batch, torch.full((n_pad,), num_molecules, dtype=batch.batch.dtype, device=dev)])
+    # padding atoms -> PAD_MOLECULES padding molecules, contiguous runs (bonds between padding molecules are harmless: every
+    # padding row of the embedding is cut off)
+    pad_mol = num_molecules + (torch.arange(n_pad, device=dev) * PAD_MOLECULES // max(n_pad, 1)).to(batch.batch.dtype)
+    out.batch = torch.cat([batch.batch, pad_mol])
     out.y = batch.y
-    counts = torch.bincount(out.batch, minlength=num_molecules + 1)
-    ptr = torch.zeros(num_molecules + 2, dtype=torch.int32, device=dev)
+    counts = torch.bincount(out.batch, minlength=num_molecules + PAD_MOLECULES)
+    ptr = torch.zeros(num_molecules + PAD_MOLECULES + 1, dtype=torch.int32, device=dev)
     ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
     out.mol_ptr, out.atom_mol = ptr, out.batch.to(torch.int32)
     out.n_valid_atoms = torch.tensor([n_real], dtype=torch.int64, device=dev)
-    out.n_valid_molecules, out.num_graphs = num_molecules, num_molecules + 1
+    out.n_valid_molecules, out.num_graphs = num_molecules, num_molecules + PAD_MOLECULES
     out.bucket_sizes = [shape["n1"], shape["n2"], shape["n3"], shape["n4"]]
     assert out.x.shape[0] == shape["atoms"] and out.edge_index.shape[1] == shape["edges"]
     return out
 
 
+def _layout(batch: GraphBatch, fields):
+    """Byte offsets (256-aligned) of the fields inside one flat buffer."""
+    off, table = 0, []
+    for k in fields:
+        t = getattr(batch, k)
+        nbytes = t.numel() * t.element_size()
+        table.append((k, off, tuple(t.shape), t.dtype, nbytes))
+        off += (nbytes + 255) // 256 * 256
+    return table, off
+
+
+def pack(batch: GraphBatch) -> GraphBatch:
+    """Move the fields of a padded batch into ONE flat buffer (``batch.flat``; the fields become views of it), so that
+    loading it into the static buffers is a single device-to-device copy."""
+    table, total = _layout(batch, StaticBatch.FIELDS)
+    flat = torch.empty(total, dtype=torch.uint8, device=batch.x.device)
+    for k, off, shape, dtype, nbytes in table:
+        view = flat[off:off + nbytes].view(dtype).view(shape)
+        view.copy_(getattr(batch, k))
+        setattr(batch, k, view)
+    batch.flat = flat
+    return batch
+
+
 class StaticBatch:
     """Static device buffers of one fixed shape: ``load`` copies a padded batch in place (the tensors keep their addresses,
-    which is what a captured graph refers to); ``data`` is the object the model consumes."""
+    which is what a captured graph refers to); ``data`` is the object the model consumes.  The fields are views of one flat
+    buffer: a batch prepared with ``pack`` is loaded by a single copy."""
 
     FIELDS = ("x", "p", "edge_index", "edge_attr", "batch", "y", "mol_ptr", "atom_mol", "n_valid_atoms")
 
     def __init__(self, first: GraphBatch):
-        self.data = GraphBatch(**{k: getattr(first, k).clone() for k in self.FIELDS})
+        self.table, total = _layout(first, self.FIELDS)
+        self.flat = torch.empty(total, dtype=torch.uint8, device=first.x.device)
+        self.data = GraphBatch()
+        for k, off, shape, dtype, nbytes in self.table:
+            view = self.flat[off:off + nbytes].view(dtype).view(shape)
+            view.copy_(getattr(first, k))
+            setattr(self.data, k, view)
         self.data.n_valid_molecules, self.data.num_graphs = first.n_valid_molecules, first.num_graphs
         self.data.bucket_sizes = list(first.bucket_sizes)
 
     def load(self, padded: GraphBatch) -> None:
         if list(padded.bucket_sizes) != self.data.bucket_sizes or padded.n_valid_molecules != self.data.n_valid_molecules:
             raise ValueError("batch shape differs from the static buffers'")
+        flat = getattr(padded, "flat", None)
+        if flat is not None and flat.numel() == self.flat.numel():
+            self.flat.copy_(flat, non_blocking=True)
+            return
         for k in self.FIELDS:
             getattr(self.data, k).copy_(getattr(padded, k), non_blocking=True)

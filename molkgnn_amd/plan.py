@@ -33,7 +33,7 @@ def _as_f32(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 class Bucket:
     __slots__ = ("degree", "count", "sel", "nei", "e_nei", "p_focal", "nei_p", "_e_unit")
 
-    def __init__(self, degree, sel, nei, e_nei, p_focal, nei_p):
+    def __init__(self, degree, sel, nei, e_nei, p_focal, nei_p, e_unit=None):
         self.degree = degree
         self.count = int(sel.numel())
         self.sel = sel.contiguous().long()
@@ -43,7 +43,8 @@ class Bucket:
         self.e_nei = _as_f32(e_nei)
         self.p_focal = _as_f32(p_focal)
         self.nei_p = _as_f32(nei_p)
-        self._e_unit = None
+        # unit bond rows that came with the receptive fields (mkgnn_rf_fill writes them next to the raw ones)
+        self._e_unit = e_unit if (e_unit is not None and e_unit.numel() == self.count * degree * 8) else None
 
     def e_unit(self, E: int):
         """``[N_d * d, 8]`` unit-normalised bond attributes (``mkgnn_unit_rows8``), built once per batch: the bonds of a
@@ -194,11 +195,12 @@ class BatchPlan:
 
 
 def plan_from_lists(n_atoms, p_focal_list, nei_p_list, nei_edge_attr_list, selected_index_list, nei_index_list,
-                    edge_index=None) -> BatchPlan:
+                    edge_index=None, nei_edge_unit_list=None) -> BatchPlan:
     buckets = []
     for d in range(1, MAX_DEGREE + 1):
         buckets.append(Bucket(d, selected_index_list[d - 1], nei_index_list[d - 1], nei_edge_attr_list[d - 1],
-                              p_focal_list[d - 1], nei_p_list[d - 1]))
+                              p_focal_list[d - 1], nei_p_list[d - 1],
+                              None if nei_edge_unit_list is None else nei_edge_unit_list[d - 1]))
     return BatchPlan(n_atoms, buckets, edge_index)
 
 
@@ -208,7 +210,7 @@ _PLAN_CACHE_MAX = 32
 
 
 def plan_from_lists_cached(n_atoms, p_focal_list, nei_p_list, nei_edge_attr_list, selected_index_list, nei_index_list,
-                           edge_index=None) -> BatchPlan:
+                           edge_index=None, nei_edge_unit_list=None) -> BatchPlan:
     """``plan_from_lists`` memoised on the identity of the index, bond-attribute and coordinate tensors (address,
     length, device, in-place version AND the tensor objects themselves, held weakly).
 
@@ -234,7 +236,7 @@ def plan_from_lists_cached(n_atoms, p_focal_list, nei_p_list, nei_edge_attr_list
             return plan
         del _PLAN_CACHE[key]
     plan = plan_from_lists(n_atoms, p_focal_list, nei_p_list, nei_edge_attr_list, selected_index_list,
-                           nei_index_list, edge_index)
+                           nei_index_list, edge_index, nei_edge_unit_list)
     # build every index structure now: the lazy properties sort (and synchronise), which must not
     # happen inside a later backward pass or a hipGraph capture
     _ = plan.scatter
@@ -264,7 +266,8 @@ def plan_from_data(data) -> BatchPlan:
         [getattr(data, f"nei_edge_attr_deg{d}") for d in range(1, 5)],
         [getattr(data, f"selected_index_deg{d}") for d in range(1, 5)],
         [getattr(data, f"nei_index_deg{d}") for d in range(1, 5)],
-        getattr(data, "edge_index", None))
+        getattr(data, "edge_index", None),
+        [getattr(data, f"nei_edge_unit_deg{d}", None) for d in range(1, 5)])
     try:
         object.__setattr__(data, _PLAN_ATTR, (key, plan))
     except Exception:

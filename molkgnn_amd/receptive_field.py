@@ -132,11 +132,14 @@ def build_receptive_fields_hip(x: torch.Tensor, p: torch.Tensor, edge_index: tor
             nea = torch.empty((nd, d, E), dtype=torch.float32, device=dev)
             pfo = torch.empty((nd, 3), dtype=torch.float32, device=dev)
             pne = torch.empty((nd, d, 3), dtype=torch.float32, device=dev)
+            # the unit-normalised bond rows ride along (the kernel convolution keeps them per batch: plan.Bucket.e_unit)
+            neu = torch.empty((nd * d, 8), dtype=torch.float32, device=dev) if (ea.dim() == 2 and E <= 8) else None
             b = buckets[d - 1]
             b.count = nd
             b.selected_index, b.nei_index = sel.data_ptr(), nei.data_ptr()
             b.nei_edge_attr, b.p_focal, b.nei_p = nea.data_ptr(), pfo.data_ptr(), pne.data_ptr()
-            raw[d] = (sel, nei, nea, pfo, pne)
+            b.nei_edge_unit = _lib.ptr(neu)
+            raw[d] = (sel, nei, nea, pfo, pne, neu)
         _lib.check(lib.mkgnn_rf_fill(_lib.ptr(ei), pf.data_ptr(), _lib.ptr(ea), n, m, E, ws.data_ptr(), buckets, st),
                    "mkgnn_rf_fill")
         for d in range(1, MAX_DEGREE + 1):
@@ -147,7 +150,9 @@ def build_receptive_fields_hip(x: torch.Tensor, p: torch.Tensor, edge_index: tor
                 out[f"selected_index_deg{d}"] = torch.zeros((0,), dtype=torch.long, device=dev)
                 out[f"nei_index_deg{d}"] = torch.zeros((0,), dtype=torch.long, device=dev)
                 continue
-            sel, nei, nea, pfo, pne = raw[d]
+            sel, nei, nea, pfo, pne, neu = raw[d]
+            if neu is not None and edge_attr.dtype == torch.float32:
+                out[f"nei_edge_unit_deg{d}"] = neu
             out[f"p_focal_deg{d}"] = pfo.to(p.dtype)
             out[f"nei_p_deg{d}"] = pne.to(p.dtype)
             out[f"nei_edge_attr_deg{d}"] = nea.to(edge_attr.dtype) if ea.dim() == 2 else nea.to(edge_attr.dtype).reshape(sel.numel(), d)
