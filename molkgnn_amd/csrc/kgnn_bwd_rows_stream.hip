@@ -12,8 +12,9 @@
 // rows in B-operand order (kernel k, feature j) in 28 (D + 1) VGPRs for the whole launch; nothing is gathered (the
 // product needs no feature rows at all) and the inner loop is matrix instructions only.  A wave's result is the partial
 // sum over ITS kernels: the NS waves that hold a degree's NS column tiles exchange the partial tiles through LDS
-// (register-order images, conflict-free 16-byte accesses), each adds up a share of the feature tiles in a fixed order
-// and stores it -- bit-reproducible, no float atomics.  The coefficient inputs of a tile (dL/dsc through the focal ids,
+// (row-major images, laid out like the contribution rows), each adds up a share of the ATOMS in a fixed order and
+// stores whole 16-byte chunks of those rows -- bit-reproducible, no float atomics, 4 store instructions per slot
+// instead of 14 scattered 4-byte ones.  The coefficient inputs of a tile (dL/dsc through the focal ids,
 // permutation ids, chirality signs) are ordinary loads issued one tile ahead, the focal ids two.
 //
 // Covered shapes: the streamed forward's (F in (16 (KC - 1), 16 KC], exactly NS(d) = 1 / 2 / 2 / 4 column tiles).
@@ -81,8 +82,9 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
     const int ci = lane & 15, kq = lane >> 4;
     const int L = dg.L, kpt = dg.kpt;
     const int ct = role;
-    // exchange images: [stream][parity][role][t][lane] x 16 bytes
-    float* const xbuf = lds + (size_t)stream * (2 * NS * KC * 256);
+    // exchange images: [stream][parity][role][atom 16][FP floats] (row-major, like the contribution rows)
+    constexpr int RS = FP + 4;                  // LDS row stride (keeps the 4-byte writes of a quad off one bank, rows 16-byte aligned)
+    float* const xbuf = lds + (size_t)stream * (2 * NS * 16 * RS);
 
     const int64_t ntiles = (dg.n + 15) / 16;
     const int64_t nstreams = (int64_t)count * NSTREAM;
@@ -181,37 +183,39 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
                     }
                 }
             }
-            // ---- sum over the column tiles (waves of the stream), then the contribution rows: lane holds atoms
-            // kq * 4 + r, feature 16 t + ci
-            auto store_tile = [&](int t, const f32x4& v) {
-                if (16 * t + ci < a.F) {
+            // ---- sum over the column tiles (waves of the stream) and write the contribution rows.  A scattered 4-byte
+            // store instruction costs a wave 100 - 250 cycles here (measured in the forward), and the product would issue
+            // 14 of them per slot: instead every wave writes its partial tile into LDS as ROWS ([atom][FP] floats, the
+            // layout of the contribution rows themselves), and after the barrier each wave adds up the NS images of its
+            // share of the atoms 16 bytes at a time and stores whole 16-byte chunks of contiguous 448-byte rows.
+            float* const mine = xbuf + (size_t)((par * NS + role) * 16) * RS;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int64_t nn = tile * 16 + kq * 4 + r;
-                        if (real && nn < dg.n) dg.contrib[(size_t)(dg.contrib_base + nn * S1 + s) * a.CS + 16 * t + ci] = v[r];
+            for (int t = 0; t < KC; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mine[(kq * 4 + r) * RS + 16 * t + ci] = acc[t][r];
+            if constexpr (NS > 1) __syncthreads();
+            else __builtin_amdgcn_wave_barrier();        // (own image: LDS accesses of one wave are ordered)
+            {
+                constexpr int APW = 16 / NS;             // atoms this wave finishes
+                constexpr int CPR = FP / 4;              // 16-byte chunks per row
+                const float* const img = xbuf + (size_t)(par * NS * 16) * RS;
+                const int F4 = (a.F + 3) / 4;            // chunks that hold row data (CS = F rounded up to 4: the row's own padding)
+#pragma unroll
+                for (int c0 = 0; c0 < APW * CPR; c0 += 64) {
+                    const int c = c0 + lane;
+                    const int al = c / CPR, ch = c - al * CPR;       // atom (local), chunk
+                    const int atom = role * APW + al;
+                    if (c < APW * CPR && ch < F4) {
+                        f32x4 v = *(const f32x4*)(img + (size_t)atom * RS + 4 * ch);
+#pragma unroll
+                        for (int w = 1; w < NS; ++w) v += *(const f32x4*)(img + (size_t)(w * 16 + atom) * RS + 4 * ch);
+                        const int64_t nn = tile * 16 + atom;
+                        if (real && nn < dg.n)
+                            *(f32x4*)(dg.contrib + (size_t)(dg.contrib_base + nn * S1 + s) * a.CS + 4 * ch) = v;
                     }
                 }
-            };
-            if constexpr (NS == 1) {
-#pragma unroll
-                for (int t = 0; t < KC; ++t) store_tile(t, acc[t]);
-            } else {
-                float* const mine = xbuf + (size_t)((par * NS + role) * KC) * 256 + lane * 4;
-#pragma unroll
-                for (int t = 0; t < KC; ++t) *(f32x4*)(mine + t * 256) = acc[t];
-                __syncthreads();
-                static_for<0, KC>([&](auto tc) {
-                    constexpr int t = decltype(tc)::value;
-                    if (t % NS == role) {                // (wave-uniform)
-                        const float* src = xbuf + (size_t)(par * NS * KC + t) * 256 + lane * 4;
-                        f32x4 v = *(const f32x4*)src;
-#pragma unroll
-                        for (int w = 1; w < NS; ++w) v += *(const f32x4*)(src + (size_t)w * KC * 256);
-                        store_tile(t, v);
-                    }
-                });
-                par ^= 1;
             }
+            par ^= 1;
         });
     }
 }
@@ -309,7 +313,7 @@ hipError_t launch_backward_rows_stream(const BwdArgs a4[4], const bool use[4], h
         for (int b = 0; b < nb; ++b) a.blk_rank[b] = (uint16_t)next[a.blk_group[b]][b & 7]++;
     }
     for (int g = 0; g < ng; ++g) a.grp_count[g] = (uint16_t)count[g];
-    const size_t lds_bytes = (size_t)4 * 2 * KC * 256 * 4;       // NSTREAM * NS = 4 wave images, two parities
+    const size_t lds_bytes = (size_t)4 * 2 * 16 * (16 * KC + 4) * 4;      // NSTREAM * NS = 4 wave images of 16 rows, two parities
     if (KC == 2) kc_backward_rows_stream<2><<<nb, 256, lds_bytes, st>>>(a);
     else kc_backward_rows_stream<7><<<nb, 256, lds_bytes, st>>>(a);
     return hipGetLastError();

@@ -92,7 +92,7 @@ template <int D, int A> __device__ __forceinline__ int perm_entry(int p) {
 // Diagnostic build (make STAMPS=1): per-wave cycle totals of the loop's phases -- multiply, counted wait, barrier, DMA issue,
 // epilogue -- in stamps[4..8] (tools/stream_stamps.py).  Each s_memtime read costs an lgkmcnt(0) at a phase boundary.
 #ifdef MKGNN_FWD_STAMPS
-#define MKGNN_PHASE(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); phase[i] += t_ - t_phase; t_phase = t_; } while (0)
+#define MKGNN_PHASE(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); phase[i] += t_ - t_phase; t_phase = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define MKGNN_PHASE(i) do { } while (0)
 #endif
@@ -300,7 +300,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
 
     int buf = 0;                                         // ring buffer of the current step
 #ifdef MKGNN_FWD_STAMPS
-    unsigned long long phase[5] = {0, 0, 0, 0, 0}, t_phase = __builtin_readcyclecounter();
+    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_phase = __builtin_readcyclecounter();
 #endif
     for (int64_t it = 0; it < iters; ++it) {
         const int64_t tile = tile_at(it);
@@ -441,6 +441,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
             if constexpr (HS) cen4[j] = (half ? pcc[j] : cc[j]) * mrec[T::OFF_INV + D * 16 + kq * 4 + jj];
             else cen4[j] = cc[j] * inv4[D][j];
         }
+        MKGNN_PHASE(5);
         uint32_t signw = 0, eqw = 0;
         if constexpr (D == 4) {
             signw = __float_as_uint(mrec[T::OFF_SIGN + kq]);
@@ -486,6 +487,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
                 ed4[j][s] = v;
             }
         });
+        MKGNN_PHASE(6);
         const f32x4 focal4 = *(const f32x4*)(mrec + T::OFF_FOCAL + kq * 4);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -495,7 +497,11 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
 #pragma unroll
             for (int s = 1; s < D; ++s) ed = __fadd_rn(ed, ed4[j][s]);
             ed = div_by<D>(ed);
+#ifdef MKGNN_ABLATE_DIV                                  // (timing experiment)
+            float sc = __fadd_rn(__fadd_rn(__fmul_rn(best4[j], ws), __fmul_rn(cen4[j], wc)), __fmul_rn(ed, we)) * wsum;
+#else
             float sc = __fadd_rn(__fadd_rn(__fmul_rn(best4[j], ws), __fmul_rn(cen4[j], wc)), __fmul_rn(ed, we)) / wsum;
+#endif
             float ch = 1.f;
             if constexpr (D == 4) {
                 const int eqb = (int)((eqw >> (8 * jj)) & 0xFFu);
@@ -506,7 +512,12 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
             uint32_t focal;
             if constexpr (HS) focal = __float_as_uint(half ? focal4[2 + j] : focal4[j]);
             else focal = __float_as_uint(focal4[j]);
+#ifdef MKGNN_ABLATE_STORES                               // (timing experiment: everything computed, nothing stored)
+            asm volatile("" :: "v"(sc), "v"(ed), "v"(ch), "v"(focal), "v"(best4[j]), "v"(cen4[j]), "v"(idx4[j]));
+            if (false) {
+#else
             if (real && col_ok && n < dg.n) {
+#endif
                 a.out[focal * (uint32_t)a.os + (uint32_t)(dg.off + lcol)] = sc;     // (the host checks n_atoms * stride < 2^30)
                 const uint32_t o = (uint32_t)n * (uint32_t)L + (uint32_t)lcol;   // the host fuses a degree only if 3 * N_d * L < 2^32
                 if (dg.best) dg.best[o] = (uint8_t)idx4[j];
@@ -526,7 +537,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
         unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 16;
         o[0] = t_start; o[1] = __builtin_readcyclecounter(); o[2] = (unsigned long long)(D * 16 + cp); o[3] = (unsigned long long)iters;
 #ifdef MKGNN_FWD_STAMPS
-        for (int i = 0; i < 5; ++i) o[4 + i] = phase[i];
+        for (int i = 0; i < 8; ++i) o[4 + i] = phase[i];
 #endif
     }
 }

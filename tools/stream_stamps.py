@@ -47,6 +47,7 @@ for g in sorted(set(s[:, 2].tolist())):
     life = (end - start).float()
     print(f"degree {g // 16} part {g % 16}: {m.shape[0]:4d} waves, {int(m[0, 3])} iterations; start {int(start.min())}..{int(start.max())}; "
           f"lifetime mean {life.mean():.0f} max {life.max():.0f}")
-    if int(m[:, 4:9].sum()) > 0:                     # make STAMPS=1: cycles per phase, mean over the group's waves
-        ph = m[:, 4:9].float().mean(dim=0).tolist()
-        print("        multiply %.0f  counted wait %.0f  barrier %.0f  DMA issue %.0f  epilogue %.0f" % tuple(ph))
+    if int(m[:, 4:12].sum()) > 0:                    # make STAMPS=1: cycles per phase, mean over the group's waves
+        ph = m[:, 4:12].float().mean(dim=0).tolist()
+        print("        multiply %.0f  counted wait %.0f  barrier %.0f  DMA issue %.0f  epilogue: scan %.0f  bonds %.0f  mix+stores %.0f" %
+              (ph[0], ph[1], ph[2], ph[3], ph[5], ph[6], ph[4]))
