@@ -363,12 +363,12 @@ def main():
         lib.mkgnn_debug_last_fused_forward_ms.restype = ctypes.c_float
         saved_state = True    # the training configuration: permutation ids and scores are written too
         for _ in range(3):
-            Fn.kernelsetconv_details(h, plan, False, params, E, args.variant)
+            Fn.kernelsetconv_details(h, plan, False, params, E, args.variant, raw=True)
         # (a) the whole forward call: row norms + bank preparation + output memset + the fused kernel
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
         for _ in range(args.roofline_reps):
-            Fn.kernelsetconv_details(h, plan, False, params, E, args.variant)
+            Fn.kernelsetconv_details(h, plan, False, params, E, args.variant, raw=True)
         ev1.record()
         torch.cuda.synchronize()
         ms_call = ev0.elapsed_time(ev1) / args.roofline_reps
@@ -377,7 +377,7 @@ def main():
         if args.variant != "generic":                # (the generic kernels have no fused launch to bracket)
             lib.mkgnn_debug_time_fused_forward(1)
             for _ in range(args.roofline_reps):
-                Fn.kernelsetconv_details(h, plan, False, params, E, args.variant)
+                Fn.kernelsetconv_details(h, plan, False, params, E, args.variant, raw=True)
                 samples.append(float(lib.mkgnn_debug_last_fused_forward_ms()))
             lib.mkgnn_debug_time_fused_forward(0)
         ms = sum(samples) / len(samples) if samples and min(samples) > 0 else ms_call

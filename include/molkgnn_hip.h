@@ -38,7 +38,7 @@ extern "C" {
 #endif
 
 #define MKGNN_MAX_DEGREE 4
-#define MKGNN_ABI_VERSION 2
+#define MKGNN_ABI_VERSION 3
 
 /* One KernelConv's parameters (reference kernels.py:50-84).  The three score
  * weights are the 0-d parameters support_attr_sc_weight, center_attr_sc_weight
@@ -84,8 +84,11 @@ typedef struct mkgnn_degree_bucket {
 
 /* What forward keeps for backward, per degree (caller-allocated). */
 typedef struct mkgnn_saved {
-    uint8_t* best_index;              /* [N_d, L_d] chosen permutation (kernels.py:373); may be NULL */
-    float* scores;                    /* [3, N_d, L_d] support / centre / edge scores; may be NULL   */
+    float* pair_state;                /* [N_d, L_d, 4] per (atom, kernel) pair, one 16-byte record: the support score of
+                                         the chosen permutation, the centre score, the edge score (kernels.py:357-373,
+                                         386-395) and the chosen permutation's index (the bits of an int32).  One record
+                                         is one 16-byte store in the forward and one 16-byte load in the backward;
+                                         may be NULL (nothing is kept) */
     int8_t* chirality;                /* [N_d, L_d] +1/-1 (d = 4, last layer); may be NULL           */
 } mkgnn_saved;
 

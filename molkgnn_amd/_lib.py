@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MKGNN_LIB: a diagnostic build of the same library (make VARIANT=... in csrc/), e.g. with cycle stamps compiled in
 LIB_PATH = os.environ.get("MKGNN_LIB") or os.path.join(_HERE, "libmolkgnn_hip.so")
 MAX_DEGREE = 4
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class KernelBank(C.Structure):
@@ -39,7 +39,7 @@ class DegreeBucket(C.Structure):
 
 
 class Saved(C.Structure):
-    _fields_ = [("best_index", C.c_void_p), ("scores", C.c_void_p), ("chirality", C.c_void_p)]
+    _fields_ = [("pair_state", C.c_void_p), ("chirality", C.c_void_p)]
 
 
 class ReadoutParams(C.Structure):

@@ -46,7 +46,6 @@ __global__ void __launch_bounds__(256) kc_backward_rows_lds(BwdArgs a) {
     const float ws_n = w_s / w_sum / (float)D;
     const float ratio_c = w_c * (float)D / w_s;
     const int64_t ntiles = (a.n + TA - 1) / TA;
-    const size_t ln = (size_t)L * a.n;
     const bool act = 2 * lane < FP;
     float p0 = 0.f, p1 = 0.f, p2 = 0.f;
 
@@ -70,10 +69,9 @@ __global__ void __launch_bounds__(256) kc_backward_rows_lds(BwdArgs a) {
                 float g = a.gout[(int64_t)idbuf[buf * TA + i] * a.gs + a.off + l];
                 if (a.chir) g *= (float)a.chir[(size_t)n * L + l];
                 rg[k] = g;
-                ridx[k] = a.best[(size_t)n * L + l];
-                rS[k] = a.scores[(size_t)n * L + l];
-                rC[k] = a.scores[ln + (size_t)n * L + l];
-                rE[k] = a.scores[2 * ln + (size_t)n * L + l];
+                const mkgnn_f32x4 rec = pair_load(a.pair, (size_t)n * L + l);
+                rS[k] = rec[0]; rC[k] = rec[1]; rE[k] = rec[2];
+                ridx[k] = pair_index(rec);
             }
         }
     };
@@ -237,11 +235,10 @@ __device__ __forceinline__ void bank_body(const BwdArgs& a, const int vblock, co
     f32x4 stage[MAXQ];
     float rg[CQ], rS[CQ], rC[CQ], rE[CQ];
     int ridx[CQ], rch[CQ];
-    const size_t ln = (size_t)L * a.n;
     float p0 = 0.f, p1 = 0.f, p2 = 0.f;              // score-weight partials (when the rows kernel leaves them to us)
     float ev;                                        // one bond component per thread: (atom, slot) = tid / 8, k = tid % 8
     static_assert(TA * D * 8 <= NT, "one bond component per thread");
-    const int8_t* chp = a.chir ? a.chir : (const int8_t*)a.best;      // always loadable; ignored when there are no signs
+    const int8_t* chp = a.chir ? a.chir : (const int8_t*)a.pair;      // always loadable; ignored when there are no signs
     // fetch() only ISSUES loads (unconditional, clamped addresses) and leaves the raw values in registers;
     // every use of a loaded value -- column masks, validity masks, products -- is in the staging code at the
     // top of the next iteration, and there is no branch in here: a use, or the end of a conditional block
@@ -264,13 +261,12 @@ __device__ __forceinline__ void bank_body(const BwdArgs& a, const int vblock, co
             int64_t n = tile * TA + i;
             if (n >= a.n) n = a.n - 1;
             rg[k] = a.gout[(int64_t)idbuf[buf * NROW + i * (D + 1) + D] * a.gs + a.off + l];
-            ridx[k] = a.best[(size_t)n * L + l];
+            const mkgnn_f32x4 rec = pair_load(a.pair, (size_t)n * L + l);
+            ridx[k] = pair_index(rec);
             rch[k] = chp[(size_t)n * L + l];
             // the three cosine scores feed d sc / d theta_k = w_k (score_k - sc) / W  (SURVEY 8 a-9); this kernel visits
             // every (atom, kernel) pair exactly once, with one thread per pair: the cheapest place to sum them
-            rS[k] = a.scores[(size_t)n * L + l];
-            rC[k] = a.scores[ln + (size_t)n * L + l];
-            rE[k] = a.scores[2 * ln + (size_t)n * L + l];
+            rS[k] = rec[0]; rC[k] = rec[1]; rE[k] = rec[2];
         }
         {
             const int t = (tid >> 3) < TA * D ? (tid >> 3) : TA * D - 1, k = tid & 7;

@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(NT, 2) kc_backward_rows_mfma(BwdArgs a) {
         const int64_t n = tile * 16 + ci;
         return a.sel[n < a.n ? n : a.n - 1];
     };
-    const int8_t* chp = a.chir ? a.chir : (const int8_t*)a.best;      // always loadable; ignored when there are no signs
+    const int8_t* chp = a.chir ? a.chir : (const int8_t*)a.pair;      // always loadable; ignored when there are no signs
     auto issue = [&](int64_t tile, int64_t focal, float (&g)[LQ], int (&ix)[LQ], int (&ch)[LQ]) {
         const int64_t n = tile * 16 + ci;
         const int64_t nc = n < a.n ? n : a.n - 1;
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(NT, 2) kc_backward_rows_mfma(BwdArgs a) {
         for (int kk = 0; kk < LQ; ++kk) {
             const int l = 4 * kk + kq < L ? 4 * kk + kq : L - 1;
             g[kk] = a.gout[focal * a.gs + a.off + l];
-            ix[kk] = a.best[(size_t)nc * L + l];
+            ix[kk] = pair_index(a.pair, (size_t)nc * L + l);
             ch[kk] = chp[(size_t)nc * L + l];
         }
     };

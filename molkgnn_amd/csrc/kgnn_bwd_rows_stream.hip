@@ -53,7 +53,7 @@ __host__ __device__ constexpr int column_tiles(int d) { return d == 1 ? 1 : (d =
 
 struct RowsStreamDeg {
     const int64_t* sel;
-    const uint8_t* best; const int8_t* chir;
+    const float* pair; const int8_t* chir;
     const float* padded; const float* mix;
     float* contrib; int64_t contrib_base;
     int64_t n;
@@ -116,7 +116,7 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
     const float w_s = dg.mix[0], w_c = dg.mix[1], w_sum = dg.mix[3];
     const float ws_n = w_s / w_sum / (float)D;
     const float ratio_c = w_c * (float)D / w_s;
-    const int8_t* const chp = dg.chir ? dg.chir : (const int8_t*)dg.best;        // always loadable; ignored without signs
+    const int8_t* const chp = dg.chir ? dg.chir : (const int8_t*)dg.pair;        // always loadable; ignored without signs
 
     // coefficient inputs of a tile for this lane: atom ci, kernels 4 q + kq of the wave's column tile (clamped, masked later)
     float rg[4];
@@ -133,7 +133,7 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
             const int l = ct * kpt + 4 * q + kq;
             const int lc = l < L ? l : L - 1;
             rg[q] = a.gout[focal * a.gs + dg.off + lc];
-            ridx[q] = dg.best[(size_t)nc * L + lc];
+            ridx[q] = pair_index(dg.pair, (size_t)nc * L + lc);
             rch[q] = chp[(size_t)nc * L + lc];
         }
     };
@@ -257,7 +257,7 @@ hipError_t launch_backward_rows_stream(const BwdArgs a4[4], const bool use[4], h
         a.gout = s.gout; a.gs = s.gs; a.F = s.F; a.CS = s.CS;
         KC = mfma_padded_width(s.F) / 16;
         RowsStreamDeg& g = a.deg[i];
-        g.sel = s.sel; g.best = s.best; g.chir = s.chir; g.padded = s.padded; g.mix = s.mix;
+        g.sel = s.sel; g.pair = s.pair; g.chir = s.chir; g.padded = s.padded; g.mix = s.mix;
         g.contrib = s.contrib; g.contrib_base = s.contrib_base;
         g.n = s.n; g.L = s.L; g.off = s.off;
         const int nct = rs::column_tiles(d);

@@ -124,7 +124,7 @@ template <int D, int KC> constexpr int young_batches(int s, int role) {
 
 struct BankStreamDeg {
     const int64_t* sel; const int64_t* nei; const float* e_unit;
-    const uint8_t* best; const float* scores; const int8_t* chir;
+    const float* pair; const int8_t* chir;
     const float* mix;
     float* coefq;            // [ntiles][nct][512]: g tile, idx tile
     float* slab;             // [chunks][bank_floats]
@@ -160,8 +160,7 @@ __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
     const int64_t nrec = ((g.n + 15) / 16) * g.nct;
     const int atom = tid >> 4, k = tid & 15;
     const float w_s = g.mix[0], w_c = g.mix[1], w_e = g.mix[2], w_sum = g.mix[3];
-    const size_t ln = (size_t)g.L * g.n;
-    const int8_t* chp = g.chir ? g.chir : (const int8_t*)g.best;      // always loadable
+    const int8_t* chp = g.chir ? g.chir : (const int8_t*)g.pair;      // always loadable
     // all loads of the block's records first (clamped addresses), then the arithmetic
     float gv[PREP_RPB], S[PREP_RPB], C[PREP_RPB], Ed[PREP_RPB];
     int idx[PREP_RPB], ch[PREP_RPB];
@@ -189,9 +188,10 @@ __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
         const int l = ct * g.kpt + k, lc = l < g.L ? l : g.L - 1;
         const size_t o = (size_t)nc * g.L + lc;
         gv[r] = a.gout[focal[r] * a.gs + g.off + lc];
-        idx[r] = g.best[o];
+        const mkgnn_f32x4 pr = pair_load(g.pair, o);
+        idx[r] = pair_index(pr);
         ch[r] = chp[o];
-        S[r] = g.scores[o]; C[r] = g.scores[ln + o]; Ed[r] = g.scores[2 * ln + o];
+        S[r] = pr[0]; C[r] = pr[1]; Ed[r] = pr[2];
     }
     float p0 = 0.f, p1 = 0.f, p2 = 0.f;
 #pragma unroll
@@ -540,7 +540,7 @@ hipError_t launch_backward_bank_stream(const BwdArgs a4[4], const bool use[4], c
         a.x = s.x; a.xs = s.xs; a.inv = s.inv; a.gout = s.gout; a.gs = s.gs; a.F = s.F; a.E = s.E;
         KC = mfma_padded_width(s.F) / 16;
         BankStreamDeg& g = a.deg[i];
-        g.sel = s.sel; g.nei = s.nei; g.e_unit = e_unit[i]; g.best = s.best; g.scores = s.scores; g.chir = s.chir; g.mix = s.mix;
+        g.sel = s.sel; g.nei = s.nei; g.e_unit = e_unit[i]; g.pair = s.pair; g.chir = s.chir; g.mix = s.mix;
         g.coefq = coefq[i]; g.slab = s.slab; g.theta_slab = s.theta_slab;
         g.n = s.n; g.L = s.L; g.off = s.off;
         g.nct = d == 1 ? 1 : (d == 4 ? 4 : 2);

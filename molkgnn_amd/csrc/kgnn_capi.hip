@@ -234,7 +234,7 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
     int groups[4], total_groups = 0;
     for (int i = 0; i < 4; ++i) {
         // (the fused kernel indexes the saved planes [3, N_d, L] with 32-bit offsets)
-        const bool small = (uint64_t)buckets[i].count * (uint64_t)L[i] * 3ull < (1ull << 32);
+        const bool small = (uint64_t)buckets[i].count * (uint64_t)L[i] < (1ull << 32);     // (pair offsets are 32-bit)
         fuse[i] = buckets[i].count > 0 && L[i] > 0 && variant != 1 && aligned && small && mfma_forward_supported(i + 1, F, E, L[i]);
         groups[i] = fuse[i] ? fused_group_count(i + 1, F, L[i]) : 0;
         total_groups += groups[i];
@@ -260,8 +260,7 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
         a.padded = (const float*)(ws + w.bank[i].padded); a.edge_padded = (const float*)(ws + w.bank[i].edge_padded);
         a.n_atoms = n_atoms;
         a.out = out; a.os = out_stride; a.off = off; a.K = K;
-        a.best = saved ? saved[i].best_index : nullptr;
-        a.scores = saved ? saved[i].scores : nullptr;
+        a.pair = saved ? saved[i].pair_state : nullptr;
         a.chir_out = (saved && d == 4 && is_last_layer) ? saved[i].chirality : nullptr;
         off += L[i];
         if (a.n == 0 || a.L == 0) continue;
@@ -275,7 +274,7 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
             g.padded = a.padded; g.edge_padded = a.edge_padded; g.chir = a.chir; g.mix = a.mix;
             g.eqflag = (const int8_t*)(ws + w.eqflag);
             g.signflag = (const int8_t*)(ws + w.signflag);
-            g.best = a.best; g.scores = a.scores; g.chir_out = a.chir_out;
+            g.pair = a.pair; g.chir_out = a.chir_out;
             g.n = a.n; g.L = a.L; g.off = a.off;
             use[i] = true;
             any_fused = true;
@@ -356,7 +355,7 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         const int64_t base = base_of[i];
         hipStream_t dst = fj.stream(fj.two_way ? 0 : slot_of[i], &e);
         if (e != hipSuccess) return hip_fail("stream fork", e);
-        if (buckets[i].count > 0 && L[i] > 0 && (!saved[i].best_index || !saved[i].scores))
+        if (buckets[i].count > 0 && L[i] > 0 && !saved[i].pair_state)
             return fail("%s: degree %d has no saved forward state", who, d);
         BwdArgs a;
         a.x = x; a.xs = x_stride; a.inv = inv_norm;
@@ -365,7 +364,7 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         a.cen = (const float*)(ws + w.bank[i].cen); a.sup = (const float*)(ws + w.bank[i].sup);
         a.edg = (const float*)(ws + w.bank[i].edg); a.mix = (const float*)(ws + w.bank[i].mix);
         a.gout = grad_out; a.gs = grad_out_stride; a.off = off;
-        a.best = saved[i].best_index; a.scores = saved[i].scores;
+        a.pair = saved[i].pair_state;
         a.chir = (d == 4 && is_last_layer) ? saved[i].chirality : nullptr;
         if (d == 4 && is_last_layer && buckets[i].count > 0 && !a.chir)
             return fail("%s: degree-4 chirality signs were not saved", who);

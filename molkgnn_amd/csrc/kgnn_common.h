@@ -54,6 +54,17 @@ template <int D> __device__ __forceinline__ float div_by(float x) {
 
 typedef float mkgnn_f32x4 __attribute__((ext_vector_type(4)));
 
+// What the forward keeps of an (atom, kernel) pair for the backward (mkgnn_saved.pair_state): one 16-byte record
+// {support score of the chosen permutation, centre score, edge score, index of the chosen permutation (int bits)} at
+// pair o = n * L + l.  One store in the forward, one load in the backward (four scattered 4-byte accesses cost a wave
+// several hundred cycles of issue time, measured in the streamed forward's epilogue).
+__device__ __forceinline__ void pair_store(float* pair, size_t o, float S, float C, float Ed, int idx) {
+    *(mkgnn_f32x4*)(pair + 4 * o) = mkgnn_f32x4{S, C, Ed, __int_as_float(idx)};
+}
+__device__ __forceinline__ mkgnn_f32x4 pair_load(const float* pair, size_t o) { return *(const mkgnn_f32x4*)(pair + 4 * o); }
+__device__ __forceinline__ int pair_index(const float* pair, size_t o) { return __float_as_int(pair[4 * o + 3]); }
+__device__ __forceinline__ int pair_index(mkgnn_f32x4 rec) { return __float_as_int(rec[3]); }
+
 // Copy `n4` 16-byte chunks global -> LDS with `dst_of(q)` giving the destination chunk index;
 // eight loads in flight per thread (a plain one-at-a-time loop serialises on the load latency).
 template <typename DstOf>

@@ -519,14 +519,8 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
             if (real && col_ok && n < dg.n) {
 #endif
                 a.out[focal * (uint32_t)a.os + (uint32_t)(dg.off + lcol)] = sc;     // (the host checks n_atoms * stride < 2^30)
-                const uint32_t o = (uint32_t)n * (uint32_t)L + (uint32_t)lcol;   // the host fuses a degree only if 3 * N_d * L < 2^32
-                if (dg.best) dg.best[o] = (uint8_t)idx4[j];
-                if (dg.scores) {
-                    const uint32_t ln = (uint32_t)L * (uint32_t)dg.n;
-                    dg.scores[o] = best4[j];
-                    dg.scores[ln + o] = cen4[j];
-                    dg.scores[2u * ln + o] = ed;
-                }
+                const uint32_t o = (uint32_t)n * (uint32_t)L + (uint32_t)lcol;   // the host fuses a degree only if N_d * L < 2^32
+                if (dg.pair) pair_store(dg.pair, o, best4[j], cen4[j], ed, idx4[j]);     // one 16-byte record per pair
                 if (dg.chir_out) dg.chir_out[o] = (int8_t)ch;
             }
         }

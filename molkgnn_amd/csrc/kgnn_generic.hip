@@ -228,13 +228,7 @@ __global__ void __launch_bounds__(256) kc_forward_generic(FwdArgs a) {
                 sc *= ch;
             }
             a.out[focal * a.os + a.off + l] = sc;
-            if (a.best) a.best[(size_t)n * a.L + l] = (uint8_t)idx;
-            if (a.scores) {
-                size_t ln = (size_t)a.L * a.n;
-                a.scores[(size_t)n * a.L + l] = best;
-                a.scores[ln + (size_t)n * a.L + l] = cc;
-                a.scores[2 * ln + (size_t)n * a.L + l] = ed;
-            }
+            if (a.pair) pair_store(a.pair, (size_t)n * a.L + l, best, cc, ed, idx);
             if (a.chir_out) a.chir_out[(size_t)n * a.L + l] = (int8_t)ch;
         }
     }
@@ -260,7 +254,7 @@ __global__ void __launch_bounds__(256) kc_backward_rows(BwdArgs a) {
             for (int l = 0; l < a.L; ++l) {
                 float g = a.gout[focal * a.gs + a.off + l];
                 if (a.chir) g *= (float)a.chir[(size_t)n * a.L + l];
-                const int idx = a.best[(size_t)n * a.L + l];
+                const int idx = pair_index(a.pair, (size_t)n * a.L + l);
                 if (f < a.F) {
                     acc[0] = fmaf(g * wc, a.cen[(size_t)l * a.F + f], acc[0]);
                     const float gsup = g * ws / (float)D;
@@ -297,14 +291,13 @@ __global__ void __launch_bounds__(128) kc_backward_bank(BwdArgs a) {
     if (r == nrow) {
         // score-weight partials: d sc / d theta_k = w_k (score_k - sc) / W  
         float p0 = 0.f, p1 = 0.f, p2 = 0.f;
-        const size_t ln = (size_t)L * a.n;
         for (int64_t n = lo; n < hi; ++n) {
             const int64_t focal = a.sel[n];
             for (int l = threadIdx.x; l < L; l += blockDim.x) {
                 float g = a.gout[focal * a.gs + a.off + l];
                 if (a.chir) g *= (float)a.chir[(size_t)n * a.L + l];
-                float S = a.scores[(size_t)n * L + l], C = a.scores[ln + (size_t)n * L + l],
-                      Ed = a.scores[2 * ln + (size_t)n * L + l];
+                const mkgnn_f32x4 rec = pair_load(a.pair, (size_t)n * L + l);
+                const float S = rec[0], C = rec[1], Ed = rec[2];
                 float sc = (S * a.mix[0] + C * a.mix[1] + Ed * a.mix[2]) / a.mix[3];
                 p0 = fmaf(g * ws, S - sc, p0);
                 p1 = fmaf(g * wc, C - sc, p1);
@@ -340,7 +333,7 @@ __global__ void __launch_bounds__(128) kc_backward_bank(BwdArgs a) {
             if (kind == 0) {
                 acc = fmaf(g * wc * a.inv[focal], a.x[focal * a.xs + f], acc);
             } else {
-                const int idx = a.best[(size_t)n * a.L + l];
+                const int idx = pair_index(a.pair, (size_t)n * a.L + l);
                 // which neighbour slot was matched to support b: pi(slot) == b
                 int slot = 0;
 #pragma unroll

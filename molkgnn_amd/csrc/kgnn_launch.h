@@ -28,7 +28,7 @@ struct FwdArgs {
     int64_t n; int F, E, L, last;
     const float* cen; const float* sup; const float* edg; const int8_t* chir; const float* mix;
     float* out; int64_t os; int off, K;
-    uint8_t* best; float* scores; int8_t* chir_out;      // saved state, atom-major [N_d, L]
+    float* pair; int8_t* chir_out;                       // saved state, atom-major: [N_d, L, 4] pair records, [N_d, L] signs
     const float* padded; const float* edge_padded;       // MFMA kernels only
     int64_t n_atoms;
 };
@@ -40,7 +40,7 @@ constexpr int FUSED_MAX_GROUPS = 16;        // (degree, column part)
 struct FusedDeg {
     const int64_t* sel; const int64_t* nei; const float* e_nei; const float* e_unit; const float* p_focal; const float* p_nei;
     const float* padded; const float* edge_padded; const int8_t* chir; const float* mix; const int8_t* eqflag; const int8_t* signflag;
-    uint8_t* best; float* scores; int8_t* chir_out;
+    float* pair; int8_t* chir_out;
     int64_t n;
     int L, off;
     int nct;        // column tiles (<= 16 kernels each)
@@ -71,7 +71,7 @@ struct BwdArgs {
     int64_t n; int F, E, L;
     const float* cen; const float* sup; const float* edg; const float* mix;
     const float* gout; int64_t gs; int off;
-    const uint8_t* best; const float* scores; const int8_t* chir;
+    const float* pair; const int8_t* chir;
     float* contrib; int64_t contrib_base;      // rows base + n*(D+1) + slot
     int CS;                                    // contrib row stride: F rounded up to 4 (16-byte rows for the gather)
     float* slab; int nchunk;                   // [nchunk, bank_floats]

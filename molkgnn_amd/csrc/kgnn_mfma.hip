@@ -441,14 +441,8 @@ __device__ __forceinline__ void forward_body(const FusedFwdArgs& a, const FusedD
                     const uint32_t focal = __float_as_uint(focal4[jj]);
                     if (col_ok && n < dg.n) {
                         a.out[(size_t)focal * a.os + dg.off + lcol] = sc;
-                        const uint32_t o = (uint32_t)n * (uint32_t)L + (uint32_t)lcol;   // the host fuses a degree only if 3 * N_d * L < 2^32
-                        if (dg.best) dg.best[o] = (uint8_t)idx4[jj];
-                        if (dg.scores) {
-                            const uint32_t ln = (uint32_t)L * (uint32_t)dg.n;
-                            dg.scores[o] = best4[jj];
-                            dg.scores[ln + o] = cen4[jj];
-                            dg.scores[2u * ln + o] = ed;
-                        }
+                        const uint32_t o = (uint32_t)n * (uint32_t)L + (uint32_t)lcol;   // the host fuses a degree only if N_d * L < 2^32
+                        if (dg.pair) pair_store(dg.pair, o, best4[jj], cen4[jj], ed, idx4[jj]);
                         if (dg.chir_out) dg.chir_out[o] = (int8_t)ch;
                     }
                 }

@@ -135,14 +135,14 @@ def _forward_impl(x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad
     for i, b in enumerate(plan.buckets):
         L = Ls[i]
         if want_saved and b.count and L:
-            bi = torch.empty((b.count, L), dtype=torch.uint8, device=dev)
-            sc = torch.empty((3, b.count, L), dtype=torch.float32, device=dev)
+            # one 16-byte record per (atom, kernel) pair: support, centre, edge score, chosen permutation (int32 bits)
+            pr = torch.empty((b.count, L, 4), dtype=torch.float32, device=dev)
             ch = torch.empty((b.count, L), dtype=torch.int8, device=dev) if (i == 3 and is_last_layer) else None
-            saved[i].best_index, saved[i].scores = bi.data_ptr(), sc.data_ptr()
+            saved[i].pair_state = pr.data_ptr()
             saved[i].chirality = ch.data_ptr() if ch is not None else None
-            saved_t.append((bi, sc, ch))
+            saved_t.append((pr, ch))
         else:
-            saved_t.append((None, None, None))
+            saved_t.append((None, None))
     with torch.cuda.device(dev):
         st = _lib.stream_ptr(dev)
         if inv is None:                      # the producer of x did not hand its row norms over
@@ -157,15 +157,25 @@ def _forward_impl(x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad
     return x, out_full, inv, saved_t, Ls, ws
 
 
-def kernelsetconv_details(x, plan: BatchPlan, is_last_layer: bool, params, edge_attr_dim: int, variant: str = "auto"):
+def kernelsetconv_details(x, plan: BatchPlan, is_last_layer: bool, params, edge_attr_dim: int, variant: str = "auto",
+                          raw: bool = False):
     """Forward only, returning what the kernels keep for backward as well:
     ``(out [N, K], [(best_index [L_d, N_d] uint8, scores [3, L_d, N_d], chirality [L_d, N_d]) per degree])``
-    (transposed views of the atom-major buffers).  Used by the parity tests for the tie-aware criterion."""
+    (unpacked from the atom-major pair records of ``mkgnn_saved``; ``raw=True`` returns the records themselves,
+    ``(pair_state [N_d, L_d, 4], chirality [N_d, L_d])``, without any further device work).  Used by the parity tests for
+    the tie-aware criterion and by bench.py's forward timing."""
     with torch.no_grad():
         _, out, _, saved_t, _, _ = _forward_impl(x, plan, is_last_layer, VARIANTS[variant], 0, edge_attr_dim,
                                               [p.detach() for p in params], True, _handed_inv_norm(x))
-    tr = lambda t: None if t is None else t.transpose(-1, -2)
-    return out, [(tr(bi), tr(sc), tr(ch)) for bi, sc, ch in saved_t]
+    if raw:
+        return out, saved_t
+
+    def unpack(pr, ch):
+        if pr is None:
+            return None, None, None
+        best = pr[..., 3].contiguous().view(torch.int32).to(torch.uint8).t()
+        return best, pr[..., :3].permute(2, 1, 0), (None if ch is None else ch.t())
+    return out, [unpack(pr, ch) for pr, ch in saved_t]
 
 
 class _KernelSetConvFn(torch.autograd.Function):
@@ -197,9 +207,8 @@ class _KernelSetConvFn(torch.autograd.Function):
         banks, _, keep = _banks(params, F, E)
         buckets = _buckets(plan, E, False)
         saved = _lib.Saved4()
-        for i, (bi, sc, ch) in enumerate(ctx.saved_t):
-            saved[i].best_index = _lib.ptr(bi)
-            saved[i].scores = _lib.ptr(sc)
+        for i, (pr, ch) in enumerate(ctx.saved_t):
+            saved[i].pair_state = _lib.ptr(pr)
             saved[i].chirality = _lib.ptr(ch)
         grads = _lib.BankGrads4()
         gparams: List[Optional[torch.Tensor]] = []
