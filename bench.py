@@ -120,6 +120,7 @@ def fresh_batches_leg(args, model, opt, dev, log):
     from molkgnn_amd import padding as P
     from molkgnn_amd.receptive_field import attach_receptive_fields
     from molkgnn_amd.synthetic import make_batch
+    from molkgnn_amd.train import backward as train_backward
     nb, B = args.fresh_batches, args.batch_size
     raws = [make_batch(B, seed=int(args.assay) * 1000 + 500 + i, assay=args.assay, with_receptive_fields=False) for i in range(nb)]
     shape = P.fixed_shape([P.degree_histogram(r) for r in raws])
@@ -131,7 +132,7 @@ def fresh_batches_leg(args, model, opt, dev, log):
         attach_receptive_fields(sb.data, sizes=sb.data.bucket_sizes)
         model.zero_grad(set_to_none=True)
         loss = model.loss(sb.data)
-        loss.backward()
+        train_backward(loss)
         if opt is not None:
             opt.step()
         return loss
@@ -182,6 +183,7 @@ def main():
     from molkgnn_amd.plan import plan_from_data
     from molkgnn_amd.synthetic import ASSAY_SIZES, make_batch
     from molkgnn_amd.train import GNNModel, configure_optimizer, tune_torch_backends
+    from molkgnn_amd.train import backward as train_backward
     _lib.load()
     if not os.environ.get("MKGNN_NO_TUNE"):
         tune_torch_backends()
@@ -211,7 +213,7 @@ def main():
         b = batches[i % nb]
         model.zero_grad(set_to_none=True)
         loss = model.loss(b)
-        loss.backward()
+        train_backward(loss)
         reducer.reduce()
         if opt is not None:
             opt.step()
@@ -244,7 +246,7 @@ def main():
                     g_fb = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g_fb, stream=side, **cap):
                         static_loss = model.loss(batches[i])
-                        static_loss.backward()
+                        train_backward(static_loss)
                         if opt is not None and world == 1:
                             opt.step()
                     # this graph's gradient tensors: every captured graph writes into its own (p.grad names only the

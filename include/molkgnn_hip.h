@@ -147,7 +147,15 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
  *   variant   0 = automatic (the MFMA rows / LDS bank / pipelined gather kernels wherever a degree's shape is
  *             covered, the generic kernels elsewhere), 1 = the generic one-wave-per-atom kernels and the plain
  *             gather for every degree (the A/B reference of the parity tests), 2 = the fast kernels, failing if a
- *             degree with atoms and kernels is not covered by them. */
+ *             degree with atoms and kernels is not covered by them.
+ *             | MKGNN_BACKWARD_DEFER_BANK: `grad_x` is complete in stream order as always, but the kernel-bank
+ *             gradients (`grads`) are left running on the device's helper stream when the call returns: they -- and the
+ *             buffers their kernels read: x, inv_norm, grad_out, saved, the buckets, the workspace -- must not be
+ *             touched until mkgnn_backward_join(stream) has been called.  The next layer's backward (which needs only
+ *             grad_x) then overlaps this layer's bank gradients instead of waiting for them: nothing but the optimiser
+ *             reads a weight gradient.  Honoured where the call forks at all (inside a hipGraph capture with the fast
+ *             kernels); elsewhere the call is complete on return as without the flag and the join is a no-op. */
+#define MKGNN_BACKWARD_DEFER_BANK 0x100
 int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
                                  const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],
                                  const float* x, int64_t x_stride, const float* inv_norm,
@@ -159,6 +167,10 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
                                  const mkgnn_kernel_bank_grad grads[MKGNN_MAX_DEGREE],
                                  void* workspace, size_t workspace_bytes, int32_t workspace_from_forward,
                                  int32_t variant, void* stream);
+
+/* Makes `stream` wait for every bank-gradient chain that calls with MKGNN_BACKWARD_DEFER_BANK left on this device's
+ * helper stream (no-op when there is none).  Graph-capturable: captured, it is the edge that joins the helper branch. */
+int mkgnn_backward_join(void* stream);
 
 /* MolGCN.propagate with aggr='add' (KernelLayer.py:14,119-123) as a CSR segment
  * sum: out[i, :] = sum_{k in [rowptr[i], rowptr[i+1])} in[col[k], :].

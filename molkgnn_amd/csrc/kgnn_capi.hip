@@ -46,6 +46,7 @@ struct DegreeStreams {
     hipEvent_t fork;
     hipEvent_t join[3];
     bool ready;
+    bool deferred;      // aux[0] carries bank-gradient chains nobody has joined yet (MKGNN_BACKWARD_DEFER_BANK)
     std::once_flag once;
 };
 static DegreeStreams g_streams[16];
@@ -299,6 +300,8 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
                                  const mkgnn_kernel_bank_grad grads[MKGNN_MAX_DEGREE], void* workspace,
                                  size_t workspace_bytes, int32_t workspace_from_forward, int32_t variant, void* stream) {
     const char* who = "mkgnn_kernelsetconv_backward";
+    const bool defer_bank = (variant & MKGNN_BACKWARD_DEFER_BANK) != 0;
+    variant &= ~MKGNN_BACKWARD_DEFER_BANK;
     if (variant < 0 || variant > 2) return fail("%s: variant %d (0 = automatic, 1 = generic kernels, 2 = fast kernels)", who, variant);
     const bool force_generic = variant == 1, force_fast = variant == 2;
     int64_t n_edges = 0;
@@ -467,11 +470,22 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
                                    x_stride, inv_norm, n_atoms, F, grad_x, grad_x_stride, !force_generic, st);
         if (e != hipSuccess) return hip_fail("backward gather launch", e);
     }
-    if (split) {
+    if (split && defer_bank && fj.used[0] && !fj.used[1] && !fj.used[2]) {
+        fj.p->deferred = true;                       // the caller joins (mkgnn_backward_join), after the last layer's backward
+    } else if (split) {
         e = fj.end();
         if (e != hipSuccess) return hip_fail("stream join", e);
     }
     return 0;
+}
+
+int mkgnn_backward_join(void* stream) {
+    DegreeStreams* p = degree_streams();
+    if (!p || !p->deferred) return 0;
+    p->deferred = false;
+    hipError_t e = hipEventRecord(p->join[0], p->aux[0]);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)stream, p->join[0], 0);
+    return e == hipSuccess ? 0 : hip_fail("mkgnn_backward_join", e);
 }
 
 int mkgnn_segment_sum_rows(const float* in, int64_t in_stride, const int32_t* rowptr, const int32_t* col, int64_t n_rows,

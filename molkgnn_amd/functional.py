@@ -178,6 +178,43 @@ def kernelsetconv_details(x, plan: BatchPlan, is_last_layer: bool, params, edge_
     return out, [unpack(pr, ch) for pr, ch in saved_t]
 
 
+DEFER_BANK = 0x100           # MKGNN_BACKWARD_DEFER_BANK
+
+
+class _Deferred:
+    """State of an open ``deferred_bank_gradients`` region (one per process: backward passes do not nest)."""
+    active = False
+    held: list = []          # everything the unjoined helper-stream kernels read or write
+    seen: set = set()        # ids of the parameters whose gradients are still in flight
+
+
+class deferred_bank_gradients:
+    """``with deferred_bank_gradients(): loss.backward()`` -- inside, a KernelSetConv backward hands its input gradient
+    to the layer below as soon as the x-gradient chain is done and leaves its kernel-bank gradients running on the
+    library's helper stream (MKGNN_BACKWARD_DEFER_BANK); leaving the region makes the current stream wait for all of them
+    (mkgnn_backward_join).  Only the optimiser reads a weight gradient, so the bank chain of layer l overlaps the whole
+    backward of layer l - 1 instead of holding it up.
+
+    The gradients of the parameters are undefined until the region is left: a call whose parameters already have a
+    ``.grad`` (it would be added to at once), or that shares a parameter with an earlier call of the region, is not
+    deferred.  Buffers the helper kernels use stay referenced until the join, so the allocator cannot hand them out."""
+
+    def __enter__(self):
+        if _Deferred.active:
+            raise RuntimeError("deferred_bank_gradients regions do not nest")
+        _Deferred.active, _Deferred.held, _Deferred.seen = True, [], set()
+        return self
+
+    def __exit__(self, *exc):
+        _Deferred.active = False
+        try:
+            if _Deferred.held and torch.cuda.is_available():
+                _lib.check(_lib.load().mkgnn_backward_join(_lib.stream_ptr(_Deferred.held[0][0].device)), "mkgnn_backward_join")
+        finally:
+            _Deferred.held, _Deferred.seen = [], set()
+        return False
+
+
 class _KernelSetConvFn(torch.autograd.Function):
     """BaseKernelSetConv.forward (reference kernels.py:610-751) as one differentiable operator."""
 
@@ -246,10 +283,21 @@ class _KernelSetConvFn(torch.autograd.Function):
                 all(p._version == v for p, v in zip(params, ctx.param_versions))
             if not reuse:
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            bwd_variant = ctx.bwd_variant
+            live = [p for p in params if p.requires_grad]
+            defer = _Deferred.active and all(p.grad is None and id(p) not in _Deferred.seen for p in live)
+            if defer:
+                bwd_variant |= DEFER_BANK
+                _Deferred.seen.update(id(p) for p in live)
+                # (NOT the gradient tensors themselves: autograd takes a returned gradient over as .grad only while
+                # nobody else refers to it, and copies it -- reading it too early -- otherwise; their memory stays put
+                # because .grad holds it)
+                _Deferred.held.append((x, inv, g, ws, ctx.saved_t, plan, params, [t for t in alive if t is not None and
+                                                                                 all(t is not q for q in gparams)]))
             _lib.check(lib.mkgnn_kernelsetconv_backward(
                 banks, buckets, x.data_ptr(), _stride0(x), inv.data_ptr(), n, F, E, int(ctx.is_last),
                 g.data_ptr(), _stride0(g), saved, rowptr.data_ptr(), rows.data_ptr(),
-                _lib.ptr(gx), F4, grads, ws.data_ptr(), ws_bytes, int(reuse), ctx.bwd_variant, _lib.stream_ptr(dev)),
+                _lib.ptr(gx), F4, grads, ws.data_ptr(), ws_bytes, int(reuse), bwd_variant, _lib.stream_ptr(dev)),
                 "mkgnn_kernelsetconv_backward")
         del alive           # (freed memory is only handed out again in stream order, after the kernels above)
         return (gx, None, None, None, None, None, None, None, *gparams)

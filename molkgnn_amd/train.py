@@ -62,6 +62,16 @@ class GNNModel(torch.nn.Module):
         return self.loss_func(pred.view(-1), data.y.view(-1).float())
 
 
+def backward(loss: torch.Tensor) -> None:
+    """``loss.backward()`` with the kernel-bank gradients of every KernelSetConv left running beside the layers below
+    (functional.deferred_bank_gradients); all of them are complete, in stream order, when this returns -- which is
+    all the optimiser (or a gradient all-reduce) that follows needs.  Use it where parameters' ``.grad`` start out as
+    None (``zero_grad(set_to_none=True)``); calls that would accumulate are simply not deferred."""
+    from .functional import deferred_bank_gradients
+    with deferred_bank_gradients():
+        loss.backward()
+
+
 def tune_torch_backends() -> None:
     """PyTorch-side knobs for the plain-PyTorch parts of the step (readout GEMMs).  The weight-gradient GEMM
     [32 x N] @ [N x 110] (N ~ 1e5) takes ~225 us through hipBLASLt and ~53 us through rocBLAS on MI355X."""
