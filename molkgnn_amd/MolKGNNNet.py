@@ -65,6 +65,9 @@ class MolKGNNNet(torch.nn.Module):
         # (a batch padded to a fixed shape -- molkgnn_amd.padding -- carries its real atom count and its molecule segments)
         x = R.batch_norm(data.x, self.node_batch_norm, getattr(data, 'n_valid_atoms', None))
         # edge_batch_norm never reaches the kernel convolution in the reference: skipped
+        if getattr(data, '_rf_ready', None) is not None:     # degree buckets still being built on the index stream
+            from .receptive_field import await_receptive_fields
+            await_receptive_fields(data)
         kw = {f'{nm}_deg{d}': getattr(data, f'{nm}_deg{d}')
               for nm in ('p_focal', 'nei_p', 'nei_edge_attr', 'selected_index', 'nei_index') for d in range(1, 5)}
         for d in range(1, 5):                          # unit bond rows built with the receptive fields (mkgnn_rf_fill), if any

@@ -61,6 +61,21 @@ class Bucket:
         return self._e_unit
 
 
+_INDEX_STREAMS: dict = {}
+
+
+def index_stream(dev):
+    """The side stream (one per device) on which the index structures of a batch are built (receptive fields, plan);
+    ``None`` with ``MKGNN_INDEX_OVERLAP=0``."""
+    if os.environ.get("MKGNN_INDEX_OVERLAP") == "0":
+        return None
+    key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+    st = _INDEX_STREAMS.get(key)
+    if st is None:
+        st = _INDEX_STREAMS[key] = torch.cuda.Stream(device=key)
+    return st
+
+
 class BatchPlan:
     def __init__(self, n_atoms: int, buckets: List[Bucket], edge_index: Optional[torch.Tensor] = None):
         self.n_atoms = int(n_atoms)
@@ -74,14 +89,28 @@ class BatchPlan:
         self._csr_out = None
         self._deg8 = None
         self._csr_in_packed = None
+        self._ready = None          # event of a build still running on the index stream (build_hip)
+        self._build_ws = None
+
+    def _await(self):
+        """Make the current stream wait for a build that runs on the index stream (once)."""
+        ev, self._ready = self._ready, None
+        if ev is not None:
+            torch.cuda.current_stream(self.device).wait_event(ev)
 
     # -- all index structures in one pass on the GPU (mkgnn_plan_build) ----------
     def build_hip(self) -> bool:
         """Scatter CSR, both propagate CSRs, ``deg8`` and the packed columns from one call of ``mkgnn_plan_build``
         (no sort over the batch, no host synchronisation); entry for entry what the torch definitions below give
-        (``tests/test_hip_parity.py::test_plan_builder_hip_matches_torch_builder``).  False when not applicable (CPU)."""
+        (``tests/test_hip_parity.py::test_plan_builder_hip_matches_torch_builder``).  False when not applicable (CPU).
+
+        The kernels run on the device's index stream (``index_stream``), forked from the current stream; the first read of
+        any of the structures joins it.  Nothing before the first ``propagate`` of a step needs them, so inside a captured
+        step the build runs beside the first convolution instead of in front of it (``MKGNN_INDEX_OVERLAP=0``: in line)."""
         if not self.device.type == "cuda" or os.environ.get("MKGNN_TORCH_PLAN"):
             return False
+        if self._scatter is not None:
+            return True
         from . import _lib
         lib = _lib.load()
         dev, n = self.device, self.n_atoms
@@ -104,9 +133,18 @@ class BatchPlan:
         with torch.cuda.device(dev):
             nbytes = int(lib.mkgnn_plan_workspace_bytes(n, m, r))
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            _lib.check(lib.mkgnn_plan_build(bk, n, _lib.ptr(ei), m, s_ptr.data_ptr(), s_rows.data_ptr(), in_ptr.data_ptr(),
-                                            in_col.data_ptr(), in_pk.data_ptr(), out_ptr.data_ptr(), out_col.data_ptr(),
-                                            deg8.data_ptr(), ws.data_ptr(), nbytes, _lib.stream_ptr(dev)), "mkgnn_plan_build")
+            side = index_stream(dev)
+            cur = torch.cuda.current_stream(dev)
+            if side is not None:
+                side.wait_stream(cur)
+            with torch.cuda.stream(side if side is not None else cur):
+                _lib.check(lib.mkgnn_plan_build(bk, n, _lib.ptr(ei), m, s_ptr.data_ptr(), s_rows.data_ptr(), in_ptr.data_ptr(),
+                                                in_col.data_ptr(), in_pk.data_ptr(), out_ptr.data_ptr(), out_col.data_ptr(),
+                                                deg8.data_ptr(), ws.data_ptr(), nbytes, _lib.stream_ptr(dev)), "mkgnn_plan_build")
+                if side is not None:
+                    self._ready = torch.cuda.Event()
+                    self._ready.record(side)
+                    self._build_ws = (ws, ei, bk)      # alive until the plan goes (its kernels run on another stream)
         self._scatter = (s_ptr, s_rows[:r])
         self._deg8 = deg8[:n]
         if self.edge_index is not None:
@@ -119,6 +157,7 @@ class BatchPlan:
     def scatter(self):
         if self._scatter is None:
             self.build_hip()
+        self._await()
         if self._scatter is None:
             dest = []
             for b in self.buckets:
@@ -149,6 +188,7 @@ class BatchPlan:
         """Edges grouped by target; columns are the sources (forward of propagate)."""
         if self._csr_in is None:
             self.build_hip()
+        self._await()
         if self._csr_in is None:
             self._csr_in = self._csr(self.edge_index[1], self.edge_index[0])
         return self._csr_in
@@ -158,6 +198,7 @@ class BatchPlan:
         """Edges grouped by source; columns are the targets (gradient of propagate)."""
         if self._csr_out is None:
             self.build_hip()
+        self._await()
         if self._csr_out is None:
             self._csr_out = self._csr(self.edge_index[0], self.edge_index[1])
         return self._csr_out
@@ -169,6 +210,7 @@ class BatchPlan:
         """[n_atoms] int8: the degree bucket every atom is in (0 = none)."""
         if self._deg8 is None:
             self.build_hip()
+        self._await()
         if self._deg8 is None:
             d8 = torch.zeros(self.n_atoms, dtype=torch.int8, device=self.device)
             for b in self.buckets:
@@ -183,6 +225,7 @@ class BatchPlan:
         (``mkgnn_segment_sum_block_rows`` mode 1)."""
         if self._csr_in_packed is None:
             self.build_hip()
+        self._await()
         if self._csr_in_packed is None:
             rowptr, col = self.csr_in
             packed = col | (self.deg8[col.long()].to(torch.int32) << 28)
@@ -239,9 +282,10 @@ def plan_from_lists_cached(n_atoms, p_focal_list, nei_p_list, nei_edge_attr_list
                            nei_index_list, edge_index, nei_edge_unit_list)
     # build every index structure now: the lazy properties sort (and synchronise), which must not
     # happen inside a later backward pass or a hipGraph capture
-    _ = plan.scatter
-    if edge_index is not None:
-        _ = plan.csr_in, plan.csr_out, plan.csr_in_packed
+    if not plan.build_hip():                 # (on the index stream; joined by whoever reads a structure first)
+        _ = plan.scatter
+        if edge_index is not None:
+            _ = plan.csr_in, plan.csr_out, plan.csr_in_packed
     for b in plan.buckets:
         if b.count and b.e_nei is not None and b.e_nei.is_cuda:
             b.e_unit(b.e_nei.numel() // (b.count * b.degree))

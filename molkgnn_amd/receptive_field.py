@@ -161,11 +161,41 @@ def build_receptive_fields_hip(x: torch.Tensor, p: torch.Tensor, edge_index: tor
     return out
 
 
-def attach_receptive_fields(batch: GraphBatch, sizes=None) -> GraphBatch:
+def attach_receptive_fields(batch: GraphBatch, sizes=None, overlap: bool = False) -> GraphBatch:
+    """The reference's per-degree tensors of a collated batch, set on the batch object.
+
+    ``overlap=True`` (CUDA, ``sizes`` given -- the fixed-shape path of molkgnn_amd.padding): the builder runs on the
+    device's index stream (plan.index_stream) and the batch carries the event ``_rf_ready``; ``MolKGNNNet.forward`` makes
+    its stream wait for it after the atom batch norm, which needs none of these tensors -- inside a captured step the
+    builder runs beside the batch norm instead of in front of it."""
     if batch.edge_index.is_cuda and batch.p.shape[1] == 3:
-        rf = build_receptive_fields_hip(batch.x, batch.p, batch.edge_index, batch.edge_attr, sizes)
+        side = None
+        if overlap and sizes is not None:
+            from .plan import index_stream
+            side = index_stream(batch.edge_index.device)
+        if side is not None:
+            cur = torch.cuda.current_stream(batch.edge_index.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                rf = build_receptive_fields_hip(batch.x, batch.p, batch.edge_index, batch.edge_attr, sizes)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            for v in rf.values():
+                if torch.is_tensor(v):
+                    v.record_stream(cur)
+            batch._rf_ready = ev
+        else:
+            rf = build_receptive_fields_hip(batch.x, batch.p, batch.edge_index, batch.edge_attr, sizes)
     else:
         rf = build_receptive_fields(batch.x, batch.p, batch.edge_index, batch.edge_attr)
     for k, v in rf.items():
         setattr(batch, k, v)
     return batch
+
+
+def await_receptive_fields(batch) -> None:
+    """Make the current stream wait for a builder that ``attach_receptive_fields(..., overlap=True)`` left running."""
+    ev = getattr(batch, "_rf_ready", None)
+    if ev is not None:
+        batch._rf_ready = None
+        torch.cuda.current_stream().wait_event(ev)
