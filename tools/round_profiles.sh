@@ -1,0 +1,34 @@
+#!/bin/bash
+# Every measured artefact of a round in one GPU call, written under gpurun_out/<tag>/ (copy what is to be judged into
+# profiles/ afterwards: tools/round_profiles_collect.sh <tag>):  tools/round_profiles.sh <tag> <commit>
+# Run from the repository root on the GPU box.  Programs go straight after `--` under rocprofv3 (no wrappers); the PMC
+# passes carry --kernel-trace only.
+set -e
+tag="$1"; commit="$2"
+R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/$tag"
+mkdir -p "$O"
+cd "$R"
+# 1. the bench line (configs[1], batch 4096) with roofline, fresh-batch leg and CPU baseline
+python3 bench.py --steps 50 --warmup 10 > "$O/bench_b4096.json" 2> "$O/bench_b4096.err"
+# 2. kernel statistics + one step's timeline of the same command (shorter)
+tools/prof.sh "$tag/prof_b4096" bench.py --steps 20 --warmup 5 --windows 1 --fresh-batches 0 --no-cpu-baseline > "$O/kstats_b4096.txt"
+python3 tools/step_timeline.py "$O/prof_b4096" > "$O/step_timeline_graph.txt"
+# 3. the fresh-batch graph's timeline
+tools/prof.sh "$tag/prof_fresh" bench.py --steps 10 --warmup 3 --windows 1 --fresh-batches 16 --no-cpu-baseline > "$O/kstats_fresh.txt"
+python3 tools/step_timeline.py "$O/prof_fresh" > "$O/step_timeline_fresh.txt"
+# 4. configs[2]: AID 435008 shape, batch 256
+python3 bench.py --assay 435008 --batch-size 256 --steps 200 --warmup 20 > "$O/bench_435008_b256.json" 2> "$O/bench_435008_b256.err"
+tools/prof.sh "$tag/prof_b256" bench.py --assay 435008 --batch-size 256 --steps 50 --warmup 5 --windows 1 --fresh-batches 0 --no-cpu-baseline > "$O/kstats_435008_b256.txt"
+python3 tools/step_timeline.py "$O/prof_b256" > "$O/step_timeline_435008_b256.txt"
+# 5. bf16 similarity variant (configs[4] shape on one GPU)
+python3 bench.py --variant bf16 --steps 50 --warmup 10 --no-cpu-baseline --fresh-batches 0 > "$O/bench_b4096_bf16.json" 2> "$O/bench_b4096_bf16.err"
+# 6. HBM traffic of the forward kernel (separate PMC passes) -> the JSON bench.py reads
+tools/pmc.sh "$tag/pmc_fwd" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" -- tools/fwd_probe.py --reps 6 > "$O/pmc_fwd.txt"
+python3 tools/collect_pmc.py "kc_forward_stream<7>" "$O/forward_pmc.json" "$commit" 98774728 "$O/pmc_fwd" > /dev/null
+# 7. pipe utilisation counters of every kernel of a step
+tools/pmc.sh "$tag/pmc_step" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" \
+    "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
+    "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_SCA" \
+    "GRBM_GUI_ACTIVE TA_BUSY_avr TA_BUSY_max" "FETCH_SIZE" "WRITE_SIZE" \
+    -- bench.py --steps 3 --warmup 1 --windows 1 --fresh-batches 0 --no-cpu-baseline --roofline-reps 2 > "$O/pmc_step.txt"
+echo done
