@@ -49,6 +49,11 @@ def parse():
     return ap.parse_args()
 
 
+def assay_seed(assay):
+    """Seed base of an assay's synthetic batches ('all9': the nine assays mixed, BASELINE configs[4])."""
+    return int(assay) if str(assay).isdigit() else 9
+
+
 def layer_algorithmic(plan, F, E, Ls, last):
     """Strict algorithmic bytes and flops of one KernelSetConv forward:
     x read once, the output written once, bond attributes, the index tensors (int64, as the ABI
@@ -122,7 +127,7 @@ def fresh_batches_leg(args, model, opt, dev, log):
     from molkgnn_amd.synthetic import make_batch
     from molkgnn_amd.train import backward as train_backward
     nb, B = args.fresh_batches, args.batch_size
-    raws = [make_batch(B, seed=int(args.assay) * 1000 + 500 + i, assay=args.assay, with_receptive_fields=False) for i in range(nb)]
+    raws = [make_batch(B, seed=assay_seed(args.assay) * 1000 + 500 + i, assay=args.assay, with_receptive_fields=False) for i in range(nb)]
     shape = P.fixed_shape([P.degree_histogram(r) for r in raws])
     padded = [P.pack(P.pad_batch(r, shape, B).to(dev)) for r in raws]      # (packed: one copy loads a batch)
     pad_atoms = sum(shape["atoms"] - int(p.n_valid_atoms) for p in padded) / nb
@@ -208,7 +213,7 @@ def main():
     nb = max(1, min(args.distinct_batches, math.ceil(n_mol_assay / args.batch_size)))
     batches = []
     for i in range(nb):
-        b = make_batch(args.batch_size, seed=int(args.assay) * 1000 + i * world + rank, assay=args.assay).to(dev)
+        b = make_batch(args.batch_size, seed=assay_seed(args.assay) * 1000 + i * world + rank, assay=args.assay).to(dev)
         batches.append(b)
     atoms = sum(b.x.shape[0] for b in batches) / nb
     with torch.no_grad():                                 # index plans (sorted CSRs) are part of the resident input
@@ -420,7 +425,7 @@ def main():
                "vs_baseline": None, "dtype": "bf16 dot products, f32 otherwise" if args.variant == "bf16" else "f32",
                "data": "synthetic",
                **({"dp_replicas_max_abs_diff": replicas_diff} if replicas_diff is not None else {}),
-               "config": {"workload": f"AID {args.assay} full set shape ({n_mol_assay} molecules, ~25 atoms / ~53 directed "
+               "config": {"workload": f"{'all nine assays mixed' if args.assay == 'all9' else 'AID ' + args.assay} full set shape ({n_mol_assay} molecules, ~25 atoms / ~53 directed "
                                       f"edges each), 3 layers, hidden_dim 32, kernels 10/20/30/50 per degree, "
                                       f"batch {args.batch_size} molecules per GPU ({atoms:.0f} atoms), "
                                       f"{nb} resident batches cycled, fwd+bwd"

@@ -25,12 +25,16 @@ import torch
 from .receptive_field import GraphBatch, attach_receptive_fields
 
 # molecules per assay: actives + inactives (reference utils/data_split.py:68-79)
-ASSAY_SIZES = {
-    "1798": 187 + 61645,
-    "435008": 233 + 217923,
-    "9999": 263,
+# (actives, inactives) of the nine PubChem assays of the benchmark set (wrapper.py:351-360) and the toy set 9999
+ASSAY_COUNTS = {
+    "435008": (233, 217923), "1798": (187, 61645), "435034": (362, 61393), "1843": (172, 301318), "2258": (213, 302189),
+    "463087": (703, 100171), "488997": (252, 302051), "2689": (172, 319617), "485290": (278, 341026), "9999": (37, 226),
 }
-ASSAY_ACTIVE_FRACTION = {"1798": 187.0 / 61832.0, "435008": 233.0 / 218156.0, "9999": 0.1}
+NINE_ASSAYS = ("435008", "1798", "435034", "1843", "2258", "463087", "488997", "2689", "485290")
+ASSAY_SIZES = {k: a + i for k, (a, i) in ASSAY_COUNTS.items()}
+ASSAY_SIZES["all9"] = sum(ASSAY_SIZES[k] for k in NINE_ASSAYS)          # 2 009 905 molecules (BASELINE configs[4])
+ASSAY_ACTIVE_FRACTION = {k: a / float(a + i) for k, (a, i) in ASSAY_COUNTS.items()}
+ASSAY_ACTIVE_FRACTION["9999"] = 0.1
 
 NODE_DIM = 28
 EDGE_DIM = 7
@@ -172,13 +176,24 @@ def make_batch(num_molecules: int, seed: int, *, assay: str = "1798",
         c = edge_index[1, order_e[rowptr[pick] + 1]]
         x[c] = x[a]
     p = (1.5 * rng.standard_normal((n, 3))).astype(np.float32)
-    y = (rng.random(num_molecules) < ASSAY_ACTIVE_FRACTION.get(assay, 0.003)).astype(np.float32)
+    if assay == "all9":
+        # a mixed batch of the nine assays concatenated (BASELINE configs[4]): every molecule drawn from one of them in
+        # proportion to its size, labelled at that assay's active rate.  (The synthetic molecules themselves have one
+        # distribution whatever the assay: there is no per-assay chemistry offline.)
+        sizes = np.array([ASSAY_SIZES[k] for k in NINE_ASSAYS], dtype=np.float64)
+        which = rng.choice(len(NINE_ASSAYS), size=num_molecules, p=sizes / sizes.sum())
+        rate = np.array([ASSAY_ACTIVE_FRACTION[k] for k in NINE_ASSAYS])[which]
+        assay_id = np.array([int(k) for k in NINE_ASSAYS], dtype=np.int64)[which]
+    else:
+        rate = ASSAY_ACTIVE_FRACTION.get(assay, 0.003)
+        assay_id = np.full(num_molecules, int(assay) if str(assay).isdigit() else 0, dtype=np.int64)
+    y = (rng.random(num_molecules) < rate).astype(np.float32)
     batch_vec = np.repeat(np.arange(num_molecules, dtype=np.int64), n_atoms)
     out = GraphBatch(
         x=torch.from_numpy(x), p=torch.from_numpy(p),
         edge_index=torch.from_numpy(edge_index), edge_attr=torch.from_numpy(edge_attr),
         batch=torch.from_numpy(batch_vec), y=torch.from_numpy(y),
-        num_graphs=num_molecules, smiles=None)
+        num_graphs=num_molecules, smiles=None, assay_id=torch.from_numpy(assay_id))
     if device is not None:
         out = out.to(device)
     if with_receptive_fields:

@@ -1,0 +1,93 @@
+"""Packed molecule shards (molkgnn_amd/shards.py): format round trip, the loader's batch sequence and its
+rank split on the CPU; on the GPU the loader's batches through the HIP builders and the model against the directly
+collated batch."""
+import numpy as np
+import pytest
+import torch
+
+from molkgnn_amd import shards as S
+from molkgnn_amd.synthetic import make_batch
+
+
+def _same(a, b, fields=("x", "p", "edge_index", "edge_attr", "batch", "y", "assay_id")):
+    for f in fields:
+        ta, tb = getattr(a, f).cpu(), getattr(b, f).cpu()
+        assert ta.shape == tb.shape and torch.equal(ta.to(tb.dtype), tb), f
+
+
+def _slice(b, m0, m1):
+    """Molecules [m0, m1) of a collated batch, re-collated by hand (the definition the loader must match)."""
+    atoms = ((b.batch >= m0) & (b.batch < m1)).nonzero().view(-1)
+    a0 = int(atoms[0])
+    em = b.batch[b.edge_index[0]]
+    edges = ((em >= m0) & (em < m1)).nonzero().view(-1)
+    from molkgnn_amd.receptive_field import GraphBatch
+    return GraphBatch(x=b.x[atoms], p=b.p[atoms], edge_index=b.edge_index[:, edges] - a0, edge_attr=b.edge_attr[edges],
+                      batch=b.batch[atoms] - m0, y=b.y[m0:m1], assay_id=b.assay_id[m0:m1])
+
+
+def test_shard_round_trip_and_loader_sequence(tmp_path):
+    whole = make_batch(300, seed=4, assay="all9", with_receptive_fields=False)
+    path = str(tmp_path / "a.mkgs")
+    S.write_shard(path, whole)
+    sh = S.Shard(path)
+    assert (sh.n_molecules, sh.n_atoms, sh.n_edges) == (300, whole.x.shape[0], whole.edge_index.shape[1])
+    assert sh.x_dim == 28 and sh.e_dim == 7 and sh.p_dim == 3
+    assert np.array_equal(sh.x, whole.x.numpy()) and np.array_equal(sh.edge_attr, whole.edge_attr.numpy())
+    _same(S.collate(sh, 0, 300, "cpu"), whole)
+    loader = S.ShardLoader([path], batch_size=64, device="cpu")
+    got = list(loader)
+    assert [b.num_graphs for b in got] == [64, 64, 64, 64, 44] and len(loader) == 5
+    for k, b in enumerate(got):
+        _same(b, _slice(whole, 64 * k, min(300, 64 * k + 64)))
+        assert int(b.mol_ptr[-1]) == b.x.shape[0] and int(b.mol_ptr[0]) == 0
+    assert [b.num_graphs for b in S.ShardLoader([path], 64, drop_last=True)] == [64] * 4
+
+
+def test_rank_split_is_a_partition_of_the_single_rank_stream(tmp_path):
+    paths = S.write_shards(str(tmp_path), [make_batch(n, seed=10 + i, with_receptive_fields=False) for i, n in enumerate((100, 37, 64))])
+    one = S.ShardLoader(paths, 32).plan()
+    parts = [S.ShardLoader(paths, 32, rank=r, world=3).plan() for r in range(3)]
+    assert sorted(sum(parts, [])) == sorted(one) and all(parts[r] == one[r::3] for r in range(3))
+    assert sum(m1 - m0 for _, m0, m1 in one) == 201
+    with pytest.raises(ValueError):
+        S.ShardLoader(paths, 32, rank=3, world=3)
+
+
+def test_reader_rejects_foreign_and_truncated_files(tmp_path):
+    bad = tmp_path / "bad.mkgs"
+    bad.write_bytes(b"\0" * 300)
+    with pytest.raises(ValueError, match="not a molecule shard"):
+        S.Shard(str(bad))
+    good = str(tmp_path / "g.mkgs")
+    S.write_shard(good, make_batch(20, seed=1, with_receptive_fields=False))
+    data = open(good, "rb").read()
+    (tmp_path / "cut.mkgs").write_bytes(data[:len(data) - 4096])
+    with pytest.raises(ValueError, match="does not fit"):
+        S.Shard(str(tmp_path / "cut.mkgs"))
+    unsorted = make_batch(20, seed=1, with_receptive_fields=False)
+    unsorted.batch = unsorted.batch.flip(0)
+    with pytest.raises(ValueError, match="sorted"):
+        S.write_shard(str(tmp_path / "u.mkgs"), unsorted)
+
+
+@pytest.mark.gpu
+def test_loader_batches_on_the_gpu_feed_the_model_like_direct_batches(tmp_path):
+    from molkgnn_amd.receptive_field import attach_receptive_fields
+    from molkgnn_amd.train import GNNModel
+    dev = torch.device("cuda:0")
+    whole = make_batch(700, seed=21, assay="all9", with_receptive_fields=False)
+    paths = S.write_shards(str(tmp_path), [whole])
+    torch.manual_seed(0)
+    model = GNNModel(num_layers=3, ffn_dropout_rate=0.0).to(dev).eval()
+    n = 0
+    for k, b in enumerate(S.ShardLoader(paths, 256, device=dev, prefetch=2)):
+        ref = _slice(whole, 256 * k, min(700, 256 * k + 256))
+        _same(b, ref)
+        assert b.x.is_cuda
+        with torch.no_grad():
+            got = model(attach_receptive_fields(b))[0]
+            want = model(attach_receptive_fields(ref.to(dev)))[0]
+        assert torch.equal(got, want)
+        n += b.num_graphs
+    assert n == 700
