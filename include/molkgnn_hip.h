@@ -156,6 +156,13 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
  *             reads a weight gradient.  Honoured where the call forks at all (inside a hipGraph capture with the fast
  *             kernels); elsewhere the call is complete on return as without the flag and the join is a no-op. */
 #define MKGNN_BACKWARD_DEFER_BANK 0x100
+/*             | MKGNN_BACKWARD_THROUGH_NEIGHBOURS: `grad_out` is not the gradient of this call's `out` but of
+ *             h = propagate(out) (KernelLayer.py:119-123: h[i] = sum over edges j -> i of out[j]), [N, K] like it.  The
+ *             gradient of out[n, l] is then the sum of grad_out[m, l] over the targets m of n's edges, which are exactly
+ *             the bucket's nei_index entries of n: the kernels' pre-pass sums those d rows itself and the caller skips
+ *             the propagate step's own gradient pass.  Needs the streamed kernels for every degree
+ *             (mkgnn_backward_streams); fails otherwise. */
+#define MKGNN_BACKWARD_THROUGH_NEIGHBOURS 0x200
 int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
                                  const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],
                                  const float* x, int64_t x_stride, const float* inv_norm,
@@ -167,6 +174,12 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
                                  const mkgnn_kernel_bank_grad grads[MKGNN_MAX_DEGREE],
                                  void* workspace, size_t workspace_bytes, int32_t workspace_from_forward,
                                  int32_t variant, void* stream);
+
+/* 1 when a backward call with these banks, buckets and x would run every degree that has atoms and kernels on the
+ * streamed kernels (the condition of MKGNN_BACKWARD_THROUGH_NEIGHBOURS), else 0.  Launches nothing. */
+int mkgnn_backward_streams(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
+                           const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],
+                           const float* x, int64_t x_stride, int64_t n_atoms, int32_t F, int32_t E);
 
 /* Makes `stream` wait for every bank-gradient chain that calls with MKGNN_BACKWARD_DEFER_BANK left on this device's
  * helper stream (no-op when there is none).  Graph-capturable: captured, it is the edge that joins the helper branch. */

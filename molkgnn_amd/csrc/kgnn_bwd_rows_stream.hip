@@ -56,6 +56,7 @@ struct RowsStreamDeg {
     const float* pair; const int8_t* chir;
     const float* padded; const float* mix;
     float* contrib; int64_t contrib_base;
+    const float* coefq;      // the pre-pass's records [tile][column tile][g 16 x 16 | idx 16 x 16] (null: gather here)
     int64_t n;
     int L, off, kpt;
 };
@@ -125,7 +126,20 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
         const int64_t n = tile * 16 + ci;
         return dg.sel[n < dg.n ? n : dg.n - 1];
     };
+    const bool records = dg.coefq != nullptr;
     auto issue = [&](int64_t tile, int64_t focal) {
+        if (records) {
+            // the pre-pass (coef_prepare_kernel) has put dL/dsc (signed, zero for padding) and the permutation ids into
+            // tile order: two contiguous 1 KB images per (tile, column tile), this lane's entries at atom ci, kernel 4 q + kq
+            const float* rec = dg.coefq + ((size_t)tile * NS + ct) * 512 + ci * 16 + kq;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                rg[q] = rec[4 * q];
+                ridx[q] = __float_as_int(rec[256 + 4 * q]);
+                rch[q] = 1;
+            }
+            return;
+        }
         const int64_t n = tile * 16 + ci;
         const int64_t nc = n < dg.n ? n : dg.n - 1;
 #pragma unroll
@@ -137,8 +151,8 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
             rch[q] = chp[(size_t)nc * L + lc];
         }
     };
-    issue(tile_at(0), focal_of(tile_at(0)));
-    int64_t focal_next = focal_of(tile_at(1));
+    issue(tile_at(0), records ? 0 : focal_of(tile_at(0)));
+    int64_t focal_next = records ? 0 : focal_of(tile_at(1));
     int par = 0;
 
     for (int64_t it = 0; it < iters; ++it) {
@@ -151,13 +165,13 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
         for (int q = 0; q < 4; ++q) {
             const int i = 4 * q + kq;
             const bool ok = real && n_mine < dg.n && i < kpt && ct * kpt + i < L;
-            const float g = dg.chir ? rg[q] * (float)rch[q] : rg[q];
+            const float g = (dg.chir && !records) ? rg[q] * (float)rch[q] : rg[q];
             cf[q] = ok ? g * ws_n : 0.f;
             ix[q] = ridx[q];
         }
         // next tile's inputs: in flight during this tile's matrix work
         issue(tile_at(it + 1), focal_next);
-        focal_next = focal_of(tile_at(it + 2));
+        if (!records) focal_next = focal_of(tile_at(it + 2));
 
         static_for<0, S1>([&](auto sc) {
             constexpr int s = decltype(sc)::value;       // contribution-row slot: 0 = focal (centre rows), 1 + a = neighbour a
@@ -243,7 +257,7 @@ bool rows_stream_supported(int d, int F, int E, int L) {
     return (L + 15) / 16 == rs::column_tiles(d);
 }
 
-hipError_t launch_backward_rows_stream(const BwdArgs a4[4], const bool use[4], hipStream_t st) {
+hipError_t launch_backward_rows_stream(const BwdArgs a4[4], const bool use[4], float* const coefq[4], hipStream_t st) {
     RowsStreamArgs a;
     memset(&a, 0, sizeof(a));
     int KC = 0, ng = 0;
@@ -259,6 +273,7 @@ hipError_t launch_backward_rows_stream(const BwdArgs a4[4], const bool use[4], h
         RowsStreamDeg& g = a.deg[i];
         g.sel = s.sel; g.pair = s.pair; g.chir = s.chir; g.padded = s.padded; g.mix = s.mix;
         g.contrib = s.contrib; g.contrib_base = s.contrib_base;
+        g.coefq = coefq ? coefq[i] : nullptr;
         g.n = s.n; g.L = s.L; g.off = s.off;
         const int nct = rs::column_tiles(d);
         g.kpt = (s.L + nct - 1) / nct;

@@ -122,30 +122,6 @@ template <int D, int KC> constexpr int young_batches(int s, int role) {
 
 }  // namespace bs
 
-struct BankStreamDeg {
-    const int64_t* sel; const int64_t* nei; const float* e_unit;
-    const float* pair; const int8_t* chir;
-    const float* mix;
-    float* coefq;            // [ntiles][nct][512]: g tile, idx tile
-    float* slab;             // [chunks][bank_floats]
-    float* theta_slab;       // [prepare blocks][4]
-    int64_t n;
-    int L, off, nct, kpt, cs;
-    int prep_blk0, prep_blocks;      // this degree's blocks of the pre-pass
-};
-
-struct BankStreamArgs {
-    const float* x; int64_t xs; const float* inv;
-    const float* gout; int64_t gs;
-    int F, E;
-    BankStreamDeg deg[MKGNN_MAX_DEGREE];
-    uint8_t grp_degree[8];
-    uint8_t grp_cp[8];
-    uint16_t grp_count[8];
-    uint8_t blk_group[FUSED_MAX_BLOCKS];
-    uint16_t blk_rank[FUSED_MAX_BLOCKS];
-};
-
 // ------------------------------------------------------------- pre-pass ---
 // One thread per (atom of a tile, column of a column tile): the pair's dL/dsc (times the chirality sign) and
 // permutation id into tile order, zeros for padding; the three score-weight partials summed per block in a fixed order.
@@ -165,7 +141,11 @@ __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
     float gv[PREP_RPB], S[PREP_RPB], C[PREP_RPB], Ed[PREP_RPB];
     int idx[PREP_RPB], ch[PREP_RPB];
     bool ok[PREP_RPB];
-    int64_t focal[PREP_RPB];
+    // the rows of grad_out this pair's dL/dsc comes from: the focal atom's, or (through_nei: the propagate step's
+    // gradient folded in, KernelLayer.py:119-123) the rows of its D neighbours, summed in slot order
+    const int D = di + 1;
+    const int nsrc = a.through_nei ? D : 1;
+    int64_t src[PREP_RPB][MKGNN_MAX_DEGREE];
 #pragma unroll
     for (int r = 0; r < PREP_RPB; ++r) {
         const int64_t rec = blk * PREP_RPB + r;
@@ -173,9 +153,14 @@ __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
         const int64_t tile = rc / g.nct;
         const int ct = (int)(rc - tile * g.nct);
         const int64_t n = tile * 16 + atom;
+        const int64_t nc = n < g.n ? n : g.n - 1;
         const int l = ct * g.kpt + k;
         ok[r] = rec < nrec && n < g.n && k < g.kpt && l < g.L;
-        focal[r] = g.sel[n < g.n ? n : g.n - 1];
+#pragma unroll
+        for (int s = 0; s < MKGNN_MAX_DEGREE; ++s) {
+            const int sc = s < nsrc ? s : nsrc - 1;      // (clamped: the loads are unconditional, the sum below is not)
+            src[r][s] = a.through_nei ? g.nei[nc * D + sc] : g.sel[nc];
+        }
     }
 #pragma unroll
     for (int r = 0; r < PREP_RPB; ++r) {
@@ -187,7 +172,12 @@ __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
         const int64_t nc = n < g.n ? n : g.n - 1;
         const int l = ct * g.kpt + k, lc = l < g.L ? l : g.L - 1;
         const size_t o = (size_t)nc * g.L + lc;
-        gv[r] = a.gout[focal[r] * a.gs + g.off + lc];
+        float gs4[MKGNN_MAX_DEGREE];
+#pragma unroll
+        for (int s = 0; s < MKGNN_MAX_DEGREE; ++s) gs4[s] = a.gout[src[r][s] * a.gs + g.off + lc];
+        gv[r] = gs4[0];
+#pragma unroll
+        for (int s = 1; s < MKGNN_MAX_DEGREE; ++s) if (s < nsrc) gv[r] += gs4[s];
         const mkgnn_f32x4 pr = pair_load(g.pair, o);
         idx[r] = pair_index(pr);
         ch[r] = chp[o];
@@ -522,10 +512,10 @@ bool bank_stream_supported(int d, int F, int E, int L, int64_t n_atoms, int64_t 
     return stream_forward_supported(d, F, E, L, n_atoms, x_stride, x_stride, e_unit);
 }
 
-hipError_t launch_backward_bank_stream(const BwdArgs a4[4], const bool use[4], const float* const e_unit[4], float* const coefq[4],
-                                       int nchunk_out[4], int ntheta_out[4], hipStream_t st) {
-    BankStreamArgs a;
-    memset(&a, 0, sizeof(a));
+void plan_backward_bank_stream(const BwdArgs a4[4], const bool use[4], const float* const e_unit[4], float* const coefq[4],
+                               int nchunk_out[4], int ntheta_out[4], bool through_nei, BankStreamLaunch* out) {
+    BankStreamArgs& a = out->a;
+    memset(out, 0, sizeof(*out));
     int KC = 0, ng = 0, prep_blocks = 0;
     constexpr int MG = 8;
     double cost[MG];
@@ -538,6 +528,7 @@ hipError_t launch_backward_bank_stream(const BwdArgs a4[4], const bool use[4], c
         const BwdArgs& s = a4[i];
         const int d = i + 1;
         a.x = s.x; a.xs = s.xs; a.inv = s.inv; a.gout = s.gout; a.gs = s.gs; a.F = s.F; a.E = s.E;
+        a.through_nei = through_nei ? 1 : 0;
         KC = mfma_padded_width(s.F) / 16;
         BankStreamDeg& g = a.deg[i];
         g.sel = s.sel; g.nei = s.nei; g.e_unit = e_unit[i]; g.pair = s.pair; g.chir = s.chir; g.mix = s.mix;
@@ -567,7 +558,7 @@ hipError_t launch_backward_bank_stream(const BwdArgs a4[4], const bool use[4], c
             ++ng;
         }
     }
-    if (ng == 0) return hipSuccess;
+    if (ng == 0) return;
     // block counts: greedy min-max as in the forward; the two column parts of degree 4 get the same count (they fill the
     // same slab chunks), and a degree's streams may not outnumber its slab chunks
     auto finish = [&](int g, int blocks) {
@@ -622,8 +613,20 @@ hipError_t launch_backward_bank_stream(const BwdArgs a4[4], const bool use[4], c
         a.grp_count[g] = (uint16_t)count[g];
         nchunk_out[deg_of[g]] = count[g] * nstream_of[g];
     }
-    coef_prepare_kernel<<<prep_blocks, 256, 0, st>>>(a);
-    const size_t lds_bytes = lds_fl * 4;
+    out->nb = nb; out->prep_blocks = prep_blocks; out->KC = KC; out->lds_bytes = lds_fl * 4;
+}
+
+// the pre-pass: its records feed the rows kernel and the bank kernel
+hipError_t launch_coef_prepare(const BankStreamLaunch& p, hipStream_t st) {
+    if (p.prep_blocks == 0) return hipSuccess;
+    coef_prepare_kernel<<<p.prep_blocks, 256, 0, st>>>(p.a);
+    return hipGetLastError();
+}
+
+hipError_t launch_backward_bank_stream(const BankStreamLaunch& p, hipStream_t st) {
+    if (p.nb == 0) return hipSuccess;
+    const int KC = p.KC;
+    const size_t lds_bytes = p.lds_bytes;
     if (lds_bytes > 64 * 1024) {
         static PerDeviceOnce attr_set[2];
         const int which = KC == 2 ? 0 : 1;
@@ -634,8 +637,8 @@ hipError_t launch_backward_bank_stream(const BwdArgs a4[4], const bool use[4], c
             attr_set[which].set(slot);
         }
     }
-    if (KC == 2) kc_backward_bank_stream<2><<<nb, 256, lds_bytes, st>>>(a);
-    else kc_backward_bank_stream<7><<<nb, 256, lds_bytes, st>>>(a);
+    if (KC == 2) kc_backward_bank_stream<2><<<p.nb, 256, lds_bytes, st>>>(p.a);
+    else kc_backward_bank_stream<7><<<p.nb, 256, lds_bytes, st>>>(p.a);
     return hipGetLastError();
 }
 

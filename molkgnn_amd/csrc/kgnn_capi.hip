@@ -103,6 +103,14 @@ struct ForkJoin {
         if (!used[i]) { *e = hipStreamWaitEvent(p->aux[i], p->fork, 0); used[i] = true; }
         return p->aux[i];
     }
+    // order the helper after everything enqueued on the caller's stream so far (a second fork point)
+    hipError_t refork(int slot) {
+        if (!p || slot == 0) return hipSuccess;
+        hipError_t e = hipEventRecord(p->fork, main);
+        if (e != hipSuccess) return e;
+        used[slot - 1] = true;
+        return hipStreamWaitEvent(p->aux[slot - 1], p->fork, 0);
+    }
     hipError_t end() {
         if (!p) return hipSuccess;
         for (int i = 0; i < 3; ++i) {
@@ -301,7 +309,8 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
                                  size_t workspace_bytes, int32_t workspace_from_forward, int32_t variant, void* stream) {
     const char* who = "mkgnn_kernelsetconv_backward";
     const bool defer_bank = (variant & MKGNN_BACKWARD_DEFER_BANK) != 0;
-    variant &= ~MKGNN_BACKWARD_DEFER_BANK;
+    const bool through_nei = (variant & MKGNN_BACKWARD_THROUGH_NEIGHBOURS) != 0;
+    variant &= ~(MKGNN_BACKWARD_DEFER_BANK | MKGNN_BACKWARD_THROUGH_NEIGHBOURS);
     if (variant < 0 || variant > 2) return fail("%s: variant %d (0 = automatic, 1 = generic kernels, 2 = fast kernels)", who, variant);
     const bool force_generic = variant == 1, force_fast = variant == 2;
     int64_t n_edges = 0;
@@ -421,19 +430,13 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         r.iedg = (const float*)(ws + w.bank[i].iedg);
         r.g = grads[i];
     }
-    if (rows_streamed && (bank_use[0] || bank_use[1] || bank_use[2] || bank_use[3])) {
-        e = launch_backward_rows_stream(bank_a, bank_use, st);       // (bank_a holds every active degree's arguments)
-        if (e != hipSuccess) return hip_fail("streamed rows launch", e);
-    }
-    if (bank_use[0] || bank_use[1] || bank_use[2] || bank_use[3]) {
-        int nchunk4[4] = {0, 0, 0, 0}, ntheta4[4] = {0, 0, 0, 0};
-        hipStream_t st_bank = fj.stream(1, &e);      // the helper (the caller's stream when nothing is forked)
-        if (e != hipSuccess) return hip_fail("stream fork", e);
-        // the reference's bank shapes: the streamed MFMA kernel (kgnn_bwd_stream.hip); anything else: the LDS / VALU one.
-        // MKGNN_BANK_STREAM=0: A/B switch (diagnostics)
-        static const char* env_bank_stream = getenv("MKGNN_BANK_STREAM");
-        bool streamed = !(env_bank_stream && env_bank_stream[0] == '0');
-        const float* e_unit4[4]; float* coefq4[4];
+    const bool any_bank = bank_use[0] || bank_use[1] || bank_use[2] || bank_use[3];
+    // the reference's bank shapes: the streamed MFMA kernel (kgnn_bwd_stream.hip); anything else: the LDS / VALU one.
+    // MKGNN_BANK_STREAM=0: A/B switch (diagnostics)
+    static const char* env_bank_stream = getenv("MKGNN_BANK_STREAM");
+    bool streamed = any_bank && !(env_bank_stream && env_bank_stream[0] == '0');
+    const float* e_unit4[4]; float* coefq4[4];
+    {
         size_t coef_off = w.coefq_off[0];
         for (int i = 0; i < 4; ++i) {
             e_unit4[i] = buckets[i].nei_edge_unit; coefq4[i] = nullptr;
@@ -443,7 +446,34 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
             coefq4[i] = (float*)(ws + coef_off);
             coef_off += (size_t)((buckets[i].count + 15) / 16) * nct * 512 * 4;
         }
-        if (streamed) e = launch_backward_bank_stream(bank_a, bank_use, e_unit4, coefq4, nchunk4, ntheta4, st_bank);
+    }
+    if (through_nei) {
+        // grad_out is the gradient of h = propagate(out): only the streamed pair folds that step in (its pre-pass sums the
+        // neighbours' rows); every degree with atoms and kernels must be on it
+        bool all = streamed && rows_streamed;
+        for (int i = 0; i < 4; ++i) if (buckets[i].count > 0 && L[i] > 0 && !bank_use[i]) all = false;
+        if (!all) return fail("%s: MKGNN_BACKWARD_THROUGH_NEIGHBOURS needs the streamed kernels for every degree "
+                              "(mkgnn_backward_streams(..) tells)", who);
+    }
+    BankStreamLaunch bsl;
+    int nchunk4[4] = {0, 0, 0, 0}, ntheta4[4] = {0, 0, 0, 0};
+    if (streamed) {
+        // the pre-pass first, on the caller's stream: its records (dL/dsc and permutation ids in tile order) feed both
+        // the rows kernel here and the bank kernel on the helper
+        plan_backward_bank_stream(bank_a, bank_use, e_unit4, coefq4, nchunk4, ntheta4, through_nei, &bsl);
+        e = launch_coef_prepare(bsl, st);
+        if (e != hipSuccess) return hip_fail("coefficient pre-pass launch", e);
+        e = fj.refork(1);
+        if (e != hipSuccess) return hip_fail("stream fork", e);
+    }
+    if (rows_streamed && any_bank) {
+        e = launch_backward_rows_stream(bank_a, bank_use, streamed ? coefq4 : nullptr, st);       // (bank_a holds every active degree's arguments)
+        if (e != hipSuccess) return hip_fail("streamed rows launch", e);
+    }
+    if (any_bank) {
+        hipStream_t st_bank = fj.stream(1, &e);      // the helper (the caller's stream when nothing is forked)
+        if (e != hipSuccess) return hip_fail("stream fork", e);
+        if (streamed) e = launch_backward_bank_stream(bsl, st_bank);
         else e = launch_backward_bank_fused(bank_a, bank_use, nchunk4, ntheta4, st_bank);
         if (e != hipSuccess) return hip_fail("fused bank gradient launch", e);
         for (int i = 0; i < 4; ++i)
@@ -477,6 +507,28 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         if (e != hipSuccess) return hip_fail("stream join", e);
     }
     return 0;
+}
+
+int mkgnn_backward_streams(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE], const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],
+                           const float* x, int64_t x_stride, int64_t n_atoms, int32_t F, int32_t E) {
+    if (!banks || !buckets) return 0;
+    static const bool no_mfma_bwd = getenv("MKGNN_NO_MFMA_BWD") != nullptr;
+    static const char* env_bank_fused = getenv("MKGNN_BANK_FUSED");
+    static const char* env_rows_stream = getenv("MKGNN_ROWS_STREAM");
+    static const char* env_bank_stream = getenv("MKGNN_BANK_STREAM");
+    if (no_mfma_bwd || (env_bank_fused && env_bank_fused[0] == '0') || (env_rows_stream && env_rows_stream[0] == '0') ||
+        (env_bank_stream && env_bank_stream[0] == '0'))
+        return 0;
+    bool any = false;
+    for (int i = 0; i < 4; ++i) {
+        const int L = banks[i].num_kernels, d = i + 1;
+        if (buckets[i].count <= 0 || L <= 0) continue;
+        any = true;
+        if (!(lds_backward_supported(d, F, E, L, x_stride, x) && mfma_backward_supported(d, F, E, L, x_stride, x, n_atoms) &&
+              rows_stream_supported(d, F, E, L) && bank_stream_supported(d, F, E, L, n_atoms, x_stride, buckets[i].nei_edge_unit)))
+            return 0;
+    }
+    return any ? 1 : 0;
 }
 
 int mkgnn_backward_join(void* stream) {

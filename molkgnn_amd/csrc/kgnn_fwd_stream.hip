@@ -220,7 +220,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
     const int8_t* const eqp = do_chir ? (const int8_t*)dg.eqflag : (const int8_t*)dg.sel;       // always loadable
     const int8_t* const sgp = do_chir ? (const int8_t*)dg.signflag : (const int8_t*)dg.sel;
     const uint32_t xs = (uint32_t)a.xs;
-    const int F = a.F, E = a.E;
+    const int F = a.F;
 
     uint32_t idsD[S1];                                   // atom ids (of atom ci, every slot) of the tile the DMA pointer is in
     auto issue_rows = [&](auto sdc, float* buf) {        // this wave's pieces of slot sd of the DMA tile

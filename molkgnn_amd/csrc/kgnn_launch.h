@@ -109,11 +109,42 @@ int bank_blocks_for(int d, int64_t n);
 hipError_t launch_backward_bank_fused(const BwdArgs a4[4], const bool use[4], int nchunk_out[4], int ntheta_out[4], hipStream_t st);
 // kgnn_bwd_stream.hip: streamed MFMA bank-gradient kernel (+ its coefficient pre-pass), all degrees in one launch
 bool bank_stream_supported(int d, int F, int E, int L, int64_t n_atoms, int64_t x_stride, const float* e_unit);
-hipError_t launch_backward_bank_stream(const BwdArgs a4[4], const bool use[4], const float* const e_unit[4], float* const coefq[4],
-                                       int nchunk_out[4], int ntheta_out[4], hipStream_t st);
+struct BankStreamDeg {
+    const int64_t* sel; const int64_t* nei; const float* e_unit;
+    const float* pair; const int8_t* chir;
+    const float* mix;
+    float* coefq;            // [ntiles][nct][512]: g tile, idx tile
+    float* slab;             // [chunks][bank_floats]
+    float* theta_slab;       // [prepare blocks][4]
+    int64_t n;
+    int L, off, nct, kpt, cs;
+    int prep_blk0, prep_blocks;      // this degree's blocks of the pre-pass
+};
+
+struct BankStreamArgs {
+    const float* x; int64_t xs; const float* inv;
+    const float* gout; int64_t gs;
+    int F, E;
+    int through_nei;         // gout is the gradient of h = propagate(out): d out[n, l] = sum over n's neighbours of gout[nei, l]
+    BankStreamDeg deg[MKGNN_MAX_DEGREE];
+    uint8_t grp_degree[8];
+    uint8_t grp_cp[8];
+    uint16_t grp_count[8];
+    uint8_t blk_group[FUSED_MAX_BLOCKS];
+    uint16_t blk_rank[FUSED_MAX_BLOCKS];
+};
+
+struct BankStreamLaunch { BankStreamArgs a; int nb, prep_blocks, KC; size_t lds_bytes; };
+// block split and arguments once; then the pre-pass (coefficient records in tile order, score-weight partials) and the
+// bank kernel, each on the stream the caller chooses
+void plan_backward_bank_stream(const BwdArgs a4[4], const bool use[4], const float* const e_unit[4], float* const coefq[4],
+                               int nchunk_out[4], int ntheta_out[4], bool through_nei, BankStreamLaunch* out);
+hipError_t launch_coef_prepare(const BankStreamLaunch& p, hipStream_t st);
+hipError_t launch_backward_bank_stream(const BankStreamLaunch& p, hipStream_t st);
 // kgnn_bwd_rows_stream.hip: streamed MFMA rows kernel (bank in registers), all degrees in one launch
 bool rows_stream_supported(int d, int F, int E, int L);
-hipError_t launch_backward_rows_stream(const BwdArgs a4[4], const bool use[4], hipStream_t st);
+// coefq / nct: the pre-pass's records (null: the kernel gathers its coefficients itself)
+hipError_t launch_backward_rows_stream(const BwdArgs a4[4], const bool use[4], float* const coefq[4], hipStream_t st);
 // kgnn_bwd_mfma.hip: MFMA backward for the model's shapes
 bool mfma_backward_supported(int d, int F, int E, int L, int64_t xs, const void* x, int64_t n_atoms);
 hipError_t launch_backward_rows_mfma(int d, const BwdArgs& a, int* ntheta_out, hipStream_t st);
