@@ -19,6 +19,7 @@ from .receptive_field import GraphBatch
 
 # diagnostics: MKGNN_DENSE_PROPAGATE=1 keeps sim_sc dense (zero-filled rows, dense sums) between convolution and propagate
 _BLOCK_ROWS = os.environ.get("MKGNN_DENSE_PROPAGATE") is None
+_FUSE_PROPAGATE = _BLOCK_ROWS and os.environ.get("MKGNN_SPLIT_PROPAGATE") is None
 
 try:
     from torch_geometric.nn import MessagePassing  # type: ignore
@@ -111,8 +112,11 @@ class MolGCN(MessagePassing):
                 data.x = h
                 is_last_layer = (i == self.num_layers - 1)
                 # sim_sc goes nowhere but into propagate: block rows (no zero fill, block-sparse sums both ways)
-                sim_sc = self.layers[i]._run(h, self._plan, is_last_layer, save_score, block_rows=_BLOCK_ROWS)
-                h = self.propagate(edge_index=edge_index, sim_sc=sim_sc)
+                # ... and convolution + propagate as one operator where that applies (its backward folds the propagate
+                # step's gradient into the kernels' pre-pass); MKGNN_SPLIT_PROPAGATE=1: two operators (diagnostics)
+                sim_sc, propagated = self.layers[i]._run(h, self._plan, is_last_layer, save_score, block_rows=_BLOCK_ROWS,
+                                                         fuse_propagate=_FUSE_PROPAGATE)
+                h = sim_sc if propagated else self.propagate(edge_index=edge_index, sim_sc=sim_sc)
         finally:
             self._plan = None
         return h

@@ -9,6 +9,8 @@ from __future__ import annotations
 
 from typing import List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from . import _lib
@@ -179,6 +181,7 @@ def kernelsetconv_details(x, plan: BatchPlan, is_last_layer: bool, params, edge_
 
 
 DEFER_BANK = 0x100           # MKGNN_BACKWARD_DEFER_BANK
+THROUGH_NEIGHBOURS = 0x200   # MKGNN_BACKWARD_THROUGH_NEIGHBOURS
 
 
 class _Deferred:
@@ -220,7 +223,7 @@ class _KernelSetConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad: int, E: int, inv, bwd_variant: int,
-                *params):
+                propagate: bool, *params):
         need_grad = any(ctx.needs_input_grad)
         ctx.bwd_variant = int(bwd_variant)
         x, out_full, inv, saved_t, Ls, ws = _forward_impl(x, plan, is_last_layer, variant, out_pad, E, params, need_grad, inv)
@@ -230,19 +233,46 @@ class _KernelSetConvFn(torch.autograd.Function):
         ctx.param_versions = [p._version for p in params]
         ctx.saved_t = saved_t
         ctx.save_for_backward(x, inv, *params)
+        ctx.propagate = bool(propagate)
         K = sum(Ls)
-        return out_full[:, :K] if out_full.shape[1] != K else out_full
+        sim_sc = out_full[:, :K] if out_full.shape[1] != K else out_full
+        if not propagate:
+            return sim_sc
+        # ... followed by MolGCN.propagate (KernelLayer.py:119-123) on the block rows, as ONE differentiable operator: its
+        # backward hands the gradient of h straight to the kernels (MKGNN_BACKWARD_THROUGH_NEIGHBOURS) where they can
+        # fold the propagate step's gradient in, instead of making a pass over the edges for it
+        inv_h = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        h = _segment_sum_blocks(sim_sc, plan.csr_in_packed, None, tuple(Ls), 1, (-K) % 4, inv_h)
+        ctx.mark_non_differentiable(inv_h)
+        ctx.set_materialize_grads(False)
+        return h, inv_h
 
     @staticmethod
-    def backward(ctx, grad_out):
+    def backward(ctx, grad_out, _grad_inv=None):
         lib = _lib.load()
         x, inv, *params = ctx.saved_tensors
         plan, E, Ls = ctx.plan, ctx.E, ctx.Ls
         n, F = x.shape
         dev = x.device
+        if grad_out is None:
+            return (None,) * (9 + len(params))
         g = _row_major(grad_out if grad_out.dtype == torch.float32 else grad_out.float())
         banks, _, keep = _banks(params, F, E)
         buckets = _buckets(plan, E, False)
+        through = 0
+        if ctx.propagate:
+            # g is d loss / d h.  The streamed kernels sum the neighbours' rows of it themselves; anything else gets the
+            # propagate step's gradient (every atom's own block of d sim_sc) from its own pass first
+            with torch.cuda.device(dev):
+                streams = ctx.bwd_variant != BACKWARD_VARIANTS["generic"] and \
+                    lib.mkgnn_backward_streams(banks, buckets, x.data_ptr(), _stride0(x), n, F, E) == 1
+            if streams and not os.environ.get("MKGNN_NO_THROUGH_NEIGHBOURS"):
+                through = THROUGH_NEIGHBOURS
+            else:
+                K = sum(Ls)
+                if _stride0(g) % 4 or g.data_ptr() % 16:
+                    g = _aligned_rows(g)
+                g = _segment_sum_blocks(g, plan.csr_out, plan.deg8, tuple(Ls), 2, (-K) % 4, None)
         saved = _lib.Saved4()
         for i, (pr, ch) in enumerate(ctx.saved_t):
             saved[i].pair_state = _lib.ptr(pr)
@@ -283,7 +313,7 @@ class _KernelSetConvFn(torch.autograd.Function):
                 all(p._version == v for p, v in zip(params, ctx.param_versions))
             if not reuse:
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            bwd_variant = ctx.bwd_variant
+            bwd_variant = ctx.bwd_variant | through
             live = [p for p in params if p.requires_grad]
             defer = _Deferred.active and all(p.grad is None and id(p) not in _Deferred.seen for p in live)
             if defer:
@@ -300,7 +330,7 @@ class _KernelSetConvFn(torch.autograd.Function):
                 _lib.ptr(gx), F4, grads, ws.data_ptr(), ws_bytes, int(reuse), bwd_variant, _lib.stream_ptr(dev)),
                 "mkgnn_kernelsetconv_backward")
         del alive           # (freed memory is only handed out again in stream order, after the kernels above)
-        return (gx, None, None, None, None, None, None, None, *gparams)
+        return (gx, None, None, None, None, None, None, None, None, *gparams)
 
 
 BLOCK_ROWS = 0x100           # MKGNN_VARIANT_BLOCK_ROWS
@@ -309,7 +339,7 @@ _BLOCKS_ATTR = "_mkgnn_block_rows"
 
 def kernelsetconv(x: torch.Tensor, plan: BatchPlan, is_last_layer: bool, params: Sequence[torch.Tensor],
                   edge_attr_dim: int, variant: str = "auto", out_pad: Optional[int] = None,
-                  block_rows: bool = False, backward_variant: Optional[str] = None) -> torch.Tensor:
+                  block_rows: bool = False, backward_variant: Optional[str] = None, propagate: bool = False) -> torch.Tensor:
     """``[N, F] -> [N, K]`` kernel convolution over the four degree buckets of ``plan``.
 
     ``params`` is the flat list, degree 1..4, of (x_center, x_support,
@@ -319,7 +349,9 @@ def kernelsetconv(x: torch.Tensor, plan: BatchPlan, is_last_layer: bool, params:
     ``[:, :K]`` view) so that whatever reads the result next gets 16-byte rows;
     ``out_pad=0`` gives contiguous storage.
 
-    ``block_rows=True`` is for a caller that hands the result straight to ``propagate_add`` (as ``MolGCN.forward``
+    ``propagate=True`` (with ``block_rows=True``) returns ``h = propagate_add(sim_sc)`` instead of ``sim_sc``: convolution and
+    neighbour sum as one operator, whose backward skips the propagate step's own gradient pass where the kernels can fold
+    it in.  ``block_rows=True`` is for a caller that hands the result straight to ``propagate_add`` (as ``MolGCN.forward``
     does): only every atom's own column block is written -- the zeros elsewhere are implied, nothing reads them --
     and the gradient it gets back is defined only there.  The tensor carries the block sizes for ``propagate_add``.
     """
@@ -327,8 +359,15 @@ def kernelsetconv(x: torch.Tensor, plan: BatchPlan, is_last_layer: bool, params:
         raise ValueError("block_rows needs the default padded storage")
     if backward_variant is None:
         backward_variant = "generic" if variant == "generic" else "auto"
+    if propagate:
+        if not block_rows:
+            raise ValueError("propagate=True continues on block rows: block_rows=True is required")
+        h, inv_h = _KernelSetConvFn.apply(x, plan, is_last_layer, VARIANTS[variant] | BLOCK_ROWS, out_pad, edge_attr_dim,
+                                          _handed_inv_norm(x), BACKWARD_VARIANTS[backward_variant], True, *params)
+        setattr(h, _INV_ATTR, (inv_h, h._version))
+        return h
     out = _KernelSetConvFn.apply(x, plan, is_last_layer, VARIANTS[variant] | (BLOCK_ROWS if block_rows else 0), out_pad,
-                                 edge_attr_dim, _handed_inv_norm(x), BACKWARD_VARIANTS[backward_variant], *params)
+                                 edge_attr_dim, _handed_inv_norm(x), BACKWARD_VARIANTS[backward_variant], False, *params)
     if block_rows:
         setattr(out, _BLOCKS_ATTR, tuple(int(p.shape[0]) for p in params[0::7]))
     return out

@@ -197,7 +197,14 @@ class BaseKernelSetConv(Module):
                 [kwargv[f'nei_index_deg{d}'] for d in range(1, 5)], kwargv['edge_index'])
         return self._run(x, plan, is_last_layer, save_score)
 
-    def _run(self, x, plan: BatchPlan, is_last_layer, save_score=False, block_rows=False):
+    def _run(self, x, plan: BatchPlan, is_last_layer, save_score=False, block_rows=False, fuse_propagate=False):
+        """``sim_sc`` of this layer; with ``fuse_propagate`` (and block rows applicable) ``(h, True)`` where
+        ``h = propagate(sim_sc)`` came out of the same operator (functional.kernelsetconv(propagate=True)), else
+        ``(sim_sc, False)``."""
+        out = self._run_impl(x, plan, is_last_layer, save_score, block_rows, fuse_propagate)
+        return out if fuse_propagate else out[0]
+
+    def _run_impl(self, x, plan: BatchPlan, is_last_layer, save_score, block_rows, fuse_propagate):
         for d in range(1, 5):
             if plan.buckets[d - 1].count and self.fixed_kernelconv_set[d - 1] is None \
                     and self.trainable_kernelconv_set[d - 1] is None:
@@ -209,6 +216,9 @@ class BaseKernelSetConv(Module):
             params, E = self._bank_params("train", x)
             block_rows = (bool(block_rows) and not save_score and self.out_pad is None
                           and plan.block_rows_ok(sum(int(p.shape[0]) for p in params[0::7])))
+            if block_rows and fuse_propagate:
+                return Fn.kernelsetconv(x, plan, is_last_layer, params, E, self.variant, self.out_pad, block_rows=True,
+                                        backward_variant=self.backward_variant, propagate=True), True
             sc = Fn.kernelsetconv(x, plan, is_last_layer, params, E, self.variant, self.out_pad, block_rows=block_rows,
                                   backward_variant=self.backward_variant)
         else:
@@ -232,7 +242,7 @@ class BaseKernelSetConv(Module):
             sc = torch.cat(cols, dim=1)
         if save_score == True:  # noqa: E712  (the reference compares with ==)
             self.save_score(sc)
-        return sc
+        return sc, False
 
 
 class KernelSetConv(BaseKernelSetConv):
