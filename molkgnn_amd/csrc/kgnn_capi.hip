@@ -62,8 +62,14 @@ static DegreeStreams* degree_streams() {
     DegreeStreams& p = g_streams[dev];
     std::call_once(p.once, [&p]() {
         bool ok = true;
+        // MKGNN_HELPER_PRIORITY (diagnostics): "low" / "high" = the helpers at the least / greatest stream priority
+        int least = 0, greatest = 0;
+        static const char* env_prio = getenv("MKGNN_HELPER_PRIORITY");
+        const bool ranged = env_prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+        const int prio = (ranged && env_prio[0] == 'l') ? least : ((ranged && env_prio[0] == 'h') ? greatest : 0);
         for (int i = 0; i < 3 && ok; ++i) {
-            ok = hipStreamCreateWithFlags(&p.aux[i], hipStreamNonBlocking) == hipSuccess &&
+            ok = ((ranged && prio != 0) ? hipStreamCreateWithPriority(&p.aux[i], hipStreamNonBlocking, prio)
+                                        : hipStreamCreateWithFlags(&p.aux[i], hipStreamNonBlocking)) == hipSuccess &&
                  hipEventCreateWithFlags(&p.join[i], hipEventDisableTiming) == hipSuccess;
         }
         ok = ok && hipEventCreateWithFlags(&p.fork, hipEventDisableTiming) == hipSuccess;
