@@ -124,6 +124,17 @@ size_t mkgnn_workspace_bytes(const int32_t num_kernels[MKGNN_MAX_DEGREE], int32_
  *          | MKGNN_VARIANT_BLOCK_ROWS: the caller will read only each atom's own column block (as
  *              mkgnn_segment_sum_block_rows does): nothing outside the blocks is written, not even zeros. */
 #define MKGNN_VARIANT_BLOCK_ROWS 0x100
+/*          | MKGNN_VARIANT_BANK_PREPARED: `workspace` already holds this call's normalised kernel bank, written by
+ *              mkgnn_bank_prepare for these banks, F and E since the parameters last changed. */
+#define MKGNN_VARIANT_BANK_PREPARED 0x200
+/* The parameter-only part of `count` (<= 4 per call) forward calls -- unit-normalised kernel rows in the layouts the
+ * kernels read, their norms, the chirality sign tables, the mixing weights: reference kernels.py:189, 279-350,
+ * 386-395 -- in ONE launch: call k has banks[4 k .. 4 k + 3], feature width F[k], and gets the head of workspaces[k]
+ * (a buffer of at least mkgnn_workspace_bytes(..) for that call) filled.  The banks depend on the parameters only, so
+ * a model prepares all its layers at the start of a step instead of one small dependent launch per layer. */
+int mkgnn_bank_prepare(int32_t count, const mkgnn_kernel_bank* banks, const int32_t* F, int32_t E,
+                       void* const* workspaces, const size_t* workspace_bytes, void* stream);
+
 int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
                                 const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],
                                 const float* x, int64_t x_stride, const float* inv_norm,

@@ -20,6 +20,7 @@ from .receptive_field import GraphBatch
 # diagnostics: MKGNN_DENSE_PROPAGATE=1 keeps sim_sc dense (zero-filled rows, dense sums) between convolution and propagate
 _BLOCK_ROWS = os.environ.get("MKGNN_DENSE_PROPAGATE") is None
 _FUSE_PROPAGATE = _BLOCK_ROWS and os.environ.get("MKGNN_SPLIT_PROPAGATE") is None
+_PREPARE_ONCE = os.environ.get("MKGNN_PREPARE_PER_LAYER") is None
 
 try:
     from torch_geometric.nn import MessagePassing  # type: ignore
@@ -106,6 +107,14 @@ class MolGCN(MessagePassing):
         self._plan = plan_from_lists_cached(
             x.shape[0], *[[fields[f'{nm}_deg{d}'] for d in range(1, 5)] for nm in names], edge_index,
             units if any(u is not None for u in units) else None)
+        # the kernel banks of ALL layers are normalised by one launch (they depend on the parameters only; layer i reads rows
+        # of width F_i = K_{i-1}): MKGNN_PREPARE_PER_LAYER=1 keeps one launch per layer (diagnostics)
+        prepared = [None] * self.num_layers
+        if x.is_cuda and _PREPARE_ONCE and all(layer._can_prepare() for layer in self.layers):
+            n_slots = sum(int(fields[f'nei_index_deg{d}'].numel()) for d in range(1, 5))
+            pl = [layer._bank_params("train", x) for layer in self.layers]
+            prepared = Fn.prepare_banks([p for p, _ in pl], [x.shape[1]] + [self.num_kernels(i) for i in range(self.num_layers - 1)],
+                                        pl[0][1], x.shape[0], n_slots)
         h = x
         try:
             for i in range(self.num_layers):
@@ -115,7 +124,7 @@ class MolGCN(MessagePassing):
                 # ... and convolution + propagate as one operator where that applies (its backward folds the propagate
                 # step's gradient into the kernels' pre-pass); MKGNN_SPLIT_PROPAGATE=1: two operators (diagnostics)
                 sim_sc, propagated = self.layers[i]._run(h, self._plan, is_last_layer, save_score, block_rows=_BLOCK_ROWS,
-                                                         fuse_propagate=_FUSE_PROPAGATE)
+                                                         fuse_propagate=_FUSE_PROPAGATE, prepared=prepared[i])
                 h = sim_sc if propagated else self.propagate(edge_index=edge_index, sim_sc=sim_sc)
         finally:
             self._plan = None

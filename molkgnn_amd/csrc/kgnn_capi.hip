@@ -201,6 +201,36 @@ static int check_common(const char* who, const mkgnn_kernel_bank banks[4], const
     return 0;
 }
 
+int mkgnn_bank_prepare(int32_t count, const mkgnn_kernel_bank* banks, const int32_t* F, int32_t E, void* const* workspaces,
+                       const size_t* workspace_bytes, void* stream) {
+    const char* who = "mkgnn_bank_prepare";
+    if (count < 0 || count > PREP_MANY_MAX) return fail("%s: %d calls (0..%d per launch)", who, count, PREP_MANY_MAX);
+    if (count == 0) return 0;
+    if (!banks || !F || !workspaces || !workspace_bytes || E <= 0) return fail("%s: bad arguments", who);
+    WorkspaceLayout w[PREP_MANY_MAX];
+    char* ws[PREP_MANY_MAX];
+    int Fs[PREP_MANY_MAX];
+    for (int k = 0; k < count; ++k) {
+        int32_t L[4];
+        for (int i = 0; i < 4; ++i) {
+            const mkgnn_kernel_bank& b = banks[4 * k + i];
+            L[i] = b.num_kernels;
+            if (L[i] < 0) return fail("%s: call %d degree %d has %d kernels", who, k, i + 1, L[i]);
+            if (L[i] > 0 && (!b.x_center || !b.x_support || !b.edge_attr_support || !b.support_attr_sc_weight ||
+                             !b.center_attr_sc_weight || !b.edge_attr_support_sc_weight))
+                return fail("%s: call %d degree %d bank has null parameters", who, k, i + 1);
+        }
+        if (F[k] <= 0) return fail("%s: call %d has F=%d", who, k, F[k]);
+        w[k] = make_layout(L, F[k], E, 0, 0);
+        if (!workspaces[k] || workspace_bytes[k] < w[k].bank[3].end)
+            return fail("%s: call %d: workspace of %zu bytes, the banks need %zu", who, k, workspace_bytes[k], w[k].bank[3].end);
+        ws[k] = (char*)workspaces[k];
+        Fs[k] = F[k];
+    }
+    hipError_t e = launch_bank_prepare_many(count, banks, w, ws, Fs, E, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail(who, e);
+}
+
 int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
                                 const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE], const float* x, int64_t x_stride,
                                 const float* inv_norm, int64_t n_atoms, int32_t F, int32_t E, int32_t is_last_layer,
@@ -217,11 +247,12 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
     if (workspace_bytes < w.fwd_end || !workspace)
         return fail("%s: workspace of %zu bytes, need %zu", who, workspace_bytes, w.fwd_end);
     const bool block_rows_only = (variant & MKGNN_VARIANT_BLOCK_ROWS) != 0;     // the caller reads only each atom's own block
-    variant &= ~MKGNN_VARIANT_BLOCK_ROWS;
+    const bool bank_prepared = (variant & MKGNN_VARIANT_BANK_PREPARED) != 0;    // mkgnn_bank_prepare has filled the workspace's head
+    variant &= ~(MKGNN_VARIANT_BLOCK_ROWS | MKGNN_VARIANT_BANK_PREPARED);
     if (variant < 0 || variant > 3) return fail("%s: variant %d", who, variant);
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
-    hipError_t e = launch_bank_prepare(banks, w, ws, F, E, st);
+    hipError_t e = bank_prepared ? hipSuccess : launch_bank_prepare(banks, w, ws, F, E, st);
     if (e != hipSuccess) return hip_fail("bank_prepare", e);
     // every atom's row is zero outside its own degree block (kernels.py:674-675, 725-727): one
     // streaming memset, the degree kernels then write only their column blocks

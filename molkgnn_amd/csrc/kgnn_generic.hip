@@ -40,10 +40,25 @@ __global__ void row_inv_norm_kernel(const float* __restrict__ x, int64_t stride,
 
 // Unit-normalise every kernel row, keep 1/norm, tabulate the support
 // tetrahedron signs and the mixing weights.  One wave per task.
+__device__ __forceinline__ void bank_prepare_task(const PrepArgs& a, const int task);
+
 __global__ void bank_prepare_kernel(PrepArgs a) {
-    const int lane = threadIdx.x & 63;
     const int task = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (task >= a.row_start[MKGNN_MAX_DEGREE]) return;
+    bank_prepare_task(a, task);
+}
+
+// the banks of up to PREP_MANY_MAX forward calls (the layers of a model) in one launch: mkgnn_bank_prepare
+__global__ void bank_prepare_many_kernel(PrepManyArgs m) {
+    int task = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (task >= m.task_start[m.count]) return;
+    int k = 0;
+    while (task >= m.task_start[k + 1]) ++k;
+    bank_prepare_task(m.layer[k], task - m.task_start[k]);
+}
+
+__device__ __forceinline__ void bank_prepare_task(const PrepArgs& a, const int task) {
+    const int lane = threadIdx.x & 63;
     int i = 0;
     while (task >= a.row_start[i + 1]) ++i;
     const int d = i + 1;
@@ -570,9 +585,30 @@ hipError_t launch_row_inv_norm(const float* x, int64_t stride, int64_t n, int F,
     return hipGetLastError();
 }
 
+static int fill_prep_args(PrepArgs& a, const mkgnn_kernel_bank banks[4], const WorkspaceLayout& w, char* ws, int F, int E);
+
+hipError_t launch_bank_prepare_many(int count, const mkgnn_kernel_bank* banks, const WorkspaceLayout* w, char* const* ws,
+                                    const int* F, int E, hipStream_t st) {
+    PrepManyArgs m;
+    m.count = count;
+    m.task_start[0] = 0;
+    for (int k = 0; k < count; ++k) m.task_start[k + 1] = m.task_start[k] + fill_prep_args(m.layer[k], banks + 4 * k, w[k], ws[k], F[k], E);
+    const int tasks = m.task_start[count];
+    if (tasks == 0) return hipSuccess;
+    bank_prepare_many_kernel<<<(tasks + 3) / 4, 256, 0, st>>>(m);
+    return hipGetLastError();
+}
+
 hipError_t launch_bank_prepare(const mkgnn_kernel_bank banks[4], const WorkspaceLayout& w, char* ws, int F, int E,
                                hipStream_t st) {
     PrepArgs a;
+    const int tasks = fill_prep_args(a, banks, w, ws, F, E);
+    if (tasks == 0) return hipSuccess;
+    bank_prepare_kernel<<<(tasks + 3) / 4, 256, 0, st>>>(a);
+    return hipGetLastError();
+}
+
+static int fill_prep_args(PrepArgs& a, const mkgnn_kernel_bank banks[4], const WorkspaceLayout& w, char* ws, int F, int E) {
     a.F = F; a.E = E;
     a.row_start[0] = 0;
     for (int i = 0; i < 4; ++i) {
@@ -585,10 +621,7 @@ hipError_t launch_bank_prepare(const mkgnn_kernel_bank banks[4], const Workspace
         int L = banks[i].num_kernels, d = i + 1;
         a.row_start[i + 1] = a.row_start[i] + (L > 0 ? L + 2 * L * d + 1 : 0);
     }
-    int tasks = a.row_start[4];
-    if (tasks == 0) return hipSuccess;
-    bank_prepare_kernel<<<(tasks + 3) / 4, 256, 0, st>>>(a);
-    return hipGetLastError();
+    return a.row_start[4];
 }
 
 template <int D>

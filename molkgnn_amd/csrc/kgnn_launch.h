@@ -89,6 +89,10 @@ struct BankReduceArgs {
 };
 
 hipError_t launch_row_inv_norm(const float* x, int64_t stride, int64_t n, int F, float* inv, hipStream_t st);
+constexpr int PREP_MANY_MAX = 4;
+struct PrepManyArgs { PrepArgs layer[PREP_MANY_MAX]; int task_start[PREP_MANY_MAX + 1]; int count; };
+hipError_t launch_bank_prepare_many(int count, const mkgnn_kernel_bank* banks /* [count][4] */, const WorkspaceLayout* w,
+                                    char* const* ws, const int* F, int E, hipStream_t st);
 hipError_t launch_bank_prepare(const mkgnn_kernel_bank banks[4], const WorkspaceLayout& w, char* ws, int F, int E,
                                hipStream_t st);
 hipError_t launch_forward_generic(int d, const FwdArgs& a, hipStream_t st);

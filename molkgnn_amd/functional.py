@@ -114,8 +114,58 @@ def row_inv_norm(x: torch.Tensor) -> torch.Tensor:
     return inv
 
 
+BANK_PREPARED = 0x200        # MKGNN_VARIANT_BANK_PREPARED
+
+
+class PreparedBank:
+    """The workspace of one forward call with its normalised kernel bank already in it (``prepare_banks``)."""
+    __slots__ = ("ws", "key")
+
+    def __init__(self, ws, key):
+        self.ws, self.key = ws, key
+
+
+def _prepared_key(params, F, E, n_atoms, n_slots):
+    return (F, E, n_atoms, n_slots) + tuple((p.data_ptr(), p._version) for p in params)
+
+
+def prepare_banks(params_per_call: Sequence[Sequence[torch.Tensor]], Fs: Sequence[int], E: int, n_atoms: int, n_slots: int):
+    """``mkgnn_bank_prepare``: the normalised kernel banks of several forward calls (the layers of a model; call k will
+    be ``kernelsetconv(x [n_atoms, Fs[k]], ..., params_per_call[k], E, prepared=result[k])``) in ONE launch on the current
+    stream -- the banks depend on the parameters only, and one small dependent launch per layer leaves the step.
+    Returns one ``PreparedBank`` per call."""
+    lib = _lib.load()
+    dev = params_per_call[0][0].device
+    out: List[PreparedBank] = []
+    with torch.no_grad():
+        for lo in range(0, len(params_per_call), 4):             # (<= 4 calls per launch)
+            chunk = params_per_call[lo:lo + 4]
+            cnt = len(chunk)
+            banks_all = (_lib.KernelBank * (4 * cnt))()
+            keep, wss, nbytes = [], [], []
+            for k, params in enumerate(chunk):
+                banks, Ls, kp = _banks([p.detach() for p in params], Fs[lo + k], E)
+                keep += kp
+                for i in range(4):
+                    banks_all[4 * k + i] = banks[i]
+                nb = workspace_bytes(Ls, Fs[lo + k], E, n_atoms, n_slots)
+                wss.append(torch.empty(nb, dtype=torch.uint8, device=dev))
+                nbytes.append(nb)
+            import ctypes as C
+            Farr = (C.c_int32 * cnt)(*[int(f) for f in Fs[lo:lo + cnt]])
+            wsarr = (C.c_void_p * cnt)(*[w.data_ptr() for w in wss])
+            nbarr = (C.c_size_t * cnt)(*nbytes)
+            with torch.cuda.device(dev):
+                _lib.check(lib.mkgnn_bank_prepare(cnt, C.cast(banks_all, C.c_void_p), C.cast(Farr, C.c_void_p), E,
+                                                  C.cast(wsarr, C.c_void_p), C.cast(nbarr, C.c_void_p), _lib.stream_ptr(dev)),
+                           "mkgnn_bank_prepare")
+            for k, params in enumerate(chunk):
+                out.append(PreparedBank(wss[k], _prepared_key(params, Fs[lo + k], E, n_atoms, n_slots)))
+    return out
+
+
 def _forward_impl(x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad: int, E: int, params, want_saved: bool,
-                  inv=None):
+                  inv=None, prepared: Optional[PreparedBank] = None):
     lib = _lib.load()
     _lib.require_gpu_tensor(x, "x")
     x = _row_major(x) if (variant & 0xFF) == VARIANTS["generic"] else _aligned_rows(x)
@@ -151,7 +201,12 @@ def _forward_impl(x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad
             inv = torch.empty(n, dtype=torch.float32, device=dev)
             _lib.check(lib.mkgnn_row_inv_norm(x.data_ptr(), _stride0(x), n, F, inv.data_ptr(), st), "mkgnn_row_inv_norm")
         ws_bytes = workspace_bytes(Ls, F, E, n, plan.n_slots)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        if prepared is not None and prepared.key == _prepared_key(params, F, E, n, plan.n_slots) \
+                and prepared.ws.numel() >= ws_bytes:
+            ws = prepared.ws                  # the bank is in it already (prepare_banks)
+            variant |= BANK_PREPARED
+        else:
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         _lib.check(lib.mkgnn_kernelsetconv_forward(
             banks, buckets, x.data_ptr(), _stride0(x), inv.data_ptr(), n, F, E, int(bool(is_last_layer)),
             out_full.data_ptr(), out_w, saved, ws.data_ptr(), ws_bytes, variant, st),
@@ -223,10 +278,11 @@ class _KernelSetConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad: int, E: int, inv, bwd_variant: int,
-                propagate: bool, *params):
+                propagate: bool, prepared, *params):
         need_grad = any(ctx.needs_input_grad)
         ctx.bwd_variant = int(bwd_variant)
-        x, out_full, inv, saved_t, Ls, ws = _forward_impl(x, plan, is_last_layer, variant, out_pad, E, params, need_grad, inv)
+        x, out_full, inv, saved_t, Ls, ws = _forward_impl(x, plan, is_last_layer, variant, out_pad, E, params, need_grad, inv,
+                                                          prepared)
         ctx.plan, ctx.is_last, ctx.E, ctx.Ls = plan, bool(is_last_layer), E, Ls
         # the workspace holds the normalised kernel bank: backward reuses it (and the buffer) instead of redoing it
         ctx.ws = ws if need_grad else None
@@ -255,7 +311,7 @@ class _KernelSetConvFn(torch.autograd.Function):
         n, F = x.shape
         dev = x.device
         if grad_out is None:
-            return (None,) * (9 + len(params))
+            return (None,) * (10 + len(params))
         g = _row_major(grad_out if grad_out.dtype == torch.float32 else grad_out.float())
         banks, _, keep = _banks(params, F, E)
         buckets = _buckets(plan, E, False)
@@ -330,7 +386,7 @@ class _KernelSetConvFn(torch.autograd.Function):
                 _lib.ptr(gx), F4, grads, ws.data_ptr(), ws_bytes, int(reuse), bwd_variant, _lib.stream_ptr(dev)),
                 "mkgnn_kernelsetconv_backward")
         del alive           # (freed memory is only handed out again in stream order, after the kernels above)
-        return (gx, None, None, None, None, None, None, None, None, *gparams)
+        return (gx, None, None, None, None, None, None, None, None, None, *gparams)
 
 
 BLOCK_ROWS = 0x100           # MKGNN_VARIANT_BLOCK_ROWS
@@ -339,7 +395,8 @@ _BLOCKS_ATTR = "_mkgnn_block_rows"
 
 def kernelsetconv(x: torch.Tensor, plan: BatchPlan, is_last_layer: bool, params: Sequence[torch.Tensor],
                   edge_attr_dim: int, variant: str = "auto", out_pad: Optional[int] = None,
-                  block_rows: bool = False, backward_variant: Optional[str] = None, propagate: bool = False) -> torch.Tensor:
+                  block_rows: bool = False, backward_variant: Optional[str] = None, propagate: bool = False,
+                  prepared: Optional[PreparedBank] = None) -> torch.Tensor:
     """``[N, F] -> [N, K]`` kernel convolution over the four degree buckets of ``plan``.
 
     ``params`` is the flat list, degree 1..4, of (x_center, x_support,
@@ -363,11 +420,12 @@ def kernelsetconv(x: torch.Tensor, plan: BatchPlan, is_last_layer: bool, params:
         if not block_rows:
             raise ValueError("propagate=True continues on block rows: block_rows=True is required")
         h, inv_h = _KernelSetConvFn.apply(x, plan, is_last_layer, VARIANTS[variant] | BLOCK_ROWS, out_pad, edge_attr_dim,
-                                          _handed_inv_norm(x), BACKWARD_VARIANTS[backward_variant], True, *params)
+                                          _handed_inv_norm(x), BACKWARD_VARIANTS[backward_variant], True, prepared, *params)
         setattr(h, _INV_ATTR, (inv_h, h._version))
         return h
     out = _KernelSetConvFn.apply(x, plan, is_last_layer, VARIANTS[variant] | (BLOCK_ROWS if block_rows else 0), out_pad,
-                                 edge_attr_dim, _handed_inv_norm(x), BACKWARD_VARIANTS[backward_variant], False, *params)
+                                 edge_attr_dim, _handed_inv_norm(x), BACKWARD_VARIANTS[backward_variant], False, prepared,
+                                 *params)
     if block_rows:
         setattr(out, _BLOCKS_ATTR, tuple(int(p.shape[0]) for p in params[0::7]))
     return out

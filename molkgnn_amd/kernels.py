@@ -197,14 +197,18 @@ class BaseKernelSetConv(Module):
                 [kwargv[f'nei_index_deg{d}'] for d in range(1, 5)], kwargv['edge_index'])
         return self._run(x, plan, is_last_layer, save_score)
 
-    def _run(self, x, plan: BatchPlan, is_last_layer, save_score=False, block_rows=False, fuse_propagate=False):
+    def _can_prepare(self) -> bool:
+        """One trainable KernelConv per degree and no fixed ones (the reference's KernelSetConv): one bank per call."""
+        return all(k is not None for k in self.trainable_kernelconv_set) and all(k is None for k in self.fixed_kernelconv_set)
+
+    def _run(self, x, plan: BatchPlan, is_last_layer, save_score=False, block_rows=False, fuse_propagate=False, prepared=None):
         """``sim_sc`` of this layer; with ``fuse_propagate`` (and block rows applicable) ``(h, True)`` where
         ``h = propagate(sim_sc)`` came out of the same operator (functional.kernelsetconv(propagate=True)), else
         ``(sim_sc, False)``."""
-        out = self._run_impl(x, plan, is_last_layer, save_score, block_rows, fuse_propagate)
+        out = self._run_impl(x, plan, is_last_layer, save_score, block_rows, fuse_propagate, prepared)
         return out if fuse_propagate else out[0]
 
-    def _run_impl(self, x, plan: BatchPlan, is_last_layer, save_score, block_rows, fuse_propagate):
+    def _run_impl(self, x, plan: BatchPlan, is_last_layer, save_score, block_rows, fuse_propagate, prepared=None):
         for d in range(1, 5):
             if plan.buckets[d - 1].count and self.fixed_kernelconv_set[d - 1] is None \
                     and self.trainable_kernelconv_set[d - 1] is None:
@@ -218,9 +222,9 @@ class BaseKernelSetConv(Module):
                           and plan.block_rows_ok(sum(int(p.shape[0]) for p in params[0::7])))
             if block_rows and fuse_propagate:
                 return Fn.kernelsetconv(x, plan, is_last_layer, params, E, self.variant, self.out_pad, block_rows=True,
-                                        backward_variant=self.backward_variant, propagate=True), True
+                                        backward_variant=self.backward_variant, propagate=True, prepared=prepared), True
             sc = Fn.kernelsetconv(x, plan, is_last_layer, params, E, self.variant, self.out_pad, block_rows=block_rows,
-                                  backward_variant=self.backward_variant)
+                                  backward_variant=self.backward_variant, prepared=prepared)
         else:
             # fixed kernels come first inside every degree block (kernels.py:702-710)
             parts = {}
