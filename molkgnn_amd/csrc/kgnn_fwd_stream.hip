@@ -518,9 +518,17 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
 #else
             if (real && col_ok && n < dg.n) {
 #endif
+#ifndef MKGNN_ABLATE_OUT                                  // (timing experiments: one kind of store left out)
                 a.out[focal * (uint32_t)a.os + (uint32_t)(dg.off + lcol)] = sc;     // (the host checks n_atoms * stride < 2^30)
+#else
+                asm volatile("" :: "v"(sc), "v"(focal));
+#endif
                 const uint32_t o = (uint32_t)n * (uint32_t)L + (uint32_t)lcol;   // the host fuses a degree only if N_d * L < 2^32
+#ifndef MKGNN_ABLATE_PAIR
                 if (dg.pair) pair_store(dg.pair, o, best4[j], cen4[j], ed, idx4[j]);     // one 16-byte record per pair
+#else
+                asm volatile("" :: "v"(o), "v"(ed), "v"(best4[j]), "v"(cen4[j]), "v"(idx4[j]));
+#endif
                 if (dg.chir_out) dg.chir_out[o] = (int8_t)ch;
             }
         }

@@ -15,10 +15,10 @@ molecules of a (pre-shuffled) part of the data set **already concatenated**, in 
 * data-parallel ranks take batches ``rank, rank + world, ...`` of the same shard sequence, so the union over
   ranks is the single-GPU stream.
 
-Layout (version 1)::
+Layout (version 2)::
 
     header   256 bytes: b"MKGS", u32 version, u64 n_molecules, u64 n_atoms, u64 n_bonds (directed edges),
-                        u32 x_dim, u32 e_dim, u32 p_dim, u32 reserved, then 9 x u64 array offsets in the order below
+                        u32 x_dim, u32 e_dim, u32 p_dim, u32 reserved, then 10 x u64 array offsets in the order below
     mol_atom_ptr  i64 [M + 1]     first atom of every molecule
     mol_edge_ptr  i64 [M + 1]     first directed edge of every molecule
     y             f32 [M]         label (data.py:37 trains on one task)
@@ -28,6 +28,14 @@ Layout (version 1)::
     edge_src      i32 [E]         shard-global atom ids; bonds as consecutive (i, j), (j, i) (wrapper.py:152-156)
     edge_dst      i32 [E]
     edge_attr     f32 [E, e_dim]
+    mol_deg_ptr   i64 [M + 1, 5]  prefix sums over molecules of their atoms of degree 1, 2, 3, 4 and of any other degree:
+                                  the degree histogram of a molecule range is one subtraction (fixed-shape padding)
+
+Fixed-shape batches (``padding.py``: one captured graph serves every batch) come straight out of the loader:
+``ShardLoader(..., fixed_shape=True)`` pads every batch ON THE HOST while staging it -- the padding atoms, their bonds
+and molecules exactly as ``padding.pad_batch`` makes them -- directly in the layout of ``padding.StaticBatch``'s flat
+buffer, so a batch reaches the static buffers by one host-to-device copy and one device copy, with no device-side
+index work and no host synchronisation.
 """
 from __future__ import annotations
 
@@ -42,11 +50,11 @@ import torch
 from .receptive_field import GraphBatch
 
 MAGIC = b"MKGS"
-VERSION = 1
+VERSION = 2
 HEADER_BYTES = 256
 ALIGN = 64
-_ARRAYS = ("mol_atom_ptr", "mol_edge_ptr", "y", "assay_id", "x", "p", "edge_src", "edge_dst", "edge_attr")
-_HEAD = struct.Struct("<4sIQQQIIII9Q")
+_ARRAYS = ("mol_atom_ptr", "mol_edge_ptr", "y", "assay_id", "x", "p", "edge_src", "edge_dst", "edge_attr", "mol_deg_ptr")
+_HEAD = struct.Struct("<4sIQQQIIII10Q")
 
 
 def _align(n: int) -> int:
@@ -77,9 +85,16 @@ def write_shard(path: str, batch: GraphBatch) -> None:
     edge_ptr[1:] = np.cumsum(np.bincount(edge_mol, minlength=m))
     assay = getattr(batch, "assay_id", None)
     assay = np.zeros(m, dtype=np.int32) if assay is None else assay.detach().cpu().numpy().astype(np.int32)
+    deg = np.bincount(ei[0], minlength=a) if e else np.zeros(a, dtype=np.int64)
+    cls = np.where((deg >= 1) & (deg <= 4), deg - 1, 4)                 # 0..3: degree 1..4, 4: in no bucket
+    per_mol = np.zeros((m, 5), dtype=np.int64)
+    np.add.at(per_mol, (bvec, cls), 1)
+    deg_ptr = np.zeros((m + 1, 5), dtype=np.int64)
+    deg_ptr[1:] = np.cumsum(per_mol, axis=0)
     arrays = {"mol_atom_ptr": atom_ptr, "mol_edge_ptr": edge_ptr, "y": y, "assay_id": assay,
               "x": np.ascontiguousarray(x), "p": np.ascontiguousarray(p),
-              "edge_src": ei[0].astype(np.int32), "edge_dst": ei[1].astype(np.int32), "edge_attr": np.ascontiguousarray(ea)}
+              "edge_src": ei[0].astype(np.int32), "edge_dst": ei[1].astype(np.int32), "edge_attr": np.ascontiguousarray(ea),
+              "mol_deg_ptr": deg_ptr}
     offsets, off = [], HEADER_BYTES
     for name in _ARRAYS:
         offsets.append(off)
@@ -113,7 +128,8 @@ class Shard:
         self.x_dim, self.e_dim, self.p_dim = int(xd), int(ed), int(pd)
         shapes = {"mol_atom_ptr": (np.int64, (m + 1,)), "mol_edge_ptr": (np.int64, (m + 1,)), "y": (np.float32, (m,)),
                   "assay_id": (np.int32, (m,)), "x": (np.float32, (a, xd)), "p": (np.float32, (a, pd)),
-                  "edge_src": (np.int32, (e,)), "edge_dst": (np.int32, (e,)), "edge_attr": (np.float32, (e, ed))}
+                  "edge_src": (np.int32, (e,)), "edge_dst": (np.int32, (e,)), "edge_attr": (np.float32, (e, ed)),
+                  "mol_deg_ptr": (np.int64, (m + 1, 5))}
         size = os.path.getsize(path)
         self._mm = np.memmap(path, dtype=np.uint8, mode="r")
         for name, o in zip(_ARRAYS, offs):
@@ -124,6 +140,11 @@ class Shard:
             setattr(self, name, np.frombuffer(self._mm, dtype=dt, count=int(np.prod(shp)), offset=int(o)).reshape(shp))
         if self.mol_atom_ptr[-1] != a or self.mol_edge_ptr[-1] != e:
             raise ValueError(f"{path}: molecule pointers do not cover the arrays")
+
+    def degree_histogram(self, m0: int, m1: int) -> List[int]:
+        """``padding.degree_histogram`` of the molecules [m0, m1): [atoms, N_1, N_2, N_3, N_4, atoms in no bucket]."""
+        d = (self.mol_deg_ptr[m1] - self.mol_deg_ptr[m0]).tolist()
+        return [int(self.mol_atom_ptr[m1] - self.mol_atom_ptr[m0]), d[0], d[1], d[2], d[3], d[4]]
 
     def ranges(self, m0: int, m1: int):
         return (int(self.mol_atom_ptr[m0]), int(self.mol_atom_ptr[m1]), int(self.mol_edge_ptr[m0]), int(self.mol_edge_ptr[m1]))
@@ -183,6 +204,95 @@ def collate(shard: Shard, m0: int, m1: int, device, staging: Optional[torch.Tens
     return out
 
 
+def padded_layout(shape, num_molecules: int, x_dim: int, p_dim: int, e_dim: int):
+    """Field table of ``padding.StaticBatch``'s flat buffer for a fixed shape: (name, offset, shape, numpy dtype, bytes)."""
+    from .padding import PAD_MOLECULES, StaticBatch
+    A, Eg, G = shape["atoms"], shape["edges"], num_molecules + PAD_MOLECULES
+    spec = {"x": ((A, x_dim), np.float32), "p": ((A, p_dim), np.float32), "edge_index": ((2, Eg), np.int64),
+            "edge_attr": ((Eg, e_dim), np.float32), "batch": ((A,), np.int64), "y": ((num_molecules,), np.float32),
+            "mol_ptr": ((G + 1,), np.int32), "atom_mol": ((A,), np.int32), "n_valid_atoms": ((1,), np.int64)}
+    table, off = [], 0
+    for k in StaticBatch.FIELDS:
+        shp, dt = spec[k]
+        nbytes = int(np.prod(shp)) * np.dtype(dt).itemsize
+        table.append((k, off, shp, dt, nbytes))
+        off += (nbytes + 255) // 256 * 256
+    return table, off
+
+
+def collate_padded(shard: Shard, m0: int, m1: int, shape, host: np.ndarray) -> None:
+    """Molecules ``[m0, m1)`` padded to ``shape`` (``padding.fixed_shape``), written into ``host`` (uint8, the flat
+    layout of ``padded_layout``): what ``padding.pack(padding.pad_batch(collate(...), shape, m1 - m0))`` holds, made on
+    the host with slice copies and a few small index fills."""
+    from .padding import PAD_MOLECULES
+    nm = m1 - m0
+    a0, a1, e0, e1 = shard.ranges(m0, m1)
+    na, ne = a1 - a0, e1 - e0
+    h = shard.degree_histogram(m0, m1)
+    need = [shape[f"n{d}"] - h[d] for d in range(1, 5)]
+    if min(need) < 0 or h[5]:
+        raise ValueError(f"molecules [{m0}, {m1}) with degree histogram {h[1:5]} (+{h[5]} in no bucket) do not fit the shape {shape}")
+    n_pad = sum(need)
+    table, total = padded_layout(shape, nm, shard.x_dim, shard.p_dim, shard.e_dim)
+    if host.shape[0] < total:
+        raise ValueError("staging buffer too small")
+    f = {k: host[off:off + nbytes].view(dt).reshape(shp) for k, off, shp, dt, nbytes in table}
+    f["x"][:na] = shard.x[a0:a1]; f["x"][na:] = 0.0
+    f["p"][:na] = shard.p[a0:a1]; f["p"][na:] = 0.0
+    f["edge_attr"][:ne] = shard.edge_attr[e0:e1]
+    f["edge_attr"][ne:] = 0.0
+    f["edge_attr"][ne:, 0] = 1.0
+    ei = f["edge_index"]
+    np.subtract(shard.edge_src[e0:e1], a0, out=ei[0, :ne], casting="unsafe")
+    np.subtract(shard.edge_dst[e0:e1], a0, out=ei[1, :ne], casting="unsafe")
+    # padding atoms in degree order, their bond stubs paired off in sequence (padding.pad_batch)
+    deg_of = np.repeat(np.arange(1, 5), need)
+    stubs = np.repeat(np.arange(n_pad, dtype=np.int64), deg_of) + na
+    if stubs.shape[0] % 2 or stubs.shape[0] != shape["edges"] - ne:
+        raise ValueError("padding bond stubs do not pair up: the shape does not come from fixed_shape() over these batches")
+    a, b = stubs[0::2], stubs[1::2]
+    ei[0, ne::2] = a; ei[0, ne + 1::2] = b
+    ei[1, ne::2] = b; ei[1, ne + 1::2] = a
+    atom_ptr = shard.mol_atom_ptr[m0:m1 + 1] - a0
+    counts = np.diff(atom_ptr)
+    bt = f["batch"]
+    bt[:na] = np.repeat(np.arange(nm, dtype=np.int64), counts)
+    bt[na:] = nm + (np.arange(n_pad, dtype=np.int64) * PAD_MOLECULES) // max(n_pad, 1)
+    f["atom_mol"][:] = bt
+    f["y"][:] = shard.y[m0:m1]
+    mp = f["mol_ptr"]
+    mp[0] = 0
+    mp[1:nm + 1] = atom_ptr[1:]
+    pad_counts = np.bincount(bt[na:] - nm, minlength=PAD_MOLECULES)
+    mp[nm + 1:] = na + np.cumsum(pad_counts)
+    f["n_valid_atoms"][0] = na
+
+
+class PackedBatch:
+    """A fixed-shape batch as one flat device buffer in ``padding.StaticBatch``'s layout (``StaticBatch.load`` takes it)."""
+
+    def __init__(self, flat, shape, num_molecules: int):
+        from .padding import PAD_MOLECULES
+        self.flat = flat
+        self.bucket_sizes = [shape["n1"], shape["n2"], shape["n3"], shape["n4"]]
+        self.n_valid_molecules, self.num_graphs = num_molecules, num_molecules + PAD_MOLECULES
+
+    def unpack(self, shard_dims) -> GraphBatch:
+        """The fields as views of the flat buffer (a ``padding.pad_batch`` result)."""
+        x_dim, p_dim, e_dim = shard_dims
+        shape = {"n1": self.bucket_sizes[0], "n2": self.bucket_sizes[1], "n3": self.bucket_sizes[2], "n4": self.bucket_sizes[3]}
+        shape["atoms"] = sum(self.bucket_sizes)
+        shape["edges"] = sum((d + 1) * self.bucket_sizes[d] for d in range(4))
+        table, _ = padded_layout(shape, self.n_valid_molecules, x_dim, p_dim, e_dim)
+        out = GraphBatch()
+        tdt = {np.float32: torch.float32, np.int64: torch.int64, np.int32: torch.int32}
+        for k, off, shp, dt, nbytes in table:
+            setattr(out, k, self.flat[off:off + nbytes].view(tdt[dt]).view(shp))
+        out.flat = self.flat
+        out.bucket_sizes, out.n_valid_molecules, out.num_graphs = self.bucket_sizes, self.n_valid_molecules, self.num_graphs
+        return out
+
+
 class _null:
     def __enter__(self):
         return self
@@ -201,13 +311,24 @@ class ShardLoader:
     """
 
     def __init__(self, paths: Sequence[str], batch_size: int, device="cpu", rank: int = 0, world: int = 1,
-                 prefetch: int = 2, drop_last: bool = False, workers: int = 2):
+                 prefetch: int = 2, drop_last: bool = False, workers: int = 2, fixed_shape: bool = False):
         if not (0 <= rank < world):
             raise ValueError(f"rank {rank} of world {world}")
         self.paths, self.batch_size, self.device = list(paths), int(batch_size), torch.device(device)
         self.rank, self.world, self.prefetch, self.drop_last = rank, world, max(1, int(prefetch)), drop_last
         self.workers = max(1, int(workers))
         self.shards = [Shard(p) for p in self.paths]
+        # fixed_shape: every batch padded on the host to the common shape of this rank's batches (padding.fixed_shape) and
+        # handed over as a PackedBatch; short tail batches are dropped (the static buffers hold exactly batch_size molecules)
+        self._pinned: list = []
+        self.shape = None
+        if fixed_shape:
+            from .padding import fixed_shape as _fixed_shape
+            self.drop_last = True
+            work = self.plan()
+            if not work:
+                raise ValueError("no full batch for this rank")
+            self.shape = _fixed_shape([self.shards[si].degree_histogram(m0, m1) for si, m0, m1 in work])
 
     def plan(self) -> List[tuple]:
         """``(shard index, m0, m1)`` of this rank's batches, in order."""
@@ -229,21 +350,39 @@ class ShardLoader:
         work = self.plan()
         if self.device.type != "cuda":
             for si, m0, m1 in work:
-                yield collate(self.shards[si], m0, m1, self.device)
+                if self.shape is None:
+                    yield collate(self.shards[si], m0, m1, self.device)
+                else:
+                    sh = self.shards[si]
+                    _, total = padded_layout(self.shape, m1 - m0, sh.x_dim, sh.p_dim, sh.e_dim)
+                    flat = torch.empty(total, dtype=torch.uint8)
+                    collate_padded(sh, m0, m1, self.shape, flat.numpy())
+                    yield PackedBatch(flat, self.shape, m1 - m0)
             return
         from concurrent.futures import ThreadPoolExecutor
         copy_stream = torch.cuda.Stream(device=self.device)
         depth = self.prefetch + self.workers
         free: Queue = Queue()                            # pinned staging buffers with the event of their last copy
-        for _ in range(depth + 1):
-            free.put((None, None))
+        for k in range(depth + 1):                       # (kept across epochs: pinning memory costs milliseconds)
+            free.put((self._pinned[k] if k < len(self._pinned) else None, None))
+        self._pinned = []
 
         def stage(si, m0, m1):
             staging, last = free.get()
             if last is not None:
                 last.synchronize()                       # the buffer's previous copy has left the host
             with torch.cuda.device(self.device):
-                b = collate(self.shards[si], m0, m1, self.device, staging, copy_stream)
+                if self.shape is None:
+                    b = collate(self.shards[si], m0, m1, self.device, staging, copy_stream)
+                else:
+                    sh = self.shards[si]
+                    _, total = padded_layout(self.shape, m1 - m0, sh.x_dim, sh.p_dim, sh.e_dim)
+                    if staging is None or staging.numel() < total:
+                        staging = torch.empty(total, dtype=torch.uint8, pin_memory=True)
+                    collate_padded(sh, m0, m1, self.shape, staging.numpy())
+                    with torch.cuda.stream(copy_stream):
+                        b = PackedBatch(staging[:total].to(self.device, non_blocking=True), self.shape, m1 - m0)
+                    b._staging = staging
                 ev = torch.cuda.Event()
                 ev.record(copy_stream)
             return b, ev
@@ -266,6 +405,8 @@ class ShardLoader:
                     if torch.is_tensor(v) and v.is_cuda:
                         v.record_stream(cur)
                 free.put((b._staging, ev))
+                if all(b._staging is not t for t in self._pinned):
+                    self._pinned.append(b._staging)
                 yield b
 
 

@@ -91,3 +91,32 @@ def test_loader_batches_on_the_gpu_feed_the_model_like_direct_batches(tmp_path):
         assert torch.equal(got, want)
         n += b.num_graphs
     assert n == 700
+
+
+def test_fixed_shape_loader_pads_on_the_host_exactly_like_pad_batch(tmp_path):
+    """ShardLoader(fixed_shape=True): the batch padded while it is staged, directly in StaticBatch's flat layout, must be
+    byte for byte what padding.pack(padding.pad_batch(..)) makes of the collated batch; the shape is the common shape of
+    the rank's batches, from the shard's degree prefix sums."""
+    from molkgnn_amd import padding as P
+    whole = make_batch(200, seed=6, assay="all9", with_receptive_fields=False)
+    paths = S.write_shards(str(tmp_path), [whole])
+    sh = S.Shard(paths[0])
+    assert sh.degree_histogram(0, 200) == P.degree_histogram(whole)
+    assert sh.degree_histogram(17, 90) == P.degree_histogram(_slice(whole, 17, 90))
+    loader = S.ShardLoader(paths, 64, device="cpu", fixed_shape=True)
+    plan = loader.plan()
+    assert [m1 - m0 for _, m0, m1 in plan] == [64, 64, 64]                      # the short tail batch is dropped
+    want_shape = P.fixed_shape([P.degree_histogram(_slice(whole, m0, m1)) for _, m0, m1 in plan])
+    assert loader.shape == want_shape
+    got = list(loader)
+    assert len(got) == 3
+    for (si, m0, m1), pb in zip(plan, got):
+        ref = P.pack(P.pad_batch(_slice(whole, m0, m1), want_shape, 64))
+        assert pb.flat.numel() == ref.flat.numel()
+        g = pb.unpack((28, 3, 7))
+        for k in P.StaticBatch.FIELDS:
+            assert torch.equal(getattr(g, k), getattr(ref, k)), k
+        assert pb.bucket_sizes == list(ref.bucket_sizes) and pb.n_valid_molecules == 64 and pb.num_graphs == ref.num_graphs
+        sb = P.StaticBatch(ref)
+        sb.load(pb)                                        # a PackedBatch loads like a packed GraphBatch
+        assert torch.equal(sb.flat, pb.flat)
