@@ -294,10 +294,11 @@ def reset_head_rng(dev=None, seed=None) -> None:
 
 class _BceHeadFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, emb, weight, bias, target, p_drop):
+    def forward(ctx, emb, weight, bias, target, p_drop, n_rows):
         lib = _lib.load()
         emb = _row_major(emb if emb.dtype == torch.float32 else emb.float())
-        B, H = emb.shape
+        ctx.rows_total = emb.shape[0]
+        B, H = int(n_rows), emb.shape[1]         # the leading n_rows rows enter the loss (the rest: padding molecules)
         dev = emb.device
         w = weight.reshape(-1).contiguous()
         y = target.reshape(-1).float().contiguous()
@@ -322,10 +323,15 @@ class _BceHeadFn(torch.autograd.Function):
     def backward(ctx, grad_loss):
         lib = _lib.load()
         emb, w, y, pred, used = ctx.saved_tensors
-        B, H = emb.shape
+        B, H = y.numel(), emb.shape[1]
         dev = emb.device
         gl = grad_loss.reshape(1).float().contiguous()
-        gemb = torch.empty((B, H), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        gemb = None
+        if ctx.needs_input_grad[0]:
+            # rows beyond B (padding molecules) get a zero gradient: one small fill, only when there are any
+            gemb = torch.empty((ctx.rows_total, H), dtype=torch.float32, device=dev)
+            if ctx.rows_total > B:
+                gemb[B:].zero_()
         gw = torch.empty(H, dtype=torch.float32, device=dev)
         gb = torch.empty(1, dtype=torch.float32, device=dev) if ctx.has_bias else None
         with torch.cuda.device(dev):
@@ -334,17 +340,20 @@ class _BceHeadFn(torch.autograd.Function):
                 emb.data_ptr(), _stride0(emb), B, H, w.data_ptr(), y.data_ptr(), pred.data_ptr(), gl.data_ptr(),
                 ctx.p_drop, _lib.ptr(used), _lib.ptr(gemb), H, gw.data_ptr(), _lib.ptr(gb), ws.data_ptr(), ws.numel(),
                 _lib.stream_ptr(dev)), "mkgnn_bce_head_dropout_backward")
-        return gemb, gw.reshape(ctx.wshape), gb, None, None
+        return gemb, gw.reshape(ctx.wshape), gb, None, None, None
 
 
-def bce_head_loss(emb: torch.Tensor, ffn: torch.nn.Linear, target: torch.Tensor, dropout_p: float = 0.0) -> torch.Tensor:
+def bce_head_loss(emb: torch.Tensor, ffn: torch.nn.Linear, target: torch.Tensor, dropout_p: float = 0.0,
+                  n_rows: Optional[int] = None) -> torch.Tensor:
     """``BCEWithLogitsLoss()(ffn(dropout(emb)).view(-1), target.view(-1).float())`` for a one-output ``ffn`` (reference
     ``model.py:147-150, 169, 190-198``) as one forward and one backward kernel; ``dropout_p`` is the probability of
     zeroing an element of ``emb`` (``nn.Dropout(ffn_dropout_rate)`` in training mode; 0 otherwise), its mask drawn
-    inside the kernels from ``head_rng_state``."""
+    inside the kernels from ``head_rng_state``.  ``n_rows``: only the leading rows of ``emb`` enter the loss (a padded batch's
+    real molecules); the others get a zero gradient."""
     _lib.require_gpu_tensor(emb, "graph_embedding")
-    if ffn.out_features != 1 or emb.dim() != 2 or emb.shape[0] == 0 or target.numel() != emb.shape[0]:
-        raise ValueError("bce_head_loss needs a one-output linear layer and one target per row")
+    n_rows = emb.shape[0] if n_rows is None else int(n_rows)
+    if ffn.out_features != 1 or emb.dim() != 2 or n_rows <= 0 or n_rows > emb.shape[0] or target.numel() != n_rows:
+        raise ValueError("bce_head_loss needs a one-output linear layer and one target per (leading) row")
     if not 0.0 <= dropout_p < 1.0:
         raise ValueError(f"dropout probability {dropout_p} outside [0, 1)")
-    return _BceHeadFn.apply(emb, ffn.weight, ffn.bias, target, float(dropout_p))
+    return _BceHeadFn.apply(emb, ffn.weight, ffn.bias, target, float(dropout_p), n_rows)

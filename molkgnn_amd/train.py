@@ -53,13 +53,15 @@ class GNNModel(torch.nn.Module):
             p = self.dropout.p if (self.training and self.dropout.p < 1.0) else 0.0
             graph_embedding = self.gnn_model(data)
             nreal = getattr(data, 'n_valid_molecules', None)
-            if nreal is not None:                      # a padded batch: the padding molecule's row takes no part in the loss
-                graph_embedding = graph_embedding[:nreal]
             if self.training and self.dropout.p >= 1.0:
                 graph_embedding = self.dropout(graph_embedding)
-            return bce_head_loss(graph_embedding, self.ffn, data.y, dropout_p=p)
+            # (a padded batch: the padding molecules' rows take no part in the loss -- the head reads the first nreal rows)
+            return bce_head_loss(graph_embedding, self.ffn, data.y, dropout_p=p, n_rows=nreal)
         pred, _ = self(data)
         return self.loss_func(pred.view(-1), data.y.view(-1).float())
+
+
+_ONES: dict = {}
 
 
 def backward(loss: torch.Tensor) -> None:
@@ -68,8 +70,19 @@ def backward(loss: torch.Tensor) -> None:
     all the optimiser (or a gradient all-reduce) that follows needs.  Use it where parameters' ``.grad`` start out as
     None (``zero_grad(set_to_none=True)``); calls that would accumulate are simply not deferred."""
     from .functional import deferred_bank_gradients
+    # d loss / d loss = 1 from a tensor that already exists (autograd otherwise fills a fresh one: a launch per step)
+    key = (loss.device, loss.dtype)
+    one = _ONES.get(key)
+    if one is None:
+        if loss.is_cuda and torch.cuda.is_current_stream_capturing():
+            one = None                        # (first use inside a capture: let autograd make its own this once)
+        else:
+            one = _ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
     with deferred_bank_gradients():
-        loss.backward()
+        if one is not None and loss.dim() == 0:
+            loss.backward(one)
+        else:
+            loss.backward()
 
 
 def tune_torch_backends() -> None:
