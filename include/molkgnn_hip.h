@@ -316,6 +316,17 @@ int mkgnn_rf_fill(const int64_t* edge_index, const float* p, const float* edge_a
  * atomics, every segment sorted by one thread -- the result does not depend on the order the atomics ran in.
  * buckets: only count, selected_index and nei_index are read.  N < 2^28, M < 2^31. */
 size_t mkgnn_plan_workspace_bytes(int64_t n_atoms, int64_t n_edges, int64_t n_rows);
+
+/* A collated batch from its compact wire form (what a loader sends over PCIe, molkgnn_amd/shards.py) to the tensors the
+ * reference's batch object holds (PyG collation, wrapper.py:152-156):
+ *   bond_ij   [n_bonds, 2] int32 batch-local atom ids      -> edge_index [2, 2 n_bonds] int64: bond k as the consecutive
+ *                                                             directed edges (i, j), (j, i);
+ *   bond_attr [n_bonds, E] uint8 (0..255-valued features)  -> edge_attr [2 n_bonds, E] fp32, the same row for both directions;
+ *   mol_ptr   [n_molecules + 1] int32 first atom of every molecule -> batch [n_atoms] int64 and atom_molecule [n_atoms] int32.
+ * Any output may be NULL (skipped).  One launch. */
+int mkgnn_expand_batch(const int32_t* bond_ij, const uint8_t* bond_attr, int64_t n_bonds, int32_t E,
+                       const int32_t* mol_ptr, int64_t n_molecules, int64_t n_atoms,
+                       int64_t* edge_index, float* edge_attr, int64_t* batch, int32_t* atom_molecule, void* stream);
 int mkgnn_plan_build(const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE], int64_t n_atoms, const int64_t* edge_index,
                      int64_t n_edges, int32_t* scatter_rowptr, int32_t* scatter_rows, int32_t* in_rowptr, int32_t* in_col,
                      int32_t* in_col_packed, int32_t* out_rowptr, int32_t* out_col, int8_t* deg8, void* workspace,

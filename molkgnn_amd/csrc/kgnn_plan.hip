@@ -149,7 +149,55 @@ __global__ void __launch_bounds__(256) plan_sort_kernel(PlanArgs a) {
     }
 }
 
+// compact wire form -> collated batch tensors (mkgnn_expand_batch): thread t < n_bonds expands bond t, thread t < n_atoms
+// finds atom t's molecule by bisection of mol_ptr
+__global__ void __launch_bounds__(256) expand_batch_kernel(const int32_t* __restrict__ bond_ij, const uint8_t* __restrict__ bond_attr,
+                                                           int64_t n_bonds, int E, const int32_t* __restrict__ mol_ptr,
+                                                           int64_t n_mol, int64_t n_atoms, int64_t* __restrict__ edge_index,
+                                                           float* __restrict__ edge_attr, int64_t* __restrict__ batch,
+                                                           int32_t* __restrict__ atom_mol) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n_bonds) {
+        const int64_t i = bond_ij[2 * t], j = bond_ij[2 * t + 1], m = 2 * n_bonds;
+        if (edge_index) {
+            edge_index[2 * t] = i; edge_index[2 * t + 1] = j;
+            edge_index[m + 2 * t] = j; edge_index[m + 2 * t + 1] = i;
+        }
+        if (edge_attr && bond_attr)
+            for (int k = 0; k < E; ++k) {
+                const float v = (float)bond_attr[t * E + k];
+                edge_attr[(2 * t) * E + k] = v;
+                edge_attr[(2 * t + 1) * E + k] = v;
+            }
+    }
+    if (t < n_atoms && mol_ptr && (batch || atom_mol)) {
+        int64_t lo = 0, hi = n_mol;                  // the molecule g with mol_ptr[g] <= t < mol_ptr[g + 1]
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if ((int64_t)mol_ptr[mid] <= t) lo = mid; else hi = mid;
+        }
+        if (batch) batch[t] = lo;
+        if (atom_mol) atom_mol[t] = (int32_t)lo;
+    }
+}
+
 }  // namespace mkgnn
+
+extern "C" int mkgnn_expand_batch(const int32_t* bond_ij, const uint8_t* bond_attr, int64_t n_bonds, int32_t E,
+                                  const int32_t* mol_ptr, int64_t n_molecules, int64_t n_atoms, int64_t* edge_index,
+                                  float* edge_attr, int64_t* batch, int32_t* atom_molecule, void* stream) {
+    using namespace mkgnn;
+    if (n_bonds < 0 || n_atoms < 0 || n_molecules < 0 || E < 0) return api_fail("mkgnn_expand_batch: negative size");
+    if (n_bonds && !bond_ij) return api_fail("mkgnn_expand_batch: bond_ij is null");
+    if ((batch || atom_molecule) && n_atoms && (!mol_ptr || n_molecules < 1)) return api_fail("mkgnn_expand_batch: mol_ptr is needed for batch / atom_molecule");
+    const int64_t n = n_bonds > n_atoms ? n_bonds : n_atoms;
+    if (n == 0) return 0;
+    expand_batch_kernel<<<(unsigned)((n + 255) / 256), 256, 0, (hipStream_t)stream>>>(bond_ij, bond_attr, n_bonds, E, mol_ptr, n_molecules,
+                                                                                     n_atoms, edge_index, edge_attr, batch, atom_molecule);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : api_fail("mkgnn_expand_batch: launch failed");
+}
+
 
 using namespace mkgnn;
 

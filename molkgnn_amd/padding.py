@@ -142,3 +142,45 @@ class StaticBatch:
             return
         for k in self.FIELDS:
             getattr(self.data, k).copy_(getattr(padded, k), non_blocking=True)
+
+
+class CompactStaticBatch:
+    """Static device buffers fed in the compact wire form (``shards.compact_layout``; ``ShardLoader(compact=True)``):
+    ``load`` copies a ``CompactBatch`` into the wire buffer, ``expand`` -- called INSIDE the captured step, before the
+    receptive-field builder -- rebuilds ``edge_index``, ``edge_attr``, ``batch`` and ``atom_mol`` with one launch
+    (``mkgnn_expand_batch``).  ``data`` is the object the model consumes: ``x``, ``p``, ``y``, ``mol_ptr`` and
+    ``n_valid_atoms`` are views of the wire buffer, nothing is copied twice."""
+
+    def __init__(self, shape: Dict[str, int], num_molecules: int, x_dim: int, p_dim: int, e_dim: int, device):
+        import numpy as np
+        from .shards import compact_layout
+        self.shape, self.num_molecules, self.e_dim = dict(shape), int(num_molecules), int(e_dim)
+        self.table, total = compact_layout(shape, num_molecules, x_dim, p_dim, e_dim)
+        dev = torch.device(device)
+        self.wire = torch.zeros(total, dtype=torch.uint8, device=dev)
+        tdt = {np.float32: torch.float32, np.int64: torch.int64, np.int32: torch.int32, np.uint8: torch.uint8}
+        v = {k: self.wire[off:off + nbytes].view(tdt[dt]).view(shp) for k, off, shp, dt, nbytes in self.table}
+        self._v = v
+        A, E2 = shape["atoms"], shape["edges"]
+        self.data = GraphBatch(
+            x=v["x"], p=v["p"], y=v["y"], mol_ptr=v["mol_ptr"], n_valid_atoms=v["n_valid_atoms"],
+            edge_index=torch.zeros((2, E2), dtype=torch.int64, device=dev),
+            edge_attr=torch.zeros((E2, e_dim), dtype=torch.float32, device=dev),
+            batch=torch.zeros(A, dtype=torch.int64, device=dev), atom_mol=torch.zeros(A, dtype=torch.int32, device=dev))
+        self.data.n_valid_molecules, self.data.num_graphs = self.num_molecules, self.num_molecules + PAD_MOLECULES
+        self.data.bucket_sizes = [shape["n1"], shape["n2"], shape["n3"], shape["n4"]]
+
+    def load(self, batch) -> None:
+        if list(batch.bucket_sizes) != self.data.bucket_sizes or batch.n_valid_molecules != self.num_molecules \
+                or batch.flat.numel() != self.wire.numel():
+            raise ValueError("batch shape differs from the static buffers'")
+        self.wire.copy_(batch.flat, non_blocking=True)
+
+    def expand(self) -> None:
+        from . import _lib
+        d, v = self.data, self._v
+        with torch.cuda.device(self.wire.device):
+            _lib.check(_lib.load().mkgnn_expand_batch(
+                v["bond_ij"].data_ptr(), v["bond_attr"].data_ptr(), v["bond_ij"].shape[0], self.e_dim, v["mol_ptr"].data_ptr(),
+                d.num_graphs, d.x.shape[0], d.edge_index.data_ptr(), d.edge_attr.data_ptr(), d.batch.data_ptr(),
+                d.atom_mol.data_ptr(), _lib.stream_ptr(self.wire.device)), "mkgnn_expand_batch")

@@ -18,7 +18,8 @@ molecules of a (pre-shuffled) part of the data set **already concatenated**, in 
 Layout (version 2)::
 
     header   256 bytes: b"MKGS", u32 version, u64 n_molecules, u64 n_atoms, u64 n_bonds (directed edges),
-                        u32 x_dim, u32 e_dim, u32 p_dim, u32 reserved, then 10 x u64 array offsets in the order below
+                        u32 x_dim, u32 e_dim, u32 p_dim, u32 flags (bit 0: the compact wire form applies), then 10 x u64
+                        array offsets in the order below
     mol_atom_ptr  i64 [M + 1]     first atom of every molecule
     mol_edge_ptr  i64 [M + 1]     first directed edge of every molecule
     y             f32 [M]         label (data.py:37 trains on one task)
@@ -99,7 +100,14 @@ def write_shard(path: str, batch: GraphBatch) -> None:
     for name in _ARRAYS:
         offsets.append(off)
         off = _align(off + arrays[name].nbytes)
-    head = _HEAD.pack(MAGIC, VERSION, m, a, e, x.shape[1], ea.shape[1] if ea.ndim == 2 else 0, p.shape[1], 0, *offsets)
+    # can the batches of this shard travel in the compact wire form (collate_compact)?  Bonds stored as consecutive
+    # (i, j), (j, i) pairs with one attribute row for both directions, attributes byte-valued
+    compact = e % 2 == 0 and (e == 0 or (
+        np.array_equal(ei[0, 0::2], ei[1, 1::2]) and np.array_equal(ei[1, 0::2], ei[0, 1::2]) and
+        np.array_equal(ea[0::2], ea[1::2]) and float(ea.min()) >= 0.0 and float(ea.max()) <= 255.0 and
+        np.array_equal(ea, np.rint(ea))))
+    head = _HEAD.pack(MAGIC, VERSION, m, a, e, x.shape[1], ea.shape[1] if ea.ndim == 2 else 0, p.shape[1], 1 if compact else 0,
+                      *offsets)
     tmp = path + ".tmp"
     with open(tmp, "wb") as f:
         f.write(head.ljust(HEADER_BYTES, b"\0"))
@@ -119,13 +127,14 @@ class Shard:
             head = f.read(HEADER_BYTES)
         if len(head) < _HEAD.size:
             raise ValueError(f"{path}: not a molecule shard (short header)")
-        magic, version, m, a, e, xd, ed, pd, _, *offs = _HEAD.unpack(head[:_HEAD.size])
+        magic, version, m, a, e, xd, ed, pd, flags, *offs = _HEAD.unpack(head[:_HEAD.size])
         if magic != MAGIC:
             raise ValueError(f"{path}: not a molecule shard (magic {magic!r})")
         if version != VERSION:
             raise ValueError(f"{path}: shard version {version}, this reader knows {VERSION}")
         self.n_molecules, self.n_atoms, self.n_edges = int(m), int(a), int(e)
         self.x_dim, self.e_dim, self.p_dim = int(xd), int(ed), int(pd)
+        self.compact_ok = bool(flags & 1)    # bonds as reversed pairs with shared, byte-valued attributes: collate_compact applies
         shapes = {"mol_atom_ptr": (np.int64, (m + 1,)), "mol_edge_ptr": (np.int64, (m + 1,)), "y": (np.float32, (m,)),
                   "assay_id": (np.int32, (m,)), "x": (np.float32, (a, xd)), "p": (np.float32, (a, pd)),
                   "edge_src": (np.int32, (e,)), "edge_dst": (np.int32, (e,)), "edge_attr": (np.float32, (e, ed)),
@@ -268,6 +277,76 @@ def collate_padded(shard: Shard, m0: int, m1: int, shape, host: np.ndarray) -> N
     f["n_valid_atoms"][0] = na
 
 
+def compact_layout(shape, num_molecules: int, x_dim: int, p_dim: int, e_dim: int):
+    """Field table of the compact wire form of a fixed-shape batch (``padding.CompactStaticBatch``): what has to cross
+    PCIe and nothing derived -- features and coordinates as they are, every bond once as an int32 pair with byte-valued
+    attributes, labels, molecule pointers; ``mkgnn_expand_batch`` rebuilds ``edge_index`` (int64, both directions),
+    ``edge_attr`` (fp32, both directions), ``batch`` and ``atom_mol`` on the device.  14.5 MB instead of 23.8 MB for 4096
+    molecules."""
+    from .padding import PAD_MOLECULES
+    A, B2, G = shape["atoms"], shape["edges"] // 2, num_molecules + PAD_MOLECULES
+    spec = (("x", (A, x_dim), np.float32), ("p", (A, p_dim), np.float32), ("bond_ij", (B2, 2), np.int32),
+            ("bond_attr", (B2, e_dim), np.uint8), ("y", (num_molecules,), np.float32), ("mol_ptr", (G + 1,), np.int32),
+            ("n_valid_atoms", (1,), np.int64))
+    table, off = [], 0
+    for k, shp, dt in spec:
+        nbytes = int(np.prod(shp)) * np.dtype(dt).itemsize
+        table.append((k, off, shp, dt, nbytes))
+        off += (nbytes + 255) // 256 * 256
+    return table, off
+
+
+def collate_compact(shard: Shard, m0: int, m1: int, shape, host: np.ndarray) -> None:
+    """Molecules ``[m0, m1)`` padded to ``shape`` in the compact wire form (``compact_layout``); expands (``mkgnn_expand_batch``)
+    to exactly what ``collate_padded`` writes.  Needs ``shard.compact_ok``."""
+    from .padding import PAD_MOLECULES
+    if not shard.compact_ok:
+        raise ValueError(f"{shard.path}: bonds are not reversed pairs with shared byte-valued attributes: no compact form")
+    nm = m1 - m0
+    a0, a1, e0, e1 = shard.ranges(m0, m1)
+    na, ne = a1 - a0, e1 - e0
+    h = shard.degree_histogram(m0, m1)
+    need = [shape[f"n{d}"] - h[d] for d in range(1, 5)]
+    if min(need) < 0 or h[5]:
+        raise ValueError(f"molecules [{m0}, {m1}) with degree histogram {h[1:5]} (+{h[5]} in no bucket) do not fit the shape {shape}")
+    n_pad = sum(need)
+    table, total = compact_layout(shape, nm, shard.x_dim, shard.p_dim, shard.e_dim)
+    if host.shape[0] < total:
+        raise ValueError("staging buffer too small")
+    f = {k: host[off:off + nbytes].view(dt).reshape(shp) for k, off, shp, dt, nbytes in table}
+    nb = ne // 2
+    f["x"][:na] = shard.x[a0:a1]; f["x"][na:] = 0.0
+    f["p"][:na] = shard.p[a0:a1]; f["p"][na:] = 0.0
+    f["bond_attr"][:nb] = shard.edge_attr[e0:e1:2]           # (float -> uint8: exact, the shard checked the values)
+    f["bond_attr"][nb:] = 0
+    f["bond_attr"][nb:, 0] = 1
+    ij = f["bond_ij"]
+    np.subtract(shard.edge_src[e0:e1:2], a0, out=ij[:nb, 0], casting="unsafe")
+    np.subtract(shard.edge_dst[e0:e1:2], a0, out=ij[:nb, 1], casting="unsafe")
+    deg_of = np.repeat(np.arange(1, 5), need)
+    stubs = np.repeat(np.arange(n_pad, dtype=np.int64), deg_of) + na
+    if stubs.shape[0] % 2 or stubs.shape[0] != shape["edges"] - ne:
+        raise ValueError("padding bond stubs do not pair up: the shape does not come from fixed_shape() over these batches")
+    ij[nb:, 0] = stubs[0::2]
+    ij[nb:, 1] = stubs[1::2]
+    atom_ptr = shard.mol_atom_ptr[m0:m1 + 1] - a0
+    f["y"][:] = shard.y[m0:m1]
+    mp = f["mol_ptr"]
+    mp[0] = 0
+    mp[1:nm + 1] = atom_ptr[1:]
+    pad_mol = (np.arange(n_pad, dtype=np.int64) * PAD_MOLECULES) // max(n_pad, 1)
+    mp[nm + 1:] = na + np.cumsum(np.bincount(pad_mol, minlength=PAD_MOLECULES))
+    f["n_valid_atoms"][0] = na
+
+
+class CompactBatch:
+    """A fixed-shape batch in the compact wire form on the device (``padding.CompactStaticBatch.load`` takes it)."""
+
+    def __init__(self, flat, shape, num_molecules: int):
+        self.flat, self.shape, self.n_valid_molecules = flat, dict(shape), num_molecules
+        self.bucket_sizes = [shape["n1"], shape["n2"], shape["n3"], shape["n4"]]
+
+
 class PackedBatch:
     """A fixed-shape batch as one flat device buffer in ``padding.StaticBatch``'s layout (``StaticBatch.load`` takes it)."""
 
@@ -311,7 +390,8 @@ class ShardLoader:
     """
 
     def __init__(self, paths: Sequence[str], batch_size: int, device="cpu", rank: int = 0, world: int = 1,
-                 prefetch: int = 2, drop_last: bool = False, workers: int = 2, fixed_shape: bool = False):
+                 prefetch: int = 2, drop_last: bool = False, workers: int = 2, fixed_shape: bool = False,
+                 compact: bool = False):
         if not (0 <= rank < world):
             raise ValueError(f"rank {rank} of world {world}")
         self.paths, self.batch_size, self.device = list(paths), int(batch_size), torch.device(device)
@@ -321,7 +401,14 @@ class ShardLoader:
         # fixed_shape: every batch padded on the host to the common shape of this rank's batches (padding.fixed_shape) and
         # handed over as a PackedBatch; short tail batches are dropped (the static buffers hold exactly batch_size molecules)
         self._pinned: list = []
+        self._landing: list = []
         self.shape = None
+        # compact (with fixed_shape): batches travel in the compact wire form (collate_compact) and come out as CompactBatch
+        self.compact = bool(compact)
+        if self.compact and not fixed_shape:
+            raise ValueError("the compact wire form is a fixed-shape form: fixed_shape=True is required")
+        if self.compact and not all(sh.compact_ok for sh in self.shards):
+            raise ValueError("a shard's bonds do not allow the compact wire form")
         if fixed_shape:
             from .padding import fixed_shape as _fixed_shape
             self.drop_last = True
@@ -354,10 +441,12 @@ class ShardLoader:
                     yield collate(self.shards[si], m0, m1, self.device)
                 else:
                     sh = self.shards[si]
-                    _, total = padded_layout(self.shape, m1 - m0, sh.x_dim, sh.p_dim, sh.e_dim)
+                    layout, fill, make = (compact_layout, collate_compact, CompactBatch) if self.compact else \
+                        (padded_layout, collate_padded, PackedBatch)
+                    _, total = layout(self.shape, m1 - m0, sh.x_dim, sh.p_dim, sh.e_dim)
                     flat = torch.empty(total, dtype=torch.uint8)
-                    collate_padded(sh, m0, m1, self.shape, flat.numpy())
-                    yield PackedBatch(flat, self.shape, m1 - m0)
+                    fill(sh, m0, m1, self.shape, flat.numpy())
+                    yield make(flat, self.shape, m1 - m0)
             return
         from concurrent.futures import ThreadPoolExecutor
         copy_stream = torch.cuda.Stream(device=self.device)
@@ -366,8 +455,17 @@ class ShardLoader:
         for k in range(depth + 1):                       # (kept across epochs: pinning memory costs milliseconds)
             free.put((self._pinned[k] if k < len(self._pinned) else None, None))
         self._pinned = []
+        # fixed-shape batches land in a ring of device buffers that is allocated once: a fresh device tensor per batch
+        # would have the allocator wait for (or grow past) blocks the consumer's stream has not released yet.  A landing
+        # buffer is reused only after the consumer's stream has passed the use of the batch it held (event recorded when
+        # the consumer asks for the next batch), so a batch's ``flat`` is valid until the loader has handed out
+        # ``prefetch + workers + 1`` more batches.
+        K = depth + 2
+        if len(self._landing) != K:
+            self._landing = [None] * K
+        consumed = [None] * K
 
-        def stage(si, m0, m1):
+        def stage(i, si, m0, m1):
             staging, last = free.get()
             if last is not None:
                 last.synchronize()                       # the buffer's previous copy has left the host
@@ -376,38 +474,53 @@ class ShardLoader:
                     b = collate(self.shards[si], m0, m1, self.device, staging, copy_stream)
                 else:
                     sh = self.shards[si]
-                    _, total = padded_layout(self.shape, m1 - m0, sh.x_dim, sh.p_dim, sh.e_dim)
+                    layout, fill, make = (compact_layout, collate_compact, CompactBatch) if self.compact else \
+                        (padded_layout, collate_padded, PackedBatch)
+                    _, total = layout(self.shape, m1 - m0, sh.x_dim, sh.p_dim, sh.e_dim)
                     if staging is None or staging.numel() < total:
                         staging = torch.empty(total, dtype=torch.uint8, pin_memory=True)
-                    collate_padded(sh, m0, m1, self.shape, staging.numpy())
+                    fill(sh, m0, m1, self.shape, staging.numpy())
+                    k = i % K
+                    if self._landing[k] is None or self._landing[k].numel() < total:
+                        self._landing[k] = torch.empty(total, dtype=torch.uint8, device=self.device)
                     with torch.cuda.stream(copy_stream):
-                        b = PackedBatch(staging[:total].to(self.device, non_blocking=True), self.shape, m1 - m0)
-                    b._staging = staging
+                        if consumed[k] is not None:
+                            copy_stream.wait_event(consumed[k])
+                        dst = self._landing[k][:total]
+                        dst.copy_(staging[:total], non_blocking=True)
+                        b = make(dst, self.shape, m1 - m0)
+                    b._staging, b._slot = staging, k
                 ev = torch.cuda.Event()
                 ev.record(copy_stream)
             return b, ev
 
         with ThreadPoolExecutor(self.workers) as pool:   # (numpy's slice copies release the GIL: the workers overlap)
             pending = []
-            it = iter(work)
-            for w in it:
-                pending.append(pool.submit(stage, *w))
+            it = iter(enumerate(work))
+            for i, w in it:
+                pending.append(pool.submit(stage, i, *w))
                 if len(pending) >= depth:
                     break
             while pending:
                 b, ev = pending.pop(0).result()
                 nxt = next(it, None)
                 if nxt is not None:
-                    pending.append(pool.submit(stage, *nxt))
+                    pending.append(pool.submit(stage, nxt[0], *nxt[1]))
                 cur = torch.cuda.current_stream(self.device)
                 cur.wait_event(ev)
-                for v in b.__dict__.values():
-                    if torch.is_tensor(v) and v.is_cuda:
-                        v.record_stream(cur)
+                slot = getattr(b, "_slot", None)
+                if slot is None:                         # (per-batch device tensors: keep the allocator informed)
+                    for v in b.__dict__.values():
+                        if torch.is_tensor(v) and v.is_cuda:
+                            v.record_stream(cur)
                 free.put((b._staging, ev))
                 if all(b._staging is not t for t in self._pinned):
                     self._pinned.append(b._staging)
                 yield b
+                if slot is not None:                     # the consumer has enqueued its use of the landing buffer
+                    done = torch.cuda.Event()
+                    done.record(torch.cuda.current_stream(self.device))
+                    consumed[slot] = done
 
 
 def write_shards(directory: str, batches: Iterable[GraphBatch], prefix: str = "shard") -> List[str]:

@@ -120,3 +120,62 @@ def test_fixed_shape_loader_pads_on_the_host_exactly_like_pad_batch(tmp_path):
         sb = P.StaticBatch(ref)
         sb.load(pb)                                        # a PackedBatch loads like a packed GraphBatch
         assert torch.equal(sb.flat, pb.flat)
+
+
+def _expand_on_host(cb, dims):
+    """What mkgnn_expand_batch makes of a CompactBatch, in numpy (the definition the kernel must match)."""
+    table, _ = S.compact_layout(cb.shape, cb.n_valid_molecules, *dims)
+    host = cb.flat.cpu().numpy()
+    f = {k: host[off:off + nbytes].view(dt).reshape(shp) for k, off, shp, dt, nbytes in table}
+    ij = f["bond_ij"].astype(np.int64)
+    ei = np.empty((2, 2 * ij.shape[0]), dtype=np.int64)
+    ei[0, 0::2], ei[1, 0::2], ei[0, 1::2], ei[1, 1::2] = ij[:, 0], ij[:, 1], ij[:, 1], ij[:, 0]
+    ea = np.repeat(f["bond_attr"].astype(np.float32), 2, axis=0)
+    mp = f["mol_ptr"].astype(np.int64)
+    bt = np.repeat(np.arange(mp.shape[0] - 1, dtype=np.int64), np.diff(mp))
+    return {"x": f["x"], "p": f["p"], "edge_index": ei, "edge_attr": ea, "batch": bt, "y": f["y"], "mol_ptr": f["mol_ptr"],
+            "atom_mol": bt.astype(np.int32), "n_valid_atoms": f["n_valid_atoms"]}
+
+
+def test_compact_wire_form_expands_to_the_padded_batch(tmp_path):
+    """ShardLoader(fixed_shape=True, compact=True): every bond once as an int32 pair with byte-valued attributes, nothing
+    derived -- expanded, exactly the fields of the full fixed-shape form; 40 % fewer bytes; refused for shards whose
+    bonds are not reversed pairs with shared byte-valued attributes."""
+    whole = make_batch(200, seed=6, assay="all9", with_receptive_fields=False)
+    paths = S.write_shards(str(tmp_path), [whole])
+    assert S.Shard(paths[0]).compact_ok
+    full = list(S.ShardLoader(paths, 64, device="cpu", fixed_shape=True))
+    comp = list(S.ShardLoader(paths, 64, device="cpu", fixed_shape=True, compact=True))
+    assert len(full) == len(comp) == 3
+    for pb, cb in zip(full, comp):
+        assert cb.flat.numel() < 0.65 * pb.flat.numel()
+        want = pb.unpack((28, 3, 7))
+        got = _expand_on_host(cb, (28, 3, 7))
+        for k in ("x", "p", "edge_index", "edge_attr", "batch", "y", "mol_ptr", "atom_mol", "n_valid_atoms"):
+            assert np.array_equal(got[k], getattr(want, k).numpy()), k
+    odd = make_batch(50, seed=3, with_receptive_fields=False)
+    odd.edge_attr = odd.edge_attr + 0.5                     # not byte-valued
+    S.write_shard(str(tmp_path / "odd.mkgs"), odd)
+    assert not S.Shard(str(tmp_path / "odd.mkgs")).compact_ok
+    with pytest.raises(ValueError, match="compact"):
+        S.ShardLoader([str(tmp_path / "odd.mkgs")], 16, fixed_shape=True, compact=True)
+
+
+@pytest.mark.gpu
+def test_compact_batches_expand_on_the_gpu_into_the_static_buffers(tmp_path):
+    """padding.CompactStaticBatch: load + mkgnn_expand_batch give the tensors of the full fixed-shape batch, bit for bit."""
+    from molkgnn_amd import padding as P
+    dev = torch.device("cuda:0")
+    whole = make_batch(300, seed=12, assay="all9", with_receptive_fields=False)
+    paths = S.write_shards(str(tmp_path), [whole])
+    full = list(S.ShardLoader(paths, 128, device=dev, fixed_shape=True))
+    loader = S.ShardLoader(paths, 128, device=dev, fixed_shape=True, compact=True)
+    csb = P.CompactStaticBatch(loader.shape, 128, 28, 3, 7, dev)
+    for pb, cb in zip(full, loader):
+        csb.load(cb)
+        csb.expand()
+        torch.cuda.synchronize()
+        want = pb.unpack((28, 3, 7))
+        for k in P.StaticBatch.FIELDS:
+            assert torch.equal(getattr(csb.data, k), getattr(want, k)), k
+        assert csb.data.bucket_sizes == want.bucket_sizes and csb.data.num_graphs == want.num_graphs
