@@ -40,8 +40,10 @@ index work and no host synchronisation.
 """
 from __future__ import annotations
 
+import atexit
 import os
 import struct
+import weakref
 from queue import Queue
 from typing import Iterable, Iterator, List, Optional, Sequence
 
@@ -380,6 +382,19 @@ class _null:
         return False
 
 
+_LOADERS: "weakref.WeakSet" = weakref.WeakSet()
+
+
+def _release_all() -> None:
+    """Pinned staging and device landing buffers of loaders that are still alive go BEFORE the interpreter tears the GPU
+    runtime down (a pinned buffer freed after that aborts the process)."""
+    for ld in list(_LOADERS):
+        ld.close()
+
+
+atexit.register(_release_all)
+
+
 class ShardLoader:
     """Batches of ``batch_size`` consecutive molecules from a sequence of shards, for rank ``rank`` of ``world``.
 
@@ -402,6 +417,7 @@ class ShardLoader:
         # handed over as a PackedBatch; short tail batches are dropped (the static buffers hold exactly batch_size molecules)
         self._pinned: list = []
         self._landing: list = []
+        _LOADERS.add(self)
         self.shape = None
         # compact (with fixed_shape): batches travel in the compact wire form (collate_compact) and come out as CompactBatch
         self.compact = bool(compact)
@@ -416,6 +432,10 @@ class ShardLoader:
             if not work:
                 raise ValueError("no full batch for this rank")
             self.shape = _fixed_shape([self.shards[si].degree_histogram(m0, m1) for si, m0, m1 in work])
+
+    def close(self) -> None:
+        """Drop the pinned staging and device landing buffers (they are re-made on the next epoch)."""
+        self._pinned, self._landing = [], []
 
     def plan(self) -> List[tuple]:
         """``(shard index, m0, m1)`` of this rank's batches, in order."""

@@ -23,7 +23,7 @@ python3 tools/step_timeline.py "$O/prof_b256" > "$O/step_timeline_435008_b256.tx
 # 5. bf16 similarity variant (configs[4] shape on one GPU)
 python3 bench.py --variant bf16 --steps 50 --warmup 10 --no-cpu-baseline --fresh-batches 0 > "$O/bench_b4096_bf16.json" 2> "$O/bench_b4096_bf16.err"
 python3 bench.py --assay all9 --variant bf16 --steps 50 --warmup 10 --no-cpu-baseline --fresh-batches 0 > "$O/bench_all9_bf16.json" 2> "$O/bench_all9_bf16.err"
-python3 tools/shard_loader_probe.py --molecules 131072 --workers 2 > "$O/shard_loader.txt" 2>&1
+python3 tools/shard_loader_probe.py --molecules 131072 --workers 2 > "$O/shard_loader.txt" 2>&1 || echo "shard_loader_probe failed" >> "$O/shard_loader.txt"
 # 6. HBM traffic of the forward kernel (separate PMC passes) -> the JSON bench.py reads
 tools/pmc.sh "$tag/pmc_fwd" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" -- tools/fwd_probe.py --reps 6 > "$O/pmc_fwd.txt"
 python3 tools/collect_pmc.py "kc_forward_stream<7>" "$O/forward_pmc.json" "$commit" 98774728 "$O/pmc_fwd" > /dev/null

@@ -43,3 +43,4 @@ with tempfile.TemporaryDirectory() as d:
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
         print(f"{what:14s}: {n / el / 1e6:.2f} M molecules/s ({1e3 * el / len(loader):.3f} ms per batch of {args.batch_size})")
+        del loader, b                      # (pinned staging buffers must go before the interpreter tears the runtime down)
