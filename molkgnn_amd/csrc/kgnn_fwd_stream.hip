@@ -544,14 +544,21 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
     }
 }
 
+#ifndef MKGNN_EXP_OCC
+#define MKGNN_EXP_OCC 2
+#endif
 template <int KC>
-__global__ void __launch_bounds__(256, 2) kc_forward_stream(FusedFwdArgs a) {
+__global__ void __launch_bounds__(256, MKGNN_EXP_OCC) kc_forward_stream(FusedFwdArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int grp = a.blk_group[blockIdx.x];
     const int rank = a.blk_rank[blockIdx.x];
     const int di = a.grp_degree[grp];
     const int cp = a.grp_cp[grp];
     const int count = a.grp_count[grp];
+#ifdef MKGNN_EXP_ONLY_D                     // (occupancy experiments: one degree's body only)
+    if (di == MKGNN_EXP_ONLY_D - 1) stream_body<MKGNN_EXP_ONLY_D, KC>(a, a.deg[MKGNN_EXP_ONLY_D - 1], cp, rank, count, lds);
+    return;
+#endif
     switch (di) {
         case 0: stream_body<1, KC>(a, a.deg[0], cp, rank, count, lds); break;
         case 1: stream_body<2, KC>(a, a.deg[1], cp, rank, count, lds); break;

@@ -34,7 +34,11 @@ struct FwdArgs {
 };
 
 // One launch for all degree buckets (kgnn_mfma.hip).
+#ifdef MKGNN_EXP_MAX_BLOCKS                 // (occupancy experiments: make EXTRA=-DMKGNN_EXP_MAX_BLOCKS=768 ...)
+constexpr int FUSED_MAX_BLOCKS = MKGNN_EXP_MAX_BLOCKS;
+#else
 constexpr int FUSED_MAX_BLOCKS = 512;       // 2 blocks per CU
+#endif
 constexpr int FUSED_MAX_GROUPS = 16;        // (degree, column part)
 
 struct FusedDeg {
