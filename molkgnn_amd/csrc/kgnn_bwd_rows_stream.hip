@@ -14,8 +14,10 @@
 // sum over ITS kernels: the NS waves that hold a degree's NS column tiles exchange the partial tiles through LDS
 // (row-major images, laid out like the contribution rows), each adds up a share of the ATOMS in a fixed order and
 // stores whole 16-byte chunks of those rows -- bit-reproducible, no float atomics, 4 store instructions per slot
-// instead of 14 scattered 4-byte ones.  The coefficient inputs of a tile (dL/dsc through the focal ids,
-// permutation ids, chirality signs) are ordinary loads issued one tile ahead, the focal ids two.
+// instead of 14 scattered 4-byte ones.  The coefficient inputs of a tile come from the backward's pre-pass
+// (coef_prepare_kernel, kgnn_bwd_stream.hip: dL/dsc times the chirality sign and the permutation ids in tile order, one
+// contiguous 2 KB record per (tile, column tile), loaded one tile ahead); without a pre-pass (bank kernel not streamed)
+// the kernel gathers them itself through the focal ids, one tile ahead, the focal ids two.
 //
 // Covered shapes: the streamed forward's (F in (16 (KC - 1), 16 KC], exactly NS(d) = 1 / 2 / 2 / 4 column tiles).
 #include <stdio.h>

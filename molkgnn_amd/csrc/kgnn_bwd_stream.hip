@@ -19,7 +19,11 @@
 // The per-(atom, kernel) inputs -- dL/dsc through the focal ids, the chosen permutation, the chirality sign -- are put
 // into tile order by a small pre-pass (coef_prepare_kernel: one 1 KB + 1 KB record per (atom tile, column tile), so the
 // main kernel fetches them with two DMA pieces per tile); the pre-pass also sums the three score-weight partials
-// d sc / d theta_k = w_k (score_k - sc) / W, which need every pair's three scores exactly once.
+// d sc / d theta_k = w_k (score_k - sc) / W, which need every pair's three scores exactly once.  It runs first, on the
+// caller's stream (plan_backward_bank_stream / launch_coef_prepare / launch_backward_bank_stream): the rows kernel
+// (kgnn_bwd_rows_stream.hip) reads the same records.  With BankStreamArgs.through_nei the caller's grad_out is the
+// gradient of h = propagate(out) and the pre-pass sums the rows of an atom's neighbours (the bucket's nei_index: the
+// targets of its edges, KernelLayer.py:119-123) where it otherwise reads the focal atom's row.
 //
 // Degree 4 splits a column tile's supports over two waves like the forward (its accumulators would not fit otherwise);
 // covered shapes are the forward's (stream_forward_supported).
