@@ -296,7 +296,10 @@ hipError_t launch_backward_rows_stream(const BwdArgs a4[4], const bool use[4], f
     };
     int count[4], nb = 0;
     for (int g = 0; g < ng; ++g) { count[g] = 1; ++nb; }
-    while (nb < FUSED_MAX_BLOCKS) {
+    // grid cap: see launch_backward_bank_stream (the two kernels' caps were measured together)
+    static const char* env_blocks = getenv("MKGNN_ROWS_STREAM_BLOCKS");
+    const int max_blocks = env_blocks && atoi(env_blocks) > 8 && atoi(env_blocks) <= FUSED_MAX_BLOCKS ? atoi(env_blocks) : 448;
+    while (nb < max_blocks) {
         int worst = -1;
         double t_worst = -1.0;
         for (int g = 0; g < ng; ++g) {

@@ -576,7 +576,12 @@ void plan_backward_bank_stream(const BwdArgs a4[4], const bool use[4], const flo
         for (int h = 0; h < ng; ++h) if (h != g && deg_of[h] == 3) return h;
         return -1;
     };
-    while (nb < FUSED_MAX_BLOCKS) {
+    // Grid cap.  Not every wave slot of the chip: this kernel runs beside the other chain's kernels (the gather, the next
+    // layer's rows kernel), which need slots to make progress at all -- 320 blocks instead of 512 is 2.5 % of the step at
+    // batch 4096 (measured together with the rows kernel's 448; MKGNN_BANK_STREAM_BLOCKS / MKGNN_ROWS_STREAM_BLOCKS to re-measure)
+    static const char* env_blocks = getenv("MKGNN_BANK_STREAM_BLOCKS");
+    const int max_blocks = env_blocks && atoi(env_blocks) > 8 && atoi(env_blocks) <= FUSED_MAX_BLOCKS ? atoi(env_blocks) : 320;
+    while (nb < max_blocks) {
         int worst = -1;
         double t_worst = -1.0;
         for (int g = 0; g < ng; ++g) {
@@ -587,7 +592,7 @@ void plan_backward_bank_stream(const BwdArgs a4[4], const bool use[4], const flo
         if (worst < 0) break;
         const int p = partner(worst);
         if (p >= 0) {
-            if (nb + 2 > FUSED_MAX_BLOCKS) break;
+            if (nb + 2 > max_blocks) break;
             ++count[worst]; ++count[p]; nb += 2;
         } else { ++count[worst]; ++nb; }
     }
