@@ -181,6 +181,8 @@ def fresh_batches_leg(args, model, opt, dev, log):
     # made on the host, in the compact wire form (every bond once, byte-valued attributes, nothing derived) -> host-to-device
     # copy -> static buffers -> one more captured graph that starts by expanding the batch.  PCIe and the loader are inside.
     try:
+        if os.environ.get("MKGNN_NO_SHARD_EPOCH"):
+            raise RuntimeError("skipped (MKGNN_NO_SHARD_EPOCH)")
         import tempfile
         from molkgnn_amd import shards as S
         with tempfile.TemporaryDirectory() as d:

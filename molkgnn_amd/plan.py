@@ -135,7 +135,7 @@ class BatchPlan:
             ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             side = index_stream(dev)
             cur = torch.cuda.current_stream(dev)
-            if side is not None:
+            if side is not None and side != cur:       # (already on the index stream: attach_receptive_fields(overlap=True))
                 side.wait_stream(cur)
             with torch.cuda.stream(side if side is not None else cur):
                 _lib.check(lib.mkgnn_plan_build(bk, n, _lib.ptr(ei), m, s_ptr.data_ptr(), s_rows.data_ptr(), in_ptr.data_ptr(),

@@ -180,6 +180,13 @@ def attach_receptive_fields(batch: GraphBatch, sizes=None, overlap: bool = False
                 rf = build_receptive_fields_hip(batch.x, batch.p, batch.edge_index, batch.edge_attr, sizes)
                 ev = torch.cuda.Event()
                 ev.record(side)
+                # ... and the index plan right behind it on the same stream (it needs the buckets and edge_index, nothing of
+                # the caller's stream): MolGCN.forward finds it in the plan cache; the first propagate joins
+                from .plan import plan_from_lists_cached
+                names = ('p_focal', 'nei_p', 'nei_edge_attr', 'selected_index', 'nei_index')
+                units = [rf.get(f'nei_edge_unit_deg{d}') for d in range(1, 5)]
+                plan_from_lists_cached(batch.x.shape[0], *[[rf[f'{nm}_deg{d}'] for d in range(1, 5)] for nm in names],
+                                       batch.edge_index, units if any(u is not None for u in units) else None)
             for v in rf.values():
                 if torch.is_tensor(v):
                     v.record_stream(cur)
