@@ -73,6 +73,23 @@ EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn
            "mkgnn_plan_workspace_bytes", "mkgnn_plan_build", "mkgnn_backward_join", "mkgnn_backward_streams", "mkgnn_bank_prepare", "mkgnn_expand_batch")
 
 _lib: Optional[C.CDLL] = None
+TORCH_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libmolkgnn_torch.so")
+_torch_ops_loaded = False
+
+
+def load_torch_ops():
+    """Register ``torch.ops.molkgnn.*`` (csrc/torch_ops.cpp: TORCH_LIBRARY over the C ABI); raises if it is not built."""
+    global _torch_ops_loaded
+    import torch
+    if not _torch_ops_loaded:
+        load()                                   # (the shim links against the C-ABI library: same directory, $ORIGIN)
+        if not os.path.exists(TORCH_LIB_PATH):
+            raise MolKGNNLibraryError(f"{TORCH_LIB_PATH} is missing: build it with `make -C molkgnn_amd/csrc torch`")
+        torch.ops.load_library(TORCH_LIB_PATH)
+        if int(torch.ops.molkgnn.abi_version()) != ABI_VERSION:
+            raise MolKGNNLibraryError("libmolkgnn_torch.so was built against another ABI version")
+        _torch_ops_loaded = True
+    return torch.ops.molkgnn
 
 
 class MolKGNNLibraryError(RuntimeError):

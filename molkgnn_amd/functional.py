@@ -207,11 +207,54 @@ def _forward_impl(x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad
             variant |= BANK_PREPARED
         else:
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        _lib.check(lib.mkgnn_kernelsetconv_forward(
-            banks, buckets, x.data_ptr(), _stride0(x), inv.data_ptr(), n, F, E, int(bool(is_last_layer)),
-            out_full.data_ptr(), out_w, saved, ws.data_ptr(), ws_bytes, variant, st),
-            "mkgnn_kernelsetconv_forward")
+        if _USE_TORCH_OPS:
+            ps, bkl, counts, sv = _op_lists(plan, params, E, need_p, saved_t, dev)
+            _lib.load_torch_ops().kernelsetconv_forward(x, inv, ps, bkl, counts, E, bool(is_last_layer), out_full, sv, ws, variant)
+        else:
+            _lib.check(lib.mkgnn_kernelsetconv_forward(
+                banks, buckets, x.data_ptr(), _stride0(x), inv.data_ptr(), n, F, E, int(bool(is_last_layer)),
+                out_full.data_ptr(), out_w, saved, ws.data_ptr(), ws_bytes, variant, st),
+                "mkgnn_kernelsetconv_forward")
     return x, out_full, inv, saved_t, Ls, ws
+
+
+# MKGNN_TORCH_OPS=1: the forward / backward calls go through the registered operators (torch.ops.molkgnn.*,
+# csrc/torch_ops.cpp: TORCH_LIBRARY over the C ABI) instead of ctypes -- same kernels, same results (GPU test)
+_USE_TORCH_OPS = os.environ.get("MKGNN_TORCH_OPS") == "1"
+
+
+def use_torch_ops(on: bool) -> None:
+    """Route ``kernelsetconv``'s forward / backward calls through ``torch.ops.molkgnn`` (True) or ctypes (False)."""
+    global _USE_TORCH_OPS
+    if on:
+        _lib.load_torch_ops()
+    _USE_TORCH_OPS = bool(on)
+
+
+def _op_lists(plan: BatchPlan, params, E: int, need_p: bool, saved_t, dev):
+    """The flat tensor lists of the registered operators (torch_ops.cpp): 28 parameters, 24 bucket tensors, 4 counts, 8 saved."""
+    none = torch.empty(0, dtype=torch.float32, device=dev)
+    ps = []
+    for i in range(4):
+        xc, xs, es, p3, ts, tc, te = params[i * PARAMS_PER_DEGREE:(i + 1) * PARAMS_PER_DEGREE]
+        ps += [_f32c(xc), _f32c(xs), _f32c(es), _f32c(p3), ts.detach(), tc.detach(), te.detach()]
+    bk, counts = [], []
+    for b in plan.buckets:
+        counts.append(int(b.count))
+        if not b.count:
+            bk += [none] * 6
+            continue
+        if b.e_nei.numel() != b.count * b.degree * E:
+            raise ValueError(f"nei_edge_attr_deg{b.degree} has {b.e_nei.numel()} values, expected {b.count}x{b.degree}x{E}")
+        eu = b.e_unit(E)
+        withp = need_p and b.degree == 4
+        if withp and (b.p_focal is None or b.p_focal.shape[-1] != 3):
+            raise ValueError("chirality (degree 4, last layer) needs 3-D coordinates")
+        bk += [b.sel, b.nei, b.e_nei, b.p_focal if withp else none, b.nei_p if withp else none, eu if eu is not None else none]
+    sv = []
+    for pr, ch in saved_t:
+        sv += [pr if pr is not None else none, ch if ch is not None else none]
+    return ps, bk, counts, sv
 
 
 def kernelsetconv_details(x, plan: BatchPlan, is_last_layer: bool, params, edge_attr_dim: int, variant: str = "auto",
@@ -380,11 +423,16 @@ class _KernelSetConvFn(torch.autograd.Function):
                 # because .grad holds it)
                 _Deferred.held.append((x, inv, g, ws, ctx.saved_t, plan, params, [t for t in alive if t is not None and
                                                                                  all(t is not q for q in gparams)]))
-            _lib.check(lib.mkgnn_kernelsetconv_backward(
-                banks, buckets, x.data_ptr(), _stride0(x), inv.data_ptr(), n, F, E, int(ctx.is_last),
-                g.data_ptr(), _stride0(g), saved, rowptr.data_ptr(), rows.data_ptr(),
-                _lib.ptr(gx), F4, grads, ws.data_ptr(), ws_bytes, int(reuse), bwd_variant, _lib.stream_ptr(dev)),
-                "mkgnn_kernelsetconv_backward")
+            if _USE_TORCH_OPS:
+                ps, bkl, counts, sv = _op_lists(plan, params, E, False, ctx.saved_t, dev)
+                _lib.load_torch_ops().kernelsetconv_backward(x, inv, ps, bkl, counts, E, bool(ctx.is_last), g, sv, rowptr, rows, gx,
+                                                             list(alive), ws, bool(reuse), bwd_variant)
+            else:
+                _lib.check(lib.mkgnn_kernelsetconv_backward(
+                    banks, buckets, x.data_ptr(), _stride0(x), inv.data_ptr(), n, F, E, int(ctx.is_last),
+                    g.data_ptr(), _stride0(g), saved, rowptr.data_ptr(), rows.data_ptr(),
+                    _lib.ptr(gx), F4, grads, ws.data_ptr(), ws_bytes, int(reuse), bwd_variant, _lib.stream_ptr(dev)),
+                    "mkgnn_kernelsetconv_backward")
         del alive           # (freed memory is only handed out again in stream order, after the kernels above)
         return (gx, None, None, None, None, None, None, None, None, None, *gparams)
 

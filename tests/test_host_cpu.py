@@ -296,3 +296,14 @@ def test_receptive_field_builder_matches_the_reference_transform():
             assert g[k].numel() == want.numel(), (i, k)
             if want.numel():
                 assert torch.equal(g[k].reshape(want.shape), want.to(g[k].dtype)), (i, k)
+
+
+def test_torch_library_shim_loads_and_registers_its_operators():
+    """libmolkgnn_torch.so (csrc/torch_ops.cpp, TORCH_LIBRARY(molkgnn)): built by build(), loads on a CPU-only box, agrees with
+    the C ABI's version and exposes the three operators (they themselves need a GPU)."""
+    import torch
+    from molkgnn_amd import _lib
+    ops = _lib.load_torch_ops()
+    assert int(ops.abi_version()) == _lib.ABI_VERSION
+    for name in ("kernelsetconv_forward", "kernelsetconv_backward", "backward_join"):
+        assert hasattr(torch.ops.molkgnn, name)
