@@ -637,6 +637,35 @@ def test_random_shapes_against_the_oracle(seed):
     _oracle_check_both_variants(layer, state, cpu, plan, x, store, F, last, cot, dev, (F, E, Ls, nmol, last))
 
 
+@pytest.mark.parametrize("nmol,F,last", [(1, 110, False), (2, 28, False), (7, 110, True), (33, 110, False), (33, 28, False),
+                                         (150, 110, True)])
+def test_streamed_kernels_on_small_and_ragged_batches(nmol, F, last):
+    """The reference's own shapes (kernels 10 / 20 / 30 / 50, F = 28 / 110, E = 7: the streamed forward, rows and bank
+    kernels) on batches with fewer atom tiles than streams, buckets of one or two atoms and ragged last tiles: both
+    variants against the oracle, forward and every gradient."""
+    from molkgnn_amd.kernels import KernelSetConv
+    from molkgnn_amd.plan import plan_from_data
+    from molkgnn_amd.receptive_field import GraphBatch, build_receptive_fields
+    from molkgnn_amd.synthetic import make_batch
+    dev = _dev()
+    topo = make_batch(nmol, seed=300 + nmol, with_receptive_fields=False)
+    g = torch.Generator().manual_seed(nmol)
+    n = topo.x.shape[0]
+    x = torch.randn(n, F, generator=g)
+    fields = build_receptive_fields(x, topo.p, topo.edge_index, topo.edge_attr)
+    cpu = GraphBatch(x=x, p=topo.p, edge_index=topo.edge_index, edge_attr=topo.edge_attr, batch=topo.batch, **fields)
+    bd = cpu.to(dev)
+    torch.manual_seed(nmol)
+    layer = KernelSetConv(10, 20, 30, 50, D=3, node_attr_dim=F, edge_attr_dim=7)
+    state = {k: v.detach().clone() for k, v in layer.state_dict().items()}
+    layer = layer.to(dev)
+    plan = plan_from_data(bd)
+    cot = torch.randn(n, 110, generator=g)
+    store = torch.zeros(n, F + (-F) % 4, device=dev)
+    store[:, :F] = x.to(dev)
+    _oracle_check_both_variants(layer, state, cpu, plan, x, store, F, last, cot, dev, (F, nmol, last))
+
+
 @pytest.mark.parametrize("width,last", [(28, False), (110, False), (110, True), (55, False)])
 def test_bf16_similarity_variant_tracks_fp32(width, last):
     """variant="bf16" (BASELINE configs[4], SURVEY 8c config 5: bf16 similarity path, fp32 accumulate, parity relaxed to
