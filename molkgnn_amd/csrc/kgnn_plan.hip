@@ -235,7 +235,9 @@ extern "C" int mkgnn_plan_build(const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGR
     a.rowptr[0] = scatter_rowptr; a.rowptr[1] = in_rowptr; a.rowptr[2] = out_rowptr;
     a.scatter_rows = scatter_rows; a.in_col = in_col; a.in_col_packed = in_col_packed; a.out_col = out_col; a.deg8 = deg8;
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(a.cnt, 0, (size_t)3 * (n_atoms + 1) * 4, st);
+    // (rounded up to 16 bytes: the tail lands in the block sums, which the scan's first pass writes before anyone reads them;
+    // an odd size makes the runtime launch a second fill kernel)
+    hipError_t e = hipMemsetAsync(a.cnt, 0, ((size_t)3 * (n_atoms + 1) * 4 + 15) & ~(size_t)15, st);
     if (e != hipSuccess) return api_hip_fail(who, e);
     int64_t work = r > n_edges ? r : n_edges;
     if (n_atoms > work) work = n_atoms;

@@ -186,7 +186,9 @@ int mkgnn_rf_count(const int64_t* edge_index, int64_t n_atoms, int64_t n_edges, 
         return e == hipSuccess ? 0 : api_hip_fail("mkgnn_rf_count", e);
     }
     RfWs w = rf_ws(workspace, n_atoms);
-    e = hipMemsetAsync(w.deg, 0, (size_t)n_atoms * 4, st);
+    // (rounded up to 16 bytes -- the alignment padding in front of `slot` absorbs it: an odd size makes the runtime launch a
+    // second fill kernel for the tail)
+    e = hipMemsetAsync(w.deg, 0, ((size_t)n_atoms * 4 + 15) & ~(size_t)15, st);
     if (e != hipSuccess) return api_hip_fail("mkgnn_rf_count", e);
     const int64_t nblk = (n_atoms + RF_BLOCK - 1) / RF_BLOCK;
     if (n_edges) rf_edges_kernel<<<(int)((n_edges + 255) / 256), 256, 0, st>>>(edge_index, n_atoms, n_edges, w);
