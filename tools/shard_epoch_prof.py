@@ -46,7 +46,8 @@ with tempfile.TemporaryDirectory() as d:
     for cb in loader:
         csb.load(cb); g.replay()
     torch.cuda.synchronize()
-    for mode in ("loader+load+replay", "loader+load", "loader only", "replay only"):
+    evs = [None, None]
+    for mode in ("loader+load+replay", "loader+load+replay throttled", "loader+load", "loader only", "replay only"):
         t_next = t_load = t_rep = 0.0
         n = 0
         t0 = time.perf_counter()
@@ -58,13 +59,29 @@ with tempfile.TemporaryDirectory() as d:
                 t2 = time.perf_counter()
                 if cb is None:
                     break
-                if mode in ("loader+load+replay", "loader+load"):
+                if mode.startswith("loader+load"):
                     csb.load(cb)
                 t3 = time.perf_counter()
-                if mode in ("loader+load+replay", "replay only"):
+                if mode.endswith("throttled"):           # never more than two steps ahead of the GPU: the launch call does not block
+                    if evs[n & 1] is not None:
+                        evs[n & 1].synchronize()
+                if mode.startswith("loader+load+replay") or mode == "replay only":
                     g.replay()
+                if mode.endswith("throttled"):
+                    evs[n & 1] = torch.cuda.Event()
+                    evs[n & 1].record()
                 t4 = time.perf_counter()
                 t_next += t2 - t1; t_load += t3 - t2; t_rep += t4 - t3; n += 1
         torch.cuda.synchronize()
         el = time.perf_counter() - t0
+        if mode.startswith("loader+load+replay") or mode == "replay only":      # GPU time of one replay while the loader runs
+            ea, eb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            gts = []
+            for cb in (loader if mode != "replay only" else range(nb)):
+                if mode != "replay only":
+                    csb.load(cb)
+                ea.record(); g.replay(); eb.record(); eb.synchronize()
+                gts.append(ea.elapsed_time(eb))
+            gts.sort()
+            print(f"    one replay, timed with events while the loader runs: median {gts[len(gts) // 2]:.3f} ms")
         print(f"{mode:20s}: {1e3 * el / n:.3f} ms per batch  (host: next {1e3 * t_next / n:.3f}  load {1e3 * t_load / n:.3f}  replay {1e3 * t_rep / n:.3f})")
