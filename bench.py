@@ -263,7 +263,10 @@ def main():
     _lib.load()
     if not os.environ.get("MKGNN_NO_TUNE"):
         tune_torch_backends()
-    dp.init_process_group_from_env(os.environ.get("MKGNN_DIST_BACKEND", "nccl"))   # nccl = RCCL over xGMI
+    # MKGNN_BENCH_DP_PATH=1 (rehearsal on one GPU): take the N > 1 code path -- backward graph, RCCL all-reduce of the flat
+    # gradient buffer, one shared optimiser graph -- with a process group of ONE rank
+    dp_path = world > 1 or bool(os.environ.get("MKGNN_BENCH_DP_PATH"))
+    dp.init_process_group_from_env(os.environ.get("MKGNN_DIST_BACKEND", "nccl"), force=dp_path)   # nccl = RCCL over xGMI
 
     torch.manual_seed(1798)                       # same initial weights on every rank
     model = GNNModel(ffn_dropout_rate=float(os.environ.get("MKGNN_BENCH_FFN_DROPOUT", "0.25"))).to(dev)   # (diagnostics; 0.25 = the reference default)
@@ -316,19 +319,19 @@ def main():
                 graphs = []
                 # N > 1: RCCL's watchdog thread polls its events with HIP calls of its own; in the default ("global")
                 # capture mode such a call from another thread invalidates the capture
-                cap = {"capture_error_mode": "thread_local"} if world > 1 else {}
+                cap = {"capture_error_mode": "thread_local"} if dp_path else {}
                 for i in range(nb):
                     model.zero_grad(set_to_none=True)
                     g_fb = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g_fb, stream=side, **cap):
                         static_loss = model.loss(batches[i])
                         train_backward(static_loss)
-                        if opt is not None and world == 1:
+                        if opt is not None and not dp_path:
                             opt.step()
                     # this graph's gradient tensors: every captured graph writes into its own (p.grad names only the
                     # last capture's), and the all-reduce after it must work on exactly these
                     graphs.append([g_fb, None, static_loss, reducer.grads()])
-                if opt is not None and world > 1:
+                if opt is not None and dp_path:
                     # N > 1: backward graph -> gradients summed over the ranks in the flat buffer -> ONE optimiser graph
                     # for all batches that reads the flat views and divides by the world size itself
                     from molkgnn_amd.optim import FusedAdamW
@@ -504,7 +507,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.assay)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

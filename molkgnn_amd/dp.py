@@ -23,14 +23,16 @@ import torch
 import torch.distributed as dist
 
 
-def init_process_group_from_env(backend: Optional[str] = None) -> int:
-    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); returns world size."""
+def init_process_group_from_env(backend: Optional[str] = None, force: bool = False) -> int:
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); returns world size.
+    ``force``: also for a world of one (a rehearsal of the collective path on a single GPU)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend=backend, rank=int(os.environ.get("RANK", "0")), world_size=world)
     return world
 
 
