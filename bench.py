@@ -317,6 +317,13 @@ def main():
                 for i in range(3):                   # warm every lazy initialisation on the capture stream
                     step(i)
                 graphs = []
+                from molkgnn_amd.optim import FusedAdamW as _FA
+                fill_in_graph = isinstance(opt, _FA)
+                if fill_in_graph and dp_path:            # (flag and zero tensors of every batch's gradient pattern are made
+                    for bb in batches:                   # before the captures: a host-to-device copy cannot be captured)
+                        model.zero_grad(set_to_none=True)
+                        train_backward(model.loss(bb))
+                        reducer.prepare_patterns([reducer.grads()])
                 # N > 1: RCCL's watchdog thread polls its events with HIP calls of its own; in the default ("global")
                 # capture mode such a call from another thread invalidates the capture
                 cap = {"capture_error_mode": "thread_local"} if dp_path else {}
@@ -328,9 +335,13 @@ def main():
                         train_backward(static_loss)
                         if opt is not None and not dp_path:
                             opt.step()
-                    # this graph's gradient tensors: every captured graph writes into its own (p.grad names only the
-                    # last capture's), and the all-reduce after it must work on exactly these
-                    graphs.append([g_fb, None, static_loss, reducer.grads()])
+                        # this graph's gradient tensors: every captured graph writes into its own (p.grad names only the
+                        # last capture's), and the all-reduce after it must work on exactly these.  With the flat-buffer
+                        # optimiser the copy into the flat buffer is the graph's last node: outside, only the collective
+                        own_grads = reducer.grads()
+                        if opt is not None and dp_path and fill_in_graph:
+                            reducer.fill(own_grads)
+                    graphs.append([g_fb, None, static_loss, own_grads])
                 if opt is not None and dp_path:
                     # N > 1: backward graph -> gradients summed over the ranks in the flat buffer -> ONE optimiser graph
                     # for all batches that reads the flat views and divides by the world size itself
@@ -371,7 +382,7 @@ def main():
             g_fb.replay()
             if g_opt is not None:
                 if flat_opt:
-                    reducer.sum_into_flat(static_grads)
+                    reducer.all_reduce_filled()          # (the copy into the flat buffer is the backward graph's last node)
                 else:
                     reducer.reduce(static_grads)
                 g_opt.replay()

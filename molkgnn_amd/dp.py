@@ -72,6 +72,7 @@ class FlatGradAllReduce:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self._filled: List[torch.nn.Parameter] = []
         self._flag_cache: dict = {}
+        self._zero_cache: dict = {}
 
     @property
     def nbytes(self) -> int:
@@ -90,25 +91,33 @@ class FlatGradAllReduce:
         return {p: self.flags[i] for i, p in enumerate(self.params)}
 
     def _fill(self, grads: List[Optional[torch.Tensor]]) -> List[tuple]:
-        """Local gradients and has-gradient flags into the buffer; returns the (view, gradient) pairs present."""
+        """Local gradients and has-gradient flags into the buffer; returns the (view, gradient) pairs present.  ONE
+        multi-tensor copy: a parameter without a gradient here is filled from a resident zero tensor of its shape (its slot
+        holds the other ranks' sum from the previous step otherwise), the flags from the pattern's resident 0 / 1 tensor."""
         have = [(v, g) for v, g in zip(self.views, grads) if g is not None]
-        if len(have) != len(self.params):
-            self.flat.zero_()                         # slots of parameters without a gradient here contribute zero
-        if have:
-            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         pattern = tuple(g is not None for g in grads)
         local = self._flag_cache.get(pattern)
         if local is None:                             # one small device tensor per None-pattern, built outside any capture
             local = torch.tensor([1.0 if b else 0.0 for b in pattern], dtype=torch.float32).to(self.flags.device)
             if len(self._flag_cache) < 64:
                 self._flag_cache[pattern] = local
-        self.flags.copy_(local)
+        src = [g if g is not None else self._zeros_like(i) for i, g in enumerate(grads)]
+        torch._foreach_copy_(self.views + [self.flags], src + [local])
         return have
+
+    def _zeros_like(self, i: int) -> torch.Tensor:
+        z = self._zero_cache.get(i)
+        if z is None:                                 # (allocated once per parameter that ever lacks a gradient; call
+            z = self._zero_cache[i] = torch.zeros_like(self.views[i])      # prepare_patterns before capturing a graph)
+        return z
 
     def prepare_patterns(self, grads_lists) -> None:
         """Build the flag tensors of these gradient lists now (a host-to-device copy cannot happen inside a capture)."""
         for grads in grads_lists:
             pattern = tuple(g is not None for g in grads)
+            for i, g in enumerate(grads):
+                if g is None:
+                    self._zeros_like(i)
             if pattern not in self._flag_cache:
                 self._flag_cache[pattern] = torch.tensor([1.0 if b else 0.0 for b in pattern],
                                                          dtype=torch.float32).to(self.flags.device)
@@ -122,7 +131,18 @@ class FlatGradAllReduce:
         if len(grads) != len(self.params):
             raise ValueError("grads must come from FlatGradAllReduce.grads()")
         self._fill(grads)
-        if self.world > 1:
+        self.all_reduce_filled()
+
+    def fill(self, grads: List[Optional[torch.Tensor]]) -> None:
+        """The first half of ``sum_into_flat`` alone -- one multi-tensor copy, capturable: a backward captured as a graph
+        ends with it, and the step outside the graph is ``all_reduce_filled()`` only."""
+        if len(grads) != len(self.params):
+            raise ValueError("grads must come from FlatGradAllReduce.grads()")
+        self._fill(grads)
+
+    def all_reduce_filled(self) -> None:
+        """SUM the flat buffer (gradient slots and has-gradient flags) over the ranks."""
+        if self.world > 1 or dist.is_initialized():          # (a process group of one rank still runs the collective: rehearsals)
             dist.all_reduce(self._buf, op=dist.ReduceOp.SUM)
 
     def reduce(self, grads: Optional[List[Optional[torch.Tensor]]] = None) -> None:
