@@ -71,6 +71,132 @@ def layer_algorithmic(plan, F, E, Ls, last):
     return by, fl
 
 
+def backward_algorithmic(plan, F, E, Ls):
+    """Algorithmic bytes / flops per launch of the backward's kernels for one KernelSetConv.
+    Useful work only: of the d x d matrix entries of a pair the chosen order used d, so a pair costs 2 F (d + 1) flops
+    towards the rows and the same (+ 2 E d for the bond supports) towards the bank -- the masked dense products the
+    kernels issue are d times that for the support part."""
+    n, m = plan.n_atoms, plan.n_slots
+    pairs = sum(plan.buckets[d - 1].count * L for d, L in zip(range(1, 5), Ls))
+    bank_x = sum(L * (d + 1) * F for d, L in zip(range(1, 5), Ls))
+    bank_all = sum(L * ((d + 1) * F + d * E) + 4 for d, L in zip(range(1, 5), Ls))
+    fl_rows = sum(plan.buckets[d - 1].count * L * 2 * F * (d + 1) for d, L in zip(range(1, 5), Ls))
+    fl_bank = sum(plan.buckets[d - 1].count * L * (2 * F * (d + 1) + 2 * E * d) for d, L in zip(range(1, 5), Ls))
+    through = sum(plan.buckets[d - 1].count * d * L for d, L in zip(range(1, 5), Ls))
+    return {
+        "coef_prepare_kernel": (16 * pairs + 4 * through + 8 * pairs, 8 * pairs),      # pair records + neighbours' dL/dh blocks in, {g, order} records out
+        "kc_backward_rows_stream": (8 * pairs + 4 * (n + m) * F + 4 * bank_x, fl_rows),  # records in, contribution rows out, bank once
+        "kc_backward_bank_stream": (4 * n * F + 8 * pairs + 32 * m + 8 * m + 8 * n + 4 * bank_all, fl_bank),   # x once, records, unit bond rows, indices, one slab's worth out
+        "kc_backward_bank_reduce": (4 * bank_all, 4 * bank_all),
+        "csr_rows_kernel<gather>": (4 * (n + m) * F + 4 * (n + m) + 8 * n * F, 2 * (n + m) * F),     # contribution rows + CSR in, x in, grad_x out
+    }
+
+
+def time_backward_kernels(lib, Fn, h, plan, params, E, variant, reps):
+    """HIP-event durations (ms, mean over `reps` calls) of the five kernels of one N-hop layer's backward, each alone on the
+    GPU (mkgnn_debug_time_backward keeps the call on one stream)."""
+    import ctypes
+    out = (ctypes.c_float * 5)()
+    x = h.detach().requires_grad_(True)
+    wgt = torch.randn(h.shape[0], sum(int(p.shape[0]) for p in params[0::7]), device=h.device)
+    acc, cnt = [0.0] * 5, [0] * 5
+    lib.mkgnn_debug_time_backward(1)
+    try:
+        for r in range(reps + 2):
+            for p_ in params:
+                p_.grad = None
+            x.grad = None
+            hh = Fn.kernelsetconv(x, plan, False, params, E, variant, block_rows=True, propagate=True)
+            (hh * wgt).sum().backward()
+            if lib.mkgnn_debug_last_backward_ms(out) != 0:
+                return None
+            if r >= 2:
+                for k in range(5):
+                    if out[k] >= 0:
+                        acc[k] += float(out[k]); cnt[k] += 1
+    finally:
+        lib.mkgnn_debug_time_backward(0)
+        for p_ in params:
+            p_.grad = None
+    names = ("coef_prepare_kernel", "kc_backward_rows_stream", "kc_backward_bank_stream", "kc_backward_bank_reduce", "csr_rows_kernel<gather>")
+    return {n_: (acc[k] / cnt[k] if cnt[k] else None) for k, n_ in enumerate(names)}
+
+
+def small_batch_leg(args, model, opt, dev, log):
+    """BASELINE configs[2] in the same JSON line (outside the headline's timed region): AID 435008 shape, batch 256 -- the
+    step is launch-latency bound there; ms per step of the resident-batch replay and the N-hop forward kernel's roofline
+    fraction at that size.  configs[0]'s batch of 16 (the reference's own, README.md:81) rides along."""
+    from molkgnn_amd import _lib
+    from molkgnn_amd import functional as Fn
+    from molkgnn_amd.plan import plan_from_data
+    from molkgnn_amd.synthetic import make_batch
+    from molkgnn_amd.train import backward as train_backward
+    import ctypes
+    lib = _lib.load()
+    lib.mkgnn_debug_last_fused_forward_ms.restype = ctypes.c_float
+    out = {}
+    for assay, B in (("435008", 256), ("1798", 16)):
+        batches = [make_batch(B, seed=assay_seed(assay) * 1000 + 700 + i, assay=assay).to(dev) for i in range(4)]
+        with torch.no_grad():
+            for b in batches:
+                model(b)
+        graphs = []
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for b in batches[:2]:
+                model.zero_grad(set_to_none=True)
+                train_backward(model.loss(b))
+                if opt is not None:
+                    opt.step()
+            for b in batches:
+                model.zero_grad(set_to_none=True)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    train_backward(model.loss(b))
+                    if opt is not None:
+                        opt.step()
+                graphs.append(g)
+        torch.cuda.current_stream().wait_stream(side)
+        for g in graphs:
+            g.replay()
+        torch.cuda.synchronize()
+        steps, wins = 200, []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(steps):
+                graphs[i % 4].replay()
+            torch.cuda.synchronize()
+            wins.append((time.perf_counter() - t0) / steps)
+        wins.sort()
+        b = batches[0]
+        plan = plan_from_data(b)
+        layer = model.gnn_model.gnn.layers[1]
+        params, E = layer._bank_params("train", b.x)
+        K_in = model.gnn_model.gnn.num_kernels(0)
+        h_store = torch.zeros(b.x.shape[0], K_in + (-K_in) % 4, device=dev)
+        h_store[:, :K_in] = torch.rand(b.x.shape[0], K_in, device=dev) * 2 - 1
+        h = h_store[:, :K_in]
+        samples = []
+        lib.mkgnn_debug_time_fused_forward(1)
+        for r in range(12):
+            Fn.kernelsetconv_details(h, plan, False, params, E, args.variant, raw=True)
+            if r >= 2:
+                samples.append(float(lib.mkgnn_debug_last_fused_forward_ms()))
+        lib.mkgnn_debug_time_fused_forward(0)
+        ms_f = sum(samples) / len(samples)
+        by, fl = layer_algorithmic(plan, K_in, E, layer.L, False)
+        key = f"aid{assay}_b{B}"
+        out[key] = {"workload": f"AID {assay} shape, batch {B} ({b.x.shape[0]} atoms), fwd+bwd+AdamW, one hipGraph per resident batch",
+                    "ms_per_step": round(1e3 * wins[2], 4), "ms_per_step_min": round(1e3 * wins[0], 4),
+                    "value": round(B / wins[2], 1), "unit": "molecules/s",
+                    "forward_kernel_ms": round(ms_f, 5), "forward_kernel_frac": round(by / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+        log(f"small batch {key}: {1e3 * wins[2]:.4f} ms per step, forward kernel {1e3 * ms_f:.1f} us")
+        del graphs
+    return out
+
+
 def host_cores():
     """CPU cores this process may actually use: the cgroup quota if there is one, else the affinity mask."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -327,6 +453,14 @@ def main():
                 # N > 1: RCCL's watchdog thread polls its events with HIP calls of its own; in the default ("global")
                 # capture mode such a call from another thread invalidates the capture
                 cap = {"capture_error_mode": "thread_local"} if dp_path else {}
+                # MKGNN_DP_ONE_GRAPH=1: the collective is captured too -- backward, copy into the flat buffer, RCCL all-reduce
+                # and the optimiser (reading the flat views) are ONE graph per batch, as on one GPU.  Not the default: a
+                # collective that hangs inside a replay cannot be caught; the two-graph step is.
+                one_graph = dp_path and opt is not None and fill_in_graph and os.environ.get("MKGNN_DP_ONE_GRAPH") == "1"
+                if one_graph:
+                    for grp in opt.param_groups:
+                        grp["grad_scale"] = 1.0 / world
+                    opt.set_grad_active(reducer.active_flags())
                 for i in range(nb):
                     model.zero_grad(set_to_none=True)
                     g_fb = torch.cuda.CUDAGraph()
@@ -341,8 +475,13 @@ def main():
                         own_grads = reducer.grads()
                         if opt is not None and dp_path and fill_in_graph:
                             reducer.fill(own_grads)
+                        if one_graph:
+                            reducer.all_reduce_filled()
+                            for p_, v_ in zip(reducer.params, reducer.views):
+                                p_.grad = v_
+                            opt.step()
                     graphs.append([g_fb, None, static_loss, own_grads])
-                if opt is not None and dp_path:
+                if opt is not None and dp_path and not one_graph:
                     # N > 1: backward graph -> gradients summed over the ranks in the flat buffer -> ONE optimiser graph
                     # for all batches that reads the flat views and divides by the world size itself
                     from molkgnn_amd.optim import FusedAdamW
@@ -413,6 +552,13 @@ def main():
             el = float(t.item())
         return el
 
+    # how many ranks the collective really spans (an all-reduce of ones), outside the timed region
+    ranks_seen = None
+    if dist.is_initialized():
+        t = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(t.item())))
+
     first = timed_window()
     n_windows = args.windows if args.windows > 0 else max(5, min(200, int(math.ceil(0.5 / max(first, 1e-6)))))
     if world > 1:                                        # every rank must run the same number of windows
@@ -478,11 +624,31 @@ def main():
         traffic, traffic_source = None, None
         try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same workload; tools/pmc.sh)
             if args.batch_size == 4096 and args.variant in ("auto", "mfma"):
-                pmc = json.load(open(os.path.join(REPO, "profiles", "r02_forward_pmc.json")))
-                traffic = pmc["hbm_bytes_per_launch"]
-                traffic_source = "profiles/r02_forward_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of commit " + pmc.get("commit", "?") + ")"
+                for name in ("r03_forward_pmc.json", "r02_forward_pmc.json"):
+                    path = os.path.join(REPO, "profiles", name)
+                    if os.path.exists(path):
+                        pmc = json.load(open(path))
+                        traffic = pmc["hbm_bytes_per_launch"]
+                        traffic_source = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of commit " + pmc.get("commit", "?") + ")"
+                        break
         except Exception:
             traffic = None
+        # the other kernels of the N-hop layer (the bank gradient is the step's largest line), each alone on the GPU,
+        # HIP events in this run; flops / bytes are the USEFUL ones (backward_algorithmic)
+        kernels = [{"kernel": "kc_forward_stream<7>", "ms_per_launch": round(ms, 5), "algorithmic_bytes": by, "algorithmic_flops": fl,
+                    "hbm_frac": round(gbs / HBM_PEAK_GBS, 5), "fp32_frac": round(fl / (ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 5)}]
+        try:
+            if args.variant in ("auto", "mfma"):
+                bt = time_backward_kernels(lib, Fn, h, plan, params, E, args.variant, max(5, args.roofline_reps // 2))
+                alg = backward_algorithmic(plan, K_in, E, Ls)
+                for name, t_ms in (bt or {}).items():
+                    if t_ms:
+                        b_, f_ = alg[name]
+                        kernels.append({"kernel": name, "ms_per_launch": round(t_ms, 5), "algorithmic_bytes": b_, "algorithmic_flops": f_,
+                                        "hbm_frac": round(b_ / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                        "fp32_frac": round(f_ / (t_ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 5)})
+        except Exception as exc:
+            log(f"backward kernel timing unavailable ({type(exc).__name__}: {exc})")
         roofline = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
                     "kernel": ("kc_forward_fused<7, bf16 operands>" if args.variant == "bf16" else "kc_forward_stream<7>")
@@ -491,7 +657,8 @@ def main():
                     "ms_per_launch": round(ms, 5), "ms_whole_forward_call": round(ms_call, 5),
                     "algorithmic_bytes": by, "algorithmic_flops": fl,
                     "fp32_tflops": round(fl / (ms * 1e-3) / 1e12, 3),
-                    "fp32_vector_frac": round(fl / (ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 5)}
+                    "fp32_vector_frac": round(fl / (ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 5),
+                    "kernels": kernels}
         out = {"metric": "molecules/sec fwd+bwd, 3-layer MolKGNN on AID 1798", "value": round(value, 1),
                "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * elapsed / args.steps, 4),
@@ -503,6 +670,10 @@ def main():
                "vs_baseline": None, "dtype": "bf16 dot products, f32 otherwise" if args.variant == "bf16" else "f32",
                "data": "synthetic",
                **({"dp_replicas_max_abs_diff": replicas_diff} if replicas_diff is not None else {}),
+               **({"dp_ranks_seen": ranks_seen, "dp_backend": dist.get_backend(),
+                   "dp_step": "one graph (collective captured)" if (graphs is not None and all(e_[1] is None for e_ in graphs))
+                              else ("backward graph + all-reduce + optimiser graph" if graphs is not None else "eager")}
+                  if ranks_seen is not None else {}),
                "config": {"workload": f"{'all nine assays mixed' if args.assay == 'all9' else 'AID ' + args.assay} full set shape ({n_mol_assay} molecules, ~25 atoms / ~53 directed "
                                       f"edges each), 3 layers, hidden_dim 32, kernels 10/20/30/50 per degree, "
                                       f"batch {args.batch_size} molecules per GPU ({atoms:.0f} atoms), "
@@ -515,6 +686,11 @@ def main():
         log(f"forward kernel {ms:.4f} ms ({ms_call:.4f} ms whole call), {gbs:.1f} GB/s algorithmic")
         if world == 1 and args.fresh_batches > 0:
             out["fresh_batches"] = fresh_batches_leg(args, model, opt, dev, log)
+        if world == 1 and not os.environ.get("MKGNN_NO_SMALL_BATCH"):
+            try:
+                out["small_batch"] = small_batch_leg(args, model, opt, dev, log)
+            except Exception as exc:                         # (reported, not fatal)
+                out["small_batch"] = {"error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.assay)
         print(json.dumps(out), flush=True)

@@ -298,7 +298,7 @@ hipError_t launch_backward_rows_stream(const BwdArgs a4[4], const bool use[4], f
     for (int g = 0; g < ng; ++g) { count[g] = 1; ++nb; }
     // grid cap: see launch_backward_bank_stream (the two kernels' caps were measured together)
     static const char* env_blocks = getenv("MKGNN_ROWS_STREAM_BLOCKS");
-    const int max_blocks = env_blocks && atoi(env_blocks) > 8 && atoi(env_blocks) <= FUSED_MAX_BLOCKS ? atoi(env_blocks) : 448;
+    const int max_blocks = grid_cap(g_grid_caps.rows, env_blocks && atoi(env_blocks) > 8 && atoi(env_blocks) <= FUSED_MAX_BLOCKS ? atoi(env_blocks) : 448);
     while (nb < max_blocks) {
         int worst = -1;
         double t_worst = -1.0;
@@ -333,6 +333,7 @@ hipError_t launch_backward_rows_stream(const BwdArgs a4[4], const bool use[4], f
         for (int b = 0; b < nb; ++b) a.blk_rank[b] = (uint16_t)next[a.blk_group[b]][b & 7]++;
     }
     for (int g = 0; g < ng; ++g) a.grp_count[g] = (uint16_t)count[g];
+    note_plan(1, nb, ng, tiles_of, count, nstream_of);
     const size_t lds_bytes = (size_t)4 * 2 * 16 * (16 * KC + 4) * 4;      // NSTREAM * NS = 4 wave images of 16 rows, two parities
     if (KC == 2) kc_backward_rows_stream<2><<<nb, 256, lds_bytes, st>>>(a);
     else kc_backward_rows_stream<7><<<nb, 256, lds_bytes, st>>>(a);

@@ -580,7 +580,7 @@ void plan_backward_bank_stream(const BwdArgs a4[4], const bool use[4], const flo
     // layer's rows kernel), which need slots to make progress at all -- 320 blocks instead of 512 is 2.5 % of the step at
     // batch 4096 (measured together with the rows kernel's 448; MKGNN_BANK_STREAM_BLOCKS / MKGNN_ROWS_STREAM_BLOCKS to re-measure)
     static const char* env_blocks = getenv("MKGNN_BANK_STREAM_BLOCKS");
-    const int max_blocks = env_blocks && atoi(env_blocks) > 8 && atoi(env_blocks) <= FUSED_MAX_BLOCKS ? atoi(env_blocks) : 320;
+    const int max_blocks = grid_cap(g_grid_caps.bank, env_blocks && atoi(env_blocks) > 8 && atoi(env_blocks) <= FUSED_MAX_BLOCKS ? atoi(env_blocks) : 320);
     while (nb < max_blocks) {
         int worst = -1;
         double t_worst = -1.0;
@@ -622,6 +622,7 @@ void plan_backward_bank_stream(const BwdArgs a4[4], const bool use[4], const flo
         a.grp_count[g] = (uint16_t)count[g];
         nchunk_out[deg_of[g]] = count[g] * nstream_of[g];
     }
+    note_plan(2, nb, ng, tiles_of, count, nstream_of);
     out->nb = nb; out->prep_blocks = prep_blocks; out->KC = KC; out->lds_bytes = lds_fl * 4;
 }
 

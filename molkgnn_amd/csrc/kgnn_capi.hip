@@ -141,7 +141,67 @@ static void degree_slots(const mkgnn_kernel_bank banks[4], const mkgnn_degree_bu
     for (int r = 0; r < 4; ++r) slot_of[order[r]] = r;
 }
 
+namespace mkgnn {
+GridCaps g_grid_caps;
+PlanInfo g_last_plan[3];
+}  // namespace mkgnn
+
+// Measurement hook for bench.py (mkgnn_debug_time_backward): when enabled, a backward call keeps all its kernels on the
+// caller's stream, one after the other (no helper streams: every kernel alone on the GPU), and brackets each with HIP
+// events recorded on that stream: 0 coefficient pre-pass, 1 rows gradient, 2 bank gradient, 3 bank reduce, 4 gather.
+// One benchmarking thread; the flag is atomic, the events are not per caller.
+static std::atomic<bool> g_time_bwd{false};
+static hipEvent_t g_bwd_ev[5][2];
+static bool g_bwd_ev_made = false, g_bwd_ev_used[5];
+struct BwdTimer {
+    hipStream_t st; int k; bool on;
+    BwdTimer(hipStream_t s, int which) : st(s), k(which), on(g_time_bwd.load()) {
+        if (on) { (void)hipEventRecord(g_bwd_ev[k][0], st); g_bwd_ev_used[k] = true; }
+    }
+    ~BwdTimer() { if (on) (void)hipEventRecord(g_bwd_ev[k][1], st); }
+};
+
 extern "C" {
+
+// Diagnostics (not part of the drop-in ABI; used by tests/ and tools/): grid caps of the streamed forward / rows-gradient /
+// bank-gradient kernels, 0 = default, otherwise 8..512, effective from the next launch; and the block split of the last
+// launch of each: out[3 k ..] = {blocks, fewest, most atom tiles per stream over the (degree, column part) groups}.
+int mkgnn_debug_set_grid_caps(int32_t forward_blocks, int32_t rows_blocks, int32_t bank_blocks) {
+    for (int32_t v : {forward_blocks, rows_blocks, bank_blocks})
+        if (v != 0 && (v < 8 || v > FUSED_MAX_BLOCKS)) return fail("mkgnn_debug_set_grid_caps: %d outside 8..%d (0 = default)", v, FUSED_MAX_BLOCKS);
+    g_grid_caps.fwd.store(forward_blocks); g_grid_caps.rows.store(rows_blocks); g_grid_caps.bank.store(bank_blocks);
+    return 0;
+}
+int mkgnn_debug_time_backward(int32_t enable) {
+    if (enable && !g_bwd_ev_made) {
+        for (int k = 0; k < 5; ++k)
+            for (int j = 0; j < 2; ++j)
+                if (hipEventCreate(&g_bwd_ev[k][j]) != hipSuccess) return fail("mkgnn_debug_time_backward: hipEventCreate failed");
+        g_bwd_ev_made = true;
+    }
+    for (int k = 0; k < 5; ++k) g_bwd_ev_used[k] = false;
+    g_time_bwd.store(enable != 0);
+    return 0;
+}
+// out[k] = duration (ms) of kernel k of the last timed backward call (see BwdTimer), -1 where it did not run
+int mkgnn_debug_last_backward_ms(float out[5]) {
+    if (!out || !g_bwd_ev_made) return fail("mkgnn_debug_last_backward_ms: timing was never enabled");
+    for (int k = 0; k < 5; ++k) {
+        out[k] = -1.f;
+        if (!g_bwd_ev_used[k]) continue;
+        if (hipEventSynchronize(g_bwd_ev[k][1]) != hipSuccess) continue;
+        float ms = -1.f;
+        if (hipEventElapsedTime(&ms, g_bwd_ev[k][0], g_bwd_ev[k][1]) == hipSuccess) out[k] = ms;
+    }
+    return 0;
+}
+int mkgnn_debug_last_plans(int32_t out[9]) {
+    if (!out) return fail("mkgnn_debug_last_plans: null pointer");
+    for (int k = 0; k < 3; ++k) {
+        out[3 * k] = g_last_plan[k].blocks.load(); out[3 * k + 1] = g_last_plan[k].min_iters.load(); out[3 * k + 2] = g_last_plan[k].max_iters.load();
+    }
+    return 0;
+}
 
 int mkgnn_abi_version(void) { return MKGNN_ABI_VERSION; }
 
@@ -371,7 +431,7 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
     int slot_of[4];
     degree_slots(banks, buckets, slot_of);
     ForkJoin fj;
-    e = fj.begin(st, true);
+    e = fj.begin(st, !g_time_bwd.load());            // (timed for bench.py: everything on the caller's stream)
     if (e != hipSuccess) return hip_fail("stream fork", e);
     int off = 0;
     int64_t base = 0;
@@ -393,7 +453,9 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
     // the x-gradient rows of all degrees in one streamed launch when every degree's shape is covered (kgnn_bwd_rows_stream.hip);
     // MKGNN_ROWS_STREAM=0: one kc_backward_rows_mfma launch per degree (diagnostics)
     static const char* env_rows_stream = getenv("MKGNN_ROWS_STREAM");
-    bool rows_streamed = fuse_bank && grad_x && !(env_rows_stream && env_rows_stream[0] == '0');
+    // (without grad_x -- a layer whose input carries no gradient -- nobody reads contribution rows: with the bank gradients
+    // fused, which then sum the score-weight partials themselves, no rows kernel is launched at all)
+    bool rows_streamed = fuse_bank && !(env_rows_stream && env_rows_stream[0] == '0');
     for (int i = 0; i < 4 && rows_streamed; ++i)
         if (buckets[i].count > 0 && L[i] > 0 && !rows_stream_supported(i + 1, F, E, L[i])) rows_streamed = false;
     BwdArgs bank_a[4];
@@ -445,7 +507,7 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
                     st_bank = fj.stream(1, &e);
                     if (e != hipSuccess) return hip_fail("stream fork", e);
                 }
-                if (rows_mfma && !rows_streamed) {
+                if (rows_mfma && !rows_streamed && (grad_x || !fuse_bank)) {
                     e = launch_backward_rows_mfma(d, a, &ntheta, st_rows);
                     if (e != hipSuccess) return hip_fail("kernelconv backward launch", e);
                 }
@@ -498,20 +560,24 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         // the pre-pass first, on the caller's stream: its records (dL/dsc and permutation ids in tile order) feed both
         // the rows kernel here and the bank kernel on the helper
         plan_backward_bank_stream(bank_a, bank_use, e_unit4, coefq4, nchunk4, ntheta4, through_nei, &bsl);
-        e = launch_coef_prepare(bsl, st);
+        { BwdTimer t(st, 0); e = launch_coef_prepare(bsl, st); }
         if (e != hipSuccess) return hip_fail("coefficient pre-pass launch", e);
         e = fj.refork(1);
         if (e != hipSuccess) return hip_fail("stream fork", e);
     }
-    if (rows_streamed && any_bank) {
+    if (rows_streamed && any_bank && grad_x) {
+        BwdTimer t(st, 1);
         e = launch_backward_rows_stream(bank_a, bank_use, streamed ? coefq4 : nullptr, st);       // (bank_a holds every active degree's arguments)
         if (e != hipSuccess) return hip_fail("streamed rows launch", e);
     }
     if (any_bank) {
         hipStream_t st_bank = fj.stream(1, &e);      // the helper (the caller's stream when nothing is forked)
         if (e != hipSuccess) return hip_fail("stream fork", e);
-        if (streamed) e = launch_backward_bank_stream(bsl, st_bank);
-        else e = launch_backward_bank_fused(bank_a, bank_use, nchunk4, ntheta4, st_bank);
+        {
+            BwdTimer t(st_bank, 2);
+            if (streamed) e = launch_backward_bank_stream(bsl, st_bank);
+            else e = launch_backward_bank_fused(bank_a, bank_use, nchunk4, ntheta4, st_bank);
+        }
         if (e != hipSuccess) return hip_fail("fused bank gradient launch", e);
         for (int i = 0; i < 4; ++i)
             if (bank_use[i]) {
@@ -530,9 +596,10 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         st_reduce = fj.stream(1, &e);
         if (e != hipSuccess) return hip_fail("stream fork", e);
     }
-    e = launch_bank_reduce_all(reduce, st_reduce);   // one launch for the four banks
+    { BwdTimer t(st_reduce, 3); e = launch_bank_reduce_all(reduce, st_reduce); }   // one launch for the four banks
     if (e != hipSuccess) return hip_fail("bank gradient reduce launch", e);
     if (grad_x) {
+        BwdTimer t(st, 4);
         e = launch_backward_gather((const float*)(ws + w.contrib), (F + 3) / 4 * 4, base, scatter_rowptr, scatter_rows, x,
                                    x_stride, inv_norm, n_atoms, F, grad_x, grad_x_stride, !force_generic, st);
         if (e != hipSuccess) return hip_fail("backward gather launch", e);

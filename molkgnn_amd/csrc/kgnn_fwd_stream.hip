@@ -655,7 +655,8 @@ static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nbloc
     };
     int count[MG], nb = 0;
     for (int g = 0; g < ng; ++g) { count[g] = 1; ++nb; }
-    while (nb < FUSED_MAX_BLOCKS) {
+    const int max_blocks = grid_cap(g_grid_caps.fwd, FUSED_MAX_BLOCKS);
+    while (nb < max_blocks) {
         int worst = -1;
         double t_worst = -1.0;
         for (int g = 0; g < ng; ++g) {
@@ -689,6 +690,7 @@ static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nbloc
         for (int b = 0; b < nb; ++b) a.blk_rank[b] = (uint16_t)next[a.blk_group[b]][b & 7]++;
     }
     for (int g = 0; g < ng; ++g) a.grp_count[g] = (uint16_t)count[g];
+    note_plan(0, nb, ng, tiles_of, count, nstream_of);
     *nblocks_out = nb;
     return lds_floats * 4;
 }

@@ -187,6 +187,29 @@ struct PerDeviceOnce {
     void set(int dev) { if (dev >= 0 && dev < 16) done[dev].store(true, std::memory_order_release); }
 };
 
+// Diagnostics of the three streamed kernels' block split (mkgnn_debug_set_grid_caps / mkgnn_debug_last_plans, kgnn_capi.hip):
+// a run-time cap on the grid (0 = the kernel's default; read at every launch, so one test process can change it) -- with a
+// small cap every stream owns many tiles, which is how the parity tests reach the multi-tile steady state of the
+// benchmark at oracle-sized batches -- and what the last launch of each kernel was split into.
+struct GridCaps { std::atomic<int> fwd{0}, rows{0}, bank{0}; };
+extern GridCaps g_grid_caps;
+struct PlanInfo { std::atomic<int> blocks{0}, min_iters{0}, max_iters{0}; };
+extern PlanInfo g_last_plan[3];              // 0 forward, 1 rows gradient, 2 bank gradient
+inline int grid_cap(const std::atomic<int>& cap, int dflt) {
+    const int c = cap.load(std::memory_order_relaxed);
+    return (c >= 8 && c <= FUSED_MAX_BLOCKS) ? c : dflt;
+}
+inline void note_plan(int which, int blocks, int ng, const int64_t* tiles_of, const int* count, const int* nstream_of) {
+    int lo = 1 << 30, hi = 0;
+    for (int g = 0; g < ng; ++g) {
+        const int64_t streams = (int64_t)count[g] * nstream_of[g];
+        const int it = (int)((tiles_of[g] + streams - 1) / streams);
+        if (it < lo) lo = it;
+        if (it > hi) hi = it;
+    }
+    g_last_plan[which].blocks.store(blocks); g_last_plan[which].min_iters.store(ng ? lo : 0); g_last_plan[which].max_iters.store(hi);
+}
+
 // error reporting shared by the C-ABI translation units (kgnn_capi.hip owns the thread-local message)
 int api_fail(const char* fmt, ...);
 int api_hip_fail(const char* what, hipError_t e);

@@ -32,6 +32,9 @@ def init_process_group_from_env(backend: Optional[str] = None, force: bool = Fal
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        if world > 1 and "RANK" not in os.environ:
+            # a mis-launched multi-rank job: every process would call itself rank 0 and hang in the rendezvous
+            raise KeyError("RANK is not set although WORLD_SIZE > 1 (launch with torch.distributed.run)")
         dist.init_process_group(backend=backend, rank=int(os.environ.get("RANK", "0")), world_size=world)
     return world
 

@@ -47,6 +47,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 raise ValueError("an active flag must be one float32 element on the GPU")
         self._active = dict(flags)
         self._table_key = None
+        self.prepare_state(list(flags))                      # flagged parameters are stepped on the device's say-so: state must exist
 
     # -- state: one buffer per parameter, [exp_avg | exp_avg_sq | step | 2 scratch]; the three state entries are views of it --
     def _packed_state(self, p: torch.Tensor) -> torch.Tensor:
@@ -55,6 +56,12 @@ class FusedAdamW(torch.optim.Optimizer):
         buf = st.get("_packed")
         if buf is not None and st["exp_avg"].data_ptr() == buf.data_ptr() and st["step"].data_ptr() == buf[2 * n:].data_ptr() and buf.numel() == 2 * n + 3:
             return buf
+        if p.is_cuda and torch.cuda.is_current_stream_capturing():
+            # a zero fill recorded into a graph would reset exp_avg / exp_avg_sq / step at EVERY replay (and, data-parallel,
+            # on this rank only: the replicas would drift apart silently)
+            raise _lib.MolKGNNLibraryError(
+                "FusedAdamW: optimiser state would be allocated inside a hipGraph capture -- call prepare_state() (or run "
+                "one eager step in which every parameter has a gradient) before capturing")
         new = torch.zeros(2 * n + 3, dtype=torch.float32, device=p.device)   # + step, two scratch floats of the kernels
         if "exp_avg" in st:                                  # e.g. loaded from a state_dict (ours or torch.optim.AdamW's)
             new[:n] = st["exp_avg"].reshape(-1).to(new)
@@ -66,6 +73,16 @@ class FusedAdamW(torch.optim.Optimizer):
         st["step"] = new[2 * n:2 * n + 1].view(())
         self._table_key = None
         return new
+
+    @torch.no_grad()
+    def prepare_state(self, params=None) -> None:
+        """Materialise the packed state of ``params`` (default: every parameter of every group) now, outside any capture:
+        a parameter whose gradient is absent in the eager warm-up steps -- a degree bank that this rank's warm-up batches do
+        not contain -- must not get its zero-filled state as a node of a captured graph (``_packed_state`` refuses)."""
+        for p in (params if params is not None else [q for g in self.param_groups for q in g["params"]]):
+            if p.numel():
+                _lib.require_gpu_tensor(p, "parameter")
+                self._packed_state(p)
 
     def state_dict(self):
         sd = super().state_dict()                            # the packed buffer is an implementation detail: its three views are saved

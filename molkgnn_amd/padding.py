@@ -2,15 +2,15 @@
 
 A hipGraph bakes every kernel's sizes in: atoms, atoms per degree, edges, molecules.  Batches of molecules differ in all
 of them, so a step captured on one batch cannot replay another (bench.py's headline cycles resident batches, one graph
-each).  Padding makes the sizes equal: every batch gets ONE extra padding molecule made of as many atoms of each degree
-as the batch is short of the epoch's targets, bonded among themselves (the kernels read indices, not chemistry: multiple
-bonds and self loops are fine there).  Nothing of a real molecule touches it -- the edge list stays block diagonal --
-and it cannot reach the loss:
+each).  Padding makes the sizes equal: every batch gets as many padding atoms of each degree as it is short of the
+epoch's targets, dealt to ``PAD_MOLECULES`` (64) padding molecules and bonded among themselves in chains (the kernels read
+indices, not chemistry: multiple bonds and self loops are fine there).  Nothing of a real molecule touches them -- the
+edge list stays block diagonal -- and they cannot reach the loss:
 
 * the node batch norm takes its statistics over the real atoms only (``n_valid_atoms``, read on the device:
   ``mkgnn_batchnorm_forward``'s ``n_valid_rows``);
-* the padding molecule is the last row of the graph embedding and is cut off before the head (``n_valid_molecules``),
-  so its atoms receive a zero gradient and add exactly zero to every parameter gradient.
+* the padding molecules are the last rows of the graph embedding and are cut off before the head
+  (``n_valid_molecules``), so their atoms receive a zero gradient and add exactly zero to every parameter gradient.
 
 The step then runs from static buffers: ``StaticBatch.load`` copies the next padded batch in place, the captured graph
 rebuilds degree buckets, unit bond rows and the index plan (``mkgnn_rf_*``, ``mkgnn_unit_rows8``, ``mkgnn_plan_build``:

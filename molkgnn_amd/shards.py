@@ -415,8 +415,10 @@ class ShardLoader:
         self.shards = [Shard(p) for p in self.paths]
         # fixed_shape: every batch padded on the host to the common shape of this rank's batches (padding.fixed_shape) and
         # handed over as a PackedBatch; short tail batches are dropped (the static buffers hold exactly batch_size molecules)
-        self._pinned: list = []
+        self._pinned: list = []                          # (pinned staging buffer, event of its last host-to-device copy)
         self._landing: list = []
+        self._consumed: list = []                        # per landing buffer: the consumer's stream has passed its last use
+        self._copy_stream = None
         _LOADERS.add(self)
         self.shape = None
         # compact (with fixed_shape): batches travel in the compact wire form (collate_compact) and come out as CompactBatch
@@ -435,7 +437,12 @@ class ShardLoader:
 
     def close(self) -> None:
         """Drop the pinned staging and device landing buffers (they are re-made on the next epoch)."""
-        self._pinned, self._landing = [], []
+        if self._copy_stream is not None:
+            try:
+                self._copy_stream.synchronize()          # no copy may still be reading a pinned buffer that is about to go
+            except Exception:                            # (interpreter shutdown: the runtime may be gone already)
+                pass
+        self._pinned, self._landing, self._consumed = [], [], []
 
     def plan(self) -> List[tuple]:
         """``(shard index, m0, m1)`` of this rank's batches, in order."""
@@ -469,11 +476,18 @@ class ShardLoader:
                     yield make(flat, self.shape, m1 - m0)
             return
         from concurrent.futures import ThreadPoolExecutor
-        copy_stream = torch.cuda.Stream(device=self.device)
+        # One copy stream for the loader's life, and every buffer keeps the event that guards its reuse ACROSS epochs: a
+        # pinned staging buffer the event of its last host-to-device copy, a landing buffer the event the consumer's stream
+        # recorded after its last use.  (A fresh stream and forgotten events per epoch let a new epoch's workers overwrite
+        # buffers whose copies -- or whose consumer -- of the previous epoch's tail had not run yet whenever the GPU lagged
+        # the host by a batch or more.)
+        if getattr(self, "_copy_stream", None) is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        copy_stream = self._copy_stream
         depth = self.prefetch + self.workers
         free: Queue = Queue()                            # pinned staging buffers with the event of their last copy
         for k in range(depth + 1):                       # (kept across epochs: pinning memory costs milliseconds)
-            free.put((self._pinned[k] if k < len(self._pinned) else None, None))
+            free.put(self._pinned[k] if k < len(self._pinned) else (None, None))
         self._pinned = []
         # fixed-shape batches land in a ring of device buffers that is allocated once: a fresh device tensor per batch
         # would have the allocator wait for (or grow past) blocks the consumer's stream has not released yet.  A landing
@@ -483,7 +497,8 @@ class ShardLoader:
         K = depth + 2
         if len(self._landing) != K:
             self._landing = [None] * K
-        consumed = [None] * K
+            self._consumed = [None] * K
+        consumed = self._consumed
 
         def stage(i, si, m0, m1):
             staging, last = free.get()
@@ -534,8 +549,7 @@ class ShardLoader:
                         if torch.is_tensor(v) and v.is_cuda:
                             v.record_stream(cur)
                 free.put((b._staging, ev))
-                if all(b._staging is not t for t in self._pinned):
-                    self._pinned.append(b._staging)
+                self._pinned = [(t, e) for t, e in self._pinned if t is not b._staging] + [(b._staging, ev)]
                 yield b
                 if slot is not None:                     # the consumer has enqueued its use of the landing buffer
                     done = torch.cuda.Event()

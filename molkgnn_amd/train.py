@@ -109,7 +109,9 @@ def configure_optimizer(model: torch.nn.Module, weight_decay: float = 0.0, lr: f
         fused = all(p.is_cuda and p.dtype == torch.float32 for p in model.parameters())
     if fused:
         from .optim import FusedAdamW     # one HIP launch for the whole model; step counters on the device (capturable)
-        return FusedAdamW(groups, lr=lr)
+        opt = FusedAdamW(groups, lr=lr)
+        opt.prepare_state()               # state exists before anything can be captured (a fill inside a graph would replay)
+        return opt
     kw = {}
     if capturable:
         kw["capturable"] = True          # step counters live on the device: the step can be replayed from a hipGraph

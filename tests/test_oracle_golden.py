@@ -192,6 +192,65 @@ def test_kernelsetconv_benchmark_shape(form):
         assert checked == 24            # 4 degrees x (3 kernel tensors + 3 score weights)
 
 
+def test_closed_form_float64_gradients_against_the_reference_and_autograd():
+    """``kernelset_gradients_f64`` (the closed-form float64 gradients the 4 096-molecule GPU test is bounded by): (1) on
+    G9 it reproduces the REFERENCE's own gradients (fp32, to fp32 accuracy) with the reference's permutation choices;
+    (2) it equals autograd through the restatement in float64 to 1e-10 on a batch with duplicated rows and a zero row
+    (the epsilon clamp); (3) every value is bounded by its sum of absolute terms, which is what the GPU test scales its
+    tolerance with."""
+    import copy
+    flat = G.load("g9_setconv_fullsize.npz")
+    b = G.batch_from(flat)
+    state = {k[len("param/"):]: torch.from_numpy(v) for k, v in flat.items() if k.startswith("param/")}
+    x = torch.from_numpy(flat["x"])
+    cot = torch.from_numpy(flat["cotangent"])
+    for last in (False, True):
+        idx = []
+        sc = O.kernelsetconv(O.kernelset_params(state), x, b, last, form="faithful", idx_out=idx)
+        assert torch.allclose(sc, torch.from_numpy(flat[f"sc_last{int(last)}"]), atol=TOL, rtol=0)
+        gx, grads, gx_abs, grads_abs = O.kernelset_gradients_f64(state, x, b, last, cot, idx)
+        assert torch.allclose(gx.float(), torch.from_numpy(flat[f"grad_last{int(last)}/x"]), atol=2e-5, rtol=1e-4)
+        assert bool((gx.abs() <= gx_abs * (1 + 1e-12)).all())
+        checked = 0
+        for name, v in grads.items():
+            key = f"grad_last{int(last)}/{name}"
+            if key in flat:
+                ref = torch.from_numpy(flat[key])
+                assert torch.allclose(v.float().reshape(ref.shape), ref, atol=2e-5, rtol=1e-4), key
+                assert bool((v.abs() <= grads_abs[name] * (1 + 1e-12)).all()), key
+                checked += 1
+            else:
+                assert v is None, key
+        assert checked == 24
+    # (2) autograd in float64 through the cos-matrix form, permutation choices forced
+    from molkgnn_amd.kernels import KernelSetConv
+    from molkgnn_amd.synthetic import make_batch
+    torch.manual_seed(0)
+    for width, last in ((28, False), (110, True)):
+        bb = make_batch(12, seed=5, duplicate_fraction=0.2)
+        layer = KernelSetConv(10, 20, 30, 50, D=3, node_attr_dim=width, edge_attr_dim=7)
+        st = {k: v.detach().clone() for k, v in layer.state_dict().items()}
+        n = bb.x.shape[0]
+        xx = torch.randn(n, width)
+        xx[3] = 0.0
+        cc = torch.randn(n, 110)
+        idx = []
+        O.kernelsetconv(O.kernelset_params(st), xx, bb, last, form="cosmat", idx_out=idx)
+        st64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in st.items()}
+        b64 = copy.copy(bb)
+        for d in range(1, 5):
+            for nm in (f"nei_edge_attr_deg{d}", f"p_focal_deg{d}", f"nei_p_deg{d}"):
+                setattr(b64, nm, getattr(bb, nm).double())
+        _, gx_a, gr_a = O.kernelset_gradients(st64, xx.double(), b64, last, cc.double(), forced_idx=idx, form="cosmat")
+        gx, gr, _, _ = O.kernelset_gradients_f64(st, xx, bb, last, cc, idx)
+        assert float((gx - gx_a).abs().max()) <= 1e-10 * max(1.0, float(gx_a.abs().max()))
+        for k, v in gr_a.items():
+            if v is None:
+                assert gr.get(k) is None, k
+            else:
+                assert float((gr[k].reshape(v.shape) - v).abs().max()) <= 1e-10 * max(1.0, float(v.abs().max())), k
+
+
 def test_fullsize_seeded_model_oracle_matches_reference():
     """G7: the full-size model (10/20/30/50, hidden 32) rebuilt from the recorded seed through the package's own
     modules (same draw order as the reference) and evaluated by the oracle: the reference's first-layer
