@@ -457,9 +457,14 @@ __device__ __forceinline__ void bn_rows(const BnArgs& a, int64_t& lo, int64_t& h
 template <int MODE>   // 0: x   1: (x - mean)^2   2: (dy, dy * xhat) -> part1, part2
 __device__ __forceinline__ void bn_block_colsum(const BnArgs& a, int CL, const float* mean, const float* invstd, float* sh) {
     const int c = threadIdx.x & (CL - 1), rsub = threadIdx.x / CL, RS = 256 / CL;
-    int64_t lo, hi;
-    bn_rows(a, lo, hi);
+    // the block's share of the rows that COUNT (not of all rows): the partial sums, and with them the statistics, are then
+    // bit for bit those of the same batch without its padding rows -- a padded batch (molkgnn_amd.padding) reproduces the
+    // unpadded forward exactly, which matters more than it looks: an ulp in x decides thousands of mathematically tied
+    // neighbour orders the other way two layers later
     const int64_t nv = bn_valid(a);
+    const int64_t per = (nv + gridDim.x - 1) / gridDim.x;
+    int64_t lo = per * blockIdx.x, hi = lo + per < nv ? lo + per : nv;
+    if (lo > hi) lo = hi;
     const bool act = c < a.C;
     const int cc = act ? c : 0;
     const float mu = (MODE >= 1) ? mean[cc] : 0.f, is = (MODE == 2) ? invstd[cc] : 0.f;
