@@ -19,7 +19,10 @@
 // contiguous 2 KB record per (tile, column tile), loaded one tile ahead); without a pre-pass (bank kernel not streamed)
 // the kernel gathers them itself through the focal ids, one tile ahead, the focal ids two.
 //
-// Covered shapes: the streamed forward's (F in (16 (KC - 1), 16 KC], exactly NS(d) = 1 / 2 / 2 / 4 column tiles).
+// Covered shapes: the streamed forward's (any F <= 112: KC = 1 .. 7 chunks; any number of kernels).  A stream's
+// NS(d) = 1 / 2 / 2 / 4 waves hold one column tile each; a degree with more column tiles is done in PASSES (one launch per
+// column part, all degrees that still have a part in it): pass 0 writes the contribution rows, every later pass adds its
+// kernels' share to them (load, add, store: fixed order, bit-reproducible).  The reference's 10 / 20 / 30 / 50 take one pass.
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -60,12 +63,14 @@ struct RowsStreamDeg {
     float* contrib; int64_t contrib_base;
     const float* coefq;      // the pre-pass's records [tile][column tile][g 16 x 16 | idx 16 x 16] (null: gather here)
     int64_t n;
-    int L, off, kpt;
+    int L, off, kpt, nct;
 };
 
 struct RowsStreamArgs {
     const float* gout; int64_t gs;
     int F, CS;
+    int FPB;                 // row pitch of the padded bank
+    int cp;                  // column part (pass) of this launch: waves hold column tiles cp * NS + role; > 0: add to the rows
     RowsStreamDeg deg[MKGNN_MAX_DEGREE];
     uint8_t grp_degree[4];
     uint16_t grp_count[4];
@@ -84,7 +89,11 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
     const int stream = wave / NS, role = wave % NS;
     const int ci = lane & 15, kq = lane >> 4;
     const int L = dg.L, kpt = dg.kpt;
-    const int ct = role;
+    const int ct = a.cp * NS + role;
+    const bool ct_ok = ct < dg.nct;                  // (past the degree's last column tile: an idle wave, zero partial tiles)
+    const int ctc = ct_ok ? ct : dg.nct - 1;
+    const bool add = a.cp > 0;
+    const int FPB = a.FPB;
     // exchange images: [stream][parity][role][atom 16][FP floats] (row-major, like the contribution rows)
     constexpr int RS = FP + 4;                  // LDS row stride (keeps the 4-byte writes of a quad off one bank, rows 16-byte aligned)
     float* const xbuf = lds + (size_t)stream * (2 * NS * 16 * RS);
@@ -106,13 +115,13 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int i = 4 * q + kq, l = ct * kpt + i;
-        const bool ok = i < kpt && l < L;
+        const bool ok = ct_ok && i < kpt && l < L;
         const int lc = ok ? l : 0;
 #pragma unroll
         for (int b = 0; b <= D; ++b)
 #pragma unroll
             for (int t = 0; t < KC; ++t) {
-                const float v = dg.padded[((size_t)b * L + lc) * FP + 16 * t + ci];
+                const float v = dg.padded[((size_t)b * L + lc) * FPB + 16 * t + ci];
                 bk[b][q][t] = ok ? v : 0.f;
             }
     }
@@ -133,7 +142,7 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
         if (records) {
             // the pre-pass (coef_prepare_kernel) has put dL/dsc (signed, zero for padding) and the permutation ids into
             // tile order: two contiguous 1 KB images per (tile, column tile), this lane's entries at atom ci, kernel 4 q + kq
-            const float* rec = dg.coefq + ((size_t)tile * NS + ct) * 512 + ci * 16 + kq;
+            const float* rec = dg.coefq + ((size_t)tile * dg.nct + ctc) * 512 + ci * 16 + kq;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 rg[q] = rec[4 * q];
@@ -146,7 +155,7 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
         const int64_t nc = n < dg.n ? n : dg.n - 1;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int l = ct * kpt + 4 * q + kq;
+            const int l = ctc * kpt + 4 * q + kq;
             const int lc = l < L ? l : L - 1;
             rg[q] = a.gout[focal * a.gs + dg.off + lc];
             ridx[q] = pair_index(dg.pair, (size_t)nc * L + lc);
@@ -166,7 +175,7 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int i = 4 * q + kq;
-            const bool ok = real && n_mine < dg.n && i < kpt && ct * kpt + i < L;
+            const bool ok = real && ct_ok && n_mine < dg.n && i < kpt && ct * kpt + i < L;
             const float g = (dg.chir && !records) ? rg[q] * (float)rch[q] : rg[q];
             cf[q] = ok ? g * ws_n : 0.f;
             ix[q] = ridx[q];
@@ -226,8 +235,11 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
 #pragma unroll
                         for (int w = 1; w < NS; ++w) v += *(const f32x4*)(img + (size_t)(w * 16 + atom) * RS + 4 * ch);
                         const int64_t nn = tile * 16 + atom;
-                        if (real && nn < dg.n)
-                            *(f32x4*)(dg.contrib + (size_t)(dg.contrib_base + nn * S1 + s) * a.CS + 4 * ch) = v;
+                        if (real && nn < dg.n) {
+                            f32x4* const dst = (f32x4*)(dg.contrib + (size_t)(dg.contrib_base + nn * S1 + s) * a.CS + 4 * ch);
+                            if (add) v += *dst;              // (a later pass: this column part's share on top of the earlier ones')
+                            *dst = v;
+                        }
                     }
                 }
             }
@@ -254,12 +266,17 @@ __global__ void __launch_bounds__(256, 2) kc_backward_rows_stream(RowsStreamArgs
 // ---------------------------------------------------------------- host ----
 bool rows_stream_supported(int d, int F, int E, int L) {
     if (d < 1 || d > 4 || L < 1) return false;
-    const int FP = mfma_padded_width(F);
-    if (!FP || F <= FP - 16) return false;
-    return (L + 15) / 16 == rs::column_tiles(d);
+    if (F < 1 || F > 112 || !mfma_padded_width(F)) return false;
+    return (L + 15) / 16 <= 8 * rs::column_tiles(d);      // (at most eight passes)
 }
 
-hipError_t launch_backward_rows_stream(const BwdArgs a4[4], const bool use[4], float* const coefq[4], hipStream_t st) {
+template <int KC> static hipError_t launch_rows_kc(const RowsStreamArgs& a, int nb, size_t lds_bytes, hipStream_t st) {
+    kc_backward_rows_stream<KC><<<nb, 256, lds_bytes, st>>>(a);
+    return hipGetLastError();
+}
+
+// one pass (column part cp) over the degrees in `use`
+static hipError_t launch_rows_pass(const BwdArgs a4[4], const bool use[4], float* const coefq[4], int cp, hipStream_t st) {
     RowsStreamArgs a;
     memset(&a, 0, sizeof(a));
     int KC = 0, ng = 0;
@@ -271,15 +288,16 @@ hipError_t launch_backward_rows_stream(const BwdArgs a4[4], const bool use[4], f
         const BwdArgs& s = a4[i];
         const int d = i + 1;
         a.gout = s.gout; a.gs = s.gs; a.F = s.F; a.CS = s.CS;
-        KC = mfma_padded_width(s.F) / 16;
+        a.FPB = mfma_padded_width(s.F); a.cp = cp;
+        KC = (s.F + 15) / 16;
         RowsStreamDeg& g = a.deg[i];
         g.sel = s.sel; g.pair = s.pair; g.chir = s.chir; g.padded = s.padded; g.mix = s.mix;
         g.contrib = s.contrib; g.contrib_base = s.contrib_base;
         g.coefq = coefq ? coefq[i] : nullptr;
         g.n = s.n; g.L = s.L; g.off = s.off;
-        const int nct = rs::column_tiles(d);
-        g.kpt = (s.L + nct - 1) / nct;
-        const int nstream = 4 / nct;
+        g.nct = (s.L + 15) / 16;
+        g.kpt = (s.L + g.nct - 1) / g.nct;
+        const int nstream = 4 / rs::column_tiles(d);
         const int64_t ntiles = (s.n + 15) / 16;
         // a wave's time per tile (units of 32 cycles): matrix instructions + per-slot exchange and stores
         cost[ng] = (d * d + 1) * 4.0 * KC + (d + 1) * 30.0 + 40.0;
@@ -333,11 +351,36 @@ hipError_t launch_backward_rows_stream(const BwdArgs a4[4], const bool use[4], f
         for (int b = 0; b < nb; ++b) a.blk_rank[b] = (uint16_t)next[a.blk_group[b]][b & 7]++;
     }
     for (int g = 0; g < ng; ++g) a.grp_count[g] = (uint16_t)count[g];
-    note_plan(1, nb, ng, tiles_of, count, nstream_of);
+    if (cp == 0) note_plan(1, nb, ng, tiles_of, count, nstream_of);
+    g_last_plan[1].launches.fetch_add(1);
     const size_t lds_bytes = (size_t)4 * 2 * 16 * (16 * KC + 4) * 4;      // NSTREAM * NS = 4 wave images of 16 rows, two parities
-    if (KC == 2) kc_backward_rows_stream<2><<<nb, 256, lds_bytes, st>>>(a);
-    else kc_backward_rows_stream<7><<<nb, 256, lds_bytes, st>>>(a);
-    return hipGetLastError();
+    switch (KC) {
+        case 1: return launch_rows_kc<1>(a, nb, lds_bytes, st);
+        case 2: return launch_rows_kc<2>(a, nb, lds_bytes, st);
+        case 3: return launch_rows_kc<3>(a, nb, lds_bytes, st);
+        case 4: return launch_rows_kc<4>(a, nb, lds_bytes, st);
+        case 5: return launch_rows_kc<5>(a, nb, lds_bytes, st);
+        case 6: return launch_rows_kc<6>(a, nb, lds_bytes, st);
+        case 7: return launch_rows_kc<7>(a, nb, lds_bytes, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_backward_rows_stream(const BwdArgs a4[4], const bool use[4], float* const coefq[4], hipStream_t st) {
+    int passes = 0;
+    for (int i = 0; i < 4; ++i)
+        if (use[i]) {
+            const int p = ((a4[i].L + 15) / 16 + rs::column_tiles(i + 1) - 1) / rs::column_tiles(i + 1);
+            if (p > passes) passes = p;
+        }
+    for (int cp = 0; cp < passes; ++cp) {
+        bool use_p[4];
+        for (int i = 0; i < 4; ++i)
+            use_p[i] = use[i] && cp * rs::column_tiles(i + 1) < (a4[i].L + 15) / 16;
+        hipError_t e = launch_rows_pass(a4, use_p, coefq, cp, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 }  // namespace mkgnn

@@ -26,7 +26,9 @@
 // targets of its edges, KernelLayer.py:119-123) where it otherwise reads the focal atom's row.
 //
 // Degree 4 splits a column tile's supports over two waves like the forward (its accumulators would not fit otherwise);
-// covered shapes are the forward's (stream_forward_supported).
+// covered shapes are the forward's (stream_forward_supported): any F <= 112 (KC = 1 .. 7 chunks), any number of kernels
+// (column parts: a degree with more column tiles than a stream's waves hold is cut into parts, each a group of blocks; all
+// parts of a degree get the same number of blocks, so part p's stream s fills its kernels' rows of slab chunk s).
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -49,14 +51,25 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N <= 63, "s_waitcnt vmcnt is a 6-bit field");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-__device__ __forceinline__ void dma16(const void* src, float* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// (SITE: one instruction offset per place that issues an LDS-DMA, so that the compiler cannot merge two of them into one
+// instruction with a phi'd -- then readfirstlane'd -- LDS base: see kgnn_fwd_stream.hip)
+#define MKGNN_DMA_CASE(SZ, O) else if constexpr (OFF == O) __builtin_amdgcn_global_load_lds(g, l, SZ, O, 0)
+template <int OFF> __device__ __forceinline__ void dma16(const void* src, float* lds_wave_base) {
+    const auto g = (const __attribute__((address_space(1))) void*)((const char*)src - OFF);
+    const auto l = (__attribute__((address_space(3))) void*)((char*)lds_wave_base - OFF);
+    if constexpr (OFF == 0) __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+    MKGNN_DMA_CASE(16, 16); MKGNN_DMA_CASE(16, 32); MKGNN_DMA_CASE(16, 48);
+    else static_assert(OFF < 0, "add the offset to the list");
 }
-__device__ __forceinline__ void dma4(const void* src, float* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+template <int OFF> __device__ __forceinline__ void dma4(const void* src, float* lds_wave_base) {
+    const auto g = (const __attribute__((address_space(1))) void*)((const char*)src - OFF);
+    const auto l = (__attribute__((address_space(3))) void*)((char*)lds_wave_base - OFF);
+    if constexpr (OFF == 0) __builtin_amdgcn_global_load_lds(g, l, 4, 0, 0);
+    MKGNN_DMA_CASE(4, 4); MKGNN_DMA_CASE(4, 8); MKGNN_DMA_CASE(4, 12);
+    else static_assert(OFF < 0, "add the offset to the list");
 }
+constexpr int SITE_ROWS = 0, SITE_BONDS = 16, SITE_COEF_G = 32, SITE_COEF_I = 48;  // dma16
+constexpr int SITE_IDS = 0, SITE_IDS4 = 4, SITE_INV = 8, SITE_INV4 = 12;            // dma4
 // an LDS dword written by DMA, read behind the compiler's back (it would drain the DMA queue in front of an ordinary
 // read that may alias a pending DMA); valid after lds_fence over the same registers
 __device__ __forceinline__ float lds_read_raw(uint32_t byte_addr) {
@@ -100,7 +113,7 @@ __host__ __device__ constexpr int lds_floats(int D, int KC) {
     const int NS = (D == 1) ? 1 : (D == 4 ? 4 : 2);
     const int RING = (D == 1) ? 2 : (D == 2 ? 3 : (D == 3 ? 4 : 5));
     const int META = 32 * (D + 1) + 128 * D;
-    const int FPC = KC == 7 ? 28 : 8;
+    const int FPC = 4 * KC;
     return (4 / NS) * (RING * 16 * FPC * 4 + 2 * META) + 4 * 512;
 }
 
@@ -219,7 +232,10 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
     using namespace bs;
     using T = Traits<D>;
     constexpr int NS = T::NS, NSTREAM = T::NSTREAM, RING = T::RING, S1 = T::S1, META = T::META;
-    constexpr int FPC = KC == 7 ? 28 : 8;                // 16-byte chunks per row in the slot image
+    constexpr int FPC = 4 * KC;                          // 16-byte chunks per row in the slot image
+    // rows of an even number of 16-float chunks are a multiple of 32 banks apart: the transposed reads below (lane = atom
+    // row kq, feature ci) would collide pairwise, so chunk c of an odd row sits at c ^ 4 (its 16-float halves swapped)
+    constexpr bool SWZ = (KC % 2 == 0);
     constexpr int RF = 4 * FPC;                          // floats per row (112 / 32)
     constexpr int SLOT = 16 * RF;                        // floats per slot image
     constexpr int NP = SLOT / 256;                       // DMA pieces per slot (7 / 2 = KC)
@@ -230,7 +246,9 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int stream = wave / NS, role = wave % NS;
     const int half = HS ? (role & 1) : 0;
-    const int ct = HS ? cp * 2 + (role >> 1) : role;
+    const int ct = HS ? cp * 2 + (role >> 1) : cp * NS + role;
+    const bool ct_ok = ct < dg.nct;                      // (past the degree's last column tile: an idle wave, zeros throughout)
+    const int ctc = ct_ok ? ct : dg.nct - 1;
     const int ci = lane & 15, kq = lane >> 4;
     const int L = dg.L, kpt = dg.kpt;
     float* const ring = lds + (size_t)stream * (RING * SLOT + 2 * META);
@@ -254,8 +272,7 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
     const uint32_t xs = (uint32_t)a.xs;
     const int F = a.F;
 
-    // DMA piece t of a slot: lane q fetches chunk (64 t + q) of the row-major 16 x FPC image.  (F <= 32: chunk c of
-    // an odd row sits at c ^ 4, which makes the transposed reads below conflict-free for 8-chunk rows too.)
+    // DMA piece t of a slot: lane q fetches chunk (64 t + q) of the row-major 16 x FPC image (SWZ: see above)
     auto issue_rows = [&](auto sdc, const float* drec, float* buf) {
         constexpr int sd = decltype(sdc)::value;
         const uint32_t ids_b = (uint32_t)(uintptr_t)(drec + 16 * sd);
@@ -270,14 +287,14 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
                     const int g = 64 * (r + NS * k) + lane;
                     const int row = g / FPC;
                     int c = g - row * FPC;
-                    if constexpr (KC == 2) c ^= (row & 1) * 4;
+                    if constexpr (SWZ) c ^= (row & 1) * 4;
                     cc[k] = c;
                     id[k] = __float_as_uint(lds_read_raw(ids_b + 4u * row));
                 });
                 static_for<0, NMINE>([&](auto kc) { lds_fence(id[decltype(kc)::value]); });
                 static_for<0, NMINE>([&](auto kc) {
                     constexpr int k = decltype(kc)::value;
-                    dma16(a.x + (id[k] * xs + (4 * cc[k] < F ? 4u * cc[k] : 0u)), buf + (r + NS * k) * 256);
+                    dma16<SITE_ROWS>(a.x + (id[k] * xs + (4 * cc[k] < F ? 4u * cc[k] : 0u)), buf + (r + NS * k) * 256);
                 });
             }
         });
@@ -286,16 +303,16 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
         if (lane < 32) {
             int64_t n = t * 16 + (lane >> 1);
             if (n >= dg.n) n = dg.n - 1;
-            dma16(dg.e_unit + ((uint32_t)(n * D + sd) * 8u + 4u * (lane & 1)), mrec + T::OFF_BOND + sd * 128);
+            dma16<SITE_BONDS>(dg.e_unit + ((uint32_t)(n * D + sd) * 8u + 4u * (lane & 1)), mrec + T::OFF_BOND + sd * 128);
         }
     };
     auto issue_ids = [&](int64_t t, float* mrec) {
         int64_t n = t * 16 + ci;
         if (n >= dg.n) n = dg.n - 1;
         const void* src = (kq < D) ? (const void*)(dg.nei + n * D + kq) : (const void*)(dg.sel + n);
-        if (S1 >= 4 || kq < S1) dma4(src, mrec);
+        if (S1 >= 4 || kq < S1) dma4<SITE_IDS>(src, mrec);
         if constexpr (S1 == 5) {
-            if (kq == 0) dma4(dg.sel + n, mrec + 64);
+            if (kq == 0) dma4<SITE_IDS4>(dg.sel + n, mrec + 64);
         }
     };
     auto issue_inv = [&](float* mrec) {                  // 1 / |x| of every slot, through the ids in the record
@@ -305,15 +322,15 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
         if constexpr (S1 == 5) id4 = __float_as_uint(lds_read_raw(rec_b + 4u * (64 + ci)));
         lds_fence(idq);
         if constexpr (S1 == 5) lds_fence(id4);
-        if (S1 >= 4 || kq < S1) dma4(a.inv + idq, mrec + T::OFF_INV);
+        if (S1 >= 4 || kq < S1) dma4<SITE_INV>(a.inv + idq, mrec + T::OFF_INV);
         if constexpr (S1 == 5) {
-            if (kq == 0) dma4(a.inv + id4, mrec + T::OFF_INV + 64);
+            if (kq == 0) dma4<SITE_INV4>(a.inv + id4, mrec + T::OFF_INV + 64);
         }
     };
     auto issue_coef = [&](int64_t t, float* cb) {        // this wave's (tile, column tile) record: two 1 KB pieces
-        const float* src = dg.coefq + ((size_t)(t * dg.nct + ct) * 512 + 4 * lane);
-        dma16(src, cb);
-        dma16(src + 256, cb + 256);
+        const float* src = dg.coefq + ((size_t)(t * dg.nct + ctc) * 512 + 4 * lane);
+        dma16<SITE_COEF_G>(src, cb);
+        dma16<SITE_COEF_I>(src + 256, cb + 256);
     };
 
     f32x4 acc[NBS][KC];                                  // gradient rows of this wave's kernels: support slots
@@ -365,7 +382,7 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
                          "+v"(raw[6]), "+v"(raw[7]) : : "memory");
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                gq[q] = real ? raw[q] : 0.f;
+                gq[q] = (real && ct_ok) ? raw[q] : 0.f;
                 iq[q] = __float_as_int(raw[4 + q]);
             }
         }
@@ -415,20 +432,17 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
                         for (int q = 0; q < 4; ++q) accE[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[b][q], eb[q], accE[b], 0, 0, 0);
                 }
                 // feature tiles: lane (k = kq, j = ci) reads row 4 q + kq, feature 16 t + ci of the slot image
-                uint32_t xl_b = rb_b + 4u * (kq * RF + ci);
-                if constexpr (KC == 2) xl_b = rb_b + 4u * (kq * RF + (ci ^ ((kq & 1) * 16)));       // (odd rows: chunk ^ 4; 16 t ^ 16 below)
+                // (row 4 q + kq is odd exactly when kq is: SWZ moves its column 16 t + ci to 16 (t ^ 1) + ci, i.e. 16 floats up
+                // for even t and down for odd t -- two per-lane bases, the offsets stay immediates)
+                const uint32_t xl_b = rb_b + 4u * (kq * RF + ci + (SWZ ? (kq & 1) * 16 : 0));
+                [[maybe_unused]] const uint32_t xl_o = rb_b + 4u * (kq * RF + ci) - (SWZ ? 4u * ((kq & 1) * 16) : 0u);
                 static_for<0, KC>([&](auto tc) {
                     constexpr int t = decltype(tc)::value;
                     float bx[4];
                     static_for<0, 4>([&](auto qc) {
                         constexpr int q = decltype(qc)::value;
-                        if constexpr (KC == 2) {
-                            // column (16 t + ci) ^ 16 (kq & 1): the xor of the 16s-bit is t ^ (kq & 1), resolved per lane
-                            const uint32_t tb = (uint32_t)(t ^ (kq & 1));
-                            bx[q] = lds_read_raw(rb_b + 4u * ((4 * q + kq) * RF + 16u * tb + ci));
-                        } else {
-                            bx[q] = lds_read_raw_at<4 * (4 * q * RF + 16 * t)>(xl_b);
-                        }
+                        if constexpr (SWZ && (t & 1)) bx[q] = lds_read_raw_at<4 * (4 * q * RF + 16 * t)>(xl_o);
+                        else bx[q] = lds_read_raw_at<4 * (4 * q * RF + 16 * t)>(xl_b);
                     });
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bx[0]), "+v"(bx[1]), "+v"(bx[2]), "+v"(bx[3]) : : "memory");
                     if constexpr (s < D) {
@@ -476,7 +490,7 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int i = kq * 4 + r, l = ct * kpt + i;
-        if (i < kpt && l < L) {
+        if (ct_ok && i < kpt && l < L) {
 #pragma unroll
             for (int t = 0; t < KC; ++t) {
                 const int f = 16 * t + ci;
@@ -521,7 +535,7 @@ void plan_backward_bank_stream(const BwdArgs a4[4], const bool use[4], const flo
     BankStreamArgs& a = out->a;
     memset(out, 0, sizeof(*out));
     int KC = 0, ng = 0, prep_blocks = 0;
-    constexpr int MG = 8;
+    constexpr int MG = FUSED_MAX_GROUPS;
     double cost[MG];
     int64_t tiles_of[MG], cap[MG];
     int nstream_of[MG], deg_of[MG];
@@ -533,20 +547,20 @@ void plan_backward_bank_stream(const BwdArgs a4[4], const bool use[4], const flo
         const int d = i + 1;
         a.x = s.x; a.xs = s.xs; a.inv = s.inv; a.gout = s.gout; a.gs = s.gs; a.F = s.F; a.E = s.E;
         a.through_nei = through_nei ? 1 : 0;
-        KC = mfma_padded_width(s.F) / 16;
+        KC = (s.F + 15) / 16;
         BankStreamDeg& g = a.deg[i];
         g.sel = s.sel; g.nei = s.nei; g.e_unit = e_unit[i]; g.pair = s.pair; g.chir = s.chir; g.mix = s.mix;
         g.coefq = coefq[i]; g.slab = s.slab; g.theta_slab = s.theta_slab;
         g.n = s.n; g.L = s.L; g.off = s.off;
-        g.nct = d == 1 ? 1 : (d == 4 ? 4 : 2);
+        g.nct = (s.L + 15) / 16;
         g.kpt = (s.L + g.nct - 1) / g.nct;
-        g.cs = d == 4 ? 2 : 1;
+        g.cs = stream_column_parts(d, s.L);
         const int64_t ntiles = (s.n + 15) / 16;
         g.prep_blk0 = prep_blocks;
         g.prep_blocks = (int)((ntiles * g.nct + PREP_RPB - 1) / PREP_RPB);
         prep_blocks += g.prep_blocks;
         ntheta_out[i] = g.prep_blocks;
-        const int nstream = d == 4 ? 1 : 4 / g.nct;
+        const int nstream = d == 1 ? 4 : (d == 4 ? 1 : 2);
         const size_t fl = (size_t)bs::lds_floats(d, KC);
         if (fl > lds_fl) lds_fl = fl;
         for (int cp = 0; cp < g.cs; ++cp) {
@@ -563,7 +577,7 @@ void plan_backward_bank_stream(const BwdArgs a4[4], const bool use[4], const flo
         }
     }
     if (ng == 0) return;
-    // block counts: greedy min-max as in the forward; the two column parts of degree 4 get the same count (they fill the
+    // block counts: greedy min-max as in the forward; the column parts of a degree get the same count (they fill the
     // same slab chunks), and a degree's streams may not outnumber its slab chunks
     auto finish = [&](int g, int blocks) {
         const int64_t streams = (int64_t)blocks * nstream_of[g];
@@ -571,10 +585,10 @@ void plan_backward_bank_stream(const BwdArgs a4[4], const bool use[4], const flo
     };
     int count[MG], nb = 0;
     for (int g = 0; g < ng; ++g) { count[g] = 1; ++nb; }
-    auto partner = [&](int g) {
-        if (deg_of[g] != 3) return -1;
-        for (int h = 0; h < ng; ++h) if (h != g && deg_of[h] == 3) return h;
-        return -1;
+    auto parts_of = [&](int g) {                         // the groups of g's degree (its column parts) grow together
+        int n = 0;
+        for (int h = 0; h < ng; ++h) if (deg_of[h] == deg_of[g]) ++n;
+        return n;
     };
     // Grid cap.  Not every wave slot of the chip: this kernel runs beside the other chain's kernels (the gather, the next
     // layer's rows kernel), which need slots to make progress at all -- 320 blocks instead of 512 is 2.5 % of the step at
@@ -590,11 +604,10 @@ void plan_backward_bank_stream(const BwdArgs a4[4], const bool use[4], const flo
             if (t > t_worst) { t_worst = t; worst = g; }
         }
         if (worst < 0) break;
-        const int p = partner(worst);
-        if (p >= 0) {
-            if (nb + 2 > max_blocks) break;
-            ++count[worst]; ++count[p]; nb += 2;
-        } else { ++count[worst]; ++nb; }
+        const int np = parts_of(worst);
+        if (nb + np > max_blocks) break;
+        for (int h = 0; h < ng; ++h) if (deg_of[h] == deg_of[worst]) ++count[h];
+        nb += np;
     }
     int given[MG] = {};
     for (int b = 0; b < nb; ++b) {
@@ -633,23 +646,33 @@ hipError_t launch_coef_prepare(const BankStreamLaunch& p, hipStream_t st) {
     return hipGetLastError();
 }
 
-hipError_t launch_backward_bank_stream(const BankStreamLaunch& p, hipStream_t st) {
-    if (p.nb == 0) return hipSuccess;
-    const int KC = p.KC;
-    const size_t lds_bytes = p.lds_bytes;
-    if (lds_bytes > 64 * 1024) {
-        static PerDeviceOnce attr_set[2];
-        const int which = KC == 2 ? 0 : 1;
-        if (const int slot = attr_set[which].pending(); slot >= 0) {
-            hipError_t e = KC == 2 ? hipFuncSetAttribute((const void*)kc_backward_bank_stream<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
-                                   : hipFuncSetAttribute((const void*)kc_backward_bank_stream<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+template <int KC> static hipError_t launch_bank_kc(const BankStreamLaunch& p, hipStream_t st) {
+    if (p.lds_bytes > 64 * 1024) {
+        static PerDeviceOnce attr_set;
+        if (const int slot = attr_set.pending(); slot >= 0) {
+            hipError_t e = hipFuncSetAttribute((const void*)kc_backward_bank_stream<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
             if (e != hipSuccess) return e;
-            attr_set[which].set(slot);
+            attr_set.set(slot);
         }
     }
-    if (KC == 2) kc_backward_bank_stream<2><<<p.nb, 256, lds_bytes, st>>>(p.a);
-    else kc_backward_bank_stream<7><<<p.nb, 256, lds_bytes, st>>>(p.a);
+    kc_backward_bank_stream<KC><<<p.nb, 256, p.lds_bytes, st>>>(p.a);
     return hipGetLastError();
+}
+
+hipError_t launch_backward_bank_stream(const BankStreamLaunch& p, hipStream_t st) {
+    if (p.nb == 0) return hipSuccess;
+    if (p.lds_bytes > 80 * 1024) return hipErrorInvalidValue;
+    g_last_plan[2].launches.fetch_add(1);
+    switch (p.KC) {
+        case 1: return launch_bank_kc<1>(p, st);
+        case 2: return launch_bank_kc<2>(p, st);
+        case 3: return launch_bank_kc<3>(p, st);
+        case 4: return launch_bank_kc<4>(p, st);
+        case 5: return launch_bank_kc<5>(p, st);
+        case 6: return launch_bank_kc<6>(p, st);
+        case 7: return launch_bank_kc<7>(p, st);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 }  // namespace mkgnn

@@ -130,6 +130,34 @@ struct ForkJoin {
     }
 };
 
+// every degree of the call that has atoms and kernels can run on the streamed rows + bank kernels (and no diagnostic
+// switch turns them off): the condition of MKGNN_BACKWARD_THROUGH_NEIGHBOURS, and of taking them for shapes round 1's
+// kernels do not cover
+static bool streamed_pair_covers(const mkgnn_kernel_bank banks[4], const mkgnn_degree_bucket buckets[4], const float* x,
+                                 int64_t x_stride, int64_t n_atoms, int F, int E) {
+    static const bool no_mfma_bwd = getenv("MKGNN_NO_MFMA_BWD") != nullptr;
+    static const char* env_bank_fused = getenv("MKGNN_BANK_FUSED");
+    static const char* env_rows_stream = getenv("MKGNN_ROWS_STREAM");
+    static const char* env_bank_stream = getenv("MKGNN_BANK_STREAM");
+    if (no_mfma_bwd || (env_bank_fused && env_bank_fused[0] == '0') || (env_rows_stream && env_rows_stream[0] == '0') ||
+        (env_bank_stream && env_bank_stream[0] == '0'))
+        return false;
+    if ((x_stride % 4) != 0 || (((uintptr_t)x) & 15) != 0) return false;        // 16-byte rows (LDS-DMA pieces)
+    bool any = false, use[4];
+    int Ls[4];
+    for (int i = 0; i < 4; ++i) {
+        const int L = banks[i].num_kernels, d = i + 1;
+        Ls[i] = L;
+        use[i] = buckets[i].count > 0 && L > 0;
+        if (!use[i]) continue;
+        any = true;
+        if ((uint64_t)buckets[i].count * (uint64_t)L >= (1ull << 32)) return false;
+        if (!(rows_stream_supported(d, F, E, L) && bank_stream_supported(d, F, E, L, n_atoms, x_stride, buckets[i].nei_edge_unit)))
+            return false;
+    }
+    return any && stream_forward_groups(Ls, use) <= FUSED_MAX_GROUPS;
+}
+
 // degree index (0..3) -> concurrency slot, most expensive bucket first (N_d * L_d * (d*d + 1))
 static void degree_slots(const mkgnn_kernel_bank banks[4], const mkgnn_degree_bucket buckets[4], int slot_of[4]) {
     double cost[4];
@@ -165,7 +193,8 @@ extern "C" {
 
 // Diagnostics (not part of the drop-in ABI; used by tests/ and tools/): grid caps of the streamed forward / rows-gradient /
 // bank-gradient kernels, 0 = default, otherwise 8..512, effective from the next launch; and the block split of the last
-// launch of each: out[3 k ..] = {blocks, fewest, most atom tiles per stream over the (degree, column part) groups}.
+// launch of each: out[3 k ..] = {blocks, fewest, most atom tiles per stream over the (degree, column part) groups}; out[9 + k] =
+// how many times streamed kernel k has been launched (forward, rows gradient, bank gradient).
 int mkgnn_debug_set_grid_caps(int32_t forward_blocks, int32_t rows_blocks, int32_t bank_blocks) {
     for (int32_t v : {forward_blocks, rows_blocks, bank_blocks})
         if (v != 0 && (v < 8 || v > FUSED_MAX_BLOCKS)) return fail("mkgnn_debug_set_grid_caps: %d outside 8..%d (0 = default)", v, FUSED_MAX_BLOCKS);
@@ -195,10 +224,11 @@ int mkgnn_debug_last_backward_ms(float out[5]) {
     }
     return 0;
 }
-int mkgnn_debug_last_plans(int32_t out[9]) {
+int mkgnn_debug_last_plans(int32_t out[12]) {
     if (!out) return fail("mkgnn_debug_last_plans: null pointer");
     for (int k = 0; k < 3; ++k) {
         out[3 * k] = g_last_plan[k].blocks.load(); out[3 * k + 1] = g_last_plan[k].min_iters.load(); out[3 * k + 2] = g_last_plan[k].max_iters.load();
+        out[9 + k] = g_last_plan[k].launches.load();        // launches of the streamed kernel since the library was loaded
     }
     return 0;
 }
@@ -445,14 +475,18 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
     // blocks each ran one after the other.
     static const bool no_mfma_bwd = getenv("MKGNN_NO_MFMA_BWD") != nullptr;     // diagnostics: A/B against the LDS rows kernel
     static const char* env_bank_fused = getenv("MKGNN_BANK_FUSED");             // diagnostics: "0" = one launch per degree
+    static const char* env_rows_stream = getenv("MKGNN_ROWS_STREAM");
+    static const char* env_bank_stream = getenv("MKGNN_BANK_STREAM");
+    // the streamed pair (rows + bank kernels on the pre-pass's records) covers every degree of this call: then it runs
+    // whatever round 1's kernels would have said about the shapes
+    const bool stream_all = streamed_pair_covers(banks, buckets, x, x_stride, n_atoms, F, E) && !force_generic;
     bool fuse_bank = !(env_bank_fused && env_bank_fused[0] == '0') && !no_mfma_bwd && !force_generic;
-    for (int i = 0; i < 4 && fuse_bank; ++i)
+    for (int i = 0; i < 4 && fuse_bank && !stream_all; ++i)
         if (buckets[i].count > 0 && L[i] > 0 &&
             !(lds_backward_supported(i + 1, F, E, L[i], x_stride, x) && mfma_backward_supported(i + 1, F, E, L[i], x_stride, x, n_atoms)))
             fuse_bank = false;
     // the x-gradient rows of all degrees in one streamed launch when every degree's shape is covered (kgnn_bwd_rows_stream.hip);
     // MKGNN_ROWS_STREAM=0: one kc_backward_rows_mfma launch per degree (diagnostics)
-    static const char* env_rows_stream = getenv("MKGNN_ROWS_STREAM");
     // (without grad_x -- a layer whose input carries no gradient -- nobody reads contribution rows: with the bank gradients
     // fused, which then sum the score-weight partials themselves, no rows kernel is launched at all)
     bool rows_streamed = fuse_bank && !(env_rows_stream && env_rows_stream[0] == '0');
@@ -494,12 +528,12 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
             if (e != hipSuccess) return hip_fail("contribution rows memset", e);
         }
         if (a.n > 0 && L[i] > 0) {
-            const bool fast_ok = lds_backward_supported(d, F, E, L[i], x_stride, x);
-            if (force_fast && !(fast_ok && mfma_backward_supported(d, F, E, L[i], x_stride, x, n_atoms)))
+            const bool fast_ok = stream_all || lds_backward_supported(d, F, E, L[i], x_stride, x);
+            if (force_fast && !stream_all && !(fast_ok && mfma_backward_supported(d, F, E, L[i], x_stride, x, n_atoms)))
                 return fail("%s: the fast kernels do not cover degree %d with F=%d E=%d L=%d stride=%lld", who, d, F, E, L[i],
                             (long long)x_stride);
             if (fast_ok && !force_generic) {
-                const bool rows_mfma = !no_mfma_bwd && mfma_backward_supported(d, F, E, L[i], x_stride, x, n_atoms);
+                const bool rows_mfma = stream_all || (!no_mfma_bwd && mfma_backward_supported(d, F, E, L[i], x_stride, x, n_atoms));
                 hipStream_t st_rows = dst, st_bank = dst;
                 if (fj.two_way && !rows_mfma) bank_on_main = true;
                 if (fj.two_way && rows_mfma) {
@@ -532,8 +566,12 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
     const bool any_bank = bank_use[0] || bank_use[1] || bank_use[2] || bank_use[3];
     // the reference's bank shapes: the streamed MFMA kernel (kgnn_bwd_stream.hip); anything else: the LDS / VALU one.
     // MKGNN_BANK_STREAM=0: A/B switch (diagnostics)
-    static const char* env_bank_stream = getenv("MKGNN_BANK_STREAM");
     bool streamed = any_bank && !(env_bank_stream && env_bank_stream[0] == '0');
+    {   // (the streamed launches hold FUSED_MAX_GROUPS (degree, column part) groups)
+        int Lu[4];
+        for (int i = 0; i < 4; ++i) Lu[i] = L[i];
+        if (stream_forward_groups(Lu, bank_use) > FUSED_MAX_GROUPS) streamed = false;
+    }
     const float* e_unit4[4]; float* coefq4[4];
     {
         size_t coef_off = w.coefq_off[0];
@@ -616,23 +654,7 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
 int mkgnn_backward_streams(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE], const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],
                            const float* x, int64_t x_stride, int64_t n_atoms, int32_t F, int32_t E) {
     if (!banks || !buckets) return 0;
-    static const bool no_mfma_bwd = getenv("MKGNN_NO_MFMA_BWD") != nullptr;
-    static const char* env_bank_fused = getenv("MKGNN_BANK_FUSED");
-    static const char* env_rows_stream = getenv("MKGNN_ROWS_STREAM");
-    static const char* env_bank_stream = getenv("MKGNN_BANK_STREAM");
-    if (no_mfma_bwd || (env_bank_fused && env_bank_fused[0] == '0') || (env_rows_stream && env_rows_stream[0] == '0') ||
-        (env_bank_stream && env_bank_stream[0] == '0'))
-        return 0;
-    bool any = false;
-    for (int i = 0; i < 4; ++i) {
-        const int L = banks[i].num_kernels, d = i + 1;
-        if (buckets[i].count <= 0 || L <= 0) continue;
-        any = true;
-        if (!(lds_backward_supported(d, F, E, L, x_stride, x) && mfma_backward_supported(d, F, E, L, x_stride, x, n_atoms) &&
-              rows_stream_supported(d, F, E, L) && bank_stream_supported(d, F, E, L, n_atoms, x_stride, buckets[i].nei_edge_unit)))
-            return 0;
-    }
-    return any ? 1 : 0;
+    return streamed_pair_covers(banks, buckets, x, x_stride, n_atoms, F, E) ? 1 : 0;
 }
 
 int mkgnn_backward_join(void* stream) {

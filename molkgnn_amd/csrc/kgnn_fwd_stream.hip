@@ -33,9 +33,12 @@
 // of ~140 MB).  At the end of a tile the two waves swap, through LDS, the half of the 4 x 4 cosine matrices the other
 // needs: each finishes two of a lane's four atoms, with the same summation order as everywhere else.
 //
-// Covered shapes: F in (16 (KC - 1), 16 KC] for KC = 2 or 7 (the reference's 28 and 110), E <= 8, 16-byte aligned rows,
-// and per degree exactly NS(d) = 1 / 2 / 2 / 4 column tiles (L <= 16 / 17..32 / 17..32 / 49..64: the reference's
-// 10 / 20 / 30 / 50).  Other shapes keep kc_forward_fused.
+// Covered shapes (round 3): any F <= 112 (KC = ceil(F / 16) = 1 .. 7 sixteen-float chunks per row; the reference's 28 and
+// 110 are KC = 2 and 7, its (5, 10, 15, 25) banks give F = 55 = KC 4, a (1, 1, 1, 1) sweep F = 4 = KC 1), E <= 8, 16-byte
+// aligned rows, and ANY number of kernels per degree: a stream of NS(d) = 1 / 2 / 2 / 4 waves holds CT(d) = 1 / 2 / 2 / 2
+// column tiles (<= 16 kernels each), a degree with more column tiles than that is cut into column PARTS, each its own
+// group of blocks that gathers the atom rows again (what degree 4's 50 kernels always did); a part with fewer column
+// tiles than CT(d) leaves a wave with nothing but zeros to multiply.  The reference's 10 / 20 / 30 / 50 fill every wave.
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -59,7 +62,8 @@ template <int D> struct StreamTraits {
                          OFF_BOND = OFF_EQ + 16, META = OFF_BOND + 128 * D;
 };
 
-int stream_column_tiles(int d) { return d == 1 ? 1 : (d == 4 ? 4 : 2); }
+int stream_tiles_per_part(int d) { return d == 1 ? 1 : 2; }          // CT(d): column tiles a stream's waves hold
+int stream_column_parts(int d, int L) { return ((L + 15) / 16 + stream_tiles_per_part(d) - 1) / stream_tiles_per_part(d); }
 
 __host__ __device__ constexpr int stream_lds_floats(int D, int KC) {
     const int NS = (D == 1) ? 1 : (D == 4 ? 4 : 2);
@@ -117,15 +121,32 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// 16 / 4 bytes per lane, global -> LDS, asynchronous; the LDS address is the wave-uniform base + lane * size
-__device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// 16 / 4 bytes per lane, global -> LDS, asynchronous; the LDS address is the wave-uniform base + lane * size.
+//
+// SITE: every place that issues an LDS-DMA gets its own instruction offset (subtracted from both pointers first: the
+// hardware adds it to the memory address AND to the LDS address -- tools/probes/dma_offset_probe.hip -- so nothing
+// moves).  It is there for the compiler: two calls of the intrinsic that differ only in their (run-time) pointers are
+// "the same instruction" to LLVM's code sinking, which then merges a DMA under `if (lane < 32)` with the unconditional one
+// that follows it into ONE instruction whose LDS base is a phi of the two destinations -- made wave-uniform by
+// v_readfirstlane, i.e. half of the lanes' rows landed in the other site's record (KC = 1, where a slot is a single piece
+// next to the bond rows' DMA: every neighbour slot's upper k-lanes were wrong).  Immediate operands cannot be phi'd.
+#define MKGNN_DMA_CASE(SZ, O) else if constexpr (OFF == O) __builtin_amdgcn_global_load_lds(g, l, SZ, O, 0)
+template <int OFF> __device__ __forceinline__ void dma16(const float* src, float* lds_wave_base) {
+    const auto g = (const __attribute__((address_space(1))) void*)((const char*)src - OFF);
+    const auto l = (__attribute__((address_space(3))) void*)((char*)lds_wave_base - OFF);
+    if constexpr (OFF == 0) __builtin_amdgcn_global_load_lds(g, l, 16, 0, 0);
+    MKGNN_DMA_CASE(16, 16); MKGNN_DMA_CASE(16, 32); MKGNN_DMA_CASE(16, 48);
+    else static_assert(OFF < 0, "add the offset to the list");
 }
-__device__ __forceinline__ void dma4(const void* src, float* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 4, 0, 0);
+template <int OFF> __device__ __forceinline__ void dma4(const void* src, float* lds_wave_base) {
+    const auto g = (const __attribute__((address_space(1))) void*)((const char*)src - OFF);
+    const auto l = (__attribute__((address_space(3))) void*)((char*)lds_wave_base - OFF);
+    if constexpr (OFF == 0) __builtin_amdgcn_global_load_lds(g, l, 4, 0, 0);
+    MKGNN_DMA_CASE(4, 4); MKGNN_DMA_CASE(4, 8); MKGNN_DMA_CASE(4, 12); MKGNN_DMA_CASE(4, 16); MKGNN_DMA_CASE(4, 20);
+    else static_assert(OFF < 0, "add the offset to the list");
 }
+constexpr int SITE_ROWS = 0, SITE_BONDS = 16;                                     // dma16
+constexpr int SITE_IDS = 0, SITE_IDS4 = 4, SITE_INV = 8, SITE_INV4 = 12, SITE_SIGN = 16, SITE_EQ = 20;      // dma4
 
 // DMA pieces of one row slot that wave `role` (0 .. NS-1) of a stream issues: t = role, role + NS, ...
 template <int KC, int NS> constexpr int pieces_of(int role) { return (KC - role + NS - 1) / NS; }
@@ -153,7 +174,6 @@ template <int D, int KC>
 __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDeg& dg, const int cp, const int rank, const int count, float* lds) {
     using T = StreamTraits<D>;
     constexpr int NS = T::NS, NSTREAM = T::NSTREAM, RING = T::RING, S1 = T::S1, META = T::META;
-    constexpr int FP = 16 * KC;
     constexpr int SLOT = KC * 256;                       // floats per row-slot buffer (KC pieces of 1 KB)
     // HS ("half supports", degree 4): wave = (column tile of the block, support half); see the file comment
     constexpr bool HS = (D == 4);
@@ -164,11 +184,12 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
     const unsigned long long t_start = a.stamps ? __builtin_readcyclecounter() : 0ull;
     const int stream = wave / NS, role = wave % NS;
     const int half = HS ? (role & 1) : 0;                // supports 2 * half, 2 * half + 1
-    const int ct = HS ? cp * 2 + (role >> 1) : role;     // this wave's column tile (the degree has exactly NS: host-checked)
+    const int ct = HS ? cp * 2 + (role >> 1) : cp * NS + role;     // this wave's column tile (past the degree's last: an idle wave)
     const int ci = lane & 15, kq = lane >> 4;
     const int L = dg.L, kpt = dg.kpt;
     const int lcol = ct * kpt + ci;
-    const bool col_ok = (ci < kpt) && (lcol < L);
+    const bool col_ok = (ct < dg.nct) && (ci < kpt) && (lcol < L);
+    const int FPB = a.FPB;                               // row pitch of the padded bank (>= FP)
     const bool do_chir = (D == 4) && a.last;
     float* const ring = lds + (size_t)stream * (RING * SLOT + 2 * META);
     float* const meta = ring + RING * SLOT;
@@ -200,7 +221,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
             const bool zero = !col_ok || (HS && bl == NBS && half != 0);      // (the second half multiplies no centre)
 #pragma unroll
             for (int t = 0; t < KC; ++t) {
-                f32x4 v = *(const f32x4*)(dg.padded + ((size_t)b * L + l) * FP + 16 * t + 4 * kq);
+                f32x4 v = *(const f32x4*)(dg.padded + ((size_t)b * L + l) * FPB + 16 * t + 4 * kq);
                 if (zero) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 bk[bl][t] = v;
             }
@@ -235,7 +256,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
                         // a chunk entirely beyond the row's width is fetched from the row's first chunk instead (in
                         // bounds, finite whenever the row is) and masked to zero where it is used
                         const uint32_t off = (t == KC - 1 && 16 * t + 4 * kq >= F) ? idsD[sd] * xs : rowbase + 16u * t;
-                        dma16(a.x + off, buf + t * 256);
+                        dma16<SITE_ROWS>(a.x + off, buf + t * 256);
                     }
                 });
             }
@@ -246,7 +267,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
         if (lane < 32) {
             int64_t n = t * 16 + (lane >> 1);
             if (n >= dg.n) n = dg.n - 1;
-            dma16(dg.e_unit + ((uint32_t)(n * D + sd) * 8u + 4u * (lane & 1)), mrec + T::OFF_BOND + sd * 128);
+            dma16<SITE_BONDS>(dg.e_unit + ((uint32_t)(n * D + sd) * 8u + 4u * (lane & 1)), mrec + T::OFF_BOND + sd * 128);
         }
     };
     // lane q -> (slot q >> 4, atom q & 15): slots 0..3 in one 64-dword piece, slot 4 (degree 4's focal row) in a second
@@ -254,25 +275,25 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
         int64_t n = t * 16 + ci;
         if (n >= dg.n) n = dg.n - 1;
         const void* src = (kq < D) ? (const void*)(dg.nei + n * D + kq) : (const void*)(dg.sel + n);    // kq == D: the focal id (D < 4)
-        if (S1 >= 4 || kq < S1) dma4(src, mrec);
+        if (S1 >= 4 || kq < S1) dma4<SITE_IDS>(src, mrec);
         if constexpr (S1 == 5) {
-            if (kq == 0) dma4(dg.sel + n, mrec + 64);
+            if (kq == 0) dma4<SITE_IDS4>(dg.sel + n, mrec + 64);
         }
     };
     auto issue_meta = [&](int64_t t, float* mrec) {      // 1 / |x| of every slot (through the ids in the record), flags, focal ids
         // lane q needs the id of (slot q >> 4, atom q & 15): read it from the record (idsD[kq] would be a run-time index)
         const uint32_t idq = __float_as_uint(mrec[16 * ((S1 >= 4 || kq < S1) ? kq : 0) + ci]);
-        if (S1 >= 4 || kq < S1) dma4(a.inv + idq, mrec + T::OFF_INV);
+        if (S1 >= 4 || kq < S1) dma4<SITE_INV>(a.inv + idq, mrec + T::OFF_INV);
         if constexpr (S1 == 5) {
-            if (kq == 0) dma4(a.inv + idsD[4], mrec + T::OFF_INV + 64);
+            if (kq == 0) dma4<SITE_INV4>(a.inv + idsD[4], mrec + T::OFF_INV + 64);
         }
         if constexpr (D == 4) {                          // 16 flag bytes each = 4 dwords
             if (lane < 4) {
                 int64_t n4 = t * 4 + lane;               // dword index; the last tile may be partial: clamp into the array
                 const int64_t hi = (dg.n + 3) / 4 - 1;
                 n4 = n4 > hi ? hi : n4;
-                dma4(sgp + 4 * n4, mrec + T::OFF_SIGN);
-                dma4(eqp + 4 * n4, mrec + T::OFF_EQ);
+                dma4<SITE_SIGN>(sgp + 4 * n4, mrec + T::OFF_SIGN);
+                dma4<SITE_EQ>(eqp + 4 * n4, mrec + T::OFF_EQ);
             }
         }
         if (kq == 0) mrec[T::OFF_FOCAL + ci] = __uint_as_float(idsD[D]);     // (a plain LDS store from registers)
@@ -349,6 +370,9 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
             MKGNN_PHASE(0);
             // ---- retire: the batch of the NEXT step must have landed; the RING - 2 batches issued after it may stay in
             // flight (vmcnt retires in order).  (A 2-buffer ring has just one batch in flight.)
+#ifdef MKGNN_EXP_WAIT0                                   // (diagnostic build: every wait drains the DMA queue)
+            wait_vmcnt<0>();
+#else
             if constexpr (RING == 2) {
                 wait_vmcnt<0>();
             } else {
@@ -358,6 +382,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
                     if (role == r) wait_vmcnt<n_young>();
                 });
             }
+#endif
             MKGNN_PHASE(1);
             if constexpr (NS > 1) __builtin_amdgcn_s_barrier();
             MKGNN_PHASE(2);
@@ -570,14 +595,14 @@ __global__ void __launch_bounds__(256, MKGNN_EXP_OCC) kc_forward_stream(FusedFwd
 // ---------------------------------------------------------------- host ----
 bool stream_forward_supported(int d, int F, int E, int L, int64_t n_atoms, int64_t x_stride, int64_t out_stride, const float* e_unit) {
     if (d < 1 || d > 4 || L < 1 || E < 1 || E > 8 || !e_unit) return false;
-    const int FP = mfma_padded_width(F);
-    if (!FP || F <= FP - 16) return false;               // only the last 16-float chunk of a row may be partial
+    if (F < 1 || F > 112 || !mfma_padded_width(F)) return false;     // KC = ceil(F / 16) <= 7 chunks; only the last may be partial
     if (d == 4 && L * 12 > 768) return false;            // the chirality sign table's LDS slot
+    if (stream_column_parts(d, L) > 8) return false;     // (a bank of > 128 / 256 kernels of one degree: the generic kernels)
     // 32-bit element offsets into x, out and the unit bond rows
     if ((uint64_t)n_atoms * (uint64_t)x_stride >= (1ull << 30) || (uint64_t)n_atoms * (uint64_t)out_stride >= (1ull << 30) ||
         (uint64_t)n_atoms * 32ull >= (1ull << 30))
         return false;
-    return (L + 15) / 16 == stream_column_tiles(d);
+    return true;
 }
 
 __global__ void unit_rows8_kernel(const float* __restrict__ in, int64_t n, int E, float* __restrict__ out) {
@@ -608,7 +633,7 @@ hipError_t launch_unit_rows8(const float* in, int64_t n_rows, int E, float* out,
 // groups interleaved over the block ids, the blocks of a group that share an XCD (block id mod 8) given adjacent runs
 // of tiles (the buckets are sorted by atom id: what one group gathers as neighbours another gathers as focal rows).
 static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nblocks_out) {
-    constexpr int MG = 8;                               // groups: degrees 1-3 one each, degree 4 two (its column parts)
+    constexpr int MG = FUSED_MAX_GROUPS;                // groups = (degree, column part); launch_forward_stream checks the total
     double cost[MG];
     int64_t tiles_of[MG], cap[MG];
     int nstream_of[MG], ng = 0;
@@ -617,10 +642,10 @@ static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nbloc
         if (!use[i]) continue;
         FusedDeg& g = a.deg[i];
         const int d = i + 1;
-        g.nct = stream_column_tiles(d);
+        g.nct = (g.L + 15) / 16;
         g.kpt = (g.L + g.nct - 1) / g.nct;
-        g.cs = (d == 4) ? 2 : 1; g.nloc = g.nct / g.cs; g.ics = g.nloc;
-        const int nstream = (d == 4) ? 1 : 4 / g.nct;
+        g.cs = stream_column_parts(d, g.L); g.nloc = stream_tiles_per_part(d); g.ics = g.nloc;
+        const int nstream = (d == 1) ? 4 : (d == 4 ? 1 : 2);     // streams per 4-wave block (NSTREAM of the degree's body)
         const int64_t ntiles = (g.n + 15) / 16;
         const size_t fl = (size_t)stream_lds_floats(d, KC);
         if (fl > lds_floats) lds_floats = fl;
@@ -628,6 +653,7 @@ static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nbloc
             // what a wave takes per tile, everything included (multiply, DMA issue, waits, epilogue), in units of 32
             // cycles -- measured with tools/stream_stamps.py at two waves per SIMD and all groups resident (F = 110, batch
             // 4096: 10.2 k / 15.2 k / 27.3 k / 33.8 k cycles for degree 1..4), scaled with the chunk count for F <= 32
+            // (other chunk counts: interpolated)
             static double calib7[4] = {319.0, 475.0, 853.0, 1056.0}, calib2[4] = {200.0, 260.0, 420.0, 560.0};
             static const bool env_read = [] {            // diagnostics: MKGNN_STREAM_COST="c1,c2,c3,c4" (applies to both widths)
                 if (const char* e = getenv("MKGNN_STREAM_COST")) {
@@ -638,7 +664,8 @@ static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nbloc
                 return true;
             }();
             (void)env_read;
-            cost[ng] = KC == 7 ? calib7[i] : calib2[i];
+            cost[ng] = calib2[i] + (calib7[i] - calib2[i]) * (KC - 2) / 5.0;
+            if (ng >= MG) { *nblocks_out = -1; return 0; }
             tiles_of[ng] = ntiles;
             cap[ng] = (ntiles + nstream - 1) / nstream;
             nstream_of[ng] = nstream;
@@ -698,25 +725,45 @@ static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nbloc
 static unsigned long long* g_stream_stamps = nullptr;
 extern "C" int mkgnn_debug_set_stream_stamps(void* device_ptr) { g_stream_stamps = (unsigned long long*)device_ptr; return 0; }
 
+// groups (degree, column part) a streamed launch over these degrees needs (budget: FUSED_MAX_GROUPS)
+int stream_forward_groups(const int L[4], const bool use[4]) {
+    int n = 0;
+    for (int i = 0; i < 4; ++i) if (use[i]) n += stream_column_parts(i + 1, L[i]);
+    return n;
+}
+
+template <int KC> static hipError_t launch_stream_kc(const FusedFwdArgs& a, int nb, size_t lds_bytes, hipStream_t st) {
+    if (lds_bytes > 64 * 1024) {                         // (two such blocks still fit a CU's 160 KB)
+        static PerDeviceOnce attr_set;
+        if (const int slot = attr_set.pending(); slot >= 0) {
+            hipError_t e = hipFuncSetAttribute((const void*)kc_forward_stream<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            if (e != hipSuccess) return e;
+            attr_set.set(slot);
+        }
+    }
+    kc_forward_stream<KC><<<nb, 256, lds_bytes, st>>>(a);
+    return hipGetLastError();
+}
+
 hipError_t launch_forward_stream(FusedFwdArgs& a, const bool use[4], hipStream_t st) {
-    const int KC = mfma_padded_width(a.F) / 16;
+    const int KC = (a.F + 15) / 16;
     a.stamps = g_stream_stamps;
+    a.FPB = mfma_padded_width(a.F);
     int nb = 0;
     const size_t lds_bytes = plan_stream(a, use, KC, &nb);
     if (nb == 0) return hipSuccess;
-    if (lds_bytes > 64 * 1024) {                         // (two such blocks still fit a CU's 160 KB)
-        static PerDeviceOnce attr_set[2];
-        const int which = KC == 2 ? 0 : 1;
-        if (const int slot = attr_set[which].pending(); slot >= 0) {
-            hipError_t e = KC == 2 ? hipFuncSetAttribute((const void*)kc_forward_stream<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024)
-                                   : hipFuncSetAttribute((const void*)kc_forward_stream<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-            if (e != hipSuccess) return e;
-            attr_set[which].set(slot);
-        }
+    if (nb < 0 || lds_bytes > 80 * 1024) return hipErrorInvalidValue;     // (the caller checks stream_forward_groups first)
+    g_last_plan[0].launches.fetch_add(1);
+    switch (KC) {
+        case 1: return launch_stream_kc<1>(a, nb, lds_bytes, st);
+        case 2: return launch_stream_kc<2>(a, nb, lds_bytes, st);
+        case 3: return launch_stream_kc<3>(a, nb, lds_bytes, st);
+        case 4: return launch_stream_kc<4>(a, nb, lds_bytes, st);
+        case 5: return launch_stream_kc<5>(a, nb, lds_bytes, st);
+        case 6: return launch_stream_kc<6>(a, nb, lds_bytes, st);
+        case 7: return launch_stream_kc<7>(a, nb, lds_bytes, st);
+        default: return hipErrorInvalidValue;
     }
-    if (KC == 2) kc_forward_stream<2><<<nb, 256, lds_bytes, st>>>(a);
-    else kc_forward_stream<7><<<nb, 256, lds_bytes, st>>>(a);
-    return hipGetLastError();
 }
 
 }  // namespace mkgnn

@@ -60,6 +60,7 @@ struct FusedFwdArgs {
     int K, F, E, last;
     int64_t n_atoms;
     int bf16;                                // node-feature dot products with bf16 operands (variant 3)
+    int FPB;                                 // row pitch (floats) of the padded bank copies (streamed kernel; = mfma_padded_width(F))
     FusedDeg deg[MKGNN_MAX_DEGREE];
     uint8_t grp_degree[FUSED_MAX_GROUPS];   // group -> degree index (0..3)
     uint8_t grp_cp[FUSED_MAX_GROUPS];       // group -> column part
@@ -106,6 +107,9 @@ hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t 
 // kgnn_fwd_stream.hip: bank in registers, atom rows streamed through LDS by DMA (the reference's shapes)
 bool stream_forward_supported(int d, int F, int E, int L, int64_t n_atoms, int64_t x_stride, int64_t out_stride, const float* e_unit);
 hipError_t launch_forward_stream(FusedFwdArgs& a, const bool use[4], hipStream_t st);
+int stream_tiles_per_part(int d);
+int stream_column_parts(int d, int L);
+int stream_forward_groups(const int L[4], const bool use[4]);
 hipError_t launch_unit_rows8(const float* in, int64_t n_rows, int E, float* out, hipStream_t st);
 hipError_t launch_backward_generic(int d, const BwdArgs& a, hipStream_t st);
 struct BankReduceAllArgs { BankReduceArgs deg[4]; int blk_start[4]; };
@@ -135,9 +139,9 @@ struct BankStreamArgs {
     int F, E;
     int through_nei;         // gout is the gradient of h = propagate(out): d out[n, l] = sum over n's neighbours of gout[nei, l]
     BankStreamDeg deg[MKGNN_MAX_DEGREE];
-    uint8_t grp_degree[8];
-    uint8_t grp_cp[8];
-    uint16_t grp_count[8];
+    uint8_t grp_degree[FUSED_MAX_GROUPS];
+    uint8_t grp_cp[FUSED_MAX_GROUPS];
+    uint16_t grp_count[FUSED_MAX_GROUPS];
     uint8_t blk_group[FUSED_MAX_BLOCKS];
     uint16_t blk_rank[FUSED_MAX_BLOCKS];
 };
@@ -193,7 +197,7 @@ struct PerDeviceOnce {
 // benchmark at oracle-sized batches -- and what the last launch of each kernel was split into.
 struct GridCaps { std::atomic<int> fwd{0}, rows{0}, bank{0}; };
 extern GridCaps g_grid_caps;
-struct PlanInfo { std::atomic<int> blocks{0}, min_iters{0}, max_iters{0}; };
+struct PlanInfo { std::atomic<int> blocks{0}, min_iters{0}, max_iters{0}, launches{0}; };
 extern PlanInfo g_last_plan[3];              // 0 forward, 1 rows gradient, 2 bank gradient
 inline int grid_cap(const std::atomic<int>& cap, int dflt) {
     const int c = cap.load(std::memory_order_relaxed);

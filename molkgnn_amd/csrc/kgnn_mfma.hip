@@ -702,6 +702,16 @@ hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t 
         use_bank[i] = use[i] && !use_stream[i];
         any_bank = any_bank || use_bank[i];
     }
+    {   // the streamed launch holds FUSED_MAX_GROUPS (degree, column part) groups: very wide banks go to the LDS-bank kernel, widest first
+        int Ls[4];
+        for (int i = 0; i < 4; ++i) Ls[i] = a.deg[i].L;
+        while (stream_forward_groups(Ls, use_stream) > FUSED_MAX_GROUPS) {
+            int big = -1;
+            for (int i = 0; i < 4; ++i)
+                if (use_stream[i] && (big < 0 || stream_column_parts(i + 1, Ls[i]) > stream_column_parts(big + 1, Ls[big]))) big = i;
+            use_stream[big] = false; use_bank[big] = true; any_bank = true;
+        }
+    }
     if (g_time_fused.load()) (void)hipEventRecord(g_ev0, st);
     {
         FusedFwdArgs s = a;

@@ -307,3 +307,33 @@ def test_torch_library_shim_loads_and_registers_its_operators():
     assert int(ops.abi_version()) == _lib.ABI_VERSION
     for name in ("kernelsetconv_forward", "kernelsetconv_backward", "backward_join"):
         assert hasattr(torch.ops.molkgnn, name)
+
+
+def test_no_lds_dma_site_was_merged_by_the_compiler(tmp_path):
+    """The LDS base of an LDS-DMA (M0) is wave-uniform by construction in the streamed kernels.  LLVM's code sinking once
+    merged the DMA of a ``if (lane < 32)`` region with the unconditional one behind it into ONE instruction whose LDS base
+    was a phi of two destinations, made uniform by ``v_readfirstlane`` -- half of the lanes' rows landed in the other site's
+    record (round 3, KC = 1; csrc/kgnn_fwd_stream.hip, ``SITE``).  Every site now carries its own immediate offset, which
+    cannot be phi'd; this test compiles the two kernels that issue such DMAs to ISA and checks that no M0 write is fed by a
+    ``v_readfirstlane``."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc is not available")
+    csrc = os.path.join(REPO, "molkgnn_amd", "csrc")
+    procs = []
+    for name in ("kgnn_fwd_stream", "kgnn_bwd_stream"):
+        out = str(tmp_path / f"{name}.s")
+        procs.append((name, out, subprocess.Popen(
+            [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", "-Wno-unused-command-line-argument",
+             os.path.join(csrc, name + ".hip"), "-o", out], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)))
+    for name, out, pr in procs:
+        _, err = pr.communicate(timeout=900)
+        assert pr.returncode == 0, err.decode()[-2000:]
+        text = open(out).read()
+        n_dma = len(re.findall(r"global_load_lds_dword", text))
+        assert n_dma > 100, (name, n_dma)                     # (the kernels are in there)
+        merged = re.findall(r"v_readfirstlane_b32 (s\d+), v\d+\n(?:[^\n]*\n){0,2}?\s*s_mov_b32 m0, \1\b", text)
+        assert not merged, (name, len(merged))
