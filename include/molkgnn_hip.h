@@ -362,6 +362,17 @@ int mkgnn_bce_head_dropout_backward(const float* emb, int64_t emb_stride, int64_
                                     float* grad_emb, int64_t grad_emb_stride, float* grad_weight, float* grad_bias,
                                     void* workspace, size_t workspace_bytes, void* stream);
 
+/* Forward of mkgnn_bce_head_dropout_forward AND the gradients of mkgnn_bce_head_dropout_backward for d loss = 1 in one
+ * pass (two launches instead of four): the loss ends the graph, so its own gradient is 1 in a training step, and
+ * d loss / d pred of a row needs only that row's pred.  grad_emb [n_rows, H] (may be NULL), grad_weight [H], grad_bias [1]
+ * (may be NULL) are fully overwritten with the gradients a backward call with *grad_loss == 1 would give, bit for bit.
+ * A caller whose d loss is something else scales them.  Same workspace, same dropout generator protocol. */
+int mkgnn_bce_head_fused(const float* emb, int64_t emb_stride, int64_t n_rows, int32_t H,
+                         const float* weight, const float* bias, const float* target, float dropout_p,
+                         int64_t* rng_state, int64_t* rng_used, float* pred, float* loss,
+                         float* grad_emb, int64_t grad_emb_stride, float* grad_weight, float* grad_bias,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* AdamW step over all trainable tensors of the model in one launch (reference model.py:368-385: torch.optim.AdamW,
  * two parameter groups -- kernel banks without weight decay).  Per tensor: param / grad [numel] fp32 contiguous,
  * state [2 * numel + 3] = exp_avg, exp_avg_sq, step count (as a float, advanced by this call), two scratch floats.  Per group: the

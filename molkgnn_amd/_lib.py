@@ -70,7 +70,7 @@ EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn
            "mkgnn_batchnorm_backward", "mkgnn_bce_head_workspace_bytes", "mkgnn_bce_head_forward",
            "mkgnn_bce_head_backward", "mkgnn_rf_workspace_bytes", "mkgnn_rf_count", "mkgnn_rf_fill", "mkgnn_adamw_step",
            "mkgnn_bce_head_dropout_forward", "mkgnn_bce_head_dropout_backward", "mkgnn_segment_sum_block_rows",
-           "mkgnn_plan_workspace_bytes", "mkgnn_plan_build", "mkgnn_backward_join", "mkgnn_backward_streams", "mkgnn_bank_prepare", "mkgnn_expand_batch")
+           "mkgnn_plan_workspace_bytes", "mkgnn_plan_build", "mkgnn_backward_join", "mkgnn_backward_streams", "mkgnn_bank_prepare", "mkgnn_expand_batch", "mkgnn_bce_head_fused")
 
 _lib: Optional[C.CDLL] = None
 TORCH_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libmolkgnn_torch.so")
@@ -162,6 +162,8 @@ def load() -> C.CDLL:
     lib.mkgnn_bce_head_dropout_forward.argtypes = [P, I64, I64, I32, P, P, P, C.c_float, P, P, P, P, P, C.c_size_t, P]
     lib.mkgnn_bce_head_dropout_backward.restype = C.c_int
     lib.mkgnn_bce_head_dropout_backward.argtypes = [P, I64, I64, I32, P, P, P, P, C.c_float, P, P, I64, P, P, P, C.c_size_t, P]
+    lib.mkgnn_bce_head_fused.restype = C.c_int
+    lib.mkgnn_bce_head_fused.argtypes = [P, I64, I64, I32, P, P, P, C.c_float, P, P, P, P, P, I64, P, P, P, C.c_size_t, P]
     lib.mkgnn_bce_head_workspace_bytes.restype = C.c_size_t
     lib.mkgnn_bce_head_workspace_bytes.argtypes = [I64, I32]
     lib.mkgnn_rf_workspace_bytes.restype = C.c_size_t

@@ -871,6 +871,126 @@ __global__ void __launch_bounds__(256) bce_head_backward_final_kernel(HeadArgs a
     }
 }
 
+// ---- forward AND the gradients for d loss = 1 in one pass (mkgnn_bce_head_fused): the loss is the end of the graph, its
+// own gradient is 1 in every training step, and d loss / d pred = (sigmoid(pred) - y) / B needs nothing but the row's pred --
+// so the block that computes a row's pred also writes its row of grad_emb and adds to its partials of grad_weight /
+// grad_bias; ONE final kernel sums the loss and the gradient partials.  Two launches where forward + backward took four
+// (the four are kept: a caller whose d loss is not 1 scales these, or runs the separate backward).
+// partial row of a block: [dW[0..H) | db | loss]
+__global__ void __launch_bounds__(256) bce_head_fused_kernel(HeadArgs a) {
+    __shared__ float red[8][33];
+    __shared__ float redb[8], redl[8];
+    const int t = threadIdx.x, h = t & 31, g = t >> 5;
+    const float bias = a.b ? a.b[0] : 0.f;
+    const int PW = a.H + 2;
+    constexpr int NP = HEAD_ROWS / 8;
+    float xv[NP], yv[NP], ks0[NP], dv[NP];
+    const float w0 = h < a.H ? a.w[h] : 0.f;
+    const bool drop = a.drop_p > 0.f;
+    const uint64_t seed = drop ? (uint64_t)a.rng[0] : 0, offset = drop ? (uint64_t)a.rng[1] : 0;
+    const float invB = 1.f / (float)a.B;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int64_t i = (int64_t)blockIdx.x * HEAD_ROWS + k * 8 + g;
+        const int64_t ic = i < a.B ? i : a.B - 1;
+        xv[k] = a.emb[ic * a.es + (h < a.H ? h : 0)];
+        yv[k] = a.y[ic];
+    }
+    float ls = 0.f, db = 0.f;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int64_t i = (int64_t)blockIdx.x * HEAD_ROWS + k * 8 + g;
+        const int64_t ic = i < a.B ? i : a.B - 1;
+        ks0[k] = drop ? keep_scale_of(seed, offset, (uint64_t)ic * a.H + (h < a.H ? h : 0), a.drop_p) : 1.f;
+        float x = h < a.H ? xv[k] * w0 : 0.f;
+        if (drop) x *= ks0[k];
+        for (int h0 = 32; h0 < a.H; h0 += 32)                   // (wider embeddings: the rare path)
+            if (h0 + h < a.H) {
+                float e = a.emb[ic * a.es + h0 + h];
+                if (drop) e *= keep_scale_of(seed, offset, (uint64_t)ic * a.H + h0 + h, a.drop_p);
+                x = fmaf(e, a.w[h0 + h], x);
+            }
+        x = half_wave_sum(x) + bias;                            // (the xor tree leaves the sum in every lane of the row)
+        dv[k] = i < a.B ? invB * (1.f / (1.f + expf(-x)) - yv[k]) : 0.f;
+        if (h == 0 && i < a.B) {
+            a.pred[i] = x;
+            ls += fmaxf(x, 0.f) - x * yv[k] + log1pf(expf(-fabsf(x)));   // torch's stable form
+            db += dv[k];
+        }
+    }
+    for (int h0 = 0; h0 < a.H; h0 += 32) {
+        const int hh = h0 + h;
+        const bool ok = hh < a.H;
+        const float wv = ok ? a.w[hh] : 0.f;
+        float dw = 0.f;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int64_t i = (int64_t)blockIdx.x * HEAD_ROWS + k * 8 + g;
+            if (i < a.B && ok) {
+                float e = xv[k], ks = ks0[k];
+                if (h0 > 0) {
+                    e = a.emb[i * a.es + hh];
+                    ks = drop ? keep_scale_of(seed, offset, (uint64_t)i * a.H + hh, a.drop_p) : 1.f;
+                }
+                dw = fmaf(dv[k], e * ks, dw);
+                if (a.gemb) a.gemb[i * a.ges + hh] = dv[k] * wv * ks;
+            }
+        }
+        red[g][h] = dw;
+        __syncthreads();
+        if (g == 0 && ok) {
+            float p = 0.f;
+            for (int k = 0; k < 8; ++k) p += red[k][h];
+            a.partial[(size_t)blockIdx.x * PW + hh] = p;
+        }
+        __syncthreads();
+    }
+    if (h == 0) { redb[g] = db; redl[g] = ls; }
+    __syncthreads();
+    if (t == 0) {
+        float p = 0.f, q = 0.f;
+        for (int k = 0; k < 8; ++k) { p += redb[k]; q += redl[k]; }
+        a.partial[(size_t)blockIdx.x * PW + a.H] = p;
+        a.partial[(size_t)blockIdx.x * PW + a.H + 1] = q;
+    }
+}
+
+// columns of the block partials (dW, db, loss), four row parts per column, eight loads in flight; fixed order; advances
+// the dropout generator
+__global__ void __launch_bounds__(256) bce_head_fused_final_kernel(HeadArgs a, int nb) {
+    __shared__ float fin[4][64];
+    const int t = threadIdx.x;
+    const int PW = a.H + 2;
+    const float* part = a.partial;
+    for (int c0 = 0; c0 < PW; c0 += 64) {
+        const int c = c0 + (t & 63), pr = t >> 6;
+        float tot = 0.f;
+        if (c < PW) {
+            for (int bk = pr; bk < nb; bk += 32) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = part[(size_t)(bk + 4 * u < nb ? bk + 4 * u : bk) * PW + c];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (bk + 4 * u < nb) tot += v[u];
+            }
+        }
+        fin[pr][t & 63] = tot;
+        __syncthreads();
+        if (pr == 0 && c < PW) {
+            const float r = (fin[0][t] + fin[1][t]) + (fin[2][t] + fin[3][t]);
+            if (c < a.H) a.gw[c] = r;
+            else if (c == a.H) { if (a.gb) a.gb[0] = r; }
+            else a.loss[0] = r / (float)a.B;
+        }
+        __syncthreads();
+    }
+    if (t == 0 && a.drop_p > 0.f) {
+        const int64_t seed = a.rng[0], offset = a.rng[1];
+        a.rng_used[0] = seed; a.rng_used[1] = offset;
+        a.rng[1] = offset + 1;
+    }
+}
+
 }  // namespace mkgnn
 
 using namespace mkgnn;
@@ -1082,7 +1202,31 @@ int mkgnn_batchnorm_backward(const float* grad_out, int64_t grad_out_stride, con
 
 size_t mkgnn_bce_head_workspace_bytes(int64_t n_rows, int32_t H) {
     if (n_rows < 1 || H < 1) return 0;
-    return 16 + (size_t)((n_rows + HEAD_ROWS - 1) / HEAD_ROWS) * (H + 1) * 4;
+    return 16 + (size_t)((n_rows + HEAD_ROWS - 1) / HEAD_ROWS) * (H + 2) * 4;
+}
+
+int mkgnn_bce_head_fused(const float* emb, int64_t emb_stride, int64_t n_rows, int32_t H, const float* weight, const float* bias,
+                         const float* target, float dropout_p, int64_t* rng_state, int64_t* rng_used, float* pred, float* loss,
+                         float* grad_emb, int64_t grad_emb_stride, float* grad_weight, float* grad_bias, void* ws,
+                         size_t ws_bytes, void* stream) {
+    const char* who = "mkgnn_bce_head_fused";
+    if (n_rows < 1 || H < 1 || emb_stride < H) return api_fail("%s: bad shape", who);
+    if (!emb || !weight || !target || !pred || !loss || !grad_weight) return api_fail("%s: null pointer", who);
+    if (grad_emb && grad_emb_stride < H) return api_fail("%s: bad grad_emb stride", who);
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return api_fail("%s: dropout probability %g outside [0, 1)", who, dropout_p);
+    if (dropout_p > 0.f && (!rng_state || !rng_used)) return api_fail("%s: dropout needs rng_state and rng_used", who);
+    HeadArgs a{};
+    if (!ws || ws_bytes < mkgnn_bce_head_workspace_bytes(n_rows, H) || ((uintptr_t)ws & 3))
+        return api_fail("%s: workspace too small or misaligned", who);
+    a.partial = (float*)((char*)ws + 16);
+    a.emb = emb; a.es = emb_stride; a.B = n_rows; a.H = H; a.w = weight; a.b = bias; a.y = target; a.pred = pred; a.loss = loss;
+    a.gemb = grad_emb; a.ges = grad_emb_stride; a.gw = grad_weight; a.gb = grad_bias;
+    a.drop_p = dropout_p; a.rng = rng_state; a.rng_used = rng_used;
+    const int nblk = (int)((n_rows + HEAD_ROWS - 1) / HEAD_ROWS);
+    bce_head_fused_kernel<<<nblk, 256, 0, (hipStream_t)stream>>>(a);
+    bce_head_fused_final_kernel<<<1, 256, 0, (hipStream_t)stream>>>(a, nblk);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : api_hip_fail(who, e);
 }
 
 static int head_ws(const char* who, int64_t n_rows, int32_t H, void* ws, size_t ws_bytes, HeadArgs& a) {

@@ -14,6 +14,8 @@ from __future__ import annotations
 import weakref
 from typing import Optional
 
+import os
+
 import torch
 
 from . import _lib
@@ -270,6 +272,8 @@ def _head_workspace(dev, nbytes: int) -> torch.Tensor:
 
 
 _HEAD_RNG: dict = {}
+# MKGNN_SPLIT_HEAD=1 (diagnostics): the head's forward and backward as separate launches (two each) even in a training step
+_SPLIT_HEAD = os.environ.get("MKGNN_SPLIT_HEAD") == "1"
 
 
 def head_rng_state(dev) -> torch.Tensor:
@@ -292,6 +296,16 @@ def reset_head_rng(dev=None, seed=None) -> None:
             _HEAD_RNG[k] = torch.tensor([int(seed), 0], dtype=torch.int64, device=torch.device(k))
 
 
+_UNIT_SEEDS: set = set()
+
+
+def register_unit_gradient(one: torch.Tensor) -> None:
+    """Tell the head that ``one`` is a resident tensor holding 1.0 which seeds ``backward`` (``train.backward`` does):
+    when the loss's incoming gradient IS that tensor, the gradients the fused forward already wrote are the answer and the
+    backward launches nothing.  Any other incoming gradient scales them."""
+    _UNIT_SEEDS.add((one.data_ptr(), str(one.device)))
+
+
 class _BceHeadFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, emb, weight, bias, target, p_drop, n_rows):
@@ -306,6 +320,25 @@ class _BceHeadFn(torch.autograd.Function):
         loss = torch.empty((), dtype=torch.float32, device=dev)
         rng = head_rng_state(dev) if p_drop > 0.0 else None
         used = torch.empty(2, dtype=torch.int64, device=dev) if p_drop > 0.0 else None
+        ctx.unit = None
+        if any(ctx.needs_input_grad[:3]) and not _SPLIT_HEAD:
+            # a training step: forward and the gradients for d loss = 1 in the same two launches (mkgnn_bce_head_fused)
+            gemb = None
+            if ctx.needs_input_grad[0]:
+                gemb = torch.empty((ctx.rows_total, H), dtype=torch.float32, device=dev)
+                if ctx.rows_total > B:               # rows beyond B (padding molecules) get a zero gradient
+                    gemb[B:].zero_()
+            gw = torch.empty(H, dtype=torch.float32, device=dev)
+            gb = torch.empty(1, dtype=torch.float32, device=dev) if bias is not None else None
+            with torch.cuda.device(dev):
+                ws = _head_workspace(dev, int(lib.mkgnn_bce_head_workspace_bytes(B, H)))
+                _lib.check(lib.mkgnn_bce_head_fused(
+                    emb.data_ptr(), _stride0(emb), B, H, w.data_ptr(), _lib.ptr(bias), y.data_ptr(), float(p_drop),
+                    _lib.ptr(rng), _lib.ptr(used), pred.data_ptr(), loss.data_ptr(), _lib.ptr(gemb), H, gw.data_ptr(),
+                    _lib.ptr(gb), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "mkgnn_bce_head_fused")
+            ctx.unit = (gemb, gw, gb)
+            ctx.wshape = weight.shape
+            return loss
         with torch.cuda.device(dev):
             nbytes = int(lib.mkgnn_bce_head_workspace_bytes(B, H))
             ws = _head_workspace(dev, nbytes)
@@ -321,6 +354,15 @@ class _BceHeadFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_loss):
+        if ctx.unit is not None:
+            gemb, gw, gb = ctx.unit
+            ctx.unit = None
+            if (grad_loss.data_ptr(), str(grad_loss.device)) not in _UNIT_SEEDS:     # d loss is not the registered 1: scale
+                gl = grad_loss.reshape(()).float()
+                gemb = None if gemb is None else gemb * gl
+                gw = gw * gl
+                gb = None if gb is None else gb * gl
+            return gemb, gw.reshape(ctx.wshape), gb, None, None, None
         lib = _lib.load()
         emb, w, y, pred, used = ctx.saved_tensors
         B, H = y.numel(), emb.shape[1]

@@ -78,6 +78,8 @@ def backward(loss: torch.Tensor) -> None:
             one = None                        # (first use inside a capture: let autograd make its own this once)
         else:
             one = _ONES[key] = torch.ones((), dtype=loss.dtype, device=loss.device)
+            from .readout import register_unit_gradient
+            register_unit_gradient(one)       # the head's fused forward has d loss = 1 gradients ready: nothing to launch
     with deferred_bank_gradients():
         if one is not None and loss.dim() == 0:
             loss.backward(one)

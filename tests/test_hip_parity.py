@@ -521,6 +521,42 @@ def test_bce_head_loss_matches_torch(B, H):
         assert torch.allclose(a, w, atol=1e-7, rtol=2e-5), float((a - w).abs().max())
 
 
+@pytest.mark.parametrize("B,H,p", [(4096, 32, 0.25), (37, 5, 0.0), (300, 40, 0.5)])
+def test_fused_head_gives_the_separate_backward_bit_for_bit(B, H, p, monkeypatch):
+    """mkgnn_bce_head_fused (forward + the gradients for d loss = 1 in the same two launches): the same loss (to the last
+    bit or two) and the same gradients, bit for bit, as the separate forward and backward launches -- seeded through train.backward (the registered
+    ones tensor: the backward launches nothing) and through an arbitrary upstream gradient (scaled)."""
+    from molkgnn_amd import readout as R
+    from molkgnn_amd.train import backward
+    dev = _dev()
+    torch.manual_seed(B + H)
+    ffn = torch.nn.Linear(H, 1).to(dev)
+    emb0 = torch.randn(B + 3, H, device=dev) * 2
+    y = (torch.rand(B, device=dev) < 0.3).long()
+
+    def run(split, scale):
+        monkeypatch.setattr(R, "_SPLIT_HEAD", split)
+        R.reset_head_rng(dev, seed=1234)
+        emb = emb0.clone().requires_grad_(True)
+        ffn.zero_grad(set_to_none=True)
+        loss = R.bce_head_loss(emb, ffn, y, dropout_p=p, n_rows=B)
+        if scale is None:
+            backward(loss)
+        else:
+            (loss * scale).backward()
+        torch.cuda.synchronize()
+        return loss.detach().clone(), emb.grad.clone(), ffn.weight.grad.clone(), ffn.bias.grad.clone()
+
+    for scale in (None, 1.7):
+        a, c = run(True, scale), run(False, scale)
+        assert abs(float(a[0]) - float(c[0])) <= 1e-6 * abs(float(c[0]))      # (the two final kernels sum the block partials in different fixed orders)
+        if scale is None:
+            assert all(torch.equal(u, v) for u, v in zip(a[1:], c[1:]))
+        else:                                   # (g * 1.7 after the sum against 1.7 folded into every term)
+            assert all(float((u - v).abs().max()) <= 2e-6 * float(v.abs().max()) for u, v in zip(a[1:], c[1:]))
+        assert float(a[1][B:].abs().max()) == 0.0 and float(c[1][B:].abs().max()) == 0.0
+
+
 def _oracle_check_both_variants(layer, state, cpu_batch, plan, x_cpu, store, width, last, cot_cpu, dev, what):
     """Forward (two-part tie criterion) and every gradient of the generic AND of the fast kernels against the oracle
     replayed with that variant's own permutation choices: no HIP-vs-HIP comparison, no skipped gradient checks."""
