@@ -31,6 +31,10 @@
 
 #include "kgnn_launch.h"
 
+#ifndef MKGNN_ROWS_RS_PAD                    // (A/B builds: make VARIANT=rspad0 EXTRA=-DMKGNN_ROWS_RS_PAD=0 is a linear image)
+#define MKGNN_ROWS_RS_PAD 4
+#endif
+
 namespace mkgnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -95,7 +99,14 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
     const bool add = a.cp > 0;
     const int FPB = a.FPB;
     // exchange images: [stream][parity][role][atom 16][FP floats] (row-major, like the contribution rows)
-    constexpr int RS = FP + 4;                  // LDS row stride (keeps the 4-byte writes of a quad off one bank, rows 16-byte aligned)
+    // LDS row stride: FP + 4 floats keeps the 4-byte writes of a quad (rows 4 kq + r) on different banks.  The finishing pass
+    // reads 16-byte chunks: a ds_read_b128 is served in four fixed 16-lane groups, each of which tiles the 64 banks when its
+    // lanes read consecutive chunks OF ONE ROW -- so a half-wave takes one row (lanes 28..31 of the half idle), whatever the
+    // stride.  (Round 2 ran 64 consecutive chunks of the padded image through every instruction: three of the four groups
+    // straddled a row's pad chunk and hit a busy bank, 40 % of the kernel's LDS cycles were conflict cycles; a linear image
+    // without padding moved the conflicts to the writes instead, 2.2 M conflict cycles of 5.7 M.  Neither changes the
+    // kernel's time -- 72.4 / 72.8 us: the exchange is ~4 % of its wave cycles.)
+    constexpr int RS = FP + MKGNN_ROWS_RS_PAD;
     float* const xbuf = lds + (size_t)stream * (2 * NS * 16 * RS);
 
     const int64_t ntiles = (dg.n + 15) / 16;
@@ -223,14 +234,15 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
             {
                 constexpr int APW = 16 / NS;             // atoms this wave finishes
                 constexpr int CPR = FP / 4;              // 16-byte chunks per row
+                static_assert(CPR <= 32, "a half-wave finishes one row per pass");
                 const float* const img = xbuf + (size_t)(par * NS * 16) * RS;
                 const int F4 = (a.F + 3) / 4;            // chunks that hold row data (CS = F rounded up to 4: the row's own padding)
+                const int ch = lane & 31, hw = lane >> 5;
 #pragma unroll
-                for (int c0 = 0; c0 < APW * CPR; c0 += 64) {
-                    const int c = c0 + lane;
-                    const int al = c / CPR, ch = c - al * CPR;       // atom (local), chunk
+                for (int a0 = 0; a0 < APW; a0 += 2) {
+                    const int al = a0 + hw;              // (APW = 16 / 8 / 4: always even)
                     const int atom = role * APW + al;
-                    if (c < APW * CPR && ch < F4) {
+                    if (ch < F4 && ch < CPR) {
                         f32x4 v = *(const f32x4*)(img + (size_t)atom * RS + 4 * ch);
 #pragma unroll
                         for (int w = 1; w < NS; ++w) v += *(const f32x4*)(img + (size_t)(w * 16 + atom) * RS + 4 * ch);
@@ -353,7 +365,7 @@ static hipError_t launch_rows_pass(const BwdArgs a4[4], const bool use[4], float
     for (int g = 0; g < ng; ++g) a.grp_count[g] = (uint16_t)count[g];
     if (cp == 0) note_plan(1, nb, ng, tiles_of, count, nstream_of);
     g_last_plan[1].launches.fetch_add(1);
-    const size_t lds_bytes = (size_t)4 * 2 * 16 * (16 * KC + 4) * 4;      // NSTREAM * NS = 4 wave images of 16 rows, two parities
+    const size_t lds_bytes = (size_t)4 * 2 * 16 * (16 * KC + MKGNN_ROWS_RS_PAD) * 4;      // NSTREAM * NS = 4 wave images of 16 rows, two parities
     switch (KC) {
         case 1: return launch_rows_kc<1>(a, nb, lds_bytes, st);
         case 2: return launch_rows_kc<2>(a, nb, lds_bytes, st);
