@@ -234,12 +234,14 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
             {
                 constexpr int APW = 16 / NS;             // atoms this wave finishes
                 constexpr int CPR = FP / 4;              // 16-byte chunks per row
-                static_assert(CPR <= 32, "a half-wave finishes one row per pass");
+                static_assert(CPR <= 64, "at most one wave per row");
                 const float* const img = xbuf + (size_t)(par * NS * 16) * RS;
                 const int F4 = (a.F + 3) / 4;            // chunks that hold row data (CS = F rounded up to 4: the row's own padding)
-                const int ch = lane & 31, hw = lane >> 5;
+                // (rows of more than 32 chunks, KC > 8: a whole wave per row)
+                constexpr int RPI = CPR <= 32 ? 2 : 1;   // rows per wave-instruction
+                const int ch = RPI == 2 ? (lane & 31) : lane, hw = RPI == 2 ? (lane >> 5) : 0;
 #pragma unroll
-                for (int a0 = 0; a0 < APW; a0 += 2) {
+                for (int a0 = 0; a0 < APW; a0 += RPI) {
                     const int al = a0 + hw;              // (APW = 16 / 8 / 4: always even)
                     const int atom = role * APW + al;
                     if (ch < F4 && ch < CPR) {
@@ -261,7 +263,7 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
 }
 
 template <int KC>
-__global__ void __launch_bounds__(256, 2) kc_backward_rows_stream(RowsStreamArgs a) {
+__global__ void __launch_bounds__(256, (KC >= 8 ? 1 : 2)) kc_backward_rows_stream(RowsStreamArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int grp = a.blk_group[blockIdx.x];
     const int rank = a.blk_rank[blockIdx.x];
@@ -278,11 +280,19 @@ __global__ void __launch_bounds__(256, 2) kc_backward_rows_stream(RowsStreamArgs
 // ---------------------------------------------------------------- host ----
 bool rows_stream_supported(int d, int F, int E, int L) {
     if (d < 1 || d > 4 || L < 1) return false;
-    if (F < 1 || F > 112 || !mfma_padded_width(F)) return false;
+    if (F < 1 || F > STREAM_MAX_F || !bank_pitch(F)) return false;
     return (L + 15) / 16 <= 8 * rs::column_tiles(d);      // (at most eight passes)
 }
 
 template <int KC> static hipError_t launch_rows_kc(const RowsStreamArgs& a, int nb, size_t lds_bytes, hipStream_t st) {
+    if (lds_bytes > 64 * 1024) {
+        static PerDeviceOnce attr_set;
+        if (const int slot = attr_set.pending(); slot >= 0) {
+            hipError_t e = hipFuncSetAttribute((const void*)kc_backward_rows_stream<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            if (e != hipSuccess) return e;
+            attr_set.set(slot);
+        }
+    }
     kc_backward_rows_stream<KC><<<nb, 256, lds_bytes, st>>>(a);
     return hipGetLastError();
 }
@@ -300,7 +310,7 @@ static hipError_t launch_rows_pass(const BwdArgs a4[4], const bool use[4], float
         const BwdArgs& s = a4[i];
         const int d = i + 1;
         a.gout = s.gout; a.gs = s.gs; a.F = s.F; a.CS = s.CS;
-        a.FPB = mfma_padded_width(s.F); a.cp = cp;
+        a.FPB = bank_pitch(s.F); a.cp = cp;
         KC = (s.F + 15) / 16;
         RowsStreamDeg& g = a.deg[i];
         g.sel = s.sel; g.pair = s.pair; g.chir = s.chir; g.padded = s.padded; g.mix = s.mix;
@@ -374,6 +384,9 @@ static hipError_t launch_rows_pass(const BwdArgs a4[4], const bool use[4], float
         case 5: return launch_rows_kc<5>(a, nb, lds_bytes, st);
         case 6: return launch_rows_kc<6>(a, nb, lds_bytes, st);
         case 7: return launch_rows_kc<7>(a, nb, lds_bytes, st);
+        case 8: return launch_rows_kc<8>(a, nb, lds_bytes, st);
+        case 9: return launch_rows_kc<9>(a, nb, lds_bytes, st);
+        case 10: return launch_rows_kc<10>(a, nb, lds_bytes, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -509,7 +509,7 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
 }
 
 template <int KC>
-__global__ void __launch_bounds__(256, 2) kc_backward_bank_stream(BankStreamArgs a) {
+__global__ void __launch_bounds__(256, (KC >= 8 ? 1 : 2)) kc_backward_bank_stream(BankStreamArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int grp = a.blk_group[blockIdx.x];
     const int rank = a.blk_rank[blockIdx.x];
@@ -650,7 +650,8 @@ template <int KC> static hipError_t launch_bank_kc(const BankStreamLaunch& p, hi
     if (p.lds_bytes > 64 * 1024) {
         static PerDeviceOnce attr_set;
         if (const int slot = attr_set.pending(); slot >= 0) {
-            hipError_t e = hipFuncSetAttribute((const void*)kc_backward_bank_stream<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            hipError_t e = hipFuncSetAttribute((const void*)kc_backward_bank_stream<KC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (KC >= 8 ? 128 : 80) * 1024);
             if (e != hipSuccess) return e;
             attr_set.set(slot);
         }
@@ -661,7 +662,7 @@ template <int KC> static hipError_t launch_bank_kc(const BankStreamLaunch& p, hi
 
 hipError_t launch_backward_bank_stream(const BankStreamLaunch& p, hipStream_t st) {
     if (p.nb == 0) return hipSuccess;
-    if (p.lds_bytes > 80 * 1024) return hipErrorInvalidValue;
+    if (p.lds_bytes > (size_t)(p.KC >= 8 ? 128 : 80) * 1024) return hipErrorInvalidValue;
     g_last_plan[2].launches.fetch_add(1);
     switch (p.KC) {
         case 1: return launch_bank_kc<1>(p, st);
@@ -671,6 +672,9 @@ hipError_t launch_backward_bank_stream(const BankStreamLaunch& p, hipStream_t st
         case 5: return launch_bank_kc<5>(p, st);
         case 6: return launch_bank_kc<6>(p, st);
         case 7: return launch_bank_kc<7>(p, st);
+        case 8: return launch_bank_kc<8>(p, st);
+        case 9: return launch_bank_kc<9>(p, st);
+        case 10: return launch_bank_kc<10>(p, st);
         default: return hipErrorInvalidValue;
     }
 }

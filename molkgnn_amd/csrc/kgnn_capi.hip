@@ -158,6 +158,11 @@ static bool streamed_pair_covers(const mkgnn_kernel_bank banks[4], const mkgnn_d
     return any && stream_forward_groups(Ls, use) <= FUSED_MAX_GROUPS;
 }
 
+static bool fwd_stream_enabled() {              // MKGNN_FWD_STREAM=0: round 1's forward kernel (diagnostics)
+    static const char* env_stream = getenv("MKGNN_FWD_STREAM");
+    return !(env_stream && env_stream[0] == '0');
+}
+
 // degree index (0..3) -> concurrency slot, most expensive bucket first (N_d * L_d * (d*d + 1))
 static void degree_slots(const mkgnn_kernel_bank banks[4], const mkgnn_degree_bucket buckets[4], int slot_of[4]) {
     double cost[4];
@@ -371,8 +376,12 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
     for (int i = 0; i < 4; ++i) {
         // (the fused kernel indexes the saved planes [3, N_d, L] with 32-bit offsets)
         const bool small = (uint64_t)buckets[i].count * (uint64_t)L[i] < (1ull << 32);     // (pair offsets are 32-bit)
-        fuse[i] = buckets[i].count > 0 && L[i] > 0 && variant != 1 && aligned && small && mfma_forward_supported(i + 1, F, E, L[i]);
-        groups[i] = fuse[i] ? fused_group_count(i + 1, F, L[i]) : 0;
+        // (rows wider than round 1's kernels take, F > 112: only the streamed kernel, so only the exact-fp32 variants)
+        const bool old_ok = mfma_forward_supported(i + 1, F, E, L[i]);
+        const bool stream_only = !old_ok && variant != 3 && fwd_stream_enabled() &&
+                                 stream_forward_supported(i + 1, F, E, L[i], n_atoms, x_stride, out_stride, buckets[i].nei_edge_unit);
+        fuse[i] = buckets[i].count > 0 && L[i] > 0 && variant != 1 && aligned && small && (old_ok || stream_only);
+        groups[i] = (fuse[i] && old_ok) ? fused_group_count(i + 1, F, L[i]) : 0;
         total_groups += groups[i];
     }
     while (total_groups > FUSED_MAX_GROUPS) {

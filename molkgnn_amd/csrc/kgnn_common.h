@@ -139,6 +139,13 @@ struct BankLayout {
 
 // Feature width the MFMA kernels pad to (0 = shape not covered by them).
 __host__ __device__ static inline int mfma_padded_width(int F) { return F <= 32 ? 32 : (F <= 112 ? 112 : 0); }
+// Row pitch of the padded bank copies (BankLayout::padded): round 1's kernels' width where they apply, whole 16-float
+// chunks up to STREAM_MAX_F for the streamed kernels (KC = ceil(F / 16) <= 10 chunks: the (16, 32, 48, 64) banks' 160-wide
+// N-hop rows), 0 = no padded copy.
+constexpr int STREAM_MAX_F = 160;
+__host__ __device__ static inline int bank_pitch(int F) {
+    return F <= 112 ? mfma_padded_width(F) : (F <= STREAM_MAX_F ? (F + 15) / 16 * 16 : 0);
+}
 
 struct WorkspaceLayout {
     BankLayout bank[MKGNN_MAX_DEGREE];
@@ -181,7 +188,7 @@ static inline WorkspaceLayout make_layout(const int32_t L[MKGNN_MAX_DEGREE], int
         b.iedg = off; off = align_up(off + l * d * 4);
         b.chir = off; off = align_up(off + l * 12);
         b.mix = off;  off = align_up(off + 16);
-        const int FP = mfma_padded_width(F);
+        const int FP = bank_pitch(F);
         b.padded = off;      off = align_up(off + (size_t)(d + 1) * l * FP * 4);
         b.edge_padded = off; off = align_up(off + (size_t)d * l * 8 * 4);
         b.end = off;

@@ -33,8 +33,9 @@
 // of ~140 MB).  At the end of a tile the two waves swap, through LDS, the half of the 4 x 4 cosine matrices the other
 // needs: each finishes two of a lane's four atoms, with the same summation order as everywhere else.
 //
-// Covered shapes (round 3): any F <= 112 (KC = ceil(F / 16) = 1 .. 7 sixteen-float chunks per row; the reference's 28 and
-// 110 are KC = 2 and 7, its (5, 10, 15, 25) banks give F = 55 = KC 4, a (1, 1, 1, 1) sweep F = 4 = KC 1), E <= 8, 16-byte
+// Covered shapes (round 3): any F <= 160 (KC = ceil(F / 16) = 1 .. 10 sixteen-float chunks per row; the reference's 28 and
+// 110 are KC = 2 and 7, its (5, 10, 15, 25) banks give F = 55 = KC 4, a (1, 1, 1, 1) sweep F = 4 = KC 1, (16, 32, 48, 64) banks
+// F = 160 = KC 10; from KC = 8 on the bank needs more than half the register file: one wave per SIMD), E <= 8, 16-byte
 // aligned rows, and ANY number of kernels per degree: a stream of NS(d) = 1 / 2 / 2 / 4 waves holds CT(d) = 1 / 2 / 2 / 2
 // column tiles (<= 16 kernels each), a degree with more column tiles than that is cut into column PARTS, each its own
 // group of blocks that gathers the atom rows again (what degree 4's 50 kernels always did); a part with fewer column
@@ -572,8 +573,9 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
 #ifndef MKGNN_EXP_OCC
 #define MKGNN_EXP_OCC 2
 #endif
+// (KC >= 8, rows of 113 .. 160 floats: the bank alone is up to 160 registers -- one wave per SIMD, 512 registers)
 template <int KC>
-__global__ void __launch_bounds__(256, MKGNN_EXP_OCC) kc_forward_stream(FusedFwdArgs a) {
+__global__ void __launch_bounds__(256, (KC >= 8 ? 1 : MKGNN_EXP_OCC)) kc_forward_stream(FusedFwdArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int grp = a.blk_group[blockIdx.x];
     const int rank = a.blk_rank[blockIdx.x];
@@ -595,7 +597,7 @@ __global__ void __launch_bounds__(256, MKGNN_EXP_OCC) kc_forward_stream(FusedFwd
 // ---------------------------------------------------------------- host ----
 bool stream_forward_supported(int d, int F, int E, int L, int64_t n_atoms, int64_t x_stride, int64_t out_stride, const float* e_unit) {
     if (d < 1 || d > 4 || L < 1 || E < 1 || E > 8 || !e_unit) return false;
-    if (F < 1 || F > 112 || !mfma_padded_width(F)) return false;     // KC = ceil(F / 16) <= 7 chunks; only the last may be partial
+    if (F < 1 || F > STREAM_MAX_F || !bank_pitch(F)) return false;   // KC = ceil(F / 16) <= 10 chunks; only the last may be partial
     if (d == 4 && L * 12 > 768) return false;            // the chirality sign table's LDS slot
     if (stream_column_parts(d, L) > 8) return false;     // (a bank of > 128 / 256 kernels of one degree: the generic kernels)
     // 32-bit element offsets into x, out and the unit bond rows
@@ -733,10 +735,11 @@ int stream_forward_groups(const int L[4], const bool use[4]) {
 }
 
 template <int KC> static hipError_t launch_stream_kc(const FusedFwdArgs& a, int nb, size_t lds_bytes, hipStream_t st) {
-    if (lds_bytes > 64 * 1024) {                         // (two such blocks still fit a CU's 160 KB)
+    if (lds_bytes > 64 * 1024) {                         // (two such blocks still fit a CU's 160 KB; KC >= 8: one block per CU)
         static PerDeviceOnce attr_set;
         if (const int slot = attr_set.pending(); slot >= 0) {
-            hipError_t e = hipFuncSetAttribute((const void*)kc_forward_stream<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+            hipError_t e = hipFuncSetAttribute((const void*)kc_forward_stream<KC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (KC >= 8 ? 128 : 80) * 1024);
             if (e != hipSuccess) return e;
             attr_set.set(slot);
         }
@@ -748,11 +751,11 @@ template <int KC> static hipError_t launch_stream_kc(const FusedFwdArgs& a, int 
 hipError_t launch_forward_stream(FusedFwdArgs& a, const bool use[4], hipStream_t st) {
     const int KC = (a.F + 15) / 16;
     a.stamps = g_stream_stamps;
-    a.FPB = mfma_padded_width(a.F);
+    a.FPB = bank_pitch(a.F);
     int nb = 0;
     const size_t lds_bytes = plan_stream(a, use, KC, &nb);
     if (nb == 0) return hipSuccess;
-    if (nb < 0 || lds_bytes > 80 * 1024) return hipErrorInvalidValue;     // (the caller checks stream_forward_groups first)
+    if (nb < 0 || lds_bytes > (size_t)(KC >= 8 ? 128 : 80) * 1024) return hipErrorInvalidValue;     // (the caller checks stream_forward_groups first)
     g_last_plan[0].launches.fetch_add(1);
     switch (KC) {
         case 1: return launch_stream_kc<1>(a, nb, lds_bytes, st);
@@ -762,6 +765,9 @@ hipError_t launch_forward_stream(FusedFwdArgs& a, const bool use[4], hipStream_t
         case 5: return launch_stream_kc<5>(a, nb, lds_bytes, st);
         case 6: return launch_stream_kc<6>(a, nb, lds_bytes, st);
         case 7: return launch_stream_kc<7>(a, nb, lds_bytes, st);
+        case 8: return launch_stream_kc<8>(a, nb, lds_bytes, st);
+        case 9: return launch_stream_kc<9>(a, nb, lds_bytes, st);
+        case 10: return launch_stream_kc<10>(a, nb, lds_bytes, st);
         default: return hipErrorInvalidValue;
     }
 }

@@ -71,7 +71,7 @@ __device__ __forceinline__ void bank_prepare_task(const PrepArgs& a, const int t
     int width;
     float* pad_dst = nullptr;
     int pad_width = 0;
-    const int FP = mfma_padded_width(a.F);
+    const int FP = bank_pitch(a.F);
     if (r < L) {
         src = a.bank[i].x_center + (size_t)r * a.F; dst = a.cen[i] + (size_t)r * a.F; inv = a.icen[i] + r; width = a.F;
         if (FP) { pad_dst = a.padded[i] + ((size_t)d * L + r) * FP; pad_width = FP; }

@@ -684,7 +684,6 @@ static size_t plan_fused(FusedFwdArgs& a, const bool use[4], int KC, int* nblock
 }
 
 hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t st) {
-    const int KC = mfma_padded_width(a.F) / 16;
     if (a.last && use[3] && a.deg[3].n > 0) {
         int64_t blocks = (a.deg[3].n + 3) / 4;
         if (blocks > 2048) blocks = 2048;
@@ -702,6 +701,7 @@ hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t 
         use_bank[i] = use[i] && !use_stream[i];
         any_bank = any_bank || use_bank[i];
     }
+    const int KC = mfma_padded_width(a.F) / 16;          // (0: rows wider than the LDS-bank kernel takes -- streamed or nothing)
     {   // the streamed launch holds FUSED_MAX_GROUPS (degree, column part) groups: very wide banks go to the LDS-bank kernel, widest first
         int Ls[4];
         for (int i = 0; i < 4; ++i) Ls[i] = a.deg[i].L;
@@ -719,6 +719,7 @@ hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t 
         if (e != hipSuccess) return e;
     }
     if (any_bank) {
+        if (KC == 0) return hipErrorInvalidValue;
         int nb = 0;
         const size_t lds_bytes = plan_fused(a, use_bank, KC, &nb);
         if (nb > 0) {
