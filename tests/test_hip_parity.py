@@ -1316,3 +1316,39 @@ def test_plan_builder_hip_matches_torch_builder():
                     assert torch.equal(gv[0], wv[0]) and torch.equal(gv[1], wv[1]), (ci, with_edges, gi)
                 else:
                     assert torch.equal(gv, wv), (ci, with_edges, gi)
+
+
+def test_evaluation_metrics_on_the_device_match_reference_golden():
+    """SURVEY 8 f-4 on the GPU: ``molkgnn_amd.evaluation`` (the reference's ``evaluation.py:11-127``: logAUC with
+    scikit-learn's ``roc_curve`` / ``drop_intermediate`` and ``np.interp`` semantics, AUC, PPV, accuracy, F1) evaluated on
+    CUDA tensors -- the validation scores never leave the device -- against the numbers the reference's own functions
+    produced (tests/golden/g8_metrics.npz), to 1e-12; and on the scores of a model's forward on the device."""
+    import os
+    from molkgnn_amd import evaluation as E
+    dev = _dev()
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "g8_metrics.npz"))
+    names = sorted({k.split("/")[0] for k in g.files if k.endswith("/y")})
+    assert len(names) == 6
+    for name in names:
+        y, s = torch.from_numpy(g[f"{name}/y"]).to(dev), torch.from_numpy(g[f"{name}/score"]).to(dev)
+        for key, got in (("logauc", E.calculate_logAUC(y, s)), ("logauc_wide", E.calculate_logAUC(y, s, FPR_range=(0.01, 0.5))),
+                         ("auc", E.calculate_auc(y, s)), ("ppv", E.calculate_ppv(y, s)), ("ppv_cut", E.calculate_ppv(y, s, cutoff=0.8)),
+                         ("accuracy", E.calculate_accuracy(y, s)), ("f1", E.calculate_f1_score(y, s))):
+            want = float(g[f"{name}/{key}"])
+            if want != want:
+                assert got != got, (name, key)
+            else:
+                assert abs(got - want) <= 1e-12 * max(1.0, abs(want)), (name, key, got, want)
+    # scores straight from the HIP model: same metrics on the device and on the host copy
+    from molkgnn_amd.synthetic import make_batch
+    from molkgnn_amd.train import GNNModel
+    torch.manual_seed(8)
+    b = make_batch(400, seed=80).to(dev)
+    b.y = (torch.arange(400, device=dev) % 7 == 0).long()
+    model = GNNModel(num_layers=3, ffn_dropout_rate=0.0).to(dev).eval()
+    with torch.no_grad():
+        pred, _ = model(b)
+    score = torch.sigmoid(pred.view(-1))
+    for fn in (E.calculate_logAUC, E.calculate_auc, E.calculate_ppv, E.calculate_accuracy, E.calculate_f1_score):
+        a, c = fn(b.y, score), fn(b.y.cpu(), score.cpu())
+        assert abs(a - c) <= 1e-12 * max(1.0, abs(c)), (fn.__name__, a, c)

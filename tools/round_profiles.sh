@@ -13,13 +13,16 @@ python3 bench.py --steps 50 --warmup 10 > "$O/bench_b4096.json" 2> "$O/bench_b40
 # 2. kernel statistics + one step's timeline of the same command (shorter)
 tools/prof.sh "$tag/prof_b4096" bench.py --steps 20 --warmup 5 --windows 1 --fresh-batches 0 --no-cpu-baseline > "$O/kstats_b4096.txt"
 python3 tools/step_timeline.py "$O/prof_b4096" > "$O/step_timeline_graph.txt"
+find "$O/prof_b4096" -name "*kernel_trace.csv" -delete     # (gpurun brings back at most 64 MiB: the summaries stay, the raw traces go)
 # 3. the fresh-batch graph's timeline
 tools/prof.sh "$tag/prof_fresh" bench.py --steps 10 --warmup 3 --windows 1 --fresh-batches 16 --no-cpu-baseline > "$O/kstats_fresh.txt"
 python3 tools/step_timeline.py "$O/prof_fresh" > "$O/step_timeline_fresh.txt"
+find "$O/prof_fresh" -name "*kernel_trace.csv" -delete
 # 4. configs[2]: AID 435008 shape, batch 256
 python3 bench.py --assay 435008 --batch-size 256 --steps 200 --warmup 20 > "$O/bench_435008_b256.json" 2> "$O/bench_435008_b256.err"
 tools/prof.sh "$tag/prof_b256" bench.py --assay 435008 --batch-size 256 --steps 50 --warmup 5 --windows 1 --fresh-batches 0 --no-cpu-baseline > "$O/kstats_435008_b256.txt"
 python3 tools/step_timeline.py "$O/prof_b256" > "$O/step_timeline_435008_b256.txt"
+find "$O/prof_b256" -name "*kernel_trace.csv" -delete
 # 5. bf16 similarity variant (configs[4] shape on one GPU)
 python3 bench.py --variant bf16 --steps 50 --warmup 10 --no-cpu-baseline --fresh-batches 0 > "$O/bench_b4096_bf16.json" 2> "$O/bench_b4096_bf16.err"
 python3 bench.py --assay all9 --variant bf16 --steps 50 --warmup 10 --no-cpu-baseline --fresh-batches 0 > "$O/bench_all9_bf16.json" 2> "$O/bench_all9_bf16.err"
@@ -27,10 +30,13 @@ python3 tools/shard_loader_probe.py --molecules 131072 --workers 2 > "$O/shard_l
 # 6. HBM traffic of the forward kernel (separate PMC passes) -> the JSON bench.py reads
 tools/pmc.sh "$tag/pmc_fwd" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" -- tools/fwd_probe.py --reps 6 > "$O/pmc_fwd.txt"
 python3 tools/collect_pmc.py "kc_forward_stream<7>" "$O/forward_pmc.json" "$commit" 98774728 "$O/pmc_fwd" > /dev/null
+rm -rf "$O"/pmc_fwd/pass*/
 # 7. pipe utilisation counters of every kernel of a step
 tools/pmc.sh "$tag/pmc_step" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" \
     "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \
     "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_ACTIVE_INST_SCA" \
     "GRBM_GUI_ACTIVE TA_BUSY_avr TA_BUSY_max" "FETCH_SIZE" "WRITE_SIZE" \
     -- bench.py --steps 3 --warmup 1 --windows 1 --fresh-batches 0 --no-cpu-baseline --roofline-reps 2 > "$O/pmc_step.txt"
+rm -rf "$O"/pmc_step/pass*/
+du -sh "$O"
 echo done
