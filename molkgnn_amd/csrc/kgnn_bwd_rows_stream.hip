@@ -121,21 +121,6 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
         return t > tile_hi ? tile_hi : t;
     };
 
-    // ---- one-time: this wave's kernels' unit rows in B-operand order: lane (k = kq, j = ci) -> kernel 4 q + kq, feature 16 t + ci
-    float bk[D + 1][4][KC];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i = 4 * q + kq, l = ct * kpt + i;
-        const bool ok = ct_ok && i < kpt && l < L;
-        const int lc = ok ? l : 0;
-#pragma unroll
-        for (int b = 0; b <= D; ++b)
-#pragma unroll
-            for (int t = 0; t < KC; ++t) {
-                const float v = dg.padded[((size_t)b * L + lc) * FPB + 16 * t + ci];
-                bk[b][q][t] = ok ? v : 0.f;
-            }
-    }
     const float w_s = dg.mix[0], w_c = dg.mix[1], w_sum = dg.mix[3];
     const float ws_n = w_s / w_sum / (float)D;
     const float ratio_c = w_c * (float)D / w_s;
@@ -176,6 +161,24 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
     issue(tile_at(0), records ? 0 : focal_of(tile_at(0)));
     int64_t focal_next = records ? 0 : focal_of(tile_at(1));
     int par = 0;
+
+    // (the first tile's coefficient loads are in flight while the bank is loaded: one dependent round trip less in front of
+    // the first tile)
+    // ---- one-time: this wave's kernels' unit rows in B-operand order: lane (k = kq, j = ci) -> kernel 4 q + kq, feature 16 t + ci
+    float bk[D + 1][4][KC];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = 4 * q + kq, l = ct * kpt + i;
+        const bool ok = ct_ok && i < kpt && l < L;
+        const int lc = ok ? l : 0;
+#pragma unroll
+        for (int b = 0; b <= D; ++b)
+#pragma unroll
+            for (int t = 0; t < KC; ++t) {
+                const float v = dg.padded[((size_t)b * L + lc) * FPB + 16 * t + ci];
+                bk[b][q][t] = ok ? v : 0.f;
+            }
+    }
 
     for (int64_t it = 0; it < iters; ++it) {
         const int64_t tile = tile_at(it);

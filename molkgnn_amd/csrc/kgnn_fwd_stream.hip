@@ -210,6 +210,19 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
         return t > tile_hi ? tile_hi : t;
     };
 
+    // (tile 0's ids first: their DMA flies while the bank is loaded -- one dependent round trip less in front of the first
+    // tile, which is all a stream has at small batches)
+    if (role == 0) {
+        int64_t n0 = tile_at(0) * 16 + (lane & 15);
+        if (n0 >= dg.n) n0 = dg.n - 1;
+        const int kq0 = lane >> 4;
+        const void* src0 = (kq0 < D) ? (const void*)(dg.nei + n0 * D + kq0) : (const void*)(dg.sel + n0);
+        float* const meta0 = lds + (size_t)stream * (RING * SLOT + 2 * META) + RING * SLOT;
+        if (S1 >= 4 || kq0 < S1) dma4<SITE_IDS>(src0, meta0);
+        if constexpr (S1 == 5) {
+            if (kq0 == 0) dma4<SITE_IDS4>(dg.sel + n0, meta0 + 64);
+        }
+    }
     // ---- one-time: this wave's share of the bank -> registers (unit rows, zero beyond F; idle columns all zero)
     f32x4 bk[NB][KC];
     float2 bv[D];
@@ -303,8 +316,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
     // ---- prologue: tile 0's ids go through the LDS record like every later tile's (idsD must never be indexed by a
     // run-time value: the array would live in scratch); then the first RING slots, tile 0's record, tile 1's ids;
     // everything drained before the loop
-    if (role == 0) issue_ids(tile_at(0), meta);
-    wait_vmcnt<0>();
+    wait_vmcnt<0>();                                     // (tile 0's ids: issued ahead of the bank load)
     __syncthreads();                                     // (also: chirality table written)
 #pragma unroll
     for (int q = 0; q < S1; ++q) idsD[q] = __float_as_uint(meta[16 * q + ci]);
