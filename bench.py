@@ -392,6 +392,12 @@ def main():
     # MKGNN_BENCH_DP_PATH=1 (rehearsal on one GPU): take the N > 1 code path -- backward graph, RCCL all-reduce of the flat
     # gradient buffer, one shared optimiser graph -- with a process group of ONE rank
     dp_path = world > 1 or bool(os.environ.get("MKGNN_BENCH_DP_PATH"))
+    if os.environ.get("MKGNN_DP_ONE_GRAPH") == "1":
+        # a collective captured into the step's graph: the process group's watchdog thread must not query the events of a
+        # work object recorded in a capturing stream (hipErrorCapturedEvent aborts the process on this stack: PyTorch 2.10,
+        # RCCL 2.26); with these set before the group is created the one-rank rehearsal captures and replays
+        for k in ("TORCH_NCCL_ASYNC_ERROR_HANDLING", "TORCH_NCCL_ENABLE_MONITORING", "TORCH_NCCL_CUDA_EVENT_CACHE", "TORCH_NCCL_BLOCKING_WAIT"):
+            os.environ.setdefault(k, "0")
     dp.init_process_group_from_env(os.environ.get("MKGNN_DIST_BACKEND", "nccl"), force=dp_path)   # nccl = RCCL over xGMI
 
     torch.manual_seed(1798)                       # same initial weights on every rank
@@ -461,6 +467,9 @@ def main():
                     for grp in opt.param_groups:
                         grp["grad_scale"] = 1.0 / world
                     opt.set_grad_active(reducer.active_flags())
+                    # the communicator's first collective allocates and synchronises: not inside a capture
+                    reducer.all_reduce_filled()
+                    torch.cuda.synchronize()
                 for i in range(nb):
                     model.zero_grad(set_to_none=True)
                     g_fb = torch.cuda.CUDAGraph()
@@ -507,6 +516,14 @@ def main():
             torch.cuda.synchronize()
         except Exception as exc:                     # capture is an optimisation, never a requirement
             log(f"hipGraph capture unavailable ({type(exc).__name__}: {str(exc).splitlines()[0]}); running eagerly")
+            if os.environ.get("MKGNN_BENCH_DEBUG"):
+                import traceback
+                traceback.print_exc()
+            try:                                     # (a failed capture leaves a sticky HIP error behind: read it away)
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+            _lib.load().mkgnn_debug_clear_error()
             graphs = None
             flat_opt = False
             if opt is not None:

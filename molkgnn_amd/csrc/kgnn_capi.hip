@@ -206,6 +206,8 @@ int mkgnn_debug_set_grid_caps(int32_t forward_blocks, int32_t rows_blocks, int32
     g_grid_caps.fwd.store(forward_blocks); g_grid_caps.rows.store(rows_blocks); g_grid_caps.bank.store(bank_blocks);
     return 0;
 }
+// reads the runtime's sticky last-error away (after a failed hipGraph capture the next launch check would report it)
+int mkgnn_debug_clear_error(void) { (void)hipGetLastError(); return 0; }
 int mkgnn_debug_time_backward(int32_t enable) {
     if (enable && !g_bwd_ev_made) {
         for (int k = 0; k < 5; ++k)
