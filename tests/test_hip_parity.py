@@ -197,6 +197,71 @@ def test_three_layer_network_tie_aware(variant):
     assert checked > 40
 
 
+@pytest.mark.parametrize("counts,layers,hidden", [((5, 10, 15, 25), 3, 32), ((16, 32, 48, 64), 3, 64), ((1, 1, 1, 1), 4, 32)])
+def test_three_layer_network_other_reference_configurations(counts, layers, hidden):
+    """The reference takes any ``--num_kernel{1..4}_{1hop,Nhop}`` / ``--num_layers`` / ``--hidden_dim`` (MolKGNNNet.py:162-174;
+    its sweep launcher runs (1, 1, 1, 1) x 4 layers, utils/scheduler-barium-kgnn.py:181-185).  The whole network -- batch
+    norm, every layer on the streamed kernels (55-, 160-, 4-wide N-hop rows), propagate, readout -- against the oracle
+    evaluated with the build's own permutation choices, layer by layer and end to end, forward and every parameter gradient."""
+    dev = _dev()
+    from molkgnn_amd import functional as Fn
+    from molkgnn_amd.MolKGNNNet import MolKGNNNet
+    from molkgnn_amd.plan import plan_from_data
+    from molkgnn_amd.synthetic import make_batch
+    torch.manual_seed(sum(counts) + layers)
+    names = [f"num_kernel{d}_{h}" for h in ("1hop", "Nhop") for d in range(1, 5)]
+    model = MolKGNNNet(num_layers=layers, x_dim=28, p_dim=3, edge_attr_dim=7, drop_ratio=0.0, graph_embedding_dim=hidden,
+                       **dict(zip(names, counts * 2)))
+    with torch.no_grad():                                    # non-trivial running statistics for the eval-mode batch norm
+        model.node_batch_norm.running_mean.normal_(0.0, 0.3)
+        model.node_batch_norm.running_var.uniform_(0.5, 1.5)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(dev).eval()
+    b = make_batch(40, seed=sum(counts), duplicate_fraction=0.1)
+    b.num_graphs = 40
+    bd = b.to(dev)
+    cot = torch.randn(40, hidden, generator=torch.Generator().manual_seed(1))
+    emb = model(bd)
+    (emb * cot.to(dev)).sum().backward()
+    plan = plan_from_data(bd)
+    ostate = {k: v.clone() for k, v in state.items()}
+    forced = []
+    lib_launches = []
+    from molkgnn_amd import readout as R
+    with torch.no_grad():
+        # (the model's own batch norm operator, not torch's: with duplicated neighbour rows an ulp in x decides
+        # mathematically tied orders the other way, and the choices replayed here must be the model's)
+        h = R.batch_norm(bd.x, model.node_batch_norm, None)
+        h_o = O.batch_norm(b.x, ostate["node_batch_norm.weight"], ostate["node_batch_norm.bias"],
+                           ostate["node_batch_norm.running_mean"], ostate["node_batch_norm.running_var"], False)
+        for i, layer in enumerate(model.gnn.layers):
+            params, E = layer._bank_params("train", h)
+            sim, saved = Fn.kernelsetconv_details(h, plan, i == layers - 1, params, E, "mfma")     # (fails if a degree is not covered)
+            idx = [None if s[0] is None else s[0].cpu().long() for s in saved]
+            forced.append(idx)
+            per_degree = O.kernelset_params(ostate, f"gnn.layers.{i}.")
+            assert O.kernelset_tie_aware_mismatch(per_degree, h_o, b, i == layers - 1, sim.cpu(), idx) == 0, f"layer {i}"
+            sim_o = O.kernelsetconv(per_degree, h_o, b, i == layers - 1, form="faithful", forced_idx=idx)
+            assert torch.allclose(sim.cpu(), sim_o, atol=FWD_TOL, rtol=0)
+            h = Fn.propagate_add(sim, plan, out_pad=(-sim.shape[1]) % 4)
+            h_o = O.propagate_add(b.edge_index, sim_o)
+    ostate = {k: (v.requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in ostate.items()}
+    emb_o = O.molkgnnnet(ostate, b, layers, training_bn=False, form="faithful", forced_idx=forced)
+    scale = max(1.0, float(emb_o.detach().abs().max()))
+    assert float((emb.detach().cpu() - emb_o.detach()).abs().max()) <= 5e-5 * scale
+    (emb_o * cot).sum().backward()
+    checked = 0
+    for nm, prm in model.named_parameters():
+        ref = ostate[nm].grad
+        if prm.grad is None:
+            assert ref is None or float(ref.abs().max()) == 0.0, nm
+            continue
+        assert float((prm.grad.cpu() - ref).abs().max()) <= 5e-5 * max(1.0, float(ref.abs().max())) + 1e-3 * float(ref.abs().max()), \
+            (nm, float((prm.grad.cpu() - ref).abs().max()), float(ref.abs().max()))
+        checked += 1
+    assert checked >= 6 * 4 * layers
+
+
 def test_fullsize_seeded_model_matches_reference_output():
     """Same seed -> same 130 090 parameters as the reference (init order)
     and, on a tie-free first layer, the same first-layer scores."""
