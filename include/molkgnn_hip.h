@@ -261,6 +261,35 @@ int mkgnn_readout_backward(const mkgnn_readout_params* params, const float* h, i
                            float* grad_lin2_weight, float* grad_lin2_bias,
                            void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same readout fed by the BLOCK ROWS of the last kernel convolution instead of by h = propagate(sim)
+ * (KernelLayer.py:119-123 followed by MolKGNNNet.py:144-146): both steps are linear and row n of sim is non-zero only in
+ * the column block of atom n's degree, so  z[n] = W1[:, block(n)] sim[n, block(n)]  is taken first and the H-wide rows are
+ * propagated,  pre = propagate(z) + b1.  Same sums, re-associated; no dense [N, K] h and no gradient of it.
+ *   sim [n_atoms, K] block rows (as MKGNN_VARIANT_BLOCK_ROWS leaves them), K = sum num_kernels = params->F, num_kernels <= 64
+ *   buckets: only count and selected_index are read (the projection works on 16-atom tiles of one degree bucket, on the
+ *   matrix cores); in_* / out_*: mkgnn_plan_build's CSRs of edge_index by target / by source
+ *   z, pre (forward), dpre, dz (backward): [n_atoms, HS], HS = mkgnn_readout_hidden_stride(H); pre (WITHOUT b1) and
+ *   pooled are kept for the backward.  grad_sim: [n_atoms, K] block rows (every atom's own block is written), may be NULL.
+ * Limits: K <= 255, every block <= 64 kernels, H <= 64, G <= 64.  Workspace of the backward:
+ * mkgnn_readout_blocks_workspace_bytes. */
+size_t mkgnn_readout_blocks_workspace_bytes(int32_t K, int32_t H, int32_t G, int64_t n_mols);
+int mkgnn_readout_blocks_supported(int32_t F, int32_t H, int32_t G, const int32_t num_kernels[MKGNN_MAX_DEGREE]);
+int mkgnn_readout_blocks_forward(const mkgnn_readout_params* params, const float* sim, int64_t sim_stride,
+                                 const int32_t num_kernels[MKGNN_MAX_DEGREE],
+                                 const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE], int64_t n_atoms,
+                                 const int32_t* in_rowptr, const int32_t* in_col, const int32_t* mol_ptr, int64_t n_mols,
+                                 const float* keep_scale, float* z, float* pre, float* pooled,
+                                 float* out, int64_t out_stride, void* stream);
+int mkgnn_readout_blocks_backward(const mkgnn_readout_params* params, const float* sim, int64_t sim_stride,
+                                  const int32_t num_kernels[MKGNN_MAX_DEGREE],
+                                  const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE], int64_t n_atoms,
+                                  const int32_t* out_rowptr, const int32_t* out_col, const int32_t* mol_ptr,
+                                  const int32_t* atom_mol, int64_t n_mols, const float* keep_scale, const float* pre,
+                                  const float* pooled, const float* grad_out, int64_t grad_out_stride,
+                                  float* dpre, float* dz, float* grad_sim, int64_t grad_sim_stride,
+                                  float* grad_lin1_weight, float* grad_lin1_bias, float* grad_lin2_weight,
+                                  float* grad_lin2_bias, void* workspace, size_t workspace_bytes, void* stream);
+
 /* BatchNorm1d over atom rows, reference MolKGNNNet.py:115 (torch.nn.BatchNorm1d semantics: biased
  * variance for the normalisation, unbiased for running_var, running <- running + momentum (batch - running)).
  * training != 0: batch statistics, running_* (may be NULL) updated in place, save_* written.

@@ -115,11 +115,20 @@ class MolGCN(MessagePassing):
             pl = [layer._bank_params("train", x) for layer in self.layers]
             prepared = Fn.prepare_banks([p for p, _ in pl], [x.shape[1]] + [self.num_kernels(i) for i in range(self.num_layers - 1)],
                                         pl[0][1], x.shape[0], n_slots)
+        # (private: MolKGNNNet asks for the LAST layer's block rows instead of h -- its readout projects them before the
+        # propagate step, readout.readout_blocks; None is returned where that does not apply and h as usual)
+        defer = kwargv.get('_defer_last_propagate') is not None
         h = x
         try:
             for i in range(self.num_layers):
                 data.x = h
                 is_last_layer = (i == self.num_layers - 1)
+                if defer and is_last_layer and _BLOCK_ROWS and not save_score:
+                    layer = self.layers[i]
+                    sim_sc = layer._run_block_rows(h, self._plan, True, prepared=prepared[i])
+                    if sim_sc is not None:
+                        kwargv['_defer_last_propagate'].append((sim_sc, self._plan, tuple(layer.L)))
+                        return None
                 # sim_sc goes nowhere but into propagate: block rows (no zero fill, block-sparse sums both ways)
                 # ... and convolution + propagate as one operator where that applies (its backward folds the propagate
                 # step's gradient into the kernels' pre-pass); MKGNN_SPLIT_PROPAGATE=1: two operators (diagnostics)

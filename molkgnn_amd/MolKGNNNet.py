@@ -22,6 +22,14 @@ def global_add_pool(x, batch, size=None):
     return torch.zeros(size, x.shape[1], dtype=x.dtype, device=x.device).index_add_(0, batch, x)
 
 
+import os as _os
+
+# MKGNN_PROJECT_FIRST: '1' always / '0' never take the block-row readout; default: from _PROJECT_FIRST_ATOMS atoms on (the
+# three small passes cost one more dependent launch each way than the two big ones: a loss below a few thousand atoms)
+_PROJECT_FIRST = _os.environ.get('MKGNN_PROJECT_FIRST', '')
+_PROJECT_FIRST_ATOMS = 16384
+
+
 class MolKGNNNet(torch.nn.Module):
     def __init__(self, num_layers=1, num_kernel1_1hop=0, num_kernel2_1hop=0, num_kernel3_1hop=0,
                  num_kernel4_1hop=0, num_kernel1_Nhop=0, num_kernel2_Nhop=0, num_kernel3_Nhop=0,
@@ -74,14 +82,28 @@ class MolKGNNNet(torch.nn.Module):
             u = getattr(data, f'nei_edge_unit_deg{d}', None)
             if u is not None:
                 kw[f'nei_edge_unit_deg{d}'] = u
-        node_representation = self.gnn(x=x, edge_index=data.edge_index, edge_attr=data.edge_attr, p=data.p,
-                                       save_score=save_score, **kw)
-        # pool(lin2(dropout(act(lin1(h)))), batch) -- MolKGNNNet.py:144-146 -- as one operator
         seg = None
         if getattr(data, 'mol_ptr', None) is not None and getattr(data, 'atom_mol', None) is not None:
             seg = R.MoleculeSegments.from_tensors(data.mol_ptr, data.atom_mol)
-        return R.readout(node_representation, self.graph_embedding_lin1, self.graph_embedding_lin2, self.dropout,
-                         data.batch, getattr(data, 'num_graphs', None), segments=seg)
+        # The last layer's output goes nowhere but through propagate into lin1: where it applies (large batches: it trades
+        # two big passes for three small ones), the readout takes the last convolution's BLOCK ROWS and projects them
+        # before the propagate step (readout.readout_blocks); MKGNN_PROJECT_FIRST=0 / 1 forces the choice (diagnostics)
+        blocks_out = []
+        lin1, lin2 = self.graph_embedding_lin1, self.graph_embedding_lin2
+        want = x.is_cuda and not save_score and (_PROJECT_FIRST == '1' or (_PROJECT_FIRST != '0' and x.shape[0] >= _PROJECT_FIRST_ATOMS))
+        if want:
+            Ls = self.gnn.layers[-1].L
+            want = R.readout_blocks_supported(sum(Ls), lin1.weight.shape[0], lin2.weight.shape[0], Ls)
+        if want and seg is None:
+            seg = R.molecule_segments(data.batch, getattr(data, 'num_graphs', None))
+        want = want and seg.sorted and seg.size > 0
+        node_representation = self.gnn(x=x, edge_index=data.edge_index, edge_attr=data.edge_attr, p=data.p,
+                                       save_score=save_score, **kw, **({'_defer_last_propagate': blocks_out} if want else {}))
+        if node_representation is None:                     # the last propagate was left to the readout
+            sim_sc, plan, Ls = blocks_out[0]
+            return R.readout_blocks(sim_sc, plan, Ls, lin1, lin2, self.dropout, seg)
+        # pool(lin2(dropout(act(lin1(h)))), batch) -- MolKGNNNet.py:144-146 -- as one operator
+        return R.readout(node_representation, lin1, lin2, self.dropout, data.batch, getattr(data, 'num_graphs', None), segments=seg)
 
     @staticmethod
     def add_model_specific_args(parent_parser):

@@ -70,7 +70,9 @@ EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn
            "mkgnn_batchnorm_backward", "mkgnn_bce_head_workspace_bytes", "mkgnn_bce_head_forward",
            "mkgnn_bce_head_backward", "mkgnn_rf_workspace_bytes", "mkgnn_rf_count", "mkgnn_rf_fill", "mkgnn_adamw_step",
            "mkgnn_bce_head_dropout_forward", "mkgnn_bce_head_dropout_backward", "mkgnn_segment_sum_block_rows",
-           "mkgnn_plan_workspace_bytes", "mkgnn_plan_build", "mkgnn_backward_join", "mkgnn_backward_streams", "mkgnn_bank_prepare", "mkgnn_expand_batch", "mkgnn_bce_head_fused")
+           "mkgnn_plan_workspace_bytes", "mkgnn_plan_build", "mkgnn_backward_join", "mkgnn_backward_streams", "mkgnn_bank_prepare", "mkgnn_expand_batch", "mkgnn_bce_head_fused",
+           "mkgnn_readout_blocks_supported", "mkgnn_readout_blocks_forward", "mkgnn_readout_blocks_backward",
+           "mkgnn_readout_blocks_workspace_bytes")
 
 _lib: Optional[C.CDLL] = None
 TORCH_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libmolkgnn_torch.so")
@@ -148,6 +150,15 @@ def load() -> C.CDLL:
     lib.mkgnn_readout_backward.restype = C.c_int
     lib.mkgnn_readout_backward.argtypes = [C.POINTER(ReadoutParams), P, I64, I64, P, P, I64, P, P, P, P, I64, P, I64,
                                            P, P, P, P, P, C.c_size_t, P]
+    lib.mkgnn_readout_blocks_workspace_bytes.restype = C.c_size_t
+    lib.mkgnn_readout_blocks_workspace_bytes.argtypes = [I32, I32, I32, I64]
+    lib.mkgnn_readout_blocks_supported.restype = C.c_int
+    lib.mkgnn_readout_blocks_supported.argtypes = [I32, I32, I32, Int32x4]
+    lib.mkgnn_readout_blocks_forward.restype = C.c_int
+    lib.mkgnn_readout_blocks_forward.argtypes = [C.POINTER(ReadoutParams), P, I64, Int32x4, Buckets4, I64, P, P, P, I64, P, P, P, P, P, I64, P]
+    lib.mkgnn_readout_blocks_backward.restype = C.c_int
+    lib.mkgnn_readout_blocks_backward.argtypes = [C.POINTER(ReadoutParams), P, I64, Int32x4, Buckets4, I64, P, P, P, P, I64, P, P, P,
+                                                  P, I64, P, P, P, I64, P, P, P, P, P, C.c_size_t, P]
     lib.mkgnn_batchnorm_workspace_bytes.restype = C.c_size_t
     lib.mkgnn_batchnorm_workspace_bytes.argtypes = [I32]
     lib.mkgnn_batchnorm_forward.restype = C.c_int

@@ -41,6 +41,9 @@ struct ReadoutArgs {
     float* gh; int64_t ghs;
     float* slab_atoms; int slab_atoms_stride; int nblk_atoms;
     float* slab_mol; int slab_mol_stride; int nblk_mol;
+    // block-row readout (mkgnn_readout_blocks_*): `pre` holds propagate(W1 sim) WITHOUT the bias, added where it is read
+    const float* pre_bias;         // b1 (or null: pre includes it)
+    float* dpre;                   // [n, HP]: readout_bwd_mol_kernel also writes d loss / d pre of its molecules' atoms
 };
 
 __device__ __forceinline__ float sigmoid_f(float p) { return 1.f / (1.f + expf(-p)); }
@@ -131,6 +134,7 @@ __global__ void __launch_bounds__(256) readout_pool_kernel(ReadoutArgs a, int HP
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int groups = 64 / HP, c = lane & (HP - 1), gid = lane / HP;
     const bool kc = a.keep && c < H;
+    const float pb = (a.pre_bias && c < H) ? a.pre_bias[c] : 0.f;
     for (int64_t mol = (int64_t)blockIdx.x * 4 + wave; mol < a.nmol; mol += (int64_t)gridDim.x * 4) {
         const int lo = a.mol_ptr[mol], hi = a.mol_ptr[mol + 1];
         float s = 0.f;
@@ -140,7 +144,7 @@ __global__ void __launch_bounds__(256) readout_pool_kernel(ReadoutArgs a, int HP
             for (int u = 0; u < 4; ++u) {
                 const int at = at0 + u * groups;
                 const int atc = at < hi ? at : hi - 1;
-                p[u] = a.pre[(int64_t)atc * HP + c];
+                p[u] = a.pre[(int64_t)atc * HP + c] + pb;
                 k[u] = kc ? a.keep[(int64_t)atc * H + c] : 1.f;
             }
 #pragma unroll
@@ -183,7 +187,7 @@ __global__ void __launch_bounds__(256) readout_bwd_mol_kernel(ReadoutArgs a, int
         if (p >= G * H) p = 0;
         po[k] = p / H; pc[k] = p - po[k] * H;
     }
-    float accb = 0.f;
+    float accb = 0.f, accb1 = 0.f;
     for (int64_t m0 = m_lo; m0 < m_hi; m0 += MC) {
         __syncthreads();
         {   // MC * 64 = 4 * 256 entries: all loads first (unconditional, clamped), then the LDS stores
@@ -213,6 +217,7 @@ __global__ void __launch_bounds__(256) readout_bwd_mol_kernel(ReadoutArgs a, int
                 if (256 * k < G * H) accw[k] = fmaf(dzs[m][po[k]], As[m][pc[k]], accw[k]);      // (uniform: G * H = 1024 uses 4 of 16)
             if (tid < G) accb = fmaf(nat[m], dzs[m][tid], accb);
         }
+        if (a.dpre) __syncthreads();                         // (As is rewritten below: everybody is done with the pooled rows)
         for (int i = tid; i < MC * HP; i += 256) {
             const int m = i / HP, c = i - m * HP;
             if (m0 + m < m_hi) {
@@ -220,6 +225,37 @@ __global__ void __launch_bounds__(256) readout_bwd_mol_kernel(ReadoutArgs a, int
                 if (c < H)
                     for (int o = 0; o < G; ++o) v = fmaf(dzs[m][o], w2s[o * (H + 1) + c], v);
                 a.dA[(m0 + m) * HP + c] = v;
+                As[m][c] = v;                                // (pooled is no longer needed: the chunk's dA for the atom pass below)
+            }
+        }
+        if (a.dpre) {
+            // block-row readout: d loss / d pre of the chunk's atoms, dpre[n, c] = dA[mol(n), c] * keep * swish'(pre + b1);
+            // a thread's column c = tid % HP is fixed (HP divides 256): its share of db1 = sum_n dpre[n, c] stays in a register
+            __syncthreads();
+            const int64_t mlast = (m0 + MC < m_hi ? m0 + MC : m_hi);
+            const int at_lo = a.mol_ptr[m0], at_hi = a.mol_ptr[mlast];
+            const int c = tid & (HP - 1);
+            const float pb = (a.pre_bias && c < H) ? a.pre_bias[c] : 0.f;
+            for (int at0 = at_lo + tid / HP; at0 < at_hi; at0 += 4 * (256 / HP)) {
+                float pv[4], kv[4]; int mv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int at = at0 + u * (256 / HP);
+                    const int atc = at < at_hi ? at : at_hi - 1;
+                    pv[u] = a.pre[(int64_t)atc * HP + c];
+                    kv[u] = (a.keep && c < H) ? a.keep[(int64_t)atc * H + c] : 1.f;
+                    mv[u] = a.atom_mol[atc];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int at = at0 + u * (256 / HP);
+                    if (at < at_hi) {
+                        const float p = pv[u] + pb, sg = sigmoid_f(p);
+                        const float d = (c < H) ? As[mv[u] - (int)m0][c] * (sg * fmaf(p, 1.f - sg, 1.f)) * kv[u] : 0.f;
+                        a.dpre[(int64_t)at * HP + c] = d;
+                        accb1 += d;
+                    }
+                }
             }
         }
     }
@@ -227,6 +263,17 @@ __global__ void __launch_bounds__(256) readout_bwd_mol_kernel(ReadoutArgs a, int
 #pragma unroll
     for (int k = 0; k < 16; ++k) { const int p = tid + 256 * k; if (p < G * H) slab[p] = accw[k]; }
     if (tid < G) slab[G * H + tid] = accb;
+    if (a.dpre) {                                            // db1 partial of this block: the 256 / HP row groups in a fixed order
+        __syncthreads();
+        float* red = &dzs[0][0];                             // (MC * 64 >= 256 floats)
+        red[tid] = accb1;
+        __syncthreads();
+        if (tid < HP) {
+            float t = 0.f;
+            for (int k = 0; k < 256 / HP; ++k) t += red[k * HP + tid];
+            slab[G * H + G + tid] = t;
+        }
+    }
 }
 
 // ----------------------------------- backward, per atom tile: dpre, dh = dpre W1, dW1 += dpre^T h, db1 += dpre ----
@@ -386,8 +433,9 @@ struct SlabSeg {
     int src_cols, dst_rows, dst_cols;           // 2-D window [dst_rows, dst_cols] of a [*, src_cols] slab image
     float* dst;
     int blk_start;
+    int dst_stride;                             // row stride of dst (0: dst_cols -- contiguous)
 };
-struct SlabReduceArgs { SlabSeg seg[4]; int nseg; };
+struct SlabReduceArgs { SlabSeg seg[8]; int nseg; };
 
 __global__ void __launch_bounds__(256) slab_reduce_kernel(SlabReduceArgs a) {
     __shared__ float part[8][32];
@@ -415,7 +463,249 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(SlabReduceArgs a) {
         float t = part[0][threadIdx.x];
 #pragma unroll
         for (int k = 1; k < 8; ++k) t += part[k][threadIdx.x];
-        g.dst[e] = t;
+        g.dst[g.dst_stride ? (size_t)row * g.dst_stride + col : (size_t)e] = t;
+    }
+}
+
+// ---------------------------------------------------------------------- block-row readout (round 3) ----
+// The last kernel convolution's output sim goes nowhere but into  h = propagate(sim)  and  pre = W1 h + b1  (reference
+// KernelLayer.py:119-123, MolKGNNNet.py:144-146).  Both are linear, and row n of sim is non-zero only in the column block
+// of atom n's degree: project first, z[n] = W1[:, block(n)] sim[n, block(n)]  (H numbers from L_d), then propagate the
+// H-wide rows instead of the K-wide ones, pre = propagate(z) (+ b1 where it is read).  Same sums, re-associated.  Removes a
+// 45 MB dense h, its 45 MB gradient and the [N x K] x [K x H] tile products from the step.
+struct BlockProjArgs {
+    const float* sim; int64_t ss; const int8_t* deg; int64_t n;
+    const float* w1; int H, K, HP;
+    int off[MKGNN_MAX_DEGREE], L[MKGNN_MAX_DEGREE];
+    float* z;                                   // forward: [n, HP]
+    // backward
+    const float* dz;                            // [n, HP] = propagate^T(dpre)
+    const int64_t* sel[MKGNN_MAX_DEGREE]; int64_t cnt[MKGNN_MAX_DEGREE];
+    float* dsim; int64_t dss;                   // [n, K] block rows (only every atom's own block is written)
+    float* slab; int slab_stride; int FP;       // per block: dW1 image [HP][FP]
+};
+
+// Both kernels work on TILES OF ONE DEGREE BUCKET (16 atoms of degree d in selected_index order, so the block [off, off + L)
+// is the same for the whole tile) on the fp32 matrix cores; a block's four waves take four consecutive tiles of one bucket
+// and share that degree's slice of W1 in LDS ([HP][LP], rows 16-byte aligned, zero beyond H / L).
+//
+// Lane layout of a tile (r = lane & 15, q = lane >> 4), as in readout_pre_kernel: lane (r, q) holds, of atom r's row, the four
+// consecutive columns 16 j + 4 q .. + 3 of chunk j -- an MFMA's k index may be any permutation as long as both operands use
+// the same one.
+struct BlockTile { int di; int64_t t; int64_t cnt; int L, off, nj; };
+__device__ __forceinline__ bool block_tile_of(const BlockProjArgs& a, int64_t blk, int wave, BlockTile& T) {
+    // blocks are numbered bucket by bucket: bucket d has ceil(ceil(cnt_d / 16) / 4) of them
+    int64_t b0 = 0;
+    for (int di = 0; di < MKGNN_MAX_DEGREE; ++di) {
+        const int64_t tiles = (a.cnt[di] + 15) / 16, nb = a.L[di] > 0 ? (tiles + 3) / 4 : 0;
+        if (blk < b0 + nb) {
+            T.di = di; T.t = (blk - b0) * 4 + wave; T.cnt = a.cnt[di]; T.L = a.L[di]; T.off = a.off[di]; T.nj = (a.L[di] + 15) / 16;
+            return true;
+        }
+        b0 += nb;
+    }
+    return false;
+}
+// four consecutive floats of a row whose alignment (in floats, mod 4) is wave-uniform: one, two or four loads
+__device__ __forceinline__ f32x4 load4_at(const float* p, int align4) {
+    f32x4 v;
+    if (align4 == 0) v = *(const f32x4*)p;
+    else if (align4 == 2) { const float2 lo = *(const float2*)p, hi = *(const float2*)(p + 2); v = f32x4{lo.x, lo.y, hi.x, hi.y}; }
+    else v = f32x4{p[0], p[1], p[2], p[3]};
+    return v;
+}
+// this degree's slice of W1 -> LDS [HP][LP] (LP = 16 nj + 4), zero beyond H and L
+__device__ __forceinline__ void w1_block_to_lds(float* w1s, const BlockProjArgs& a, int HP, int L, int off, int LP, int tid) {
+    for (int i = tid; i < HP * LP; i += 256) {
+        const int hid = i / LP, l = i - hid * LP;
+        w1s[i] = (hid < a.H && l < L) ? a.w1[(size_t)hid * a.K + off + l] : 0.f;
+    }
+}
+
+// z[n] = W1[:, block(n)] sim[n, block(n)]  for the atoms of the degree buckets: [16 atoms x L] . [L x HP] per tile
+template <int NT>
+__global__ void __launch_bounds__(256) block_project_mfma_kernel(BlockProjArgs a) {
+    constexpr int HP = 16 * NT, LZ = HP + 4;
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    BlockTile T;
+    if (!block_tile_of(a, blockIdx.x, wave, T)) return;
+    const int LP = 16 * T.nj + 4;
+    float* const w1s = lds;
+    float* const zt = lds + HP * 68 + wave * 16 * LZ;             // this wave's [16][LZ] transpose image
+    w1_block_to_lds(w1s, a, HP, T.L, T.off, LP, tid);
+    // the tile's rows while the weights arrive: lane (r, q) <- atom r, columns 16 j + 4 q .. + 3
+    const int64_t p = T.t * 16 + r, pc = p < T.cnt ? p : T.cnt - 1;
+    const bool tile_ok = T.t * 16 < T.cnt;
+    const int64_t id = tile_ok ? a.sel[T.di][pc] : 0;
+    const float* row = a.sim + id * a.ss + T.off;
+    const int al = T.off & 3;                                      // (row bases are 16-byte aligned: the block's offset decides)
+    f32x4 v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = 16 * j + 4 * q;
+        v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (j < T.nj && tile_ok) {
+            if (col + 3 < T.L) v[j] = load4_at(row + col, al);
+            else {                                                 // the block's last, partial chunk: element by element
+#pragma unroll
+                for (int c = 0; c < 4; ++c) v[j][c] = col + c < T.L ? row[col + c] : 0.f;
+            }
+        }
+    }
+    __syncthreads();
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (j < T.nj) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 w = *(const f32x4*)&w1s[(16 * t + r) * LP + 16 * j + 4 * q];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[j][c], w[c], acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // acc[t][i] = z[atom 4 q + i][16 t + r]: through the wave's LDS image to whole 16-byte chunks of the z rows
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) zt[(4 * q + i) * LZ + 16 * t + r] = acc[t][i];
+    __builtin_amdgcn_wave_barrier();
+    constexpr int CPRZ = HP / 4;                                   // chunks per z row (8 or 16)
+#pragma unroll
+    for (int c0 = 0; c0 < 16 * CPRZ; c0 += 64) {
+        const int cidx = c0 + lane, at = cidx / CPRZ, ch = cidx - at * CPRZ;
+        const int64_t ida = __shfl(id, at, 64);                    // (lane `at` holds atom at's id: r = at, q = 0)
+        if (T.t * 16 + at < T.cnt) *(f32x4*)(a.z + ida * HP + 4 * ch) = *(const f32x4*)&zt[at * LZ + 4 * ch];
+    }
+}
+
+// Backward per tile:  dsim[n, block] = dz[n] W1[:, block]  ([16 x HP] . [HP x L]),  dW1[:, block] += dz^T sim  ([HP x 16] . [16 x L],
+// accumulators in registers over the block's tiles, then block -> slab -> fixed-order reduction, one slab image per block
+// holding only its degree's columns).
+template <int NT>
+__global__ void __launch_bounds__(256) block_project_bwd_mfma_kernel(BlockProjArgs a, int tiles_per_wave) {
+    constexpr int HP = 16 * NT, LZ = HP + 4;
+    extern __shared__ __align__(16) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r = lane & 15, q = lane >> 4;
+    // blocks bucket by bucket; a block takes 4 * tiles_per_wave consecutive tiles of its bucket
+    int di = -1; int64_t blk_in = 0;
+    {
+        int64_t b0 = 0;
+        for (int k = 0; k < MKGNN_MAX_DEGREE; ++k) {
+            const int64_t tiles = (a.cnt[k] + 15) / 16, per = 4 * (int64_t)tiles_per_wave;
+            const int64_t nb = a.L[k] > 0 ? (tiles + per - 1) / per : 0;
+            if (di < 0 && (int64_t)blockIdx.x < b0 + nb) { di = k; blk_in = blockIdx.x - b0; }
+            b0 += nb;
+        }
+    }
+    if (di < 0) return;
+    const int L = a.L[di], off = a.off[di], nj = (L + 15) / 16, LP = 16 * nj + 4;
+    const int64_t cnt = a.cnt[di];
+    float* const w1s = lds;                                        // [HP][LP]
+    float* const dzs = lds + HP * 68 + wave * (16 * LZ + 16 * 68); // per wave: dz tile [16][LZ] | sim tile [16][68]
+    float* const sms = dzs + 16 * LZ;
+    w1_block_to_lds(w1s, a, HP, L, off, LP, tid);
+    __syncthreads();
+    const int al = off & 3;
+    f32x4 accw[NT][4];
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) accw[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < tiles_per_wave; ++it) {
+        const int64_t tile = (blk_in * 4 + wave) * tiles_per_wave + it;
+        if (tile * 16 >= cnt) break;                               // (wave-uniform)
+        const int64_t p = tile * 16 + r, pc = p < cnt ? p : cnt - 1;
+        const int64_t id = a.sel[di][pc];
+        const bool valid = p < cnt;
+        // dz rows as the A operand of the dsim product (k = hidden unit 16 jh + 4 q + c); sim blocks for the dW1 product
+        f32x4 dzv[NT], sv[4];
+#pragma unroll
+        for (int jh = 0; jh < NT; ++jh) dzv[jh] = *(const f32x4*)(a.dz + id * HP + 16 * jh + 4 * q);
+        const float* row = a.sim + id * a.ss + off;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = 16 * j + 4 * q;
+            sv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (j < nj) {
+                if (col + 3 < L) sv[j] = load4_at(row + col, al);
+                else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) sv[j][c] = col + c < L ? row[col + c] : 0.f;
+                }
+            }
+        }
+#pragma unroll
+        for (int jh = 0; jh < NT; ++jh) {
+            if (!valid) dzv[jh] = f32x4{0.f, 0.f, 0.f, 0.f};       // (a padding atom of the last tile contributes nothing)
+            *(f32x4*)&dzs[r * LZ + 16 * jh + 4 * q] = dzv[jh];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (j < nj) *(f32x4*)&sms[r * 68 + 16 * j + 4 * q] = sv[j];
+        __builtin_amdgcn_wave_barrier();
+        // ---- dsim tile
+        if (a.dsim) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                if (t < nj) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int jh = 0; jh < NT; ++jh)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(dzv[jh][c], w1s[(16 * jh + 4 * q + c) * LP + 16 * t + r], acc, 0, 0, 0);
+                    const int col = 16 * t + r;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int at = 4 * q + i;
+                        const int64_t ida = __shfl(id, at, 64);
+                        if (tile * 16 + at < cnt && col < L) a.dsim[ida * a.dss + off + col] = acc[i];
+                    }
+                }
+            }
+        }
+        // ---- dW1 += dz^T . sim  (k = atom 4 s + q)
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            float av[NT], bv[4];
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt) av[mt] = dzs[(4 * s4 + q) * LZ + 16 * mt + r];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) bv[t] = t < nj ? sms[(4 * s4 + q) * 68 + 16 * t + r] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < NT; ++mt)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    if (t < nj) accw[mt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[t], accw[mt][t], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- block reduction of the four waves' accumulators (fixed order), one hidden tile at a time, then this block's slab:
+    // [HP][FP], only its degree's columns
+    float* const red = lds + HP * 68;                              // reuses the waves' tile images: [4 waves][4 column tiles][256]
+    float* slab = a.slab + (size_t)blockIdx.x * a.slab_stride;
+#pragma unroll
+    for (int mt = 0; mt < NT; ++mt) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[(wave * 4 + t) * 256 + i * 64 + lane] = accw[mt][t][i];
+        __syncthreads();
+        for (int e = tid; e < 4 * 256; e += 256) {
+            const int t = e >> 8, i = (e & 255) >> 6, ln = e & 63;
+            if (t < nj) {
+                const float sum = (red[(0 * 4 + t) * 256 + (e & 255)] + red[(1 * 4 + t) * 256 + (e & 255)]) +
+                                  (red[(2 * 4 + t) * 256 + (e & 255)] + red[(3 * 4 + t) * 256 + (e & 255)]);
+                // accumulator element (i, lane): row (hidden) 16 mt + 4 (ln >> 4) + i, column 16 t + (ln & 15)
+                const int hid = 16 * mt + 4 * (ln >> 4) + i, col = 16 * t + (ln & 15);
+                if (col < L) slab[(size_t)hid * a.FP + off + col] = sum;
+            }
+        }
     }
 }
 
@@ -1019,10 +1309,10 @@ ReadoutWs readout_ws(const ReadoutDims& d, int H, int G, int64_t nmol) {
     ReadoutWs w;
     auto up = [](size_t v) { return (v + 255) / 256 * 256; };
     w.slab_atoms_stride = d.HP * d.FP + d.HP;
-    w.slab_mol_stride = G * H + G;
+    w.slab_mol_stride = G * H + G + d.HP;              // (+ the db1 partial of the block-row readout)
     w.dA = 0;
     w.slab_atoms = up(w.dA + (size_t)nmol * d.HP * 4);
-    w.slab_mol = up(w.slab_atoms + (size_t)RO_ATOM_BLOCKS * w.slab_atoms_stride * 4);
+    w.slab_mol = up(w.slab_atoms + (size_t)2 * RO_ATOM_BLOCKS * w.slab_atoms_stride * 4);   // (block-row readout: up to 2 x)
     w.total = up(w.slab_mol + (size_t)RO_MOL_BLOCKS * w.slab_mol_stride * 4);
     return w;
 }
@@ -1135,6 +1425,175 @@ int mkgnn_readout_backward(const mkgnn_readout_params* p, const float* h, int64_
     if (blk) slab_reduce_kernel<<<blk, 256, 0, st>>>(r);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : api_hip_fail("mkgnn_readout_backward", e);
+}
+
+// ---- block-row readout: see block_project_mfma_kernel.  Its own limits: H, G <= 64 (the pool / per-molecule kernels), K <= 255
+// and every block <= 64 kernels; K may exceed the 128 columns of the dense tile-product kernels (they are not used here).
+static bool blocks_dims(int K, int H, int G, ReadoutDims& d) {
+    if (K < 1 || K > 255 || H < 1 || H > 64 || G < 1 || G > 64) return false;
+    d.NT = H <= 32 ? 2 : 4;
+    d.HP = 16 * d.NT;
+    d.FP = (K + 63) / 64 * 64;
+    d.NU = d.FP / 64;
+    return true;
+}
+
+static int check_blocks(const char* who, const mkgnn_readout_params* p, const int32_t num_kernels[MKGNN_MAX_DEGREE],
+                        const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE], int64_t n_atoms, int64_t sim_stride, const float* sim,
+                        BlockProjArgs& b, const ReadoutDims& d, int64_t* n_focal) {
+    if (!num_kernels || !buckets) return api_fail("%s: num_kernels / buckets is null", who);
+    int K = 0;
+    *n_focal = 0;
+    for (int i = 0; i < MKGNN_MAX_DEGREE; ++i) {
+        if (num_kernels[i] < 0 || num_kernels[i] > 64) return api_fail("%s: num_kernels[%d] = %d outside 0..64", who, i, num_kernels[i]);
+        b.off[i] = K; b.L[i] = num_kernels[i]; K += num_kernels[i];
+        b.cnt[i] = buckets[i].count; b.sel[i] = buckets[i].selected_index;
+        if (b.cnt[i] < 0 || (b.cnt[i] > 0 && !b.sel[i])) return api_fail("%s: degree %d bucket has no selected_index", who, i + 1);
+        *n_focal += b.cnt[i];
+    }
+    if (K != p->F) return api_fail("%s: lin1 takes %d columns, the blocks hold %d", who, p->F, K);
+    if (sim_stride < K || sim_stride % 4 || !sim || ((uintptr_t)sim & 15)) return api_fail("%s: sim rows must be 16-byte aligned", who);
+    if (*n_focal > n_atoms) return api_fail("%s: the buckets hold more atoms than the batch", who);
+    b.w1 = p->lin1_weight; b.H = p->H; b.K = K; b.HP = d.HP; b.FP = d.FP;
+    return 0;
+}
+
+size_t mkgnn_readout_blocks_workspace_bytes(int32_t K, int32_t H, int32_t G, int64_t n_mols) {
+    ReadoutDims d;
+    if (!blocks_dims(K, H, G, d) || n_mols < 0) return 0;
+    return readout_ws(d, H, G, n_mols).total;
+}
+
+int mkgnn_readout_blocks_supported(int32_t F, int32_t H, int32_t G, const int32_t num_kernels[MKGNN_MAX_DEGREE]) {
+    ReadoutDims d;
+    if (!num_kernels || !blocks_dims(F, H, G, d)) return 0;
+    int K = 0;
+    for (int i = 0; i < MKGNN_MAX_DEGREE; ++i) { if (num_kernels[i] < 0 || num_kernels[i] > 64) return 0; K += num_kernels[i]; }
+    return K == F;
+}
+
+int mkgnn_readout_blocks_forward(const mkgnn_readout_params* p, const float* sim, int64_t sim_stride,
+                                 const int32_t num_kernels[MKGNN_MAX_DEGREE], const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],
+                                 int64_t n_atoms, const int32_t* in_rowptr, const int32_t* in_col, const int32_t* mol_ptr,
+                                 int64_t n_mols, const float* keep_scale, float* z, float* pre, float* pooled, float* out,
+                                 int64_t out_stride, void* stream) {
+    const char* who = "mkgnn_readout_blocks_forward";
+    ReadoutDims d;
+    if (!p || !blocks_dims(p->F, p->H, p->G, d)) return api_fail("%s: shape outside K<=255, H<=64, G<=64", who);
+    if (!p->lin1_weight || !p->lin2_weight) return api_fail("%s: weight pointer is null", who);
+    if (n_atoms < 1 || n_mols < 1 || n_atoms >= (int64_t)1 << 31) return api_fail("%s: bad sizes", who);
+    if (!in_rowptr || !in_col || !mol_ptr || !z || !pre || !pooled || !out || out_stride < p->G)
+        return api_fail("%s: null pointer or bad out stride", who);
+    BlockProjArgs b{};
+    int64_t n_focal = 0;
+    if (int rc = check_blocks(who, p, num_kernels, buckets, n_atoms, sim_stride, sim, b, d, &n_focal)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    b.sim = sim; b.ss = sim_stride; b.n = n_atoms; b.z = z;
+    hipError_t e = hipSuccess;
+    if (n_focal < n_atoms) {                             // atoms in no bucket: their sim row is zero, and so is their z row
+        e = hipMemsetAsync(z, 0, (size_t)n_atoms * d.HP * 4, st);
+        if (e != hipSuccess) return api_hip_fail(who, e);
+    }
+    int64_t grid = 0;
+    for (int i = 0; i < MKGNN_MAX_DEGREE; ++i) if (b.L[i] > 0) grid += ((b.cnt[i] + 15) / 16 + 3) / 4;
+    if (grid > 0) {
+        const size_t lds = ((size_t)d.HP * 68 + 4 * 16 * (d.HP + 4)) * 4;
+        if (d.NT == 2) block_project_mfma_kernel<2><<<(unsigned)grid, 256, lds, st>>>(b);
+        else block_project_mfma_kernel<4><<<(unsigned)grid, 256, lds, st>>>(b);
+    }
+    // pre = propagate(z): the propagate step on H-wide rows (+ b1 where pre is read)
+    e = launch_segment_sum(z, d.HP, in_rowptr, in_col, n_atoms, d.HP, pre, d.HP, nullptr, st);
+    if (e != hipSuccess) return api_hip_fail(who, e);
+    ReadoutArgs a = readout_args(p, nullptr, 0, n_atoms, mol_ptr, nullptr, n_mols, keep_scale, pre, pooled);
+    a.out = out; a.os = out_stride; a.pre_bias = p->lin1_bias;
+    const int pgrid = (int)((n_mols + 3) / 4 < 2048 ? (n_mols + 3) / 4 : 2048);
+    readout_pool_kernel<<<pgrid, 256, 0, st>>>(a, d.HP);
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : api_hip_fail(who, e);
+}
+
+int mkgnn_readout_blocks_backward(const mkgnn_readout_params* p, const float* sim, int64_t sim_stride,
+                                  const int32_t num_kernels[MKGNN_MAX_DEGREE], const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],
+                                  int64_t n_atoms, const int32_t* out_rowptr, const int32_t* out_col, const int32_t* mol_ptr,
+                                  const int32_t* atom_mol, int64_t n_mols, const float* keep_scale, const float* pre,
+                                  const float* pooled, const float* grad_out, int64_t grad_out_stride, float* dpre, float* dz,
+                                  float* grad_sim, int64_t grad_sim_stride, float* grad_lin1_weight, float* grad_lin1_bias,
+                                  float* grad_lin2_weight, float* grad_lin2_bias, void* ws, size_t ws_bytes, void* stream) {
+    const char* who = "mkgnn_readout_blocks_backward";
+    ReadoutDims d;
+    if (!p || !blocks_dims(p->F, p->H, p->G, d)) return api_fail("%s: shape outside K<=255, H<=64, G<=64", who);
+    if (n_atoms < 1 || n_mols < 1 || n_atoms >= (int64_t)1 << 31) return api_fail("%s: bad sizes", who);
+    if (!out_rowptr || !out_col || !mol_ptr || !atom_mol || !pre || !pooled || !grad_out || grad_out_stride < p->G || !dpre || !dz)
+        return api_fail("%s: null pointer or bad grad_out stride", who);
+    BlockProjArgs b{};
+    int64_t n_focal = 0;
+    if (int rc = check_blocks(who, p, num_kernels, buckets, n_atoms, sim_stride, sim, b, d, &n_focal)) return rc;
+    if (grad_sim && grad_sim_stride < b.K) return api_fail("%s: bad grad_sim stride", who);
+    const ReadoutWs w = readout_ws(d, p->H, p->G, n_mols);
+    if (!ws || ws_bytes < w.total) return api_fail("%s: workspace too small (%zu < %zu)", who, ws_bytes, w.total);
+    hipStream_t st = (hipStream_t)stream;
+    ReadoutArgs a = readout_args(p, nullptr, 0, n_atoms, mol_ptr, atom_mol, n_mols, keep_scale, (float*)pre, (float*)pooled);
+    a.gout = grad_out; a.gos = grad_out_stride;
+    a.dA = (float*)((char*)ws + w.dA);
+    a.slab_atoms = (float*)((char*)ws + w.slab_atoms); a.slab_atoms_stride = w.slab_atoms_stride;
+    a.slab_mol = (float*)((char*)ws + w.slab_mol); a.slab_mol_stride = w.slab_mol_stride;
+    a.nblk_mol = (int)((n_mols + 15) / 16 < RO_MOL_BLOCKS ? (n_mols + 15) / 16 : RO_MOL_BLOCKS);
+    a.pre_bias = p->lin1_bias; a.dpre = dpre;
+    readout_bwd_mol_kernel<<<a.nblk_mol, 256, 0, st>>>(a, d.HP);
+    // d loss / d z = propagate^T (d loss / d pre): the same segment sum over the edges grouped by source
+    hipError_t e = launch_segment_sum(dpre, d.HP, out_rowptr, out_col, n_atoms, d.HP, dz, d.HP, nullptr, st);
+    if (e != hipSuccess) return api_hip_fail(who, e);
+    b.sim = sim; b.ss = sim_stride; b.n = n_atoms; b.dz = dz; b.dsim = grad_sim; b.dss = grad_sim_stride;
+    // blocks bucket by bucket, 4 * tiles_per_wave tiles each; at most 2 * RO_ATOM_BLOCKS blocks (the slab capacity)
+    int64_t tiles_all = 0;
+    for (int i = 0; i < MKGNN_MAX_DEGREE; ++i) if (b.L[i] > 0) tiles_all += (b.cnt[i] + 15) / 16;
+    int tpw = (int)((tiles_all + 4 * (2 * RO_ATOM_BLOCKS - 4) - 1) / (4 * (2 * RO_ATOM_BLOCKS - 4)));
+    if (tpw < 1) tpw = 1;
+    int64_t nb_of[MKGNN_MAX_DEGREE], nb = 0;
+    for (int i = 0; i < MKGNN_MAX_DEGREE; ++i) {
+        const int64_t tiles = (b.cnt[i] + 15) / 16, per = 4 * (int64_t)tpw;
+        nb_of[i] = b.L[i] > 0 ? (tiles + per - 1) / per : 0;
+        nb += nb_of[i];
+    }
+    if (nb > 2 * RO_ATOM_BLOCKS) return api_fail("%s: internal: %lld blocks for %d slabs", who, (long long)nb, 2 * RO_ATOM_BLOCKS);
+    b.slab = a.slab_atoms; b.slab_stride = a.slab_atoms_stride;
+    if (nb > 0) {
+        const size_t img = (size_t)4 * (16 * (d.HP + 4) + 16 * 68);
+        const size_t lds = ((size_t)d.HP * 68 + (img > 4096 ? img : 4096)) * 4;
+        if (d.NT == 2) block_project_bwd_mfma_kernel<2><<<(unsigned)nb, 256, lds, st>>>(b, tpw);
+        else block_project_bwd_mfma_kernel<4><<<(unsigned)nb, 256, lds, st>>>(b, tpw);
+    }
+    SlabReduceArgs r{};
+    int blk = 0;
+    auto add = [&](const float* src, int stride, int count, int src_cols, int rows, int cols, float* dst, int dst_stride) {
+        if (!dst || count < 1 || rows * cols < 1) return;
+        SlabSeg& sg = r.seg[r.nseg++];
+        sg.src = src; sg.stride = stride; sg.count = count; sg.src_cols = src_cols; sg.dst_rows = rows; sg.dst_cols = cols;
+        sg.dst = dst; sg.blk_start = blk; sg.dst_stride = dst_stride;
+        blk += (rows * cols + 31) / 32;
+    };
+    // dW1: per degree, the column window [H x L_d] of its blocks' slab images -> columns [off_d, off_d + L_d) of grad_lin1_weight
+    bool absent = false;
+    {
+        int64_t b0 = 0;
+        for (int i = 0; i < MKGNN_MAX_DEGREE; ++i) {
+            if (b.L[i] > 0 && nb_of[i] == 0) absent = true;
+            if (nb_of[i] > 0)
+                add(a.slab_atoms + (size_t)b0 * a.slab_atoms_stride + b.off[i], a.slab_atoms_stride, (int)nb_of[i], d.FP, p->H, b.L[i],
+                    grad_lin1_weight ? grad_lin1_weight + b.off[i] : nullptr, b.K);
+            b0 += nb_of[i];
+        }
+    }
+    if (absent && grad_lin1_weight) {                    // a degree without atoms: its columns of the gradient are zero
+        e = hipMemsetAsync(grad_lin1_weight, 0, (size_t)p->H * b.K * 4, st);
+        if (e != hipSuccess) return api_hip_fail(who, e);
+    }
+    add(a.slab_mol + p->G * p->H + p->G, a.slab_mol_stride, a.nblk_mol, d.HP, 1, p->H, grad_lin1_bias, 0);
+    add(a.slab_mol, a.slab_mol_stride, a.nblk_mol, p->H, p->G, p->H, grad_lin2_weight, 0);
+    add(a.slab_mol + p->G * p->H, a.slab_mol_stride, a.nblk_mol, p->G, 1, p->G, grad_lin2_bias, 0);
+    if (blk > 0) slab_reduce_kernel<<<blk, 256, 0, st>>>(r);
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : api_hip_fail(who, e);
 }
 
 size_t mkgnn_batchnorm_workspace_bytes(int32_t C) { return C > 0 ? (size_t)2 * BN_BLOCKS * C * 4 : 0; }

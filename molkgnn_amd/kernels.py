@@ -208,6 +208,22 @@ class BaseKernelSetConv(Module):
         out = self._run_impl(x, plan, is_last_layer, save_score, block_rows, fuse_propagate, prepared)
         return out if fuse_propagate else out[0]
 
+    def _run_block_rows(self, x, plan: BatchPlan, is_last_layer, prepared=None):
+        """The block rows of this layer's output for a consumer that is not ``propagate_add`` (the block-row readout), or
+        None where block rows do not apply (a fixed / trainable split, more than 255 kernels, ``out_pad`` set)."""
+        has_fixed = any(k is not None for k in self.fixed_kernelconv_set)
+        has_train = any(k is not None for k in self.trainable_kernelconv_set)
+        if not has_train or has_fixed or self.out_pad is not None:
+            return None
+        params, E = self._bank_params("train", x)
+        if not plan.block_rows_ok(sum(int(p.shape[0]) for p in params[0::7])):
+            return None
+        for d in range(1, 5):
+            if plan.buckets[d - 1].count and self.trainable_kernelconv_set[d - 1] is None:
+                return None
+        return Fn.kernelsetconv(x, plan, is_last_layer, params, E, self.variant, self.out_pad, block_rows=True,
+                                backward_variant=self.backward_variant, prepared=prepared)
+
     def _run_impl(self, x, plan: BatchPlan, is_last_layer, save_score, block_rows, fuse_propagate, prepared=None):
         for d in range(1, 5):
             if plan.buckets[d - 1].count and self.fixed_kernelconv_set[d - 1] is None \

@@ -145,6 +145,98 @@ class _ReadoutFn(torch.autograd.Function):
         return gh, gw1, gb1, gw2, gb2, None, None
 
 
+def _sel_buckets(plan):
+    bk = _lib.Buckets4()
+    for i, b in enumerate(plan.buckets):
+        bk[i].count = b.count
+        if b.count:
+            bk[i].selected_index = b.sel.data_ptr()
+    return bk
+
+
+class _ReadoutBlocksFn(torch.autograd.Function):
+    """``pool(lin2(dropout(swish(lin1(propagate(sim))))))`` from the block rows ``sim`` of the last kernel convolution:
+    ``mkgnn_readout_blocks_forward`` / ``_backward`` (projection first, then the propagate step on H-wide rows)."""
+
+    @staticmethod
+    def forward(ctx, sim, w1, b1, w2, b2, keep, seg: MoleculeSegments, plan, blocks):
+        lib = _lib.load()
+        _lib.require_gpu_tensor(sim, "sim_sc")
+        n, K = sim.shape
+        w1c, w2c = w1.contiguous(), w2.contiguous()
+        H, G = w1c.shape[0], w2c.shape[0]
+        dev = sim.device
+        hs = lib.mkgnn_readout_hidden_stride(H)
+        z = torch.empty((n, hs), dtype=torch.float32, device=dev)
+        pre = torch.empty((n, hs), dtype=torch.float32, device=dev)
+        pooled = torch.empty((seg.size, hs), dtype=torch.float32, device=dev)
+        out = torch.empty((seg.size, G), dtype=torch.float32, device=dev)
+        keepc = None if keep is None else keep.contiguous()
+        p = _params(w1c, b1, w2c, b2)
+        rowptr, col = plan.csr_in
+        with torch.cuda.device(dev):
+            _lib.check(lib.mkgnn_readout_blocks_forward(
+                p, sim.data_ptr(), _stride0(sim), _lib.Int32x4(*blocks), _sel_buckets(plan), n, rowptr.data_ptr(), col.data_ptr(),
+                seg.mol_ptr.data_ptr(), seg.size, _lib.ptr(keepc), z.data_ptr(), pre.data_ptr(), pooled.data_ptr(), out.data_ptr(), G,
+                _lib.stream_ptr(dev)), "mkgnn_readout_blocks_forward")
+        ctx.seg, ctx.plan, ctx.blocks = seg, plan, tuple(blocks)
+        ctx.save_for_backward(sim, w1c, b1, w2c, b2, keepc, pre, pooled)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        sim, w1, b1, w2, b2, keep, pre, pooled = ctx.saved_tensors
+        seg, plan, blocks = ctx.seg, ctx.plan, ctx.blocks
+        n, K = sim.shape
+        H, G = w1.shape[0], w2.shape[0]
+        dev = sim.device
+        g = _row_major(grad_out if grad_out.dtype == torch.float32 else grad_out.float())
+        hs = pre.shape[1]
+        dpre = torch.empty((n, hs), dtype=torch.float32, device=dev)
+        dz = torch.empty((n, hs), dtype=torch.float32, device=dev)
+        K4 = K + (-K) % 4
+        # block rows: only every atom's own block of the gradient is defined -- all the convolution's backward reads
+        gsim = torch.empty((n, K4), dtype=torch.float32, device=dev)[:, :K] if ctx.needs_input_grad[0] else None
+        gw1, gw2 = torch.empty_like(w1), torch.empty_like(w2)
+        gb1 = torch.empty_like(b1) if b1 is not None else None
+        gb2 = torch.empty_like(b2) if b2 is not None else None
+        p = _params(w1, b1, w2, b2)
+        bk = _sel_buckets(plan)
+        rowptr, col = plan.csr_out
+        with torch.cuda.device(dev):
+            ws_bytes = int(lib.mkgnn_readout_blocks_workspace_bytes(K, H, G, seg.size))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.mkgnn_readout_blocks_backward(
+                p, sim.data_ptr(), _stride0(sim), _lib.Int32x4(*blocks), bk, n, rowptr.data_ptr(), col.data_ptr(),
+                seg.mol_ptr.data_ptr(), seg.atom_mol.data_ptr(), seg.size, _lib.ptr(keep), pre.data_ptr(), pooled.data_ptr(),
+                g.data_ptr(), _stride0(g), dpre.data_ptr(), dz.data_ptr(), _lib.ptr(gsim), K4, gw1.data_ptr(), _lib.ptr(gb1),
+                gw2.data_ptr(), _lib.ptr(gb2), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)), "mkgnn_readout_blocks_backward")
+        return gsim, gw1, gb1, gw2, gb2, None, None, None, None
+
+
+def readout_blocks_supported(K: int, H: int, G: int, blocks) -> bool:
+    return bool(_lib.load().mkgnn_readout_blocks_supported(int(K), int(H), int(G), _lib.Int32x4(*[int(b) for b in blocks])))
+
+
+def readout_blocks(sim: torch.Tensor, plan, blocks, lin1: torch.nn.Linear, lin2: torch.nn.Linear,
+                   dropout: Optional[torch.nn.Dropout], seg: "MoleculeSegments") -> torch.Tensor:
+    """``readout(propagate_add(sim), ...)`` for the block rows ``sim`` of the LAST kernel convolution (``kernelsetconv(...,
+    block_rows=True)``; ``blocks`` = its four kernel counts): the projection ``lin1`` runs on every atom's own block first
+    and the propagate step carries H-wide rows (``_ReadoutBlocksFn``).  The caller checks ``readout_blocks_supported`` and
+    that the molecule segments are sorted."""
+    H = lin1.weight.shape[0]
+    p_drop = dropout.p if (dropout is not None and dropout.training) else 0.0
+    keep = None
+    if p_drop > 0.0:
+        keep = torch.empty((sim.shape[0], H), dtype=torch.float32, device=sim.device)
+        if p_drop >= 1.0:
+            keep.zero_()
+        else:
+            keep.bernoulli_(1.0 - p_drop).mul_(1.0 / (1.0 - p_drop))
+    return _ReadoutBlocksFn.apply(sim, lin1.weight, lin1.bias, lin2.weight, lin2.bias, keep, seg, plan, tuple(blocks))
+
+
 def readout(h: torch.Tensor, lin1: torch.nn.Linear, lin2: torch.nn.Linear, dropout: Optional[torch.nn.Dropout],
             batch: torch.Tensor, size: Optional[int] = None, segments: Optional["MoleculeSegments"] = None) -> torch.Tensor:
     """``global_add_pool(lin2(dropout(swish(lin1(h)))), batch, size)`` -> ``[size, G]``.  ``segments``: the molecule

@@ -418,6 +418,91 @@ def test_readout_matches_torch_formula(F, H, G, bias, drop):
         assert float((a - w).abs().max()) <= 2e-5 * max(float(w.abs().max()), 1.0), (a.shape, float((a - w).abs().max()))
 
 
+@pytest.mark.parametrize("counts,H,G,bias,drop,mols", [((10, 20, 30, 50), 32, 32, True, True, 300), ((5, 10, 15, 25), 33, 7, False, False, 37),
+                                                       ((1, 1, 1, 1), 5, 64, True, False, 60), ((16, 32, 48, 64), 64, 32, True, True, 90)])
+def test_block_row_readout_matches_torch_formula(counts, H, G, bias, drop, mols):
+    """readout.readout_blocks (mkgnn_readout_blocks_*: lin1 on every atom's own column block first, the propagate step on
+    H-wide rows) against  pool(lin2(dropout(swish(lin1(propagate(sim))))))  in PyTorch fp32 operators (KernelLayer.py:
+    119-123, MolKGNNNet.py:144-146): forward 1e-5 of the output scale, the gradient of sim on every atom's own block and all
+    four parameter gradients 2e-5 relative.  NaN is written everywhere outside the blocks: nothing may read it."""
+    from molkgnn_amd import readout as R
+    from molkgnn_amd.plan import plan_from_data
+    from molkgnn_amd.synthetic import make_batch
+    dev = _dev()
+    b = make_batch(mols, seed=sum(counts) + H, device=dev)
+    plan = plan_from_data(b)
+    n, K = b.x.shape[0], sum(counts)
+    g = torch.Generator().manual_seed(K * 100 + H)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    K4 = K + (-K) % 4
+    # block rows: atom n holds values only in the columns of its degree
+    deg = torch.zeros(n, dtype=torch.long)
+    for d in range(1, 5):
+        deg[getattr(b, f"selected_index_deg{d}").cpu()] = d
+    offs = [0, counts[0], counts[0] + counts[1], counts[0] + counts[1] + counts[2], K]
+    mask = torch.zeros(n, K, dtype=torch.bool)
+    for d in range(1, 5):
+        mask[deg == d, offs[d - 1]:offs[d]] = True
+    dense = torch.where(mask, rnd(n, K), torch.zeros(()))
+    store = torch.full((n, K4), float("nan"))
+    store[:, :K] = torch.where(mask, dense, torch.full((), float("nan")))
+    sim = store.to(dev)[:, :K].requires_grad_(True)
+    w1 = (rnd(H, K) * K ** -0.5).to(dev).requires_grad_(True)
+    w2 = (rnd(G, H) * H ** -0.5).to(dev).requires_grad_(True)
+    b1 = rnd(H).to(dev).requires_grad_(True) if bias else None
+    b2 = rnd(G).to(dev).requires_grad_(True) if bias else None
+    keep = ((torch.rand(n, H, generator=g) > 0.25).float() / 0.75).to(dev) if drop else None
+    cot = rnd(mols, G).to(dev)
+    seg = R.molecule_segments(b.batch, mols)
+    assert seg.sorted and R.readout_blocks_supported(K, H, G, counts)
+    out = R._ReadoutBlocksFn.apply(sim, w1, b1, w2, b2, keep, seg, plan, tuple(counts))
+    leaves = [t for t in (sim, w1, b1, w2, b2) if t is not None]
+    got = torch.autograd.grad((out * cot).sum(), leaves)
+    # the reference: dense sim (zeros outside the blocks) -> propagate -> readout, in PyTorch operators
+    sim_ref = dense.to(dev).requires_grad_(True)
+    h = torch.zeros(n, K, device=dev).index_add(0, b.edge_index[1], sim_ref[b.edge_index[0]])
+    ref = _torch_readout(h, w1, b1, w2, b2, keep, b.batch, mols)
+    want = torch.autograd.grad((ref * cot).sum(), [sim_ref] + leaves[1:])
+    scale = float(ref.detach().abs().max())
+    assert float((out - ref).detach().abs().max()) <= 1e-5 * max(scale, 1.0)
+    m = mask.to(dev)
+    gs, ws_ = got[0], want[0]
+    assert float((gs[m] - ws_[m]).abs().max()) <= 2e-5 * max(float(ws_.abs().max()), 1.0)
+    for a, w in zip(got[1:], want[1:]):
+        assert float((a - w).abs().max()) <= 2e-5 * max(float(w.abs().max()), 1.0), (a.shape, float((a - w).abs().max()))
+
+
+def test_model_with_block_row_readout_matches_the_propagate_then_readout_model(monkeypatch):
+    """MolKGNNNet with the last propagate left to the readout (MKGNN_PROJECT_FIRST) against the same model with
+    propagate -> readout: the same embedding to 1e-5 and every parameter's gradient to 2e-5 of its scale (the sums are
+    re-associated, nothing else), in training mode with batch-norm statistics, through the fused convolution backward."""
+    import copy
+    from molkgnn_amd import MolKGNNNet as M
+    from molkgnn_amd.synthetic import make_batch
+    from molkgnn_amd.train import GNNModel, backward
+    dev = _dev()
+    torch.manual_seed(4)
+    b = make_batch(700, seed=14).to(dev)
+    b.y = (torch.arange(700, device=dev) % 4 == 0).long()
+    m0 = GNNModel(num_layers=3, ffn_dropout_rate=0.0).to(dev)
+    m1 = copy.deepcopy(m0)
+    res = []
+    for model, flag in ((m0, '0'), (m1, '1')):
+        monkeypatch.setattr(M, "_PROJECT_FIRST", flag)
+        model.zero_grad(set_to_none=True)
+        emb = model.gnn_model(b)
+        loss = model.loss(b)
+        backward(loss)
+        torch.cuda.synchronize()
+        res.append((emb.detach().clone(), float(loss.detach()), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    (e0, l0, g0), (e1, l1, g1) = res
+    assert float((e0 - e1).abs().max()) <= 1e-5 * max(1.0, float(e0.abs().max()))
+    assert abs(l0 - l1) <= 2e-6 * max(1.0, abs(l0))
+    assert g0.keys() == g1.keys()
+    for n, gw in g0.items():
+        assert float((g1[n] - gw).abs().max()) <= 2e-5 * max(float(gw.abs().max()), 1e-3) + 1e-7, (n, float((g1[n] - gw).abs().max()))
+
+
 def test_readout_module_paths():
     """The module-level entry point: fused path, dropout in eval mode, an unsorted batch vector (PyTorch
     operators on the GPU) and an empty molecule in the middle of the batch."""
