@@ -404,10 +404,12 @@ int mkgnn_bce_head_fused(const float* emb, int64_t emb_stride, int64_t n_rows, i
 
 /* AdamW step over all trainable tensors of the model in one launch (reference model.py:368-385: torch.optim.AdamW,
  * two parameter groups -- kernel banks without weight decay).  Per tensor: param / grad [numel] fp32 contiguous,
- * state [2 * numel + 3] = exp_avg, exp_avg_sq, step count (as a float, advanced by this call), two scratch floats.  Per group: the
+ * state [mkgnn_adamw_state_floats(numel)] = exp_avg, exp_avg_sq, step count (as a float, advanced by this call), two reserved
+ * floats, then one copy of the step count per 1024 elements (every block of the update advances its own: one launch per
+ * step, no counting pass; a caller that sets the step count sets every copy).  Per group: the
  * learning rate either by value (lr_device NULL) or read from a device float at run time (so that a captured graph
  * follows a scheduler), betas, eps, decoupled weight_decay, maximize, grad_scale.  The update is torch's fused AdamW formula
- * (bias corrections 1 - beta^step).  At most 4 groups; any number of tensors (80 per launch pair). */
+ * (bias corrections 1 - beta^step).  At most 4 groups; any number of tensors (80 per launch). */
 typedef struct mkgnn_adamw_tensor {
     float* param;
     const float* grad;
@@ -424,6 +426,7 @@ typedef struct mkgnn_adamw_group {
     int32_t maximize;
     float grad_scale;      /* every gradient is multiplied by this first (1 / world size after a summing all-reduce; else 1) */
 } mkgnn_adamw_group;
+int64_t mkgnn_adamw_state_floats(int64_t numel);
 int mkgnn_adamw_step(const mkgnn_adamw_tensor* tensors, int32_t n_tensors, const mkgnn_adamw_group* groups,
                      int32_t n_groups, void* stream);
 

@@ -100,13 +100,20 @@ struct ForkJoin {
         main = st; p = enable ? degree_streams() : nullptr;
         used[0] = used[1] = used[2] = false;
         if (!p) return hipSuccess;
-        return hipEventRecord(p->fork, main);
+        // (inside a capture the fork point is recorded where the helper is first needed: a fork here, ahead of the pre-pass,
+        // would give the kernel before it a second child in the graph -- a cross-stream edge costs the caller's chain ~5 us --
+        // and the helper's kernels all follow the re-fork behind the pre-pass anyway)
+        return two_way ? hipSuccess : hipEventRecord(p->fork, main);
     }
     hipStream_t stream(int slot, hipError_t* e) {
         *e = hipSuccess;
         if (!p || slot == 0) return main;
         const int i = slot - 1;
-        if (!used[i]) { *e = hipStreamWaitEvent(p->aux[i], p->fork, 0); used[i] = true; }
+        if (!used[i]) {
+            if (two_way) *e = hipEventRecord(p->fork, main);
+            if (*e == hipSuccess) *e = hipStreamWaitEvent(p->aux[i], p->fork, 0);
+            used[i] = true;
+        }
         return p->aux[i];
     }
     // order the helper after everything enqueued on the caller's stream so far (a second fork point)
@@ -549,8 +556,10 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
                 if (fj.two_way && !rows_mfma) bank_on_main = true;
                 if (fj.two_way && rows_mfma) {
                     st_rows = st;
-                    st_bank = fj.stream(1, &e);
-                    if (e != hipSuccess) return hip_fail("stream fork", e);
+                    if (!fuse_bank) {                        // (fused: the bank kernels are launched below, behind the pre-pass's re-fork)
+                        st_bank = fj.stream(1, &e);
+                        if (e != hipSuccess) return hip_fail("stream fork", e);
+                    }
                 }
                 if (rows_mfma && !rows_streamed && (grad_x || !fuse_bank)) {
                     e = launch_backward_rows_mfma(d, a, &ntheta, st_rows);

@@ -64,7 +64,7 @@ __device__ __forceinline__ void bank_prepare_task(const PrepArgs& a, const int t
     const int d = i + 1;
     const int L = a.bank[i].num_kernels;
     int r = task - a.row_start[i];
-    // task order inside a degree: L centre rows, L*d support rows, L*d edge rows, 1 misc task
+    // task order inside a degree: L centre rows, L*d support rows, L*d edge rows, 1 misc task, degree 4: ceil(12 L / 64) table tasks
     const float* src;
     float* dst;
     float* inv;
@@ -83,8 +83,17 @@ __device__ __forceinline__ void bank_prepare_task(const PrepArgs& a, const int t
         r -= L + L * d;
         src = a.bank[i].edge_attr_support + (size_t)r * a.E; dst = a.edg[i] + (size_t)r * a.E; inv = a.iedg[i] + r; width = a.E;
         if (a.E <= 8) { pad_dst = a.edge_padded[i] + ((size_t)(r % d) * L + r / d) * 8; pad_width = 8; }
+    } else if (r > L + 2 * L * d) {
+        // chirality table (kernels.py:331-341), 64 entries per task: every entry is a chain of dependent loads
+        const int t = (r - (L + 2 * L * d) - 1) * 64 + lane;
+        if (d == 4 && a.bank[i].p_support != nullptr && t < L * 12) {
+            const int l = t / 12, p = t % 12;
+            const float* ps = a.bank[i].p_support + (size_t)l * 12;   // [4, 3]
+            a.chir[i][t] = (int8_t)triple_sign(ps + 3 * PERM4[p][0], ps + 3 * PERM4[p][1], ps + 3 * PERM4[p][2]);
+        }
+        return;
     } else {
-        // misc: mixing weights (kernels.py:402-412) and chirality table (:331-341)
+        // misc: mixing weights (kernels.py:402-412)
         if (lane == 0) {
             float es = expf(*a.bank[i].support_attr_sc_weight);
             float ec = expf(*a.bank[i].center_attr_sc_weight);
@@ -93,16 +102,6 @@ __device__ __forceinline__ void bank_prepare_task(const PrepArgs& a, const int t
             float ws = es / den, wc = ec / den, we = ee / den;
             a.mix[i][0] = ws; a.mix[i][1] = wc; a.mix[i][2] = we;
             a.mix[i][3] = __fadd_rn(__fadd_rn(ws, wc), we);
-        }
-        if (d == 4 && a.bank[i].p_support != nullptr) {
-            for (int t = lane; t < L * 12; t += 64) {
-                int l = t / 12, p = t % 12;
-                const float* ps = a.bank[i].p_support + (size_t)l * 12;   // [4, 3]
-                const float* t1 = ps + 3 * PERM4[p][0];
-                const float* t2 = ps + 3 * PERM4[p][1];
-                const float* t3 = ps + 3 * PERM4[p][2];
-                a.chir[i][t] = (int8_t)triple_sign(t1, t2, t3);
-            }
         }
         return;
     }
@@ -619,7 +618,7 @@ static int fill_prep_args(PrepArgs& a, const mkgnn_kernel_bank banks[4], const W
         a.chir[i] = (int8_t*)(ws + w.bank[i].chir); a.mix[i] = (float*)(ws + w.bank[i].mix);
         a.padded[i] = (float*)(ws + w.bank[i].padded); a.edge_padded[i] = (float*)(ws + w.bank[i].edge_padded);
         int L = banks[i].num_kernels, d = i + 1;
-        a.row_start[i + 1] = a.row_start[i] + (L > 0 ? L + 2 * L * d + 1 : 0);
+        a.row_start[i + 1] = a.row_start[i] + (L > 0 ? L + 2 * L * d + 1 + (d == 4 ? (12 * L + 63) / 64 : 0) : 0);
     }
     return a.row_start[4];
 }

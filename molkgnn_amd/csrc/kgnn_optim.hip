@@ -4,9 +4,9 @@
 // from weight decay).  MolKGNN has ~80 small trainable tensors (132 k floats in all): PyTorch's fused multi-tensor
 // path needs two launches per group plus one per group for the step counters -- five launch-bound kernels, ~40 us
 // of a 1.3 ms training step, for 2 MB of traffic.  Here the tensor table travels in the kernel arguments (pointers
-// are baked into a captured graph exactly like PyTorch's), one block per 1024 elements.  A one-block kernel ahead of
-// it advances the per-tensor step counters and computes the bias corrections (a "last block done" counter inside
-// the update kernel was measured at 27 us for the pair of device-scope fences it needs; two plain launches take 10).
+// are baked into a captured graph exactly like PyTorch's), one block per 1024 elements, each with its own copy of the
+// tensor's step counter (round 2: a one-block kernel ahead of it advanced the counters -- 10 us for the pair; a "last block
+// done" counter inside the update kernel was measured at 27 us for the two device-scope fences it needs).
 //
 // Arithmetic: the update of torch's fused kernel (fused_adam_utils.cuh, ADAMW mode), in the same order:
 //   p -= lr * wd * p;  m += (1 - b1) (g - m);  v = b2 v + (1 - b2) g g;
@@ -29,22 +29,12 @@ struct AdamArgs {
     int32_t nt;
 };
 
-// One thread per tensor: advance its step counter and leave the two bias-correction factors next to it
-// (double-precision pow once per tensor instead of once per thread of the update kernel).
-__global__ void __launch_bounds__(128) adamw_count_kernel(AdamArgs a) {
-    const int ti = threadIdx.x;
-    if (ti >= a.nt) return;
-    const AdamTensor T = a.t[ti];
-    const AdamGroup G = a.grp[T.group];
-    if (T.active && *T.active == 0.f) return;                // no gradient anywhere this step: the step count stands still
-    float* tail = T.state + 2 * (size_t)T.n;
-    const double t = (double)tail[0] + 1.0;
-    tail[0] = (float)t;
-    tail[1] = (float)(1.0 - pow((double)G.beta1, t));
-    tail[2] = sqrtf((float)(1.0 - pow((double)G.beta2, t)));
-}
-
+// state of a tensor: [exp_avg | exp_avg_sq | step | 2 reserved | one step counter per block of the tensor].  Every block
+// advances ITS OWN copy of the step count and derives the bias corrections from it (two double-precision pow per block), so
+// no block reads a counter another block writes: the separate one-block counting kernel of round 2 (a dependent launch,
+// 4 us of every step) is gone.  Block 0 also writes the canonical `step` the caller's state_dict reads.
 __global__ void __launch_bounds__(256) adamw_step_kernel(AdamArgs a) {
+    __shared__ float bc[2];
     // block -> tensor: the last ti with blk_start[ti] <= blockIdx.x
     int lo = 0, hi = a.nt - 1;
     while (lo < hi) {
@@ -52,14 +42,13 @@ __global__ void __launch_bounds__(256) adamw_step_kernel(AdamArgs a) {
         if (a.blk_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
     const AdamTensor T = a.t[lo];
-    if (T.active && *T.active == 0.f) return;                // (block-uniform)
+    if (T.active && *T.active == 0.f) return;                // (block-uniform) no gradient anywhere this step: the step count stands still
     const AdamGroup G = a.grp[T.group];
     const float lr = G.lr_ptr ? *G.lr_ptr : G.lr;
     float* m = T.state;
     float* v = T.state + T.n;
-    const float bc1 = T.state[2 * (size_t)T.n + 1], bc2_sqrt = T.state[2 * (size_t)T.n + 2];
-    const float step_size = lr / bc1;
-    const int base = ((int)blockIdx.x - a.blk_start[lo]) * ADAM_CHUNK;
+    const int blk = (int)blockIdx.x - a.blk_start[lo];
+    const int base = blk * ADAM_CHUNK;
     float g[ADAM_CHUNK / 256], p[ADAM_CHUNK / 256], mi[ADAM_CHUNK / 256], vi[ADAM_CHUNK / 256];
 #pragma unroll
     for (int k = 0; k < ADAM_CHUNK / 256; ++k) {          // all loads first (clamped), then the arithmetic
@@ -67,6 +56,17 @@ __global__ void __launch_bounds__(256) adamw_step_kernel(AdamArgs a) {
         const int ic = i < T.n ? i : T.n - 1;
         g[k] = T.g[ic]; p[k] = T.p[ic]; mi[k] = m[ic]; vi[k] = v[ic];
     }
+    if (threadIdx.x == 0) {
+        float* tail = T.state + 2 * (size_t)T.n;
+        const double t = (double)tail[3 + blk] + 1.0;
+        tail[3 + blk] = (float)t;
+        if (blk == 0) tail[0] = (float)t;
+        bc[0] = (float)(1.0 - pow((double)G.beta1, t));
+        bc[1] = sqrtf((float)(1.0 - pow((double)G.beta2, t)));
+    }
+    __syncthreads();
+    const float bc1 = bc[0], bc2_sqrt = bc[1];
+    const float step_size = lr / bc1;
 #pragma unroll
     for (int k = 0; k < ADAM_CHUNK / 256; ++k) {
         const int i = base + 256 * k + (int)threadIdx.x;
@@ -86,6 +86,10 @@ __global__ void __launch_bounds__(256) adamw_step_kernel(AdamArgs a) {
 }  // namespace mkgnn
 
 using namespace mkgnn;
+
+extern "C" int64_t mkgnn_adamw_state_floats(int64_t numel) {
+    return numel < 1 ? 0 : 2 * numel + 3 + (numel + ADAM_CHUNK - 1) / ADAM_CHUNK;
+}
 
 extern "C" int mkgnn_adamw_step(const mkgnn_adamw_tensor* tensors, int32_t n_tensors, const mkgnn_adamw_group* groups,
                                 int32_t n_groups, void* stream) {
@@ -114,7 +118,6 @@ extern "C" int mkgnn_adamw_step(const mkgnn_adamw_tensor* tensors, int32_t n_ten
         }
         a.blk_start[nt] = blocks;
         a.nt = nt;
-        adamw_count_kernel<<<1, 128, 0, st>>>(a);
         adamw_step_kernel<<<blocks, 256, 0, st>>>(a);
     }
     hipError_t e = hipGetLastError();

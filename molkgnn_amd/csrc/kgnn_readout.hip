@@ -965,7 +965,7 @@ struct HeadArgs {
     int64_t* rng;                  // forward: {seed, offset}, offset advanced by one per launch
     int64_t* rng_used;             // forward writes / backward reads the {seed, offset} of this call's mask
 };
-constexpr int HEAD_ROWS = 64;       // rows per block
+constexpr int HEAD_ROWS = 16;       // rows per block (two per half-wave: the block's latency is one row's chain, mostly its Philox rounds)
 
 // Philox4x32-10 (Salmon et al., SC'11): counter-based, so the backward regenerates the forward's mask instead of
 // storing it.  counter = (element / 4, offset), key = seed; element e takes word e % 4.

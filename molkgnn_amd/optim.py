@@ -49,12 +49,17 @@ class FusedAdamW(torch.optim.Optimizer):
         self._table_key = None
         self.prepare_state(list(flags))                      # flagged parameters are stepped on the device's say-so: state must exist
 
-    # -- state: one buffer per parameter, [exp_avg | exp_avg_sq | step | 2 scratch]; the three state entries are views of it --
+    # -- state: one buffer per parameter, [exp_avg | exp_avg_sq | step | 2 reserved | a step count per 1024 elements]
+    # (mkgnn_adamw_state_floats); the three state entries are views of it --
+    @staticmethod
+    def _state_floats(n: int) -> int:
+        return 2 * n + 3 + (n + 1023) // 1024
+
     def _packed_state(self, p: torch.Tensor) -> torch.Tensor:
         st = self.state[p]
         n = p.numel()
         buf = st.get("_packed")
-        if buf is not None and st["exp_avg"].data_ptr() == buf.data_ptr() and st["step"].data_ptr() == buf[2 * n:].data_ptr() and buf.numel() == 2 * n + 3:
+        if buf is not None and st["exp_avg"].data_ptr() == buf.data_ptr() and st["step"].data_ptr() == buf[2 * n:].data_ptr() and buf.numel() == self._state_floats(n):
             return buf
         if p.is_cuda and torch.cuda.is_current_stream_capturing():
             # a zero fill recorded into a graph would reset exp_avg / exp_avg_sq / step at EVERY replay (and, data-parallel,
@@ -62,11 +67,12 @@ class FusedAdamW(torch.optim.Optimizer):
             raise _lib.MolKGNNLibraryError(
                 "FusedAdamW: optimiser state would be allocated inside a hipGraph capture -- call prepare_state() (or run "
                 "one eager step in which every parameter has a gradient) before capturing")
-        new = torch.zeros(2 * n + 3, dtype=torch.float32, device=p.device)   # + step, two scratch floats of the kernels
+        new = torch.zeros(self._state_floats(n), dtype=torch.float32, device=p.device)
         if "exp_avg" in st:                                  # e.g. loaded from a state_dict (ours or torch.optim.AdamW's)
             new[:n] = st["exp_avg"].reshape(-1).to(new)
             new[n:2 * n] = st["exp_avg_sq"].reshape(-1).to(new)
             new[2 * n] = float(st["step"])
+            new[2 * n + 3:] = float(st["step"])              # (the update's per-block copies of the step count)
         st["_packed"] = new
         st["exp_avg"] = new[:n].view_as(p)
         st["exp_avg_sq"] = new[n:2 * n].view_as(p)

@@ -266,7 +266,10 @@ def test_fused_adamw_host_side():
     opt2.load_state_dict(ref.state_dict())
     st = opt2.state[p]
     buf = st["_packed"]
-    assert buf.numel() == 2 * 15 + 3 and float(st["step"]) == 1.0
+    from molkgnn_amd import _lib
+    assert buf.numel() == 2 * 15 + 3 + 1 == _lib.load().mkgnn_adamw_state_floats(15) and float(st["step"]) == 1.0
+    assert all(FusedAdamW._state_floats(n) == _lib.load().mkgnn_adamw_state_floats(n) for n in (1, 1023, 1024, 1025, 22000))
+    assert float(buf[2 * 15 + 3]) == 1.0                      # the update's per-block copy of the step count follows the loaded one
     assert st["exp_avg"].data_ptr() == buf.data_ptr() and st["exp_avg"].shape == p.shape
     assert torch.equal(st["exp_avg"], ref.state[p]["exp_avg"]) and torch.equal(st["exp_avg_sq"], ref.state[p]["exp_avg_sq"])
     assert "_packed" not in next(iter(opt2.state_dict()["state"].values()))
