@@ -268,8 +268,12 @@ int mkgnn_readout_backward(const mkgnn_readout_params* params, const float* h, i
  *   sim [n_atoms, K] block rows (as MKGNN_VARIANT_BLOCK_ROWS leaves them), K = sum num_kernels = params->F, num_kernels <= 64
  *   buckets: only count and selected_index are read (the projection works on 16-atom tiles of one degree bucket, on the
  *   matrix cores); in_* / out_*: mkgnn_plan_build's CSRs of edge_index by target / by source
- *   z, pre (forward), dpre, dz (backward): [n_atoms, HS], HS = mkgnn_readout_hidden_stride(H); pre (WITHOUT b1) and
- *   pooled are kept for the backward.  grad_sim: [n_atoms, K] block rows (every atom's own block is written), may be NULL.
+ *   z, pre (forward), dz (backward): [n_atoms, HS], HS = mkgnn_readout_hidden_stride(H); pooled, gate_sum [n_mols, HS].
+ *   gate_sum NULL (inference): pre holds propagate(z), WITHOUT b1.  gate_sum non-NULL (a backward will follow): the forward
+ *   leaves  gate = keep_scale * swish'(pre + b1)  IN PLACE of pre and its per-molecule sums in gate_sum; the backward takes
+ *   that buffer as `gate` (d loss / d pre = dA[molecule] * gate is formed on the fly inside the propagate^T pass; db1 comes
+ *   from gate_sum) and needs neither keep_scale nor pre.  grad_sim: [n_atoms, K] block rows (every atom's own block is
+ *   written), may be NULL.
  * Limits: K <= 255, every block <= 64 kernels, H <= 64, G <= 64.  Workspace of the backward:
  * mkgnn_readout_blocks_workspace_bytes. */
 size_t mkgnn_readout_blocks_workspace_bytes(int32_t K, int32_t H, int32_t G, int64_t n_mols);
@@ -278,15 +282,15 @@ int mkgnn_readout_blocks_forward(const mkgnn_readout_params* params, const float
                                  const int32_t num_kernels[MKGNN_MAX_DEGREE],
                                  const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE], int64_t n_atoms,
                                  const int32_t* in_rowptr, const int32_t* in_col, const int32_t* mol_ptr, int64_t n_mols,
-                                 const float* keep_scale, float* z, float* pre, float* pooled,
+                                 const float* keep_scale, float* z, float* pre, float* pooled, float* gate_sum,
                                  float* out, int64_t out_stride, void* stream);
 int mkgnn_readout_blocks_backward(const mkgnn_readout_params* params, const float* sim, int64_t sim_stride,
                                   const int32_t num_kernels[MKGNN_MAX_DEGREE],
                                   const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE], int64_t n_atoms,
                                   const int32_t* out_rowptr, const int32_t* out_col, const int32_t* mol_ptr,
-                                  const int32_t* atom_mol, int64_t n_mols, const float* keep_scale, const float* pre,
+                                  const int32_t* atom_mol, int64_t n_mols, const float* gate, const float* gate_sum,
                                   const float* pooled, const float* grad_out, int64_t grad_out_stride,
-                                  float* dpre, float* dz, float* grad_sim, int64_t grad_sim_stride,
+                                  float* dz, float* grad_sim, int64_t grad_sim_stride,
                                   float* grad_lin1_weight, float* grad_lin1_bias, float* grad_lin2_weight,
                                   float* grad_lin2_bias, void* workspace, size_t workspace_bytes, void* stream);
 

@@ -155,10 +155,10 @@ def load() -> C.CDLL:
     lib.mkgnn_readout_blocks_supported.restype = C.c_int
     lib.mkgnn_readout_blocks_supported.argtypes = [I32, I32, I32, Int32x4]
     lib.mkgnn_readout_blocks_forward.restype = C.c_int
-    lib.mkgnn_readout_blocks_forward.argtypes = [C.POINTER(ReadoutParams), P, I64, Int32x4, Buckets4, I64, P, P, P, I64, P, P, P, P, P, I64, P]
+    lib.mkgnn_readout_blocks_forward.argtypes = [C.POINTER(ReadoutParams), P, I64, Int32x4, Buckets4, I64, P, P, P, I64, P, P, P, P, P, P, I64, P]
     lib.mkgnn_readout_blocks_backward.restype = C.c_int
     lib.mkgnn_readout_blocks_backward.argtypes = [C.POINTER(ReadoutParams), P, I64, Int32x4, Buckets4, I64, P, P, P, P, I64, P, P, P,
-                                                  P, I64, P, P, P, I64, P, P, P, P, P, C.c_size_t, P]
+                                                  P, I64, P, P, I64, P, P, P, P, P, C.c_size_t, P]
     lib.mkgnn_batchnorm_workspace_bytes.restype = C.c_size_t
     lib.mkgnn_batchnorm_workspace_bytes.argtypes = [I32]
     lib.mkgnn_batchnorm_forward.restype = C.c_int

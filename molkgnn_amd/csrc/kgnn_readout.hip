@@ -43,7 +43,8 @@ struct ReadoutArgs {
     float* slab_mol; int slab_mol_stride; int nblk_mol;
     // block-row readout (mkgnn_readout_blocks_*): `pre` holds propagate(W1 sim) WITHOUT the bias, added where it is read
     const float* pre_bias;         // b1 (or null: pre includes it)
-    float* dpre;                   // [n, HP]: readout_bwd_mol_kernel also writes d loss / d pre of its molecules' atoms
+    float* gsum;                   // [nmol, HP] or null.  Forward (pool kernel): `pre` is OVERWRITTEN with the gate keep * swish'(pre + b1)
+                                   // the backward multiplies by, gsum receives its per-molecule sums; backward (mol kernel): db1 from it
 };
 
 __device__ __forceinline__ float sigmoid_f(float p) { return 1.f / (1.f + expf(-p)); }
@@ -137,7 +138,7 @@ __global__ void __launch_bounds__(256) readout_pool_kernel(ReadoutArgs a, int HP
     const float pb = (a.pre_bias && c < H) ? a.pre_bias[c] : 0.f;
     for (int64_t mol = (int64_t)blockIdx.x * 4 + wave; mol < a.nmol; mol += (int64_t)gridDim.x * 4) {
         const int lo = a.mol_ptr[mol], hi = a.mol_ptr[mol + 1];
-        float s = 0.f;
+        float s = 0.f, gs = 0.f;
         for (int at0 = lo + gid; at0 < hi; at0 += 4 * groups) {
             float p[4], k[4];
 #pragma unroll
@@ -149,13 +150,21 @@ __global__ void __launch_bounds__(256) readout_pool_kernel(ReadoutArgs a, int HP
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const float v = p[u] * sigmoid_f(p[u]) * k[u];
-                if (at0 + u * groups < hi) s += v;
+                const float sg = sigmoid_f(p[u]);
+                const float v = p[u] * sg * k[u];
+                if (at0 + u * groups < hi) {
+                    s += v;
+                    if (a.gsum) {                                // (wave-uniform) training: leave the backward's gate in place of pre
+                        const float gate = c < H ? k[u] * (sg * fmaf(p[u], 1.f - sg, 1.f)) : 0.f;
+                        a.pre[(int64_t)(at0 + u * groups) * HP + c] = gate;
+                        gs += gate;
+                    }
+                }
             }
         }
-        if (groups == 2) s += __shfl_xor(s, 32, 64);
-        else if (groups == 4) { s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64); }
-        if (gid == 0) { a.pooled[mol * HP + c] = s; scr[wave][c] = s; }
+        if (groups == 2) { s += __shfl_xor(s, 32, 64); gs += __shfl_xor(gs, 32, 64); }
+        else if (groups == 4) { s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64); gs += __shfl_xor(gs, 16, 64); gs += __shfl_xor(gs, 32, 64); }
+        if (gid == 0) { a.pooled[mol * HP + c] = s; scr[wave][c] = s; if (a.gsum) a.gsum[mol * HP + c] = gs; }
         __builtin_amdgcn_wave_barrier();
         if (lane < G) {
             float z = 0.f;
@@ -217,7 +226,6 @@ __global__ void __launch_bounds__(256) readout_bwd_mol_kernel(ReadoutArgs a, int
                 if (256 * k < G * H) accw[k] = fmaf(dzs[m][po[k]], As[m][pc[k]], accw[k]);      // (uniform: G * H = 1024 uses 4 of 16)
             if (tid < G) accb = fmaf(nat[m], dzs[m][tid], accb);
         }
-        if (a.dpre) __syncthreads();                         // (As is rewritten below: everybody is done with the pooled rows)
         for (int i = tid; i < MC * HP; i += 256) {
             const int m = i / HP, c = i - m * HP;
             if (m0 + m < m_hi) {
@@ -225,37 +233,9 @@ __global__ void __launch_bounds__(256) readout_bwd_mol_kernel(ReadoutArgs a, int
                 if (c < H)
                     for (int o = 0; o < G; ++o) v = fmaf(dzs[m][o], w2s[o * (H + 1) + c], v);
                 a.dA[(m0 + m) * HP + c] = v;
-                As[m][c] = v;                                // (pooled is no longer needed: the chunk's dA for the atom pass below)
-            }
-        }
-        if (a.dpre) {
-            // block-row readout: d loss / d pre of the chunk's atoms, dpre[n, c] = dA[mol(n), c] * keep * swish'(pre + b1);
-            // a thread's column c = tid % HP is fixed (HP divides 256): its share of db1 = sum_n dpre[n, c] stays in a register
-            __syncthreads();
-            const int64_t mlast = (m0 + MC < m_hi ? m0 + MC : m_hi);
-            const int at_lo = a.mol_ptr[m0], at_hi = a.mol_ptr[mlast];
-            const int c = tid & (HP - 1);
-            const float pb = (a.pre_bias && c < H) ? a.pre_bias[c] : 0.f;
-            for (int at0 = at_lo + tid / HP; at0 < at_hi; at0 += 4 * (256 / HP)) {
-                float pv[4], kv[4]; int mv[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int at = at0 + u * (256 / HP);
-                    const int atc = at < at_hi ? at : at_hi - 1;
-                    pv[u] = a.pre[(int64_t)atc * HP + c];
-                    kv[u] = (a.keep && c < H) ? a.keep[(int64_t)atc * H + c] : 1.f;
-                    mv[u] = a.atom_mol[atc];
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int at = at0 + u * (256 / HP);
-                    if (at < at_hi) {
-                        const float p = pv[u] + pb, sg = sigmoid_f(p);
-                        const float d = (c < H) ? As[mv[u] - (int)m0][c] * (sg * fmaf(p, 1.f - sg, 1.f)) * kv[u] : 0.f;
-                        a.dpre[(int64_t)at * HP + c] = d;
-                        accb1 += d;
-                    }
-                }
+                // block-row readout: db1 = sum_n dpre[n] = sum_mol dA[mol] * (sum of the molecule's gates); a thread's column
+                // c = tid % HP is fixed (HP divides 256)
+                if (a.gsum && c < H) accb1 = fmaf(v, a.gsum[(m0 + m) * HP + c], accb1);
             }
         }
     }
@@ -263,7 +243,7 @@ __global__ void __launch_bounds__(256) readout_bwd_mol_kernel(ReadoutArgs a, int
 #pragma unroll
     for (int k = 0; k < 16; ++k) { const int p = tid + 256 * k; if (p < G * H) slab[p] = accw[k]; }
     if (tid < G) slab[G * H + tid] = accb;
-    if (a.dpre) {                                            // db1 partial of this block: the 256 / HP row groups in a fixed order
+    if (a.gsum) {                                            // db1 partial of this block: the 256 / HP thread groups in a fixed order
         __syncthreads();
         float* red = &dzs[0][0];                             // (MC * 64 >= 256 floats)
         red[tid] = accb1;
@@ -468,6 +448,44 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(SlabReduceArgs a) {
 }
 
 // ---------------------------------------------------------------------- block-row readout (round 3) ----
+// d loss / d z = propagate^T(dpre), dpre[t] = dA[mol(t)] * gate[t] taken on the fly (gate = keep * swish'(pre + b1), left
+// in place of pre by the forward's pool kernel): row n of dz is the sum of dpre over n's neighbours t (the CSR of the edges by
+// source) -- the [N x H] dpre array is never written or read.  CPR lanes per row (16-byte chunks of the HP-wide rows),
+// 256 / CPR rows per pass; the first four neighbours' loads are all in flight at once (atoms have at most four neighbours
+// but for a handful: the rest of such a row follows serially).
+struct DzArgs {
+    const float* dA; const float* gate; const int32_t* atom_mol;
+    const int32_t* rowptr; const int32_t* col; int64_t n;
+    float* dz;
+};
+constexpr int DZ_BLOCKS = 2048;
+
+template <int CPR>
+__global__ void __launch_bounds__(256) readout_dz_gather_kernel(DzArgs a) {
+    constexpr int HP = 4 * CPR, RPB = 256 / CPR;
+    const int tid = threadIdx.x, l = tid % CPR, rs = tid / CPR, c0 = 4 * l;
+    for (int64_t r = (int64_t)blockIdx.x * RPB + rs; r < a.n; r += (int64_t)gridDim.x * RPB) {
+        const int e0 = a.rowptr[r], e1 = a.rowptr[r + 1];
+        int64_t t[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t[j] = e0 + j < e1 ? (int64_t)a.col[e0 + j] : r;         // (clamped loads, masked below)
+        int m[4];
+        f32x4 g4[4], d4[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { m[j] = a.atom_mol[t[j]]; g4[j] = *(const f32x4*)(a.gate + t[j] * HP + c0); }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d4[j] = *(const f32x4*)(a.dA + (int64_t)m[j] * HP + c0);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (e0 + j < e1) acc += d4[j] * g4[j];
+        for (int e = e0 + 4; e < e1; ++e) {                                                  // (more than four neighbours)
+            const int64_t tt = a.col[e];
+            acc += *(const f32x4*)(a.dA + (int64_t)a.atom_mol[tt] * HP + c0) * *(const f32x4*)(a.gate + tt * HP + c0);
+        }
+        *(f32x4*)(a.dz + r * HP + c0) = acc;
+    }
+}
+
 // The last kernel convolution's output sim goes nowhere but into  h = propagate(sim)  and  pre = W1 h + b1  (reference
 // KernelLayer.py:119-123, MolKGNNNet.py:144-146).  Both are linear, and row n of sim is non-zero only in the column block
 // of atom n's degree: project first, z[n] = W1[:, block(n)] sim[n, block(n)]  (H numbers from L_d), then propagate the
@@ -1475,8 +1493,8 @@ int mkgnn_readout_blocks_supported(int32_t F, int32_t H, int32_t G, const int32_
 int mkgnn_readout_blocks_forward(const mkgnn_readout_params* p, const float* sim, int64_t sim_stride,
                                  const int32_t num_kernels[MKGNN_MAX_DEGREE], const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],
                                  int64_t n_atoms, const int32_t* in_rowptr, const int32_t* in_col, const int32_t* mol_ptr,
-                                 int64_t n_mols, const float* keep_scale, float* z, float* pre, float* pooled, float* out,
-                                 int64_t out_stride, void* stream) {
+                                 int64_t n_mols, const float* keep_scale, float* z, float* pre, float* pooled, float* gate_sum,
+                                 float* out, int64_t out_stride, void* stream) {
     const char* who = "mkgnn_readout_blocks_forward";
     ReadoutDims d;
     if (!p || !blocks_dims(p->F, p->H, p->G, d)) return api_fail("%s: shape outside K<=255, H<=64, G<=64", who);
@@ -1505,7 +1523,7 @@ int mkgnn_readout_blocks_forward(const mkgnn_readout_params* p, const float* sim
     e = launch_segment_sum(z, d.HP, in_rowptr, in_col, n_atoms, d.HP, pre, d.HP, nullptr, st);
     if (e != hipSuccess) return api_hip_fail(who, e);
     ReadoutArgs a = readout_args(p, nullptr, 0, n_atoms, mol_ptr, nullptr, n_mols, keep_scale, pre, pooled);
-    a.out = out; a.os = out_stride; a.pre_bias = p->lin1_bias;
+    a.out = out; a.os = out_stride; a.pre_bias = p->lin1_bias; a.gsum = gate_sum;
     const int pgrid = (int)((n_mols + 3) / 4 < 2048 ? (n_mols + 3) / 4 : 2048);
     readout_pool_kernel<<<pgrid, 256, 0, st>>>(a, d.HP);
     e = hipGetLastError();
@@ -1515,15 +1533,15 @@ int mkgnn_readout_blocks_forward(const mkgnn_readout_params* p, const float* sim
 int mkgnn_readout_blocks_backward(const mkgnn_readout_params* p, const float* sim, int64_t sim_stride,
                                   const int32_t num_kernels[MKGNN_MAX_DEGREE], const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],
                                   int64_t n_atoms, const int32_t* out_rowptr, const int32_t* out_col, const int32_t* mol_ptr,
-                                  const int32_t* atom_mol, int64_t n_mols, const float* keep_scale, const float* pre,
-                                  const float* pooled, const float* grad_out, int64_t grad_out_stride, float* dpre, float* dz,
+                                  const int32_t* atom_mol, int64_t n_mols, const float* gate, const float* gate_sum,
+                                  const float* pooled, const float* grad_out, int64_t grad_out_stride, float* dz,
                                   float* grad_sim, int64_t grad_sim_stride, float* grad_lin1_weight, float* grad_lin1_bias,
                                   float* grad_lin2_weight, float* grad_lin2_bias, void* ws, size_t ws_bytes, void* stream) {
     const char* who = "mkgnn_readout_blocks_backward";
     ReadoutDims d;
     if (!p || !blocks_dims(p->F, p->H, p->G, d)) return api_fail("%s: shape outside K<=255, H<=64, G<=64", who);
     if (n_atoms < 1 || n_mols < 1 || n_atoms >= (int64_t)1 << 31) return api_fail("%s: bad sizes", who);
-    if (!out_rowptr || !out_col || !mol_ptr || !atom_mol || !pre || !pooled || !grad_out || grad_out_stride < p->G || !dpre || !dz)
+    if (!out_rowptr || !out_col || !mol_ptr || !atom_mol || !gate || !gate_sum || !pooled || !grad_out || grad_out_stride < p->G || !dz)
         return api_fail("%s: null pointer or bad grad_out stride", who);
     BlockProjArgs b{};
     int64_t n_focal = 0;
@@ -1532,17 +1550,22 @@ int mkgnn_readout_blocks_backward(const mkgnn_readout_params* p, const float* si
     const ReadoutWs w = readout_ws(d, p->H, p->G, n_mols);
     if (!ws || ws_bytes < w.total) return api_fail("%s: workspace too small (%zu < %zu)", who, ws_bytes, w.total);
     hipStream_t st = (hipStream_t)stream;
-    ReadoutArgs a = readout_args(p, nullptr, 0, n_atoms, mol_ptr, atom_mol, n_mols, keep_scale, (float*)pre, (float*)pooled);
+    ReadoutArgs a = readout_args(p, nullptr, 0, n_atoms, mol_ptr, atom_mol, n_mols, nullptr, (float*)gate, (float*)pooled);
+    a.gsum = (float*)gate_sum;
     a.gout = grad_out; a.gos = grad_out_stride;
     a.dA = (float*)((char*)ws + w.dA);
     a.slab_atoms = (float*)((char*)ws + w.slab_atoms); a.slab_atoms_stride = w.slab_atoms_stride;
     a.slab_mol = (float*)((char*)ws + w.slab_mol); a.slab_mol_stride = w.slab_mol_stride;
     a.nblk_mol = (int)((n_mols + 15) / 16 < RO_MOL_BLOCKS ? (n_mols + 15) / 16 : RO_MOL_BLOCKS);
-    a.pre_bias = p->lin1_bias; a.dpre = dpre;
     readout_bwd_mol_kernel<<<a.nblk_mol, 256, 0, st>>>(a, d.HP);
-    // d loss / d z = propagate^T (d loss / d pre): the same segment sum over the edges grouped by source
-    hipError_t e = launch_segment_sum(dpre, d.HP, out_rowptr, out_col, n_atoms, d.HP, dz, d.HP, nullptr, st);
-    if (e != hipSuccess) return api_hip_fail(who, e);
+    // d loss / d z = propagate^T (d loss / d pre), d loss / d pre taken on the fly (readout_dz_gather_kernel)
+    DzArgs z{};
+    z.dA = a.dA; z.gate = gate; z.atom_mol = atom_mol; z.rowptr = out_rowptr; z.col = out_col; z.n = n_atoms; z.dz = dz;
+    const int rpb = 256 / (d.HP / 4);
+    const int nb_dz = (int)((n_atoms + rpb - 1) / rpb < DZ_BLOCKS ? (n_atoms + rpb - 1) / rpb : DZ_BLOCKS);
+    if (d.NT == 2) readout_dz_gather_kernel<8><<<nb_dz, 256, 0, st>>>(z);
+    else readout_dz_gather_kernel<16><<<nb_dz, 256, 0, st>>>(z);
+    hipError_t e = hipSuccess;
     b.sim = sim; b.ss = sim_stride; b.n = n_atoms; b.dz = dz; b.dsim = grad_sim; b.dss = grad_sim_stride;
     // blocks bucket by bucket, 4 * tiles_per_wave tiles each; at most 2 * RO_ATOM_BLOCKS blocks (the slab capacity)
     int64_t tiles_all = 0;

@@ -171,29 +171,30 @@ class _ReadoutBlocksFn(torch.autograd.Function):
         pre = torch.empty((n, hs), dtype=torch.float32, device=dev)
         pooled = torch.empty((seg.size, hs), dtype=torch.float32, device=dev)
         out = torch.empty((seg.size, G), dtype=torch.float32, device=dev)
+        # a backward will follow: the forward leaves the gate keep * swish'(pre + b1) in place of pre, and its sums per molecule
+        gsum = torch.empty((seg.size, hs), dtype=torch.float32, device=dev) if any(ctx.needs_input_grad) else None
         keepc = None if keep is None else keep.contiguous()
         p = _params(w1c, b1, w2c, b2)
         rowptr, col = plan.csr_in
         with torch.cuda.device(dev):
             _lib.check(lib.mkgnn_readout_blocks_forward(
                 p, sim.data_ptr(), _stride0(sim), _lib.Int32x4(*blocks), _sel_buckets(plan), n, rowptr.data_ptr(), col.data_ptr(),
-                seg.mol_ptr.data_ptr(), seg.size, _lib.ptr(keepc), z.data_ptr(), pre.data_ptr(), pooled.data_ptr(), out.data_ptr(), G,
-                _lib.stream_ptr(dev)), "mkgnn_readout_blocks_forward")
+                seg.mol_ptr.data_ptr(), seg.size, _lib.ptr(keepc), z.data_ptr(), pre.data_ptr(), pooled.data_ptr(), _lib.ptr(gsum),
+                out.data_ptr(), G, _lib.stream_ptr(dev)), "mkgnn_readout_blocks_forward")
         ctx.seg, ctx.plan, ctx.blocks = seg, plan, tuple(blocks)
-        ctx.save_for_backward(sim, w1c, b1, w2c, b2, keepc, pre, pooled)
+        ctx.save_for_backward(sim, w1c, b1, w2c, b2, pre, gsum, pooled)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         lib = _lib.load()
-        sim, w1, b1, w2, b2, keep, pre, pooled = ctx.saved_tensors
+        sim, w1, b1, w2, b2, gate, gsum, pooled = ctx.saved_tensors
         seg, plan, blocks = ctx.seg, ctx.plan, ctx.blocks
         n, K = sim.shape
         H, G = w1.shape[0], w2.shape[0]
         dev = sim.device
         g = _row_major(grad_out if grad_out.dtype == torch.float32 else grad_out.float())
-        hs = pre.shape[1]
-        dpre = torch.empty((n, hs), dtype=torch.float32, device=dev)
+        hs = gate.shape[1]
         dz = torch.empty((n, hs), dtype=torch.float32, device=dev)
         K4 = K + (-K) % 4
         # block rows: only every atom's own block of the gradient is defined -- all the convolution's backward reads
@@ -209,8 +210,8 @@ class _ReadoutBlocksFn(torch.autograd.Function):
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             _lib.check(lib.mkgnn_readout_blocks_backward(
                 p, sim.data_ptr(), _stride0(sim), _lib.Int32x4(*blocks), bk, n, rowptr.data_ptr(), col.data_ptr(),
-                seg.mol_ptr.data_ptr(), seg.atom_mol.data_ptr(), seg.size, _lib.ptr(keep), pre.data_ptr(), pooled.data_ptr(),
-                g.data_ptr(), _stride0(g), dpre.data_ptr(), dz.data_ptr(), _lib.ptr(gsim), K4, gw1.data_ptr(), _lib.ptr(gb1),
+                seg.mol_ptr.data_ptr(), seg.atom_mol.data_ptr(), seg.size, gate.data_ptr(), gsum.data_ptr(), pooled.data_ptr(),
+                g.data_ptr(), _stride0(g), dz.data_ptr(), _lib.ptr(gsim), K4, gw1.data_ptr(), _lib.ptr(gb1),
                 gw2.data_ptr(), _lib.ptr(gb2), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)), "mkgnn_readout_blocks_backward")
         return gsim, gw1, gb1, gw2, gb2, None, None, None, None
 
