@@ -145,6 +145,15 @@ class BatchPlan:
                     self._ready = torch.cuda.Event()
                     self._ready.record(side)
                     self._build_ws = (ws, ei, bk)      # alive until the plan goes (its kernels run on another stream)
+                    if side != cur and not torch.cuda.is_current_stream_capturing():
+                        # ... and beyond: a plan that is dropped before anything joined the index stream (a loader probe, an
+                        # exception) hands these blocks back to the allocator of the CALLER's stream, whose next allocation --
+                        # the next batch's builder -- would overwrite the workspace under the kernels still running here
+                        # (seen as a GPU memory fault once in a few hundred batches).  The allocator now waits for this stream.
+                        for t in (ws, ei, s_ptr, s_rows, in_ptr, in_col, in_pk, out_ptr, out_col, deg8,
+                                  *[x for b in self.buckets if b.count for x in (b.sel, b.nei)]):
+                            if t is not None and t.is_cuda:
+                                t.record_stream(side)
         self._scatter = (s_ptr, s_rows[:r])
         self._deg8 = deg8[:n]
         if self.edge_index is not None:

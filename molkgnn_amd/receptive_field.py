@@ -190,6 +190,11 @@ def attach_receptive_fields(batch: GraphBatch, sizes=None, overlap: bool = False
             for v in rf.values():
                 if torch.is_tensor(v):
                     v.record_stream(cur)
+            if not torch.cuda.is_current_stream_capturing():
+                # (the builder reads the batch on the index stream: a batch dropped before anything joined must not have its
+                # memory handed out again under it)
+                for v in (batch.x, batch.p, batch.edge_index, batch.edge_attr):
+                    v.record_stream(side)
             batch._rf_ready = ev
         else:
             rf = build_receptive_fields_hip(batch.x, batch.p, batch.edge_index, batch.edge_attr, sizes)

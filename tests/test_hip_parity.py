@@ -1468,6 +1468,46 @@ def test_plan_builder_hip_matches_torch_builder():
                     assert torch.equal(gv, wv), (ci, with_edges, gi)
 
 
+def test_plan_dropped_before_anything_joins_the_index_stream():
+    """``BatchPlan.build_hip`` runs its kernels on the device's index stream.  A plan (and its batch) dropped before anything
+    read it used to hand its workspace back to the allocator of the CALLER's stream while those kernels were still running --
+    the next batch's builder then wrote over it (a GPU memory fault, once, in tools/shard_loader_probe.py with six loader
+    threads).  The buffers are now recorded on the index stream: build, drop, and at once allocate and overwrite blocks of
+    the same sizes, many times over; the plan built last still equals the torch definition."""
+    from molkgnn_amd.plan import plan_from_data
+    from molkgnn_amd.synthetic import make_batch
+    dev = _dev()
+    base = make_batch(1500, seed=21, device=dev)
+    names = [k for k, v in base.__dict__.items() if torch.is_tensor(v)]
+    def clone():
+        b = type(base)()
+        for k, v in base.__dict__.items():
+            if not k.startswith("_"):
+                setattr(b, k, v.clone() if torch.is_tensor(v) else v)
+        return b
+
+    for it in range(24):
+        b = clone()
+        plan = plan_from_data(b)
+        assert plan.build_hip()
+        del plan, b                                              # nothing joined the index stream
+        junk = [torch.full_like(getattr(base, k), -7 if not getattr(base, k).is_floating_point() else float("nan")) for k in names]
+        junk += [torch.full((getattr(base, "x").shape[0] * 16,), -7, dtype=torch.int32, device=dev) for _ in range(6)]
+        del junk
+    hip = plan_from_data(clone())
+    assert hip.build_hip()
+    ref = plan_from_data(clone())                               # (another object: the plan is cached on the batch)
+    os.environ["MKGNN_TORCH_PLAN"] = "1"
+    try:
+        want = [ref.scatter, ref.csr_in, ref.csr_out, ref.csr_in_packed]
+    finally:
+        del os.environ["MKGNN_TORCH_PLAN"]
+    for gv, wv in zip([hip.scatter, hip.csr_in, hip.csr_out, hip.csr_in_packed], want):
+        assert torch.equal(gv[0], wv[0]) and torch.equal(gv[1], wv[1])
+    assert torch.equal(hip.deg8, ref.deg8)
+    torch.cuda.synchronize()
+
+
 def test_evaluation_metrics_on_the_device_match_reference_golden():
     """SURVEY 8 f-4 on the GPU: ``molkgnn_amd.evaluation`` (the reference's ``evaluation.py:11-127``: logAUC with
     scikit-learn's ``roc_curve`` / ``drop_intermediate`` and ``np.interp`` semantics, AUC, PPV, accuracy, F1) evaluated on
