@@ -492,7 +492,7 @@ __global__ void __launch_bounds__(256) readout_dz_gather_kernel(DzArgs a) {
 // H-wide rows instead of the K-wide ones, pre = propagate(z) (+ b1 where it is read).  Same sums, re-associated.  Removes a
 // 45 MB dense h, its 45 MB gradient and the [N x K] x [K x H] tile products from the step.
 struct BlockProjArgs {
-    const float* sim; int64_t ss; const int8_t* deg; int64_t n;
+    const float* sim; int64_t ss; int64_t n;
     const float* w1; int H, K, HP;
     int off[MKGNN_MAX_DEGREE], L[MKGNN_MAX_DEGREE];
     float* z;                                   // forward: [n, HP]

@@ -456,6 +456,9 @@ def test_block_row_readout_matches_torch_formula(counts, H, G, bias, drop, mols)
     seg = R.molecule_segments(b.batch, mols)
     assert seg.sorted and R.readout_blocks_supported(K, H, G, counts)
     out = R._ReadoutBlocksFn.apply(sim, w1, b1, w2, b2, keep, seg, plan, tuple(counts))
+    with torch.no_grad():                    # inference: no gate is left in place of pre, the same output bit for bit
+        out_ng = R._ReadoutBlocksFn.apply(sim, w1, b1, w2, b2, keep, seg, plan, tuple(counts))
+    assert torch.equal(out_ng, out.detach())
     leaves = [t for t in (sim, w1, b1, w2, b2) if t is not None]
     got = torch.autograd.grad((out * cot).sum(), leaves)
     # the reference: dense sim (zeros outside the blocks) -> propagate -> readout, in PyTorch operators
