@@ -90,10 +90,14 @@ class MolKGNNNet(torch.nn.Module):
         # before the propagate step (readout.readout_blocks); MKGNN_PROJECT_FIRST=0 / 1 forces the choice (diagnostics)
         blocks_out = []
         lin1, lin2 = self.graph_embedding_lin1, self.graph_embedding_lin2
-        want = x.is_cuda and not save_score and (_PROJECT_FIRST == '1' or (_PROJECT_FIRST != '0' and x.shape[0] >= _PROJECT_FIRST_ATOMS))
+        Ls = self.gnn.layers[-1].L
+        dims = (sum(Ls), lin1.weight.shape[0], lin2.weight.shape[0])
+        # (from _PROJECT_FIRST_ATOMS atoms on -- or at any size where the dense readout kernels do not take the shape, e.g. 160
+        # kernels per layer: the block-row form takes up to 255 columns and keeps such a model off the PyTorch-operator path)
+        want = x.is_cuda and not save_score and (_PROJECT_FIRST == '1' or (_PROJECT_FIRST != '0' and (
+            x.shape[0] >= _PROJECT_FIRST_ATOMS or not R.readout_supported(*dims))))
         if want:
-            Ls = self.gnn.layers[-1].L
-            want = R.readout_blocks_supported(sum(Ls), lin1.weight.shape[0], lin2.weight.shape[0], Ls)
+            want = R.readout_blocks_supported(*dims, Ls)
         if want and seg is None:
             seg = R.molecule_segments(data.batch, getattr(data, 'num_graphs', None))
         want = want and seg.sorted and seg.size > 0

@@ -221,7 +221,17 @@ def test_three_layer_network_other_reference_configurations(counts, layers, hidd
     b.num_graphs = 40
     bd = b.to(dev)
     cot = torch.randn(40, hidden, generator=torch.Generator().manual_seed(1))
-    emb = model(bd)
+    from molkgnn_amd import readout as R0
+    took = []
+    orig_blocks, orig_dense = R0._ReadoutBlocksFn.apply, R0._ReadoutFn.apply
+    R0._ReadoutBlocksFn.apply = staticmethod(lambda *a: (took.append("blocks"), orig_blocks(*a))[1])
+    R0._ReadoutFn.apply = staticmethod(lambda *a: (took.append("dense"), orig_dense(*a))[1])
+    try:
+        emb = model(bd)
+    finally:
+        R0._ReadoutBlocksFn.apply, R0._ReadoutFn.apply = orig_blocks, orig_dense
+    # a HIP readout for every one of these shapes: the dense kernels up to 128 columns, the block-row form (K <= 255) beyond
+    assert took == (["blocks"] if sum(counts) > 128 else ["dense"]), took
     (emb * cot.to(dev)).sum().backward()
     plan = plan_from_data(bd)
     ostate = {k: v.clone() for k, v in state.items()}
