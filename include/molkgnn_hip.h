@@ -434,6 +434,32 @@ int64_t mkgnn_adamw_state_floats(int64_t numel);
 int mkgnn_adamw_step(const mkgnn_adamw_tensor* tensors, int32_t n_tensors, const mkgnn_adamw_group* groups,
                      int32_t n_groups, void* stream);
 
+/* ---- host side of the packed-shard loader (no device work): a fixed-shape batch of molecules [m0, m1) of a shard in the
+ * compact wire form that mkgnn_expand_batch takes -- features and coordinates as they are, every bond once as an int32
+ * pair with byte-valued attributes, labels, molecule pointers; padding atoms / bonds / molecules as molkgnn_amd.padding
+ * defines them.  Replaces PyG's Python collation (reference data.py:168-203: DataLoader workers) on the loader threads;
+ * one call per batch, so a Python caller's interpreter lock is released for all of it.  `shape` = {atoms, directed edges,
+ * N_1, N_2, N_3, N_4} of the epoch's common shape; out: the staging buffer (mkgnn_collate_compact_bytes, fields 256-byte
+ * aligned in the order x, p, bond_ij, bond_attr, y, mol_ptr, n_valid_atoms).  The shard's bonds must be stored as reversed
+ * pairs (i, j), (j, i) with shared byte-valued attributes (the shard writer's `compact` flag). */
+typedef struct mkgnn_shard_view {
+    const float* x;                 /* [n_atoms, x_dim] */
+    const float* p;                 /* [n_atoms, p_dim] */
+    const int32_t* edge_src;        /* [n_edges] shard-global atom ids */
+    const int32_t* edge_dst;
+    const float* edge_attr;         /* [n_edges, e_dim] */
+    const float* y;                 /* [n_molecules] */
+    const int64_t* mol_atom_ptr;    /* [n_molecules + 1] */
+    const int64_t* mol_edge_ptr;    /* [n_molecules + 1] */
+    const int64_t* mol_deg_ptr;     /* [n_molecules + 1, 5] prefix sums of the atoms of degree 1..4 / in no bucket */
+    int64_t n_molecules;
+    int32_t x_dim, p_dim, e_dim, reserved;
+} mkgnn_shard_view;
+size_t mkgnn_collate_compact_bytes(const int64_t shape[6], int64_t n_molecules, int32_t pad_molecules, int32_t x_dim,
+                                   int32_t p_dim, int32_t e_dim);
+int mkgnn_collate_compact(const mkgnn_shard_view* shard, int64_t m0, int64_t m1, const int64_t shape[6],
+                          int32_t pad_molecules, void* out, size_t out_bytes);
+
 #ifdef __cplusplus
 }
 #endif

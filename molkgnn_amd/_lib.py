@@ -57,6 +57,14 @@ class AdamWGroup(C.Structure):
                 ("eps", C.c_float), ("weight_decay", C.c_float), ("maximize", C.c_int32), ("grad_scale", C.c_float)]
 
 
+class ShardView(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("p", C.c_void_p), ("edge_src", C.c_void_p), ("edge_dst", C.c_void_p),
+                ("edge_attr", C.c_void_p), ("y", C.c_void_p), ("mol_atom_ptr", C.c_void_p), ("mol_edge_ptr", C.c_void_p),
+                ("mol_deg_ptr", C.c_void_p), ("n_molecules", C.c_int64), ("x_dim", C.c_int32), ("p_dim", C.c_int32),
+                ("e_dim", C.c_int32), ("reserved", C.c_int32)]
+
+
+Int64x6 = C.c_int64 * 6
 Banks4 = KernelBank * MAX_DEGREE
 BankGrads4 = KernelBankGrad * MAX_DEGREE
 Buckets4 = DegreeBucket * MAX_DEGREE
@@ -70,7 +78,7 @@ EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn
            "mkgnn_batchnorm_backward", "mkgnn_bce_head_workspace_bytes", "mkgnn_bce_head_forward",
            "mkgnn_bce_head_backward", "mkgnn_rf_workspace_bytes", "mkgnn_rf_count", "mkgnn_rf_fill", "mkgnn_adamw_step", "mkgnn_adamw_state_floats",
            "mkgnn_bce_head_dropout_forward", "mkgnn_bce_head_dropout_backward", "mkgnn_segment_sum_block_rows",
-           "mkgnn_plan_workspace_bytes", "mkgnn_plan_build", "mkgnn_backward_join", "mkgnn_backward_streams", "mkgnn_bank_prepare", "mkgnn_expand_batch", "mkgnn_bce_head_fused",
+           "mkgnn_plan_workspace_bytes", "mkgnn_plan_build", "mkgnn_backward_join", "mkgnn_backward_streams", "mkgnn_bank_prepare", "mkgnn_expand_batch", "mkgnn_bce_head_fused", "mkgnn_collate_compact", "mkgnn_collate_compact_bytes",
            "mkgnn_readout_blocks_supported", "mkgnn_readout_blocks_forward", "mkgnn_readout_blocks_backward",
            "mkgnn_readout_blocks_workspace_bytes")
 
@@ -132,6 +140,10 @@ def load() -> C.CDLL:
     lib.mkgnn_backward_streams.argtypes = [Banks4, Buckets4, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32]
     lib.mkgnn_bank_prepare.restype = C.c_int
     lib.mkgnn_bank_prepare.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mkgnn_collate_compact_bytes.restype = C.c_size_t
+    lib.mkgnn_collate_compact_bytes.argtypes = [Int64x6, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    lib.mkgnn_collate_compact.restype = C.c_int
+    lib.mkgnn_collate_compact.argtypes = [C.POINTER(ShardView), C.c_int64, C.c_int64, Int64x6, C.c_int32, C.c_void_p, C.c_size_t]
     lib.mkgnn_expand_batch.restype = C.c_int
     lib.mkgnn_expand_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int64,
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -340,3 +340,36 @@ def test_no_lds_dma_site_was_merged_by_the_compiler(tmp_path):
         assert n_dma > 100, (name, n_dma)                     # (the kernels are in there)
         merged = re.findall(r"v_readfirstlane_b32 (s\d+), v\d+\n(?:[^\n]*\n){0,2}?\s*s_mov_b32 m0, \1\b", text)
         assert not merged, (name, len(merged))
+
+
+def test_native_collate_writes_the_numpy_collate_byte_for_byte(tmp_path):
+    """mkgnn_collate_compact (host code of the library, one call per batch on a loader thread) against shards.collate_compact
+    (numpy, the definition): the same staging buffer byte for byte on ragged molecule ranges of several shards, padding atoms
+    / bonds / molecules included; a range that does not fit the shape is refused with the same complaint."""
+    import numpy as np
+    from molkgnn_amd import padding as P, shards as S
+    from molkgnn_amd._lib import MolKGNNLibraryError
+    from molkgnn_amd.synthetic import make_batch
+    raws = [make_batch(150 + 30 * i, seed=70 + i, assay="all9", with_receptive_fields=False) for i in range(3)]
+    shards = [S.Shard(p) for p in S.write_shards(str(tmp_path), raws)]
+    for B in (1, 37, 64):
+        work = [(si, m0, m0 + B) for si, sh in enumerate(shards) for m0 in range(0, sh.n_molecules - B + 1, B)]
+        shape = P.fixed_shape([shards[si].degree_histogram(m0, m1) for si, m0, m1 in work])
+        for si, m0, m1 in work:
+            sh = shards[si]
+            _, total = S.compact_layout(shape, m1 - m0, sh.x_dim, sh.p_dim, sh.e_dim)
+            a, b = np.full(total, 0xAB, dtype=np.uint8), np.full(total, 0xAB, dtype=np.uint8)
+            S.collate_compact(sh, m0, m1, shape, a)
+            S.collate_compact_native(sh, m0, m1, shape, b)
+            assert np.array_equal(a, b), (B, si, m0)
+    small = dict(shape)
+    small["n2"] = 0
+    sh = shards[0]
+    buf = np.zeros(1 << 22, dtype=np.uint8)
+    with pytest.raises(ValueError):
+        S.collate_compact(sh, 0, 64, small, buf)
+    with pytest.raises(MolKGNNLibraryError, match="degree 2"):
+        S.collate_compact_native(sh, 0, 64, small, buf)
+    with pytest.raises(MolKGNNLibraryError, match="too small"):
+        S.collate_compact_native(sh, 0, 64, shape, buf[:1024])
+    del shards, sh
