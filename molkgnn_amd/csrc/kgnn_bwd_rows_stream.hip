@@ -240,14 +240,17 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
                 static_assert(CPR <= 64, "at most one wave per row");
                 const float* const img = xbuf + (size_t)(par * NS * 16) * RS;
                 const int F4 = (a.F + 3) / 4;            // chunks that hold row data (CS = F rounded up to 4: the row's own padding)
-                // (rows of more than 32 chunks, KC > 8: a whole wave per row)
-                constexpr int RPI = CPR <= 32 ? 2 : 1;   // rows per wave-instruction
-                const int ch = RPI == 2 ? (lane & 31) : lane, hw = RPI == 2 ? (lane >> 5) : 0;
+                // (rows of more than 32 chunks, KC > 8: a whole wave per row; narrow rows -- the 1-hop layer's 28 floats are 7
+                // chunks -- share an instruction eight or four at a time: a finishing pass of 1 instead of 4 read-add-store
+                // rounds per slot)
+                constexpr int LPRR = CPR <= 8 ? 8 : (CPR <= 16 ? 16 : (CPR <= 32 ? 32 : 64));   // lanes per row
+                constexpr int RPI = 64 / LPRR;           // rows per wave-instruction
+                const int ch = lane % LPRR, hw = lane / LPRR;
 #pragma unroll
                 for (int a0 = 0; a0 < APW; a0 += RPI) {
-                    const int al = a0 + hw;              // (APW = 16 / 8 / 4: always even)
-                    const int atom = role * APW + al;
-                    if (ch < F4 && ch < CPR) {
+                    const int al = a0 + hw;
+                    const int atom = role * APW + (al < APW ? al : 0);
+                    if (al < APW && ch < F4 && ch < CPR) {
                         f32x4 v = *(const f32x4*)(img + (size_t)atom * RS + 4 * ch);
 #pragma unroll
                         for (int w = 1; w < NS; ++w) v += *(const f32x4*)(img + (size_t)(w * 16 + atom) * RS + 4 * ch);
