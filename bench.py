@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Throughput of the 3-layer MolKGNN training step on AID-1798-shaped synthetic molecules.
 
     python bench.py --gpus N --steps K --warmup W
@@ -43,6 +42,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--roofline-reps", type=int, default=20)
     ap.add_argument("--windows", type=int, default=0, help="timed windows of --steps steps each (0: as many as make >= 0.5 s of timed work, at least 5)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher check (no GPU needed): every rank prints its RANK / LOCAL_RANK / WORLD_SIZE as one JSON line and exits")
     ap.add_argument("--fresh-batches", type=int, default=16,
                     help="also time an epoch of this many distinct batches (one AID-1798 epoch at batch 4096 is 16) with the "
                          "receptive-field and index-plan build inside the timed region; 0 = skip")
@@ -387,14 +388,58 @@ def fresh_batches_leg(args, model, opt, dev, log):
     return out
 
 
+def free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """``python bench.py --gpus N`` with N > 1 and no torchrun environment: start N fresh rank processes -- this
+    process has made no GPU call and makes none -- as ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 bench.py <same arguments>``, pass rank 0's JSON line through and exit with the children's
+    code.  No retry: a rank that fails fails the run."""
+    import subprocess
+    n = args.gpus
+    if not args.dry_launch and not os.environ.get("MKGNN_ALLOW_SHARED_GPU"):
+        have = torch.cuda.device_count()                 # (counts devices without creating a HIP context)
+        if have < n:
+            print(f"bench.py: --gpus {n} asked for {n} ranks, one per GPU, but this box has {have} GPU(s); "
+                  f"refusing to run a {have}-GPU job labelled n_gpus={n} "
+                  "(MKGNN_ALLOW_SHARED_GPU=1 MKGNN_DIST_BACKEND=gloo rehearses several ranks on one card)",
+                  file=sys.stderr, flush=True)
+            raise SystemExit(2)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # the host driver supports dmabuf IPC only (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    print(f"[bench] launching {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    rc = subprocess.run(cmd, env=env).returncode
+    raise SystemExit(rc)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args, sys.argv[1:])                 # (does not return)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus must agree")
+    if args.dry_launch:
+        print(json.dumps({"dry_launch": True, "rank": rank, "local_rank": local_rank, "world_size": world,
+                          "master": f"{os.environ.get('MASTER_ADDR', '')}:{os.environ.get('MASTER_PORT', '')}"}), flush=True)
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path for the HIP kernels)")
-    local_rank %= max(1, torch.cuda.device_count())      # (rehearsals put several ranks on one card)
+    n_dev = torch.cuda.device_count()
+    if world > n_dev and not os.environ.get("MKGNN_ALLOW_SHARED_GPU"):
+        raise SystemExit(f"bench.py: {world} ranks but {n_dev} GPU(s) on this box (one rank per GPU; "
+                         "MKGNN_ALLOW_SHARED_GPU=1 MKGNN_DIST_BACKEND=gloo rehearses several ranks on one card)")
+    local_rank %= max(1, n_dev)                          # (rehearsals put several ranks on one card)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
@@ -416,7 +461,7 @@ def main():
         # RCCL 2.26); with these set before the group is created the one-rank rehearsal captures and replays
         for k in ("TORCH_NCCL_ASYNC_ERROR_HANDLING", "TORCH_NCCL_ENABLE_MONITORING", "TORCH_NCCL_CUDA_EVENT_CACHE", "TORCH_NCCL_BLOCKING_WAIT"):
             os.environ.setdefault(k, "0")
-    dp.init_process_group_from_env(os.environ.get("MKGNN_DIST_BACKEND", "nccl"), force=dp_path)   # nccl = RCCL over xGMI
+    dp.init_process_group_from_env(os.environ.get("MKGNN_DIST_BACKEND", "nccl"), force=dp_path, device=dev)   # nccl = RCCL over xGMI
 
     torch.manual_seed(1798)                       # same initial weights on every rank
     model = GNNModel(ffn_dropout_rate=float(os.environ.get("MKGNN_BENCH_FFN_DROPOUT", "0.25"))).to(dev)   # (diagnostics; 0.25 = the reference default)
@@ -617,6 +662,26 @@ def main():
             replicas_diff = float(d.item())
         log(f"replicas: max |parameter - rank 0's| over all ranks after {args.warmup + args.steps} steps = {replicas_diff:g}")
 
+    # the collective part is over: check it, then every rank leaves the process group; rank 0 goes on alone with the
+    # kernel measurements and the CPU baseline (the other ranks must not sit in a collective for those 30 s)
+    dp_info = {}
+    dp_failure = None
+    if dist.is_initialized():
+        dp_info = {"dp_ranks_seen": ranks_seen, "dp_backend": dist.get_backend(),
+                   "dp_step": "one graph (collective captured)" if (graphs is not None and all(e_[1] is None for e_ in graphs))
+                              else ("backward graph + all-reduce + optimiser graph" if graphs is not None else "eager")}
+        if ranks_seen != world:
+            dp_failure = f"the all-reduce spanned {ranks_seen} rank(s), not the {world} that --gpus asked for"
+        elif replicas_diff is not None and replicas_diff > 0.0:
+            dp_failure = f"replicas diverged: max |parameter - rank 0's| = {replicas_diff:g} after {args.warmup + args.steps} steps"
+        dist.barrier()
+        dist.destroy_process_group()
+    if dp_failure is not None:
+        if rank == 0:
+            print(f"bench.py: data-parallel check FAILED: {dp_failure}; {value:.0f} molecules/s NOT reported", file=sys.stderr, flush=True)
+        raise SystemExit(3)
+    if rank != 0:
+        return
     log(f"{value:.0f} molecules/s; measuring the forward kernels")
     out = None
     if rank == 0:
@@ -646,14 +711,21 @@ def main():
         torch.cuda.synchronize()
         ms_call = ev0.elapsed_time(ev1) / args.roofline_reps
         # (b) the dominant kernel alone (kc_forward_fused): HIP events recorded around its launch, on its stream
-        samples = []
+        # -- `roofline_reps` launches back to back between ONE event pair per sample (the kernel is idempotent); the median of
+        # 9 samples.  An event pair around a single launch read 5-10 % above the rocprofv3 duration of the same kernel.
+        samples, single = [], []
         if args.variant != "generic":                # (the generic kernels have no fused launch to bracket)
-            lib.mkgnn_debug_time_fused_forward(1)
-            for _ in range(args.roofline_reps):
+            lib.mkgnn_debug_time_fused_forward(max(2, args.roofline_reps))
+            for _ in range(9):
                 Fn.kernelsetconv_details(h, plan, False, params, E, args.variant, raw=True)
                 samples.append(float(lib.mkgnn_debug_last_fused_forward_ms()))
+            lib.mkgnn_debug_time_fused_forward(1)
+            for _ in range(9):
+                Fn.kernelsetconv_details(h, plan, False, params, E, args.variant, raw=True)
+                single.append(float(lib.mkgnn_debug_last_fused_forward_ms()))
             lib.mkgnn_debug_time_fused_forward(0)
-        ms = sum(samples) / len(samples) if samples and min(samples) > 0 else ms_call
+        ms = sorted(samples)[len(samples) // 2] if samples and min(samples) > 0 else ms_call
+        ms_single = sorted(single)[len(single) // 2] if single and min(single) > 0 else None
         by, fl = layer_algorithmic(plan, K_in, E, Ls, False)
         gbs = by / (ms * 1e-3) / 1e9
         traffic, traffic_source = None, None
@@ -690,12 +762,14 @@ def main():
                               + ": one launch = KernelSetConv forward of one N-hop layer (F=110, K=110), "
                               "all four degree buckets, training configuration (saves the pair records)",
                     "ms_per_launch": round(ms, 5), "ms_whole_forward_call": round(ms_call, 5),
+                    "timing": f"HIP events on the kernel's stream around {max(2, args.roofline_reps)} back-to-back launches, median of 9 samples",
+                    "ms_per_launch_single_bracket": None if ms_single is None else round(ms_single, 5),
                     "algorithmic_bytes": by, "algorithmic_flops": fl,
                     "fp32_tflops": round(fl / (ms * 1e-3) / 1e12, 3),
                     "fp32_vector_frac": round(fl / (ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 5),
                     "kernels": kernels}
         out = {"metric": "molecules/sec fwd+bwd, 3-layer MolKGNN on AID 1798", "value": round(value, 1),
-               "unit": "molecules/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "unit": "molecules/s", "n_gpus": (ranks_seen if ranks_seen is not None else world), "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * elapsed / args.steps, 4),
                "windows": {"n": len(windows), "steps_each": args.steps, "statistic": "median",
                            "ms_per_step_min": round(1e3 * windows[0] / args.steps, 4),
@@ -705,10 +779,7 @@ def main():
                "vs_baseline": None, "dtype": "bf16 dot products, f32 otherwise" if args.variant == "bf16" else "f32",
                "data": "synthetic",
                **({"dp_replicas_max_abs_diff": replicas_diff} if replicas_diff is not None else {}),
-               **({"dp_ranks_seen": ranks_seen, "dp_backend": dist.get_backend(),
-                   "dp_step": "one graph (collective captured)" if (graphs is not None and all(e_[1] is None for e_ in graphs))
-                              else ("backward graph + all-reduce + optimiser graph" if graphs is not None else "eager")}
-                  if ranks_seen is not None else {}),
+               **dp_info,
                "config": {"workload": f"{'all nine assays mixed' if args.assay == 'all9' else 'AID ' + args.assay} full set shape ({n_mol_assay} molecules, ~25 atoms / ~53 directed "
                                       f"edges each), 3 layers, hidden_dim 32, kernels 10/20/30/50 per degree, "
                                       f"batch {args.batch_size} molecules per GPU ({atoms:.0f} atoms), "
@@ -719,19 +790,27 @@ def main():
                           "parallelism": f"dp{world}"},
                "roofline": roofline}
         log(f"forward kernel {ms:.4f} ms ({ms_call:.4f} ms whole call), {gbs:.1f} GB/s algorithmic")
-        if world == 1 and args.fresh_batches > 0:
-            out["fresh_batches"] = fresh_batches_leg(args, model, opt, dev, log)
-        if world == 1 and not os.environ.get("MKGNN_NO_SMALL_BATCH"):
+        # the legs below train a model of their own at N > 1 (this one's optimiser reads the flat all-reduce buffer)
+        leg_model, leg_opt = model, opt
+        if dp_path and (args.fresh_batches > 0 or not os.environ.get("MKGNN_NO_SMALL_BATCH")):
+            torch.manual_seed(1798)
+            leg_model = GNNModel(ffn_dropout_rate=float(os.environ.get("MKGNN_BENCH_FFN_DROPOUT", "0.25"))).to(dev)
+            leg_model.gnn_model.gnn.set_variant(args.variant)
+            leg_model.train()
+            leg_opt = None if args.no_optimizer else configure_optimizer(leg_model, lr=1e-3, capturable=not args.no_graph)
+        if args.fresh_batches > 0:
             try:
-                out["small_batch"] = small_batch_leg(args, model, opt, dev, log)
+                out["fresh_batches"] = fresh_batches_leg(args, leg_model, leg_opt, dev, log)
+            except Exception as exc:                         # (reported, not fatal)
+                out["fresh_batches"] = {"error": f"{type(exc).__name__}: {exc}"}
+        if not os.environ.get("MKGNN_NO_SMALL_BATCH"):
+            try:
+                out["small_batch"] = small_batch_leg(args, leg_model, leg_opt, dev, log)
             except Exception as exc:                         # (reported, not fatal)
                 out["small_batch"] = {"error": f"{type(exc).__name__}: {exc}"}
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds, args.assay)
         print(json.dumps(out), flush=True)
-    if dist.is_initialized():
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -38,7 +38,7 @@ extern "C" {
 #endif
 
 #define MKGNN_MAX_DEGREE 4
-#define MKGNN_ABI_VERSION 3
+#define MKGNN_ABI_VERSION 4
 
 /* One KernelConv's parameters (reference kernels.py:50-84).  The three score
  * weights are the 0-d parameters support_attr_sc_weight, center_attr_sc_weight
@@ -92,6 +92,10 @@ typedef struct mkgnn_saved {
     int8_t* chirality;                /* [N_d, L_d] +1/-1 (d = 4, last layer); may be NULL           */
 } mkgnn_saved;
 
+/* ABI history.  v3: pair records (mkgnn_saved.pair_state).  v4: the AdamW state buffer of a tensor is
+ * mkgnn_adamw_state_floats(numel) = 2 numel + 3 + ceil(numel / 1024) floats (v3: 2 numel + 3) -- a caller built against
+ * v3 would hand mkgnn_adamw_step a buffer its blocks write past, so the version check must refuse it; the
+ * molecule-resident small-batch entry points (mkgnn_molecule_*) were added with the same version. */
 int mkgnn_abi_version(void);
 const char* mkgnn_last_error(void);
 

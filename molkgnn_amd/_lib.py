@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MKGNN_LIB: a diagnostic build of the same library (make VARIANT=... in csrc/), e.g. with cycle stamps compiled in
 LIB_PATH = os.environ.get("MKGNN_LIB") or os.path.join(_HERE, "libmolkgnn_hip.so")
 MAX_DEGREE = 4
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class KernelBank(C.Structure):

@@ -382,6 +382,7 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
     // largest first
     bool fuse[4];
     int groups[4], total_groups = 0;
+    int only_groups[4] = {0, 0, 0, 0}, total_only = 0;      // (degree, column part) groups of the degrees ONLY the streamed kernel covers
     for (int i = 0; i < 4; ++i) {
         // (the fused kernel indexes the saved planes [3, N_d, L] with 32-bit offsets)
         const bool small = (uint64_t)buckets[i].count * (uint64_t)L[i] < (1ull << 32);     // (pair offsets are 32-bit)
@@ -392,6 +393,17 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
         fuse[i] = buckets[i].count > 0 && L[i] > 0 && variant != 1 && aligned && small && (old_ok || stream_only);
         groups[i] = (fuse[i] && old_ok) ? fused_group_count(i + 1, F, L[i]) : 0;
         total_groups += groups[i];
+        only_groups[i] = (fuse[i] && !old_ok) ? stream_column_parts(i + 1, L[i]) : 0;
+        total_only += only_groups[i];
+    }
+    // a degree only the streamed kernel covers cannot be handed to the LDS-bank kernel when the streamed launch's group table
+    // overflows (launch_forward_fused demotes covered degrees only): more such groups than the table holds go to the generic kernels
+    while (total_only > FUSED_MAX_GROUPS) {
+        int big = 0;
+        for (int i = 1; i < 4; ++i) if (only_groups[i] > only_groups[big]) big = i;
+        if (variant >= 2)
+            return fail("%s: the banks need %d column groups, the streamed launch holds %d", who, total_only, FUSED_MAX_GROUPS);
+        total_only -= only_groups[big]; only_groups[big] = 0; fuse[big] = false;
     }
     while (total_groups > FUSED_MAX_GROUPS) {
         int big = 0;

@@ -678,8 +678,8 @@ static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nbloc
                 return true;
             }();
             (void)env_read;
-            cost[ng] = calib2[i] + (calib7[i] - calib2[i]) * (KC - 2) / 5.0;
             if (ng >= MG) { *nblocks_out = -1; return 0; }
+            cost[ng] = calib2[i] + (calib7[i] - calib2[i]) * (KC - 2) / 5.0;
             tiles_of[ng] = ntiles;
             cap[ng] = (ntiles + nstream - 1) / nstream;
             nstream_of[ng] = nstream;

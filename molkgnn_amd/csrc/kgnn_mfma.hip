@@ -539,12 +539,17 @@ extern "C" int mkgnn_debug_set_stamp_buffer(void* device_ptr) {
 // Measurement hook for bench.py: when enabled, every fused forward launch is bracketed by HIP
 // events on its own stream; the getter waits for the last one and returns its duration.
 // (a measurement hook for one benchmarking thread: the flag is atomic, the event pair is not per caller)
+// enable = R > 1: the forward kernel is launched R times back to back between ONE event pair (it is idempotent: the same
+// output and pair records every time) and the getter returns the mean -- an event pair around a single launch adds its own
+// few microseconds, which is 5-10 % of this kernel.
 static std::atomic<bool> g_time_fused{false};
+static std::atomic<int> g_time_reps{1};
 static hipEvent_t g_ev0 = nullptr, g_ev1 = nullptr;
 extern "C" int mkgnn_debug_time_fused_forward(int enable) {
     if (enable && !g_ev0) {
         if (hipEventCreate(&g_ev0) != hipSuccess || hipEventCreate(&g_ev1) != hipSuccess) return 1;
     }
+    g_time_reps.store(enable > 1 ? (enable > 1000 ? 1000 : enable) : 1);
     g_time_fused.store(enable != 0);
     return 0;
 }
@@ -552,7 +557,7 @@ extern "C" float mkgnn_debug_last_fused_forward_ms(void) {
     float ms = -1.f;
     if (!g_ev0 || hipEventSynchronize(g_ev1) != hipSuccess) return -1.f;
     if (hipEventElapsedTime(&ms, g_ev0, g_ev1) != hipSuccess) return -1.f;
-    return ms;
+    return ms / (float)g_time_reps.load();
 }
 
 bool mfma_forward_supported(int d, int F, int E, int L) {
@@ -706,14 +711,17 @@ hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t 
         int Ls[4];
         for (int i = 0; i < 4; ++i) Ls[i] = a.deg[i].L;
         while (stream_forward_groups(Ls, use_stream) > FUSED_MAX_GROUPS) {
-            int big = -1;
-            for (int i = 0; i < 4; ++i)
-                if (use_stream[i] && (big < 0 || stream_column_parts(i + 1, Ls[i]) > stream_column_parts(big + 1, Ls[big]))) big = i;
+            int big = -1;                                    // (only a degree the LDS-bank kernel covers can move there; the caller
+            for (int i = 0; i < 4; ++i)                      //  keeps the stream-only degrees within the table by itself)
+                if (use_stream[i] && mfma_forward_supported(i + 1, a.F, a.E, Ls[i]) &&
+                    (big < 0 || stream_column_parts(i + 1, Ls[i]) > stream_column_parts(big + 1, Ls[big]))) big = i;
+            if (big < 0) return hipErrorInvalidValue;
             use_stream[big] = false; use_bank[big] = true; any_bank = true;
         }
     }
+    const int time_reps = g_time_fused.load() ? g_time_reps.load() : 1;
     if (g_time_fused.load()) (void)hipEventRecord(g_ev0, st);
-    {
+    for (int rep = 0; rep < time_reps; ++rep) {
         FusedFwdArgs s = a;
         hipError_t e = launch_forward_stream(s, use_stream, st);
         if (e != hipSuccess) return e;

@@ -1461,17 +1461,19 @@ static int check_blocks(const char* who, const mkgnn_readout_params* p, const in
                         BlockProjArgs& b, const ReadoutDims& d, int64_t* n_focal) {
     if (!num_kernels || !buckets) return api_fail("%s: num_kernels / buckets is null", who);
     int K = 0;
+    int64_t n_bucketed = 0;
     *n_focal = 0;
     for (int i = 0; i < MKGNN_MAX_DEGREE; ++i) {
         if (num_kernels[i] < 0 || num_kernels[i] > 64) return api_fail("%s: num_kernels[%d] = %d outside 0..64", who, i, num_kernels[i]);
         b.off[i] = K; b.L[i] = num_kernels[i]; K += num_kernels[i];
         b.cnt[i] = buckets[i].count; b.sel[i] = buckets[i].selected_index;
         if (b.cnt[i] < 0 || (b.cnt[i] > 0 && !b.sel[i])) return api_fail("%s: degree %d bucket has no selected_index", who, i + 1);
-        *n_focal += b.cnt[i];
-    }
+        n_bucketed += b.cnt[i];
+        if (num_kernels[i] > 0) *n_focal += b.cnt[i];        // (a bucket with atoms but no kernels launches no projection tile:
+    }                                                        //  its z rows count as unwritten, the caller zero-fills)
     if (K != p->F) return api_fail("%s: lin1 takes %d columns, the blocks hold %d", who, p->F, K);
     if (sim_stride < K || sim_stride % 4 || !sim || ((uintptr_t)sim & 15)) return api_fail("%s: sim rows must be 16-byte aligned", who);
-    if (*n_focal > n_atoms) return api_fail("%s: the buckets hold more atoms than the batch", who);
+    if (n_bucketed > n_atoms) return api_fail("%s: the buckets hold more atoms than the batch", who);
     b.w1 = p->lin1_weight; b.H = p->H; b.K = K; b.HP = d.HP; b.FP = d.FP;
     return 0;
 }

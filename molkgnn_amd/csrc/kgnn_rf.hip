@@ -122,6 +122,27 @@ __global__ void __launch_bounds__(RF_BLOCK) rf_fill_kernel(const int64_t* __rest
         if (lane == 0) wave_cnt[k][wave] = __popcll(mask);
     }
     __syncthreads();
+    // rows the caller allocated beyond the batch's real bucket sizes (a fixed-shape caller whose `sizes` are larger than
+    // the degree counts): zero-filled -- atom 0, zero attributes -- so that nothing downstream gathers through
+    // uninitialised indices; mkgnn_rf_count's `counts` says what the real sizes were (receptive_field.check_sizes)
+    {
+        const int64_t nthreads = (int64_t)gridDim.x * RF_BLOCK;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int dk = k + 1;
+            for (int64_t rr = w.total[k] + i; rr < o.cap[k]; rr += nthreads) {
+                o.sel[k][rr] = 0;
+                for (int c = 0; c < 3; ++c) o.pf[k][rr * 3 + c] = 0.f;
+                for (int s_ = 0; s_ < dk; ++s_) {
+                    const int64_t row = rr * dk + s_;
+                    o.nei[k][row] = 0;
+                    for (int c = 0; c < 3; ++c) o.pn[k][row * 3 + c] = 0.f;
+                    for (int c = 0; c < E; ++c) o.eattr[k][row * E + c] = 0.f;
+                    if (o.eunit[k] && E <= 8) for (int c = 0; c < 8; ++c) o.eunit[k][row * 8 + c] = 0.f;
+                }
+            }
+        }
+    }
     if (b < 0) return;
     int r = w.blk[(int64_t)blockIdx.x * 4 + b] + below;
     for (int k = 0; k < wave; ++k) r += wave_cnt[b][k];

@@ -123,10 +123,10 @@ int64_t abi_version() { return mkgnn_abi_version(); }
 
 TORCH_LIBRARY(molkgnn, m) {
     m.def("kernelsetconv_forward(Tensor x, Tensor inv_norm, Tensor[] params, Tensor[] buckets, int[] counts, int E, "
-          "bool is_last_layer, Tensor(a!) out, Tensor[] saved, Tensor(b!) workspace, int variant) -> ()");
+          "bool is_last_layer, Tensor(a!) out, Tensor(b!)[] saved, Tensor(c!) workspace, int variant) -> ()");
     m.def("kernelsetconv_backward(Tensor x, Tensor inv_norm, Tensor[] params, Tensor[] buckets, int[] counts, int E, "
-          "bool is_last_layer, Tensor grad_out, Tensor[] saved, Tensor scatter_rowptr, Tensor scatter_rows, Tensor? grad_x, "
-          "Tensor[] grads, Tensor(a!) workspace, bool workspace_from_forward, int variant) -> ()");
+          "bool is_last_layer, Tensor grad_out, Tensor[] saved, Tensor scatter_rowptr, Tensor scatter_rows, Tensor(a!)? grad_x, "
+          "Tensor(b!)[] grads, Tensor(c!) workspace, bool workspace_from_forward, int variant) -> ()");
     m.def("backward_join(Tensor any_gpu_tensor) -> ()");
     m.def("abi_version() -> int");
 }

@@ -23,9 +23,12 @@ import torch
 import torch.distributed as dist
 
 
-def init_process_group_from_env(backend: Optional[str] = None, force: bool = False) -> int:
+def init_process_group_from_env(backend: Optional[str] = None, force: bool = False,
+                                device: Optional[torch.device] = None) -> int:
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun); returns world size.
-    ``force``: also for a world of one (a rehearsal of the collective path on a single GPU)."""
+    ``force``: also for a world of one (a rehearsal of the collective path on a single GPU).  ``device``: this rank's
+    GPU, handed to the RCCL backend as ``device_id`` (the communicator is bound to it at once instead of guessing the
+    device at the first collective)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
@@ -35,7 +38,8 @@ def init_process_group_from_env(backend: Optional[str] = None, force: bool = Fal
         if world > 1 and "RANK" not in os.environ:
             # a mis-launched multi-rank job: every process would call itself rank 0 and hang in the rendezvous
             raise KeyError("RANK is not set although WORLD_SIZE > 1 (launch with torch.distributed.run)")
-        dist.init_process_group(backend=backend, rank=int(os.environ.get("RANK", "0")), world_size=world)
+        extra = {"device_id": device} if (device is not None and device.type == "cuda" and backend == "nccl") else {}
+        dist.init_process_group(backend=backend, rank=int(os.environ.get("RANK", "0")), world_size=world, **extra)
     return world
 
 

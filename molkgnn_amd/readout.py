@@ -238,6 +238,9 @@ def readout_blocks(sim: torch.Tensor, plan, blocks, lin1: torch.nn.Linear, lin2:
     return _ReadoutBlocksFn.apply(sim, lin1.weight, lin1.bias, lin2.weight, lin2.bias, keep, seg, plan, tuple(blocks))
 
 
+_TORCH_READOUT_OK = os.environ.get("MKGNN_TORCH_READOUT", "") == "1"
+
+
 def readout(h: torch.Tensor, lin1: torch.nn.Linear, lin2: torch.nn.Linear, dropout: Optional[torch.nn.Dropout],
             batch: torch.Tensor, size: Optional[int] = None, segments: Optional["MoleculeSegments"] = None) -> torch.Tensor:
     """``global_add_pool(lin2(dropout(swish(lin1(h)))), batch, size)`` -> ``[size, G]``.  ``segments``: the molecule
@@ -248,7 +251,14 @@ def readout(h: torch.Tensor, lin1: torch.nn.Linear, lin2: torch.nn.Linear, dropo
     H, F = lin1.weight.shape
     G = lin2.weight.shape[0]
     p_drop = dropout.p if (dropout is not None and dropout.training) else 0.0
+    if not readout_supported(F, H, G) and not _TORCH_READOUT_OK:
+        # no silent PyTorch-operator path for a shape the HIP kernels do not take: the caller decides
+        raise _lib.MolKGNNLibraryError(
+            f"readout: lin1 {F} -> {H}, lin2 -> {G} is outside the HIP readout kernels (F <= 128, H <= 64, G <= 64; inside "
+            "MolKGNNNet the block-row readout takes up to 255 kernel columns); set MKGNN_TORCH_READOUT=1 to run this shape "
+            "through PyTorch operators on the GPU instead")
     if not (seg.sorted and readout_supported(F, H, G) and h.shape[0] > 0 and seg.size > 0):
+        # (an unsorted `batch` vector or an empty batch: the same formula through PyTorch operators)
         z = swish(lin1(h))
         if dropout is not None:
             z = dropout(z)
@@ -389,14 +399,24 @@ def reset_head_rng(dev=None, seed=None) -> None:
             _HEAD_RNG[k] = torch.tensor([int(seed), 0], dtype=torch.int64, device=torch.device(k))
 
 
-_UNIT_SEEDS: set = set()
+_UNIT_SEEDS: list = []        # (tensor, its version counter when registered): held, so the address cannot be reused
 
 
 def register_unit_gradient(one: torch.Tensor) -> None:
     """Tell the head that ``one`` is a resident tensor holding 1.0 which seeds ``backward`` (``train.backward`` does):
     when the loss's incoming gradient IS that tensor, the gradients the fused forward already wrote are the answer and the
-    backward launches nothing.  Any other incoming gradient scales them."""
-    _UNIT_SEEDS.add((one.data_ptr(), str(one.device)))
+    backward launches nothing.  Any other incoming gradient scales them.  The tensor is kept alive here (its storage
+    address stays its own) and a later in-place write to it (a changed version counter) retires the registration."""
+    if not any(t is one for t, _ in _UNIT_SEEDS):
+        _UNIT_SEEDS.append((one, one._version))
+
+
+def _is_unit_seed(grad: torch.Tensor) -> bool:
+    for t, version in _UNIT_SEEDS:
+        if t._version == version and t.device == grad.device and (grad is t or (
+                grad.data_ptr() == t.data_ptr() and grad.numel() == 1 and grad.dtype == t.dtype)):
+            return True
+    return False
 
 
 class _BceHeadFn(torch.autograd.Function):
@@ -430,7 +450,11 @@ class _BceHeadFn(torch.autograd.Function):
                     _lib.ptr(rng), _lib.ptr(used), pred.data_ptr(), loss.data_ptr(), _lib.ptr(gemb), H, gw.data_ptr(),
                     _lib.ptr(gb), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "mkgnn_bce_head_fused")
             ctx.unit = (gemb, gw, gb)
+            # (references only: a second backward over a retained graph takes the separate backward kernel below)
+            ctx.save_for_backward(emb, w, y, pred, used)
             ctx.wshape = weight.shape
+            ctx.has_bias = bias is not None
+            ctx.p_drop = float(p_drop)
             return loss
         with torch.cuda.device(dev):
             nbytes = int(lib.mkgnn_bce_head_workspace_bytes(B, H))
@@ -450,7 +474,7 @@ class _BceHeadFn(torch.autograd.Function):
         if ctx.unit is not None:
             gemb, gw, gb = ctx.unit
             ctx.unit = None
-            if (grad_loss.data_ptr(), str(grad_loss.device)) not in _UNIT_SEEDS:     # d loss is not the registered 1: scale
+            if not _is_unit_seed(grad_loss):                 # d loss is not the registered 1: scale
                 gl = grad_loss.reshape(()).float()
                 gemb = None if gemb is None else gemb * gl
                 gw = gw * gl

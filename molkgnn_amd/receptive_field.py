@@ -98,12 +98,28 @@ def build_receptive_fields(x: torch.Tensor, p: torch.Tensor,
     return out
 
 
+def check_sizes(rf) -> None:
+    """Raise if a builder run with ``sizes=`` met a batch whose real degree counts differ (one host round trip; call it
+    outside captures, e.g. once per epoch or in tests).  ``rf``: the builder's dict, or the batch it was attached to."""
+    get = rf.get if isinstance(rf, dict) else (lambda k: getattr(rf, k, None))
+    counts, sizes = get("rf_counts"), get("rf_sizes")
+    if counts is None or sizes is None:
+        return
+    real = [int(v) for v in counts.tolist()]
+    if real != [int(v) for v in sizes]:
+        raise ValueError(f"receptive fields were built for bucket sizes {list(sizes)} but the batch has {real} atoms of "
+                         "degree 1..4 (rows beyond the real sizes are zero-filled, rows beyond the given sizes were dropped)")
+
+
 def build_receptive_fields_hip(x: torch.Tensor, p: torch.Tensor, edge_index: torch.Tensor,
-                               edge_attr: torch.Tensor, sizes=None) -> Dict[str, torch.Tensor]:
+                               edge_attr: torch.Tensor, sizes=None, validate: bool = False) -> Dict[str, torch.Tensor]:
     """Same result as ``build_receptive_fields`` (bit for bit) for a batch on the GPU, through the C ABI.
 
     ``sizes`` = the four bucket sizes when the caller knows them (a batch padded to a fixed shape): no host round trip,
-    so the build can run inside a captured graph; the degree counts of the batch must be exactly these."""
+    so the build can run inside a captured graph; the degree counts of the batch must be exactly these.  If they are
+    not, atoms beyond a given size are dropped and rows beyond a real size are zero-filled (never uninitialised); the
+    result then carries ``rf_counts`` (device, the real sizes) / ``rf_sizes`` for ``check_sizes``, which ``validate=True``
+    calls at once (a host synchronisation)."""
     from . import _lib
     lib = _lib.load()
     _lib.require_gpu_tensor(edge_index, "edge_index")
@@ -118,9 +134,12 @@ def build_receptive_fields_hip(x: torch.Tensor, p: torch.Tensor, edge_index: tor
         ws = torch.empty(int(lib.mkgnn_rf_workspace_bytes(n)), dtype=torch.uint8, device=dev)
         counts = torch.empty(4, dtype=torch.int64, device=dev)
         _lib.check(lib.mkgnn_rf_count(_lib.ptr(ei), n, m, ws.data_ptr(), ws.numel(), counts.data_ptr(), st), "mkgnn_rf_count")
+        given = sizes is not None
         if sizes is None:
             sizes = counts.tolist()              # the one host round trip: the outputs have to be allocated
         out: Dict[str, torch.Tensor] = {}
+        if given:
+            out["rf_counts"], out["rf_sizes"] = counts, tuple(int(v) for v in sizes)
         buckets = _lib.Buckets4()
         raw = {}
         for d in range(1, MAX_DEGREE + 1):
@@ -158,6 +177,8 @@ def build_receptive_fields_hip(x: torch.Tensor, p: torch.Tensor, edge_index: tor
             out[f"nei_edge_attr_deg{d}"] = nea.to(edge_attr.dtype) if ea.dim() == 2 else nea.to(edge_attr.dtype).reshape(sel.numel(), d)
             out[f"selected_index_deg{d}"] = sel
             out[f"nei_index_deg{d}"] = nei
+    if given and validate:
+        check_sizes(out)
     return out
 
 

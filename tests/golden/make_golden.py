@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Generate the golden vectors under tests/golden/ from the reference itself.
 
 Runs ONLY in the build container, where the reference checkout is mounted at

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Golden vectors for the evaluation metrics, from the reference's own evaluation.py.
 
 Runs ONLY in the build container (the reference checkout is mounted at /root/reference and needs scikit-learn);

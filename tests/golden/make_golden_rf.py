@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Golden vectors for the receptive-field builder from the reference itself.
 
 Runs ONLY in the build container (the reference checkout is at /root/reference; nothing in tests/, smoke() or

@@ -1,6 +1,9 @@
-#!/usr/bin/env python3
 """The five kernels of one N-hop layer's backward (batch 4096, F = K = 110), each alone on the GPU: HIP-event durations
-(mkgnn_debug_time_backward).  MKGNN_LIB=<variant build> for A/B runs; under rocprofv3 --pmc for counters."""
+(mkgnn_debug_time_backward).  MKGNN_LIB=<variant build> for A/B runs.  For counters:
+    tools/pmc.sh <out dir> "<counters>" -- tools/bwd_kernel_times.py --plain
+(pmc.sh puts `python3 <script>` itself behind rocprofv3's `--`; never run this file through an env shebang or a shell
+wrapper under the profiler: its preloaded library has initialised the GPU by then, and an exec from there is refused
+on this pool.)"""
 import argparse
 import os
 import sys

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Diagnostic: cycle stamps inside the backward kernels (kc_backward_bank_lds, kc_backward_rows_mfma), per degree.
 Needs a library built with the stamps compiled in: make -C molkgnn_amd/csrc clean && make -C molkgnn_amd/csrc STAMPS=1.
 Per tile the kernel records: staging done, barrier passed, prefetch issued, accumulate loop done, barrier + id store."""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Aggregate rocprofv3 --pmc passes (tools/pmc.sh: one directory per pass) of one kernel into the JSON bench.py reads for
 roofline.traffic.  usage: tools/collect_pmc.py <kernel substring> <out.json> <commit> <algorithmic bytes> <dir with pass*/>"""
 import csv

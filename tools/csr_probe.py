@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Diagnostic: the three propagate passes (dense, block-row sources, block-row destinations) alone, for rocprofv3
 kernel traces / PMC passes: tools/csr_probe.py [batch] [reps]"""
 import os

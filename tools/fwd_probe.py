@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Run only the kernel-convolution forward (and optionally backward) of one layer, for rocprofv3 runs."""
 import argparse
 import os

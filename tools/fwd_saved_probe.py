@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Forward of one N-hop layer with and without the saved backward state (ids, scores): run under
 rocprofv3 --kernel-trace and compare the two halves of the kc_forward_fused calls."""
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Do host-to-device copies overlap a replayed training-step graph on this stack?  Times N iterations of (a) the graph alone,
 (b) a 14.6 MB pinned copy alone on a second stream, (c) both issued together with no dependence between them."""
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """List the control flow, waits and memory instructions of one kernel in a hipcc -S listing:
 tools/isa_waits.py file.s mangled-name-fragment [first_line last_line]"""
 import re

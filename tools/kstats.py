@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Print the top rows of a rocprofv3 kernel_stats.csv: tools/kstats.py <dir or csv> [rows]."""
 import csv
 import glob

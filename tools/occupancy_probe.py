@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Forward kernel on a batch whose atoms all have ONE degree (rings: 2; bond pairs: 1), for occupancy experiments with
 single-degree builds (make VARIANT=... EXTRA="-DMKGNN_EXP_ONLY_D=2 -DMKGNN_EXP_OCC=3 -DMKGNN_EXP_MAX_BLOCKS=768"):
 tools/occupancy_probe.py <degree 1|2> [atoms]"""

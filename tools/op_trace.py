@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Diagnostic: which Python lines launch the small PyTorch kernels (fills, adds, copies) of one training step.
 usage: tools/op_trace.py [batch]   -- eager step under torch.profiler with stacks; prints op, shape and the nearest frames."""
 import os

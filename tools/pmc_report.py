@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Per-kernel averages of the rocprofv3 --pmc passes under a directory: tools/pmc_report.py <dir> [kernel substring]"""
 import csv
 import glob

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Host time of one hipGraph replay of the training step against its GPU time (is the replay loop host- or GPU-bound?)."""
 import os
 import sys

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Time the receptive-field builders on a resident batch: torch index arithmetic vs the HIP passes (f-2)."""
 import os
 import sys

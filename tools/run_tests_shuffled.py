@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Run the GPU tests in reversed and in shuffled orders inside one process each (order dependence = shared state,
 uninitialised memory or lifetime bugs that a fixed order hides): tools/run_tests_shuffled.py [n_shuffles]"""
 import random

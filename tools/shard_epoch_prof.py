@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Where the host time of a shard-fed epoch goes (loader hand-off / static-buffer copy / graph replay), diagnostics."""
 import os
 import sys

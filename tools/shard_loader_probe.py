@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Throughput of the packed-shard loader (molkgnn_amd/shards.py) on the GPU box: molecules/s of (a) staging + host-to-device
 copy + device-side index rebuild alone, (b) the same followed by the HIP receptive-field builder and index plan, i.e. a
 batch ready for the model.  tools/shard_loader_probe.py [--molecules 65536] [--batch-size 4096]"""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Diagnostic: cycle stamps inside the fused forward kernel, grouped by (degree, column part).
 Needs a library built with the stamps compiled in: make -C molkgnn_amd/csrc clean && make -C molkgnn_amd/csrc STAMPS=1
 (they cost ~5 us of the kernel and perturb its wait-count placement, so the default build leaves them out)."""

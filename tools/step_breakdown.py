@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Wall-clock breakdown of one training step (HIP events): forward / backward / optimiser, and per-op pieces."""
 import os
 import sys

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """One training step's kernels, in launch order, from a rocprofv3 --kernel-trace CSV of bench.py:
 tools/step_timeline.py <dir or kernel_trace.csv> > profiles/...txt   (the step is delimited by bn_sum_kernel launches)"""
 import csv

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Per-group wave lifetimes of kc_forward_stream (diagnostics): start / end cycle stamps of every wave."""
 import argparse
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """The whole pipeline on one GPU, fed from packed shards: synthetic molecules with a label the graph determines (at least two
 degree-4 atoms) -> shards on disk (molkgnn_amd/shards.py) -> ShardLoader(fixed_shape, compact): host-side padding, pinned
 staging, one copy per batch -> CompactStaticBatch -> ONE captured graph per run (expand, receptive fields, index plan,

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """End-to-end sanity run of the whole path on one GPU: synthetic molecules -> HIP receptive-field builder -> 3-layer
 MolKGNN (HIP convolution, propagate, batch norm, readout, head + loss) -> AdamW, then the reference's metrics.
 The label is a structural property the network can read off the graph (at least two degree-4 atoms), so the loss
