@@ -126,18 +126,20 @@ def time_backward_kernels(lib, Fn, h, plan, params, E, variant, reps):
 def small_batch_leg(args, model, opt, dev, log):
     """BASELINE configs[2] in the same JSON line (outside the headline's timed region): AID 435008 shape, batch 256 -- the
     step is launch-latency bound there; ms per step of the resident-batch replay and the N-hop forward kernel's roofline
-    fraction at that size.  configs[0]'s batch of 16 (the reference's own, README.md:81) rides along."""
+    fraction at that size.  configs[0]'s batch of 16 (the reference's own, README.md:81) rides along.  Both through the
+    per-operator kernels (the default) and through the molecule-resident one-launch step (molkgnn_amd.molecule,
+    MKGNN_MOLECULE=1): `ms_per_step` is the default path's, `molecule_resident` the other's."""
     from molkgnn_amd import _lib
     from molkgnn_amd import functional as Fn
+    from molkgnn_amd import molecule as Mol
     from molkgnn_amd.plan import plan_from_data
     from molkgnn_amd.synthetic import make_batch
     from molkgnn_amd.train import backward as train_backward
     import ctypes
     lib = _lib.load()
     lib.mkgnn_debug_last_fused_forward_ms.restype = ctypes.c_float
-    out = {}
-    for assay, B in (("435008", 256), ("1798", 16)):
-        batches = [make_batch(B, seed=assay_seed(assay) * 1000 + 700 + i, assay=assay).to(dev) for i in range(4)]
+
+    def replay_ms(batches):
         with torch.no_grad():
             for b in batches:
                 model(b)
@@ -171,6 +173,26 @@ def small_batch_leg(args, model, opt, dev, log):
             torch.cuda.synchronize()
             wins.append((time.perf_counter() - t0) / steps)
         wins.sort()
+        del graphs
+        return wins
+
+    out = {}
+    mode0 = Mol._MODE
+    for assay, B in (("435008", 256), ("1798", 16)):
+        batches = [make_batch(B, seed=assay_seed(assay) * 1000 + 700 + i, assay=assay).to(dev) for i in range(4)]
+        try:
+            Mol._MODE = "0"
+            wins = replay_ms(batches)
+            Mol._MODE = "1"
+            try:
+                mwins = replay_ms(batches)
+                mol = {"ms_per_step": round(1e3 * mwins[2], 4), "ms_per_step_min": round(1e3 * mwins[0], 4),
+                       "launches_per_step": 4, "what": "prepare + ONE fwd/loss/bwd launch (a workgroup per chunk of whole molecules) "
+                                                       "+ fixed-order reduction + AdamW (MKGNN_MOLECULE=1; not the default: slower)"}
+            except Exception as exc:
+                mol = {"error": f"{type(exc).__name__}: {exc}"}
+        finally:
+            Mol._MODE = mode0
         b = batches[0]
         plan = plan_from_data(b)
         layer = model.gnn_model.gnn.layers[1]
@@ -180,21 +202,21 @@ def small_batch_leg(args, model, opt, dev, log):
         h_store[:, :K_in] = torch.rand(b.x.shape[0], K_in, device=dev) * 2 - 1
         h = h_store[:, :K_in]
         samples = []
-        lib.mkgnn_debug_time_fused_forward(1)
-        for r in range(12):
+        lib.mkgnn_debug_time_fused_forward(8)
+        for r in range(7):
             Fn.kernelsetconv_details(h, plan, False, params, E, args.variant, raw=True)
             if r >= 2:
                 samples.append(float(lib.mkgnn_debug_last_fused_forward_ms()))
         lib.mkgnn_debug_time_fused_forward(0)
-        ms_f = sum(samples) / len(samples)
+        ms_f = sorted(samples)[len(samples) // 2]
         by, fl = layer_algorithmic(plan, K_in, E, layer.L, False)
         key = f"aid{assay}_b{B}"
         out[key] = {"workload": f"AID {assay} shape, batch {B} ({b.x.shape[0]} atoms), fwd+bwd+AdamW, one hipGraph per resident batch",
                     "ms_per_step": round(1e3 * wins[2], 4), "ms_per_step_min": round(1e3 * wins[0], 4),
                     "value": round(B / wins[2], 1), "unit": "molecules/s",
-                    "forward_kernel_ms": round(ms_f, 5), "forward_kernel_frac": round(by / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
-        log(f"small batch {key}: {1e3 * wins[2]:.4f} ms per step, forward kernel {1e3 * ms_f:.1f} us")
-        del graphs
+                    "forward_kernel_ms": round(ms_f, 5), "forward_kernel_frac": round(by / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "molecule_resident": mol}
+        log(f"small batch {key}: {1e3 * wins[2]:.4f} ms per step (molecule-resident: {mol.get('ms_per_step')}), forward kernel {1e3 * ms_f:.1f} us")
     return out
 
 

@@ -438,6 +438,90 @@ int64_t mkgnn_adamw_state_floats(int64_t numel);
 int mkgnn_adamw_step(const mkgnn_adamw_tensor* tensors, int32_t n_tensors, const mkgnn_adamw_group* groups,
                      int32_t n_groups, void* stream);
 
+/* ---- Molecule-resident small-batch step (ABI v4).
+ *
+ * At the reference's own batch sizes (README.md:81 `--batch_size 16`, data.py:236 default 17; BASELINE configs[0] / [2]) a
+ * step of one launch per operator is a chain of ~30 dependent launches of a few microseconds each.  Nothing on the path
+ * crosses a molecule boundary after the batch-norm statistics (edge_index is block-diagonal), so here ONE launch runs, for
+ * a chunk of whole molecules per workgroup (at most 64 atoms, its rows resident in LDS):
+ *
+ *   node_batch_norm -> num_layers x (KernelSetConv -> propagate) -> lin1, swish, add-pool, lin2   (MolKGNNNet.py:115-146,
+ *                                                                                                  KernelLayer.py:109-120)
+ *   [-> dropout -> ffn -> BCEWithLogitsLoss                                                       (model.py:150, 169, 190-198)]
+ *   [-> the backward of all of it, back to the batch norm's weight and bias]
+ *
+ * followed by one reduction launch that sums the per-workgroup partial gradients in a fixed order (no float atomics) and
+ * undoes the unit normalisation of the kernel rows, and preceded by one preparation launch (unit-normalised kernel rows,
+ * mixing weights, chirality tables of every layer; partial batch-norm statistics).  Same arithmetic as the per-operator
+ * entry points above -- cosines of unit rows, every neighbour order scored ((c0+c1)+c2)+c3 then / d, strict '>' scan in
+ * table order, chirality sign -- so the parity criteria of the per-operator path apply unchanged; results are not
+ * bit-identical to it (other summation orders inside a dot product).
+ *
+ * Shapes taken: 1..4 layers; first layer's input width <= 32, every layer's kernel count K <= 112 with at most 64
+ * kernels per degree and (L_1 + 2 L_2 + 3 L_3) + (L_1 + L_2 + L_3) <= 256, 5 L_4 <= 256; E <= 8; H, G <= 64; every
+ * molecule <= 64 atoms, atoms of a molecule contiguous, every atom's degree <= 4 and its bonds stored in both
+ * directions (as the reference stores them, wrapper.py:152-156), unit bond rows present.  mkgnn_molecule_supported says
+ * whether a model shape is taken; the batch conditions are the caller's (molkgnn_amd.molecule checks them once per batch). */
+#define MKGNN_MOLECULE_MAX_LAYERS 4
+#define MKGNN_MOLECULE_MAX_ATOMS 64      /* atoms per chunk (and so per molecule) */
+#define MKGNN_MOLECULE_MAX_MOLS 16       /* molecules per chunk */
+
+typedef struct mkgnn_molecule_layer {
+    mkgnn_kernel_bank bank[MKGNN_MAX_DEGREE];        /* this layer's KernelSetConv (kernels.py:759-778) */
+    mkgnn_kernel_bank_grad grad[MKGNN_MAX_DEGREE];   /* backward: where the bank gradients go (a NULL x_center: skipped) */
+    mkgnn_saved saved[MKGNN_MAX_DEGREE];             /* pair records [N_d, L_d, 4] (+ chirality, last layer, d = 4):
+                                                        written by the forward, needed by the backward */
+    int32_t F;                                       /* input width of the layer (x_dim, then the previous layer's K) */
+    int32_t reserved;
+    float* sim_out;                                  /* optional [n_atoms, sim_stride]: this layer's sim_sc (tests) */
+    int64_t sim_stride;
+} mkgnn_molecule_layer;
+
+typedef struct mkgnn_molecule_net {
+    int32_t num_layers, E;
+    mkgnn_molecule_layer layer[MKGNN_MOLECULE_MAX_LAYERS];
+    /* node_batch_norm (MolKGNNNet.py:26, 115) */
+    const float* bn_weight; const float* bn_bias;    /* [F0] or NULL */
+    float* bn_running_mean; float* bn_running_var;   /* [F0]; updated when bn_training */
+    int64_t* bn_num_batches_tracked;                 /* or NULL */
+    float bn_eps, bn_momentum;
+    int32_t bn_training, reserved;
+    float* grad_bn_weight; float* grad_bn_bias;      /* backward outputs (NULL: skipped) */
+    /* readout (MolKGNNNet.py:144-146): lin1 [H, K_last], lin2 [G, H] */
+    mkgnn_readout_params readout;
+    float* grad_lin1_weight; float* grad_lin1_bias; float* grad_lin2_weight; float* grad_lin2_bias;
+    /* head (model.py:149-150, 169): ffn [1, G], dropout in front of it */
+    const float* ffn_weight; const float* ffn_bias;
+    float* grad_ffn_weight; float* grad_ffn_bias;
+    float head_dropout;                              /* 0 = none */
+    int32_t reserved2;
+    int64_t* rng_state;                              /* {seed, offset} of the head's dropout (offset advanced by the call) */
+    int64_t* rng_used;                               /* optional: the {seed, offset} this call's mask was drawn with */
+} mkgnn_molecule_net;
+
+typedef struct mkgnn_molecule_batch {
+    int64_t n_atoms, n_mols, n_chunks;
+    int64_t max_chunk_atoms;                         /* atoms of the largest chunk (<= 32: the half-size kernel variant) */
+    const int32_t* chunk_mol_ptr;                    /* [n_chunks + 1] first molecule of every chunk */
+    const int64_t* mol_atom_ptr;                     /* [n_mols + 1] first atom of every molecule */
+    const int8_t* atom_degree;                       /* [n_atoms] out-degree, 0..4 */
+    const int32_t* atom_rank;                        /* [n_atoms] position of the atom in its degree bucket */
+    mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE];   /* nei_index, nei_edge_unit; p_focal / nei_p for d = 4 */
+    const float* x; int64_t x_stride;                /* [n_atoms, F0] raw node features */
+} mkgnn_molecule_batch;
+
+#define MKGNN_MOLECULE_HEAD      1   /* dropout -> ffn -> BCE-with-logits against `target`; writes pred, loss */
+#define MKGNN_MOLECULE_BACKWARD  2   /* gradients of every parameter (d loss = 1 with HEAD, else from grad_emb) */
+#define MKGNN_MOLECULE_GRAD_EMB  4   /* BACKWARD without HEAD: d loss / d graph embedding is given */
+
+int mkgnn_molecule_supported(const mkgnn_molecule_net* net, int32_t x_dim);
+size_t mkgnn_molecule_workspace_bytes(const mkgnn_molecule_net* net, int32_t x_dim, int64_t n_atoms, int64_t n_chunks);
+/* emb [n_mols, G] is always written.  target [n_mols] and pred [n_mols] / loss [1] with HEAD; grad_emb [n_mols, G] with
+ * GRAD_EMB.  The workspace is scratch between calls (the backward of a call recomputes what it needs). */
+int mkgnn_molecule_step(const mkgnn_molecule_net* net, const mkgnn_molecule_batch* batch, int32_t mode,
+                        const float* target, const float* grad_emb, float* emb, float* pred, float* loss,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- host side of the packed-shard loader (no device work): a fixed-shape batch of molecules [m0, m1) of a shard in the
  * compact wire form that mkgnn_expand_batch takes -- features and coordinates as they are, every bond once as an int32
  * pair with byte-valued attributes, labels, molecule pointers; padding atoms / bonds / molecules as molkgnn_amd.padding

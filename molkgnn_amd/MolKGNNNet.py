@@ -70,6 +70,13 @@ class MolKGNNNet(torch.nn.Module):
             # (MolKGNNNet.py:70-89 then :115); only the single-``data`` form is meaningful
             raise ValueError("unmatched number of arguments.")
         data = argv[0]
+        # small batches (the reference's own regime, README.md:81): batch norm, every layer and the readout in ONE launch, a
+        # workgroup per chunk of whole molecules (molkgnn_amd.molecule); None where the model or the batch does not qualify
+        if data.x.is_cuda and not save_score:
+            from . import molecule as _mol
+            emb = _mol.net_forward(self, data)
+            if emb is not None:
+                return emb
         # (a batch padded to a fixed shape -- molkgnn_amd.padding -- carries its real atom count and its molecule segments)
         x = R.batch_norm(data.x, self.node_batch_norm, getattr(data, 'n_valid_atoms', None))
         # edge_batch_norm never reaches the kernel convolution in the reference: skipped

@@ -71,6 +71,37 @@ Buckets4 = DegreeBucket * MAX_DEGREE
 Saved4 = Saved * MAX_DEGREE
 Int32x4 = C.c_int32 * MAX_DEGREE
 
+MOLECULE_MAX_LAYERS = 4
+MOLECULE_MAX_ATOMS = 64
+MOLECULE_MAX_MOLS = 16
+MOLECULE_HEAD, MOLECULE_BACKWARD, MOLECULE_GRAD_EMB = 1, 2, 4
+
+
+class MoleculeLayer(C.Structure):
+    _fields_ = [("bank", Banks4), ("grad", BankGrads4), ("saved", Saved4), ("F", C.c_int32), ("reserved", C.c_int32),
+                ("sim_out", C.c_void_p), ("sim_stride", C.c_int64)]
+
+
+class MoleculeNet(C.Structure):
+    _fields_ = [("num_layers", C.c_int32), ("E", C.c_int32), ("layer", MoleculeLayer * MOLECULE_MAX_LAYERS),
+                ("bn_weight", C.c_void_p), ("bn_bias", C.c_void_p), ("bn_running_mean", C.c_void_p),
+                ("bn_running_var", C.c_void_p), ("bn_num_batches_tracked", C.c_void_p),
+                ("bn_eps", C.c_float), ("bn_momentum", C.c_float), ("bn_training", C.c_int32), ("reserved", C.c_int32),
+                ("grad_bn_weight", C.c_void_p), ("grad_bn_bias", C.c_void_p),
+                ("readout", ReadoutParams),
+                ("grad_lin1_weight", C.c_void_p), ("grad_lin1_bias", C.c_void_p), ("grad_lin2_weight", C.c_void_p),
+                ("grad_lin2_bias", C.c_void_p),
+                ("ffn_weight", C.c_void_p), ("ffn_bias", C.c_void_p), ("grad_ffn_weight", C.c_void_p),
+                ("grad_ffn_bias", C.c_void_p), ("head_dropout", C.c_float), ("reserved2", C.c_int32),
+                ("rng_state", C.c_void_p), ("rng_used", C.c_void_p)]
+
+
+class MoleculeBatch(C.Structure):
+    _fields_ = [("n_atoms", C.c_int64), ("n_mols", C.c_int64), ("n_chunks", C.c_int64), ("max_chunk_atoms", C.c_int64),
+                ("chunk_mol_ptr", C.c_void_p), ("mol_atom_ptr", C.c_void_p), ("atom_degree", C.c_void_p),
+                ("atom_rank", C.c_void_p), ("buckets", Buckets4), ("x", C.c_void_p), ("x_stride", C.c_int64)]
+
+
 EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn_unit_rows8", "mkgnn_workspace_bytes",
            "mkgnn_kernelsetconv_forward", "mkgnn_kernelsetconv_backward", "mkgnn_segment_sum_rows",
            "mkgnn_readout_hidden_stride", "mkgnn_readout_workspace_bytes", "mkgnn_readout_forward",
@@ -80,7 +111,8 @@ EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn
            "mkgnn_bce_head_dropout_forward", "mkgnn_bce_head_dropout_backward", "mkgnn_segment_sum_block_rows",
            "mkgnn_plan_workspace_bytes", "mkgnn_plan_build", "mkgnn_backward_join", "mkgnn_backward_streams", "mkgnn_bank_prepare", "mkgnn_expand_batch", "mkgnn_bce_head_fused", "mkgnn_collate_compact", "mkgnn_collate_compact_bytes",
            "mkgnn_readout_blocks_supported", "mkgnn_readout_blocks_forward", "mkgnn_readout_blocks_backward",
-           "mkgnn_readout_blocks_workspace_bytes")
+           "mkgnn_readout_blocks_workspace_bytes", "mkgnn_molecule_supported", "mkgnn_molecule_workspace_bytes",
+           "mkgnn_molecule_step")
 
 _lib: Optional[C.CDLL] = None
 TORCH_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libmolkgnn_torch.so")
@@ -205,6 +237,12 @@ def load() -> C.CDLL:
     lib.mkgnn_adamw_state_floats.restype = C.c_int64
     lib.mkgnn_adamw_state_floats.argtypes = [I64]
     lib.mkgnn_adamw_step.argtypes = [P, I32, P, I32, P]
+    lib.mkgnn_molecule_supported.restype = C.c_int
+    lib.mkgnn_molecule_supported.argtypes = [C.POINTER(MoleculeNet), I32]
+    lib.mkgnn_molecule_workspace_bytes.restype = C.c_size_t
+    lib.mkgnn_molecule_workspace_bytes.argtypes = [C.POINTER(MoleculeNet), I32, I64, I64]
+    lib.mkgnn_molecule_step.restype = C.c_int
+    lib.mkgnn_molecule_step.argtypes = [C.POINTER(MoleculeNet), C.POINTER(MoleculeBatch), I32, P, P, P, P, P, P, C.c_size_t, P]
     if lib.mkgnn_abi_version() != ABI_VERSION:
         raise MolKGNNLibraryError(f"ABI version {lib.mkgnn_abi_version()} != {ABI_VERSION}: rebuild the library")
     _lib = lib

@@ -51,6 +51,12 @@ class GNNModel(torch.nn.Module):
             # dropout -> ffn -> loss in one kernel each way (same formula, 2 kernels instead of ~25; the dropout mask
             # comes from the kernels' own counter-based generator, see readout.head_rng_state)
             p = self.dropout.p if (self.training and self.dropout.p < 1.0) else 0.0
+            if not (self.training and self.dropout.p >= 1.0):
+                # small batches: forward, loss and (when a gradient will be asked for) the whole backward in one launch
+                from . import molecule as _mol
+                fused = _mol.loss_forward(self, data, p)
+                if fused is not None:
+                    return fused
             graph_embedding = self.gnn_model(data)
             nreal = getattr(data, 'n_valid_molecules', None)
             if self.training and self.dropout.p >= 1.0:

@@ -1,0 +1,276 @@
+"""The molecule-resident small-batch path (molkgnn_amd.molecule, csrc/kgnn_molecule.hip) against the ORACLE.  ``pytest -m gpu``.
+
+Same criteria as the per-operator path: every layer's scores by the tie-aware criterion against the
+reference-faithful oracle form, the network's embedding / loss and every parameter gradient against the oracle evaluated
+with the build's own permutation choices -- at 1, 2, 16 and 256 molecules, with absent degrees, a molecule of more than 32
+atoms (the full-size kernel variant), several molecules per chunk, training- and eval-mode batch norm.
+"""
+import pytest
+import torch
+
+from oracle import kgnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 1e-5
+
+
+def _dev():
+    assert torch.cuda.is_available(), "pytest -m gpu needs the MI355X"
+    return torch.device("cuda:0")
+
+
+def _model(counts, layers, hidden, seed, dev, train_bn):
+    from molkgnn_amd.MolKGNNNet import MolKGNNNet
+    torch.manual_seed(seed)
+    names = [f"num_kernel{d}_{h}" for h in ("1hop", "Nhop") for d in range(1, 5)]
+    model = MolKGNNNet(num_layers=layers, x_dim=28, p_dim=3, edge_attr_dim=7, drop_ratio=0.0, graph_embedding_dim=hidden,
+                       **dict(zip(names, counts * 2)))
+    with torch.no_grad():
+        model.node_batch_norm.running_mean.normal_(0.0, 0.3)
+        model.node_batch_norm.running_var.uniform_(0.5, 1.5)
+        model.node_batch_norm.weight.uniform_(0.5, 1.5)
+        model.node_batch_norm.bias.normal_(0.0, 0.2)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(dev)
+    model.train(train_bn)
+    return model, state
+
+
+def _forced_from_capture(cap, layers):
+    forced = []
+    for li in range(layers):
+        idx = []
+        for d in range(4):
+            sv = cap["saved"][li][d]
+            idx.append(None if sv is None else sv[0][..., 3].contiguous().view(torch.int32).t().cpu().long())
+        forced.append(idx)
+    return forced
+
+
+def _check_against_oracle(model, state, b, layers, train_bn, emb, cap, cot, grads_of):
+    """Layer by layer (tie-aware) and end to end (embedding, every parameter gradient) against the oracle replayed with the
+    build's permutation choices."""
+    forced = _forced_from_capture(cap, layers)
+    ostate = {k: v.clone() for k, v in state.items()}
+    h_o = O.batch_norm(b.x, ostate["node_batch_norm.weight"], ostate["node_batch_norm.bias"],
+                       ostate["node_batch_norm.running_mean"].clone(), ostate["node_batch_norm.running_var"].clone(), train_bn)
+    for i in range(layers):
+        per_degree = O.kernelset_params(ostate, f"gnn.layers.{i}.")
+        sim = cap["sims"][i].cpu()
+        assert O.kernelset_tie_aware_mismatch(per_degree, h_o, b, i == layers - 1, sim, forced[i]) == 0, f"layer {i}"
+        sim_o = O.kernelsetconv(per_degree, h_o, b, i == layers - 1, form="faithful", forced_idx=forced[i])
+        assert torch.allclose(sim, sim_o, atol=FWD_TOL, rtol=0), (i, float((sim - sim_o).abs().max()))
+        h_o = O.propagate_add(b.edge_index, sim_o)
+    ostate = {k: (v.requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v) for k, v in ostate.items()}
+    if "node_batch_norm.running_mean" in ostate:
+        ostate["node_batch_norm.running_mean"] = ostate["node_batch_norm.running_mean"].clone()
+        ostate["node_batch_norm.running_var"] = ostate["node_batch_norm.running_var"].clone()
+    emb_o = O.molkgnnnet(ostate, b, layers, training_bn=train_bn, form="faithful", forced_idx=forced)
+    scale = max(1.0, float(emb_o.detach().abs().max()))
+    assert float((emb.detach().cpu() - emb_o.detach()).abs().max()) <= 5e-5 * scale
+    if cot is None:
+        return ostate, emb_o
+    (emb_o * cot).sum().backward()
+    checked = 0
+    for nm, got in grads_of.items():
+        ref = ostate[nm].grad
+        if got is None:
+            assert ref is None or float(ref.abs().max()) == 0.0, nm
+            continue
+        assert ref is not None, nm
+        err = float((got.cpu() - ref).abs().max())
+        assert err <= 5e-5 * max(1.0, float(ref.abs().max())) + 1e-3 * float(ref.abs().max()), (nm, err, float(ref.abs().max()))
+        checked += 1
+    return checked
+
+
+@pytest.mark.parametrize("mols,train_bn,counts,layers,hidden", [
+    (16, False, (10, 20, 30, 50), 3, 32), (16, True, (10, 20, 30, 50), 3, 32), (1, False, (10, 20, 30, 50), 3, 32),
+    (2, True, (10, 20, 30, 50), 3, 32), (40, True, (5, 10, 15, 25), 3, 32), (24, False, (1, 1, 1, 1), 4, 32),
+    (256, True, (10, 20, 30, 50), 3, 32), (12, True, (10, 20, 30, 50), 2, 64)])
+def test_network_forward_and_backward_against_the_oracle(mols, train_bn, counts, layers, hidden, monkeypatch):
+    dev = _dev()
+    from molkgnn_amd import molecule as M
+    from molkgnn_amd.synthetic import make_batch
+    monkeypatch.setattr(M, "_MODE", "1")
+    model, state = _model(counts, layers, hidden, sum(counts) + layers + mols, dev, train_bn)
+    b = make_batch(mols, seed=sum(counts) + mols, duplicate_fraction=0.1)
+    b.num_graphs = mols
+    bd = b.to(dev)
+    cot = torch.randn(mols, hidden, generator=torch.Generator().manual_seed(1))
+    cap = {}
+    monkeypatch.setattr(M, "debug_capture", cap)
+    calls = []
+    orig = M._run
+    monkeypatch.setattr(M, "_run", lambda *a, **k: (calls.append(a[6]), orig(*a, **k))[1])
+    emb = model(bd)
+    assert calls == [0], calls                             # the molecule-resident kernels ran (forward-only mode)
+    fwd_cap = dict(cap)
+    (emb * cot.to(dev)).sum().backward()
+    assert calls == [0, 6], calls                          # ... and their backward (recompute + gradient of the embedding)
+    grads = {nm: prm.grad for nm, prm in model.named_parameters()}
+    checked = _check_against_oracle(model, state, b, layers, train_bn, emb, fwd_cap, cot, grads)
+    present = sum(1 for d in range(1, 5) if getattr(b, f"selected_index_deg{d}").numel() > 0)
+    assert checked >= 6 * present * layers + 6
+    if train_bn:                                            # running statistics moved once (the recompute does not move them again)
+        rm = torch.nn.functional.batch_norm(b.x, state["node_batch_norm.running_mean"].clone(), state["node_batch_norm.running_var"].clone(),
+                                            None, None, True, 0.1, 1e-5)
+        ref_m, ref_v = state["node_batch_norm.running_mean"].clone(), state["node_batch_norm.running_var"].clone()
+        torch.nn.functional.batch_norm(b.x, ref_m, ref_v, None, None, True, 0.1, 1e-5)
+        assert torch.allclose(model.node_batch_norm.running_mean.cpu(), ref_m, atol=1e-5)
+        assert torch.allclose(model.node_batch_norm.running_var.cpu(), ref_v, atol=1e-5, rtol=1e-5)
+        assert int(model.node_batch_norm.num_batches_tracked) == 1
+        del rm
+
+
+def _big_molecule_batch(dev):
+    """Molecules of up to 60 atoms next to small ones: chunks of more than 32 atoms (the full-size kernel variant), several
+    molecules per chunk, and a chunk table that mixes both."""
+    from molkgnn_amd.synthetic import make_batch
+    for seed in range(200, 400):
+        b = make_batch(24, seed=seed, duplicate_fraction=0.1)
+        sizes = torch.bincount(b.batch).tolist()
+        if max(sizes) >= 40 and min(sizes) <= 14:
+            b.num_graphs = 24
+            return b
+    raise AssertionError("no batch with a large and a small molecule found")
+
+
+def test_large_molecules_and_packed_chunks(monkeypatch):
+    dev = _dev()
+    from molkgnn_amd import molecule as M
+    monkeypatch.setattr(M, "_MODE", "1")
+    b = _big_molecule_batch(dev)
+    bd = b.to(dev)
+    model, state = _model((10, 20, 30, 50), 3, 32, 5, dev, True)
+    cap = {}
+    monkeypatch.setattr(M, "debug_capture", cap)
+    plan = M._plan_of(bd)
+    plan._molecule = (M.build_molecule_plan(plan, bd.batch, 24, cap=64),)          # chunks of up to 64 atoms: several molecules each
+    emb = model(bd)
+    mp = M.molecule_plan(plan, bd.batch, 24)
+    assert mp is not None and mp.max_chunk_atoms > 48 and mp.n_chunks < 16, (mp.max_chunk_atoms, mp.n_chunks)
+    fwd_cap = dict(cap)
+    cot = torch.randn(24, 32, generator=torch.Generator().manual_seed(2))
+    (emb * cot.to(dev)).sum().backward()
+    grads = {nm: prm.grad for nm, prm in model.named_parameters()}
+    assert _check_against_oracle(model, state, b, 3, True, emb, fwd_cap, cot, grads) > 60
+
+
+@pytest.mark.parametrize("mols,p_drop", [(16, 0.0), (256, 0.0), (16, 0.25)])
+def test_training_step_loss_and_gradients(mols, p_drop, monkeypatch):
+    """``GNNModel.loss`` as ONE launch (forward + BCE head + backward): loss and every gradient against the oracle replayed
+    with the build's choices (dropout 0), and with dropout against the per-operator head fed the same embedding and the
+    same generator state."""
+    dev = _dev()
+    from molkgnn_amd import molecule as M
+    from molkgnn_amd import readout as R
+    from molkgnn_amd.synthetic import make_batch
+    from molkgnn_amd.train import GNNModel
+    from molkgnn_amd.train import backward as train_backward
+    monkeypatch.setattr(M, "_MODE", "1")
+    torch.manual_seed(40 + mols)
+    model = GNNModel(ffn_dropout_rate=p_drop)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.to(dev).train()
+    b = make_batch(mols, seed=900 + mols, duplicate_fraction=0.1)
+    b.num_graphs = mols
+    b.y = (torch.rand(mols, generator=torch.Generator().manual_seed(3)) < 0.3).float()
+    bd = b.to(dev)
+    cap = {}
+    monkeypatch.setattr(M, "debug_capture", cap)
+    calls = []
+    orig = M._run
+    monkeypatch.setattr(M, "_run", lambda *a, **k: (calls.append(a[6]), orig(*a, **k))[1])
+    R.reset_head_rng(dev, seed=77)
+    loss = model.loss(bd)
+    assert calls == [3], calls                              # HEAD | BACKWARD in one launch
+    train_backward(loss)
+    assert calls == [3]                                     # the backward launched nothing
+    gstate = {k[len("gnn_model."):]: v for k, v in state.items() if k.startswith("gnn_model.")}
+    grads = {nm[len("gnn_model."):]: prm.grad for nm, prm in model.named_parameters() if nm.startswith("gnn_model.")}
+    if p_drop == 0.0:
+        forced = _forced_from_capture(cap, 3)
+        ostate = {k: (v.clone().requires_grad_(True) if v.dtype.is_floating_point and "running" not in k else v.clone()) for k, v in gstate.items()}
+        emb_o = O.molkgnnnet(ostate, b, 3, training_bn=True, form="faithful", forced_idx=forced)
+        w = state["ffn.weight"].clone().requires_grad_(True)
+        bias = state["ffn.bias"].clone().requires_grad_(True)
+        pred_o = emb_o @ w.T + bias
+        loss_o = torch.nn.functional.binary_cross_entropy_with_logits(pred_o.view(-1), b.y)
+        assert abs(float(loss) - float(loss_o)) <= 2e-6 * max(1.0, abs(float(loss_o)))
+        assert torch.allclose(cap["pred"].cpu(), pred_o.detach().view(-1), atol=5e-5, rtol=1e-5)
+        loss_o.backward()
+        checked = 0
+        for nm, got in list(grads.items()) + [("ffn.weight", model.ffn.weight.grad), ("ffn.bias", model.ffn.bias.grad)]:
+            ref = {"ffn.weight": w.grad, "ffn.bias": bias.grad}.get(nm, ostate[nm].grad if nm in ostate else None)
+            if got is None:
+                assert ref is None or float(ref.abs().max()) == 0.0, nm
+                continue
+            err = float((got.cpu() - ref).abs().max())
+            assert err <= 2e-6 * max(1.0, float(ref.abs().max())) + 1e-3 * float(ref.abs().max()), (nm, err, float(ref.abs().max()))
+            checked += 1
+        assert checked >= 70
+    else:
+        # the per-operator head on the SAME embedding with the same generator state draws the same mask
+        emb = cap["emb"].detach().clone().requires_grad_(True)
+        w = model.ffn.weight.detach().clone().requires_grad_(True)
+        bias = model.ffn.bias.detach().clone().requires_grad_(True)
+        ffn = torch.nn.Linear(32, 1).to(dev)
+        ffn.weight, ffn.bias = torch.nn.Parameter(w), torch.nn.Parameter(bias)
+        R.reset_head_rng(dev, seed=77)
+        loss2 = R.bce_head_loss(emb, ffn, bd.y, dropout_p=p_drop)
+        loss2.backward()
+        assert abs(float(loss) - float(loss2)) <= 2e-6
+        assert torch.allclose(model.ffn.weight.grad, ffn.weight.grad, atol=2e-6, rtol=1e-5)
+        assert torch.allclose(model.ffn.bias.grad, ffn.bias.grad, atol=2e-6, rtol=1e-5)
+        state_now = R.head_rng_state(dev).tolist()
+        assert state_now[1] == 1                            # (reset to offset 0, one draw by the per-operator head after the reset)
+
+
+def test_step_under_graph_capture_replays_the_eager_step(monkeypatch):
+    """forward + loss + backward + AdamW captured once and replayed: same loss and parameters as the eager steps."""
+    dev = _dev()
+    from molkgnn_amd import molecule as M
+    from molkgnn_amd.synthetic import make_batch
+    from molkgnn_amd.train import GNNModel, configure_optimizer
+    from molkgnn_amd.train import backward as train_backward
+    monkeypatch.setattr(M, "_MODE", "1")
+    b = make_batch(16, seed=31).to(dev)
+
+    def run(graph):
+        torch.manual_seed(8)
+        model = GNNModel(ffn_dropout_rate=0.0).to(dev).train()
+        opt = configure_optimizer(model, lr=1e-3, capturable=True)
+
+        def step():
+            model.zero_grad(set_to_none=True)
+            loss = model.loss(b)
+            train_backward(loss)
+            opt.step()
+            return loss
+        losses = []
+        if not graph:
+            for _ in range(5):
+                losses.append(float(step()))
+        else:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    losses.append(float(step()))
+                model.zero_grad(set_to_none=True)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    sl = step()
+            torch.cuda.current_stream().wait_stream(side)
+            for _ in range(3):
+                g.replay()
+                torch.cuda.synchronize()
+                losses.append(float(sl))
+        return losses, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu()
+
+    l0, p0 = run(False)
+    l1, p1 = run(True)
+    assert l0[0] > 0 and all(abs(a - c) <= 1e-6 * max(1.0, abs(a)) for a, c in zip(l0, l1)), (l0, l1)
+    assert torch.allclose(p0, p1, atol=1e-6, rtol=1e-5)
