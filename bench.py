@@ -182,15 +182,21 @@ def small_batch_leg(args, model, opt, dev, log):
         batches = [make_batch(B, seed=assay_seed(assay) * 1000 + 700 + i, assay=assay).to(dev) for i in range(4)]
         try:
             Mol._MODE = "0"
-            wins = replay_ms(batches)
+            pwins = replay_ms(batches)
             Mol._MODE = "1"
             try:
                 mwins = replay_ms(batches)
-                mol = {"ms_per_step": round(1e3 * mwins[2], 4), "ms_per_step_min": round(1e3 * mwins[0], 4),
-                       "launches_per_step": 4, "what": "prepare + ONE fwd/loss/bwd launch (a workgroup per chunk of whole molecules) "
-                                                       "+ fixed-order reduction + AdamW (MKGNN_MOLECULE=1; not the default: slower)"}
             except Exception as exc:
-                mol = {"error": f"{type(exc).__name__}: {exc}"}
+                mwins = None
+                log(f"molecule-resident step unavailable ({type(exc).__name__}: {exc})")
+            # the path a run takes by default at this batch size (molkgnn_amd.molecule: up to 32 molecules the one-launch step)
+            default_mol = mwins is not None and mode0 != "0" and B <= (Mol._MAX_MOLS_FORCED if mode0 == "1" else Mol._MAX_MOLS_AUTO)
+            wins = mwins if default_mol else pwins
+            mol = {"default_path": "molecule_resident" if default_mol else "per_operator",
+                   "per_operator_ms_per_step": round(1e3 * pwins[2], 4),
+                   "molecule_resident_ms_per_step": None if mwins is None else round(1e3 * mwins[2], 4),
+                   "molecule_resident": "prepare + ONE fwd/loss/bwd launch (a workgroup per chunk of whole molecules) + fixed-order "
+                                        "reduction + AdamW: 4 launches per step; the default up to 32 molecules (MKGNN_MOLECULE)"}
         finally:
             Mol._MODE = mode0
         b = batches[0]
@@ -215,8 +221,9 @@ def small_batch_leg(args, model, opt, dev, log):
                     "ms_per_step": round(1e3 * wins[2], 4), "ms_per_step_min": round(1e3 * wins[0], 4),
                     "value": round(B / wins[2], 1), "unit": "molecules/s",
                     "forward_kernel_ms": round(ms_f, 5), "forward_kernel_frac": round(by / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                    "molecule_resident": mol}
-        log(f"small batch {key}: {1e3 * wins[2]:.4f} ms per step (molecule-resident: {mol.get('ms_per_step')}), forward kernel {1e3 * ms_f:.1f} us")
+                    "paths": mol}
+        log(f"small batch {key}: {1e3 * wins[2]:.4f} ms per step ({mol['default_path']}; per operator {mol['per_operator_ms_per_step']}, "
+            f"molecule-resident {mol['molecule_resident_ms_per_step']}), forward kernel {1e3 * ms_f:.1f} us")
     return out
 
 

@@ -220,7 +220,8 @@ struct MolMeta {                        // (LDS)
     float red[MOL_NW][16];
     float hv[MOL_MAXM][2];
     float mix[16];                      // the current layer's mixing weights [degree][w_s, w_c, w_e, sum] (a global load per use otherwise)
-    int back[MOL_MAXA];                 // per atom, 2 bits per slot: the position of the atom in that neighbour's own slot list
+    int back[MOL_MAXA];
+    int tgt[5 * 8];                     // backward, degree 4 on the vector pipe: target atom of every part row                 // per atom, 2 bits per slot: the position of the atom in that neighbour's own slot list
     int8_t idx[MOL_MAXA * 112];
 };
 
@@ -440,6 +441,170 @@ __device__ __forceinline__ void mol_edge_grad_degree(MolLayerK& Y, const float* 
     }
 }
 
+// ---- Degree 4 without the dense pass.  Its bank is more than half of a layer's rows (5 L_4 of them) while a few per cent of
+// the atoms have four bonds: multiplying every atom of the chunk with those rows is the largest single waste of the dense
+// form.  With at most MOL_D4_VALU_MAX such atoms in the chunk their 17 dot products per kernel run on the vector pipe, eight
+// lanes per (atom, kernel) pair, each lane a strided eighth of the feature chunks; the backward likewise touches only the
+// rows and atoms involved.  More degree-4 atoms than that: the dense pass 1.
+constexpr int MOL_D4_VALU_MAX = 6;
+
+__device__ __forceinline__ float mol_dot4(const v4 a, const v4 b, float acc) {
+    acc = fmaf(a[0], b[0], acc); acc = fmaf(a[1], b[1], acc); acc = fmaf(a[2], b[2], acc); return fmaf(a[3], b[3], acc);
+}
+
+__device__ __forceinline__ void mol_pairs4_valu(MolLayerK& Y, bool last, const float* xin, int XS, float* sim, const float* bond,
+                                                const MolMeta& m, int tid) {
+    constexpr int D = 4;
+    const int L = Y.L[3], cnt = m.dcnt[3];
+    if (L == 0 || cnt == 0) return;
+    const int FP = Y.FP, KV = FP >> 2, off = Y.off[3];
+    const float* sup0 = Y.bankU + (size_t)(Y.row_base[1] + Y.sup_row[3]) * FP;
+    const float* cen0 = Y.bankU + (size_t)(Y.row_base[1] + Y.cen_row[3]) * FP;
+    const float ws = m.mix[12], wc = m.mix[13], we = m.mix[14], wsum = m.mix[15];
+    for (int it = tid; it < cnt * L * 8; it += MOL_THREADS) {
+        const int s8 = it & 7, p = it >> 3, ai = p / L, l = p - ai * L;
+        const int n = m.dlist[3][ai], pk = m.nei[n];
+        int nb[D];
+#pragma unroll
+        for (int a = 0; a < D; ++a) nb[a] = (pk >> (8 * a)) & 0xFF;
+        v4 es0[D], es1[D];
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+            const float* es = Y.edgeU + (size_t)(Y.e_row[3] + b * L + l) * 8;
+            es0[b] = *(const v4*)es; es1[b] = *(const v4*)(es + 4);
+        }
+        float cm[D][D], cc = 0.f;
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) cm[a][b] = 0.f;
+        for (int k = s8; k < KV; k += 8) {
+            v4 sb[D];
+#pragma unroll
+            for (int b = 0; b < D; ++b) sb[b] = *(const v4*)(sup0 + (size_t)(b * L + l) * FP + 4 * k);
+            const v4 sc = *(const v4*)(cen0 + (size_t)l * FP + 4 * k);
+            cc = mol_dot4(*(const v4*)&xin[n * XS + 4 * k], sc, cc);
+#pragma unroll
+            for (int a = 0; a < D; ++a) {
+                const v4 xa = *(const v4*)&xin[nb[a] * XS + 4 * k];
+#pragma unroll
+                for (int b = 0; b < D; ++b) cm[a][b] = mol_dot4(xa, sb[b], cm[a][b]);
+            }
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1) {
+            cc += __shfl_xor(cc, o, 64);
+#pragma unroll
+            for (int a = 0; a < D; ++a)
+#pragma unroll
+                for (int b = 0; b < D; ++b) cm[a][b] += __shfl_xor(cm[a][b], o, 64);
+        }
+        cc *= m.inv[n];
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            const float iv = m.inv[nb[a]];
+#pragma unroll
+            for (int b = 0; b < D; ++b) cm[a][b] *= iv;
+        }
+        float best; int idx;
+        best_permutation<D>(cm, best, idx);
+        float ed = 0.f;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            const int pb = mol_perm(D, idx, a);
+            v4 e0 = es0[0], e1 = es1[0];
+#pragma unroll
+            for (int b = 1; b < D; ++b) if (pb == b) { e0 = es0[b]; e1 = es1[b]; }
+            const v4 b0 = *(const v4*)&bond[(n * 4 + a) * 8], b1 = *(const v4*)&bond[(n * 4 + a) * 8 + 4];
+            float dt = b0[0] * e0[0];
+            dt = fmaf(b0[1], e0[1], dt); dt = fmaf(b0[2], e0[2], dt); dt = fmaf(b0[3], e0[3], dt);
+            dt = fmaf(b1[0], e1[0], dt); dt = fmaf(b1[1], e1[1], dt); dt = fmaf(b1[2], e1[2], dt); dt = fmaf(b1[3], e1[3], dt);
+            ed = (a == 0) ? dt : __fadd_rn(ed, dt);
+        }
+        ed = div_by<D>(ed);
+        float sc = __fadd_rn(__fadd_rn(__fmul_rn(best, ws), __fmul_rn(cc, wc)), __fmul_rn(ed, we)) / wsum;
+        float ch = 1.f;
+        if (last && !m.eq[n]) ch = ((float)Y.chir[l * 12 + idx] == m.sgn[n]) ? 1.f : -1.f;
+        sc *= ch;
+        if (s8 == 0) {
+            if (Y.chir_out) Y.chir_out[(size_t)m.rank[n] * L + l] = (int8_t)ch;
+            sim[n * MOL_XS + off + l] = sc;
+            if (Y.pair[3]) pair_store(Y.pair[3], (size_t)m.rank[n] * L + l, best, cc, ed, idx);
+        }
+    }
+}
+
+// Backward of the same: (A) for every degree-4 atom the rows  sum_l coef(n, l) * unit bank row  that go to each of its four
+// neighbours and to itself (`part`: [atoms][5][XS], one thread per 16-byte piece, kernels in order; merged into G afterwards
+// in part order);
+// (B) the gradient of the degree-4 bank rows, straight into the chunk's slab (every row / piece has one owner thread, the
+// degree-4 atoms in ascending order).
+__device__ __forceinline__ void mol_bwd4_rows(MolLayerK& Y, const float* gtab, float* part, MolMeta& m, int tid) {
+    const int L = Y.L[3], cnt = m.dcnt[3], FP = Y.FP, KV = FP >> 2, XS = FP + 4, off = Y.off[3];
+    if (tid < cnt * 5) {                                  // whose row each part is: neighbour t of the atom, or the atom itself
+        const int ia = tid / 5, t = tid - ia * 5, n = m.dlist[3][ia];
+        m.tgt[tid] = t < 4 ? (m.nei[n] >> (8 * t)) & 0xFF : n;
+    }
+    const float* sup0 = Y.bankU + (size_t)(Y.row_base[1] + Y.sup_row[3]) * FP;
+    const float* cen0 = Y.bankU + (size_t)(Y.row_base[1] + Y.cen_row[3]) * FP;
+    const float wsd = m.mix[12] / m.mix[15] * 0.25f, wcd = m.mix[13] / m.mix[15];
+    // eight lanes per 16-byte piece of a part row, each taking every eighth kernel (one round of loads in flight per lane),
+    // combined by a fixed xor tree
+    for (int it = tid; it < cnt * 5 * KV * 8; it += MOL_THREADS) {
+        const int s8 = it & 7, pc = it >> 3, k = pc % KV, t = (pc / KV) % 5, ia = pc / (5 * KV);
+        const int n = m.dlist[3][ia];
+        v4 acc = v4{0.f, 0.f, 0.f, 0.f};
+        for (int l0 = s8; l0 < L; l0 += 64) {
+            v4 bv[8]; float c[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int lw = l0 + 8 * u, l = lw < L ? lw : L - 1;
+                const float g = gtab[n * MOL_XS + off + l];
+                const float* row = t < 4 ? sup0 + (size_t)(mol_perm(4, m.idx[n * 112 + off + l], t) * L + l) * FP : cen0 + (size_t)l * FP;
+                bv[u] = *(const v4*)(row + 4 * k);
+                c[u] = lw < L ? g * (t < 4 ? wsd : wcd) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                acc[0] = fmaf(c[u], bv[u][0], acc[0]); acc[1] = fmaf(c[u], bv[u][1], acc[1]);
+                acc[2] = fmaf(c[u], bv[u][2], acc[2]); acc[3] = fmaf(c[u], bv[u][3], acc[3]);
+            }
+        }
+#pragma unroll
+        for (int o = 4; o > 0; o >>= 1)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] += __shfl_xor(acc[e], o, 64);
+        if (s8 == 0) *(v4*)&part[(ia * 5 + t) * XS + 4 * k] = acc;
+    }
+}
+
+__device__ __forceinline__ void mol_bwd4_bank(MolLayerK& Y, const float* gtab, const float* U, float* bslab, const MolMeta& m, int tid) {
+    const int L = Y.L[3], cnt = m.dcnt[3], FP = Y.FP, KV = FP >> 2, XS = FP + 4, off = Y.off[3];
+    const float wsd = m.mix[12] / m.mix[15] * 0.25f, wcd = m.mix[13] / m.mix[15];
+    const int sup = Y.sup_row[3], cen = Y.cen_row[3];
+    for (int it = tid; it < 5 * L * KV; it += MOL_THREADS) {
+        const int k = it % KV, row = it / KV;             // row < 4 L: support (b, l); else centre l
+        const int b = row < 4 * L ? row / L : 4, l = row - b * L;
+        v4 acc = v4{0.f, 0.f, 0.f, 0.f};
+        for (int ai = 0; ai < cnt; ++ai) {
+            const int n = m.dlist[3][ai];
+            const float g = gtab[n * MOL_XS + off + l];
+            int src = n;
+            if (b < 4) {
+                const int idx = m.idx[n * 112 + off + l], pk = m.nei[n];
+                int sl = 0;
+#pragma unroll
+                for (int s = 1; s < 4; ++s) if (mol_perm(4, idx, s) == b) sl = s;
+                src = (pk >> (8 * sl)) & 0xFF;
+            }
+            const v4 uv = *(const v4*)&U[src * XS + 4 * k];
+            const float c = g * (b < 4 ? wsd : wcd);
+            acc[0] = fmaf(c, uv[0], acc[0]); acc[1] = fmaf(c, uv[1], acc[1]); acc[2] = fmaf(c, uv[2], acc[2]); acc[3] = fmaf(c, uv[3], acc[3]);
+        }
+        *(v4*)&bslab[(size_t)((b < 4 ? sup + b * L : cen) + l) * FP + 4 * k] = acc;
+    }
+}
+
 // NT: atom tiles the LDS buffers are laid out for (the launch's largest chunk); NTR <= NT: atom tiles of THIS chunk, a
 // compile-time count so that every product loop is straight-line code
 template <int NT, int NTR>
@@ -638,8 +803,10 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
         MOL_STAMP();   // layer: norms, save, equal-row test
         // (A operand: the chunk's rows, k-permuted 16-byte reads -- lane (r, q) holds columns 16 j + 4 q .. of row r; read per
         // product tile: seven LDS reads against 28 matrix instructions)
+        const bool d4_valu = m.dcnt[3] <= MOL_D4_VALU_MAX;      // (chunk-uniform)
         for (int p = 0; p < 2; ++p) {
             const int RT = Y.pass_rows[p] >> 4;
+            if (p == 1 && d4_valu) { MOL_STAMP(); MOL_STAMP(); continue; }
             if (RT == 0) continue;
 #pragma unroll
             for (int t = 0; t < MOL_TPW; ++t) {
@@ -658,11 +825,12 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
                     for (int i = 0; i < 4; ++i) St[(mt * 16 + 4 * q + i) * MOL_RS + nt * 16 + r] = acc[i] * m.inv[mt * 16 + 4 * q + i];
                 }
             }
-            if (p == 0) fetch_pass(1);                  // (arrives under the pairs of pass 0)
+            if (p == 0 && !d4_valu) fetch_pass(1);      // (arrives under the pairs of pass 0)
             __syncthreads();
             MOL_STAMP();   // layer: products of the pass
             if (p == 0) { mol_pairs_forward<1>(Y, last, St, sim, bond, m, tid); mol_pairs_forward<2>(Y, last, St, sim, bond, m, tid);
-                          mol_pairs_forward<3>(Y, last, St, sim, bond, m, tid); }
+                          mol_pairs_forward<3>(Y, last, St, sim, bond, m, tid);
+                          if (d4_valu) mol_pairs4_valu(Y, last, xin, XS, sim, bond, m, tid); }
             else mol_pairs_forward<4>(Y, last, St, sim, bond, m, tid);
             __syncthreads();
             MOL_STAMP();   // layer: pairs of the pass
@@ -913,8 +1081,10 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
         v4 gacc[NT];
 #pragma unroll
         for (int mt = 0; mt < NT; ++mt) gacc[mt] = v4{0.f, 0.f, 0.f, 0.f};
+        const bool d4_valu = m.dcnt[3] <= MOL_D4_VALU_MAX;      // (chunk-uniform; the forward took the same branch)
         for (int p = 0; p < 2; ++p) {
             const int RT = Y.pass_rows[p] >> 4;
+            if (p == 1 && d4_valu) { MOL_STAMP(); MOL_STAMP(); continue; }
             if (RT == 0) continue;
             // (the B operand of G += Cf . BankU for this pass: issued now, used behind the barrier)
             const int gft = wave & 7, gk0 = (wave >> 3) * MOL_GPW;       // this wave's feature tile and its first 16-row group
@@ -969,6 +1139,13 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
             MOL_STAMP();   // bwd layer: products of the pass
         }
         // (s5) G -> oth (the coefficient table is dead), then d loss / d (input rows) = inv (G - (G . u) u), in place
+        if (d4_valu && Y.L[3] > 0) {
+            // degree 4 on the vector pipe: part rows into the (now free) Cf region, bank rows straight into the slab (zeros
+            // when the chunk has no such atom: the reduction sums every chunk's rows)
+            if (m.dcnt[3] > 0) mol_bwd4_rows(Y, gtab, Cf, m, tid);
+            mol_bwd4_bank(Y, gtab, U, slab + Y.slab_bank + (size_t)Y.row_base[1] * FP, m, tid);
+            __syncthreads();
+        }
         if (li > 0 && tid < 16) m.mix[tid] = a.layer[li - 1].mix[tid];      // (this layer's are not read again)
         // (the contraction's parts in wave order: part 0 stores, the others add)
 #pragma unroll
@@ -981,6 +1158,16 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
                         float* dst = &oth[(mt * 16 + 4 * q + i) * XS + (wave & 7) * 16 + r];
                         *dst = part == 0 ? gacc[mt][i] : *dst + gacc[mt][i];
                     }
+            }
+            __syncthreads();
+        }
+        if (d4_valu && Y.L[3] > 0 && m.dcnt[3] > 0) {        // G += the degree-4 part rows, in part order
+            const int KV = FP >> 2, ne = m.dcnt[3] * 5;
+            for (int it = tid; it < NR * KV; it += MOL_THREADS) {
+                const int j = it / KV, k = it - j * KV;
+                v4 v = *(v4*)&oth[j * XS + 4 * k];
+                for (int e = 0; e < ne; ++e) if (m.tgt[e] == j) v += *(const v4*)&Cf[e * XS + 4 * k];
+                *(v4*)&oth[j * XS + 4 * k] = v;
             }
             __syncthreads();
         }

@@ -24,13 +24,15 @@ from .plan import BatchPlan
 
 MAX_ATOMS = _lib.MOLECULE_MAX_ATOMS
 MAX_MOLS = _lib.MOLECULE_MAX_MOLS
-# MKGNN_MOLECULE: '1' whenever the model and the batch qualify (up to MKGNN_MOLECULE_MAX_MOLS molecules: larger batches fill
-# the chip through the streamed kernels, and the per-workgroup gradient slabs grow with the number of chunks); '0' / unset:
-# never.  NOT the default: measured on MI355X (round 4) the one-launch step is 0.306 / 0.262 ms at 256 / 16
-# molecules against 0.289 / 0.255 ms for the per-operator path -- a workgroup per molecule is bound by its own fp32 matrix
-# work (the dense [atoms x all bank rows] products) where the per-operator kernels spread a layer over the whole chip.
-_MODE = os.environ.get("MKGNN_MOLECULE", "0")
-_MAX_MOLS_AUTO = int(os.environ.get("MKGNN_MOLECULE_MAX_MOLS", "512"))
+# MKGNN_MOLECULE: unset -- batches of up to MKGNN_MOLECULE_AUTO_MOLS (32) molecules, the reference's own regime (README.md:81:
+# batch 16), where the one-launch step is the faster one; '1' -- whenever the model and the batch qualify, up to
+# MKGNN_MOLECULE_MAX_MOLS (512) molecules; '0' -- never.  Measured on MI355X (round 4): 0.238 ms per step at 16
+# molecules against 0.255 ms for the per-operator path, but 0.334 against 0.289 ms at 256 -- a workgroup per molecule is bound
+# by its own fp32 matrix work, and with one chunk per CU the launch lasts as long as its slowest chunk (a 60-atom molecule,
+# or one with six four-bonded atoms), where the per-operator kernels spread a layer over the whole chip.
+_MODE = os.environ.get("MKGNN_MOLECULE", "")
+_MAX_MOLS_AUTO = int(os.environ.get("MKGNN_MOLECULE_AUTO_MOLS", "32"))
+_MAX_MOLS_FORCED = int(os.environ.get("MKGNN_MOLECULE_MAX_MOLS", "512"))
 debug_capture: Optional[dict] = None      # tests: a dict here receives the pair records / sim rows of the next forward
 
 
@@ -167,7 +169,9 @@ _SHAPE_OK: dict = {}
 
 
 def wanted(n_mols: int) -> bool:
-    return _MODE == "1" and n_mols <= _MAX_MOLS_AUTO
+    if _MODE == "0":
+        return False
+    return n_mols <= (_MAX_MOLS_FORCED if _MODE == "1" else _MAX_MOLS_AUTO)
 
 
 def _net_struct(net, ffn, params, grads, saved, sims, head_dropout, update_running, rng=None, rng_used=None):
@@ -398,7 +402,7 @@ def _plan_of(data) -> BatchPlan:
 
 def _ready(net, data, ffn):
     """(plan, molecule plan, parameters) when the molecule-resident path takes this model and batch, else None."""
-    if _MODE != "1" or not data.x.is_cuda:
+    if _MODE == "0" or not data.x.is_cuda:
         return None
     n_mols = getattr(data, 'num_graphs', None)
     if n_mols is not None and not wanted(int(n_mols)):

@@ -11,6 +11,8 @@ from molkgnn_amd.synthetic import make_batch                                   #
 from molkgnn_amd.train import GNNModel                                         # noqa: E402
 from molkgnn_amd.train import backward as train_backward                       # noqa: E402
 
+from molkgnn_amd import molecule as _mol                                        # noqa: E402
+_mol._MODE = "1"                                                               # (the molecule-resident path is opt-in)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 dev = torch.device("cuda:0")
 torch.manual_seed(1798)
