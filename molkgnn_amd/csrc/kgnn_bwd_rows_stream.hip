@@ -39,6 +39,15 @@ namespace mkgnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic build (make STAMPS=1), as in kgnn_bwd_stream.hip.  Rows kernel phases: 0 tile coefficients + next tile's loads
+// issued, 1 matrix products of a slot, 2 partial tile into LDS, 3 barrier, 4 finishing pass (read, add, store).
+#ifdef MKGNN_BWD_STAMPS
+__device__ unsigned long long* g_rows_stream_stamps = nullptr;
+#define MKGNN_RPHASE(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); phase[i] += t_ - t_phase; t_phase = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define MKGNN_RPHASE(i) do { } while (0)
+#endif
+
 namespace rs {
 
 template <int I> using IC = std::integral_constant<int, I>;
@@ -180,6 +189,10 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
             }
     }
 
+#ifdef MKGNN_BWD_STAMPS
+    const unsigned long long t_start = __builtin_readcyclecounter();
+    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_phase = t_start;
+#endif
     for (int64_t it = 0; it < iters; ++it) {
         const int64_t tile = tile_at(it);
         const bool real = tile_first + it < tile_end;
@@ -197,6 +210,7 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
         // next tile's inputs: in flight during this tile's matrix work
         issue(tile_at(it + 1), focal_next);
         if (!records) focal_next = focal_of(tile_at(it + 2));
+        MKGNN_RPHASE(0);
 
         static_for<0, S1>([&](auto sc) {
             constexpr int s = decltype(sc)::value;       // contribution-row slot: 0 = focal (centre rows), 1 + a = neighbour a
@@ -227,13 +241,16 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
             // 14 of them per slot: instead every wave writes its partial tile into LDS as ROWS ([atom][FP] floats, the
             // layout of the contribution rows themselves), and after the barrier each wave adds up the NS images of its
             // share of the atoms 16 bytes at a time and stores whole 16-byte chunks of contiguous 448-byte rows.
+            MKGNN_RPHASE(1);
             float* const mine = xbuf + (size_t)((par * NS + role) * 16) * RS;
 #pragma unroll
             for (int t = 0; t < KC; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mine[(kq * 4 + r) * RS + 16 * t + ci] = acc[t][r];
+            MKGNN_RPHASE(2);
             if constexpr (NS > 1) __syncthreads();
             else __builtin_amdgcn_wave_barrier();        // (own image: LDS accesses of one wave are ordered)
+            MKGNN_RPHASE(3);
             {
                 constexpr int APW = 16 / NS;             // atoms this wave finishes
                 constexpr int CPR = FP / 4;              // 16-byte chunks per row
@@ -264,8 +281,16 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
                 }
             }
             par ^= 1;
+            MKGNN_RPHASE(4);
         });
     }
+#ifdef MKGNN_BWD_STAMPS
+    if (g_rows_stream_stamps && lane == 0) {
+        unsigned long long* o = g_rows_stream_stamps + ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+        o[0] = t_start; o[1] = __builtin_readcyclecounter(); o[2] = (unsigned long long)(D * 16 + a.cp); o[3] = (unsigned long long)iters;
+        for (int i = 0; i < 8; ++i) o[4 + i] = phase[i];
+    }
+#endif
 }
 
 template <int KC>
@@ -284,6 +309,15 @@ __global__ void __launch_bounds__(256, (KC >= 8 ? 1 : 2)) kc_backward_rows_strea
 }
 
 // ---------------------------------------------------------------- host ----
+extern "C" int mkgnn_debug_set_rows_stream_stamps(void* device_ptr) {
+#ifdef MKGNN_BWD_STAMPS
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_rows_stream_stamps), &device_ptr, sizeof(void*));
+#else
+    (void)device_ptr;
+    return -1;
+#endif
+}
+
 bool rows_stream_supported(int d, int F, int E, int L) {
     if (d < 1 || d > 4 || L < 1) return false;
     if (F < 1 || F > STREAM_MAX_F || !bank_pitch(F)) return false;

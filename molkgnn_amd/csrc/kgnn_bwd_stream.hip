@@ -41,6 +41,17 @@ namespace mkgnn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// Diagnostic build (make STAMPS=1): per-wave cycle totals of the loop's phases in a buffer set by
+// mkgnn_debug_set_bwd_stream_stamps (tools/bwd_stream_stamps.py): [start, end, degree * 16 + column part, iterations,
+// phase 0..7].  Bank kernel phases: 0 tile coefficients, 1 operand preparation (norms, bond rows, masks, bond products),
+// 2 row products (B reads + matrix instructions), 3 counted wait, 4 barrier, 5 DMA issue, 6 slab store.
+#ifdef MKGNN_BWD_STAMPS
+__device__ unsigned long long* g_bank_stream_stamps = nullptr;
+#define MKGNN_BPHASE(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); phase[i] += t_ - t_phase; t_phase = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define MKGNN_BPHASE(i) do { } while (0)
+#endif
+
 namespace bs {
 
 template <int I> using IC = std::integral_constant<int, I>;
@@ -363,6 +374,10 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
     __builtin_amdgcn_s_barrier();
 
     int buf = 0;
+#ifdef MKGNN_BWD_STAMPS
+    const unsigned long long t_start = __builtin_readcyclecounter();
+    unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_phase = t_start;
+#endif
     for (int64_t it = 0; it < iters; ++it) {
         const bool real = tile_first + it < tile_end;    // a repeated tile must not be accumulated twice
         const uint32_t mrec_b = (uint32_t)(uintptr_t)(meta + (it & 1) * META);            // LDS byte addresses
@@ -386,6 +401,7 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
                 iq[q] = __float_as_int(raw[4 + q]);
             }
         }
+        MKGNN_BPHASE(0);
         static_for<0, S1>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             if (s < D || !HS || half == 0) {
@@ -431,6 +447,7 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
 #pragma unroll
                         for (int q = 0; q < 4; ++q) accE[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae[b][q], eb[q], accE[b], 0, 0, 0);
                 }
+                MKGNN_BPHASE(1);
                 // feature tiles: lane (k = kq, j = ci) reads row 4 q + kq, feature 16 t + ci of the slot image
                 // (row 4 q + kq is odd exactly when kq is: SWZ moves its column 16 t + ci to 16 (t ^ 1) + ci, i.e. 16 floats up
                 // for even t and down for odd t -- two per-lane bases, the offsets stay immediates)
@@ -456,6 +473,7 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
                     }
                 });
             }
+            MKGNN_BPHASE(2);
             // ---- retire / barrier / issue: as in the forward
             if constexpr (RING == 2) {
                 wait_vmcnt<0>();
@@ -466,7 +484,9 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
                     if (role == r) wait_vmcnt<n_young>();
                 });
             }
+            MKGNN_BPHASE(3);
             if constexpr (NS > 1) __builtin_amdgcn_s_barrier();
+            MKGNN_BPHASE(4);
             constexpr int sd = (s + RING) % S1;
             const int64_t itd = it + (s + RING) / S1;
             float* const drec = meta + (itd & 1) * META;
@@ -480,9 +500,11 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
                 }
             }
             buf = (buf + 1 == RING) ? 0 : buf + 1;
+            MKGNN_BPHASE(5);
         });
     }
     wait_vmcnt<0>();
+    MKGNN_BPHASE(3);
 
     // ---- this wave's slice of its stream's partial slab: C layout col = feature 16 t + ci, row = kernel kq * 4 + r
     float* const slab = dg.slab + (size_t)sg * bank_floats(D, L, F, a.E);
@@ -506,6 +528,14 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
             }
         }
     }
+#ifdef MKGNN_BWD_STAMPS
+    MKGNN_BPHASE(6);
+    if (g_bank_stream_stamps && lane == 0) {
+        unsigned long long* o = g_bank_stream_stamps + ((size_t)blockIdx.x * 4 + wave) * 16;
+        o[0] = t_start; o[1] = __builtin_readcyclecounter(); o[2] = (unsigned long long)(D * 16 + cp); o[3] = (unsigned long long)iters;
+        for (int i = 0; i < 8; ++i) o[4 + i] = phase[i];
+    }
+#endif
 }
 
 template <int KC>
@@ -525,6 +555,16 @@ __global__ void __launch_bounds__(256, (KC >= 8 ? 1 : 2)) kc_backward_bank_strea
 }
 
 // ---------------------------------------------------------------- host ----
+// diagnostics (make STAMPS=1): device buffer of (blocks * 4 waves * 16) uint64 for the bank kernel's phase stamps; 0 = off
+extern "C" int mkgnn_debug_set_bank_stream_stamps(void* device_ptr) {
+#ifdef MKGNN_BWD_STAMPS
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_bank_stream_stamps), &device_ptr, sizeof(void*));
+#else
+    (void)device_ptr;
+    return -1;
+#endif
+}
+
 // Same conditions as the forward's streamed kernel (the pre-pass and the slab chunk capacity added).
 bool bank_stream_supported(int d, int F, int E, int L, int64_t n_atoms, int64_t x_stride, const float* e_unit) {
     return stream_forward_supported(d, F, E, L, n_atoms, x_stride, x_stride, e_unit);
