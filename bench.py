@@ -760,7 +760,7 @@ def main():
         traffic, traffic_source = None, None
         try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same workload; tools/pmc.sh)
             if args.batch_size == 4096 and args.variant in ("auto", "mfma"):
-                for name in ("r03_forward_pmc.json", "r02_forward_pmc.json"):
+                for name in ("r04_forward_pmc.json", "r03_forward_pmc.json", "r02_forward_pmc.json"):
                     path = os.path.join(REPO, "profiles", name)
                     if os.path.exists(path):
                         pmc = json.load(open(path))

@@ -607,6 +607,12 @@ __device__ __forceinline__ void mol_bwd4_bank(MolLayerK& Y, const float* gtab, c
 
 // NT: atom tiles the LDS buffers are laid out for (the launch's largest chunk); NTR <= NT: atom tiles of THIS chunk, a
 // compile-time count so that every product loop is straight-line code
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding vector-memory operation
+// (s_waitcnt vmcnt(0)): the stores of a phase (pair records, kept input rows, slab rows) and the loads issued a phase ahead
+// would be drained at each of the ~70 barriers of a chunk.  Nothing the kernel writes to global memory is read back before
+// the one full barrier at the forward -> backward transition.
+#define MOL_BAR() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+
 template <int NT, int NTR>
 __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
     const MOL_K MolArgs& a = *ap;
@@ -661,7 +667,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
         }
         if (tid < NAP) { m.sgn[tid] = sg; m.eq[tid] = 0; }
     }
-    __syncthreads();
+    MOL_BAR();
     // molecule of every atom; unit bond rows of every slot
     if (tid < NAP) {
         int g = 0;
@@ -696,13 +702,13 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
         float part = 0.f;
         if (a.bn_training && k < 16) for (int b = k; b < a.bn_nblk; b += 16) part += a.bn_part[(size_t)b * 2 * C + cc];
         if (k < 16) red[k * 32 + c] = part;
-        __syncthreads();
+        MOL_BAR();
         float mu = 0.f;
         if (a.bn_training) {
             for (int kk = 0; kk < 16; ++kk) mu += red[kk * 32 + c];
             mu /= (float)a.n_atoms;
         }
-        __syncthreads();
+        MOL_BAR();
         part = 0.f;
         if (a.bn_training && k < 16) for (int b = k; b < a.bn_nblk; b += 16) {
             const int64_t lo = per * b, hi = lo + per < a.n_atoms ? lo + per : a.n_atoms;
@@ -712,7 +718,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
             }
         }
         if (k < 16) red[k * 32 + c] = part;
-        __syncthreads();
+        MOL_BAR();
         if (tid < 32) {
             float is = 1.f;
             if (tid < C) {
@@ -739,7 +745,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
             if (chunk == 0 && tid == 0 && a.nbt && a.bn_training) a.nbt[0] += 1;
         }
     }
-    __syncthreads();
+    MOL_BAR();
     const int XS0 = a.layer[0].FP + 4;
     for (int it = tid; it < NR * 32; it += MOL_THREADS) {
         const int j = it >> 5, c = it & 31;
@@ -747,7 +753,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
         if (j < NA && c < C) v = fmaf(a.x[(a0 + j) * a.xs + c] - m.bn_mu[c], m.bn_scale[c], m.bn_shift[c]);
         if (c < a.layer[0].FP) bufA[j * XS0 + c] = v;
     }
-    __syncthreads();
+    MOL_BAR();
 
     MOL_STAMP();    // 2: batch norm
     // ---------------------------------------------------------------------------------------------- the layers ----
@@ -799,7 +805,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
                 if (h32 == 0) m.eq[n] = diff != 0x3Fu ? 1 : 0;
             }
         }
-        __syncthreads();
+        MOL_BAR();
         MOL_STAMP();   // layer: norms, save, equal-row test
         // (A operand: the chunk's rows, k-permuted 16-byte reads -- lane (r, q) holds columns 16 j + 4 q .. of row r; read per
         // product tile: seven LDS reads against 28 matrix instructions)
@@ -826,13 +832,13 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
                 }
             }
             if (p == 0 && !d4_valu) fetch_pass(1);      // (arrives under the pairs of pass 0)
-            __syncthreads();
+            MOL_BAR();
             MOL_STAMP();   // layer: products of the pass
             if (p == 0) { mol_pairs_forward<1>(Y, last, St, sim, bond, m, tid); mol_pairs_forward<2>(Y, last, St, sim, bond, m, tid);
                           mol_pairs_forward<3>(Y, last, St, sim, bond, m, tid);
                           if (d4_valu) mol_pairs4_valu(Y, last, xin, XS, sim, bond, m, tid); }
             else mol_pairs_forward<4>(Y, last, St, sim, bond, m, tid);
-            __syncthreads();
+            MOL_BAR();
             MOL_STAMP();   // layer: pairs of the pass
         }
         if (Y.sim_out) for (int it = tid; it < NA * Y.K; it += MOL_THREADS) {
@@ -850,7 +856,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
             }
             *(v4*)&xin[i * MOL_XS + 4 * c4] = s;
         }
-        __syncthreads();
+        MOL_BAR();
         MOL_STAMP();   // layer: propagate
     }
     // xin = h of the last layer [NAP, 116]; sim free; St free
@@ -875,7 +881,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) pre[(mt * 16 + 4 * q + i) * MOL_HS + ht * 16 + r] = acc[i] + bias;
         }
-        __syncthreads();
+        MOL_BAR();
         // the molecules' sums of swish(pre): 8 threads per (molecule, hidden unit)
         for (int it = tid; it < nm * H * 8; it += MOL_THREADS) {
             const int s8 = it & 7, gh = it >> 3, g = gh / H, h = gh - g * H;
@@ -884,7 +890,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
             s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
             if (s8 == 0) pooled[g * 64 + h] = s;
         }
-        __syncthreads();
+        MOL_BAR();
         for (int it = tid; it < nm * G * 8; it += MOL_THREADS) {
             const int s8 = it & 7, go = it >> 3, g = go / G, o = go - g * G;
             float s = 0.f;
@@ -896,7 +902,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
                 a.emb[(size_t)(m0 + g) * G + o] = s;
             }
         }
-        __syncthreads();
+        MOL_BAR();
     }
     float* small = slab;
     MOL_STAMP();   // readout forward
@@ -935,7 +941,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
 #pragma unroll
             for (int k = 0; k < 2; ++k) { const int o = h32 + 32 * k; if (o < G) dpool[g * 64 + o] = dv * embs[g * 64 + o] * ks[k]; }
         }
-        __syncthreads();
+        MOL_BAR();
         if (tid < G) {
             float s = 0.f;
             for (int gg = 0; gg < nm; ++gg) s += dpool[gg * 64 + tid];
@@ -945,17 +951,18 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
             for (int gg = 0; gg < nm; ++gg) s += m.hv[gg][tid - G];
             small[a.s_loss + (tid - G == 0 ? 1 : 0)] = s;       // [s_loss] sum of the molecules' losses, [s_loss + 1] d ffn bias
         }
-        __syncthreads();
+        MOL_BAR();
     } else if (do_bwd) {
         for (int it = tid; it < nm * G; it += MOL_THREADS) {
             const int g = it / G, o = it - g * G;
             dembs[g * 64 + o] = a.demb[(size_t)(m0 + g) * G + o];
         }
-        __syncthreads();
+        MOL_BAR();
     }
     MOL_STAMP();   // head
     if (!do_bwd) return;
     __threadfence_block();      // (pair records, chirality signs and input rows written above are read back below by other threads)
+    __syncthreads();
 
     // ------------------------------------------------------------------------------------- readout, backward ----
     for (int it = tid; it < nm * H * 8; it += MOL_THREADS) {     // d pooled = d emb . W2   (8 threads per element)
@@ -978,7 +985,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
             small[a.s_lin2 + it] = s;
         }
     }
-    __syncthreads();
+    MOL_BAR();
     for (int it = tid; it < NR * HP; it += MOL_THREADS) {        // d pre = d pooled[mol] * swish'(pre), in place
         const int j = it / HP, h = it - j * HP;
         float v = 0.f;
@@ -988,7 +995,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
         }
         pre[j * MOL_HS + h] = v;
     }
-    __syncthreads();
+    MOL_BAR();
     for (int it = tid; it < H * 8; it += MOL_THREADS) {          // d b1   (8 threads per hidden unit)
         const int s8 = it & 7, h = it >> 3;
         float s = 0.f;
@@ -1021,7 +1028,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
             for (int i = 0; i < 4; ++i) sim[(mt * 16 + 4 * q + i) * MOL_XS + ft * 16 + r] = acc[i];
         }
     }
-    __syncthreads();
+    MOL_BAR();
 
     MOL_STAMP();   // readout backward
     // -------------------------------------------------------------------------------------- the layers, backward ----
@@ -1048,7 +1055,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
         mol_pairs_backward<2>(Y, last, dh, gtab, m, pf2, tid);
         mol_pairs_backward<3>(Y, last, dh, gtab, m, pf3, tid);
         mol_pairs_backward<4>(Y, last, dh, gtab, m, pf4, tid);
-        __syncthreads();
+        MOL_BAR();
         MOL_STAMP();   // bwd layer: pairs
         if (tid < 12) {
             float s = 0.f;
@@ -1067,10 +1074,10 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
             mol_edge_grad_degree<1>(Y, gtab, bond, eslab, m, tid); mol_edge_grad_degree<2>(Y, gtab, bond, eslab, m, tid);
             mol_edge_grad_degree<3>(Y, gtab, bond, eslab, m, tid); mol_edge_grad_degree<4>(Y, gtab, bond, eslab, m, tid);
         }
-        __syncthreads();
+        MOL_BAR();
         MOL_STAMP();   // bwd layer: input rows back, edge-support gradient
         mol_row_norms(U, NR, XS, FP, m, tid);
-        __syncthreads();
+        MOL_BAR();
         for (int it = tid; it < NR * (FP / 4); it += MOL_THREADS) {
             const int j = it / (FP / 4), c4 = it - j * (FP / 4);
             v4 v = *(v4*)&U[j * XS + 4 * c4];
@@ -1103,7 +1110,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
                 const int j = it / np, c = it - j * np;
                 Cf[j * MOL_RS + Y.rows_real[p] + c] = 0.f;
             }
-            __syncthreads();
+            MOL_BAR();
             MOL_STAMP();   // bwd layer: Cf of the pass
             // (s3) G += Cf . BankU  (wave = feature tile)
             if (gft < KJ) {
@@ -1135,7 +1142,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
                     }
                 }
             }
-            __syncthreads();
+            MOL_BAR();
             MOL_STAMP();   // bwd layer: products of the pass
         }
         // (s5) G -> oth (the coefficient table is dead), then d loss / d (input rows) = inv (G - (G . u) u), in place
@@ -1144,7 +1151,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
             // when the chunk has no such atom: the reduction sums every chunk's rows)
             if (m.dcnt[3] > 0) mol_bwd4_rows(Y, gtab, Cf, m, tid);
             mol_bwd4_bank(Y, gtab, U, slab + Y.slab_bank + (size_t)Y.row_base[1] * FP, m, tid);
-            __syncthreads();
+            MOL_BAR();
         }
         if (li > 0 && tid < 16) m.mix[tid] = a.layer[li - 1].mix[tid];      // (this layer's are not read again)
         // (the contraction's parts in wave order: part 0 stores, the others add)
@@ -1159,7 +1166,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
                         *dst = part == 0 ? gacc[mt][i] : *dst + gacc[mt][i];
                     }
             }
-            __syncthreads();
+            MOL_BAR();
         }
         if (d4_valu && Y.L[3] > 0 && m.dcnt[3] > 0) {        // G += the degree-4 part rows, in part order
             const int KV = FP >> 2, ne = m.dcnt[3] * 5;
@@ -1169,7 +1176,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
                 for (int e = 0; e < ne; ++e) if (m.tgt[e] == j) v += *(const v4*)&Cf[e * XS + 4 * k];
                 *(v4*)&oth[j * XS + 4 * k] = v;
             }
-            __syncthreads();
+            MOL_BAR();
         }
         for (int j0 = 0; j0 < NR; j0 += MOL_THREADS / 8) {
             const int j = j0 + (tid >> 3), s8 = tid & 7;
@@ -1190,7 +1197,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
                 }
             }
         }
-        __syncthreads();
+        MOL_BAR();
         MOL_STAMP();   // bwd layer: projection
         float* t_ = dh; dh = oth; oth = t_;
     }
