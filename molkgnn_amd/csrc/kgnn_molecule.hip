@@ -68,6 +68,9 @@ struct MolArgs {
     int mode; const float *ffn_w, *ffn_b, *y; float head_drop; const int64_t* rng;
     const float* demb; float* emb; float* pred;
     // partial outputs
+    // small read-only tables copied into LDS at the start of a chunk when they fit behind the buffers (the NT = 2 variant: unit
+    // edge-support rows of every layer, lin1 padded and transposed, lin2): a global load behind every use otherwise
+    int cache_on, c_edge[MKGNN_MOLECULE_MAX_LAYERS], c_w1p, c_w1pt, c_w2, cache_floats;
     unsigned long long* stamps;        // diagnostics (mkgnn_debug_molecule_stamps): cycle stamps of chunk 0's phases
     float* slab; size_t slab_floats;   // per chunk: [small | dW1 | per layer: bank, edge]
     int s_loss, s_ffn, s_lin2, s_lin1b, s_bn; size_t s_dw1;      // offsets inside the small slab / the slab
@@ -219,6 +222,9 @@ struct MolMeta {                        // (LDS)
     int mol_first[MOL_MAXM + 1];
     float red[MOL_NW][16];
     float hv[MOL_MAXM][2];
+    float mixs[MKGNN_MOLECULE_MAX_LAYERS][16];   // every layer's mixing weights
+    const float* p_edge[MKGNN_MOLECULE_MAX_LAYERS];   // unit edge-support rows of a layer, lin1 padded / transposed, lin2: in the
+    const float *p_w1p, *p_w1pt, *p_w2;               // LDS cache behind this struct, or where the preparation launch left them
     float mix[16];                      // the current layer's mixing weights [degree][w_s, w_c, w_e, sum] (a global load per use otherwise)
     int back[MOL_MAXA];
     int tgt[5 * 8];                     // backward, degree 4 on the vector pipe: target atom of every part row                 // per atom, 2 bits per slot: the position of the atom in that neighbour's own slot list
@@ -290,7 +296,7 @@ __device__ __forceinline__ void mol_row_norms(const float* buf, int NAP, int XS,
 // One degree's (atom, kernel) pairs of the forward: permutation scan on the gathered d x d matrix, edge score with the chosen
 // order, mix, chirality sign (kernels.py:353-425), written into the chunk's sim rows and the pair records.
 template <int D>
-__device__ __forceinline__ void mol_pairs_forward(MolLayerK& Y, bool last, const float* St, float* sim, const float* bond,
+__device__ __forceinline__ void mol_pairs_forward(MolLayerK& Y, const float* edgeU, bool last, const float* St, float* sim, const float* bond,
                                                   const MolMeta& m, int tid) {
     const int L = Y.L[D - 1], cnt = m.dcnt[D - 1];
     if (L == 0 || cnt == 0) return;
@@ -304,7 +310,7 @@ __device__ __forceinline__ void mol_pairs_forward(MolLayerK& Y, bool last, const
         v4 es0[D], es1[D];
 #pragma unroll
         for (int b = 0; b < D; ++b) {
-            const float* es = Y.edgeU + (size_t)(Y.e_row[D - 1] + b * L + l) * 8;
+            const float* es = edgeU + (size_t)(Y.e_row[D - 1] + b * L + l) * 8;
             es0[b] = *(const v4*)es; es1[b] = *(const v4*)(es + 4);
         }
         float cm[D][D];
@@ -452,7 +458,7 @@ __device__ __forceinline__ float mol_dot4(const v4 a, const v4 b, float acc) {
     acc = fmaf(a[0], b[0], acc); acc = fmaf(a[1], b[1], acc); acc = fmaf(a[2], b[2], acc); return fmaf(a[3], b[3], acc);
 }
 
-__device__ __forceinline__ void mol_pairs4_valu(MolLayerK& Y, bool last, const float* xin, int XS, float* sim, const float* bond,
+__device__ __forceinline__ void mol_pairs4_valu(MolLayerK& Y, const float* edgeU, bool last, const float* xin, int XS, float* sim, const float* bond,
                                                 const MolMeta& m, int tid) {
     constexpr int D = 4;
     const int L = Y.L[3], cnt = m.dcnt[3];
@@ -470,7 +476,7 @@ __device__ __forceinline__ void mol_pairs4_valu(MolLayerK& Y, bool last, const f
         v4 es0[D], es1[D];
 #pragma unroll
         for (int b = 0; b < D; ++b) {
-            const float* es = Y.edgeU + (size_t)(Y.e_row[3] + b * L + l) * 8;
+            const float* es = edgeU + (size_t)(Y.e_row[3] + b * L + l) * 8;
             es0[b] = *(const v4*)es; es1[b] = *(const v4*)(es + 4);
         }
         float cm[D][D], cc = 0.f;
@@ -631,6 +637,25 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
     constexpr int ksa = 4 * NTR;                         // k-steps of a product that contracts over the chunk's atoms
     float* slab = a.slab + (size_t)chunk * a.slab_floats;
     const bool do_head = (a.mode & MKGNN_MOLECULE_HEAD) != 0, do_bwd = (a.mode & MKGNN_MOLECULE_BACKWARD) != 0;
+    {
+        float* cache = (float*)((char*)&m + ((sizeof(MolMeta) + 15) & ~(size_t)15));
+        if (tid < a.nl * 16) m.mixs[tid >> 4][tid & 15] = a.layer[tid >> 4].mix[tid & 15];
+        if (a.cache_on) {
+            for (int li = 0; li < a.nl; ++li) {
+                const v4* src = (const v4*)a.layer[li].edgeU;
+                v4* dst = (v4*)(cache + a.c_edge[li]);
+                for (int i = tid; i < a.layer[li].ER * 2; i += MOL_THREADS) dst[i] = src[i];
+            }
+            for (int i = tid; i < a.HP * 28; i += MOL_THREADS) { ((v4*)(cache + a.c_w1p))[i] = ((const v4*)a.w1p)[i]; ((v4*)(cache + a.c_w1pt))[i] = ((const v4*)a.w1pt)[i]; }
+            for (int i = tid; i < a.G * a.H; i += MOL_THREADS) cache[a.c_w2 + i] = a.w2[i];
+        }
+        if (tid < a.nl) m.p_edge[tid] = a.cache_on ? cache + a.c_edge[tid] : a.layer[tid].edgeU;
+        if (tid == 0) {
+            m.p_w1p = a.cache_on ? cache + a.c_w1p : a.w1p;
+            m.p_w1pt = a.cache_on ? cache + a.c_w1pt : a.w1pt;
+            m.p_w2 = a.cache_on ? cache + a.c_w2 : a.w2;
+        }
+    }
     int stamp_i = 0;
 #define MOL_STAMP() do { if (a.stamps && chunk == 0 && tid == 0) a.stamps[stamp_i] = __builtin_readcyclecounter(); ++stamp_i; } while (0)
     MOL_STAMP();
@@ -777,7 +802,8 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
             }
         };
         fetch_pass(0);
-        if (tid < 16) m.mix[tid] = Y.mix[tid];
+        const float* edgeU = m.p_edge[li];
+        if (tid < 16) m.mix[tid] = m.mixs[li][tid];
         mol_row_norms(xin, NR, XS, FP, m, tid);
         // this layer's input rows, kept for the backward half (and zero the sim rows)
         if (do_bwd) for (int it = tid; it < NA * (FP / 4); it += MOL_THREADS) {
@@ -834,10 +860,10 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
             if (p == 0 && !d4_valu) fetch_pass(1);      // (arrives under the pairs of pass 0)
             MOL_BAR();
             MOL_STAMP();   // layer: products of the pass
-            if (p == 0) { mol_pairs_forward<1>(Y, last, St, sim, bond, m, tid); mol_pairs_forward<2>(Y, last, St, sim, bond, m, tid);
-                          mol_pairs_forward<3>(Y, last, St, sim, bond, m, tid);
-                          if (d4_valu) mol_pairs4_valu(Y, last, xin, XS, sim, bond, m, tid); }
-            else mol_pairs_forward<4>(Y, last, St, sim, bond, m, tid);
+            if (p == 0) { mol_pairs_forward<1>(Y, edgeU, last, St, sim, bond, m, tid); mol_pairs_forward<2>(Y, edgeU, last, St, sim, bond, m, tid);
+                          mol_pairs_forward<3>(Y, edgeU, last, St, sim, bond, m, tid);
+                          if (d4_valu) mol_pairs4_valu(Y, edgeU, last, xin, XS, sim, bond, m, tid); }
+            else mol_pairs_forward<4>(Y, edgeU, last, St, sim, bond, m, tid);
             MOL_BAR();
             MOL_STAMP();   // layer: pairs of the pass
         }
@@ -874,7 +900,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
                 const v4 av = *(const v4*)&xin[(mt * 16 + r) * MOL_XS + 16 * j + 4 * q];
-                const v4 bv = *(const v4*)(a.w1p + (size_t)(ht * 16 + r) * 112 + 16 * j + 4 * q);
+                const v4 bv = *(const v4*)(m.p_w1p + (size_t)(ht * 16 + r) * 112 + 16 * j + 4 * q);
                 acc = mfma4(av, bv, acc);
             }
             const float bias = (a.b1 && ht * 16 + r < H) ? a.b1[ht * 16 + r] : 0.f;
@@ -894,7 +920,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
         for (int it = tid; it < nm * G * 8; it += MOL_THREADS) {
             const int s8 = it & 7, go = it >> 3, g = go / G, o = go - g * G;
             float s = 0.f;
-            for (int h = s8; h < H; h += 8) s = fmaf(a.w2[(size_t)o * H + h], pooled[g * 64 + h], s);
+            for (int h = s8; h < H; h += 8) s = fmaf(m.p_w2[(size_t)o * H + h], pooled[g * 64 + h], s);
             s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
             if (s8 == 0) {
                 if (a.b2) s = fmaf((float)(m.mol_first[g + 1] - m.mol_first[g]), a.b2[o], s);
@@ -968,7 +994,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
     for (int it = tid; it < nm * H * 8; it += MOL_THREADS) {     // d pooled = d emb . W2   (8 threads per element)
         const int s8 = it & 7, gh = it >> 3, g = gh / H, h = gh - g * H;
         float s = 0.f;
-        for (int o = s8; o < G; o += 8) s = fmaf(dembs[g * 64 + o], a.w2[(size_t)o * H + h], s);
+        for (int o = s8; o < G; o += 8) s = fmaf(dembs[g * 64 + o], m.p_w2[(size_t)o * H + h], s);
         s += __shfl_xor(s, 4, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 1, 64);
         if (s8 == 0) dpool[g * 64 + h] = s;
     }
@@ -1021,7 +1047,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
             v4 acc = v4{0.f, 0.f, 0.f, 0.f};
             for (int j = 0; j < HT; ++j) {
                 const v4 av = *(const v4*)&pre[(mt * 16 + r) * MOL_HS + 16 * j + 4 * q];
-                const v4 bv = *(const v4*)(a.w1pt + (size_t)(ft * 16 + r) * HP + 16 * j + 4 * q);
+                const v4 bv = *(const v4*)(m.p_w1pt + (size_t)(ft * 16 + r) * HP + 16 * j + 4 * q);
                 acc = mfma4(av, bv, acc);
             }
 #pragma unroll
@@ -1153,7 +1179,7 @@ __device__ __forceinline__ void molecule_step_body(MolArgsP ap, float* lds) {
             mol_bwd4_bank(Y, gtab, U, slab + Y.slab_bank + (size_t)Y.row_base[1] * FP, m, tid);
             MOL_BAR();
         }
-        if (li > 0 && tid < 16) m.mix[tid] = a.layer[li - 1].mix[tid];      // (this layer's are not read again)
+        if (li > 0 && tid < 16) m.mix[tid] = m.mixs[li - 1][tid];          // (this layer's are not read again)
         // (the contraction's parts in wave order: part 0 stores, the others add)
 #pragma unroll
         for (int part = 0; part < MOL_KSPLIT; ++part) {
@@ -1222,7 +1248,9 @@ __global__ void __launch_bounds__(MOL_THREADS) molecule_step_kernel(MolArgs a) {
     MolArgsP ap = (MolArgsP)__builtin_amdgcn_kernarg_segment_ptr();        // (`a` is the kernel's first and only argument)
     if constexpr (NT > 2) {
         const int m0 = a.chunk_ptr[blockIdx.x], m1 = a.chunk_ptr[blockIdx.x + 1];
-        if (a.mol_ptr[m1] - a.mol_ptr[m0] > 32) { molecule_step_body<NT, NT>(ap, lds); return; }
+        const int64_t na = a.mol_ptr[m1] - a.mol_ptr[m0];
+        if (na > 48) { molecule_step_body<NT, NT>(ap, lds); return; }
+        if (na > 32) { molecule_step_body<NT, 3>(ap, lds); return; }      // (molecules of 33 .. 48 atoms: three atom tiles, not four)
     }
     molecule_step_body<NT, 2>(ap, lds);
 }
@@ -1476,8 +1504,9 @@ MolWs mol_ws(const MolShape& s, int64_t n_atoms, int64_t n_chunks) {
 
 size_t mol_lds_bytes(int NT) {
     const int NAP = 16 * NT;
-    return (size_t)(2 * NAP * MOL_XS + NAP * MOL_RS + NAP * 32) * 4 + sizeof(MolMeta);
+    return (size_t)(2 * NAP * MOL_XS + NAP * MOL_RS + NAP * 32) * 4 + ((sizeof(MolMeta) + 15) & ~(size_t)15);
 }
+constexpr size_t MOL_LDS_MAX = 160 * 1024;
 
 }  // namespace
 
@@ -1600,15 +1629,25 @@ int mkgnn_molecule_step(const mkgnn_molecule_net* net, const mkgnn_molecule_batc
     // chunks of at most 32 atoms take half the LDS and half the products
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)molecule_step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mol_lds_bytes(2));
-        (void)hipFuncSetAttribute((const void*)molecule_step_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mol_lds_bytes(4));
+        (void)hipFuncSetAttribute((const void*)molecule_step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MOL_LDS_MAX);
+        (void)hipFuncSetAttribute((const void*)molecule_step_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MOL_LDS_MAX);
         attr_set = true;
     }
     if (batch->max_chunk_atoms < 1 || batch->max_chunk_atoms > MKGNN_MOLECULE_MAX_ATOMS)
         return api_fail("%s: max_chunk_atoms = %lld outside 1..%d", who, (long long)batch->max_chunk_atoms, MKGNN_MOLECULE_MAX_ATOMS);
     const bool small_chunks = batch->max_chunk_atoms <= 32;
-    if (small_chunks) molecule_step_kernel<2><<<(unsigned)batch->n_chunks, MOL_THREADS, mol_lds_bytes(2), st>>>(a);
-    else molecule_step_kernel<4><<<(unsigned)batch->n_chunks, MOL_THREADS, mol_lds_bytes(4), st>>>(a);
+    {   // the LDS table cache, if it fits behind this variant's buffers
+        int o = 0;
+        for (int li = 0; li < s.nl; ++li) { a.c_edge[li] = o; o += (s.ER[li] * 8 + 3) / 4 * 4; }
+        a.c_w1p = o; o += s.HP * 112;
+        a.c_w1pt = o; o += s.HP * 112;
+        a.c_w2 = o; o += (s.G * s.H + 3) / 4 * 4;
+        a.cache_floats = o;
+        a.cache_on = mol_lds_bytes(small_chunks ? 2 : 4) + (size_t)o * 4 <= MOL_LDS_MAX ? 1 : 0;
+    }
+    const size_t lds_bytes = mol_lds_bytes(small_chunks ? 2 : 4) + (a.cache_on ? (size_t)a.cache_floats * 4 : 0);
+    if (small_chunks) molecule_step_kernel<2><<<(unsigned)batch->n_chunks, MOL_THREADS, lds_bytes, st>>>(a);
+    else molecule_step_kernel<4><<<(unsigned)batch->n_chunks, MOL_THREADS, lds_bytes, st>>>(a);
 
     // ---- reduction of the chunks' partials (and the loss; the head's generator moves on)
     MolReduceArgs ra{};

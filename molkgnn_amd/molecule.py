@@ -44,6 +44,22 @@ class MoleculePlan:
         self.n_mols, self.n_chunks, self.max_chunk_atoms = n_mols, n_chunks, max_chunk_atoms
 
 
+def chunk_molecules(sizes, cap: int):
+    """Greedy chunk table: consecutive whole molecules while the chunk stays within ``cap`` atoms (a molecule larger than
+    ``cap`` gets a chunk of its own) and ``MAX_MOLS`` molecules.  Returns (chunk_ptr: first molecule of every chunk + the
+    molecule count, atoms of the largest chunk)."""
+    chunk_ptr, cur_atoms, cur_mols, max_atoms = [0], 0, 0, 0
+    for g, sz in enumerate(sizes):
+        if cur_mols and (cur_atoms + sz > max(cap, sz) or cur_mols >= MAX_MOLS):
+            chunk_ptr.append(g)
+            max_atoms = max(max_atoms, cur_atoms)
+            cur_atoms, cur_mols = 0, 0
+        cur_atoms += sz
+        cur_mols += 1
+    chunk_ptr.append(len(sizes))
+    return chunk_ptr, max(max_atoms, cur_atoms)
+
+
 def build_molecule_plan(plan: BatchPlan, batch_vec: torch.Tensor, n_mols: Optional[int], cap: Optional[int] = None) -> Optional[MoleculePlan]:
     """The chunk table, or ``None`` when the batch does not qualify.  One host synchronisation (the molecule sizes);
     call it outside captures -- ``molecule_plan`` caches the result on the batch's index plan."""
@@ -76,16 +92,7 @@ def build_molecule_plan(plan: BatchPlan, batch_vec: torch.Tensor, n_mols: Option
         return None
     if cap is None:
         cap = 32 if n_mols <= 512 else MAX_ATOMS
-    chunk_ptr, cur_atoms, cur_mols, max_atoms = [0], 0, 0, 0
-    for g, sz in enumerate(sizes):
-        if cur_mols and (cur_atoms + sz > max(cap, sz) or cur_mols >= MAX_MOLS):
-            chunk_ptr.append(g)
-            max_atoms = max(max_atoms, cur_atoms)
-            cur_atoms, cur_mols = 0, 0
-        cur_atoms += sz
-        cur_mols += 1
-    chunk_ptr.append(n_mols)
-    max_atoms = max(max_atoms, cur_atoms)
+    chunk_ptr, max_atoms = chunk_molecules(sizes, cap)
     mol_ptr = torch.zeros(n_mols + 1, dtype=torch.int64)
     mol_ptr[1:] = torch.tensor(sizes, dtype=torch.int64).cumsum(0)
     atom_deg = torch.zeros(n, dtype=torch.int8, device=dev)

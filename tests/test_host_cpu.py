@@ -373,3 +373,51 @@ def test_native_collate_writes_the_numpy_collate_byte_for_byte(tmp_path):
     with pytest.raises(MolKGNNLibraryError, match="too small"):
         S.collate_compact_native(sh, 0, 64, shape, buf[:1024])
     del shards, sh
+
+
+def test_molecule_chunk_table_and_abi_structs():
+    """Host side of the molecule-resident step (molkgnn_amd.molecule): the greedy chunk table keeps molecules whole, stays
+    within the atom cap and 16 molecules per chunk, gives an oversized molecule a chunk of its own; the ctypes structs have
+    the header's sizes (a C compile of include/molkgnn_hip.h); the shape query needs no GPU."""
+    import subprocess
+    import tempfile
+    from molkgnn_amd import _lib
+    from molkgnn_amd import molecule as M
+    sizes = [25, 8, 8, 8, 40, 3, 30, 2] + [1] * 40 + [60, 33]
+    ptr, big = M.chunk_molecules(sizes, 32)
+    assert ptr[0] == 0 and ptr[-1] == len(sizes) and all(b > a for a, b in zip(ptr, ptr[1:]))
+    per_chunk = [sum(sizes[a:b]) for a, b in zip(ptr, ptr[1:])]
+    for (a, b), atoms in zip(zip(ptr, ptr[1:]), per_chunk):
+        assert b - a <= M.MAX_MOLS
+        assert atoms <= 32 or b - a == 1            # over the cap only as a single oversized molecule
+    assert big == max(per_chunk) == 60 and sum(per_chunk) == sum(sizes)
+    assert M.chunk_molecules([], 32) == ([0, 0], 0) or M.chunk_molecules([], 32)[0][-1] == 0
+    src = '#include "molkgnn_hip.h"\n#include <stdio.h>\nint main(void){printf("%zu %zu %zu %d\\n", sizeof(mkgnn_molecule_layer), ' \
+          'sizeof(mkgnn_molecule_net), sizeof(mkgnn_molecule_batch), MKGNN_MOLECULE_MAX_ATOMS);return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "sz.c"), "w").write(src)
+        subprocess.run(["gcc", "-std=c99", "-I", os.path.join(REPO, "include"), os.path.join(d, "sz.c"), "-o", os.path.join(d, "sz")], check=True)
+        got = subprocess.run([os.path.join(d, "sz")], capture_output=True, text=True, check=True).stdout.split()
+    assert [int(v) for v in got] == [ctypes.sizeof(_lib.MoleculeLayer), ctypes.sizeof(_lib.MoleculeNet),
+                                     ctypes.sizeof(_lib.MoleculeBatch), M.MAX_ATOMS]
+    # the shape query is host code: the reference's 3-layer model qualifies, a 5-layer one or a 113-kernel layer does not
+    lib = _lib.load()
+
+    def net(layers, counts, x_dim=28, H=32, G=32):
+        st = _lib.MoleculeNet()
+        st.num_layers, st.E = layers, 7
+        F = x_dim
+        for li in range(min(layers, 4)):
+            st.layer[li].F = F
+            for d in range(4):
+                st.layer[li].bank[d].num_kernels = counts[d]
+            F = sum(counts)
+        st.readout.F, st.readout.H, st.readout.G = F, H, G
+        return st
+    assert lib.mkgnn_molecule_supported(ctypes.byref(net(3, (10, 20, 30, 50))), 28) == 1
+    assert lib.mkgnn_molecule_supported(ctypes.byref(net(4, (1, 1, 1, 1))), 28) == 1
+    assert lib.mkgnn_molecule_supported(ctypes.byref(net(5, (10, 20, 30, 50))), 28) == 0
+    assert lib.mkgnn_molecule_supported(ctypes.byref(net(3, (10, 20, 30, 53))), 28) == 0        # K = 113 > 112
+    assert lib.mkgnn_molecule_supported(ctypes.byref(net(3, (10, 20, 30, 50), x_dim=40)), 40) == 0
+    assert lib.mkgnn_molecule_supported(ctypes.byref(net(3, (10, 20, 30, 50), H=65)), 28) == 0
+    assert lib.mkgnn_molecule_workspace_bytes(ctypes.byref(net(3, (10, 20, 30, 50))), 28, 400, 16) > 7_000_000
