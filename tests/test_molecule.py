@@ -274,3 +274,37 @@ def test_step_under_graph_capture_replays_the_eager_step(monkeypatch):
     l1, p1 = run(True)
     assert l0[0] > 0 and all(abs(a - c) <= 1e-6 * max(1.0, abs(a)) for a, c in zip(l0, l1)), (l0, l1)
     assert torch.allclose(p0, p1, atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("mols", [16, 200])
+def test_step_is_bit_reproducible(mols, monkeypatch):
+    """Every sum on the path has a fixed order (owner threads for the coefficient scatter, chunk-ascending slab sums, no
+    float atomics): the same step run five times gives the same bits -- loss, every gradient, the pair records.  (A missing
+    barrier between two LDS phases shows up here long before it shows up against the oracle.)"""
+    dev = _dev()
+    from molkgnn_amd import molecule as M
+    from molkgnn_amd.synthetic import make_batch
+    from molkgnn_amd.train import GNNModel
+    from molkgnn_amd.train import backward as train_backward
+    monkeypatch.setattr(M, "_MODE", "1")
+    torch.manual_seed(5)
+    model = GNNModel(ffn_dropout_rate=0.0).to(dev).train()
+    b = make_batch(mols, seed=77 + mols, duplicate_fraction=0.1)
+    b.num_graphs = mols
+    bd = b.to(dev)
+    runs = []
+    for _ in range(5):
+        cap = {}
+        monkeypatch.setattr(M, "debug_capture", cap)
+        model.zero_grad(set_to_none=True)
+        loss = model.loss(bd)
+        train_backward(loss)
+        torch.cuda.synchronize()
+        grads = [None if p.grad is None else p.grad.clone() for p in model.parameters()]
+        pairs = [sv[0].clone() for layer in cap["saved"] for sv in layer if sv is not None]
+        runs.append((loss.detach().clone(), grads, pairs))
+    for loss, grads, pairs in runs[1:]:
+        assert torch.equal(loss, runs[0][0])
+        assert all((a is None and c is None) or torch.equal(a, c) for a, c in zip(grads, runs[0][1]))
+        assert all(torch.equal(a, c) for a, c in zip(pairs, runs[0][2]))
+    assert sum(g is not None for g in runs[0][1]) >= 70
