@@ -176,6 +176,38 @@ def small_batch_leg(args, model, opt, dev, log):
         del graphs
         return wins
 
+    def forward_ms(batches):
+        """Forward only (eval mode, no gradient: scoring molecules), one hipGraph per resident batch."""
+        model.eval()
+        try:
+            graphs = []
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for b in batches:
+                    model.gnn_model(b)
+                for b in batches:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=side):
+                        model.gnn_model(b)
+                    graphs.append(g)
+            torch.cuda.current_stream().wait_stream(side)
+            for g in graphs:
+                g.replay()
+            torch.cuda.synchronize()
+            wins = []
+            for _ in range(5):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(200):
+                    graphs[i % 4].replay()
+                torch.cuda.synchronize()
+                wins.append((time.perf_counter() - t0) / 200)
+            del graphs
+            return sorted(wins)[2]
+        finally:
+            model.train()
+
     out = {}
     mode0 = Mol._MODE
     for assay, B in (("435008", 256), ("1798", 16)):
@@ -183,11 +215,13 @@ def small_batch_leg(args, model, opt, dev, log):
         try:
             Mol._MODE = "0"
             pwins = replay_ms(batches)
+            pfwd = forward_ms(batches)
             Mol._MODE = "1"
             try:
                 mwins = replay_ms(batches)
+                mfwd = forward_ms(batches)
             except Exception as exc:
-                mwins = None
+                mwins = mfwd = None
                 log(f"molecule-resident step unavailable ({type(exc).__name__}: {exc})")
             # the path a run takes by default at this batch size (molkgnn_amd.molecule: up to 32 molecules the one-launch step)
             default_mol = mwins is not None and mode0 != "0" and B <= (Mol._MAX_MOLS_FORCED if mode0 == "1" else Mol._MAX_MOLS_AUTO)
@@ -195,6 +229,9 @@ def small_batch_leg(args, model, opt, dev, log):
             mol = {"default_path": "molecule_resident" if default_mol else "per_operator",
                    "per_operator_ms_per_step": round(1e3 * pwins[2], 4),
                    "molecule_resident_ms_per_step": None if mwins is None else round(1e3 * mwins[2], 4),
+                   "forward_only_ms": {"what": "MolKGNNNet.forward in eval mode, no gradient (scoring a batch), graph replay",
+                                       "per_operator": round(1e3 * pfwd, 4),
+                                       "molecule_resident": None if mfwd is None else round(1e3 * mfwd, 4)},
                    "molecule_resident": "prepare + ONE fwd/loss/bwd launch (a workgroup per chunk of whole molecules) + fixed-order "
                                         "reduction + AdamW: 4 launches per step; the default up to 32 molecules (MKGNN_MOLECULE)"}
         finally:

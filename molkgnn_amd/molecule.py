@@ -424,7 +424,11 @@ def _ready(net, data, ffn):
 
 
 def net_forward(net, data) -> Optional[torch.Tensor]:
-    """``MolKGNNNet.forward(data)`` through the molecule-resident kernels, or ``None`` if they do not take it."""
+    """``MolKGNNNet.forward(data)`` through the molecule-resident kernels, or ``None`` if they do not take it.  Only with
+    ``MKGNN_MOLECULE=1``: the forward alone is the slower one even at 16 molecules (0.084 against 0.074 ms per operator, bench.py
+    ``small_batch.*.paths.forward_only_ms``); what the one-launch form wins it wins in the backward, i.e. through ``loss_forward``."""
+    if _MODE != "1":
+        return None
     r = _ready(net, data, None)
     if r is None:
         return None
