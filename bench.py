@@ -808,7 +808,7 @@ def main():
             traffic = None
         # the other kernels of the N-hop layer (the bank gradient is the step's largest line), each alone on the GPU,
         # HIP events in this run; flops / bytes are the USEFUL ones (backward_algorithmic)
-        kernels = [{"kernel": "kc_forward_stream<7>", "ms_per_launch": round(ms, 5), "algorithmic_bytes": by, "algorithmic_flops": fl,
+        kernels = [{"kernel": "kc_forward_stream<7, bf16 operands>" if args.variant == "bf16" else "kc_forward_stream<7>", "ms_per_launch": round(ms, 5), "algorithmic_bytes": by, "algorithmic_flops": fl,
                     "hbm_frac": round(gbs / HBM_PEAK_GBS, 5), "fp32_frac": round(fl / (ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 5)}]
         try:
             if args.variant in ("auto", "mfma"):
@@ -824,7 +824,7 @@ def main():
             log(f"backward kernel timing unavailable ({type(exc).__name__}: {exc})")
         roofline = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
-                    "kernel": ("kc_forward_fused<7, bf16 operands>" if args.variant == "bf16" else "kc_forward_stream<7>")
+                    "kernel": ("kc_forward_stream<7, bf16 operands>" if args.variant == "bf16" else "kc_forward_stream<7>")
                               + ": one launch = KernelSetConv forward of one N-hop layer (F=110, K=110), "
                               "all four degree buckets, training configuration (saves the pair records)",
                     "ms_per_launch": round(ms, 5), "ms_whole_forward_call": round(ms_call, 5),

@@ -171,7 +171,20 @@ template <int D, int KC> constexpr int young_batches(int s, int role) {
     return n;
 }
 
-template <int D, int KC>
+// BF = true: the bf16 similarity path (BASELINE configs[4]) on the streamed skeleton -- round 4.  The node-feature dot products
+// take bf16 operands and accumulate in fp32: a lane's four consecutive columns of a 16-float chunk are exactly the k = 4 (lane >> 4)
+// + i of v_mfma_f32_16x16x16_bf16, so the atom chunk read from the ring is converted (two v_cvt_pk_bf16_f32) and ONE matrix
+// instruction of 8 cycles replaces four of 32; the bank sits in the registers as bf16 (half of them).  Norms, bond cosines,
+// the order scan, mix and stores are the fp32 code.  (Rounds 1-3 ran this variant on the LDS-bank kernel of kgnn_mfma.hip.)
+typedef short s16x4s __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ s16x4s to_bf16x4s(f32x4 v) {
+    // (plain conversions: the compiler emits v_cvt_pk_bf16_f32 and knows the VALU -> MFMA operand hazards)
+    const bf16x4s r = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+    return __builtin_bit_cast(s16x4s, r);
+}
+
+template <int D, int KC, bool BF = false>
 __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDeg& dg, const int cp, const int rank, const int count, float* lds) {
     using T = StreamTraits<D>;
     constexpr int NS = T::NS, NSTREAM = T::NSTREAM, RING = T::RING, S1 = T::S1, META = T::META;
@@ -224,7 +237,8 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
         }
     }
     // ---- one-time: this wave's share of the bank -> registers (unit rows, zero beyond F; idle columns all zero)
-    f32x4 bk[NB][KC];
+    using BankReg = std::conditional_t<BF, s16x4s, f32x4>;
+    BankReg bk[NB][KC];
     float2 bv[D];
     {
         const int l = col_ok ? lcol : 0;
@@ -237,7 +251,8 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
             for (int t = 0; t < KC; ++t) {
                 f32x4 v = *(const f32x4*)(dg.padded + ((size_t)b * L + l) * FPB + 16 * t + 4 * kq);
                 if (zero) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                bk[bl][t] = v;
+                if constexpr (BF) bk[bl][t] = to_bf16x4s(v);
+                else bk[bl][t] = v;
             }
         }
 #pragma unroll
@@ -364,19 +379,29 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
                         if (col + 2 >= F) cur.z = 0.f;
                         if (col + 3 >= F) cur.w = 0.f;
                     }
-                    if constexpr (s < D) {
+                    if constexpr (BF) {
+                        const s16x4s a4 = to_bf16x4s(cur);
+                        if constexpr (s < D) {
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4)
-#pragma unroll
-                            for (int b = 0; b < NBS; ++b)
-                                cm[s][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[q4], bk[b][t][q4], cm[s][b], 0, 0, 0);
+                            for (int b = 0; b < NBS; ++b) cm[s][b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a4, bk[b][t], cm[s][b], 0, 0, 0);
+                        } else {
+                            cc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a4, bk[NBS][t], cc, 0, 0, 0);
+                        }
                     } else {
+                        if constexpr (s < D) {
 #pragma unroll
-                        for (int q4 = 0; q4 < 4; ++q4) cc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[q4], bk[NBS][t][q4], cc, 0, 0, 0);
+                            for (int q4 = 0; q4 < 4; ++q4)
+#pragma unroll
+                                for (int b = 0; b < NBS; ++b)
+                                    cm[s][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[q4], bk[b][t][q4], cm[s][b], 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int q4 = 0; q4 < 4; ++q4) cc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[q4], bk[NBS][t][q4], cc, 0, 0, 0);
+                        }
+                        // pin the order: the next chunk's read ahead of this chunk's matrix instructions
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, s < D ? 4 * NBS : 4, 0);
                     }
-                    // pin the order: the next chunk's read ahead of this chunk's matrix instructions
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, s < D ? 4 * NBS : 4, 0);
                 }
             }
             prio_other();
@@ -586,7 +611,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
 #define MKGNN_EXP_OCC 2
 #endif
 // (KC >= 8, rows of 113 .. 160 floats: the bank alone is up to 160 registers -- one wave per SIMD, 512 registers)
-template <int KC>
+template <int KC, bool BF = false>
 __global__ void __launch_bounds__(256, (KC >= 8 ? 1 : MKGNN_EXP_OCC)) kc_forward_stream(FusedFwdArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int grp = a.blk_group[blockIdx.x];
@@ -599,14 +624,17 @@ __global__ void __launch_bounds__(256, (KC >= 8 ? 1 : MKGNN_EXP_OCC)) kc_forward
     return;
 #endif
     switch (di) {
-        case 0: stream_body<1, KC>(a, a.deg[0], cp, rank, count, lds); break;
-        case 1: stream_body<2, KC>(a, a.deg[1], cp, rank, count, lds); break;
-        case 2: stream_body<3, KC>(a, a.deg[2], cp, rank, count, lds); break;
-        default: stream_body<4, KC>(a, a.deg[3], cp, rank, count, lds); break;
+        case 0: stream_body<1, KC, BF>(a, a.deg[0], cp, rank, count, lds); break;
+        case 1: stream_body<2, KC, BF>(a, a.deg[1], cp, rank, count, lds); break;
+        case 2: stream_body<3, KC, BF>(a, a.deg[2], cp, rank, count, lds); break;
+        default: stream_body<4, KC, BF>(a, a.deg[3], cp, rank, count, lds); break;
     }
 }
 
 // ---------------------------------------------------------------- host ----
+// the bf16 similarity variant runs on the streamed kernel for the model's own row widths (KC = 2: F <= 32; KC = 7: 97 .. 112)
+bool stream_forward_bf16_supported(int F) { const int KC = (F + 15) / 16; return KC == 2 || KC == 7; }
+
 bool stream_forward_supported(int d, int F, int E, int L, int64_t n_atoms, int64_t x_stride, int64_t out_stride, const float* e_unit) {
     if (d < 1 || d > 4 || L < 1 || E < 1 || E > 8 || !e_unit) return false;
     if (F < 1 || F > STREAM_MAX_F || !bank_pitch(F)) return false;   // KC = ceil(F / 16) <= 10 chunks; only the last may be partial
@@ -746,17 +774,17 @@ int stream_forward_groups(const int L[4], const bool use[4]) {
     return n;
 }
 
-template <int KC> static hipError_t launch_stream_kc(const FusedFwdArgs& a, int nb, size_t lds_bytes, hipStream_t st) {
+template <int KC, bool BF = false> static hipError_t launch_stream_kc(const FusedFwdArgs& a, int nb, size_t lds_bytes, hipStream_t st) {
     if (lds_bytes > 64 * 1024) {                         // (two such blocks still fit a CU's 160 KB; KC >= 8: one block per CU)
         static PerDeviceOnce attr_set;
         if (const int slot = attr_set.pending(); slot >= 0) {
-            hipError_t e = hipFuncSetAttribute((const void*)kc_forward_stream<KC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipError_t e = hipFuncSetAttribute((const void*)kc_forward_stream<KC, BF>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (KC >= 8 ? 128 : 80) * 1024);
             if (e != hipSuccess) return e;
             attr_set.set(slot);
         }
     }
-    kc_forward_stream<KC><<<nb, 256, lds_bytes, st>>>(a);
+    kc_forward_stream<KC, BF><<<nb, 256, lds_bytes, st>>>(a);
     return hipGetLastError();
 }
 
@@ -769,6 +797,11 @@ hipError_t launch_forward_stream(FusedFwdArgs& a, const bool use[4], hipStream_t
     if (nb == 0) return hipSuccess;
     if (nb < 0 || lds_bytes > (size_t)(KC >= 8 ? 128 : 80) * 1024) return hipErrorInvalidValue;     // (the caller checks stream_forward_groups first)
     g_last_plan[0].launches.fetch_add(1);
+    if (a.bf16) {
+        if (KC == 2) return launch_stream_kc<2, true>(a, nb, lds_bytes, st);
+        if (KC == 7) return launch_stream_kc<7, true>(a, nb, lds_bytes, st);
+        return hipErrorInvalidValue;                     // (the caller asks stream_forward_bf16_supported first)
+    }
     switch (KC) {
         case 1: return launch_stream_kc<1>(a, nb, lds_bytes, st);
         case 2: return launch_stream_kc<2>(a, nb, lds_bytes, st);

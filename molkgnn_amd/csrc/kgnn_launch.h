@@ -109,6 +109,7 @@ bool stream_forward_supported(int d, int F, int E, int L, int64_t n_atoms, int64
 hipError_t launch_forward_stream(FusedFwdArgs& a, const bool use[4], hipStream_t st);
 int stream_tiles_per_part(int d);
 int stream_column_parts(int d, int L);
+bool stream_forward_bf16_supported(int F);           // the bf16 similarity variant on the streamed kernel (KC = 2 or 7)
 int stream_forward_groups(const int L[4], const bool use[4]);
 hipError_t launch_unit_rows8(const float* in, int64_t n_rows, int E, float* out, hipStream_t st);
 hipError_t launch_backward_generic(int d, const BwdArgs& a, hipStream_t st);

@@ -698,7 +698,10 @@ hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t 
     // The reference's bank shapes take the streamed kernel (kgnn_fwd_stream.hip); every other covered shape, and the
     // bf16 variant, the LDS-bank kernel below.  MKGNN_FWD_STREAM=0: A/B switch (diagnostics).
     static const char* env_stream = getenv("MKGNN_FWD_STREAM");
-    const bool stream_on = !(env_stream && env_stream[0] == '0') && !a.bf16;
+    // (round 4: the bf16 variant too, for the model's row widths; MKGNN_BF16_STREAM=0 keeps it on the LDS-bank kernel)
+    static const char* env_bf = getenv("MKGNN_BF16_STREAM");
+    const bool bf_stream = !(env_bf && env_bf[0] == '0') && stream_forward_bf16_supported(a.F);
+    const bool stream_on = !(env_stream && env_stream[0] == '0') && (!a.bf16 || bf_stream);
     bool use_stream[4], use_bank[4];
     bool any_bank = false;
     for (int i = 0; i < 4; ++i) {
@@ -722,6 +725,7 @@ hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t 
     const int time_reps = g_time_fused.load() ? g_time_reps.load() : 1;
     if (g_time_fused.load()) (void)hipEventRecord(g_ev0, st);
     for (int rep = 0; rep < time_reps; ++rep) {
+    {
         FusedFwdArgs s = a;
         hipError_t e = launch_forward_stream(s, use_stream, st);
         if (e != hipSuccess) return e;
@@ -741,6 +745,7 @@ hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t 
             }
         }
     }
+    }   // (timing repetitions: both launches of a call inside the event pair)
     if (g_time_fused.load()) (void)hipEventRecord(g_ev1, st);
     return hipGetLastError();
 }
