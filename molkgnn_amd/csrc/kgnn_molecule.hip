@@ -1627,11 +1627,14 @@ int mkgnn_molecule_step(const mkgnn_molecule_net* net, const mkgnn_molecule_batc
     a.slab = (float*)(ws + w.slab); a.slab_floats = s.slab_floats;
     a.s_loss = s.s_loss; a.s_ffn = s.s_ffn; a.s_lin2 = s.s_lin2; a.s_lin1b = s.s_lin1b; a.s_bn = s.s_bn; a.s_dw1 = s.s_dw1;
     // chunks of at most 32 atoms take half the LDS and half the products
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)molecule_step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MOL_LDS_MAX);
-        (void)hipFuncSetAttribute((const void*)molecule_step_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MOL_LDS_MAX);
-        attr_set = true;
+    {   // (the LDS ceiling is a per-device function attribute)
+        static PerDeviceOnce attr_set;
+        if (const int slot = attr_set.pending(); slot >= 0) {
+            hipError_t e2 = hipFuncSetAttribute((const void*)molecule_step_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MOL_LDS_MAX);
+            if (e2 == hipSuccess) e2 = hipFuncSetAttribute((const void*)molecule_step_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)MOL_LDS_MAX);
+            if (e2 != hipSuccess) return api_hip_fail(who, e2);
+            attr_set.set(slot);
+        }
     }
     if (batch->max_chunk_atoms < 1 || batch->max_chunk_atoms > MKGNN_MOLECULE_MAX_ATOMS)
         return api_fail("%s: max_chunk_atoms = %lld outside 1..%d", who, (long long)batch->max_chunk_atoms, MKGNN_MOLECULE_MAX_ATOMS);
