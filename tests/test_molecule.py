@@ -308,3 +308,41 @@ def test_step_is_bit_reproducible(mols, monkeypatch):
         assert all((a is None and c is None) or torch.equal(a, c) for a, c in zip(grads, runs[0][1]))
         assert all(torch.equal(a, c) for a, c in zip(pairs, runs[0][2]))
     assert sum(g is not None for g in runs[0][1]) >= 70
+
+
+def test_zero_norm_rows_through_the_one_launch_step(monkeypatch):
+    """SURVEY 8 a-6 in the molecule-resident kernels: a row of norm < 1e-8 is divided by 1e-8, not by its norm (its cosines
+    are 0, its gradient is v_hat / eps-sized and takes no projection).  With the batch norm's weight and bias at zero EVERY
+    first-layer input row is exactly zero; half of the atoms get a bias back so that both branches run in one chunk."""
+    dev = _dev()
+    from molkgnn_amd import molecule as M
+    from molkgnn_amd.synthetic import make_batch
+    monkeypatch.setattr(M, "_MODE", "1")
+    model, state = _model((10, 20, 30, 50), 3, 32, 11, dev, False)
+    with torch.no_grad():
+        model.node_batch_norm.weight.zero_()
+        model.node_batch_norm.bias.zero_()
+        # columns 0..13: a feature that is non-zero only for every other atom survives through the running statistics
+        model.node_batch_norm.weight[:14] = 1.0
+        model.node_batch_norm.running_mean[:14] = 0.0        # (x = 0 in the live columns is then normalised to exactly 0)
+    state = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    b = make_batch(6, seed=5)
+    b.num_graphs = 6
+    with torch.no_grad():
+        x = b.x.clone()
+        rm, rv = state["node_batch_norm.running_mean"], state["node_batch_norm.running_var"]
+        x[:, :14] = 0.0                                      # (x - mean) = 0 in the live columns ...
+        x[1::2, :14] += torch.randn(x[1::2, :14].shape, generator=torch.Generator().manual_seed(2)) * rv[:14].sqrt()   # ... except for every other atom
+        b.x = x
+    bd = b.to(dev)
+    cap = {}
+    monkeypatch.setattr(M, "debug_capture", cap)
+    emb = model(bd)
+    fwd_cap = dict(cap)
+    cot = torch.randn(6, 32, generator=torch.Generator().manual_seed(4))
+    (emb * cot.to(dev)).sum().backward()
+    x0 = torch.nn.functional.batch_norm(b.x, rm.clone(), rv.clone(), state["node_batch_norm.weight"], state["node_batch_norm.bias"], False, 0.1, 1e-5)
+    assert int((x0.norm(dim=1) == 0).sum()) >= b.x.shape[0] // 2 - 1 and int((x0.norm(dim=1) > 1e-3).sum()) >= b.x.shape[0] // 2 - 1
+    grads = {nm: prm.grad for nm, prm in model.named_parameters()}
+    # (gradients through 1 / eps are 1e7-sized: the relative part of the criterion carries them)
+    assert _check_against_oracle(model, state, b, 3, False, emb, fwd_cap, cot, grads) > 60
