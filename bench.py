@@ -208,6 +208,23 @@ def small_batch_leg(args, model, opt, dev, log):
         finally:
             model.train()
 
+    def eager_ms(batches, n=120):
+        """The same step launched eagerly (no graph: the reference's own training-loop style), host overhead included."""
+        for i in range(10):
+            model.zero_grad(set_to_none=True)
+            train_backward(model.loss(batches[i % 4]))
+            if opt is not None:
+                opt.step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            model.zero_grad(set_to_none=True)
+            train_backward(model.loss(batches[i % 4]))
+            if opt is not None:
+                opt.step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+
     out = {}
     mode0 = Mol._MODE
     for assay, B in (("435008", 256), ("1798", 16)):
@@ -216,19 +233,25 @@ def small_batch_leg(args, model, opt, dev, log):
             Mol._MODE = "0"
             pwins = replay_ms(batches)
             pfwd = forward_ms(batches)
+            peag = eager_ms(batches)
             Mol._MODE = "1"
             try:
                 mwins = replay_ms(batches)
                 mfwd = forward_ms(batches)
+                meag = eager_ms(batches)
             except Exception as exc:
-                mwins = mfwd = None
+                mwins = mfwd = meag = None
                 log(f"molecule-resident step unavailable ({type(exc).__name__}: {exc})")
             # the path a run takes by default at this batch size (molkgnn_amd.molecule: up to 32 molecules the one-launch step)
+            # (a captured step: up to 32 molecules; an eager step also takes it up to 512 -- eager_ms_per_step below)
             default_mol = mwins is not None and mode0 != "0" and B <= (Mol._MAX_MOLS_FORCED if mode0 == "1" else Mol._MAX_MOLS_AUTO)
             wins = mwins if default_mol else pwins
             mol = {"default_path": "molecule_resident" if default_mol else "per_operator",
                    "per_operator_ms_per_step": round(1e3 * pwins[2], 4),
                    "molecule_resident_ms_per_step": None if mwins is None else round(1e3 * mwins[2], 4),
+                   "eager_ms_per_step": {"what": "the same step launched eagerly, host overhead included (no hipGraph)",
+                                         "per_operator": round(1e3 * peag, 4),
+                                         "molecule_resident": None if meag is None else round(1e3 * meag, 4)},
                    "forward_only_ms": {"what": "MolKGNNNet.forward in eval mode, no gradient (scoring a batch), graph replay",
                                        "per_operator": round(1e3 * pfwd, 4),
                                        "molecule_resident": None if mfwd is None else round(1e3 * mfwd, 4)},

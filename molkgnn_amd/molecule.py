@@ -24,12 +24,14 @@ from .plan import BatchPlan
 
 MAX_ATOMS = _lib.MOLECULE_MAX_ATOMS
 MAX_MOLS = _lib.MOLECULE_MAX_MOLS
-# MKGNN_MOLECULE: unset -- batches of up to MKGNN_MOLECULE_AUTO_MOLS (32) molecules, the reference's own regime (README.md:81:
-# batch 16), where the one-launch step is the faster one; '1' -- whenever the model and the batch qualify, up to
-# MKGNN_MOLECULE_MAX_MOLS (512) molecules; '0' -- never.  Measured on MI355X (round 4): 0.238 ms per step at 16
-# molecules against 0.255 ms for the per-operator path, but 0.334 against 0.289 ms at 256 -- a workgroup per molecule is bound
-# by its own fp32 matrix work, and with one chunk per CU the launch lasts as long as its slowest chunk (a 60-atom molecule,
-# or one with six four-bonded atoms), where the per-operator kernels spread a layer over the whole chip.
+# MKGNN_MOLECULE: unset -- the one-launch TRAINING step where it is the faster one: inside a hipGraph capture up to
+# MKGNN_MOLECULE_AUTO_MOLS (32) molecules, launched eagerly up to MKGNN_MOLECULE_MAX_MOLS (512); '1' -- whenever the model and
+# the batch qualify, up to MKGNN_MOLECULE_MAX_MOLS, and MolKGNNNet.forward alone as well; '0' -- never.  Measured on MI355X
+# (round 4).  Replayed graphs: 0.23-0.25 ms per step at 16 molecules against 0.255 per operator, but 0.33 against
+# 0.289 ms at 256 -- a workgroup per molecule is bound by its own fp32 matrix work, and with one chunk per CU the launch lasts
+# as long as its slowest chunk, where the per-operator kernels spread a layer over the whole chip.  Eager steps (the
+# reference's own training-loop style, host-bound): 1.4 ms against 1.95 ms per operator from 64 to 512 molecules -- 4 launches
+# and one autograd node instead of ~36 and a dozen.
 _MODE = os.environ.get("MKGNN_MOLECULE", "")
 _MAX_MOLS_AUTO = int(os.environ.get("MKGNN_MOLECULE_AUTO_MOLS", "32"))
 _MAX_MOLS_FORCED = int(os.environ.get("MKGNN_MOLECULE_MAX_MOLS", "512"))
@@ -122,9 +124,27 @@ def _layer_params(layer) -> Optional[List[torch.Tensor]]:
     return layer._bank_params("train", next(iter(layer.parameters())))[0]
 
 
+_PARAM_CACHE_ATTR = "_mkgnn_molecule_params"
+
+
 def flat_parameters(net, ffn=None):
     """The operator's parameters in a fixed order: 7 tensors per degree per layer, batch norm weight / bias, lin1, lin2
-    (weight, bias each), then the head's weight / bias.  ``None`` for an absent optional tensor."""
+    (weight, bias each), then the head's weight / bias.  ``None`` for an absent optional tensor.  Cached on the module (an
+    eager step at batch 16 is host-bound: rebuilding the list twice per step was a quarter of it); the cache is keyed by the
+    identity of every parameter, so swapping a parameter or a kernel set rebuilds it."""
+    cached = getattr(net, _PARAM_CACHE_ATTR, None)
+    key = (id(ffn),) + tuple(id(p) for p in net.parameters()) + (() if ffn is None else tuple(id(p) for p in ffn.parameters()))
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    out = _flat_parameters(net, ffn)
+    try:
+        object.__setattr__(net, _PARAM_CACHE_ATTR, (key, out))
+    except Exception:
+        pass
+    return out
+
+
+def _flat_parameters(net, ffn=None):
     out = []
     for layer in net.gnn.layers:
         lp = _layer_params(layer)
@@ -158,7 +178,13 @@ def model_qualifies(net, data, ffn=None) -> bool:
     if bn.momentum is None or (not bn.training and bn.running_mean is None):
         return False
     params = flat_parameters(net, ffn)
-    if params is None or not all(_f32(p) for p in params):
+    if params is None:
+        return False
+    okc = getattr(net, "_mkgnn_molecule_f32", None)          # (dtype / device / layout of ~90 tensors: checked once per list)
+    if okc is None or okc[0] is not params:
+        okc = (params, all(_f32(p) for p in params))
+        object.__setattr__(net, "_mkgnn_molecule_f32", okc)
+    if not okc[1] or (params[0] is not None and params[0].device != x.device):
         return False
     if ffn is not None and (ffn.out_features != 1):
         return False
@@ -178,7 +204,9 @@ _SHAPE_OK: dict = {}
 def wanted(n_mols: int) -> bool:
     if _MODE == "0":
         return False
-    return n_mols <= (_MAX_MOLS_FORCED if _MODE == "1" else _MAX_MOLS_AUTO)
+    if _MODE == "1" or not torch.cuda.is_current_stream_capturing():
+        return n_mols <= _MAX_MOLS_FORCED
+    return n_mols <= _MAX_MOLS_AUTO
 
 
 def _net_struct(net, ffn, params, grads, saved, sims, head_dropout, update_running, rng=None, rng_used=None):
