@@ -37,6 +37,11 @@ class FusedAdamW(torch.optim.Optimizer):
         self._table_key = None
         self._table = None
         self._active: dict = {}
+        # per-parameter constants of step() -- group, packed-state pointer, element count, active-flag pointer -- looked up once
+        # and kept while nothing that determines them changes (an eager step of this model is host-bound: ~80 tensors)
+        self._fast: list = []
+        self._fast_sig = None
+        self._ver = 0
 
     def set_grad_active(self, flags: dict) -> None:
         """``{parameter: one-element float32 CUDA tensor}``: a parameter whose flag reads 0 when the step runs is
@@ -47,6 +52,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 raise ValueError("an active flag must be one float32 element on the GPU")
         self._active = dict(flags)
         self._table_key = None
+        self._ver += 1
         self.prepare_state(list(flags))                      # flagged parameters are stepped on the device's say-so: state must exist
 
     # -- state: one buffer per parameter, [exp_avg | exp_avg_sq | step | 2 reserved | a step count per 1024 elements]
@@ -78,6 +84,7 @@ class FusedAdamW(torch.optim.Optimizer):
         st["exp_avg_sq"] = new[n:2 * n].view_as(p)
         st["step"] = new[2 * n:2 * n + 1].view(())
         self._table_key = None
+        self._ver += 1
         return new
 
     @torch.no_grad()
@@ -98,6 +105,7 @@ class FusedAdamW(torch.optim.Optimizer):
     @torch.no_grad()
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        self._ver += 1
         for p in list(self.state):                           # pack now: torch may hand over the caller's tensors uncopied
             if isinstance(p, torch.Tensor) and "exp_avg" in self.state[p]:
                 self.state[p].pop("_packed", None)
@@ -113,26 +121,39 @@ class FusedAdamW(torch.optim.Optimizer):
         rows: List[tuple] = []
         keep = []                                            # tensors the enqueued kernel reads: referenced until the call returns
         dev = None
-        for gi, group in enumerate(self.param_groups):
-            for p in group["params"]:
-                if p.grad is None or p.numel() == 0:         # (an empty bank's tensors have nothing to update)
-                    continue
+        sig = (self._ver, tuple(len(g["params"]) for g in self.param_groups))
+        if sig != self._fast_sig:                            # (param_groups, state or flags changed: look everything up again)
+            self._fast = [[p, gi, None, p.numel(), None] for gi, group in enumerate(self.param_groups) for p in group["params"] if p.numel()]
+            self._fast_sig = sig
+        for ent in self._fast:
+            p = ent[0]
+            g = p.grad
+            if g is None:
+                continue
+            if ent[2] is None or ent[2][1] != p.data_ptr():  # first step with a gradient (or the parameter's storage moved)
                 _lib.require_gpu_tensor(p, "parameter")
                 if p.dtype != torch.float32 or not p.is_contiguous():
                     raise _lib.MolKGNNLibraryError("FusedAdamW needs contiguous float32 parameters")
-                g = p.grad
-                if g.is_sparse:
-                    raise RuntimeError("FusedAdamW does not support sparse gradients")
-                if g.dtype != torch.float32 or not g.is_contiguous():
-                    g = g.float().contiguous()
-                    keep.append(g)
-                if dev is None:
-                    dev = p.device
-                elif p.device != dev:
-                    raise _lib.MolKGNNLibraryError("FusedAdamW: parameters on more than one device")
+                ver = self._ver
+                st_ptr = self._packed_state(p).data_ptr()    # (may allocate: bumps _ver, the list is rebuilt next step)
                 act = self._active.get(p)
-                rows.append((p.data_ptr(), g.data_ptr(), self._packed_state(p).data_ptr(), p.numel(), gi,
-                             None if act is None else act.data_ptr()))
+                ent[2], ent[4] = (st_ptr, p.data_ptr()), (None if act is None else act.data_ptr())
+                if ver != self._ver:
+                    self._fast_sig = None
+            else:
+                st = self.state[p]                           # a state entry replaced from outside (not through load_state_dict)
+                if st["exp_avg"].data_ptr() != ent[2][0]:
+                    ent[2] = (self._packed_state(p).data_ptr(), p.data_ptr())
+            if g.is_sparse:
+                raise RuntimeError("FusedAdamW does not support sparse gradients")
+            if g.dtype != torch.float32 or not g.is_contiguous():
+                g = g.float().contiguous()
+                keep.append(g)
+            if dev is None:
+                dev = p.device
+            elif p.device != dev:
+                raise _lib.MolKGNNLibraryError("FusedAdamW: parameters on more than one device")
+            rows.append((ent[2][1], g.data_ptr(), ent[2][0], ent[3], ent[1], ent[4]))
         if not rows:
             return loss
         key = tuple(rows)
