@@ -284,32 +284,74 @@ def _batch_struct(plan: BatchPlan, mp: MoleculePlan, x: torch.Tensor):
     return b, keep
 
 
+class _Arena:
+    """Slices of ONE device buffer (16-byte aligned), handed out in order: an eager step at these sizes is host-bound, and ~60
+    small ``torch.empty`` calls were a tenth of it."""
+
+    def __init__(self, dev):
+        self.dev, self.want, self.buf, self.off = dev, [], None, 0
+
+    def plan(self, numel: int) -> int:
+        self.want.append(numel)
+        return len(self.want) - 1
+
+    def allocate(self):
+        total = sum((n + 3) // 4 * 4 for n in self.want)
+        self.buf = torch.empty(max(total, 4), dtype=torch.float32, device=self.dev)
+        offs, o = [], 0
+        for n in self.want:
+            offs.append(o)
+            o += (n + 3) // 4 * 4
+        self.offs = offs
+
+    def take(self, slot: int, shape):
+        n = self.want[slot]
+        return self.buf[self.offs[slot]:self.offs[slot] + n].view(shape)
+
+
 def _alloc_state(net, plan: BatchPlan, params, want_grads: bool, want_sims: bool):
-    """Pair records (+ the last layer's chirality record) of every layer, and -- for a backward -- the gradient tensors."""
+    """Pair records (+ the last layer's chirality record) of every layer, and -- for a backward -- the gradient tensors
+    (views of one buffer each: the pair records of a call, the kernel-bank gradients of a call)."""
     dev = plan.device
     layers = net.gnn.layers
-    saved, grads, sims = [], [], []
+    rec, gra = _Arena(dev), _Arena(dev)
+    todo = []
     k = 0
     for li, layer in enumerate(layers):
         lp = params[k:k + 28]
         k += 28
-        sv, gr = [], []
         for d in range(4):
             L, nd = int(lp[7 * d].shape[0]), plan.buckets[d].count
             if L == 0 or nd == 0:
-                sv.append(None)
-                gr.append(None)
+                todo.append(None)
                 continue
-            pr = torch.empty((nd, L, 4), dtype=torch.float32, device=dev)
-            ch = torch.empty((nd, L), dtype=torch.int8, device=dev) if (d == 3 and li == len(layers) - 1) else None
-            sv.append((pr, ch))
+            last4 = d == 3 and li == len(layers) - 1
+            ent = [li, d, nd, L, rec.plan(nd * L * 4), rec.plan((nd * L + 3) // 4) if last4 else None, None]
             if want_grads:
-                gr.append((torch.empty_like(lp[7 * d]), torch.empty_like(lp[7 * d + 1]), torch.empty_like(lp[7 * d + 2]),
-                           torch.empty(4, dtype=torch.float32, device=dev)))
-            else:
-                gr.append(None)
-        saved.append(sv)
-        grads.append(gr)
+                ent[6] = (gra.plan(lp[7 * d].numel()), gra.plan(lp[7 * d + 1].numel()), gra.plan(lp[7 * d + 2].numel()), gra.plan(4))
+            todo.append((ent, lp))
+    rec.allocate()
+    if want_grads:
+        gra.allocate()
+    saved = [[None] * 4 for _ in layers]
+    grads = [[None] * 4 for _ in layers]
+    for item in todo:
+        if item is None:
+            continue
+        (li, d, nd, L, s_pr, s_ch, s_g), lp = item
+        pr = rec.take(s_pr, (nd, L, 4))
+        ch = None
+        if s_ch is not None:
+            ch = rec.take(s_ch, ((nd * L + 3) // 4,)).view(torch.int8)[:nd * L].view(nd, L)
+        saved[li][d] = (pr, ch)
+        if s_g is not None:
+            grads[li][d] = (gra.take(s_g[0], lp[7 * d].shape), gra.take(s_g[1], lp[7 * d + 1].shape),
+                            gra.take(s_g[2], lp[7 * d + 2].shape), gra.take(s_g[3], (4,)))
+    sims = []
+    k = 0
+    for li in range(len(layers)):
+        lp = params[k:k + 28]
+        k += 28
         K = sum(int(lp[7 * d].shape[0]) for d in range(4))
         sims.append(torch.zeros((plan.n_atoms, K), dtype=torch.float32, device=dev) if want_sims else None)
     return saved, grads, sims
