@@ -38,7 +38,7 @@ extern "C" {
 #endif
 
 #define MKGNN_MAX_DEGREE 4
-#define MKGNN_ABI_VERSION 4
+#define MKGNN_ABI_VERSION 5
 
 /* One KernelConv's parameters (reference kernels.py:50-84).  The three score
  * weights are the 0-d parameters support_attr_sc_weight, center_attr_sc_weight
@@ -95,7 +95,8 @@ typedef struct mkgnn_saved {
 /* ABI history.  v3: pair records (mkgnn_saved.pair_state).  v4: the AdamW state buffer of a tensor is
  * mkgnn_adamw_state_floats(numel) = 2 numel + 3 + ceil(numel / 1024) floats (v3: 2 numel + 3) -- a caller built against
  * v3 would hand mkgnn_adamw_step a buffer its blocks write past, so the version check must refuse it; the
- * molecule-resident small-batch entry points (mkgnn_molecule_*) were added with the same version. */
+ * molecule-resident small-batch entry points (mkgnn_molecule_*) were added with the same version.  v5: the statistics-only
+ * batch-norm companion (mkgnn_bn_stats, mkgnn_batchnorm_update_stats, mkgnn_batchnorm_forward_with_stats). */
 int mkgnn_abi_version(void);
 const char* mkgnn_last_error(void);
 
@@ -316,6 +317,34 @@ int mkgnn_batchnorm_forward(const float* x, int64_t x_stride, int64_t n_rows, in
                             int32_t training, float* out, int64_t out_stride,
                             float* save_mean, float* save_invstd, float* inv_norm, int64_t* num_batches_tracked,
                             const int64_t* n_valid_rows, void* workspace, size_t workspace_bytes, void* stream);
+/* Statistics-only companion of a batch norm (ABI v5).  The reference runs edge_batch_norm(data.edge_attr) in every
+ * forward (MolKGNNNet.py:116); its OUTPUT never reaches the kernel convolution (kernels.py:610-751 ignores edge_attr,
+ * SURVEY 8 a-1), but in training mode the call moves the module's running_mean / running_var / num_batches_tracked, and
+ * those buffers are state-dict contents.  This is that side effect without the normalised rows: BatchNorm1d's update
+ * (biased batch variance -> unbiased for running_var, running <- running + momentum (batch - running), counter + 1).
+ *   row_key / key_limit (both or neither; device pointers): row r counts iff row_key[r] < *key_limit -- for a batch padded
+ *   to a fixed shape (molkgnn_amd.padding) the bond rows of real atoms are those whose source id edge_index[0][r] is
+ *   below n_valid_atoms.
+ * mkgnn_batchnorm_update_stats runs it alone (one launch up to 64 K padded elements, three above);
+ * mkgnn_batchnorm_forward_with_stats = mkgnn_batchnorm_forward with the companion's rows summed by extra blocks of the same
+ * launches (training != 0 only; companion may be NULL).  Workspace: mkgnn_batchnorm_stats_workspace_bytes(companion C). */
+typedef struct mkgnn_bn_stats {
+    const float* x; int64_t x_stride; int64_t n_rows; int32_t C;
+    float* running_mean; float* running_var;      /* [C], updated in place (either may be NULL) */
+    float momentum;
+    int64_t* num_batches_tracked;                 /* may be NULL */
+    const int64_t* row_key; const int64_t* key_limit;
+} mkgnn_bn_stats;
+size_t mkgnn_batchnorm_stats_workspace_bytes(int32_t C);
+int mkgnn_batchnorm_update_stats(const mkgnn_bn_stats* stats, void* workspace, size_t workspace_bytes, void* stream);
+int mkgnn_batchnorm_forward_with_stats(const float* x, int64_t x_stride, int64_t n_rows, int32_t C,
+                            const float* weight, const float* bias,
+                            float* running_mean, float* running_var, float momentum, float eps,
+                            int32_t training, float* out, int64_t out_stride,
+                            float* save_mean, float* save_invstd, float* inv_norm, int64_t* num_batches_tracked,
+                            const int64_t* n_valid_rows, void* workspace, size_t workspace_bytes,
+                            const mkgnn_bn_stats* companion, void* companion_workspace, size_t companion_workspace_bytes,
+                            void* stream);
 /* grad_x (may be NULL), grad_weight, grad_bias (may be NULL) are fully overwritten. */
 int mkgnn_batchnorm_backward(const float* grad_out, int64_t grad_out_stride, const float* x, int64_t x_stride,
                              int64_t n_rows, int32_t C, const float* weight,

@@ -64,6 +64,19 @@ class MolKGNNNet(torch.nn.Module):
             print(f'saving {i}th layer')
             torch.save(layer.state_dict(), f'{path}/{time_stamp}_{i}th_layer.pth')
 
+    def _edge_stats(self, data):
+        """(edge_attr, edge_batch_norm, key, key_limit) for ``readout.update_running_stats`` or None (eval mode, no bonds).  A
+        batch padded to a fixed shape counts the bonds of its real atoms only: padding bonds start at padding atoms."""
+        bn = self.edge_batch_norm
+        ea = getattr(data, 'edge_attr', None)
+        if not (bn.training and bn.track_running_stats and bn.running_mean is not None) or ea is None or ea.shape[0] == 0:
+            return None
+        nv = getattr(data, 'n_valid_atoms', None)
+        if nv is None:
+            return (ea, bn, None, None)
+        src = data.edge_index[0]
+        return (ea, bn, src if src.is_contiguous() else src.contiguous(), nv)
+
     def forward(self, *argv, save_score=False):
         if len(argv) != 1:
             # the reference's 33-positional-argument form reads ``data`` afterwards and cannot work
@@ -76,10 +89,15 @@ class MolKGNNNet(torch.nn.Module):
             from . import molecule as _mol
             emb = _mol.net_forward(self, data)
             if emb is not None:
+                es = self._edge_stats(data)
+                if es is not None:
+                    R.update_running_stats(*es)
                 return emb
         # (a batch padded to a fixed shape -- molkgnn_amd.padding -- carries its real atom count and its molecule segments)
-        x = R.batch_norm(data.x, self.node_batch_norm, getattr(data, 'n_valid_atoms', None))
-        # edge_batch_norm never reaches the kernel convolution in the reference: skipped
+        # edge_batch_norm(data.edge_attr) (reference MolKGNNNet.py:116): its output never reaches the kernel convolution
+        # (SURVEY 8 a-1), but in training mode the call moves the module's running statistics and num_batches_tracked, which
+        # are state-dict contents -- that side effect rides along in the node batch norm's launches (readout.batch_norm)
+        x = R.batch_norm(data.x, self.node_batch_norm, getattr(data, 'n_valid_atoms', None), companion=self._edge_stats(data))
         if getattr(data, '_rf_ready', None) is not None:     # degree buckets still being built on the index stream
             from .receptive_field import await_receptive_fields
             await_receptive_fields(data)

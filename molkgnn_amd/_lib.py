@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MKGNN_LIB: a diagnostic build of the same library (make VARIANT=... in csrc/), e.g. with cycle stamps compiled in
 LIB_PATH = os.environ.get("MKGNN_LIB") or os.path.join(_HERE, "libmolkgnn_hip.so")
 MAX_DEGREE = 4
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class KernelBank(C.Structure):
@@ -102,6 +102,13 @@ class MoleculeBatch(C.Structure):
                 ("atom_rank", C.c_void_p), ("buckets", Buckets4), ("x", C.c_void_p), ("x_stride", C.c_int64)]
 
 
+class BnStats(C.Structure):
+    """``mkgnn_bn_stats``: the statistics-only companion of a batch norm (reference MolKGNNNet.py:116)."""
+    _fields_ = [("x", C.c_void_p), ("x_stride", C.c_int64), ("n_rows", C.c_int64), ("C", C.c_int32),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("momentum", C.c_float),
+                ("num_batches_tracked", C.c_void_p), ("row_key", C.c_void_p), ("key_limit", C.c_void_p)]
+
+
 EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn_unit_rows8", "mkgnn_workspace_bytes",
            "mkgnn_kernelsetconv_forward", "mkgnn_kernelsetconv_backward", "mkgnn_segment_sum_rows",
            "mkgnn_readout_hidden_stride", "mkgnn_readout_workspace_bytes", "mkgnn_readout_forward",
@@ -112,7 +119,8 @@ EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn
            "mkgnn_plan_workspace_bytes", "mkgnn_plan_build", "mkgnn_backward_join", "mkgnn_backward_streams", "mkgnn_bank_prepare", "mkgnn_expand_batch", "mkgnn_bce_head_fused", "mkgnn_collate_compact", "mkgnn_collate_compact_bytes",
            "mkgnn_readout_blocks_supported", "mkgnn_readout_blocks_forward", "mkgnn_readout_blocks_backward",
            "mkgnn_readout_blocks_workspace_bytes", "mkgnn_molecule_supported", "mkgnn_molecule_workspace_bytes",
-           "mkgnn_molecule_step")
+           "mkgnn_molecule_step", "mkgnn_batchnorm_stats_workspace_bytes", "mkgnn_batchnorm_update_stats",
+           "mkgnn_batchnorm_forward_with_stats")
 
 _lib: Optional[C.CDLL] = None
 TORCH_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libmolkgnn_torch.so")
@@ -207,6 +215,13 @@ def load() -> C.CDLL:
     lib.mkgnn_batchnorm_workspace_bytes.argtypes = [I32]
     lib.mkgnn_batchnorm_forward.restype = C.c_int
     lib.mkgnn_batchnorm_forward.argtypes = [P, I64, I64, I32, P, P, P, P, F32, F32, I32, P, I64, P, P, P, P, P, P, C.c_size_t, P]
+    lib.mkgnn_batchnorm_stats_workspace_bytes.restype = C.c_size_t
+    lib.mkgnn_batchnorm_stats_workspace_bytes.argtypes = [I32]
+    lib.mkgnn_batchnorm_update_stats.restype = C.c_int
+    lib.mkgnn_batchnorm_update_stats.argtypes = [C.POINTER(BnStats), P, C.c_size_t, P]
+    lib.mkgnn_batchnorm_forward_with_stats.restype = C.c_int
+    lib.mkgnn_batchnorm_forward_with_stats.argtypes = [P, I64, I64, I32, P, P, P, P, F32, F32, I32, P, I64, P, P, P, P, P, P, C.c_size_t,
+                                                       C.POINTER(BnStats), P, C.c_size_t, P]
     lib.mkgnn_batchnorm_backward.restype = C.c_int
     lib.mkgnn_batchnorm_backward.argtypes = [P, I64, P, I64, I64, I32, P, P, P, I32, P, I64, P, P, P, P, C.c_size_t, P]
     lib.mkgnn_bce_head_forward.restype = C.c_int

@@ -196,6 +196,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned long long t_start = a.stamps ? __builtin_readcyclecounter() : 0ull;
+    const unsigned long long rt_start = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz: the in-kernel clock is d(cycles) / d(this)
     const int stream = wave / NS, role = wave % NS;
     const int half = HS ? (role & 1) : 0;                // supports 2 * half, 2 * half + 1
     const int ct = HS ? cp * 2 + (role >> 1) : cp * NS + role;     // this wave's column tile (past the degree's last: an idle wave)
@@ -601,6 +602,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
     if (a.stamps && lane == 0) {
         unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 16;
         o[0] = t_start; o[1] = __builtin_readcyclecounter(); o[2] = (unsigned long long)(D * 16 + cp); o[3] = (unsigned long long)iters;
+        o[12] = rt_start; o[13] = __builtin_amdgcn_s_memrealtime();
 #ifdef MKGNN_FWD_STAMPS
         for (int i = 0; i < 8; ++i) o[4 + i] = phase[i];
 #endif

@@ -728,6 +728,21 @@ __global__ void __launch_bounds__(256) block_project_bwd_mfma_kernel(BlockProjAr
 }
 
 // ------------------------------------------------------------------------------------ batch norm ----
+// Statistics-only companion of a batch norm (mkgnn_bn_stats): the reference runs edge_batch_norm(data.edge_attr) in every
+// forward (MolKGNNNet.py:116) although its output never reaches the kernel convolution; what remains of the
+// call is its side effect in training mode -- running_mean / running_var / num_batches_tracked move.  The rows are summed
+// by extra blocks of the node batch norm's own three launches (no launch of their own in a step), or by
+// mkgnn_batchnorm_update_stats alone.  part: [3][nblk][C] = column sums | centred squares | (column 0) counted rows.
+constexpr int BN_MAIN_BLOCKS = 256;                    // (= BN_BLOCKS: the grid of the batch norm's own passes)
+constexpr int BN_SIDE_BLOCKS = 32;                     // companion blocks at most
+struct BnSide {
+    const float* x; int64_t xs; int64_t n; int C, CL, nblk;
+    float *running_mean, *running_var; float momentum;
+    int64_t* nbt;
+    const int64_t* key; const int64_t* key_limit;      // both or neither: row r counts iff key[r] < *key_limit
+    float* part;
+};
+
 struct BnArgs {
     const float* x; int64_t xs; int64_t n; int C;
     const float *weight, *bias;
@@ -743,7 +758,11 @@ struct BnArgs {
     float* inv_out;                // forward: 1 / max(|out row|, eps) for the convolution that reads out next (17 <= C <= 32)
     int64_t* nbt;                  // forward, training: BatchNorm1d.num_batches_tracked, incremented
     const int64_t* nvalid;         // device scalar or null: only rows [0, *nvalid) enter the batch statistics (padded batches)
+    BnSide side;                   // statistics-only companion (blocks gridDim.x - side.nblk .. of the same launches); nblk = 0: none
 };
+
+// blocks that work on the batch norm's own rows: the grid, less the companion's extra blocks (BnSide) behind them
+__device__ __forceinline__ int bn_nblk() { return (int)gridDim.x < BN_MAIN_BLOCKS ? (int)gridDim.x : BN_MAIN_BLOCKS; }
 
 // rows that count for the statistics: all of them, or the leading *nvalid (the rest is padding: normalised like any
 // row, excluded from every sum)
@@ -755,7 +774,7 @@ __device__ __forceinline__ int64_t bn_valid(const BnArgs& a) {
 
 // rows of this block: [lo, hi)
 __device__ __forceinline__ void bn_rows(const BnArgs& a, int64_t& lo, int64_t& hi) {
-    const int64_t per = (a.n + gridDim.x - 1) / gridDim.x;
+    const int64_t per = (a.n + bn_nblk() - 1) / bn_nblk();
     lo = per * blockIdx.x;
     hi = lo + per < a.n ? lo + per : a.n;
     if (lo > hi) lo = hi;
@@ -770,7 +789,7 @@ __device__ __forceinline__ void bn_block_colsum(const BnArgs& a, int CL, const f
     // unpadded forward exactly, which matters more than it looks: an ulp in x decides thousands of mathematically tied
     // neighbour orders the other way two layers later
     const int64_t nv = bn_valid(a);
-    const int64_t per = (nv + gridDim.x - 1) / gridDim.x;
+    const int64_t per = (nv + bn_nblk() - 1) / bn_nblk();
     int64_t lo = per * blockIdx.x, hi = lo + per < nv ? lo + per : nv;
     if (lo > hi) lo = hi;
     const bool act = c < a.C;
@@ -833,15 +852,118 @@ __device__ __forceinline__ void bn_total(const float* part, int nblk, int C, int
     __syncthreads();
 }
 
+
+// companion statistics, block `blk` of s.nblk.  MODE 0: column sums + counted rows; MODE 1: centred squares (mean from the
+// totals of MODE 0).  Fixed order everywhere (rows of a block by row lane, row lanes ascending, blocks ascending).
+__device__ __forceinline__ void bn_side_total(const BnSide& s, int plane, int col, float* sh, float& out) {
+    // (one block-wide sum of part[plane][b][col] over the blocks b, identical in every block; col < C)
+    float t = 0.f;
+    for (int b = threadIdx.x; b < s.nblk; b += 256) t += s.part[((size_t)plane * s.nblk + b) * s.C + col];
+    __syncthreads();
+    sh[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float u = 0.f;
+        for (int k = 0; k < 256; ++k) u += sh[k];
+        sh[256] = u;
+    }
+    __syncthreads();
+    out = sh[256];
+}
+
+template <int MODE>
+__device__ __forceinline__ void bn_side_colsum(const BnSide& s, int blk, float* sh) {
+    const int CL = s.CL, c = threadIdx.x & (CL - 1), rsub = threadIdx.x / CL, RS = 256 / CL;
+    const bool act = c < s.C;
+    const int cc = act ? c : 0;
+    float mu = 0.f;
+    if (MODE == 1) {                                     // the mean of every column, from the totals (one column at a time)
+        float cnt;
+        bn_side_total(s, 2, 0, sh, cnt);
+        __shared__ float mean_sh[256];
+        for (int col = 0; col < s.C; ++col) {
+            float t;
+            bn_side_total(s, 0, col, sh, t);
+            if (threadIdx.x == 0) mean_sh[col] = t / fmaxf(cnt, 1.f);
+        }
+        __syncthreads();
+        mu = mean_sh[cc];
+    }
+    const int64_t per = (s.n + s.nblk - 1) / s.nblk;
+    int64_t lo = per * blk, hi = lo + per < s.n ? lo + per : s.n;
+    if (lo > hi) lo = hi;
+    const int64_t lim = s.key ? *s.key_limit : 0;
+    float s0 = 0.f, cnt = 0.f;
+    for (int64_t r0 = lo + rsub; r0 < hi; r0 += 8 * RS) {
+        float v[8];
+        bool ok[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t rr = r0 + u * RS < hi ? r0 + u * RS : hi - 1;
+            v[u] = s.x[rr * s.xs + cc];
+            ok[u] = r0 + u * RS < hi && (!s.key || s.key[rr] < lim);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (ok[u]) {
+                if (MODE == 0) { s0 += v[u]; cnt += 1.f; }
+                else { const float d = v[u] - mu; s0 = fmaf(d, d, s0); }
+            }
+        }
+    }
+    __syncthreads();
+    sh[threadIdx.x] = s0;
+    if (MODE == 0) sh[256 + threadIdx.x] = cnt;
+    __syncthreads();
+    if (rsub == 0 && act) {
+        float t0 = 0.f, t1 = 0.f;
+        for (int k = 0; k < RS; ++k) { t0 += sh[k * CL + c]; if (MODE == 0) t1 += sh[256 + k * CL + c]; }
+        s.part[((size_t)MODE * s.nblk + blk) * s.C + c] = t0;
+        if (MODE == 0 && c == 0) s.part[((size_t)2 * s.nblk + blk) * s.C] = t1;     // (exact: counts below 2^24 per block)
+    }
+}
+
+// running <- running + momentum (batch - running), unbiased variance, counter + 1 (one block)
+__device__ __forceinline__ void bn_side_final(const BnSide& s, float* sh) {
+    float cnt;
+    bn_side_total(s, 2, 0, sh, cnt);
+    for (int col = 0; col < s.C; ++col) {
+        float t0, t1;
+        bn_side_total(s, 0, col, sh, t0);
+        bn_side_total(s, 1, col, sh, t1);
+        if (threadIdx.x == 0 && cnt > 0.f) {
+            const float mu = t0 / cnt, var = t1 / cnt;
+            if (s.running_mean) s.running_mean[col] = fmaf(s.momentum, mu - s.running_mean[col], s.running_mean[col]);
+            if (s.running_var) {
+                const float unbiased = cnt > 1.f ? var * (cnt / (cnt - 1.f)) : var;
+                s.running_var[col] = fmaf(s.momentum, unbiased - s.running_var[col], s.running_var[col]);
+            }
+        }
+    }
+    if (threadIdx.x == 0 && s.nbt) s.nbt[0] += 1;
+}
+
+// the companion alone: three launches, or -- one block's worth of rows -- one
+__global__ void __launch_bounds__(256) bn_side_kernel(BnSide s, int phase) {
+    __shared__ float sh[512];
+    if (phase == 0 || phase == 3) bn_side_colsum<0>(s, blockIdx.x, sh);
+    if (phase == 3) __syncthreads();                     // (one block: its own global stores are visible to it behind a barrier)
+    if (phase == 1 || phase == 3) bn_side_colsum<1>(s, blockIdx.x, sh);
+    if (phase == 3) __syncthreads();
+    if (phase == 2 || phase == 3) bn_side_final(s, sh);
+}
+
 __global__ void __launch_bounds__(256) bn_sum_kernel(BnArgs a, int CL) {
     __shared__ float sh[512];
+    if (blockIdx.x >= BN_MAIN_BLOCKS) { bn_side_colsum<0>(a.side, blockIdx.x - BN_MAIN_BLOCKS, sh); return; }
     bn_block_colsum<0>(a, CL, nullptr, nullptr, sh);
 }
 
 __global__ void __launch_bounds__(256) bn_var_kernel(BnArgs a, int CL) {
     __shared__ float sh[512];
     __shared__ float mean[256];
-    bn_total(a.part1, gridDim.x, a.C, CL, sh, mean);
+    if (blockIdx.x >= BN_MAIN_BLOCKS) { bn_side_colsum<1>(a.side, blockIdx.x - BN_MAIN_BLOCKS, sh); return; }
+    bn_total(a.part1, bn_nblk(), a.C, CL, sh, mean);
     if (threadIdx.x < a.C) mean[threadIdx.x] = mean[threadIdx.x] / (float)bn_valid(a);
     __syncthreads();
     bn_block_colsum<1>(a, CL, mean, nullptr, sh);
@@ -851,9 +973,10 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(BnArgs a, int CL) {
     __shared__ float sh[512];
     __shared__ float mean[256], invstd[256], scale[256], shift[256];
     const int t = threadIdx.x;
+    if (blockIdx.x >= BN_MAIN_BLOCKS) { bn_side_final(a.side, sh); return; }      // (one extra block, training mode only)
     if (a.training) {
-        bn_total(a.part1, gridDim.x, a.C, CL, sh, mean);
-        bn_total(a.part2, gridDim.x, a.C, CL, sh, invstd);
+        bn_total(a.part1, bn_nblk(), a.C, CL, sh, mean);
+        bn_total(a.part2, bn_nblk(), a.C, CL, sh, invstd);
         if (t < a.C) {
             const int64_t nv = bn_valid(a);
             const float mu = mean[t] / (float)nv, var = invstd[t] / (float)nv;
@@ -1631,13 +1754,60 @@ static int bn_common(const char* who, int64_t n, int32_t C, int& CL) {
     return 0;
 }
 
+size_t mkgnn_batchnorm_stats_workspace_bytes(int32_t C) { return C > 0 ? (size_t)3 * BN_SIDE_BLOCKS * C * 4 : 0; }
+
+// checks a companion and turns it into the kernels' form; s.nblk blocks
+static int bn_side_setup(const char* who, const mkgnn_bn_stats* c, void* ws, size_t ws_bytes, BnSide& s) {
+    if (!c->x || c->n_rows < 1 || c->C < 1 || c->C > 256 || c->x_stride < c->C) return api_fail("%s: bad companion tensor", who);
+    if ((c->row_key != nullptr) != (c->key_limit != nullptr)) return api_fail("%s: row_key and key_limit come together", who);
+    if (!ws || ws_bytes < mkgnn_batchnorm_stats_workspace_bytes(c->C)) return api_fail("%s: companion workspace too small", who);
+    s.x = c->x; s.xs = c->x_stride; s.n = c->n_rows; s.C = c->C;
+    s.CL = 1;
+    while (s.CL < s.C) s.CL <<= 1;
+    s.running_mean = c->running_mean; s.running_var = c->running_var; s.momentum = c->momentum; s.nbt = c->num_batches_tracked;
+    s.key = c->row_key; s.key_limit = c->key_limit; s.part = (float*)ws;
+    const int64_t rows_per_pass = 8 * (256 / s.CL);      // rows a block takes per loop trip
+    int64_t nb = (c->n_rows + 4 * rows_per_pass - 1) / (4 * rows_per_pass);
+    s.nblk = (int)(nb < 1 ? 1 : (nb > BN_SIDE_BLOCKS ? BN_SIDE_BLOCKS : nb));
+    return 0;
+}
+
+int mkgnn_batchnorm_update_stats(const mkgnn_bn_stats* c, void* ws, size_t ws_bytes, void* stream) {
+    const char* who = "mkgnn_batchnorm_update_stats";
+    if (!c) return api_fail("%s: null argument", who);
+    BnSide s{};
+    if (int rc = bn_side_setup(who, c, ws, ws_bytes, s)) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    if ((int64_t)c->n_rows * s.CL <= 64 * 1024) {         // one block does all three steps in one launch
+        s.nblk = 1;
+        bn_side_kernel<<<1, 256, 0, st>>>(s, 3);
+    } else {
+        bn_side_kernel<<<s.nblk, 256, 0, st>>>(s, 0);
+        bn_side_kernel<<<s.nblk, 256, 0, st>>>(s, 1);
+        bn_side_kernel<<<1, 256, 0, st>>>(s, 2);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : api_hip_fail(who, e);
+}
+
 int mkgnn_batchnorm_forward(const float* x, int64_t x_stride, int64_t n_rows, int32_t C, const float* weight,
                             const float* bias, float* running_mean, float* running_var, float momentum, float eps,
                             int32_t training, float* out, int64_t out_stride, float* save_mean, float* save_invstd,
                             float* inv_norm, int64_t* num_batches_tracked, const int64_t* n_valid_rows, void* ws, size_t ws_bytes,
                             void* stream) {
+    return mkgnn_batchnorm_forward_with_stats(x, x_stride, n_rows, C, weight, bias, running_mean, running_var, momentum, eps, training,
+                                              out, out_stride, save_mean, save_invstd, inv_norm, num_batches_tracked, n_valid_rows,
+                                              ws, ws_bytes, nullptr, nullptr, 0, stream);
+}
+
+int mkgnn_batchnorm_forward_with_stats(const float* x, int64_t x_stride, int64_t n_rows, int32_t C, const float* weight,
+                            const float* bias, float* running_mean, float* running_var, float momentum, float eps,
+                            int32_t training, float* out, int64_t out_stride, float* save_mean, float* save_invstd,
+                            float* inv_norm, int64_t* num_batches_tracked, const int64_t* n_valid_rows, void* ws, size_t ws_bytes,
+                            const mkgnn_bn_stats* companion, void* companion_ws, size_t companion_ws_bytes, void* stream) {
     int CL;
     if (int rc = bn_common("mkgnn_batchnorm_forward", n_rows, C, CL)) return rc;
+    if (companion && !training) return api_fail("mkgnn_batchnorm_forward: a statistics companion needs training mode (nothing moves in eval mode)");
     if (!x || !out || x_stride < C || out_stride < C) return api_fail("mkgnn_batchnorm_forward: bad x/out");
     if (training && (!save_mean || !save_invstd)) return api_fail("mkgnn_batchnorm_forward: save_mean/save_invstd is null");
     if (!training && (!running_mean || !running_var)) return api_fail("mkgnn_batchnorm_forward: eval mode needs running statistics");
@@ -1651,11 +1821,15 @@ int mkgnn_batchnorm_forward(const float* x, int64_t x_stride, int64_t n_rows, in
         return api_fail("mkgnn_batchnorm_forward: inv_norm needs C <= 32, a multiple of 4, and 16-byte aligned rows of x and out (C=%d)", C);
     a.inv_out = inv_norm; a.nbt = num_batches_tracked; a.nvalid = n_valid_rows;
     a.part1 = (float*)ws; a.part2 = a.part1 ? a.part1 + (size_t)BN_BLOCKS * C : nullptr;
-    if (training) {
-        bn_sum_kernel<<<BN_BLOCKS, 256, 0, st>>>(a, CL);
-        bn_var_kernel<<<BN_BLOCKS, 256, 0, st>>>(a, CL);
+    static_assert(BN_BLOCKS == BN_MAIN_BLOCKS, "the companion's blocks sit behind the batch norm's own");
+    if (companion) {
+        if (int rc = bn_side_setup("mkgnn_batchnorm_forward", companion, companion_ws, companion_ws_bytes, a.side)) return rc;
     }
-    bn_apply_kernel<<<BN_BLOCKS, 256, 0, st>>>(a, CL);
+    if (training) {
+        bn_sum_kernel<<<BN_BLOCKS + a.side.nblk, 256, 0, st>>>(a, CL);
+        bn_var_kernel<<<BN_BLOCKS + a.side.nblk, 256, 0, st>>>(a, CL);
+    }
+    bn_apply_kernel<<<BN_BLOCKS + (a.side.nblk ? 1 : 0), 256, 0, st>>>(a, CL);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : api_hip_fail("mkgnn_batchnorm_forward", e);
 }

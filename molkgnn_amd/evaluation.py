@@ -84,10 +84,13 @@ def calculate_logAUC(true_y, predicted_score, FPR_range=(0.001, 0.1)) -> float:
 
 
 def calculate_auc(true_y, predicted_score) -> float:
-    """``roc_auc_score``; NaN when only one class is present (what the container's scikit-learn returns)."""
+    """``roc_auc_score``, or ``-1`` when it is undefined (reference ``evaluation.py:81-86``: ``try: roc_auc_score(...)
+    except: -1``).  With only one class present the reference's pinned scikit-learn (``requirements.txt:101``: 1.0.2) raises
+    ``ValueError`` and the caller gets ``-1``; the build container's scikit-learn 1.7 warns and returns NaN instead (which
+    is what the golden file, generated here, holds) -- the pinned behaviour is the contract."""
     y, _ = _as_vectors(true_y, predicted_score)
     if float(y.sum()) == 0.0 or float(y.sum()) == float(y.numel()):
-        return float("nan")
+        return -1
     fpr, tpr = roc_curve(true_y, predicted_score)
     return _trapz(tpr, fpr)
 

@@ -63,33 +63,41 @@ def chunk_molecules(sizes, cap: int):
 
 
 def build_molecule_plan(plan: BatchPlan, batch_vec: torch.Tensor, n_mols: Optional[int], cap: Optional[int] = None) -> Optional[MoleculePlan]:
-    """The chunk table, or ``None`` when the batch does not qualify.  One host synchronisation (the molecule sizes);
-    call it outside captures -- ``molecule_plan`` caches the result on the batch's index plan."""
+    """The chunk table, or ``None`` when the batch does not qualify.  One host synchronisation (the validity flag and the
+    molecule sizes in one transfer); call it outside captures -- ``molecule_plan`` caches the result on the batch's index
+    plan."""
     dev = plan.device
     n = plan.n_atoms
     if dev.type != "cuda" or n < 1 or batch_vec is None or batch_vec.numel() != n or plan.edge_index is None:
         return None
-    ei = plan.edge_index
-    bv = batch_vec.long()
-    n_mols = int(n_mols) if n_mols is not None else int(bv.max().item()) + 1
-    src, dst = ei[0].long(), ei[1].long()
-    deg = torch.bincount(src, minlength=n)
-    keys, rkeys = src * n + dst, dst * n + src
-    checks = [bool((bv[1:] >= bv[:-1]).all()) if n > 1 else True, bool((deg <= 4).all())]
-    if src.numel():
-        checks.append(bool((bv[src] == bv[dst]).all()))
-        sk = torch.sort(keys).values
-        checks.append(bool(torch.equal(sk, torch.sort(rkeys).values)))        # every bond stored in both directions
-        checks.append(bool((sk[1:] != sk[:-1]).all()) if sk.numel() > 1 else True)   # ... and only once
-    if not all(checks):
-        return None
-    # the buckets must be what the edge list says (sum of the buckets' atoms = atoms of degree 1..4)
-    if plan.n_focal != int((deg >= 1).sum().item()):
-        return None
-    for b in plan.buckets:
+    for b in plan.buckets:                               # (host-side facts first: no device work for a batch that cannot qualify)
         if b.count and b.e_unit(8 if b.e_nei is None else int(b.e_nei.shape[-1])) is None:
             return None
-    sizes = torch.bincount(bv, minlength=n_mols).tolist()
+    ei = plan.edge_index
+    bv = batch_vec.long()
+    if n_mols is None:
+        n_mols = int(bv.max().item()) + 1               # (a loader that knows the molecule count passes it: data.num_graphs)
+    n_mols = int(n_mols)
+    src, dst = ei[0].long(), ei[1].long()
+    deg = torch.bincount(src, minlength=n)
+    true = torch.ones((), dtype=torch.bool, device=dev)
+    # every check is left on the device and read back in ONE transfer together with the molecule sizes (round 4 read each
+    # of them back by itself: eight host round trips per fresh batch, ADVICE round 4)
+    checks = [(bv[1:] >= bv[:-1]).all() if n > 1 else true, (deg <= 4).all()]
+    if src.numel():
+        keys, rkeys = src * n + dst, dst * n + src
+        sk = torch.sort(keys).values
+        checks.append((bv[src] == bv[dst]).all())
+        checks.append((sk == torch.sort(rkeys).values).all())                 # every bond stored in both directions
+        checks.append((sk[1:] != sk[:-1]).all() if sk.numel() > 1 else true)  # ... and only once
+    # the buckets must be what the edge list says (sum of the buckets' atoms = atoms of degree 1..4)
+    checks.append((deg >= 1).sum() == plan.n_focal)
+    checks.append((bv.max() < n_mols) & (bv.min() >= 0))
+    ok = torch.stack(checks).all().to(torch.int64).reshape(1)
+    host = torch.cat([ok, torch.bincount(bv.clamp(0, n_mols - 1), minlength=n_mols)]).tolist()
+    if not host[0]:
+        return None
+    sizes = host[1:]
     if len(sizes) != n_mols or max(sizes) > MAX_ATOMS:
         return None
     if cap is None:
@@ -180,16 +188,17 @@ def model_qualifies(net, data, ffn=None) -> bool:
     params = flat_parameters(net, ffn)
     if params is None:
         return False
-    okc = getattr(net, "_mkgnn_molecule_f32", None)          # (dtype / device / layout of ~90 tensors: checked once per list)
-    if okc is None or okc[0] is not params:
-        okc = (params, all(_f32(p) for p in params))
-        object.__setattr__(net, "_mkgnn_molecule_f32", okc)
-    if not okc[1] or (params[0] is not None and params[0].device != x.device):
-        return False
+    # dtype / device / layout of ~90 tensors, every call: nn.Module.to() / .half() / .double() change p.data in place and keep
+    # the Parameter objects, so nothing keyed by their identity may remember the answer
+    xdev = x.device
+    for p in params:
+        if p is not None and (p.dtype != torch.float32 or p.device != xdev or not p.is_contiguous()):
+            return False
     if ffn is not None and (ffn.out_features != 1):
         return False
-    key = (tuple(tuple(layer.L) for layer in net.gnn.layers), x.shape[1], net.graph_embedding_lin1.weight.shape,
-           net.graph_embedding_lin2.weight.shape)
+    key = (tuple(tuple(layer.L) for layer in net.gnn.layers), x.shape[1], tuple(net.graph_embedding_lin1.weight.shape),
+           tuple(net.graph_embedding_lin2.weight.shape), int(params[2].shape[-1]) if params[2] is not None else 0,
+           None if ffn is None else (ffn.in_features, ffn.out_features, ffn.bias is not None))
     ok = _SHAPE_OK.get(key)
     if ok is None:
         st, keep = _net_struct(net, ffn, params, None, None, None, 0.0, True)
@@ -486,11 +495,28 @@ def _ready(net, data, ffn):
         return None
     if not model_qualifies(net, data, ffn):
         return None
+    if getattr(data, '_rf_ready', None) is not None:     # degree buckets still being filled on the index stream: join first
+        from .receptive_field import await_receptive_fields
+        await_receptive_fields(data)
     plan = _plan_of(data)
     mp = molecule_plan(plan, getattr(data, 'batch', None), n_mols)
     if mp is None or not wanted(mp.n_mols):
         return None
+    if mp.n_mols > _MAX_MOLS_AUTO and _MODE != "1" and not torch.cuda.is_current_stream_capturing():
+        # This batch runs here only while it is launched eagerly; once the step is CAPTURED it takes the per-operator
+        # path (wanted()), and that path's lazy per-batch builds synchronise with the host (readout.MoleculeSegments).
+        # Build them now, outside any capture, so the captured step is not the per-operator path's first use of the batch.
+        _prebuild_per_operator(data, mp.n_mols)
     return plan, mp, flat_parameters(net, ffn)
+
+
+def _prebuild_per_operator(data, n_mols: int) -> None:
+    if getattr(data, 'mol_ptr', None) is not None and getattr(data, 'atom_mol', None) is not None:
+        return                                           # (segments come with the batch: nothing is built lazily)
+    bv = getattr(data, 'batch', None)
+    if bv is not None:
+        from .readout import molecule_segments
+        molecule_segments(bv, getattr(data, 'num_graphs', None))
 
 
 def net_forward(net, data) -> Optional[torch.Tensor]:
@@ -513,4 +539,8 @@ def loss_forward(model, data, p_drop: float) -> Optional[torch.Tensor]:
     if r is None or data.y.numel() != r[1].n_mols:
         return None
     plan, mp, params = r
+    es = net._edge_stats(data) if hasattr(net, '_edge_stats') else None
+    if es is not None:                                   # edge_batch_norm's side effect (reference MolKGNNNet.py:116): one small launch
+        from .readout import update_running_stats
+        update_running_stats(*es)
     return _MoleculeLossFn.apply(net, ffn, float(p_drop), data.y, plan, mp, data.x, *params)

@@ -141,8 +141,9 @@ class FusedAdamW(torch.optim.Optimizer):
                 if ver != self._ver:
                     self._fast_sig = None
             else:
-                st = self.state[p]                           # a state entry replaced from outside (not through load_state_dict)
-                if st["exp_avg"].data_ptr() != ent[2][0]:
+                # a state entry replaced -- or the whole state cleared -- from outside (not through load_state_dict)
+                ea = self.state[p].get("exp_avg")
+                if ea is None or ea.data_ptr() != ent[2][0]:
                     ent[2] = (self._packed_state(p).data_ptr(), p.data_ptr())
             if g.is_sparse:
                 raise RuntimeError("FusedAdamW does not support sparse gradients")

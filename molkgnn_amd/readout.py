@@ -11,6 +11,8 @@ outside the kernels' limits (hidden width > 64, node width > 128, an unsorted ``
 """
 from __future__ import annotations
 
+import ctypes
+
 import weakref
 from typing import Optional
 
@@ -278,7 +280,7 @@ def readout(h: torch.Tensor, lin1: torch.nn.Linear, lin2: torch.nn.Linear, dropo
 # ------------------------------------------------------------------------------------------ batch norm --
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, bn: torch.nn.BatchNorm1d, use_batch_stats: bool, n_valid=None):
+    def forward(ctx, x, weight, bias, bn: torch.nn.BatchNorm1d, use_batch_stats: bool, n_valid=None, companion=None):
         lib = _lib.load()
         ctx.n_valid = n_valid
         x = _row_major(x if x.dtype == torch.float32 else x.float())
@@ -299,11 +301,18 @@ class _BatchNormFn(torch.autograd.Function):
         with torch.cuda.device(dev):
             ws_bytes = int(lib.mkgnn_batchnorm_workspace_bytes(C))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            _lib.check(lib.mkgnn_batchnorm_forward(
+            st, keep, cws, cws_bytes = None, None, None, 0
+            if companion is not None and use_batch_stats and bn.training:
+                st, keep = _bn_stats_struct(*companion)      # (statistics move in training mode only)
+                cws_bytes = int(lib.mkgnn_batchnorm_stats_workspace_bytes(st.C))
+                cws = torch.empty(cws_bytes, dtype=torch.uint8, device=dev)
+            _lib.check(lib.mkgnn_batchnorm_forward_with_stats(
                 x.data_ptr(), _stride0(x), n, C, _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(rm), _lib.ptr(rv),
                 float(bn.momentum if bn.momentum is not None else 0.0), float(bn.eps), int(use_batch_stats),
                 out.data_ptr(), C, save_mean.data_ptr(), save_invstd.data_ptr(), _lib.ptr(inv), _lib.ptr(nbt),
-                _lib.ptr(n_valid), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)), "mkgnn_batchnorm_forward")
+                _lib.ptr(n_valid), ws.data_ptr(), ws_bytes, None if st is None else ctypes.byref(st), _lib.ptr(cws), cws_bytes,
+                _lib.stream_ptr(dev)), "mkgnn_batchnorm_forward_with_stats")
+            del keep
         ctx.use_batch_stats = use_batch_stats
         ctx.save_for_backward(x, weight, save_mean, save_invstd)
         if inv is None:
@@ -316,7 +325,7 @@ class _BatchNormFn(torch.autograd.Function):
     def backward(ctx, grad_out, _g_inv=None):
         lib = _lib.load()
         if grad_out is None:
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
         x, weight, save_mean, save_invstd = ctx.saved_tensors
         n, C = x.shape
         dev = x.device
@@ -331,12 +340,65 @@ class _BatchNormFn(torch.autograd.Function):
                 g.data_ptr(), _stride0(g), x.data_ptr(), _stride0(x), n, C, _lib.ptr(weight), save_mean.data_ptr(),
                 save_invstd.data_ptr(), int(ctx.use_batch_stats), _lib.ptr(gx), C, _lib.ptr(gw), _lib.ptr(gb),
                 _lib.ptr(ctx.n_valid), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)), "mkgnn_batchnorm_backward")
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
-def batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm1d, n_valid: Optional[torch.Tensor] = None) -> torch.Tensor:
+def _stats_supported(x: torch.Tensor, bn: torch.nn.BatchNorm1d) -> bool:
+    return (x.is_cuda and x.dim() == 2 and 1 <= x.shape[1] <= 256 and x.shape[0] >= 1 and x.shape[1] == bn.num_features
+            and bn.momentum is not None and bn.running_mean is not None and bn.running_mean.is_cuda)
+
+
+def _bn_stats_struct(x: torch.Tensor, bn: torch.nn.BatchNorm1d, key: Optional[torch.Tensor], key_limit: Optional[torch.Tensor]):
+    """The C struct of a statistics companion and the tensors it points at (to be kept alive across the call)."""
+    x = _row_major(x if x.dtype == torch.float32 else x.float())
+    if (key is None) != (key_limit is None):
+        raise ValueError("key and key_limit come together")
+    if key is not None:
+        if not (key.is_cuda and key.dtype == torch.int64 and key.is_contiguous() and key.numel() == x.shape[0]):
+            raise ValueError("key must be a contiguous int64 GPU tensor with one entry per row")
+        if not (key_limit.is_cuda and key_limit.dtype == torch.int64 and key_limit.numel() == 1):
+            raise ValueError("key_limit must be a one-element int64 tensor on the GPU")
+    nbt = bn.num_batches_tracked
+    if nbt is not None and (nbt.dtype != torch.int64 or nbt.device != x.device):
+        raise _lib.MolKGNNLibraryError("num_batches_tracked must be an int64 tensor on the input's device")
+    st = _lib.BnStats(x.data_ptr(), _stride0(x), x.shape[0], x.shape[1], _lib.ptr(bn.running_mean), _lib.ptr(bn.running_var),
+                      float(bn.momentum), _lib.ptr(nbt), _lib.ptr(key), _lib.ptr(key_limit))
+    return st, (x, key, key_limit)
+
+
+def update_running_stats(x: torch.Tensor, bn: torch.nn.BatchNorm1d, key: Optional[torch.Tensor] = None,
+                         key_limit: Optional[torch.Tensor] = None) -> None:
+    """What ``bn(x)`` does to the module's buffers in training mode, without computing ``bn(x)``: the reference calls
+    ``edge_batch_norm(data.edge_attr)`` in every forward (``MolKGNNNet.py:116``) and the kernel convolution never reads the
+    result -- ``running_mean``, ``running_var`` and ``num_batches_tracked`` still move, and they are
+    state-dict contents.  ``key`` / ``key_limit``: only rows with ``key[r] < key_limit`` count (padded batches: the bonds of
+    real atoms).  No-op in eval mode or without tracked statistics."""
+    if not (bn.training and bn.track_running_stats and bn.running_mean is not None):
+        return
+    _lib.require_gpu_tensor(x, "x")
+    if not _stats_supported(x, bn):
+        if key is not None:
+            x = x[key < key_limit]
+        bn(x)                                             # (PyTorch's operator on the GPU: cumulative-average momentum, > 256 channels)
+        return
+    lib = _lib.load()
+    dev = x.device
+    st, keep = _bn_stats_struct(x, bn, key, key_limit)
+    with torch.cuda.device(dev):
+        ws_bytes = int(lib.mkgnn_batchnorm_stats_workspace_bytes(st.C))
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        _lib.check(lib.mkgnn_batchnorm_update_stats(ctypes.byref(st), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)),
+                   "mkgnn_batchnorm_update_stats")
+    del keep
+
+
+def batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm1d, n_valid: Optional[torch.Tensor] = None,
+               companion=None) -> torch.Tensor:
     """``bn(x)`` for a 2-D input on the GPU, with ``torch.nn.BatchNorm1d``'s semantics (batch statistics in
     training mode or when no running statistics are tracked; running statistics updated in place).
+
+    ``companion`` = ``(x2, bn2, key, key_limit)``: ``update_running_stats(x2, bn2, key, key_limit)`` done by extra blocks of
+    this batch norm's own launches (training mode).
 
     ``n_valid`` (a one-element int64 CUDA tensor): only the leading ``n_valid`` rows enter the batch statistics; the
     remaining rows are padding (``molkgnn_amd.padding``) -- normalised with the same statistics, excluded from every sum.
@@ -347,13 +409,22 @@ def batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm1d, n_valid: Optional[torc
     if x.dim() != 2 or x.shape[1] != bn.num_features:
         raise ValueError(f"expected a [N, {bn.num_features}] input, got {tuple(x.shape)}")
     use_batch_stats = bn.training or bn.running_mean is None
+    if companion is not None:
+        x2, bn2 = companion[0], companion[1]
+        if not (bn2.training and bn2.track_running_stats and bn2.running_mean is not None):
+            companion = None                              # nothing of bn2 moves
+        elif not (_stats_supported(x2, bn2) and bn.training and use_batch_stats):
+            update_running_stats(*companion)              # (on its own)
+            companion = None
     if x.shape[1] > 256 or x.shape[0] == 0 or (bn.training and bn.track_running_stats and bn.momentum is None):
         if n_valid is not None:
             raise ValueError("n_valid needs the HIP batch norm (<= 256 channels, momentum set)")
+        if companion is not None:
+            update_running_stats(*companion)
         return bn(x)
     if use_batch_stats and bn.training and x.shape[0] == 1:
         raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
-    out, inv = _BatchNormFn.apply(x, bn.weight, bn.bias, bn, use_batch_stats, n_valid)
+    out, inv = _BatchNormFn.apply(x, bn.weight, bn.bias, bn, use_batch_stats, n_valid, companion)
     if inv.numel():
         from .functional import _INV_ATTR
         setattr(out, _INV_ATTR, (inv, out._version))

@@ -1559,3 +1559,80 @@ def test_evaluation_metrics_on_the_device_match_reference_golden():
     for fn in (E.calculate_logAUC, E.calculate_auc, E.calculate_ppv, E.calculate_accuracy, E.calculate_f1_score):
         a, c = fn(b.y, score), fn(b.y.cpu(), score.cpu())
         assert abs(a - c) <= 1e-12 * max(1.0, abs(c)), (fn.__name__, a, c)
+
+
+@pytest.mark.parametrize("n,C,masked", [(300, 7, False), (300, 7, True), (218_000, 7, False), (218_000, 7, True), (5000, 1, False),
+                                        (40_000, 33, False), (1, 7, False)])
+def test_statistics_only_batch_norm_matches_torch(n, C, masked):
+    """``readout.update_running_stats`` (mkgnn_batchnorm_update_stats): what ``bn(x)`` does to a BatchNorm1d's buffers in
+    training mode without the normalised rows -- the reference's ``edge_batch_norm(data.edge_attr)`` (MolKGNNNet.py:116),
+    whose output nothing reads.  One-launch and three-launch forms, the row mask of padded batches, three calls in a row."""
+    from molkgnn_amd import readout as R
+    dev = _dev()
+    torch.manual_seed(n + C)
+    mine, ref = torch.nn.BatchNorm1d(C).to(dev), torch.nn.BatchNorm1d(C).to(dev)
+    for step in range(3):
+        x = torch.randn(n, C, device=dev) * (1.0 + step) + 0.3 * step
+        key = lim = None
+        xr = x
+        if masked:
+            key = torch.randint(0, 1000, (n,), device=dev)
+            lim = torch.tensor([700], dtype=torch.int64, device=dev)
+            xr = x[key < 700]
+        R.update_running_stats(x, mine, key, lim)
+        if xr.shape[0] > 1:
+            ref(xr)
+        else:                                             # (torch refuses one row per channel in training mode; the formula: var = 0)
+            with torch.no_grad():
+                ref.running_mean += 0.1 * (xr[0] - ref.running_mean)
+                ref.running_var += 0.1 * (0.0 - ref.running_var)
+                ref.num_batches_tracked += 1
+        assert torch.allclose(mine.running_mean, ref.running_mean, atol=2e-6, rtol=1e-5), step
+        assert torch.allclose(mine.running_var, ref.running_var, atol=1e-5, rtol=2e-5), step
+        assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == step + 1
+    mine.eval()
+    before = mine.running_mean.clone()
+    R.update_running_stats(torch.randn(n, C, device=dev), mine)
+    assert torch.equal(mine.running_mean, before) and int(mine.num_batches_tracked) == 3      # eval mode: nothing moves
+
+
+@pytest.mark.parametrize("mols,padded", [(64, False), (700, False), (300, True)])
+def test_every_buffer_of_the_state_dict_after_three_training_steps(mols, padded):
+    """state-dict contents are API.  After three training steps every BUFFER of ``MolKGNNNet`` -- node_batch_norm's and
+    edge_batch_norm's running_mean / running_var / num_batches_tracked -- equals what torch.nn.BatchNorm1d leaves when fed
+    the same rows (reference MolKGNNNet.py:115-116: both batch norms run in every forward).  Padded batches
+    (molkgnn_amd.padding) count their real atoms and the bonds of their real atoms only."""
+    from molkgnn_amd.MolKGNNNet import MolKGNNNet
+    from molkgnn_amd.synthetic import make_batch
+    from molkgnn_amd import padding as P
+    dev = _dev()
+    torch.manual_seed(3)
+    names = [f"num_kernel{d}_{h}" for h in ("1hop", "Nhop") for d in range(1, 5)]
+    model = MolKGNNNet(num_layers=2, x_dim=28, p_dim=3, edge_attr_dim=7, drop_ratio=0.0, graph_embedding_dim=32,
+                       **dict(zip(names, (10, 20, 30, 50) * 2))).to(dev).train()
+    ref_node, ref_edge = torch.nn.BatchNorm1d(28).to(dev), torch.nn.BatchNorm1d(7).to(dev)
+    raws = [make_batch(mols, seed=900 + s, with_receptive_fields=not padded) for s in range(3)]
+    if padded:
+        shape = P.fixed_shape([P.degree_histogram(b) for b in raws])
+    for raw in raws:
+        if padded:
+            from molkgnn_amd.receptive_field import attach_receptive_fields
+            b = P.pad_batch(raw, shape, mols).to(dev)
+            attach_receptive_fields(b, sizes=b.bucket_sizes)
+            assert b.edge_attr.shape[0] > raw.edge_attr.shape[0]                  # (there are padding bonds to leave out)
+        else:
+            b = raw.to(dev)
+        model(b).sum().backward()
+        ref_node(raw.x.to(dev)); ref_edge(raw.edge_attr.to(dev))
+    torch.cuda.synchronize()
+    got = dict(model.named_buffers())
+    assert sorted(got) == ["edge_batch_norm.num_batches_tracked", "edge_batch_norm.running_mean", "edge_batch_norm.running_var",
+                           "node_batch_norm.num_batches_tracked", "node_batch_norm.running_mean", "node_batch_norm.running_var"]
+    for pre, ref in (("node_batch_norm", ref_node), ("edge_batch_norm", ref_edge)):
+        assert torch.allclose(got[f"{pre}.running_mean"], ref.running_mean, atol=2e-6, rtol=1e-5), pre
+        assert torch.allclose(got[f"{pre}.running_var"], ref.running_var, atol=1e-5, rtol=2e-5), pre
+        assert int(got[f"{pre}.num_batches_tracked"]) == int(ref.num_batches_tracked) == 3, pre
+    model.eval()
+    with torch.no_grad():
+        model(b)
+    assert int(model.edge_batch_norm.num_batches_tracked) == 3                                  # eval mode moves nothing

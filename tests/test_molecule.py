@@ -346,3 +346,92 @@ def test_zero_norm_rows_through_the_one_launch_step(monkeypatch):
     grads = {nm: prm.grad for nm, prm in model.named_parameters()}
     # (gradients through 1 / eps are 1e7-sized: the relative part of the criterion carries them)
     assert _check_against_oracle(model, state, b, 3, False, emb, fwd_cap, cot, grads) > 60
+
+
+@pytest.mark.parametrize("mols", [24, 64, 256])
+def test_default_mode_eager_warm_up_then_capture(mols, monkeypatch):
+    """with MKGNN_MOLECULE unset an eager step of 33 .. 512 molecules takes the one-launch path while the
+    same step inside a hipGraph capture takes the per-operator kernels -- so the eager warm-up never ran the per-operator path
+    for that batch and the CAPTURED step was its first use, lazy per-batch builds (a host synchronisation in
+    readout.MoleculeSegments) included.  The eager steps now build those caches; warm-up + capture + replay must work in the
+    default mode at every size, and replay what the eager step of the captured path computes."""
+    dev = _dev()
+    import copy
+    from molkgnn_amd import molecule as M
+    from molkgnn_amd.synthetic import make_batch
+    from molkgnn_amd.train import GNNModel, configure_optimizer
+    from molkgnn_amd.train import backward as train_backward
+    monkeypatch.setattr(M, "_MODE", "")                      # the default
+    torch.manual_seed(9)
+    model = GNNModel(ffn_dropout_rate=0.0).to(dev).train()
+    twin = copy.deepcopy(model)
+    opt, opt_t = configure_optimizer(model, lr=1e-3, fused=True), configure_optimizer(twin, lr=1e-3, fused=True)
+    b = make_batch(mols, seed=1234 + mols).to(dev)
+    b.num_graphs = mols
+    b.y = (torch.arange(mols, device=dev) % 4 == 0).long()
+    calls = []
+    orig = M._run
+    monkeypatch.setattr(M, "_run", lambda *a, **k: (calls.append(a[6]), orig(*a, **k))[1])
+
+    def step(m, o):
+        m.zero_grad(set_to_none=True)
+        loss = m.loss(b)
+        train_backward(loss)
+        o.step()
+        return loss
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):                                   # eager warm-up: the molecule-resident step (<= 512 molecules)
+            step(model, opt)
+        assert len(calls) == 2, calls
+        model.zero_grad(set_to_none=True)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):               # captured: one launch up to 32 molecules, per operator above
+            static_loss = step(model, opt)
+    torch.cuda.current_stream().wait_stream(side)
+    assert len(calls) == (3 if mols <= 32 else 2), calls
+    g.replay()
+    torch.cuda.synchronize()
+    # the twin: the same two eager steps, then the third step eagerly on the path the capture took
+    for _ in range(2):
+        step(twin, opt_t)
+    monkeypatch.setattr(M, "_MODE", "1" if mols <= 32 else "0")
+    want = step(twin, opt_t)
+    torch.cuda.synchronize()
+    assert torch.isfinite(static_loss).all()
+    assert float((static_loss.detach() - want.detach()).abs()) <= 1e-6 * max(1.0, float(want.detach().abs())), (float(static_loss.detach()), float(want.detach()))
+    for (nm, p), (_, q) in zip(model.named_parameters(), twin.named_parameters()):
+        assert torch.allclose(p, q, atol=1e-6, rtol=1e-5), nm
+    for (nm, p), (_, q) in zip(model.named_buffers(), twin.named_buffers()):
+        assert torch.allclose(p.float(), q.float(), atol=1e-6, rtol=1e-5), nm
+
+
+@pytest.mark.parametrize("mols", [16, 200])
+def test_edge_batch_norm_buffers_move_in_the_one_launch_step(mols, monkeypatch):
+    """Reference MolKGNNNet.py:116: ``edge_batch_norm(data.edge_attr)`` runs in every forward; the one-launch step launches its
+    side effect (``readout.update_running_stats``) next to it.  Three training steps against torch.nn.BatchNorm1d."""
+    dev = _dev()
+    from molkgnn_amd import molecule as M
+    from molkgnn_amd.synthetic import make_batch
+    from molkgnn_amd.train import GNNModel
+    monkeypatch.setattr(M, "_MODE", "1")
+    torch.manual_seed(2)
+    model = GNNModel(ffn_dropout_rate=0.0).to(dev).train()
+    ref = torch.nn.BatchNorm1d(7).to(dev)
+    calls = []
+    orig = M._run
+    monkeypatch.setattr(M, "_run", lambda *a, **k: (calls.append(a[6]), orig(*a, **k))[1])
+    for s in range(3):
+        b = make_batch(mols, seed=40 + s).to(dev)
+        b.num_graphs = mols
+        b.y = (torch.arange(mols, device=dev) % 2).long()
+        model.zero_grad(set_to_none=True)
+        model.loss(b).backward()
+        ref(b.edge_attr)
+    assert len(calls) == 3
+    bn = model.gnn_model.edge_batch_norm
+    assert torch.allclose(bn.running_mean, ref.running_mean, atol=2e-6, rtol=1e-5)
+    assert torch.allclose(bn.running_var, ref.running_var, atol=1e-5, rtol=2e-5)
+    assert int(bn.num_batches_tracked) == 3 and int(model.gnn_model.node_batch_norm.num_batches_tracked) == 3
