@@ -74,6 +74,18 @@ __host__ __device__ constexpr int stream_lds_floats(int D, int KC) {
     return (4 / NS) * (RING * KC * 256 + 2 * META) + (D == 4 ? 192 + 4 * 18 * 64 : 0);
 }
 
+// Ping-pong launch (PP, round 5): a block is TWO such 4-wave teams ("sides"), each with its own rings and records; the
+// chirality table is shared, the exchange buffer holds all 8 waves.
+__host__ __device__ constexpr int stream_side_floats(int D, int KC) {
+    const int NS = (D == 1) ? 1 : (D == 4 ? 4 : 2);
+    const int RING = D + 1;
+    const int META = 32 * (D + 1) + 48 + 128 * D;
+    return (4 / NS) * (RING * KC * 256 + 2 * META);
+}
+__host__ __device__ constexpr int stream_pp_lds_floats(int D, int KC) {
+    return 2 * stream_side_floats(D, KC) + (D == 4 ? 192 + 8 * 18 * 64 : 0);
+}
+
 template <int I> using IC = std::integral_constant<int, I>;
 template <int B, int E, typename Fn> __device__ __forceinline__ void static_for(Fn&& fn) {
     if constexpr (B < E) { fn(IC<B>{}); static_for<B + 1, E>(fn); }
@@ -116,6 +128,15 @@ __device__ __forceinline__ void prio_other() {
     if constexpr (MKGNN_STREAM_PRIO == 1) __builtin_amdgcn_s_setprio(2);
     else if constexpr (MKGNN_STREAM_PRIO == 2) __builtin_amdgcn_s_setprio(0);
 }
+
+// LDS reads behind the compiler's back (immediate byte offset, one address register per family of reads) and the wait that
+// hands their registers over
+template <int OFFB> __device__ __forceinline__ void lds_read128(f32x4& dst, uint32_t addr) {
+    static_assert(OFFB >= 0 && OFFB < 65536 && OFFB % 16 == 0, "ds_read_b128 offset: 16 bits, 16-byte aligned");
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFFB));
+}
+__device__ __forceinline__ void lds_wait0(f32x4& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); }
+__device__ __forceinline__ void lds_wait0(f32x4& a, f32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     static_assert(N >= 0 && N <= 63, "s_waitcnt vmcnt is a 6-bit field");
@@ -184,17 +205,33 @@ __device__ __forceinline__ s16x4s to_bf16x4s(f32x4 v) {
     return __builtin_bit_cast(s16x4s, r);
 }
 
-template <int D, int KC, bool BF = false>
+// PP = true (round 5, "ping-pong"): 8-wave blocks, one per CU.  Waves 0-3 ("side 0") and 4-7 ("side 1") are two teams of the
+// 4-wave kind above, each on its own tiles; wave w and wave w + 4 share a SIMD.  Measured with ONE wave per SIMD
+// (tools/stream_stamps.py --blocks 256) a tile costs a degree-3 wave 10.4 k cycles of products and 7.2 k of everything else
+// (DMA issue, order scan, bond cosines, mix, stores); two unsynchronised waves per SIMD take 26.5 k each -- 13.2 k per tile
+// and SIMD, the matrix pipe 68 % busy in the steady state -- because their product phases collide as often as they
+// interleave.  Here they cannot collide: a side's tile is two PHASES separated by block-wide barriers,
+//     M: multiply all S1 slots of the tile (the ring holds exactly one tile: RING = S1) -- matrix instructions + LDS reads only;
+//     O: issue the whole next tile's DMA into the ring just read, then the epilogue of this tile, then vmcnt(0);
+// and side 1 runs one phase behind side 0, so on every SIMD one wave multiplies while its partner issues, scans and stores.
+// No counted vmcnt any more (every DMA of a tile lands before the phase that reads it begins).  Degree 4 (two waves per
+// column tile swap halves through LDS in the epilogue, with a barrier): every phase has a second barrier in its middle.
+template <int D, int KC, bool BF = false, bool PP = false>
 __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDeg& dg, const int cp, const int rank, const int count, float* lds) {
     using T = StreamTraits<D>;
     constexpr int NS = T::NS, NSTREAM = T::NSTREAM, RING = T::RING, S1 = T::S1, META = T::META;
+    static_assert(!PP || RING == S1, "ping-pong: the ring holds exactly one tile");
+    constexpr int NSIDE = PP ? 2 : 1;
+    constexpr int NTHREADS = PP ? 512 : 256;
     constexpr int SLOT = KC * 256;                       // floats per row-slot buffer (KC pieces of 1 KB)
     // HS ("half supports", degree 4): wave = (column tile of the block, support half); see the file comment
     constexpr bool HS = (D == 4);
     constexpr int NBS = HS ? 2 : D;                      // support slots this wave multiplies
     constexpr int NB = NBS + 1;                          // bank slots in registers: the supports + the centre (HS: half 0 only)
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave of the block (PP: 0..7)
+    const int side = PP ? (wave8 >> 2) : 0;                           // PP: team of the block
+    const int wave = PP ? (wave8 & 3) : wave8;                        // wave of its team
     const unsigned long long t_start = a.stamps ? __builtin_readcyclecounter() : 0ull;
     const unsigned long long rt_start = a.stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz: the in-kernel clock is d(cycles) / d(this)
     const int stream = wave / NS, role = wave % NS;
@@ -206,15 +243,16 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
     const bool col_ok = (ct < dg.nct) && (ci < kpt) && (lcol < L);
     const int FPB = a.FPB;                               // row pitch of the padded bank (>= FP)
     const bool do_chir = (D == 4) && a.last;
-    float* const ring = lds + (size_t)stream * (RING * SLOT + 2 * META);
+    constexpr int SIDE_FLOATS = NSTREAM * (RING * SLOT + 2 * META);
+    float* const ring = lds + (size_t)side * SIDE_FLOATS + (size_t)stream * (RING * SLOT + 2 * META);
     float* const meta = ring + RING * SLOT;
-    int8_t* const chirtab = (int8_t*)(lds + (size_t)NSTREAM * (RING * SLOT + 2 * META));
-    float* const xbuf = lds + (size_t)NSTREAM * (RING * SLOT + 2 * META) + 192;      // (HS only) [wave][18][64]
+    int8_t* const chirtab = (int8_t*)(lds + (size_t)NSIDE * SIDE_FLOATS);
+    float* const xbuf = lds + (size_t)NSIDE * SIDE_FLOATS + 192;      // (HS only) [wave of the block][18][64]
 
     // ---- tiles of this stream: a contiguous run; every block of the group runs the same number of iterations
     const int64_t ntiles = (dg.n + 15) / 16;
-    const int64_t nstreams = (int64_t)count * NSTREAM;
-    const int64_t sg = (int64_t)rank * NSTREAM + stream;
+    const int64_t nstreams = (int64_t)count * NSTREAM * NSIDE;
+    const int64_t sg = ((int64_t)rank * NSIDE + side) * NSTREAM + stream;
     const int64_t tile_first = sg * ntiles / nstreams;
     const int64_t tile_end = (sg + 1) * ntiles / nstreams;
     const int64_t iters = (ntiles + nstreams - 1) / nstreams;
@@ -224,6 +262,17 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
         return t > tile_hi ? tile_hi : t;
     };
 
+    // PP: the team on the other side of the block (same stream, same role: its waves are this team's SIMD partners)
+    [[maybe_unused]] float* const pring = lds + (size_t)(PP ? 1 - side : 0) * SIDE_FLOATS + (size_t)stream * (RING * SLOT + 2 * META);
+    [[maybe_unused]] float* const pmeta = pring + RING * SLOT;
+    const int64_t psg = ((int64_t)rank * NSIDE + (PP ? 1 - side : 0)) * NSTREAM + stream;
+    const int64_t ptile_first = psg * ntiles / nstreams, ptile_end = (psg + 1) * ntiles / nstreams;
+    const int64_t ptile_hi = (ptile_end > ptile_first ? ptile_end : (ptile_first + 1 < ntiles ? ptile_first + 1 : ntiles)) - 1;
+    [[maybe_unused]] auto ptile_at = [&](int64_t i) -> int64_t {
+        const int64_t t = ptile_first + i;
+        return t > ptile_hi ? ptile_hi : t;
+    };
+
     // (tile 0's ids first: their DMA flies while the bank is loaded -- one dependent round trip less in front of the first
     // tile, which is all a stream has at small batches)
     if (role == 0) {
@@ -231,7 +280,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
         if (n0 >= dg.n) n0 = dg.n - 1;
         const int kq0 = lane >> 4;
         const void* src0 = (kq0 < D) ? (const void*)(dg.nei + n0 * D + kq0) : (const void*)(dg.sel + n0);
-        float* const meta0 = lds + (size_t)stream * (RING * SLOT + 2 * META) + RING * SLOT;
+        float* const meta0 = meta;
         if (S1 >= 4 || kq0 < S1) dma4<SITE_IDS>(src0, meta0);
         if constexpr (S1 == 5) {
             if (kq0 == 0) dma4<SITE_IDS4>(dg.sel + n0, meta0 + 64);
@@ -266,7 +315,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
     const float ws = dg.mix[0], wc = dg.mix[1], we = dg.mix[2], wsum = dg.mix[3];
     if constexpr (D == 4) {
         if (do_chir)
-            for (int q = tid; q < L * 12; q += 256) chirtab[q] = dg.chir[q];
+            for (int q = tid; q < L * 12; q += NTHREADS) chirtab[q] = dg.chir[q];
     }
     const int8_t* const eqp = do_chir ? (const int8_t*)dg.eqflag : (const int8_t*)dg.sel;       // always loadable
     const int8_t* const sgp = do_chir ? (const int8_t*)dg.signflag : (const int8_t*)dg.sel;
@@ -348,7 +397,13 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
 
-    int buf = 0;                                         // ring buffer of the current step
+    [[maybe_unused]] int buf = 0;                        // ring buffer of the current step
+    if constexpr (PP) {                                  // side 1 runs one phase behind: it multiplies while side 0 finishes a tile
+        if (side == 1) {
+            __builtin_amdgcn_s_barrier();
+            if constexpr (HS) __builtin_amdgcn_s_barrier();
+        }
+    }
 #ifdef MKGNN_FWD_STAMPS
     unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_phase = __builtin_readcyclecounter();
 #endif
@@ -362,6 +417,125 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
         for (int s = 0; s < D; ++s)
 #pragma unroll
             for (int b = 0; b < NBS; ++b) cm[s][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (PP) {
+            // ---- M phase: the whole tile.  Slots 0 .. D-2 one after the other; the last neighbour slot and the focal slot
+            // chunk by chunk TOGETHER, so that two consecutive matrix instructions never share an accumulator (the centre's
+            // chain alone would issue every 40 cycles instead of every 32: dependent-accumulator latency; every sum keeps
+            // its own order).
+            // The DMA of the NEXT tile is issued from here too -- but the PARTNER team's, not this team's: this team's ring
+            // is being read, the partner team (one phase behind / ahead) has just finished reading its own.  A first version
+            // issued a team's whole next tile at the head of its own O phase: 17-20 pieces in one burst from every wave of
+            // the phase cost ~500 cycles of issue EACH (7 k cycles per tile, tools/stream_stamps.py) -- the request queue is
+            // a few pieces deep and an issue blocks while it is full.  One or two pieces between two chunks of matrix
+            // instructions (8-12 of them, 256-384 cycles) find the queue drained.
+            const int64_t pt = it + side;                // the partner's tile (iteration) whose rows are fetched in this phase
+            {
+                const float* const prec = pmeta + (pt & 1) * META;
+#pragma unroll
+                for (int q = 0; q < S1; ++q) idsD[q] = __float_as_uint(prec[16 * q + ci]);      // (its ids were DMA'd a tile ago)
+            }
+#ifndef MKGNN_PP_NO_DMA                                   // (timing experiment: nothing is fetched after tile 0)
+            if (role == 0) {                             // the small records first (bond rows, 1 / |x| and flags, the ids of the tile after)
+                float* const prec = pmeta + (pt & 1) * META;
+                static_for<0, D>([&](auto sdc) { issue_bonds(ptile_at(pt), decltype(sdc)::value, prec); });
+                issue_meta(ptile_at(pt), prec);
+                issue_ids(ptile_at(pt + 1), pmeta + ((pt + 1) & 1) * META);
+            }
+#endif
+            prio_multiply();
+            auto mask_last = [&](f32x4& cur) {           // only the last chunk of a row can be partial or empty
+                const int col = 16 * (KC - 1) + 4 * kq;
+                if (col >= F) cur.x = 0.f;
+                if (col + 1 >= F) cur.y = 0.f;
+                if (col + 2 >= F) cur.z = 0.f;
+                if (col + 3 >= F) cur.w = 0.f;
+            };
+            // this wave's share of the partner tile's S1 * KC row pieces: the flat pieces f = NS g + role, g = 0 .. TOTW-1,
+            // PW of them after every chunk step (all issued in the first two thirds of the phase, so that the last ones have
+            // landed when the phase ends); f -> slot f / KC, chunk f % KC, LDS image 256 f floats into the partner's ring
+            constexpr int TOT = S1 * KC, TOTW = (TOT + NS - 1) / NS, STEPS = D * KC;
+            constexpr int SPREAD = (2 * STEPS) / 3 > 0 ? (2 * STEPS) / 3 : 1;
+            constexpr int PW = (TOTW + SPREAD - 1) / SPREAD;
+            auto issue_step = [&](auto stepc) {
+                constexpr int step = decltype(stepc)::value;
+#ifdef MKGNN_PP_NO_DMA
+                return;
+#endif
+                static_for<0, PW>([&](auto jc) {
+                    constexpr int g = step * PW + decltype(jc)::value;
+                    if constexpr (g < TOTW) {
+                        int f = NS * g + role;
+                        if constexpr (NS * g + NS - 1 >= TOT) {                  // (the last round may be short: repeat this wave's previous piece)
+                            if (f >= TOT) f -= NS;
+                        }
+                        // its slot f / KC (wave-uniform, but not a compile-time value: the role is not): a chain of selects, not
+                        // an index -- idsD must never be indexed by a run-time value (it would live in scratch)
+                        const int slf = f / KC;
+                        uint32_t idv = idsD[0];
+#pragma unroll
+                        for (int q = 1; q < S1; ++q) idv = (slf == q) ? idsD[q] : idv;
+                        const int t = f - slf * KC;
+                        // a chunk entirely beyond the row's width is fetched from the row's first chunk instead (in bounds,
+                        // finite whenever the row is) and masked to zero where it is used
+                        const uint32_t off = (t == KC - 1 && 16 * t + 4 * kq >= F) ? idv * xs : idv * xs + 4u * kq + 16u * (uint32_t)t;
+                        dma16<SITE_ROWS>(a.x + off, pring + f * 256);
+                    }
+                });
+            };
+            // The A-operand reads are inline asm with their own lgkmcnt waits: left to the compiler the read of chunk t + 1,
+            // written ahead of chunk t's matrix instructions, is sunk to where its value is first used and every chunk
+            // starts with an exposed LDS round trip (the 4-wave kernel's listing shows it too: ds_read_b128, s_waitcnt
+            // lgkmcnt(0), v_mfma ...).  Here: wait for step k's registers, issue step k + 1's reads, multiply step k.
+            const uint32_t rbase = (uint32_t)(uintptr_t)(ring + lane * 4);      // LDS byte address of this lane's 16 bytes of piece 0
+            auto m_phase = [&](auto withc) {
+                constexpr bool WC = decltype(withc)::value;           // (HS: the centre belongs to half 0)
+                f32x4 bufA[2], bufF[2];
+                auto rd = [&](auto stepc) {
+                    constexpr int step = decltype(stepc)::value;
+                    constexpr bool merged = step >= (D - 1) * KC;
+                    constexpr int sl = merged ? D - 1 : step / KC, t = step - sl * KC;
+                    lds_read128<(sl * SLOT + t * 256) * 4>(bufA[step & 1], rbase);
+                    if constexpr (merged && WC) lds_read128<(D * SLOT + t * 256) * 4>(bufF[step & 1], rbase);
+                };
+                rd(IC<0>{});
+                static_for<0, STEPS>([&](auto stepc) {
+                    constexpr int step = decltype(stepc)::value;
+                    constexpr bool merged = step >= (D - 1) * KC;
+                    constexpr int sl = merged ? D - 1 : step / KC, t = step - sl * KC;
+                    if constexpr (merged && WC) lds_wait0(bufA[step & 1], bufF[step & 1]);
+                    else lds_wait0(bufA[step & 1]);
+                    if constexpr (step + 1 < STEPS) rd(IC<step + 1>{});
+                    f32x4 cA = bufA[step & 1];
+                    [[maybe_unused]] f32x4 cF = bufF[step & 1];
+                    if constexpr (t == KC - 1) { mask_last(cA); if constexpr (merged && WC) mask_last(cF); }
+                    if constexpr (BF) {
+                        const s16x4s a4 = to_bf16x4s(cA);
+#pragma unroll
+                        for (int b = 0; b < NBS; ++b) cm[sl][b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a4, bk[b][t], cm[sl][b], 0, 0, 0);
+                        if constexpr (merged && WC) cc = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(to_bf16x4s(cF), bk[NBS][t], cc, 0, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+#pragma unroll
+                            for (int b = 0; b < NBS; ++b)
+                                cm[sl][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(cA[q4], bk[b][t][q4], cm[sl][b], 0, 0, 0);
+                            if constexpr (merged && WC) cc = __builtin_amdgcn_mfma_f32_16x16x4f32(cF[q4], bk[NBS][t][q4], cc, 0, 0, 0);
+                        }
+                    }
+                    issue_step(stepc);
+                    if constexpr (HS && step == 2 * KC - 1) __builtin_amdgcn_s_barrier();      // (the partner side's exchange barrier)
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            };
+            if (!HS || half == 0) m_phase(std::true_type{});
+            else m_phase(std::false_type{});
+            prio_other();
+            MKGNN_PHASE(0);
+            wait_vmcnt<0>();                             // the partner's next tile has landed (and this wave's stores are out)
+            MKGNN_PHASE(1);
+            __builtin_amdgcn_s_barrier();                // this team is done reading its ring; the partner may read its own
+            MKGNN_PHASE(2);
+        } else {
         static_for<0, S1>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             // ---- multiply slot s: one LDS read per 4 NBS (or 4) matrix instructions, issued one chunk ahead
@@ -445,6 +619,8 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
             MKGNN_PHASE(3);
         });
 
+        }
+
         // ---- epilogue: lane = kernel lcol, atoms kq * 4 + jj (the arithmetic of kc_forward_fused).  One atom at a
         // time, fenced: left to itself the scheduler interleaves the atoms' permutation scans for ILP, and with the
         // bank resident in registers that is what spills.
@@ -453,8 +629,8 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
         [[maybe_unused]] float pcc[NJ];
         if constexpr (HS) {
             // swap: my columns of the PARTNER's atoms out, the partner's columns of MY atoms in
-            float* const mine = xbuf + (size_t)wave * (18 * 64) + lane;
-            const float* const theirs = xbuf + (size_t)(wave ^ 1) * (18 * 64) + lane;
+            float* const mine = xbuf + (size_t)wave8 * (18 * 64) + lane;
+            const float* const theirs = xbuf + (size_t)(wave8 ^ 1) * (18 * 64) + lane;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -597,10 +773,17 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
             }
         }
         MKGNN_PHASE(4);
+        if constexpr (PP) __builtin_amdgcn_s_barrier();   // (end of the O phase: nothing to wait for -- the stores may stay in flight)
+    }
+    if constexpr (PP) {                                  // side 0's share of the phase side 1 sat out at the start
+        if (side == 0) {
+            __builtin_amdgcn_s_barrier();
+            if constexpr (HS) __builtin_amdgcn_s_barrier();
+        }
     }
     wait_vmcnt<0>();                                     // no DMA may land in this block's LDS after it is gone
     if (a.stamps && lane == 0) {
-        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * 4 + wave) * 16;
+        unsigned long long* o = a.stamps + ((size_t)blockIdx.x * (PP ? 8 : 4) + wave8) * 16;
         o[0] = t_start; o[1] = __builtin_readcyclecounter(); o[2] = (unsigned long long)(D * 16 + cp); o[3] = (unsigned long long)iters;
         o[12] = rt_start; o[13] = __builtin_amdgcn_s_memrealtime();
 #ifdef MKGNN_FWD_STAMPS
@@ -611,6 +794,12 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
 
 #ifndef MKGNN_EXP_OCC
 #define MKGNN_EXP_OCC 2
+#endif
+#ifndef MKGNN_FWD_PP_DEFAULT
+#define MKGNN_FWD_PP_DEFAULT 0
+#endif
+#ifndef MKGNN_FWD_PAIR_DEFAULT
+#define MKGNN_FWD_PAIR_DEFAULT 0
 #endif
 // (KC >= 8, rows of 113 .. 160 floats: the bank alone is up to 160 registers -- one wave per SIMD, 512 registers)
 template <int KC, bool BF = false>
@@ -630,6 +819,23 @@ __global__ void __launch_bounds__(256, (KC >= 8 ? 1 : MKGNN_EXP_OCC)) kc_forward
         case 1: stream_body<2, KC, BF>(a, a.deg[1], cp, rank, count, lds); break;
         case 2: stream_body<3, KC, BF>(a, a.deg[2], cp, rank, count, lds); break;
         default: stream_body<4, KC, BF>(a, a.deg[3], cp, rank, count, lds); break;
+    }
+}
+
+// the ping-pong form: 8 waves, one block per CU, 2 waves per SIMD (KC <= 7: the bank leaves room for two waves)
+template <int KC, bool BF = false>
+__global__ void __launch_bounds__(512, 2) kc_forward_pp(FusedFwdArgs a) {
+    extern __shared__ __align__(16) float lds[];
+    const int grp = a.blk_group[blockIdx.x];
+    const int rank = a.blk_rank[blockIdx.x];
+    const int di = a.grp_degree[grp];
+    const int cp = a.grp_cp[grp];
+    const int count = a.grp_count[grp];
+    switch (di) {
+        case 0: stream_body<1, KC, BF, true>(a, a.deg[0], cp, rank, count, lds); break;
+        case 1: stream_body<2, KC, BF, true>(a, a.deg[1], cp, rank, count, lds); break;
+        case 2: stream_body<3, KC, BF, true>(a, a.deg[2], cp, rank, count, lds); break;
+        default: stream_body<4, KC, BF, true>(a, a.deg[3], cp, rank, count, lds); break;
     }
 }
 
@@ -676,7 +882,7 @@ hipError_t launch_unit_rows8(const float* in, int64_t n_rows, int E, float* out,
 // prologue + iterations * cost per tile (all blocks are resident at once: the launch lasts as long as its slowest wave),
 // groups interleaved over the block ids, the blocks of a group that share an XCD (block id mod 8) given adjacent runs
 // of tiles (the buckets are sorted by atom id: what one group gathers as neighbours another gathers as focal rows).
-static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nblocks_out) {
+static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nblocks_out, bool pp = false) {
     constexpr int MG = FUSED_MAX_GROUPS;                // groups = (degree, column part); launch_forward_stream checks the total
     double cost[MG];
     int64_t tiles_of[MG], cap[MG];
@@ -689,9 +895,10 @@ static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nbloc
         g.nct = (g.L + 15) / 16;
         g.kpt = (g.L + g.nct - 1) / g.nct;
         g.cs = stream_column_parts(d, g.L); g.nloc = stream_tiles_per_part(d); g.ics = g.nloc;
-        const int nstream = (d == 1) ? 4 : (d == 4 ? 1 : 2);     // streams per 4-wave block (NSTREAM of the degree's body)
+        // streams per block: NSTREAM of the degree's body (a ping-pong block is two 4-wave teams)
+        const int nstream = ((d == 1) ? 4 : (d == 4 ? 1 : 2)) * (pp ? 2 : 1);
         const int64_t ntiles = (g.n + 15) / 16;
-        const size_t fl = (size_t)stream_lds_floats(d, KC);
+        const size_t fl = (size_t)(pp ? stream_pp_lds_floats(d, KC) : stream_lds_floats(d, KC));
         if (fl > lds_floats) lds_floats = fl;
         for (int cp = 0; cp < g.cs; ++cp) {
             // what a wave takes per tile, everything included (multiply, DMA issue, waits, epilogue), in units of 32
@@ -726,7 +933,8 @@ static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nbloc
     };
     int count[MG], nb = 0;
     for (int g = 0; g < ng; ++g) { count[g] = 1; ++nb; }
-    const int max_blocks = grid_cap(g_grid_caps.fwd, FUSED_MAX_BLOCKS);
+    // (a ping-pong block is 8 waves, one per CU: half as many blocks for the same number of waves, run-time caps included)
+    const int max_blocks = pp ? (grid_cap(g_grid_caps.fwd, FUSED_MAX_BLOCKS) + 1) / 2 : grid_cap(g_grid_caps.fwd, FUSED_MAX_BLOCKS);
     while (nb < max_blocks) {
         int worst = -1;
         double t_worst = -1.0;
@@ -738,17 +946,60 @@ static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nbloc
         if (worst < 0) break;
         ++count[worst]; ++nb;
     }
+    // Which blocks share a CU matters: two co-resident blocks of DIFFERENT degrees run at different speeds than two of the
+    // same degree, and the launch lasts as long as its unluckiest wave (round 5 stamps: the waves of one group, all with the
+    // same number of tiles, ended between 52 and 69 us).  MKGNN_FWD_PAIR = P (diagnostics; 0 = the interleave of rounds 1-4):
+    // blocks b and b + P get the same group where the counts allow it.
+    static const int pair_dist = [] { const char* e = getenv("MKGNN_FWD_PAIR"); return e ? atoi(e) : MKGNN_FWD_PAIR_DEFAULT; }();
     int given[MG] = {};
-    for (int b = 0; b < nb; ++b) {
-        int pick = -1;
-        double best = -1e30;
-        for (int g = 0; g < ng; ++g) {
-            if (given[g] >= count[g]) continue;
-            const double lag = (double)count[g] * (b + 1) / nb - given[g];
-            if (lag > best) { best = lag; pick = g; }
+    if (!pp && pair_dist > 0 && nb == 2 * 256 && (pair_dist == 256 || pair_dist == 8)) {
+        // deal PAIRS (b, b + P): half of every group's blocks to the first member, the same groups to the second; a group
+        // with an odd count shares one CU with another odd one
+        int half_cnt[MG], odd[MG], nodd = 0;
+        for (int g = 0; g < ng; ++g) { half_cnt[g] = count[g] / 2; if (count[g] & 1) odd[nodd++] = g; }
+        int seq[256], npairs = 0, hg[MG] = {};
+        int full_pairs = 0;
+        for (int g = 0; g < ng; ++g) full_pairs += half_cnt[g];
+        for (int k = 0; k < full_pairs; ++k) {
+            int pick = -1;
+            double best = -1e30;
+            for (int g = 0; g < ng; ++g) {
+                if (hg[g] >= half_cnt[g]) continue;
+                const double lag = (double)half_cnt[g] * (k + 1) / full_pairs - hg[g];
+                if (lag > best) { best = lag; pick = g; }
+            }
+            seq[npairs++] = pick; ++hg[pick];
         }
-        a.blk_group[b] = (uint8_t)pick;
-        ++given[pick];
+        // first members: pair slots in order; odd leftovers fill the remaining slots two by two
+        int first[256], second[256];
+        for (int k = 0; k < npairs; ++k) first[k] = second[k] = seq[k];
+        for (int k = 0; k + 1 < nodd + 1 && npairs < 256; k += 2) {
+            first[npairs] = odd[k]; second[npairs] = (k + 1 < nodd) ? odd[k + 1] : odd[k]; ++npairs;
+        }
+        if (npairs == 256) {
+            for (int k = 0; k < 256; ++k) {
+                int b0, b1;
+                if (pair_dist == 256) { b0 = k; b1 = k + 256; }
+                else { b0 = (k / 8) * 16 + (k % 8); b1 = b0 + 8; }       // (b, b + 8): neighbours on one XCD
+                a.blk_group[b0] = (uint8_t)first[k]; a.blk_group[b1] = (uint8_t)second[k];
+            }
+            for (int b = 0; b < nb; ++b) ++given[a.blk_group[b]];
+            for (int g = 0; g < ng; ++g) if (given[g] != count[g]) given[0] = -1;      // (cannot happen; falls through to the interleave)
+        } else given[0] = -1;
+    } else given[0] = -1;
+    if (given[0] < 0) {
+        for (int g = 0; g < ng; ++g) given[g] = 0;
+        for (int b = 0; b < nb; ++b) {
+            int pick = -1;
+            double best = -1e30;
+            for (int g = 0; g < ng; ++g) {
+                if (given[g] >= count[g]) continue;
+                const double lag = (double)count[g] * (b + 1) / nb - given[g];
+                if (lag > best) { best = lag; pick = g; }
+            }
+            a.blk_group[b] = (uint8_t)pick;
+            ++given[pick];
+        }
     }
     {
         int per_xcd[MG][8] = {};
@@ -790,11 +1041,49 @@ template <int KC, bool BF = false> static hipError_t launch_stream_kc(const Fuse
     return hipGetLastError();
 }
 
+template <int KC, bool BF = false> static hipError_t launch_pp_kc(const FusedFwdArgs& a, int nb, size_t lds_bytes, hipStream_t st) {
+    static PerDeviceOnce attr_set;
+    if (const int slot = attr_set.pending(); slot >= 0) {
+        hipError_t e = hipFuncSetAttribute((const void*)kc_forward_pp<KC, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set.set(slot);
+    }
+    kc_forward_pp<KC, BF><<<nb, 512, lds_bytes, st>>>(a);
+    return hipGetLastError();
+}
+
+// MKGNN_FWD_PP: 0 = the 4-wave blocks of rounds 2-4, 1 = ping-pong blocks wherever they apply (KC <= 7), unset = default
+static int fwd_pp_mode() {
+    static const int m = [] { const char* e = getenv("MKGNN_FWD_PP"); return e ? atoi(e) : MKGNN_FWD_PP_DEFAULT; }();
+    return m;
+}
+
 hipError_t launch_forward_stream(FusedFwdArgs& a, const bool use[4], hipStream_t st) {
     const int KC = (a.F + 15) / 16;
     a.stamps = g_stream_stamps;
     a.FPB = bank_pitch(a.F);
     int nb = 0;
+    if (KC <= 7 && fwd_pp_mode() != 0) {
+        const size_t lds_pp = plan_stream(a, use, KC, &nb, true);
+        if (nb == 0) return hipSuccess;
+        if (nb > 0 && lds_pp <= (size_t)160 * 1024) {
+            g_last_plan[0].launches.fetch_add(1);
+            if (a.bf16) {
+                if (KC == 2) return launch_pp_kc<2, true>(a, nb, lds_pp, st);
+                if (KC == 7) return launch_pp_kc<7, true>(a, nb, lds_pp, st);
+                return hipErrorInvalidValue;
+            }
+            switch (KC) {
+                case 1: return launch_pp_kc<1>(a, nb, lds_pp, st);
+                case 2: return launch_pp_kc<2>(a, nb, lds_pp, st);
+                case 3: return launch_pp_kc<3>(a, nb, lds_pp, st);
+                case 4: return launch_pp_kc<4>(a, nb, lds_pp, st);
+                case 5: return launch_pp_kc<5>(a, nb, lds_pp, st);
+                case 6: return launch_pp_kc<6>(a, nb, lds_pp, st);
+                default: return launch_pp_kc<7>(a, nb, lds_pp, st);
+            }
+        }
+    }
     const size_t lds_bytes = plan_stream(a, use, KC, &nb);
     if (nb == 0) return hipSuccess;
     if (nb < 0 || lds_bytes > (size_t)(KC >= 8 ? 128 : 80) * 1024) return hipErrorInvalidValue;     // (the caller checks stream_forward_groups first)

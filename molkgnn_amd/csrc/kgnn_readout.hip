@@ -734,7 +734,7 @@ __global__ void __launch_bounds__(256) block_project_bwd_mfma_kernel(BlockProjAr
 // by extra blocks of the node batch norm's own three launches (no launch of their own in a step), or by
 // mkgnn_batchnorm_update_stats alone.  part: [3][nblk][C] = column sums | centred squares | (column 0) counted rows.
 constexpr int BN_MAIN_BLOCKS = 256;                    // (= BN_BLOCKS: the grid of the batch norm's own passes)
-constexpr int BN_SIDE_BLOCKS = 32;                     // companion blocks at most
+constexpr int BN_SIDE_BLOCKS = 256;                    // companion blocks at most (a block takes two loop trips or more)
 struct BnSide {
     const float* x; int64_t xs; int64_t n; int C, CL, nblk;
     float *running_mean, *running_var; float momentum;
@@ -854,40 +854,18 @@ __device__ __forceinline__ void bn_total(const float* part, int nblk, int C, int
 
 
 // companion statistics, block `blk` of s.nblk.  MODE 0: column sums + counted rows; MODE 1: centred squares (mean from the
-// totals of MODE 0).  Fixed order everywhere (rows of a block by row lane, row lanes ascending, blocks ascending).
-__device__ __forceinline__ void bn_side_total(const BnSide& s, int plane, int col, float* sh, float& out) {
-    // (one block-wide sum of part[plane][b][col] over the blocks b, identical in every block; col < C)
-    float t = 0.f;
-    for (int b = threadIdx.x; b < s.nblk; b += 256) t += s.part[((size_t)plane * s.nblk + b) * s.C + col];
-    __syncthreads();
-    sh[threadIdx.x] = t;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float u = 0.f;
-        for (int k = 0; k < 256; ++k) u += sh[k];
-        sh[256] = u;
-    }
-    __syncthreads();
-    out = sh[256];
-}
-
+// totals of MODE 0).  Fixed order everywhere (rows of a block by row lane, row lanes ascending, blocks by bn_total).
 template <int MODE>
 __device__ __forceinline__ void bn_side_colsum(const BnSide& s, int blk, float* sh) {
     const int CL = s.CL, c = threadIdx.x & (CL - 1), rsub = threadIdx.x / CL, RS = 256 / CL;
     const bool act = c < s.C;
     const int cc = act ? c : 0;
     float mu = 0.f;
-    if (MODE == 1) {                                     // the mean of every column, from the totals (one column at a time)
-        float cnt;
-        bn_side_total(s, 2, 0, sh, cnt);
-        __shared__ float mean_sh[256];
-        for (int col = 0; col < s.C; ++col) {
-            float t;
-            bn_side_total(s, 0, col, sh, t);
-            if (threadIdx.x == 0) mean_sh[col] = t / fmaxf(cnt, 1.f);
-        }
-        __syncthreads();
-        mu = mean_sh[cc];
+    if (MODE == 1) {                                     // the mean of every column, from the totals
+        __shared__ float tot_sh[256], cnt_sh[256];
+        bn_total(s.part, s.nblk, s.C, CL, sh, tot_sh);
+        bn_total(s.part + (size_t)2 * s.nblk * s.C, s.nblk, s.C, CL, sh, cnt_sh);       // (column 0 holds the counts)
+        mu = tot_sh[cc] / fmaxf(cnt_sh[0], 1.f);
     }
     const int64_t per = (s.n + s.nblk - 1) / s.nblk;
     int64_t lo = per * blk, hi = lo + per < s.n ? lo + per : s.n;
@@ -915,29 +893,29 @@ __device__ __forceinline__ void bn_side_colsum(const BnSide& s, int blk, float* 
     sh[threadIdx.x] = s0;
     if (MODE == 0) sh[256 + threadIdx.x] = cnt;
     __syncthreads();
-    if (rsub == 0 && act) {
+    if (rsub == 0) {
         float t0 = 0.f, t1 = 0.f;
         for (int k = 0; k < RS; ++k) { t0 += sh[k * CL + c]; if (MODE == 0) t1 += sh[256 + k * CL + c]; }
-        s.part[((size_t)MODE * s.nblk + blk) * s.C + c] = t0;
-        if (MODE == 0 && c == 0) s.part[((size_t)2 * s.nblk + blk) * s.C] = t1;     // (exact: counts below 2^24 per block)
+        if (act) s.part[((size_t)MODE * s.nblk + blk) * s.C + c] = t0;
+        // counts: every column of the plane is written (bn_total reads them all); exact below 2^24 rows per block
+        if (MODE == 0 && act) s.part[((size_t)2 * s.nblk + blk) * s.C + c] = t1;
     }
 }
 
 // running <- running + momentum (batch - running), unbiased variance, counter + 1 (one block)
 __device__ __forceinline__ void bn_side_final(const BnSide& s, float* sh) {
-    float cnt;
-    bn_side_total(s, 2, 0, sh, cnt);
-    for (int col = 0; col < s.C; ++col) {
-        float t0, t1;
-        bn_side_total(s, 0, col, sh, t0);
-        bn_side_total(s, 1, col, sh, t1);
-        if (threadIdx.x == 0 && cnt > 0.f) {
-            const float mu = t0 / cnt, var = t1 / cnt;
-            if (s.running_mean) s.running_mean[col] = fmaf(s.momentum, mu - s.running_mean[col], s.running_mean[col]);
-            if (s.running_var) {
-                const float unbiased = cnt > 1.f ? var * (cnt / (cnt - 1.f)) : var;
-                s.running_var[col] = fmaf(s.momentum, unbiased - s.running_var[col], s.running_var[col]);
-            }
+    __shared__ float tot_sh[256], sq_sh[256], cnt_sh[256];
+    bn_total(s.part, s.nblk, s.C, s.CL, sh, tot_sh);
+    bn_total(s.part + (size_t)s.nblk * s.C, s.nblk, s.C, s.CL, sh, sq_sh);
+    bn_total(s.part + (size_t)2 * s.nblk * s.C, s.nblk, s.C, s.CL, sh, cnt_sh);
+    const int col = threadIdx.x;
+    const float cnt = cnt_sh[0];
+    if (col < s.C && cnt > 0.f) {
+        const float mu = tot_sh[col] / cnt, var = sq_sh[col] / cnt;
+        if (s.running_mean) s.running_mean[col] = fmaf(s.momentum, mu - s.running_mean[col], s.running_mean[col]);
+        if (s.running_var) {
+            const float unbiased = cnt > 1.f ? var * (cnt / (cnt - 1.f)) : var;
+            s.running_var[col] = fmaf(s.momentum, unbiased - s.running_var[col], s.running_var[col]);
         }
     }
     if (threadIdx.x == 0 && s.nbt) s.nbt[0] += 1;
@@ -1767,7 +1745,7 @@ static int bn_side_setup(const char* who, const mkgnn_bn_stats* c, void* ws, siz
     s.running_mean = c->running_mean; s.running_var = c->running_var; s.momentum = c->momentum; s.nbt = c->num_batches_tracked;
     s.key = c->row_key; s.key_limit = c->key_limit; s.part = (float*)ws;
     const int64_t rows_per_pass = 8 * (256 / s.CL);      // rows a block takes per loop trip
-    int64_t nb = (c->n_rows + 4 * rows_per_pass - 1) / (4 * rows_per_pass);
+    int64_t nb = (c->n_rows + 2 * rows_per_pass - 1) / (2 * rows_per_pass);
     s.nblk = (int)(nb < 1 ? 1 : (nb > BN_SIDE_BLOCKS ? BN_SIDE_BLOCKS : nb));
     return 0;
 }
