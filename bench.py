@@ -42,6 +42,11 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--roofline-reps", type=int, default=20)
     ap.add_argument("--windows", type=int, default=0, help="timed windows of --steps steps each (0: as many as make >= 0.5 s of timed work, at least 5)")
+    ap.add_argument("--dp-one-graph", action="store_true",
+                    help="N > 1: capture the gradient all-reduce INTO the step's graph (one graph per batch, as on one GPU) instead "
+                         "of backward graph + all-reduce + optimiser graph; recorded in the line as dp_one_graph (same as "
+                         "MKGNN_DP_ONE_GRAPH=1).  Not the default until it has run on more than one GPU: a collective that hangs "
+                         "inside a replay cannot be caught")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher check (no GPU needed): every rank prints its RANK / LOCAL_RANK / WORLD_SIZE as one JSON line and exits")
     ap.add_argument("--fresh-batches", type=int, default=16,
@@ -544,7 +549,8 @@ def main():
     # MKGNN_BENCH_DP_PATH=1 (rehearsal on one GPU): take the N > 1 code path -- backward graph, RCCL all-reduce of the flat
     # gradient buffer, one shared optimiser graph -- with a process group of ONE rank
     dp_path = world > 1 or bool(os.environ.get("MKGNN_BENCH_DP_PATH"))
-    if os.environ.get("MKGNN_DP_ONE_GRAPH") == "1":
+    want_one_graph = args.dp_one_graph or os.environ.get("MKGNN_DP_ONE_GRAPH") == "1"
+    if want_one_graph:
         # a collective captured into the step's graph: the process group's watchdog thread must not query the events of a
         # work object recorded in a capturing stream (hipErrorCapturedEvent aborts the process on this stack: PyTorch 2.10,
         # RCCL 2.26); with these set before the group is created the one-rank rehearsal captures and replays
@@ -614,7 +620,7 @@ def main():
                 # MKGNN_DP_ONE_GRAPH=1: the collective is captured too -- backward, copy into the flat buffer, RCCL all-reduce
                 # and the optimiser (reading the flat views) are ONE graph per batch, as on one GPU.  Not the default: a
                 # collective that hangs inside a replay cannot be caught; the two-graph step is.
-                one_graph = dp_path and opt is not None and fill_in_graph and os.environ.get("MKGNN_DP_ONE_GRAPH") == "1"
+                one_graph = dp_path and opt is not None and fill_in_graph and want_one_graph
                 if one_graph:
                     for grp in opt.param_groups:
                         grp["grad_scale"] = 1.0 / world
@@ -667,7 +673,8 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
         except Exception as exc:                     # capture is an optimisation, never a requirement
-            log(f"hipGraph capture unavailable ({type(exc).__name__}: {str(exc).splitlines()[0]}); running eagerly")
+            log(f"hipGraph capture FAILED ({type(exc).__name__}: {str(exc).splitlines()[0]}); running eagerly -- the line says "
+                "\"graph_replay\": false: a different execution mode from the documented headline")
             if os.environ.get("MKGNN_BENCH_DEBUG"):
                 import traceback
                 traceback.print_exc()
@@ -715,11 +722,15 @@ def main():
         if world > 1:
             dist.barrier()
         el = time.perf_counter() - t0
+        own = el
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
+        own_windows.append(own)                          # (this rank's own clock for the window: per-rank figures below)
         return el
+
+    own_windows = []
 
     # how many ranks the collective really spans (an all-reduce of ones), outside the timed region
     ranks_seen = None
@@ -734,8 +745,41 @@ def main():
         t = torch.tensor([n_windows], dtype=torch.int64, device=dev)
         dist.broadcast(t, 0)
         n_windows = int(t.item())
-    windows = sorted([first] + [timed_window() for _ in range(n_windows - 1)])
+    unsorted = [first] + [timed_window() for _ in range(n_windows - 1)]
+    windows = sorted(unsorted)
     elapsed = windows[len(windows) // 2]                 # the median window is the reported one
+    # N > 1, for whoever has to explain the scaling curve: every rank's own time for the reported window (the slowest sets
+    # `value`), and the gradient all-reduce's own GPU time -- HIP events around the collective, one more untimed window
+    per_rank = None
+    allreduce_ms = None
+    if dist.is_initialized():
+        k_med = unsorted.index(elapsed)
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = own_windows[k_med]
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        per = [1e3 * float(v) / args.steps for v in t.tolist()]
+        per_rank = {"ms_per_step_min": round(min(per), 4), "ms_per_step_max": round(max(per), 4),
+                    "ms_per_step_by_rank": [round(v, 4) for v in per],
+                    "what": "each rank's own wall clock for the reported (median) window, barrier to barrier"}
+        if graphs is not None and flat_opt:
+            pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+            dist.barrier()
+            for i, (e0, e1) in enumerate(pairs):
+                g_fb, g_opt, _, _ = graphs[i % nb]
+                g_fb.replay()
+                e0.record()
+                reducer.all_reduce_filled()
+                e1.record()
+                g_opt.replay()
+            torch.cuda.synchronize()
+            ts = sorted(e0.elapsed_time(e1) for e0, e1 in pairs)
+            t = torch.tensor([ts[len(ts) // 2], ts[0], ts[-1]], dtype=torch.float64, device=dev)
+            tmax = t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            allreduce_ms = {"median": round(float(tmax[0]), 4), "min": round(float(tmax[1]), 4), "max": round(float(tmax[2]), 4),
+                            "bytes": reducer.nbytes,
+                            "what": "HIP events around the flat-buffer all-reduce between the backward graph and the optimiser graph "
+                                    "(includes waiting for the slowest rank's backward), max over ranks, one untimed window"}
     mols = args.batch_size * args.steps * world
     value = mols / elapsed
     # data-parallel sanity, outside the timed region: identical initial weights + averaged gradients + a deterministic
@@ -750,19 +794,34 @@ def main():
             dist.all_reduce(d, op=dist.ReduceOp.MAX)
             replicas_diff = float(d.item())
         log(f"replicas: max |parameter - rank 0's| over all ranks after {args.warmup + args.steps} steps = {replicas_diff:g}")
+    # ... and the BUFFERS (BatchNorm running statistics): every rank accumulated its own batches' statistics; averaged over
+    # the ranks once here, as a training run would at a checkpoint (dp.BufferSync), then checked like the parameters
+    buffers_before = buffers_after = None
+    if dist.is_initialized():
+        bsync = dp.BufferSync(model)
+        buffers_before = bsync.max_abs_diff()
+        bsync.average()
+        buffers_after = bsync.max_abs_diff()
+        log(f"buffers: max |buffer - rank 0's| {buffers_before:g} before the average over ranks, {buffers_after:g} after")
 
     # the collective part is over: check it, then every rank leaves the process group; rank 0 goes on alone with the
     # kernel measurements and the CPU baseline (the other ranks must not sit in a collective for those 30 s)
     dp_info = {}
     dp_failure = None
     if dist.is_initialized():
-        dp_info = {"dp_ranks_seen": ranks_seen, "dp_backend": dist.get_backend(),
+        dp_info = {"dp_ranks_seen": ranks_seen, "dp_backend": dist.get_backend(), "dp_one_graph": bool(want_one_graph),
+                   "dp_per_rank": per_rank, "dp_allreduce_ms": allreduce_ms,
+                   "dp_buffers": {"max_abs_diff_before_sync": buffers_before, "max_abs_diff": buffers_after,
+                                  "sync": "BatchNorm running statistics averaged over the ranks once after the timed steps "
+                                          "(dp.BufferSync.average; outside the timed region)"},
                    "dp_step": "one graph (collective captured)" if (graphs is not None and all(e_[1] is None for e_ in graphs))
                               else ("backward graph + all-reduce + optimiser graph" if graphs is not None else "eager")}
         if ranks_seen != world:
             dp_failure = f"the all-reduce spanned {ranks_seen} rank(s), not the {world} that --gpus asked for"
         elif replicas_diff is not None and replicas_diff > 0.0:
             dp_failure = f"replicas diverged: max |parameter - rank 0's| = {replicas_diff:g} after {args.warmup + args.steps} steps"
+        elif buffers_after is not None and buffers_after > 0.0:
+            dp_failure = f"buffers differ after the average over ranks: max |buffer - rank 0's| = {buffers_after:g}"
         dist.barrier()
         dist.destroy_process_group()
     if dp_failure is not None:
@@ -864,6 +923,7 @@ def main():
                            "ms_per_step_min": round(1e3 * windows[0] / args.steps, 4),
                            "ms_per_step_max": round(1e3 * windows[-1] / args.steps, 4),
                            "timed_seconds_total": round(sum(windows), 4)},
+               "graph_replay": graphs is not None,       # False: the capture failed (or --no-graph) and the steps were launched eagerly
                "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16 dot products, f32 otherwise" if args.variant == "bf16" else "f32",
                "data": "synthetic",

@@ -190,6 +190,71 @@ class FlatGradAllReduce:
                     self._filled.append(p)
 
 
+class BufferSync:
+    """The model's BUFFERS across the ranks: BatchNorm's ``running_mean`` / ``running_var`` are statistics of the rank's own
+    batches (``dp.py`` reduces gradients, i.e. parameters, only), so without this rank 0's checkpoint holds rank 0's
+    statistics -- where PyTorch's DDP would broadcast rank 0's buffers before every forward.  ``average()`` makes every
+    rank's floating-point buffers the MEAN over the ranks (every rank saw 1 / world of the stream: the mean is the
+    better estimate of what one process would have accumulated) with ONE all-reduce of one flat buffer, and takes the
+    integer buffers (``num_batches_tracked``) from rank 0; ``broadcast()`` is DDP's form (everything from rank 0).  Call
+    it at checkpoints / ends of epochs, outside captured steps; ``max_abs_diff()`` says how far the replicas' buffers are
+    from rank 0's (0 after either call)."""
+
+    def __init__(self, module: torch.nn.Module):
+        named = [(n, b) for n, b in module.named_buffers() if b is not None and b.numel()]
+        self.float_names = [n for n, b in named if b.dtype.is_floating_point]
+        self.floats = [b for _, b in named if b.dtype.is_floating_point]
+        self.others = [b for _, b in named if not b.dtype.is_floating_point]
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+
+    def _flat(self) -> Optional[torch.Tensor]:
+        if not self.floats:
+            return None
+        return torch.cat([b.detach().reshape(-1).to(torch.float32) for b in self.floats])
+
+    def _scatter_back(self, flat: torch.Tensor) -> None:
+        off = 0
+        with torch.no_grad():
+            for b in self.floats:
+                b.copy_(flat[off:off + b.numel()].view_as(b).to(b.dtype))
+                off += b.numel()
+
+    def average(self) -> None:
+        if self.world == 1 and not dist.is_initialized():
+            return
+        flat = self._flat()
+        if flat is not None:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat.mul_(1.0 / self.world)
+            self._scatter_back(flat)
+        for b in self.others:
+            dist.broadcast(b, 0)
+
+    def broadcast(self) -> None:
+        if self.world == 1 and not dist.is_initialized():
+            return
+        flat = self._flat()
+        if flat is not None:
+            dist.broadcast(flat, 0)
+            self._scatter_back(flat)
+        for b in self.others:
+            dist.broadcast(b, 0)
+
+    def max_abs_diff(self) -> float:
+        """max over ranks and buffers of |buffer - rank 0's| (a collective: every rank calls it)."""
+        if self.world == 1 and not dist.is_initialized():
+            return 0.0
+        parts = [b.detach().reshape(-1).to(torch.float64) for b in self.floats + self.others]
+        if not parts:
+            return 0.0
+        mine = torch.cat(parts)
+        ref = mine.clone()
+        dist.broadcast(ref, 0)
+        d = (mine - ref).abs().max().reshape(1)
+        dist.all_reduce(d, op=dist.ReduceOp.MAX)
+        return float(d.item())
+
+
 # parameter-name fragments that never receive a gradient in the reference's model (SURVEY 8 a-9); "^" anchors a
 # prefix: GNNModel's own unused heads are lin1 / lin2 (model.py:147-148), while gnn_model.graph_embedding_lin1 / lin2
 # ARE trained and must be reduced

@@ -161,3 +161,54 @@ def test_reduce_works_on_the_gradients_of_the_replayed_graph(tmp_path):
     # rank 1 had no bias gradient: both ranks still see rank 0's in the flat view (and would apply the same update)
     assert torch.allclose(r0["flat_holed"][1], r0["before"][1][1], atol=1e-6)
     assert torch.equal(r0["flat_holed"][1], r1["flat_holed"][1])
+
+
+def _buffer_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from molkgnn_amd import dp
+    assert dp.init_process_group_from_env("gloo") == world
+    torch.manual_seed(3)                                   # identical replicas
+    net = torch.nn.Sequential(torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 4), torch.nn.BatchNorm1d(4))
+    net.train()
+    g = torch.Generator().manual_seed(20 + rank)           # every rank its own batches: its own running statistics
+    steps = 3 + rank                                       # (and, here, its own step count)
+    for _ in range(steps):
+        net(torch.randn(16, 5, generator=g) * (1 + rank) + rank)
+    mine = {n: b.clone() for n, b in net.named_buffers()}
+    sync = dp.BufferSync(net)
+    before = sync.max_abs_diff()
+    gathered = {}
+    for n, b in mine.items():
+        if b.dtype.is_floating_point:
+            t = [torch.zeros_like(b) for _ in range(world)]
+            dist.all_gather(t, b)
+            gathered[n] = torch.stack(t).mean(dim=0)
+    sync.average()
+    after = sync.max_abs_diff()
+    ok_mean = all(torch.allclose(b, gathered[n], atol=1e-6) for n, b in net.named_buffers() if b.dtype.is_floating_point)
+    counts = [int(b) for n, b in net.named_buffers() if not b.dtype.is_floating_point]
+    # DDP's form: everything from rank 0
+    net2 = torch.nn.BatchNorm1d(3)
+    net2.train()
+    net2(torch.randn(8, 3, generator=g) + rank)
+    s2 = dp.BufferSync(net2)
+    d2 = s2.max_abs_diff()
+    s2.broadcast()
+    torch.save({"before": before, "after": after, "ok_mean": ok_mean, "counts": counts, "d2_before": d2, "d2_after": s2.max_abs_diff(),
+                "rm2": net2.running_mean.clone()}, os.path.join(out_dir, f"buf{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_buffer_sync_averages_running_statistics_over_the_ranks(tmp_path):
+    """dp.BufferSync: BatchNorm's running statistics are per-rank state that the gradient
+    all-reduce never touches; ``average()`` leaves every rank with the mean over ranks (integer buffers from rank 0),
+    ``broadcast()`` with rank 0's, and ``max_abs_diff()`` -- bench.py's dp_buffers.max_abs_diff -- is 0 afterwards."""
+    port = _free_port()
+    mp.spawn(_buffer_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "buf0.pt"), torch.load(tmp_path / "buf1.pt")
+    for r in (r0, r1):
+        assert r["before"] > 1e-3 and r["after"] == 0.0 and r["ok_mean"]
+        assert r["counts"] == [3, 3]                        # rank 0's step count on both ranks
+        assert r["d2_before"] > 1e-3 and r["d2_after"] == 0.0
+    assert torch.equal(r0["rm2"], r1["rm2"])

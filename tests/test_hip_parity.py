@@ -1636,3 +1636,30 @@ def test_every_buffer_of_the_state_dict_after_three_training_steps(mols, padded)
     with torch.no_grad():
         model(b)
     assert int(model.edge_batch_norm.num_batches_tracked) == 3                                  # eval mode moves nothing
+
+
+def test_bench_two_ranks_on_one_card_reports_the_data_parallel_keys(tmp_path):
+    """``python bench.py --gpus 2`` through its own launcher, both ranks on the test box's one GPU (gloo): the N > 1 line
+    must explain itself -- per-rank step times, the all-reduce's own time, the step form, parameters AND buffers
+    identical over the ranks after the run."""
+    import json
+    import subprocess
+    import sys
+    _dev()
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MKGNN_ALLOW_SHARED_GPU="1", MKGNN_DIST_BACKEND="gloo", MKGNN_NO_SMALL_BATCH="1", MKGNN_NO_SHARD_EPOCH="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(repo, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--windows", "2",
+                        "--batch-size", "256", "--fresh-batches", "0", "--no-cpu-baseline", "--roofline-reps", "2"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["dp_ranks_seen"] == 2 and line["graph_replay"] is True
+    assert line["dp_one_graph"] is False and "optimiser graph" in line["dp_step"]
+    assert line["dp_replicas_max_abs_diff"] == 0.0
+    pr = line["dp_per_rank"]
+    assert len(pr["ms_per_step_by_rank"]) == 2 and pr["ms_per_step_min"] <= pr["ms_per_step_max"] <= line["ms_per_step"] * 1.001 + 1e-3
+    ar = line["dp_allreduce_ms"]
+    assert ar["median"] > 0 and ar["bytes"] > 4 * 120_000
+    db = line["dp_buffers"]
+    assert db["max_abs_diff_before_sync"] > 0 and db["max_abs_diff"] == 0.0      # the ranks' batches differ; averaged once at the end
