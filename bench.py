@@ -98,6 +98,19 @@ def backward_algorithmic(plan, F, E, Ls):
     }
 
 
+def committed_traffic(names):
+    """(HBM bytes per launch, where it comes from) of the first of these files under profiles/ that exists."""
+    for name in names:
+        path = os.path.join(REPO, "profiles", name)
+        try:
+            pmc = json.load(open(path))
+            return pmc["hbm_bytes_per_launch"], (f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of commit "
+                                                + pmc.get("commit", "?") + ")")
+        except Exception:
+            continue
+    return None, None
+
+
 def time_backward_kernels(lib, Fn, h, plan, params, E, variant, reps):
     """HIP-event durations (ms, mean over `reps` calls) of the five kernels of one N-hop layer's backward, each alone on the
     GPU (mkgnn_debug_time_backward keeps the call on one stream)."""
@@ -282,7 +295,9 @@ def small_batch_leg(args, model, opt, dev, log):
         ms_f = sorted(samples)[len(samples) // 2]
         by, fl = layer_algorithmic(plan, K_in, E, layer.L, False)
         key = f"aid{assay}_b{B}"
-        out[key] = {"workload": f"AID {assay} shape, batch {B} ({b.x.shape[0]} atoms), fwd+bwd+AdamW, one hipGraph per resident batch",
+        tr, tr_src = committed_traffic(("r05_forward_pmc_b256.json",)) if (B == 256 and args.variant in ("auto", "mfma")) else (None, None)
+        out[key] = {"forward_kernel_traffic": tr, "forward_kernel_traffic_source": tr_src, "forward_kernel_algorithmic_bytes": by,
+                    "workload": f"AID {assay} shape, batch {B} ({b.x.shape[0]} atoms), fwd+bwd+AdamW, one hipGraph per resident batch",
                     "ms_per_step": round(1e3 * wins[2], 4), "ms_per_step_min": round(1e3 * wins[0], 4),
                     "value": round(B / wins[2], 1), "unit": "molecules/s",
                     "forward_kernel_ms": round(ms_f, 5), "forward_kernel_frac": round(by / (ms_f * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
@@ -876,22 +891,45 @@ def main():
         ms_single = sorted(single)[len(single) // 2] if single and min(single) > 0 else None
         by, fl = layer_algorithmic(plan, K_in, E, Ls, False)
         gbs = by / (ms * 1e-3) / 1e9
-        traffic, traffic_source = None, None
-        try:    # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same workload; tools/pmc.sh)
-            if args.batch_size == 4096 and args.variant in ("auto", "mfma"):
-                for name in ("r04_forward_pmc.json", "r03_forward_pmc.json", "r02_forward_pmc.json"):
-                    path = os.path.join(REPO, "profiles", name)
-                    if os.path.exists(path):
-                        pmc = json.load(open(path))
-                        traffic = pmc["hbm_bytes_per_launch"]
-                        traffic_source = f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of commit " + pmc.get("commit", "?") + ")"
-                        break
-        except Exception:
-            traffic = None
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same workload; tools/pmc.sh -- counters
+        # cannot be read from inside this process: the figure is the committed one, labelled with the commit it was taken at)
+        traffic, traffic_source = (committed_traffic(("r05_forward_pmc.json", "r04_forward_pmc.json", "r03_forward_pmc.json"))
+                                   if args.batch_size == 4096 and args.variant in ("auto", "mfma") else (None, None))
         # the other kernels of the N-hop layer (the bank gradient is the step's largest line), each alone on the GPU,
         # HIP events in this run; flops / bytes are the USEFUL ones (backward_algorithmic)
         kernels = [{"kernel": "kc_forward_stream<7, bf16 operands>" if args.variant == "bf16" else "kc_forward_stream<7>", "ms_per_launch": round(ms, 5), "algorithmic_bytes": by, "algorithmic_flops": fl,
                     "hbm_frac": round(gbs / HBM_PEAK_GBS, 5), "fp32_frac": round(fl / (ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 5)}]
+        try:
+            # the 1-hop layer's forward (reference KernelLayer.py:21-37: F = 28, ~19 flop/B by the strict count -- at the fp32
+            # ridge, the one KernelConv forward that HBM could bound): same kernel family, its KC = 2 instantiation
+            layer0 = model.gnn_model.gnn.layers[0]
+            params0, E0 = layer0._bank_params("train", b.x)
+            F0 = int(b.x.shape[1])
+            x0 = torch.zeros(b.x.shape[0], F0 + (-F0) % 4, device=dev)
+            x0[:, :F0] = torch.randn(b.x.shape[0], F0, generator=g, device=dev)
+            x0 = x0[:, :F0]
+            s0 = []
+            if args.variant != "generic":
+                for _ in range(3):
+                    Fn.kernelsetconv_details(x0, plan, False, params0, E0, args.variant, raw=True)
+                lib.mkgnn_debug_time_fused_forward(max(2, args.roofline_reps))
+                for _ in range(9):
+                    Fn.kernelsetconv_details(x0, plan, False, params0, E0, args.variant, raw=True)
+                    s0.append(float(lib.mkgnn_debug_last_fused_forward_ms()))
+                lib.mkgnn_debug_time_fused_forward(0)
+            if s0 and min(s0) > 0:
+                ms0 = sorted(s0)[len(s0) // 2]
+                by0, fl0 = layer_algorithmic(plan, F0, E0, layer0.L, False)
+                t0_, src0 = (committed_traffic(("r05_forward_pmc_1hop.json",)) if args.batch_size == 4096 and args.variant in ("auto", "mfma")
+                             else (None, None))
+                kernels.append({"kernel": "kc_forward_stream<2, bf16 operands>" if args.variant == "bf16" else "kc_forward_stream<2>",
+                                "what": "KernelSetConv forward of the 1-hop layer (F=28, K=110), training configuration",
+                                "ms_per_launch": round(ms0, 5), "algorithmic_bytes": by0, "algorithmic_flops": fl0,
+                                "hbm_frac": round(by0 / (ms0 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                                "fp32_frac": round(fl0 / (ms0 * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 5),
+                                "traffic": t0_, "traffic_source": src0})
+        except Exception as exc:
+            log(f"1-hop forward timing unavailable ({type(exc).__name__}: {exc})")
         try:
             if args.variant in ("auto", "mfma"):
                 bt = time_backward_kernels(lib, Fn, h, plan, params, E, args.variant, max(5, args.roofline_reps // 2))

@@ -7,6 +7,7 @@ import os
 import sys
 
 kernel, out, commit, alg_bytes, root = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), sys.argv[5]
+workload = sys.argv[6] if len(sys.argv) > 6 else "tools/fwd_probe.py (batch 4096 molecules, ~102.5 k atoms, N-hop layer F=110, training configuration)"
 sums, counts, name = {}, {}, None
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(f)):
@@ -22,7 +23,7 @@ hit, miss = avg.get("TCC_HIT_sum"), avg.get("TCC_MISS_sum")
 res = {
     "kernel": name,
     "commit": commit,
-    "workload": "tools/fwd_probe.py (batch 4096 molecules, ~102.5 k atoms, N-hop layer F=110, training configuration)",
+    "workload": workload,
     "collected": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_HIT_sum TCC_MISS_sum, separate passes "
                  f"(tools/pmc.sh), averages over {len(counts['FETCH_SIZE'])} launches",
     "FETCH_SIZE_KB_raw": fetch_kb,

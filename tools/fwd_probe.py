@@ -37,6 +37,9 @@ for _ in range(args.reps):
         Fn.kernelsetconv_details(x, plan, args.last, params, E, args.variant)
 torch.cuda.synchronize()
 print("done", b.x.shape[0], "atoms", [bk.count for bk in plan.buckets])
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import layer_algorithmic                 # noqa: E402
+print("algorithmic_bytes=%d algorithmic_flops=%d" % layer_algorithmic(plan, F, E, layer.L, args.last))
 if not args.backward and args.variant != "generic":
     # the fused forward launch alone: HIP events recorded around it on its own stream (several rounds, sorted)
     import ctypes

@@ -29,10 +29,19 @@ find "$O/prof_b256" -name "*kernel_trace.csv" -delete
 python3 bench.py --variant bf16 --steps 50 --warmup 10 --no-cpu-baseline --fresh-batches 0 > "$O/bench_b4096_bf16.json" 2> "$O/bench_b4096_bf16.err"
 python3 bench.py --assay all9 --variant bf16 --steps 50 --warmup 10 --no-cpu-baseline --fresh-batches 0 > "$O/bench_all9_bf16.json" 2> "$O/bench_all9_bf16.err"
 python3 tools/shard_loader_probe.py --molecules 131072 --workers 2 > "$O/shard_loader.txt" 2>&1 || echo "shard_loader_probe failed" >> "$O/shard_loader.txt"
-# 6. HBM traffic of the forward kernel (separate PMC passes) -> the JSON bench.py reads
-tools/pmc.sh "$tag/pmc_fwd" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" -- tools/fwd_probe.py --reps 6 > "$O/pmc_fwd.txt"
-python3 tools/collect_pmc.py "kc_forward_stream<7>" "$O/forward_pmc.json" "$commit" 98774728 "$O/pmc_fwd" > /dev/null
-rm -rf "$O"/pmc_fwd/pass*/
+# 6. HBM traffic of the forward kernels (separate PMC passes) -> the JSONs bench.py reads: the N-hop layer at batch 4096
+#    (roofline.traffic), the 1-hop layer at batch 4096 (roofline.kernels), the N-hop layer at configs[2]'s batch of 256
+pmc_fwd() {      # <name> <kernel substring> <json> <workload text> <fwd_probe arguments ...>
+    local name="$1" kern="$2" json="$3" what="$4"; shift 4
+    tools/pmc.sh "$tag/$name" "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" -- tools/fwd_probe.py --reps 6 "$@" > "$O/$name.txt"
+    local alg
+    alg=$(python3 tools/fwd_probe.py --reps 1 "$@" 2>/dev/null | grep -o "algorithmic_bytes=[0-9]*" | cut -d= -f2)
+    python3 tools/collect_pmc.py "$kern" "$O/$json" "$commit" "$alg" "$O/$name" "$what" > /dev/null
+    rm -rf "$O/$name"/pass*/
+}
+pmc_fwd pmc_fwd "kc_forward_stream<7" forward_pmc.json "tools/fwd_probe.py (batch 4096 molecules, ~102.5 k atoms, N-hop layer F=110, training configuration)"
+pmc_fwd pmc_fwd_1hop "kc_forward_stream<2" forward_pmc_1hop.json "tools/fwd_probe.py --width 28 (batch 4096 molecules, ~102.5 k atoms, 1-hop layer F=28, training configuration)" --width 28
+pmc_fwd pmc_fwd_b256 "kc_forward_stream<7" forward_pmc_b256.json "tools/fwd_probe.py --batch-size 256 (256 molecules, ~6.4 k atoms, N-hop layer F=110, training configuration: BASELINE configs[2]'s batch)" --batch-size 256
 # 7. pipe utilisation counters of every kernel of a step
 tools/pmc.sh "$tag/pmc_step" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" \
     "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" \

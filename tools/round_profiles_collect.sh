@@ -15,5 +15,7 @@ cp "$O/step_timeline_graph.txt" "${P}_step_timeline_graph.txt"
 cp "$O/step_timeline_fresh.txt" "${P}_step_timeline_fresh_graph.txt"
 cp "$O/step_timeline_435008_b256.txt" "${P}_step_timeline_435008_b256.txt"
 cp "$O/forward_pmc.json" "${P}_forward_pmc.json"
+cp "$O/forward_pmc_1hop.json" "${P}_forward_pmc_1hop.json"
+cp "$O/forward_pmc_b256.json" "${P}_forward_pmc_b256.json"
 grep -v "^W2026\|^E2026" "$O/pmc_step.txt" > "${P}_pmc_step_kernels.txt"
 ls -la profiles | grep "$2"
