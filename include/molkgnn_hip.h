@@ -383,6 +383,22 @@ int mkgnn_rf_fill(const int64_t* edge_index, const float* p, const float* edge_a
  * buckets: only count, selected_index and nei_index are read.  N < 2^28, M < 2^31. */
 size_t mkgnn_plan_workspace_bytes(int64_t n_atoms, int64_t n_edges, int64_t n_rows);
 
+/* Receptive fields AND index plan in one pass (ABI v5): mkgnn_rf_count + mkgnn_rf_fill + mkgnn_plan_build for a caller that knows the
+ * bucket capacities up front (a batch padded to a fixed shape: molkgnn_amd.padding) -- one memset and six kernels instead of
+ * two and nine, no host round trip (capturable).  Inputs as mkgnn_rf_fill; out[d-1].count = rows allocated for degree d, which
+ * must equal the batch's number of atoms of out-degree d: counts[0..3] (device, int64[6]) receive the real numbers, counts[4]
+ * the number of atoms that did not fit (0 for a well-formed call); rows beyond a real size are zero-filled.  Outputs as
+ * mkgnn_rf_fill (the 20 tensors of wrapper.py:559-672 + the unit bond rows) and as mkgnn_plan_build (contribution rows
+ * numbered with the allocated row counts), entry for entry what the separate calls give.  rf_ready_event (a hipEvent_t, may be
+ * NULL) is recorded on the stream where the receptive fields are complete (the plan's two kernels follow): the first
+ * convolution of a step needs only those. */
+size_t mkgnn_index_workspace_bytes(int64_t n_atoms, int64_t n_edges, int64_t n_rows);
+int mkgnn_index_build(const int64_t* edge_index, const float* p, const float* edge_attr, int64_t n_atoms, int64_t n_edges,
+                      int32_t E, const mkgnn_degree_bucket out[MKGNN_MAX_DEGREE],
+                      int32_t* scatter_rowptr, int32_t* scatter_rows, int32_t* in_rowptr, int32_t* in_col,
+                      int32_t* in_col_packed, int32_t* out_rowptr, int32_t* out_col, int8_t* deg8, int64_t* counts,
+                      void* workspace, size_t workspace_bytes, void* rf_ready_event, void* stream);
+
 /* A collated batch from its compact wire form (what a loader sends over PCIe, molkgnn_amd/shards.py) to the tensors the
  * reference's batch object holds (PyG collation, wrapper.py:152-156):
  *   bond_ij   [n_bonds, 2] int32 batch-local atom ids      -> edge_index [2, 2 n_bonds] int64: bond k as the consecutive

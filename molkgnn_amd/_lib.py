@@ -120,7 +120,7 @@ EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn
            "mkgnn_readout_blocks_supported", "mkgnn_readout_blocks_forward", "mkgnn_readout_blocks_backward",
            "mkgnn_readout_blocks_workspace_bytes", "mkgnn_molecule_supported", "mkgnn_molecule_workspace_bytes",
            "mkgnn_molecule_step", "mkgnn_batchnorm_stats_workspace_bytes", "mkgnn_batchnorm_update_stats",
-           "mkgnn_batchnorm_forward_with_stats")
+           "mkgnn_batchnorm_forward_with_stats", "mkgnn_index_workspace_bytes", "mkgnn_index_build")
 
 _lib: Optional[C.CDLL] = None
 TORCH_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libmolkgnn_torch.so")
@@ -248,6 +248,10 @@ def load() -> C.CDLL:
     lib.mkgnn_plan_workspace_bytes.argtypes = [I64, I64, I64]
     lib.mkgnn_plan_build.restype = C.c_int
     lib.mkgnn_plan_build.argtypes = [Buckets4, I64, P, I64, P, P, P, P, P, P, P, P, P, C.c_size_t, P]
+    lib.mkgnn_index_workspace_bytes.restype = C.c_size_t
+    lib.mkgnn_index_workspace_bytes.argtypes = [I64, I64, I64]
+    lib.mkgnn_index_build.restype = C.c_int
+    lib.mkgnn_index_build.argtypes = [P, P, P, I64, I64, I32, Buckets4, P, P, P, P, P, P, P, P, P, P, C.c_size_t, P, P]
     lib.mkgnn_adamw_step.restype = C.c_int
     lib.mkgnn_adamw_state_floats.restype = C.c_int64
     lib.mkgnn_adamw_state_floats.argtypes = [I64]

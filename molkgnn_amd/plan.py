@@ -161,6 +161,28 @@ class BatchPlan:
             self._csr_in_packed = (in_ptr, in_pk[:m])
         return True
 
+    def adopt(self, parts) -> bool:
+        """Take over index structures built elsewhere (``receptive_field.build_index_hip``: the one-pass builder), on the
+        stream that is current now; readers on other streams join through ``_ready`` like after ``build_hip``."""
+        if self.device.type != "cuda" or self._scatter is not None:
+            return self._scatter is not None
+        self._scatter, self._deg8 = parts["scatter"], parts["deg8"]
+        if self.edge_index is not None:
+            self._csr_in, self._csr_out, self._csr_in_packed = parts["csr_in"], parts["csr_out"], parts["csr_in_packed"]
+        self._build_ws = parts.get("keep")
+        cur = torch.cuda.current_stream(self.device)
+        side = index_stream(self.device)
+        if side is not None and cur == side:
+            self._ready = torch.cuda.Event()
+            self._ready.record(side)
+            if not torch.cuda.is_current_stream_capturing():
+                keep = parts.get("keep") or ()
+                for t in (*self._scatter, self._deg8, *(self._csr_in or ()), *(self._csr_out or ()), *(self._csr_in_packed or ()),
+                          *[x for x in keep if torch.is_tensor(x)]):
+                    if t is not None and t.is_cuda:
+                        t.record_stream(side)
+        return True
+
     # -- backward scatter CSR -------------------------------------------------
     @property
     def scatter(self):
@@ -262,7 +284,7 @@ _PLAN_CACHE_MAX = 32
 
 
 def plan_from_lists_cached(n_atoms, p_focal_list, nei_p_list, nei_edge_attr_list, selected_index_list, nei_index_list,
-                           edge_index=None, nei_edge_unit_list=None) -> BatchPlan:
+                           edge_index=None, nei_edge_unit_list=None, prebuilt=None) -> BatchPlan:
     """``plan_from_lists`` memoised on the identity of the index, bond-attribute and coordinate tensors (address,
     length, device, in-place version AND the tensor objects themselves, held weakly).
 
@@ -291,7 +313,9 @@ def plan_from_lists_cached(n_atoms, p_focal_list, nei_p_list, nei_edge_attr_list
                            nei_index_list, edge_index, nei_edge_unit_list)
     # build every index structure now: the lazy properties sort (and synchronise), which must not
     # happen inside a later backward pass or a hipGraph capture
-    if not plan.build_hip():                 # (on the index stream; joined by whoever reads a structure first)
+    if prebuilt is not None and plan.adopt(prebuilt):
+        pass                                 # (receptive_field.build_index_hip made them in the pass that made the buckets)
+    elif not plan.build_hip():               # (on the index stream; joined by whoever reads a structure first)
         _ = plan.scatter
         if edge_index is not None:
             _ = plan.csr_in, plan.csr_out, plan.csr_in_packed

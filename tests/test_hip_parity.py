@@ -1663,3 +1663,66 @@ def test_bench_two_ranks_on_one_card_reports_the_data_parallel_keys(tmp_path):
     assert ar["median"] > 0 and ar["bytes"] > 4 * 120_000
     db = line["dp_buffers"]
     assert db["max_abs_diff_before_sync"] > 0 and db["max_abs_diff"] == 0.0      # the ranks' batches differ; averaged once at the end
+
+
+def test_one_pass_index_builder_matches_the_separate_builders():
+    """mkgnn_index_build (round 5: receptive fields AND index plan from one memset + six kernels) against the definitions:
+    the 20 per-degree tensors + unit bond rows of the torch receptive-field builder (itself pinned to the reference's
+    wrapper.py:559-672 by G10) and the torch plan builder's scatter CSR, propagate CSRs, deg8 and packed columns -- exact
+    equality, on a synthetic batch, with the bonds shuffled, with hub atoms of degree 9 / isolated atoms / an absent degree,
+    and on the reference's own G10 molecules."""
+    from molkgnn_amd import _lib
+    from molkgnn_amd.plan import plan_from_lists
+    from molkgnn_amd.receptive_field import build_index_hip, build_receptive_fields, check_sizes
+    from molkgnn_amd.synthetic import make_batch
+    dev = _dev()
+    b = make_batch(300, seed=4, device=dev, with_receptive_fields=False)
+    cases = [(b.x, b.p, b.edge_index, b.edge_attr)]
+    g = torch.Generator().manual_seed(1)
+    nb = b.edge_index.shape[1] // 2
+    perm = torch.randperm(nb, generator=g).to(dev)
+    eperm = torch.stack([2 * perm, 2 * perm + 1], dim=1).reshape(-1)
+    cases.append((b.x, b.p, b.edge_index[:, eperm].contiguous(), b.edge_attr[eperm].contiguous()))
+    pairs = [(i, 9) for i in range(9)] + [(12, 13), (13, 14)] + [(i, 24) for i in range(15, 24)] + [(24, 25)]
+    ei = torch.tensor([[a, c] for a, c in pairs for (a, c) in ((a, c), (c, a))]).t().contiguous().to(dev)
+    ea = torch.rand(ei.shape[1] // 2, 7, generator=g).repeat_interleave(2, dim=0).to(dev)
+    cases.append((torch.randn(26, 28, device=dev), torch.randn(26, 3, device=dev), ei, ea))
+    big = make_batch(4096, seed=77, device=dev, with_receptive_fields=False)       # many scan blocks (2048 atoms each)
+    cases.append((big.x, big.p, big.edge_index, big.edge_attr))
+    lib = _lib.load()
+    for ci, (x, p, edge_index, edge_attr) in enumerate(cases):
+        f = build_receptive_fields(x, p, edge_index, edge_attr)
+        sizes = [int(f[f"selected_index_deg{d}"].numel()) for d in range(1, 5)]
+        rf, parts = build_index_hip(x, p, edge_index, edge_attr, sizes)
+        check_sizes(rf)
+        assert rf["rf_counts"].tolist()[:5] == sizes + [0]
+        for d in range(1, 5):
+            for nm in ("selected_index", "nei_index", "p_focal", "nei_p", "nei_edge_attr"):
+                got, want = rf[f"{nm}_deg{d}"], f[f"{nm}_deg{d}"]
+                assert got.numel() == want.numel() and torch.equal(got.reshape(-1), want.reshape(-1)), (ci, nm, d)
+            if sizes[d - 1]:
+                unit = torch.empty((sizes[d - 1] * d, 8), dtype=torch.float32, device=dev)
+                raw = f[f"nei_edge_attr_deg{d}"].reshape(-1, 7).contiguous()
+                _lib.check(lib.mkgnn_unit_rows8(raw.data_ptr(), raw.shape[0], 7, unit.data_ptr(), _lib.stream_ptr(dev)), "unit")
+                assert torch.equal(rf[f"nei_edge_unit_deg{d}"], unit), (ci, d)
+        lists = [[f[f"{nm}_deg{d}"] for d in range(1, 5)] for nm in ("p_focal", "nei_p", "nei_edge_attr", "selected_index", "nei_index")]
+        ref = plan_from_lists(x.shape[0], *lists, edge_index)
+        os.environ["MKGNN_TORCH_PLAN"] = "1"
+        try:
+            want = [ref.scatter, ref.deg8, ref.csr_in, ref.csr_out, ref.csr_in_packed]
+        finally:
+            del os.environ["MKGNN_TORCH_PLAN"]
+        got = [parts["scatter"], parts["deg8"], parts["csr_in"], parts["csr_out"], parts["csr_in_packed"]]
+        for gi, (gv, wv) in enumerate(zip(got, want)):
+            if isinstance(gv, tuple):
+                assert torch.equal(gv[0], wv[0]) and torch.equal(gv[1], wv[1]), (ci, gi)
+            else:
+                assert torch.equal(gv, wv), (ci, gi)
+    # capacities that do not match the batch: reported, not silent
+    x, p, edge_index, edge_attr = cases[0]
+    f = build_receptive_fields(x, p, edge_index, edge_attr)
+    sizes = [int(f[f"selected_index_deg{d}"].numel()) for d in range(1, 5)]
+    small = [sizes[0], sizes[1] - 3, sizes[2], sizes[3]]
+    rf, _ = build_index_hip(x, p, edge_index, edge_attr, small)
+    with pytest.raises(ValueError):
+        check_sizes(rf)
