@@ -1726,3 +1726,38 @@ def test_one_pass_index_builder_matches_the_separate_builders():
     rf, _ = build_index_hip(x, p, edge_index, edge_attr, small)
     with pytest.raises(ValueError):
         check_sizes(rf)
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_training_step_with_the_one_pass_index_builder(overlap, monkeypatch):
+    """MKGNN_MERGED_INDEX=1: a padded batch's receptive fields and index plan from mkgnn_index_build (attached to the plan
+    cache, the first convolution waiting on the event recorded inside the call) -- loss and every gradient bit for bit those
+    of the same step with the separate builders."""
+    from molkgnn_amd import padding as P
+    from molkgnn_amd.receptive_field import attach_receptive_fields, check_sizes
+    from molkgnn_amd.synthetic import make_batch
+    from molkgnn_amd.train import GNNModel
+    dev = _dev()
+    torch.manual_seed(21)
+    model = GNNModel(num_layers=3, ffn_dropout_rate=0.0).to(dev).train()
+    raws = [make_batch(200, seed=70 + i, with_receptive_fields=False) for i in range(2)]
+    for i, r in enumerate(raws):
+        r.y = ((torch.arange(200) + i) % 3 == 0).long()
+    shape = P.fixed_shape([P.degree_histogram(r) for r in raws])
+    results = {}
+    for merged in ("0", "1"):
+        monkeypatch.setenv("MKGNN_MERGED_INDEX", merged)
+        out = []
+        for r in raws:
+            pb = P.pad_batch(r, shape, 200).to(dev)
+            attach_receptive_fields(pb, sizes=pb.bucket_sizes, overlap=overlap)
+            model.zero_grad(set_to_none=True)
+            loss = model.loss(pb)
+            loss.backward()
+            torch.cuda.synchronize()
+            check_sizes(pb)
+            out.append((loss.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+        results[merged] = out
+    for (l0, g0), (l1, g1) in zip(results["0"], results["1"]):
+        assert torch.equal(l0, l1)
+        assert g0.keys() == g1.keys() and all(torch.equal(g0[k], g1[k]) for k in g0)

@@ -31,6 +31,11 @@ store[:, :F] = torch.rand(b.x.shape[0], F, device=dev) * 2 - 1
 x = store[:, :F]
 out, saved = Fn.kernelsetconv_details(x, plan, args.last, params, E, "auto")
 torch.cuda.synchronize()
+import ctypes                                       # noqa: E402
+from molkgnn_amd import _lib                        # noqa: E402
+plans = (ctypes.c_int32 * 12)()
+if hasattr(_lib.load(), "mkgnn_debug_last_plans") and _lib.load().mkgnn_debug_last_plans(plans) == 0:
+    print("forward plan: blocks", plans[0], "launches", plans[9])
 out = out.cpu()
 if args.mode == "save":
     torch.save({"out": out, "saved": [None if s[0] is None else s[0].cpu() for s in saved]}, args.file)
