@@ -798,6 +798,9 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
 #ifndef MKGNN_FWD_PP_DEFAULT
 #define MKGNN_FWD_PP_DEFAULT 0
 #endif
+#ifndef MKGNN_PP_OCC4_KC
+#define MKGNN_PP_OCC4_KC 0                               // (experiment: ping-pong bodies up to this chunk count built for 4 waves per SIMD)
+#endif
 #ifndef MKGNN_FWD_PAIR_DEFAULT
 #define MKGNN_FWD_PAIR_DEFAULT 0
 #endif
@@ -824,7 +827,7 @@ __global__ void __launch_bounds__(256, (KC >= 8 ? 1 : MKGNN_EXP_OCC)) kc_forward
 
 // the ping-pong form: 8 waves, one block per CU, 2 waves per SIMD (KC <= 7: the bank leaves room for two waves)
 template <int KC, bool BF = false>
-__global__ void __launch_bounds__(512, 2) kc_forward_pp(FusedFwdArgs a) {
+__global__ void __launch_bounds__(512, (KC <= MKGNN_PP_OCC4_KC ? 4 : 2)) kc_forward_pp(FusedFwdArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int grp = a.blk_group[blockIdx.x];
     const int rank = a.blk_rank[blockIdx.x];
@@ -934,7 +937,9 @@ static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nbloc
     int count[MG], nb = 0;
     for (int g = 0; g < ng; ++g) { count[g] = 1; ++nb; }
     // (a ping-pong block is 8 waves, one per CU: half as many blocks for the same number of waves, run-time caps included)
-    const int max_blocks = pp ? (grid_cap(g_grid_caps.fwd, FUSED_MAX_BLOCKS) + 1) / 2 : grid_cap(g_grid_caps.fwd, FUSED_MAX_BLOCKS);
+    // (... unless the ping-pong body of this chunk count is built for two blocks per CU: MKGNN_PP_OCC4_KC)
+    const int max_blocks = (pp && KC > MKGNN_PP_OCC4_KC) ? (grid_cap(g_grid_caps.fwd, FUSED_MAX_BLOCKS) + 1) / 2
+                                                         : grid_cap(g_grid_caps.fwd, FUSED_MAX_BLOCKS);
     while (nb < max_blocks) {
         int worst = -1;
         double t_worst = -1.0;
