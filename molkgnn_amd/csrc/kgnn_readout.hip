@@ -933,7 +933,16 @@ __global__ void __launch_bounds__(256) bn_side_kernel(BnSide s, int phase) {
 
 __global__ void __launch_bounds__(256) bn_sum_kernel(BnArgs a, int CL) {
     __shared__ float sh[512];
-    if (blockIdx.x >= BN_MAIN_BLOCKS) { bn_side_colsum<0>(a.side, blockIdx.x - BN_MAIN_BLOCKS, sh); return; }
+    if (blockIdx.x >= BN_MAIN_BLOCKS) {
+        bn_side_colsum<0>(a.side, blockIdx.x - BN_MAIN_BLOCKS, sh);
+        if (a.side.nblk == 1) {                          // a companion of one block's worth of rows: all of it here, in this launch
+            __syncthreads();                             // (its own global stores are visible to the block behind a barrier)
+            bn_side_colsum<1>(a.side, 0, sh);
+            __syncthreads();
+            bn_side_final(a.side, sh);
+        }
+        return;
+    }
     bn_block_colsum<0>(a, CL, nullptr, nullptr, sh);
 }
 
@@ -1800,14 +1809,16 @@ int mkgnn_batchnorm_forward_with_stats(const float* x, int64_t x_stride, int64_t
     a.inv_out = inv_norm; a.nbt = num_batches_tracked; a.nvalid = n_valid_rows;
     a.part1 = (float*)ws; a.part2 = a.part1 ? a.part1 + (size_t)BN_BLOCKS * C : nullptr;
     static_assert(BN_BLOCKS == BN_MAIN_BLOCKS, "the companion's blocks sit behind the batch norm's own");
+    bool side_single = false;
     if (companion) {
         if (int rc = bn_side_setup("mkgnn_batchnorm_forward", companion, companion_ws, companion_ws_bytes, a.side)) return rc;
+        if ((int64_t)companion->n_rows * a.side.CL <= 64 * 1024) { a.side.nblk = 1; side_single = true; }
     }
     if (training) {
         bn_sum_kernel<<<BN_BLOCKS + a.side.nblk, 256, 0, st>>>(a, CL);
-        bn_var_kernel<<<BN_BLOCKS + a.side.nblk, 256, 0, st>>>(a, CL);
+        bn_var_kernel<<<BN_BLOCKS + (side_single ? 0 : a.side.nblk), 256, 0, st>>>(a, CL);
     }
-    bn_apply_kernel<<<BN_BLOCKS + (a.side.nblk ? 1 : 0), 256, 0, st>>>(a, CL);
+    bn_apply_kernel<<<BN_BLOCKS + ((a.side.nblk && !side_single) ? 1 : 0), 256, 0, st>>>(a, CL);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : api_hip_fail("mkgnn_batchnorm_forward", e);
 }
