@@ -538,16 +538,33 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
         } else {
         static_for<0, S1>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
-            // ---- multiply slot s: one LDS read per 4 NBS (or 4) matrix instructions, issued one chunk ahead
-            const float* rb = ring + buf * SLOT + lane * 4;
+            // ---- multiply slot s: one LDS read per 4 NBS (or 4) matrix instructions, issued one chunk ahead.  (Written as ordinary
+            // loads the read of chunk t + 1 -- placed ahead of chunk t's matrix instructions, pinned by sched_group_barrier -- is
+            // sunk by the compiler to where its value is first used: the listing shows ds_read_b128, s_waitcnt lgkmcnt(0),
+            // v_mfma ... per chunk.  Round 5 measured the alternative, -DMKGNN_FWD_ASM_READS: inline-asm reads with their own
+            // lgkmcnt waits, truly a chunk ahead -- 255 VGPRs and the same 65.5 us: the other wave of the SIMD covers that
+            // latency.  The ping-pong form, whose multiplying wave has no such partner, keeps the asm reads.)
             prio_multiply();
             if (s < D || !HS || half == 0) {             // (HS: the centre belongs to half 0)
+#ifndef MKGNN_FWD_ASM_READS
+                const float* rb = ring + buf * SLOT + lane * 4;
                 f32x4 nxt = *(const f32x4*)rb;
-#pragma unroll
-                for (int t = 0; t < KC; ++t) {
+#else
+                const uint32_t rba = (uint32_t)(uintptr_t)(ring + buf * SLOT + lane * 4);     // LDS byte address of this lane's 16 bytes of piece 0
+                f32x4 pb[2];
+                lds_read128<0>(pb[0], rba);
+#endif
+                static_for<0, KC>([&](auto tc) {
+                    constexpr int t = decltype(tc)::value;
+#ifndef MKGNN_FWD_ASM_READS
                     f32x4 cur = nxt;
-                    if (t + 1 < KC) nxt = *(const f32x4*)(rb + (t + 1) * 256);
-                    if (t == KC - 1) {                   // only the last chunk of a row can be partial or empty
+                    if constexpr (t + 1 < KC) nxt = *(const f32x4*)(rb + (t + 1) * 256);
+#else
+                    lds_wait0(pb[t & 1]);
+                    if constexpr (t + 1 < KC) lds_read128<(t + 1) * 1024>(pb[(t + 1) & 1], rba);
+                    f32x4 cur = pb[t & 1];
+#endif
+                    if constexpr (t == KC - 1) {         // only the last chunk of a row can be partial or empty
                         const int col = 16 * t + 4 * kq;
                         if (col >= F) cur.x = 0.f;
                         if (col + 1 >= F) cur.y = 0.f;
@@ -573,11 +590,16 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
 #pragma unroll
                             for (int q4 = 0; q4 < 4; ++q4) cc = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[q4], bk[NBS][t][q4], cc, 0, 0, 0);
                         }
+#ifndef MKGNN_FWD_ASM_READS
                         // pin the order: the next chunk's read ahead of this chunk's matrix instructions
                         __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, s < D ? 4 * NBS : 4, 0);
+#endif
                     }
-                }
+#ifdef MKGNN_FWD_ASM_READS
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
+                });
             }
             prio_other();
             MKGNN_PHASE(0);
