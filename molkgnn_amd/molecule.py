@@ -25,7 +25,8 @@ from .plan import BatchPlan
 MAX_ATOMS = _lib.MOLECULE_MAX_ATOMS
 MAX_MOLS = _lib.MOLECULE_MAX_MOLS
 # MKGNN_MOLECULE: unset -- the one-launch TRAINING step where it is the faster one: inside a hipGraph capture up to
-# MKGNN_MOLECULE_AUTO_MOLS (32) molecules, launched eagerly up to MKGNN_MOLECULE_MAX_MOLS (512); '1' -- whenever the model and
+# MKGNN_MOLECULE_AUTO_MOLS (32) molecules, launched eagerly up to MKGNN_MOLECULE_MAX_MOLS (512) on batches that come back
+# (a batch seen for the first time above 32 molecules takes the per-operator kernels: _ready); '1' -- whenever the model and
 # the batch qualify, up to MKGNN_MOLECULE_MAX_MOLS, and MolKGNNNet.forward alone as well; '0' -- never.  Measured on MI355X
 # (round 4).  Replayed graphs: 0.23-0.25 ms per step at 16 molecules against 0.255 per operator, but 0.33 against
 # 0.289 ms at 256 -- a workgroup per molecule is bound by its own fp32 matrix work, and with one chunk per CU the launch lasts
@@ -499,6 +500,18 @@ def _ready(net, data, ffn):
         from .receptive_field import await_receptive_fields
         await_receptive_fields(data)
     plan = _plan_of(data)
+    if _MODE != "1" and n_mols is not None and int(n_mols) > _MAX_MOLS_AUTO and not torch.cuda.is_current_stream_capturing() \
+            and getattr(plan, "_molecule", None) is None:
+        # An eager step above the captured threshold.  On RESIDENT batches the one-launch step is 1.7x the faster eager step
+        # (1.07 against 1.84 ms at 64-256 molecules); on a batch seen for the FIRST time its chunk table has to be built
+        # (sorts over the edge list + one host round trip) and the step is no faster, at 512 molecules slower (4.3 against
+        # 3.1 ms: tools/diag/eager_fresh_probe.py, round 5) -- and a training loop that streams its data sees every batch once.
+        # So: the first sight of a batch goes through the per-operator kernels (which also builds their per-batch caches);
+        # a batch that comes back (same index tensors: the plan cache hits) gets its chunk table then.
+        seen = getattr(plan, "_mol_seen", 0)
+        plan._mol_seen = seen + 1
+        if seen == 0:
+            return None
     mp = molecule_plan(plan, getattr(data, 'batch', None), n_mols)
     if mp is None or not wanted(mp.n_mols):
         return None
