@@ -20,6 +20,8 @@
 #include "kgnn_common.h"
 #include "kgnn_launch.h"
 
+#include <type_traits>
+
 namespace mkgnn {
 
 typedef mkgnn_f32x4 f32x4;
@@ -35,6 +37,7 @@ struct CsrArgs {
     // degree d: columns [off(d), off(d) + len(d)), byte d of the two packed tables (len 0 = no block)
     const int8_t* deg8;                    // BLK == 2: degree of every destination row
     uint64_t blk_off, blk_len;
+    int fixed4;                            // diagnostics (MKGNN_CSR_FIXED4=1): four row loads per group whatever the segments hold
 };
 
 template <int LPR>
@@ -168,29 +171,36 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(CsrArgs a) {
     int j_c = segment(g, lo_c, hi_c, dg_c);
     int mine_c = idx_issue(lo_c, hi_c, lo_c);
     int j_n = segment(g + nwaves, lo_n, hi_n, dg_n);
-    for (; g < ngroups; g += nwaves) {
-        // ---- issue: rows of this group, indices of the next, row pointers of the one after
+    // The loop body for K = 1 .. SEG row loads per group (round 5).  A group used to issue SEG = 4 row loads whatever its rows'
+    // segments held -- 2.1 sources per atom on average in `propagate`, 3.1 roles in the gather -- clamped and masked; these
+    // passes are bound by the address pipe and the VALU, not by bytes, so the loads that fetch nothing cost what
+    // the others cost.  K = the longest segment among the wave's rows (wave-uniform, from the row pointers that arrived a
+    // group ago), every arm a complete body: the loads in flight across the loop's back edge are the same in every arm, so
+    // the compiler's wait counts stay static.  The sums are the same sums (the dropped terms were +0).
+    int mine_n, lo_nn, hi_nn, dg_nn, j_nn;
+    auto body = [&](auto kc) {
+        constexpr int K = decltype(kc)::value;
+        dg_nn = 0;
         int d0 = 0, d1 = 0;                                // BLK == 2: the destination's block
         if constexpr (BLK == 2) block_of(dg_c, d0, d1);
         int rid_c[SEG];
         idx_bcast(mine_c, rid_c);
         f32x4 v[SEG];
 #pragma unroll
-        for (int u = 0; u < SEG; ++u) v[u] = row_load(rid_c[u], d0, d1);
+        for (int u = 0; u < K; ++u) v[u] = row_load(rid_c[u], d0, d1);
         f32x4 xv;
         float iv = 0.f;
         if constexpr (GATHER) {
             xv = *(const f32x4*)(a.x + (uint64_t)(uint32_t)j_c * (uint32_t)a.xs + colc);
             iv = a.inv[j_c];
         }
-        const int mine_n = idx_issue(lo_n, hi_n, lo_n);
-        int lo_nn, hi_nn, dg_nn = 0;
-        const int j_nn = segment(g + 2 * nwaves, lo_nn, hi_nn, dg_nn);
+        mine_n = idx_issue(lo_n, hi_n, lo_n);
+        j_nn = segment(g + 2 * nwaves, lo_nn, hi_nn, dg_nn);
         // ---- consume
         f32x4 acc = row_keep(v[0], rid_c[0], lo_c < hi_c);
 #pragma unroll
-        for (int u = 1; u < SEG; ++u) acc += row_keep(v[u], rid_c[u], lo_c + u < hi_c);
-        if (__any(hi_c - lo_c > SEG)) {                 // long segments: rare (more than four bonds / five roles)
+        for (int u = 1; u < K; ++u) acc += row_keep(v[u], rid_c[u], lo_c + u < hi_c);
+        if (K == SEG && __any(hi_c - lo_c > SEG)) {                 // long segments: rare (more than four bonds / five roles)
             for (int k0 = lo_c + SEG; __any(k0 < hi_c); k0 += SEG) {
                 int rid[SEG];
                 idx_bcast(idx_issue(lo_c, hi_c, k0), rid);
@@ -233,6 +243,16 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(CsrArgs a) {
                 ss = group_sum<LPR>(ss);
                 if (row_ok && l == 0) a.inv_out[j_c] = 1.f / fmaxf(sqrtf(ss), MKGNN_EPS);
             }
+        }
+    };
+    for (; g < ngroups; g += nwaves) {
+        const int len = hi_c - lo_c;
+        const int need = a.fixed4 ? SEG : 1 + (int)__any(len >= 2) + (int)__any(len >= 3) + (int)__any(len >= 4);
+        switch (need) {
+            case 1: body(std::integral_constant<int, 1>{}); break;
+            case 2: body(std::integral_constant<int, 2>{}); break;
+            case 3: body(std::integral_constant<int, 3>{}); break;
+            default: body(std::integral_constant<int, SEG>{}); break;
         }
         // ---- shift the pipeline
         lo_c = lo_n; hi_c = hi_n; j_c = j_n; dg_c = dg_n; mine_c = mine_n;
@@ -287,8 +307,15 @@ bool aligned_rows(const void* p, int64_t stride, int width) {
     return ((uintptr_t)p & 15) == 0 && stride % 4 == 0 && stride >= (width + 3) / 4 * 4;
 }
 
+static int csr_fixed4() {
+    static const int v = [] { const char* e = getenv("MKGNN_CSR_FIXED4"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 template <bool GATHER>
-static hipError_t launch_csr(const CsrArgs& a, hipStream_t st) {
+static hipError_t launch_csr(const CsrArgs& a_in, hipStream_t st) {
+    CsrArgs a = a_in;
+    a.fixed4 = csr_fixed4();
     switch (lanes_per_row(a.width)) {
         case 8: csr_rows_kernel<8, GATHER><<<csr_grid(a.n, 8), 256, 0, st>>>(a); break;
         case 16: csr_rows_kernel<16, GATHER><<<csr_grid(a.n, 4), 256, 0, st>>>(a); break;
@@ -299,7 +326,9 @@ static hipError_t launch_csr(const CsrArgs& a, hipStream_t st) {
 }
 
 template <int BLK>
-static hipError_t launch_csr_blocks(const CsrArgs& a, hipStream_t st) {
+static hipError_t launch_csr_blocks(const CsrArgs& a_in, hipStream_t st) {
+    CsrArgs a = a_in;
+    a.fixed4 = csr_fixed4();
     switch (lanes_per_row(a.width)) {
         case 8: csr_rows_kernel<8, false, BLK><<<csr_grid(a.n, 8), 256, 0, st>>>(a); break;
         case 16: csr_rows_kernel<16, false, BLK><<<csr_grid(a.n, 4), 256, 0, st>>>(a); break;
