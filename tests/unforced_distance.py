@@ -16,7 +16,9 @@ reduced banks, 4 molecules with the full-size seeded model); ``bench`` -- the be
 1798000, bench.py) through the full-size seeded model against the oracle's reference-faithful form with its own argmax
 (oracle/kgnn_oracle.py, pinned to the reference by the golden files).
 
-    python tools/unforced_distance.py [g3 g7 bench] [--molecules 4096]
+    python -m tests.unforced_distance [g3 g7 bench] [--molecules 4096]
+
+Test infrastructure (it runs the oracle): lives under tests/, imported by tests/test_scale_parity.py.
 """
 import argparse
 import os
@@ -25,7 +27,7 @@ import sys
 import numpy as np
 import torch
 
-REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))      # tests/ -> the repository root
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
