@@ -255,7 +255,19 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
     const int64_t sg = ((int64_t)rank * NSIDE + side) * NSTREAM + stream;
     const int64_t tile_first = sg * ntiles / nstreams;
     const int64_t tile_end = (sg + 1) * ntiles / nstreams;
-    const int64_t iters = (ntiles + nstreams - 1) / nstreams;
+    // iterations of this BLOCK: the most tiles any of its streams owns (its waves meet at the same barriers; a stream with one
+    // tile fewer repeats its last one, results discarded).  Until round 5 every block of a group ran the group's maximum:
+    // at batch 4096 the degree-2 group ran 3 150 tile slots for 2 875 tiles.
+    int64_t iters = 0;
+    {
+        const int64_t sg0 = (int64_t)rank * NSIDE * NSTREAM;
+#pragma unroll
+        for (int q = 0; q < NSIDE * NSTREAM; ++q) {
+            const int64_t c = (sg0 + q + 1) * ntiles / nstreams - (sg0 + q) * ntiles / nstreams;
+            iters = c > iters ? c : iters;
+        }
+        if (iters < 1) iters = 1;
+    }
     const int64_t tile_hi = (tile_end > tile_first ? tile_end : (tile_first + 1 < ntiles ? tile_first + 1 : ntiles)) - 1;
     auto tile_at = [&](int64_t i) -> int64_t {           // clamped: a stream short of tiles repeats its last one
         const int64_t t = tile_first + i;
