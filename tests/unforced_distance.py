@@ -128,7 +128,8 @@ def measure(case: str, molecules: int = 4096):
         b = make_batch(molecules, seed=1798000)
         b.num_graphs = molecules
         coll = []
-        torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+        from bench import host_cores                     # (the cgroup's quota, not the affinity mask: 16 of the box's cores)
+        torch.set_num_threads(host_cores())
         with torch.no_grad():
             ref_emb = O.molkgnnnet(state, b, 3, training_bn=False, form="faithful", collect=coll)
         ref_layers = [(s.detach(), h.detach()) for s, h in coll]
