@@ -542,6 +542,11 @@ typedef struct mkgnn_molecule_net {
     int32_t reserved2;
     int64_t* rng_state;                              /* {seed, offset} of the head's dropout (offset advanced by the call) */
     int64_t* rng_used;                               /* optional: the {seed, offset} this call's mask was drawn with */
+    /* edge_batch_norm's side effect (MolKGNNNet.py:116; ABI v5): when not NULL
+     * (the caller leaves it NULL on a backward-only call), the bond rows' statistics -- 1..8192 rows, C <= 8; anything else
+     * is an error: use mkgnn_batchnorm_update_stats -- are taken by one extra block of the preparation launch and the
+     * module's buffers updated as mkgnn_batchnorm_update_stats would */
+    const mkgnn_bn_stats* edge_stats;
 } mkgnn_molecule_net;
 
 typedef struct mkgnn_molecule_batch {

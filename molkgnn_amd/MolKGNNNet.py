@@ -88,10 +88,7 @@ class MolKGNNNet(torch.nn.Module):
         if data.x.is_cuda and not save_score:
             from . import molecule as _mol
             emb = _mol.net_forward(self, data)
-            if emb is not None:
-                es = self._edge_stats(data)
-                if es is not None:
-                    R.update_running_stats(*es)
+            if emb is not None:                          # (edge_batch_norm's statistics moved inside: molecule.net_forward)
                 return emb
         # (a batch padded to a fixed shape -- molkgnn_amd.padding -- carries its real atom count and its molecule segments)
         # edge_batch_norm(data.edge_attr) (reference MolKGNNNet.py:116): its output never reaches the kernel convolution

@@ -82,6 +82,13 @@ class MoleculeLayer(C.Structure):
                 ("sim_out", C.c_void_p), ("sim_stride", C.c_int64)]
 
 
+class BnStats(C.Structure):
+    """``mkgnn_bn_stats``: the statistics-only companion of a batch norm (reference MolKGNNNet.py:116)."""
+    _fields_ = [("x", C.c_void_p), ("x_stride", C.c_int64), ("n_rows", C.c_int64), ("C", C.c_int32),
+                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("momentum", C.c_float),
+                ("num_batches_tracked", C.c_void_p), ("row_key", C.c_void_p), ("key_limit", C.c_void_p)]
+
+
 class MoleculeNet(C.Structure):
     _fields_ = [("num_layers", C.c_int32), ("E", C.c_int32), ("layer", MoleculeLayer * MOLECULE_MAX_LAYERS),
                 ("bn_weight", C.c_void_p), ("bn_bias", C.c_void_p), ("bn_running_mean", C.c_void_p),
@@ -93,20 +100,13 @@ class MoleculeNet(C.Structure):
                 ("grad_lin2_bias", C.c_void_p),
                 ("ffn_weight", C.c_void_p), ("ffn_bias", C.c_void_p), ("grad_ffn_weight", C.c_void_p),
                 ("grad_ffn_bias", C.c_void_p), ("head_dropout", C.c_float), ("reserved2", C.c_int32),
-                ("rng_state", C.c_void_p), ("rng_used", C.c_void_p)]
+                ("rng_state", C.c_void_p), ("rng_used", C.c_void_p), ("edge_stats", C.POINTER(BnStats))]
 
 
 class MoleculeBatch(C.Structure):
     _fields_ = [("n_atoms", C.c_int64), ("n_mols", C.c_int64), ("n_chunks", C.c_int64), ("max_chunk_atoms", C.c_int64),
                 ("chunk_mol_ptr", C.c_void_p), ("mol_atom_ptr", C.c_void_p), ("atom_degree", C.c_void_p),
                 ("atom_rank", C.c_void_p), ("buckets", Buckets4), ("x", C.c_void_p), ("x_stride", C.c_int64)]
-
-
-class BnStats(C.Structure):
-    """``mkgnn_bn_stats``: the statistics-only companion of a batch norm (reference MolKGNNNet.py:116)."""
-    _fields_ = [("x", C.c_void_p), ("x_stride", C.c_int64), ("n_rows", C.c_int64), ("C", C.c_int32),
-                ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("momentum", C.c_float),
-                ("num_batches_tracked", C.c_void_p), ("row_key", C.c_void_p), ("key_limit", C.c_void_p)]
 
 
 EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn_unit_rows8", "mkgnn_workspace_bytes",

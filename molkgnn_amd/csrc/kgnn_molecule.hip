@@ -90,7 +90,10 @@ struct PrepArgsMol {
     const float* w1; int H, HP, K3; float *w1p, *w1pt;
     // batch-norm partial statistics (blocks behind the task blocks)
     int task_blocks; const float* x; int64_t xs; int64_t n; int C; float* bn_part; int bn_nblk;
+    // edge_batch_norm's statistics (mkgnn_molecule_net.edge_stats): ONE more block, es_block (-1: none)
+    int es_block; mkgnn_bn_stats es;
 };
+constexpr int64_t MOL_EDGE_STATS_ROWS = 8192;     // bond rows one block takes in the preparation launch (above: the caller's own launch)
 
 // -------------------------------------------------------------------------------------------- preparation ----
 __device__ __forceinline__ void prep_unit_row(const float* src, int width, int lane, float& m0, float& m1, float& iv) {
@@ -102,7 +105,52 @@ __device__ __forceinline__ void prep_unit_row(const float* src, int width, int l
     iv = 1.f / fmaxf(sqrtf(s), MKGNN_EPS);
 }
 
+// column totals over the block's 32 row lanes (thread t: column t & 7, row lane t >> 3) -> res[0..7], in a fixed order
+__device__ __forceinline__ void prep_col8_total(float v, float* sh, float* res) {
+    const int t = threadIdx.x;
+    __syncthreads();
+    sh[t] = v;
+    __syncthreads();
+    if (t < 8) {
+        float tot = 0.f;
+        for (int k = 0; k < 32; ++k) tot += sh[k * 8 + t];
+        res[t] = tot;
+    }
+    __syncthreads();
+}
+
+// What BatchNorm1d's training-mode call does to the module's buffers, for the bond rows (reference MolKGNNNet.py:116; the
+// normalised rows themselves are never read): mean and centred squares in two passes over rows that stay in
+// cache, then running_mean / running_var / num_batches_tracked as mkgnn_batchnorm_update_stats moves them.
+__device__ __forceinline__ void prep_edge_stats(const mkgnn_bn_stats& e) {
+    __shared__ float sh[256], tot[8], sq[8], cn[8];
+    const int t = threadIdx.x, c = t & 7, rs = t >> 3;
+    const int cc = c < e.C ? c : 0;
+    const int64_t lim = e.row_key ? e.key_limit[0] : 0;
+    float s = 0.f, n = 0.f;
+    for (int64_t r = rs; r < e.n_rows; r += 32)
+        if (!e.row_key || e.row_key[r] < lim) { s += e.x[r * e.x_stride + cc]; n += 1.f; }
+    prep_col8_total(s, sh, tot);
+    prep_col8_total(n, sh, cn);
+    const float cnt = cn[0];
+    const float mu = cnt > 0.f ? tot[c] / cnt : 0.f;
+    float m2 = 0.f;
+    for (int64_t r = rs; r < e.n_rows; r += 32)
+        if (!e.row_key || e.row_key[r] < lim) { const float d = e.x[r * e.x_stride + cc] - mu; m2 = fmaf(d, d, m2); }
+    prep_col8_total(m2, sh, sq);
+    if (t < e.C && cnt > 0.f) {
+        const float var = sq[t] / cnt;
+        if (e.running_mean) e.running_mean[t] = fmaf(e.momentum, mu - e.running_mean[t], e.running_mean[t]);
+        if (e.running_var) {
+            const float unbiased = cnt > 1.f ? var * (cnt / (cnt - 1.f)) : var;
+            e.running_var[t] = fmaf(e.momentum, unbiased - e.running_var[t], e.running_var[t]);
+        }
+    }
+    if (t == 0 && e.num_batches_tracked) e.num_batches_tracked[0] += 1;
+}
+
 __global__ void __launch_bounds__(256) molecule_prepare_kernel(PrepArgsMol a) {
+    if ((int)blockIdx.x == a.es_block) { prep_edge_stats(a.es); return; }
     if ((int)blockIdx.x >= a.task_blocks) {
         // ---- partial batch-norm statistics of block b: column sums and centred squares of its rows (two passes over
         // rows that stay in cache); combined in a fixed order by every workgroup of the step kernel
@@ -1592,7 +1640,17 @@ int mkgnn_molecule_step(const mkgnn_molecule_net* net, const mkgnn_molecule_batc
     pa.bn_part = (float*)(ws + w.bn_part);
     pa.bn_nblk = (int)((batch->n_atoms + 255) / 256 < MOL_BN_BLOCKS ? (batch->n_atoms + 255) / 256 : MOL_BN_BLOCKS);
     if (!net->readout.lin1_weight || !net->readout.lin2_weight) return api_fail("%s: readout weights are null", who);
-    molecule_prepare_kernel<<<pa.task_blocks + (net->bn_training ? pa.bn_nblk : 0), 256, 0, st>>>(pa);
+    int prep_blocks = pa.task_blocks + (net->bn_training ? pa.bn_nblk : 0);
+    pa.es_block = -1;
+    if (net->edge_stats) {
+        const mkgnn_bn_stats& e = *net->edge_stats;
+        if (!e.x || e.n_rows < 1 || e.n_rows > MOL_EDGE_STATS_ROWS || e.C < 1 || e.C > 8 || e.x_stride < e.C || (e.row_key != nullptr) != (e.key_limit != nullptr))
+            return api_fail("%s: edge_stats outside what the preparation launch takes (1..%lld rows, C <= 8, row_key and key_limit together): "
+                            "use mkgnn_batchnorm_update_stats", who, (long long)MOL_EDGE_STATS_ROWS);
+        pa.es = e;
+        pa.es_block = prep_blocks++;
+    }
+    molecule_prepare_kernel<<<prep_blocks, 256, 0, st>>>(pa);
 
     // ---- the step
     MolArgs a{};

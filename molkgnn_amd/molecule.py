@@ -219,8 +219,21 @@ def wanted(n_mols: int) -> bool:
     return n_mols <= _MAX_MOLS_AUTO
 
 
-def _net_struct(net, ffn, params, grads, saved, sims, head_dropout, update_running, rng=None, rng_used=None):
-    """``mkgnn_molecule_net`` for the model; ``grads`` / ``saved`` / ``sims``: lists parallel to the layers (or None)."""
+_EDGE_STATS_ROWS = 8192          # bond rows the preparation launch's extra block takes (kgnn_molecule.hip MOL_EDGE_STATS_ROWS)
+
+
+def _edge_stats_in_launch(es) -> bool:
+    """Whether ``edge_batch_norm``'s statistics (``MolKGNNNet._edge_stats``) ride in the step's preparation launch."""
+    if es is None:
+        return False
+    ea, bn = es[0], es[1]
+    return (ea.is_cuda and ea.dim() == 2 and 1 <= ea.shape[0] <= _EDGE_STATS_ROWS and 1 <= ea.shape[1] <= 8
+            and bn.momentum is not None and bn.running_mean is not None and bn.running_mean.dtype == torch.float32)
+
+
+def _net_struct(net, ffn, params, grads, saved, sims, head_dropout, update_running, rng=None, rng_used=None, edge_stats=None):
+    """``mkgnn_molecule_net`` for the model; ``grads`` / ``saved`` / ``sims``: lists parallel to the layers (or None);
+    ``edge_stats``: ``MolKGNNNet._edge_stats(data)`` where ``_edge_stats_in_launch`` holds."""
     st = _lib.MoleculeNet()
     layers = net.gnn.layers
     st.num_layers = len(layers)
@@ -273,6 +286,11 @@ def _net_struct(net, ffn, params, grads, saved, sims, head_dropout, update_runni
         st.ffn_weight, st.ffn_bias = _lib.ptr(params[k + 6]), _lib.ptr(params[k + 7])
         st.head_dropout = float(head_dropout)
         st.rng_state, st.rng_used = _lib.ptr(rng), _lib.ptr(rng_used)
+    if edge_stats is not None and update_running:
+        from .readout import _bn_stats_struct
+        es, es_keep = _bn_stats_struct(*edge_stats)
+        st.edge_stats = C.pointer(es)
+        keep.append((es, es_keep))
     return st, keep
 
 
@@ -367,7 +385,7 @@ def _alloc_state(net, plan: BatchPlan, params, want_grads: bool, want_sims: bool
     return saved, grads, sims
 
 
-def _run(net, ffn, params, plan, mp, x, mode, target, grad_emb, head_dropout, update_running):
+def _run(net, ffn, params, plan, mp, x, mode, target, grad_emb, head_dropout, update_running, edge_stats=None):
     lib = _lib.load()
     dev = x.device
     want_grads = bool(mode & _lib.MOLECULE_BACKWARD)
@@ -387,7 +405,7 @@ def _run(net, ffn, params, plan, mp, x, mode, target, grad_emb, head_dropout, up
         rng = head_rng_state(dev)
         used = torch.empty(2, dtype=torch.int64, device=dev)
     st, keep = _net_struct(net, ffn, params, grads if want_grads else None, saved, sims if cap is not None else None,
-                           head_dropout, update_running, rng, used)
+                           head_dropout, update_running, rng, used, edge_stats)
     if want_grads:
         st.grad_bn_weight, st.grad_bn_bias = _lib.ptr(small["bn_w"]), _lib.ptr(small["bn_b"])
         st.grad_lin1_weight, st.grad_lin1_bias = _lib.ptr(small["w1"]), _lib.ptr(small["b1"])
@@ -439,9 +457,9 @@ class _MoleculeNetFn(torch.autograd.Function):
     launch that runs the backward (nothing but the parameters is kept)."""
 
     @staticmethod
-    def forward(ctx, net, plan, mp, x, *params):
+    def forward(ctx, net, plan, mp, es, x, *params):
         params = list(params)
-        emb, _, _, _ = _run(net, None, params, plan, mp, x, 0, None, None, 0.0, True)
+        emb, _, _, _ = _run(net, None, params, plan, mp, x, 0, None, None, 0.0, True, es)
         ctx.net, ctx.plan, ctx.mp, ctx.x, ctx.params = net, plan, mp, x, params
         return emb
 
@@ -450,7 +468,7 @@ class _MoleculeNetFn(torch.autograd.Function):
         g = grad_emb.contiguous().float()
         _, _, _, flat = _run(ctx.net, None, ctx.params, ctx.plan, ctx.mp, ctx.x,
                              _lib.MOLECULE_BACKWARD | _lib.MOLECULE_GRAD_EMB, None, g, 0.0, False)
-        return (None, None, None, None) + tuple(_shape_like(gr, p) if p is not None else None for gr, p in zip(flat, ctx.params))
+        return (None, None, None, None, None) + tuple(_shape_like(gr, p) if p is not None else None for gr, p in zip(flat, ctx.params))
 
 
 class _MoleculeLossFn(torch.autograd.Function):
@@ -458,11 +476,11 @@ class _MoleculeLossFn(torch.autograd.Function):
     the same launch (d loss = 1; any other incoming gradient scales the stored ones)."""
 
     @staticmethod
-    def forward(ctx, net, ffn, p_drop, target, plan, mp, x, *params):
+    def forward(ctx, net, ffn, p_drop, target, plan, mp, es, x, *params):
         params = list(params)
-        need = any(ctx.needs_input_grad[7:])
+        need = any(ctx.needs_input_grad[8:])
         mode = _lib.MOLECULE_HEAD | (_lib.MOLECULE_BACKWARD if need else 0)
-        _, pred, loss, flat = _run(net, ffn, params, plan, mp, x, mode, target.reshape(-1).float().contiguous(), None, p_drop, True)
+        _, pred, loss, flat = _run(net, ffn, params, plan, mp, x, mode, target.reshape(-1).float().contiguous(), None, p_drop, True, es)
         ctx.flat, ctx.params = flat, params
         ctx.pred = pred
         return loss
@@ -476,7 +494,7 @@ class _MoleculeLossFn(torch.autograd.Function):
         if not _is_unit_seed(grad_loss):
             gl = grad_loss.reshape(()).float()
             flat = [None if g is None else g * gl for g in flat]
-        return (None,) * 7 + tuple(_shape_like(g, p) if p is not None else None for g, p in zip(flat, ctx.params))
+        return (None,) * 8 + tuple(_shape_like(g, p) if p is not None else None for g, p in zip(flat, ctx.params))
 
 
 def _plan_of(data) -> BatchPlan:
@@ -542,7 +560,12 @@ def net_forward(net, data) -> Optional[torch.Tensor]:
     if r is None:
         return None
     plan, mp, params = r
-    return _MoleculeNetFn.apply(net, plan, mp, data.x, *params)
+    es = net._edge_stats(data) if hasattr(net, '_edge_stats') else None
+    if es is not None and not _edge_stats_in_launch(es):
+        from .readout import update_running_stats
+        update_running_stats(*es)
+        es = None
+    return _MoleculeNetFn.apply(net, plan, mp, es, data.x, *params)
 
 
 def loss_forward(model, data, p_drop: float) -> Optional[torch.Tensor]:
@@ -553,7 +576,10 @@ def loss_forward(model, data, p_drop: float) -> Optional[torch.Tensor]:
         return None
     plan, mp, params = r
     es = net._edge_stats(data) if hasattr(net, '_edge_stats') else None
-    if es is not None:                                   # edge_batch_norm's side effect (reference MolKGNNNet.py:116): one small launch
+    # edge_batch_norm's side effect (reference MolKGNNNet.py:116): one more block of the step's preparation launch, or -- more
+    # bond rows than one block takes -- a small launch of its own
+    if es is not None and not _edge_stats_in_launch(es):
         from .readout import update_running_stats
         update_running_stats(*es)
-    return _MoleculeLossFn.apply(net, ffn, float(p_drop), data.y, plan, mp, data.x, *params)
+        es = None
+    return _MoleculeLossFn.apply(net, ffn, float(p_drop), data.y, plan, mp, es, data.x, *params)
