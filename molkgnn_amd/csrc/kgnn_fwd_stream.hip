@@ -135,6 +135,11 @@ template <int OFFB> __device__ __forceinline__ void lds_read128(f32x4& dst, uint
     static_assert(OFFB >= 0 && OFFB < 65536 && OFFB % 16 == 0, "ds_read_b128 offset: 16 bits, 16-byte aligned");
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFFB));
 }
+template <int OFFB> __device__ __forceinline__ void lds_read32(float& dst, uint32_t addr) {
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFFB) : "memory");
+}
+__device__ __forceinline__ void lds_wait0(float& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a) : : "memory"); }
+__device__ __forceinline__ void lds_after_wait(float& a) { asm volatile("" : "+v"(a) : : "memory"); }      // (a value read before an lds_wait0 of another)
 __device__ __forceinline__ void lds_wait0(f32x4& a) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a)); }
 __device__ __forceinline__ void lds_wait0(f32x4& a, f32x4& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b)); }
 
@@ -205,6 +210,52 @@ __device__ __forceinline__ s16x4s to_bf16x4s(f32x4 v) {
     return __builtin_bit_cast(s16x4s, r);
 }
 
+// BF = 2 (round 5): fp32 products out of fp16 matrix instructions.  A float is split exactly into hi = fp16(x), lo = fp16(x - hi)
+// (two roundings to nearest: |x - hi - lo| <= 2^-24 |x| as long as lo stays a normal fp16 number); a product x y is then
+// hi hi' + hi lo' + lo hi' (the dropped lo lo' <= 2^-24 |x y|): three v_mfma_f32_16x16x16_f16 of 8 cycles in place of four
+// v_mfma_f32_16x16x4_f32 of 32, fp32 accumulation as before.  The error per product is that of ONE fp32 rounding -- measured
+// against float64 the sums are as close as the fp32 fma chain's (tests/test_scale_parity.py) -- provided nothing under- or
+// overflows in fp16: bank rows are unit rows, scaled by 2^8 before the split; an atom's row (a lane's A operand belongs to
+// ONE atom: lane & 15) is scaled by 2^(exponent(1 / |x|) + 8), i.e. to a norm in [256, 512), and the two powers of two
+// leave through the 1 / |x| factor the epilogue multiplies with anyway (exponent field set to -16: exact).
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+struct SplitReg { h16x4 hi, lo; };
+__device__ __forceinline__ SplitReg split_f16(f32x4 v) {
+    SplitReg r;
+    r.hi = h16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    r.lo = h16x4{(_Float16)(v[0] - (float)r.hi[0]), (_Float16)(v[1] - (float)r.hi[1]), (_Float16)(v[2] - (float)r.hi[2]), (_Float16)(v[3] - (float)r.hi[3])};
+    return r;
+}
+// the split of v * s (s a power of two) in eight instructions: v_fma_mix{lo,hi}_f16 take fp32 (or fp16) sources, compute the fma
+// in fp32 and round ONCE to the fp16 half of the destination -- hi = fp16(v s + 0), lo = fp16(v s - hi) (the fp32 fma result is
+// exact).  Left to the compiler (split_f16 of a product) the same thing is 17 instructions per chunk, and on this chip
+// vector instructions do not hide behind the other wave's matrix instructions.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ SplitReg split_scaled(f32x4 v, float s) {
+    uint32_t h0, h1, l0, l1;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h0) : "v"(v[0]), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h0) : "v"(v[1]), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h1) : "v"(v[2]), "v"(s));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h1) : "v"(v[3]), "v"(s));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(v[0]), "v"(s), "v"(h0));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l0) : "v"(v[1]), "v"(s), "v"(h0));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(v[2]), "v"(s), "v"(h1));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l1) : "v"(v[3]), "v"(s), "v"(h1));
+    SplitReg r;
+    r.hi = __builtin_bit_cast(h16x4, u32x2{h0, h1});
+    r.lo = __builtin_bit_cast(h16x4, u32x2{l0, l1});
+    return r;
+}
+constexpr int SPLIT_BANK_EXP = 8, SPLIT_ROW_EXP = 8;
+// 2^(exponent(inv) + SPLIT_ROW_EXP): the scale of an atom's row (inv = 1 / max(|x|, eps) <= 1e8: no overflow)
+__device__ __forceinline__ float split_row_scale(float inv) {
+    return __uint_as_float((__float_as_uint(inv) & 0x7f800000u) + ((uint32_t)SPLIT_ROW_EXP << 23));
+}
+// inv / (row scale * bank scale): inv's mantissa with the exponent -(SPLIT_ROW_EXP + SPLIT_BANK_EXP)
+__device__ __forceinline__ float split_inv(float inv) {
+    return __uint_as_float((__float_as_uint(inv) & 0x007fffffu) | ((uint32_t)(127 - SPLIT_ROW_EXP - SPLIT_BANK_EXP) << 23));
+}
+
 // PP = true (round 5, "ping-pong"): 8-wave blocks, one per CU.  Waves 0-3 ("side 0") and 4-7 ("side 1") are two teams of the
 // 4-wave kind above, each on its own tiles; wave w and wave w + 4 share a SIMD.  Measured with ONE wave per SIMD
 // (tools/stream_stamps.py --blocks 256) a tile costs a degree-3 wave 10.4 k cycles of products and 7.2 k of everything else
@@ -216,7 +267,7 @@ __device__ __forceinline__ s16x4s to_bf16x4s(f32x4 v) {
 // and side 1 runs one phase behind side 0, so on every SIMD one wave multiplies while its partner issues, scans and stores.
 // No counted vmcnt any more (every DMA of a tile lands before the phase that reads it begins).  Degree 4 (two waves per
 // column tile swap halves through LDS in the epilogue, with a barrier): every phase has a second barrier in its middle.
-template <int D, int KC, bool BF = false, bool PP = false>
+template <int D, int KC, int BF = 0, bool PP = false>
 __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDeg& dg, const int cp, const int rank, const int count, float* lds) {
     using T = StreamTraits<D>;
     constexpr int NS = T::NS, NSTREAM = T::NSTREAM, RING = T::RING, S1 = T::S1, META = T::META;
@@ -250,48 +301,52 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
     float* const xbuf = lds + (size_t)NSIDE * SIDE_FLOATS + 192;      // (HS only) [wave of the block][18][64]
 
     // ---- tiles of this stream: a contiguous run; every block of the group runs the same number of iterations
-    const int64_t ntiles = (dg.n + 15) / 16;
-    const int64_t nstreams = (int64_t)count * NSTREAM * NSIDE;
-    const int64_t sg = ((int64_t)rank * NSIDE + side) * NSTREAM + stream;
-    const int64_t tile_first = sg * ntiles / nstreams;
-    const int64_t tile_end = (sg + 1) * ntiles / nstreams;
+    // (32-bit from here on: the host admits n_atoms * stride < 2^30 only, and wave-uniform 64-bit values are what this kernel's
+    // scalar registers spill on)
+    const int dn = (int)dg.n;
+    const int ntiles = (dn + 15) / 16;
+    const int nstreams = count * NSTREAM * NSIDE;
+    const int sg = (rank * NSIDE + side) * NSTREAM + stream;
+    auto run_start = [&](int g) -> int { return (int)((uint64_t)(uint32_t)g * (uint32_t)ntiles / (uint32_t)nstreams); };    // < 2^11 streams x < 2^26 tiles
+    const int tile_first = run_start(sg);
+    const int tile_end = run_start(sg + 1);
     // iterations of this BLOCK: the most tiles any of its streams owns (its waves meet at the same barriers; a stream with one
     // tile fewer repeats its last one, results discarded).  Until round 5 every block of a group ran the group's maximum:
     // at batch 4096 the degree-2 group ran 3 150 tile slots for 2 875 tiles.
-    int64_t iters = 0;
+    int iters = 0;
     {
-        const int64_t sg0 = (int64_t)rank * NSIDE * NSTREAM;
+        const int sg0 = rank * NSIDE * NSTREAM;
 #pragma unroll
         for (int q = 0; q < NSIDE * NSTREAM; ++q) {
-            const int64_t c = (sg0 + q + 1) * ntiles / nstreams - (sg0 + q) * ntiles / nstreams;
+            const int c = run_start(sg0 + q + 1) - run_start(sg0 + q);
             iters = c > iters ? c : iters;
         }
         if (iters < 1) iters = 1;
     }
-    const int64_t tile_hi = (tile_end > tile_first ? tile_end : (tile_first + 1 < ntiles ? tile_first + 1 : ntiles)) - 1;
-    auto tile_at = [&](int64_t i) -> int64_t {           // clamped: a stream short of tiles repeats its last one
-        const int64_t t = tile_first + i;
+    const int tile_hi = (tile_end > tile_first ? tile_end : (tile_first + 1 < ntiles ? tile_first + 1 : ntiles)) - 1;
+    auto tile_at = [&](int i) -> int {                   // clamped: a stream short of tiles repeats its last one
+        const int t = tile_first + i;
         return t > tile_hi ? tile_hi : t;
     };
 
     // PP: the team on the other side of the block (same stream, same role: its waves are this team's SIMD partners)
     [[maybe_unused]] float* const pring = lds + (size_t)(PP ? 1 - side : 0) * SIDE_FLOATS + (size_t)stream * (RING * SLOT + 2 * META);
     [[maybe_unused]] float* const pmeta = pring + RING * SLOT;
-    const int64_t psg = ((int64_t)rank * NSIDE + (PP ? 1 - side : 0)) * NSTREAM + stream;
-    const int64_t ptile_first = psg * ntiles / nstreams, ptile_end = (psg + 1) * ntiles / nstreams;
-    const int64_t ptile_hi = (ptile_end > ptile_first ? ptile_end : (ptile_first + 1 < ntiles ? ptile_first + 1 : ntiles)) - 1;
-    [[maybe_unused]] auto ptile_at = [&](int64_t i) -> int64_t {
-        const int64_t t = ptile_first + i;
+    const int psg = (rank * NSIDE + (PP ? 1 - side : 0)) * NSTREAM + stream;
+    const int ptile_first = run_start(psg), ptile_end = run_start(psg + 1);
+    const int ptile_hi = (ptile_end > ptile_first ? ptile_end : (ptile_first + 1 < ntiles ? ptile_first + 1 : ntiles)) - 1;
+    [[maybe_unused]] auto ptile_at = [&](int i) -> int {
+        const int t = ptile_first + i;
         return t > ptile_hi ? ptile_hi : t;
     };
 
     // (tile 0's ids first: their DMA flies while the bank is loaded -- one dependent round trip less in front of the first
     // tile, which is all a stream has at small batches)
     if (role == 0) {
-        int64_t n0 = tile_at(0) * 16 + (lane & 15);
-        if (n0 >= dg.n) n0 = dg.n - 1;
+        int n0 = tile_at(0) * 16 + (lane & 15);
+        if (n0 >= dn) n0 = dn - 1;
         const int kq0 = lane >> 4;
-        const void* src0 = (kq0 < D) ? (const void*)(dg.nei + n0 * D + kq0) : (const void*)(dg.sel + n0);
+        const void* src0 = (kq0 < D) ? (const void*)(dg.nei + ((uint32_t)n0 * D + kq0)) : (const void*)(dg.sel + n0);
         float* const meta0 = meta;
         if (S1 >= 4 || kq0 < S1) dma4<SITE_IDS>(src0, meta0);
         if constexpr (S1 == 5) {
@@ -299,7 +354,8 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
         }
     }
     // ---- one-time: this wave's share of the bank -> registers (unit rows, zero beyond F; idle columns all zero)
-    using BankReg = std::conditional_t<BF, s16x4s, f32x4>;
+    static_assert(BF == 0 || BF == 1 || (BF == 2 && !PP), "BF: 0 fp32, 1 bf16 similarity, 2 fp32 out of split fp16 (4-wave blocks)");
+    using BankReg = std::conditional_t<BF == 2, SplitReg, std::conditional_t<BF == 1, s16x4s, f32x4>>;
     BankReg bk[NB][KC];
     float2 bv[D];
     {
@@ -313,7 +369,8 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
             for (int t = 0; t < KC; ++t) {
                 f32x4 v = *(const f32x4*)(dg.padded + ((size_t)b * L + l) * FPB + 16 * t + 4 * kq);
                 if (zero) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (BF) bk[bl][t] = to_bf16x4s(v);
+                if constexpr (BF == 2) bk[bl][t] = split_f16(v * (float)(1 << SPLIT_BANK_EXP));
+                else if constexpr (BF == 1) bk[bl][t] = to_bf16x4s(v);
                 else bk[bl][t] = v;
             }
         }
@@ -354,24 +411,24 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
         });
     };
     // unit bond rows of slot sd (mkgnn_degree_bucket.nei_edge_unit, [N_d, d, 8]): 16 atoms x 32 bytes = half a DMA piece
-    auto issue_bonds = [&](int64_t t, int sd, float* mrec) {
+    auto issue_bonds = [&](int t, int sd, float* mrec) {
         if (lane < 32) {
-            int64_t n = t * 16 + (lane >> 1);
-            if (n >= dg.n) n = dg.n - 1;
-            dma16<SITE_BONDS>(dg.e_unit + ((uint32_t)(n * D + sd) * 8u + 4u * (lane & 1)), mrec + T::OFF_BOND + sd * 128);
+            int n = t * 16 + (lane >> 1);
+            if (n >= dn) n = dn - 1;
+            dma16<SITE_BONDS>(dg.e_unit + (((uint32_t)n * D + sd) * 8u + 4u * (lane & 1)), mrec + T::OFF_BOND + sd * 128);
         }
     };
     // lane q -> (slot q >> 4, atom q & 15): slots 0..3 in one 64-dword piece, slot 4 (degree 4's focal row) in a second
-    auto issue_ids = [&](int64_t t, float* mrec) {       // low dwords of the int64 indices of tile t
-        int64_t n = t * 16 + ci;
-        if (n >= dg.n) n = dg.n - 1;
-        const void* src = (kq < D) ? (const void*)(dg.nei + n * D + kq) : (const void*)(dg.sel + n);    // kq == D: the focal id (D < 4)
+    auto issue_ids = [&](int t, float* mrec) {           // low dwords of the int64 indices of tile t
+        int n = t * 16 + ci;
+        if (n >= dn) n = dn - 1;
+        const void* src = (kq < D) ? (const void*)(dg.nei + ((uint32_t)n * D + kq)) : (const void*)(dg.sel + n);    // kq == D: the focal id (D < 4)
         if (S1 >= 4 || kq < S1) dma4<SITE_IDS>(src, mrec);
         if constexpr (S1 == 5) {
             if (kq == 0) dma4<SITE_IDS4>(dg.sel + n, mrec + 64);
         }
     };
-    auto issue_meta = [&](int64_t t, float* mrec) {      // 1 / |x| of every slot (through the ids in the record), flags, focal ids
+    auto issue_meta = [&](int t, float* mrec) {          // 1 / |x| of every slot (through the ids in the record), flags, focal ids
         // lane q needs the id of (slot q >> 4, atom q & 15): read it from the record (idsD[kq] would be a run-time index)
         const uint32_t idq = __float_as_uint(mrec[16 * ((S1 >= 4 || kq < S1) ? kq : 0) + ci]);
         if (S1 >= 4 || kq < S1) dma4<SITE_INV>(a.inv + idq, mrec + T::OFF_INV);
@@ -380,8 +437,8 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
         }
         if constexpr (D == 4) {                          // 16 flag bytes each = 4 dwords
             if (lane < 4) {
-                int64_t n4 = t * 4 + lane;               // dword index; the last tile may be partial: clamp into the array
-                const int64_t hi = (dg.n + 3) / 4 - 1;
+                int n4 = t * 4 + lane;                   // dword index; the last tile may be partial: clamp into the array
+                const int hi = (dn + 3) / 4 - 1;
                 n4 = n4 > hi ? hi : n4;
                 dma4<SITE_SIGN>(sgp + 4 * n4, mrec + T::OFF_SIGN);
                 dma4<SITE_EQ>(eqp + 4 * n4, mrec + T::OFF_EQ);
@@ -419,8 +476,8 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
 #ifdef MKGNN_FWD_STAMPS
     unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_phase = __builtin_readcyclecounter();
 #endif
-    for (int64_t it = 0; it < iters; ++it) {
-        const int64_t tile = tile_at(it);
+    for (int it = 0; it < iters; ++it) {
+        const int tile = tile_at(it);
         const bool real = tile_first + it < tile_end;    // else: a repeat of the last tile, results discarded
         float* const mrec = meta + (it & 1) * META;
         f32x4 cm[D][NBS];
@@ -440,7 +497,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
             // the phase cost ~500 cycles of issue EACH (7 k cycles per tile, tools/stream_stamps.py) -- the request queue is
             // a few pieces deep and an issue blocks while it is full.  One or two pieces between two chunks of matrix
             // instructions (8-12 of them, 256-384 cycles) find the queue drained.
-            const int64_t pt = it + side;                // the partner's tile (iteration) whose rows are fetched in this phase
+            const int pt = it + side;                    // the partner's tile (iteration) whose rows are fetched in this phase
             {
                 const float* const prec = pmeta + (pt & 1) * META;
 #pragma unroll
@@ -520,7 +577,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
                     f32x4 cA = bufA[step & 1];
                     [[maybe_unused]] f32x4 cF = bufF[step & 1];
                     if constexpr (t == KC - 1) { mask_last(cA); if constexpr (merged && WC) mask_last(cF); }
-                    if constexpr (BF) {
+                    if constexpr (BF == 1) {
                         const s16x4s a4 = to_bf16x4s(cA);
 #pragma unroll
                         for (int b = 0; b < NBS; ++b) cm[sl][b] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a4, bk[b][t], cm[sl][b], 0, 0, 0);
@@ -548,6 +605,10 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
             __builtin_amdgcn_s_barrier();                // this team is done reading its ring; the partner may read its own
             MKGNN_PHASE(2);
         } else {
+        // (BF == 2) the power-of-two scale of atom ci's row, slot by slot, from the 1 / |x| of the tile's record (landed with slot
+        // 0's rows; read behind the compiler's back like the bond rows below).  One register, not S1: the degree-3 body is at
+        // the 256-register limit, and a spilled value's reload is a vector-memory operation that drains the DMA queue.
+        [[maybe_unused]] const uint32_t sca_addr = (uint32_t)(uintptr_t)(mrec + T::OFF_INV + ci);
         static_for<0, S1>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
             // ---- multiply slot s: one LDS read per 4 NBS (or 4) matrix instructions, issued one chunk ahead.  (Written as ordinary
@@ -557,6 +618,12 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
             // lgkmcnt waits, truly a chunk ahead -- 255 VGPRs and the same 65.5 us: the other wave of the SIMD covers that
             // latency.  The ping-pong form, whose multiplying wave has no such partner, keeps the asm reads.)
             prio_multiply();
+            [[maybe_unused]] float sca_s = 0.f;
+            if constexpr (BF == 2) {
+                lds_read32<s * 64>(sca_s, sca_addr);
+                lds_wait0(sca_s);
+                sca_s = split_row_scale(sca_s);
+            }
             if (s < D || !HS || half == 0) {             // (HS: the centre belongs to half 0)
 #ifndef MKGNN_FWD_ASM_READS
                 const float* rb = ring + buf * SLOT + lane * 4;
@@ -583,7 +650,21 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
                         if (col + 2 >= F) cur.z = 0.f;
                         if (col + 3 >= F) cur.w = 0.f;
                     }
-                    if constexpr (BF) {
+                    if constexpr (BF == 2) {
+                        const SplitReg a4 = split_scaled(cur, sca_s);
+                        if constexpr (s < D) {
+#pragma unroll
+                            for (int b = 0; b < NBS; ++b) cm[s][b] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4.lo, bk[b][t].hi, cm[s][b], 0, 0, 0);
+#pragma unroll
+                            for (int b = 0; b < NBS; ++b) cm[s][b] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4.hi, bk[b][t].lo, cm[s][b], 0, 0, 0);
+#pragma unroll
+                            for (int b = 0; b < NBS; ++b) cm[s][b] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4.hi, bk[b][t].hi, cm[s][b], 0, 0, 0);
+                        } else {
+                            cc = __builtin_amdgcn_mfma_f32_16x16x16f16(a4.lo, bk[NBS][t].hi, cc, 0, 0, 0);
+                            cc = __builtin_amdgcn_mfma_f32_16x16x16f16(a4.hi, bk[NBS][t].lo, cc, 0, 0, 0);
+                            cc = __builtin_amdgcn_mfma_f32_16x16x16f16(a4.hi, bk[NBS][t].hi, cc, 0, 0, 0);
+                        }
+                    } else if constexpr (BF == 1) {
                         const s16x4s a4 = to_bf16x4s(cur);
                         if constexpr (s < D) {
 #pragma unroll
@@ -635,7 +716,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
             MKGNN_PHASE(2);
             // ---- issue the batch of step k + RING into the buffer just read
             constexpr int sd = (s + RING) % S1;
-            const int64_t itd = it + (s + RING) / S1;    // iteration (tile) the DMA pointer is in
+            const int itd = it + (s + RING) / S1;        // iteration (tile) the DMA pointer is in
             float* const drec = meta + (itd & 1) * META;
             if constexpr (sd == 0) {                     // the DMA pointer enters a new tile: its ids were DMA'd a tile ago
 #pragma unroll
@@ -690,7 +771,13 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
         [[maybe_unused]] f32x4 inv4[S1];
         if constexpr (!HS) {
 #pragma unroll
-            for (int s = 0; s < S1; ++s) inv4[s] = *(const f32x4*)(mrec + T::OFF_INV + s * 16 + kq * 4);
+            for (int s = 0; s < S1; ++s) {
+                inv4[s] = *(const f32x4*)(mrec + T::OFF_INV + s * 16 + kq * 4);
+                if constexpr (BF == 2) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) inv4[s][j] = split_inv(inv4[s][j]);
+                }
+            }
         }
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -699,7 +786,8 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
 #pragma unroll
             for (int s = 0; s < D; ++s) {
                 if constexpr (HS) {
-                    const float iv = mrec[T::OFF_INV + s * 16 + kq * 4 + jj];
+                    float iv = mrec[T::OFF_INV + s * 16 + kq * 4 + jj];
+                    if constexpr (BF == 2) iv = split_inv(iv);
                     const float own0 = half ? cm[s][0][2 + j] : cm[s][0][j], own1 = half ? cm[s][1][2 + j] : cm[s][1][j];
                     m[s][0] = (half ? px[j][s][0] : own0) * iv;
                     m[s][1] = (half ? px[j][s][1] : own1) * iv;
@@ -712,7 +800,11 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
                 }
             }
             best_permutation<D>(m, best4[j], idx4[j]);
-            if constexpr (HS) cen4[j] = (half ? pcc[j] : cc[j]) * mrec[T::OFF_INV + D * 16 + kq * 4 + jj];
+            if constexpr (HS) {
+                float ivc = mrec[T::OFF_INV + D * 16 + kq * 4 + jj];
+                if constexpr (BF == 2) ivc = split_inv(ivc);
+                cen4[j] = (half ? pcc[j] : cc[j]) * ivc;
+            }
             else cen4[j] = cc[j] * inv4[D][j];
         }
         MKGNN_PHASE(5);
@@ -766,7 +858,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int jj = HS ? 2 * half + j : j;
-            const int64_t n = tile * 16 + kq * 4 + jj;
+            const int n = tile * 16 + kq * 4 + jj;
             float ed = ed4[j][0];
 #pragma unroll
             for (int s = 1; s < D; ++s) ed = __fadd_rn(ed, ed4[j][s]);
@@ -790,7 +882,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
             asm volatile("" :: "v"(sc), "v"(ed), "v"(ch), "v"(focal), "v"(best4[j]), "v"(cen4[j]), "v"(idx4[j]));
             if (false) {
 #else
-            if (real && col_ok && n < dg.n) {
+            if (real && col_ok && n < dn) {
 #endif
 #ifndef MKGNN_ABLATE_OUT                                  // (timing experiments: one kind of store left out)
                 a.out[focal * (uint32_t)a.os + (uint32_t)(dg.off + lcol)] = sc;     // (the host checks n_atoms * stride < 2^30)
@@ -839,7 +931,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
 #define MKGNN_FWD_PAIR_DEFAULT 0
 #endif
 // (KC >= 8, rows of 113 .. 160 floats: the bank alone is up to 160 registers -- one wave per SIMD, 512 registers)
-template <int KC, bool BF = false>
+template <int KC, int BF = 0>
 __global__ void __launch_bounds__(256, (KC >= 8 ? 1 : MKGNN_EXP_OCC)) kc_forward_stream(FusedFwdArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int grp = a.blk_group[blockIdx.x];
@@ -860,7 +952,7 @@ __global__ void __launch_bounds__(256, (KC >= 8 ? 1 : MKGNN_EXP_OCC)) kc_forward
 }
 
 // the ping-pong form: 8 waves, one block per CU, 2 waves per SIMD (KC <= 7: the bank leaves room for two waves)
-template <int KC, bool BF = false>
+template <int KC, int BF = 0>
 __global__ void __launch_bounds__(512, (KC <= MKGNN_PP_OCC4_KC ? 4 : 2)) kc_forward_pp(FusedFwdArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int grp = a.blk_group[blockIdx.x];
@@ -1066,7 +1158,7 @@ int stream_forward_groups(const int L[4], const bool use[4]) {
     return n;
 }
 
-template <int KC, bool BF = false> static hipError_t launch_stream_kc(const FusedFwdArgs& a, int nb, size_t lds_bytes, hipStream_t st) {
+template <int KC, int BF = 0> static hipError_t launch_stream_kc(const FusedFwdArgs& a, int nb, size_t lds_bytes, hipStream_t st) {
     if (lds_bytes > 64 * 1024) {                         // (two such blocks still fit a CU's 160 KB; KC >= 8: one block per CU)
         static PerDeviceOnce attr_set;
         if (const int slot = attr_set.pending(); slot >= 0) {
@@ -1080,7 +1172,7 @@ template <int KC, bool BF = false> static hipError_t launch_stream_kc(const Fuse
     return hipGetLastError();
 }
 
-template <int KC, bool BF = false> static hipError_t launch_pp_kc(const FusedFwdArgs& a, int nb, size_t lds_bytes, hipStream_t st) {
+template <int KC, int BF = 0> static hipError_t launch_pp_kc(const FusedFwdArgs& a, int nb, size_t lds_bytes, hipStream_t st) {
     static PerDeviceOnce attr_set;
     if (const int slot = attr_set.pending(); slot >= 0) {
         hipError_t e = hipFuncSetAttribute((const void*)kc_forward_pp<KC, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1097,6 +1189,15 @@ static int fwd_pp_mode() {
     return m;
 }
 
+// MKGNN_FWD_SPLIT: 1 = the node-feature products as split fp16 (BF = 2), 0 = v_mfma_f32_16x16x4_f32, unset = default
+#ifndef MKGNN_FWD_SPLIT_DEFAULT
+#define MKGNN_FWD_SPLIT_DEFAULT 0
+#endif
+static int fwd_split_mode() {
+    static const int m = [] { const char* e = getenv("MKGNN_FWD_SPLIT"); return e ? atoi(e) : MKGNN_FWD_SPLIT_DEFAULT; }();
+    return m;
+}
+
 hipError_t launch_forward_stream(FusedFwdArgs& a, const bool use[4], hipStream_t st) {
     const int KC = (a.F + 15) / 16;
     a.stamps = g_stream_stamps;
@@ -1108,8 +1209,8 @@ hipError_t launch_forward_stream(FusedFwdArgs& a, const bool use[4], hipStream_t
         if (nb > 0 && lds_pp <= (size_t)160 * 1024) {
             g_last_plan[0].launches.fetch_add(1);
             if (a.bf16) {
-                if (KC == 2) return launch_pp_kc<2, true>(a, nb, lds_pp, st);
-                if (KC == 7) return launch_pp_kc<7, true>(a, nb, lds_pp, st);
+                if (KC == 2) return launch_pp_kc<2, 1>(a, nb, lds_pp, st);
+                if (KC == 7) return launch_pp_kc<7, 1>(a, nb, lds_pp, st);
                 return hipErrorInvalidValue;
             }
             switch (KC) {
@@ -1128,9 +1229,13 @@ hipError_t launch_forward_stream(FusedFwdArgs& a, const bool use[4], hipStream_t
     if (nb < 0 || lds_bytes > (size_t)(KC >= 8 ? 128 : 80) * 1024) return hipErrorInvalidValue;     // (the caller checks stream_forward_groups first)
     g_last_plan[0].launches.fetch_add(1);
     if (a.bf16) {
-        if (KC == 2) return launch_stream_kc<2, true>(a, nb, lds_bytes, st);
-        if (KC == 7) return launch_stream_kc<7, true>(a, nb, lds_bytes, st);
+        if (KC == 2) return launch_stream_kc<2, 1>(a, nb, lds_bytes, st);
+        if (KC == 7) return launch_stream_kc<7, 1>(a, nb, lds_bytes, st);
         return hipErrorInvalidValue;                     // (the caller asks stream_forward_bf16_supported first)
+    }
+    if (fwd_split_mode() != 0) {
+        if (KC == 2) return launch_stream_kc<2, 2>(a, nb, lds_bytes, st);
+        if (KC == 7) return launch_stream_kc<7, 2>(a, nb, lds_bytes, st);
     }
     switch (KC) {
         case 1: return launch_stream_kc<1>(a, nb, lds_bytes, st);
