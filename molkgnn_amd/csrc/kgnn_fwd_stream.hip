@@ -43,6 +43,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "kgnn_launch.h"
@@ -226,24 +227,35 @@ __device__ __forceinline__ SplitReg split_f16(f32x4 v) {
     r.lo = h16x4{(_Float16)(v[0] - (float)r.hi[0]), (_Float16)(v[1] - (float)r.hi[1]), (_Float16)(v[2] - (float)r.hi[2]), (_Float16)(v[3] - (float)r.hi[3])};
     return r;
 }
-// the split of v * s (s a power of two) in eight instructions: v_fma_mix{lo,hi}_f16 take fp32 (or fp16) sources, compute the fma
-// in fp32 and round ONCE to the fp16 half of the destination -- hi = fp16(v s + 0), lo = fp16(v s - hi) (the fp32 fma result is
-// exact).  Left to the compiler (split_f16 of a product) the same thing is 17 instructions per chunk, and on this chip
-// vector instructions do not hide behind the other wave's matrix instructions.
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+// The split of v * s (s a power of two) in ten instructions per four values: two v_pk_mul_f32, two v_cvt_pk_f16_f32 (hi), four
+// v_fma_mix_f32 (r = v s - hi with hi taken straight from its fp16 half: exact), two v_cvt_pk_f16_f32 (lo).  Left to the compiler
+// the residual alone is a v_cvt_f32_f16 and a subtraction per value (17 instructions), and on this chip vector instructions do
+// not hide behind the other wave's matrix instructions.  Only the v_fma_mix_f32 is inline asm, and what it
+// writes is read by ordinary vector instructions: the operands of the matrix instructions come out of compiler-visible
+// v_cvt_pk_f16_f32.  (A first version built hi and lo with v_fma_mixlo_f16 / v_fma_mixhi_f16 -- eight instructions -- and was
+// WRONG on the hardware: a matrix instruction that reads a register a few cycles after a 16-bit partial write of an inline-asm
+// instruction gets the old half; the hazard recognizer puts one wait state there, eight made it right.  Found by
+// tests/test_scale_parity.py::test_split_fp16_products_are_fp32_grade.)
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float residual_lo(float xs, h16x2 hi) {     // xs - (float)hi[0]
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(xs), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float residual_hi(float xs, h16x2 hi) {     // xs - (float)hi[1]
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(xs), "v"(hi));
+    return r;
+}
 __device__ __forceinline__ SplitReg split_scaled(f32x4 v, float s) {
-    uint32_t h0, h1, l0, l1;
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h0) : "v"(v[0]), "v"(s));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h0) : "v"(v[1]), "v"(s));
-    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h1) : "v"(v[2]), "v"(s));
-    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h1) : "v"(v[3]), "v"(s));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l0) : "v"(v[0]), "v"(s), "v"(h0));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l0) : "v"(v[1]), "v"(s), "v"(h0));
-    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l1) : "v"(v[2]), "v"(s), "v"(h1));
-    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l1) : "v"(v[3]), "v"(s), "v"(h1));
+    const f32x4 xs = v * s;
+    const h16x2 h0 = {(_Float16)xs[0], (_Float16)xs[1]}, h1 = {(_Float16)xs[2], (_Float16)xs[3]};
+    const h16x2 l0 = {(_Float16)residual_lo(xs[0], h0), (_Float16)residual_hi(xs[1], h0)};
+    const h16x2 l1 = {(_Float16)residual_lo(xs[2], h1), (_Float16)residual_hi(xs[3], h1)};
     SplitReg r;
-    r.hi = __builtin_bit_cast(h16x4, u32x2{h0, h1});
-    r.lo = __builtin_bit_cast(h16x4, u32x2{l0, l1});
+    r.hi = h16x4{h0[0], h0[1], h1[0], h1[1]};
+    r.lo = h16x4{l0[0], l0[1], l1[0], l1[1]};
     return r;
 }
 constexpr int SPLIT_BANK_EXP = 8, SPLIT_ROW_EXP = 8;
@@ -1011,7 +1023,7 @@ hipError_t launch_unit_rows8(const float* in, int64_t n_rows, int E, float* out,
 // prologue + iterations * cost per tile (all blocks are resident at once: the launch lasts as long as its slowest wave),
 // groups interleaved over the block ids, the blocks of a group that share an XCD (block id mod 8) given adjacent runs
 // of tiles (the buckets are sorted by atom id: what one group gathers as neighbours another gathers as focal rows).
-static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nblocks_out, bool pp = false) {
+static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nblocks_out, bool pp = false, bool split = false) {
     constexpr int MG = FUSED_MAX_GROUPS;                // groups = (degree, column part); launch_forward_stream checks the total
     double cost[MG];
     int64_t tiles_of[MG], cap[MG];
@@ -1035,17 +1047,20 @@ static size_t plan_stream(FusedFwdArgs& a, const bool use[4], int KC, int* nbloc
             // 4096: 10.2 k / 15.2 k / 27.3 k / 33.8 k cycles for degree 1..4), scaled with the chunk count for F <= 32
             // (other chunk counts: interpolated)
             static double calib7[4] = {319.0, 475.0, 853.0, 1056.0}, calib2[4] = {200.0, 260.0, 420.0, 560.0};
+            // (the split-fp16 products, round 5: 6.3 k / 10.8 k / 17.0 k / 22.7 k cycles per tile at F = 110, 4.2 k / 5.6 k / 9.7 k /
+            // 14.8 k at F = 28)
+            static double split7[4] = {230.0, 337.0, 533.0, 710.0}, split2[4] = {131.0, 176.0, 303.0, 462.0};
             static const bool env_read = [] {            // diagnostics: MKGNN_STREAM_COST="c1,c2,c3,c4" (applies to both widths)
                 if (const char* e = getenv("MKGNN_STREAM_COST")) {
                     double v[4];
                     if (sscanf(e, "%lf,%lf,%lf,%lf", &v[0], &v[1], &v[2], &v[3]) == 4)
-                        for (int k = 0; k < 4; ++k) calib7[k] = calib2[k] = v[k];
+                        for (int k = 0; k < 4; ++k) calib7[k] = calib2[k] = split7[k] = split2[k] = v[k];
                 }
                 return true;
             }();
             (void)env_read;
             if (ng >= MG) { *nblocks_out = -1; return 0; }
-            cost[ng] = calib2[i] + (calib7[i] - calib2[i]) * (KC - 2) / 5.0;
+            cost[ng] = split ? split2[i] + (split7[i] - split2[i]) * (KC - 2) / 5.0 : calib2[i] + (calib7[i] - calib2[i]) * (KC - 2) / 5.0;
             tiles_of[ng] = ntiles;
             cap[ng] = (ntiles + nstream - 1) / nstream;
             nstream_of[ng] = nstream;
@@ -1191,12 +1206,16 @@ static int fwd_pp_mode() {
 
 // MKGNN_FWD_SPLIT: 1 = the node-feature products as split fp16 (BF = 2), 0 = v_mfma_f32_16x16x4_f32, unset = default
 #ifndef MKGNN_FWD_SPLIT_DEFAULT
-#define MKGNN_FWD_SPLIT_DEFAULT 0
+#define MKGNN_FWD_SPLIT_DEFAULT 1
 #endif
+static std::atomic<int> g_fwd_split_override{-1};
 static int fwd_split_mode() {
     static const int m = [] { const char* e = getenv("MKGNN_FWD_SPLIT"); return e ? atoi(e) : MKGNN_FWD_SPLIT_DEFAULT; }();
-    return m;
+    const int o = g_fwd_split_override.load(std::memory_order_relaxed);
+    return o >= 0 ? o : m;
 }
+// tests: 1 / 0 = split-fp16 / fp32 matrix instructions from the next launch on, -1 = what the environment says
+extern "C" int mkgnn_debug_set_forward_products(int32_t mode) { g_fwd_split_override.store(mode < 0 ? -1 : (mode ? 1 : 0)); return 0; }
 
 hipError_t launch_forward_stream(FusedFwdArgs& a, const bool use[4], hipStream_t st) {
     const int KC = (a.F + 15) / 16;
@@ -1224,7 +1243,9 @@ hipError_t launch_forward_stream(FusedFwdArgs& a, const bool use[4], hipStream_t
             }
         }
     }
-    const size_t lds_bytes = plan_stream(a, use, KC, &nb);
+    // (rows of more than 112 floats, KC >= 8, keep the fp32 matrix instructions: one wave per SIMD there, a rare shape)
+    const bool split = !a.bf16 && KC <= 7 && fwd_split_mode() != 0;
+    const size_t lds_bytes = plan_stream(a, use, KC, &nb, false, split);
     if (nb == 0) return hipSuccess;
     if (nb < 0 || lds_bytes > (size_t)(KC >= 8 ? 128 : 80) * 1024) return hipErrorInvalidValue;     // (the caller checks stream_forward_groups first)
     g_last_plan[0].launches.fetch_add(1);
@@ -1233,9 +1254,16 @@ hipError_t launch_forward_stream(FusedFwdArgs& a, const bool use[4], hipStream_t
         if (KC == 7) return launch_stream_kc<7, 1>(a, nb, lds_bytes, st);
         return hipErrorInvalidValue;                     // (the caller asks stream_forward_bf16_supported first)
     }
-    if (fwd_split_mode() != 0) {
-        if (KC == 2) return launch_stream_kc<2, 2>(a, nb, lds_bytes, st);
-        if (KC == 7) return launch_stream_kc<7, 2>(a, nb, lds_bytes, st);
+    if (split) {
+        switch (KC) {
+            case 1: return launch_stream_kc<1, 2>(a, nb, lds_bytes, st);
+            case 2: return launch_stream_kc<2, 2>(a, nb, lds_bytes, st);
+            case 3: return launch_stream_kc<3, 2>(a, nb, lds_bytes, st);
+            case 4: return launch_stream_kc<4, 2>(a, nb, lds_bytes, st);
+            case 5: return launch_stream_kc<5, 2>(a, nb, lds_bytes, st);
+            case 6: return launch_stream_kc<6, 2>(a, nb, lds_bytes, st);
+            default: return launch_stream_kc<7, 2>(a, nb, lds_bytes, st);
+        }
     }
     switch (KC) {
         case 1: return launch_stream_kc<1>(a, nb, lds_bytes, st);
