@@ -27,9 +27,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <type_traits>
 
 #include "kgnn_launch.h"
+#include "kgnn_split.h"
 
 #ifndef MKGNN_ROWS_RS_PAD                    // (A/B builds: make VARIANT=rspad0 EXTRA=-DMKGNN_ROWS_RS_PAD=0 is a linear image)
 #define MKGNN_ROWS_RS_PAD 4
@@ -91,7 +93,14 @@ struct RowsStreamArgs {
     uint16_t blk_rank[FUSED_MAX_BLOCKS];
 };
 
-template <int D, int KC>
+// SP = true (round 5): the products as split fp16 (kgnn_split.h): the masked coefficient tile is the A operand, a lane's four
+// values belong to ONE atom (lane & 15) and are scaled by a power of two taken from the atom's largest coefficient; the bank
+// rows (B operand, register-resident) are split once; the partial tile is scaled back, per atom, where it is written into
+// the exchange image.  k-position (lane >> 4, i) of the 16-deep product stands for kernel 4 i + (lane >> 4): the values a lane
+// holds today (kernels 4 q + kq of atom ci; kernels 4 q + kq of feature 16 t + ci) are its operands as they are.
+constexpr int ROWS_COEF_EXP = 10, ROWS_BANK_EXP = 12;
+
+template <int D, int KC, bool SP>
 __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const RowsStreamDeg& dg, const int rank, const int count,
                                                  float* lds) {
     using namespace rs;
@@ -117,6 +126,7 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
     // kernel's time -- 72.4 / 72.8 us: the exchange is ~4 % of its wave cycles.)
     constexpr int RS = FP + MKGNN_ROWS_RS_PAD;
     float* const xbuf = lds + (size_t)stream * (2 * NS * 16 * RS);
+    [[maybe_unused]] float* const ubuf = lds + (size_t)NSTREAM * (2 * NS * 16 * RS) + wave * 16;     // (SP) 1 / scale of the tile's atoms
 
     const int64_t ntiles = (dg.n + 15) / 16;
     const int64_t nstreams = (int64_t)count * NSTREAM;
@@ -174,18 +184,29 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
     // (the first tile's coefficient loads are in flight while the bank is loaded: one dependent round trip less in front of
     // the first tile)
     // ---- one-time: this wave's kernels' unit rows in B-operand order: lane (k = kq, j = ci) -> kernel 4 q + kq, feature 16 t + ci
-    float bk[D + 1][4][KC];
+    using BankT = std::conditional_t<SP, SplitReg, f32x4>;
+    BankT bk[D + 1][KC];                                  // [.][t]: kernels 4 q + kq, q = 0..3 (fp32: component q)
+    {
+        bool ok[4];
+        int lc[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int i = 4 * q + kq, l = ct * kpt + i;
-        const bool ok = ct_ok && i < kpt && l < L;
-        const int lc = ok ? l : 0;
+        for (int q = 0; q < 4; ++q) {
+            const int i = 4 * q + kq, l = ct * kpt + i;
+            ok[q] = ct_ok && i < kpt && l < L;
+            lc[q] = ok[q] ? l : 0;
+        }
 #pragma unroll
         for (int b = 0; b <= D; ++b)
 #pragma unroll
             for (int t = 0; t < KC; ++t) {
-                const float v = dg.padded[((size_t)b * L + lc) * FPB + 16 * t + ci];
-                bk[b][q][t] = ok ? v : 0.f;
+                f32x4 v;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float e = dg.padded[((size_t)b * L + lc[q]) * FPB + 16 * t + ci];
+                    v[q] = ok[q] ? e : 0.f;
+                }
+                if constexpr (SP) bk[b][t] = split_f16(v * (float)(1 << ROWS_BANK_EXP));
+                else bk[b][t] = v;
             }
     }
 
@@ -210,6 +231,21 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
         // next tile's inputs: in flight during this tile's matrix work
         issue(tile_at(it + 1), focal_next);
         if (!records) focal_next = focal_of(tile_at(it + 2));
+        // (SP) the atom's scale: its largest coefficient (the centre's ratio included) to [2^10, 2^11); the reciprocals of
+        // the four atoms this lane's result rows belong to (rows 4 kq + r) come back through LDS
+        [[maybe_unused]] float sca = 1.f;
+        [[maybe_unused]] f32x4 unsc = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (SP) {
+            float am = fmaxf(fmaxf(fabsf(cf[0]), fabsf(cf[1])), fmaxf(fabsf(cf[2]), fabsf(cf[3])));
+            am = fmaxf(am, __shfl_xor(am, 16));
+            am = fmaxf(am, __shfl_xor(am, 32));
+            am *= fmaxf(1.f, fabsf(ratio_c));
+            sca = split_scale_for<ROWS_COEF_EXP>(am);
+            if (kq == 0) ubuf[ci] = split_unscale_of<ROWS_BANK_EXP>(sca);
+            __builtin_amdgcn_wave_barrier();
+            unsc = *(const f32x4*)(ubuf + 4 * kq);
+            __builtin_amdgcn_wave_barrier();             // (the next tile's write stays behind this read)
+        }
         MKGNN_RPHASE(0);
 
         static_for<0, S1>([&](auto sc) {
@@ -217,12 +253,34 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
             f32x4 acc[KC];
 #pragma unroll
             for (int t = 0; t < KC; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if constexpr (s == 0) {
+            if constexpr (SP) {
+                auto multiply = [&](const SplitReg& av, const SplitReg* row) {      // three instructions per feature tile, KC independent chains
+#pragma unroll
+                    for (int t = 0; t < KC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(av.lo, row[t].hi, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < KC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(av.hi, row[t].lo, acc[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < KC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(av.hi, row[t].hi, acc[t], 0, 0, 0);
+                };
+                if constexpr (s == 0) {
+                    multiply(split_scaled(f32x4{cf[0] * ratio_c, cf[1] * ratio_c, cf[2] * ratio_c, cf[3] * ratio_c}, sca), bk[D]);
+                } else {
+                    int pb[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) pb[q] = perm_entry<D, (s > 0 ? s - 1 : 0)>(ix[q]);
+#pragma unroll
+                    for (int b = 0; b < D; ++b)
+                        multiply(split_scaled(f32x4{pb[0] == b ? cf[0] : 0.f, pb[1] == b ? cf[1] : 0.f, pb[2] == b ? cf[2] : 0.f,
+                                                    pb[3] == b ? cf[3] : 0.f}, sca), bk[b]);
+                }
+#pragma unroll
+                for (int t = 0; t < KC; ++t) acc[t] *= unsc;
+            } else if constexpr (s == 0) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float av = cf[q] * ratio_c;
 #pragma unroll
-                    for (int t = 0; t < KC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bk[D][q][t], acc[t], 0, 0, 0);
+                    for (int t = 0; t < KC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bk[D][t][q], acc[t], 0, 0, 0);
                 }
             } else {
 #pragma unroll
@@ -232,7 +290,7 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
                     for (int b = 0; b < D; ++b) {
                         const float av = (pb == b) ? cf[q] : 0.f;
 #pragma unroll
-                        for (int t = 0; t < KC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bk[b][q][t], acc[t], 0, 0, 0);
+                        for (int t = 0; t < KC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bk[b][t][q], acc[t], 0, 0, 0);
                     }
                 }
             }
@@ -293,7 +351,7 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
 #endif
 }
 
-template <int KC>
+template <int KC, bool SP = false>
 __global__ void __launch_bounds__(256, (KC >= 8 ? 1 : 2)) kc_backward_rows_stream(RowsStreamArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int grp = a.blk_group[blockIdx.x];
@@ -301,10 +359,10 @@ __global__ void __launch_bounds__(256, (KC >= 8 ? 1 : 2)) kc_backward_rows_strea
     const int di = a.grp_degree[grp];
     const int count = a.grp_count[grp];
     switch (di) {
-        case 0: rows_stream_body<1, KC>(a, a.deg[0], rank, count, lds); break;
-        case 1: rows_stream_body<2, KC>(a, a.deg[1], rank, count, lds); break;
-        case 2: rows_stream_body<3, KC>(a, a.deg[2], rank, count, lds); break;
-        default: rows_stream_body<4, KC>(a, a.deg[3], rank, count, lds); break;
+        case 0: rows_stream_body<1, KC, SP>(a, a.deg[0], rank, count, lds); break;
+        case 1: rows_stream_body<2, KC, SP>(a, a.deg[1], rank, count, lds); break;
+        case 2: rows_stream_body<3, KC, SP>(a, a.deg[2], rank, count, lds); break;
+        default: rows_stream_body<4, KC, SP>(a, a.deg[3], rank, count, lds); break;
     }
 }
 
@@ -324,18 +382,31 @@ bool rows_stream_supported(int d, int F, int E, int L) {
     return (L + 15) / 16 <= 8 * rs::column_tiles(d);      // (at most eight passes)
 }
 
-template <int KC> static hipError_t launch_rows_kc(const RowsStreamArgs& a, int nb, size_t lds_bytes, hipStream_t st) {
+template <int KC, bool SP = false> static hipError_t launch_rows_kc(const RowsStreamArgs& a, int nb, size_t lds_bytes, hipStream_t st) {
     if (lds_bytes > 64 * 1024) {
         static PerDeviceOnce attr_set;
         if (const int slot = attr_set.pending(); slot >= 0) {
-            hipError_t e = hipFuncSetAttribute((const void*)kc_backward_rows_stream<KC>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+            hipError_t e = hipFuncSetAttribute((const void*)kc_backward_rows_stream<KC, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
             if (e != hipSuccess) return e;
             attr_set.set(slot);
         }
     }
-    kc_backward_rows_stream<KC><<<nb, 256, lds_bytes, st>>>(a);
+    kc_backward_rows_stream<KC, SP><<<nb, 256, lds_bytes, st>>>(a);
     return hipGetLastError();
 }
+
+// MKGNN_BWD_SPLIT: 1 = the backward's products as split fp16 (kgnn_split.h), 0 = v_mfma_f32_16x16x4_f32, unset = default;
+// mkgnn_debug_set_backward_products overrides (tests)
+#ifndef MKGNN_BWD_SPLIT_DEFAULT
+#define MKGNN_BWD_SPLIT_DEFAULT 1
+#endif
+static std::atomic<int> g_bwd_split_override{-1};
+int bwd_split_mode() {
+    static const int m = [] { const char* e = getenv("MKGNN_BWD_SPLIT"); return e ? atoi(e) : MKGNN_BWD_SPLIT_DEFAULT; }();
+    const int o = g_bwd_split_override.load(std::memory_order_relaxed);
+    return o >= 0 ? o : m;
+}
+extern "C" int mkgnn_debug_set_backward_products(int32_t mode) { g_bwd_split_override.store(mode < 0 ? -1 : (mode ? 1 : 0)); return 0; }
 
 // one pass (column part cp) over the degrees in `use`
 static hipError_t launch_rows_pass(const BwdArgs a4[4], const bool use[4], float* const coefq[4], int cp, hipStream_t st) {
@@ -415,7 +486,19 @@ static hipError_t launch_rows_pass(const BwdArgs a4[4], const bool use[4], float
     for (int g = 0; g < ng; ++g) a.grp_count[g] = (uint16_t)count[g];
     if (cp == 0) note_plan(1, nb, ng, tiles_of, count, nstream_of);
     g_last_plan[1].launches.fetch_add(1);
-    const size_t lds_bytes = (size_t)4 * 2 * 16 * (16 * KC + MKGNN_ROWS_RS_PAD) * 4;      // NSTREAM * NS = 4 wave images of 16 rows, two parities
+    // NSTREAM * NS = 4 wave images of 16 rows, two parities; + 4 x 16 reciprocal scales (split products)
+    const size_t lds_bytes = (size_t)4 * 2 * 16 * (16 * KC + MKGNN_ROWS_RS_PAD) * 4 + 256;
+    if (KC <= 7 && bwd_split_mode() != 0) {
+        switch (KC) {
+            case 1: return launch_rows_kc<1, true>(a, nb, lds_bytes, st);
+            case 2: return launch_rows_kc<2, true>(a, nb, lds_bytes, st);
+            case 3: return launch_rows_kc<3, true>(a, nb, lds_bytes, st);
+            case 4: return launch_rows_kc<4, true>(a, nb, lds_bytes, st);
+            case 5: return launch_rows_kc<5, true>(a, nb, lds_bytes, st);
+            case 6: return launch_rows_kc<6, true>(a, nb, lds_bytes, st);
+            default: return launch_rows_kc<7, true>(a, nb, lds_bytes, st);
+        }
+    }
     switch (KC) {
         case 1: return launch_rows_kc<1>(a, nb, lds_bytes, st);
         case 2: return launch_rows_kc<2>(a, nb, lds_bytes, st);

@@ -36,6 +36,7 @@
 #include <type_traits>
 
 #include "kgnn_launch.h"
+#include "kgnn_split.h"
 
 namespace mkgnn {
 
@@ -237,7 +238,21 @@ __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
 }
 
 // ------------------------------------------------------------ main body ---
-template <int D, int KC>
+// SP = true (round 5): the row products as split fp16 (kgnn_split.h).  k-position (lane >> 4, i) of the 16-deep product
+// stands for atom 4 i + (lane >> 4): the four values a lane holds today -- coefficients of kernel ci, feature ci of the rows,
+// atoms 4 q + kq -- are its A and B operands as they are.  Scales: a row (B, atom k) by 2^(exponent(1 / |x_k|) + 8), its
+// inverse moved into the coefficient of the same atom (A: g w mantissa(1 / |x_k|) 2^-8); the coefficients by ONE power of
+// two per wave, G, chosen so that the largest coefficient seen so far sits at 2^18 before the mantissa factor -- when a tile
+// brings a larger one, G drops and the accumulators (which live in registers for the whole launch) are multiplied by the
+// ratio, exactly; the slab slice is divided by G at the end.  Bit-reproducible: G depends on the wave's own tiles in order.
+constexpr int BANK_COEF_EXP = 18;
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+template <int D, int KC, bool SP>
 __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const BankStreamDeg& dg, const int cp, const int rank,
                                                  const int count, float* lds) {
     using namespace bs;
@@ -356,6 +371,9 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
 #pragma unroll
     for (int b = 0; b < NBS; ++b) accE[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    [[maybe_unused]] float G = __uint_as_float(230u << 23);      // (SP) 2^103: no coefficient seen yet
+    [[maybe_unused]] const float wmax = fmaxf(fabsf(ws_n), fabsf(wc_n));
+
     // ---- prologue
     if (role == 0) issue_ids(tile_at(0), meta);
     wait_vmcnt<0>();
@@ -401,6 +419,21 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
                 iq[q] = __float_as_int(raw[4 + q]);
             }
         }
+        if constexpr (SP) {
+            // the wave's scale: never larger than what this tile's largest coefficient allows
+            const float tm = wave_max(fmaxf(fmaxf(fabsf(gq[0]), fabsf(gq[1])), fmaxf(fabsf(gq[2]), fabsf(gq[3])))) * wmax;
+            const float need = split_scale_for<BANK_COEF_EXP>(tm);
+            if (need < G) {                              // (wave-uniform; a handful of times per launch)
+                const float ratio = need / G;            // both powers of two: exact
+#pragma unroll
+                for (int t = 0; t < KC; ++t) {
+                    accC[t] *= ratio;
+#pragma unroll
+                    for (int b = 0; b < NBS; ++b) acc[b][t] *= ratio;
+                }
+                G = need;
+            }
+        }
         MKGNN_BPHASE(0);
         static_for<0, S1>([&](auto sc) {
             constexpr int s = decltype(sc)::value;
@@ -426,6 +459,14 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(iv[0]), "+v"(iv[1]), "+v"(iv[2]), "+v"(iv[3]) : : "memory");
                 }
                 float av[NBS][4], ae[NBS][4], ac[4];
+                [[maybe_unused]] f32x4 rsc;               // (SP) the rows' scales, atoms 4 q + kq
+                if constexpr (SP) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        rsc[q] = __uint_as_float((__float_as_uint(iv[q]) & 0x7f800000u) + (8u << 23));
+                        iv[q] = __uint_as_float((__float_as_uint(iv[q]) & 0x007fffffu) | ((127u - 8u) << 23)) * G;     // mantissa 2^-8 G
+                    }
+                }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if constexpr (s < D) {
@@ -439,6 +480,15 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
                         }
                     } else {
                         ac[q] = gq[q] * wc_n * iv[q];
+                    }
+                }
+                [[maybe_unused]] SplitReg avs[NBS];       // (SP) the masked coefficient operands of the slot, split once
+                if constexpr (SP) {
+                    if constexpr (s < D) {
+#pragma unroll
+                        for (int b = 0; b < NBS; ++b) avs[b] = split_exact(f32x4{av[b][0], av[b][1], av[b][2], av[b][3]});
+                    } else {
+                        avs[0] = split_exact(f32x4{ac[0], ac[1], ac[2], ac[3]});
                     }
                 }
                 if constexpr (s < D) {
@@ -462,7 +512,19 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
                         else bx[q] = lds_read_raw_at<4 * (4 * q * RF + 16 * t)>(xl_b);
                     });
                     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bx[0]), "+v"(bx[1]), "+v"(bx[2]), "+v"(bx[3]) : : "memory");
-                    if constexpr (s < D) {
+                    if constexpr (SP) {
+                        const SplitReg xb = split_scaled(f32x4{bx[0], bx[1], bx[2], bx[3]}, rsc);
+                        if constexpr (s < D) {
+#pragma unroll
+                            for (int b = 0; b < NBS; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(avs[b].lo, xb.hi, acc[b][t], 0, 0, 0);
+#pragma unroll
+                            for (int b = 0; b < NBS; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(avs[b].hi, xb.lo, acc[b][t], 0, 0, 0);
+#pragma unroll
+                            for (int b = 0; b < NBS; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(avs[b].hi, xb.hi, acc[b][t], 0, 0, 0);
+                        } else {
+                            accC[t] = split_mfma(avs[0], xb, accC[t]);
+                        }
+                    } else if constexpr (s < D) {
 #pragma unroll
                         for (int b = 0; b < NBS; ++b)
 #pragma unroll
@@ -507,6 +569,15 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
     MKGNN_BPHASE(3);
 
     // ---- this wave's slice of its stream's partial slab: C layout col = feature 16 t + ci, row = kernel kq * 4 + r
+    if constexpr (SP) {
+        const float ug = split_unscale_of<0>(G);         // 1 / G
+#pragma unroll
+        for (int t = 0; t < KC; ++t) {
+            accC[t] *= ug;
+#pragma unroll
+            for (int b = 0; b < NBS; ++b) acc[b][t] *= ug;
+        }
+    }
     float* const slab = dg.slab + (size_t)sg * bank_floats(D, L, F, a.E);
     const size_t o_sup = (size_t)L * F, o_edg = o_sup + (size_t)L * D * F;
 #pragma unroll
@@ -538,7 +609,7 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
 #endif
 }
 
-template <int KC>
+template <int KC, bool SP = false>
 __global__ void __launch_bounds__(256, (KC >= 8 ? 1 : 2)) kc_backward_bank_stream(BankStreamArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int grp = a.blk_group[blockIdx.x];
@@ -547,10 +618,10 @@ __global__ void __launch_bounds__(256, (KC >= 8 ? 1 : 2)) kc_backward_bank_strea
     const int cp = a.grp_cp[grp];
     const int count = a.grp_count[grp];
     switch (di) {
-        case 0: bank_stream_body<1, KC>(a, a.deg[0], cp, rank, count, lds); break;
-        case 1: bank_stream_body<2, KC>(a, a.deg[1], cp, rank, count, lds); break;
-        case 2: bank_stream_body<3, KC>(a, a.deg[2], cp, rank, count, lds); break;
-        default: bank_stream_body<4, KC>(a, a.deg[3], cp, rank, count, lds); break;
+        case 0: bank_stream_body<1, KC, SP>(a, a.deg[0], cp, rank, count, lds); break;
+        case 1: bank_stream_body<2, KC, SP>(a, a.deg[1], cp, rank, count, lds); break;
+        case 2: bank_stream_body<3, KC, SP>(a, a.deg[2], cp, rank, count, lds); break;
+        default: bank_stream_body<4, KC, SP>(a, a.deg[3], cp, rank, count, lds); break;
     }
 }
 
@@ -686,17 +757,17 @@ hipError_t launch_coef_prepare(const BankStreamLaunch& p, hipStream_t st) {
     return hipGetLastError();
 }
 
-template <int KC> static hipError_t launch_bank_kc(const BankStreamLaunch& p, hipStream_t st) {
+template <int KC, bool SP = false> static hipError_t launch_bank_kc(const BankStreamLaunch& p, hipStream_t st) {
     if (p.lds_bytes > 64 * 1024) {
         static PerDeviceOnce attr_set;
         if (const int slot = attr_set.pending(); slot >= 0) {
-            hipError_t e = hipFuncSetAttribute((const void*)kc_backward_bank_stream<KC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipError_t e = hipFuncSetAttribute((const void*)kc_backward_bank_stream<KC, SP>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (KC >= 8 ? 128 : 80) * 1024);
             if (e != hipSuccess) return e;
             attr_set.set(slot);
         }
     }
-    kc_backward_bank_stream<KC><<<p.nb, 256, p.lds_bytes, st>>>(p.a);
+    kc_backward_bank_stream<KC, SP><<<p.nb, 256, p.lds_bytes, st>>>(p.a);
     return hipGetLastError();
 }
 
@@ -704,6 +775,17 @@ hipError_t launch_backward_bank_stream(const BankStreamLaunch& p, hipStream_t st
     if (p.nb == 0) return hipSuccess;
     if (p.lds_bytes > (size_t)(p.KC >= 8 ? 128 : 80) * 1024) return hipErrorInvalidValue;
     g_last_plan[2].launches.fetch_add(1);
+    if (p.KC <= 7 && bwd_split_mode() != 0) {
+        switch (p.KC) {
+            case 1: return launch_bank_kc<1, true>(p, st);
+            case 2: return launch_bank_kc<2, true>(p, st);
+            case 3: return launch_bank_kc<3, true>(p, st);
+            case 4: return launch_bank_kc<4, true>(p, st);
+            case 5: return launch_bank_kc<5, true>(p, st);
+            case 6: return launch_bank_kc<6, true>(p, st);
+            default: return launch_bank_kc<7, true>(p, st);
+        }
+    }
     switch (p.KC) {
         case 1: return launch_bank_kc<1>(p, st);
         case 2: return launch_bank_kc<2>(p, st);

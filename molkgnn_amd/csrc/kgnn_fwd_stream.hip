@@ -47,6 +47,7 @@
 #include <type_traits>
 
 #include "kgnn_launch.h"
+#include "kgnn_split.h"
 
 namespace mkgnn {
 
@@ -211,53 +212,10 @@ __device__ __forceinline__ s16x4s to_bf16x4s(f32x4 v) {
     return __builtin_bit_cast(s16x4s, r);
 }
 
-// BF = 2 (round 5): fp32 products out of fp16 matrix instructions.  A float is split exactly into hi = fp16(x), lo = fp16(x - hi)
-// (two roundings to nearest: |x - hi - lo| <= 2^-24 |x| as long as lo stays a normal fp16 number); a product x y is then
-// hi hi' + hi lo' + lo hi' (the dropped lo lo' <= 2^-24 |x y|): three v_mfma_f32_16x16x16_f16 of 8 cycles in place of four
-// v_mfma_f32_16x16x4_f32 of 32, fp32 accumulation as before.  The error per product is that of ONE fp32 rounding -- measured
-// against float64 the sums are as close as the fp32 fma chain's (tests/test_scale_parity.py) -- provided nothing under- or
-// overflows in fp16: bank rows are unit rows, scaled by 2^8 before the split; an atom's row (a lane's A operand belongs to
-// ONE atom: lane & 15) is scaled by 2^(exponent(1 / |x|) + 8), i.e. to a norm in [256, 512), and the two powers of two
-// leave through the 1 / |x| factor the epilogue multiplies with anyway (exponent field set to -16: exact).
-typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-struct SplitReg { h16x4 hi, lo; };
-__device__ __forceinline__ SplitReg split_f16(f32x4 v) {
-    SplitReg r;
-    r.hi = h16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-    r.lo = h16x4{(_Float16)(v[0] - (float)r.hi[0]), (_Float16)(v[1] - (float)r.hi[1]), (_Float16)(v[2] - (float)r.hi[2]), (_Float16)(v[3] - (float)r.hi[3])};
-    return r;
-}
-// The split of v * s (s a power of two) in ten instructions per four values: two v_pk_mul_f32, two v_cvt_pk_f16_f32 (hi), four
-// v_fma_mix_f32 (r = v s - hi with hi taken straight from its fp16 half: exact), two v_cvt_pk_f16_f32 (lo).  Left to the compiler
-// the residual alone is a v_cvt_f32_f16 and a subtraction per value (17 instructions), and on this chip vector instructions do
-// not hide behind the other wave's matrix instructions.  Only the v_fma_mix_f32 is inline asm, and what it
-// writes is read by ordinary vector instructions: the operands of the matrix instructions come out of compiler-visible
-// v_cvt_pk_f16_f32.  (A first version built hi and lo with v_fma_mixlo_f16 / v_fma_mixhi_f16 -- eight instructions -- and was
-// WRONG on the hardware: a matrix instruction that reads a register a few cycles after a 16-bit partial write of an inline-asm
-// instruction gets the old half; the hazard recognizer puts one wait state there, eight made it right.  Found by
-// tests/test_scale_parity.py::test_split_fp16_products_are_fp32_grade.)
-typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ float residual_lo(float xs, h16x2 hi) {     // xs - (float)hi[0]
-    float r;
-    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(xs), "v"(hi));
-    return r;
-}
-__device__ __forceinline__ float residual_hi(float xs, h16x2 hi) {     // xs - (float)hi[1]
-    float r;
-    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(xs), "v"(hi));
-    return r;
-}
-__device__ __forceinline__ SplitReg split_scaled(f32x4 v, float s) {
-    const f32x4 xs = v * s;
-    const h16x2 h0 = {(_Float16)xs[0], (_Float16)xs[1]}, h1 = {(_Float16)xs[2], (_Float16)xs[3]};
-    const h16x2 l0 = {(_Float16)residual_lo(xs[0], h0), (_Float16)residual_hi(xs[1], h0)};
-    const h16x2 l1 = {(_Float16)residual_lo(xs[2], h1), (_Float16)residual_hi(xs[3], h1)};
-    SplitReg r;
-    r.hi = h16x4{h0[0], h0[1], h1[0], h1[1]};
-    r.lo = h16x4{l0[0], l0[1], l1[0], l1[1]};
-    return r;
-}
+// BF = 2 (round 5): fp32 products out of fp16 matrix instructions -- the exact hi + lo split of kgnn_split.h; bank rows are unit
+// rows, scaled by 2^8 before the split; an atom's row (a lane's A operand belongs to ONE atom: lane & 15) is scaled by
+// 2^(exponent(1 / |x|) + 8), i.e. to a norm in [256, 512), and the two powers of two leave through the 1 / |x| factor the
+// epilogue multiplies with anyway (exponent field set to -16: exact).
 constexpr int SPLIT_BANK_EXP = 8, SPLIT_ROW_EXP = 8;
 // 2^(exponent(inv) + SPLIT_ROW_EXP): the scale of an atom's row (inv = 1 / max(|x|, eps) <= 1e8: no overflow)
 __device__ __forceinline__ float split_row_scale(float inv) {

@@ -219,4 +219,7 @@ inline void note_plan(int which, int blocks, int ng, const int64_t* tiles_of, co
 int api_fail(const char* fmt, ...);
 int api_hip_fail(const char* what, hipError_t e);
 
+// MKGNN_BWD_SPLIT / mkgnn_debug_set_backward_products: the streamed backward kernels' products as split fp16 (kgnn_split.h)
+int bwd_split_mode();
+
 }  // namespace mkgnn

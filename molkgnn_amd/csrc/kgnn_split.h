@@ -1,0 +1,81 @@
+// Exact fp16 splits of fp32 operands for the matrix pipe (gfx950) -- shared by the streamed forward (kgnn_fwd_stream.hip,
+// BF = 2) and the streamed backward kernels (kgnn_bwd_rows_stream.hip, kgnn_bwd_stream.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mkgnn {
+
+typedef float split_f32x4 __attribute__((ext_vector_type(4)));
+
+// fp32 products out of fp16 matrix instructions (round 5).  A float is split exactly into hi = fp16(x), lo = fp16(x - hi)
+// (two roundings to nearest: |x - hi - lo| <= 2^-24 |x| as long as lo stays a normal fp16 number); a product x y is then
+// hi hi' + hi lo' + lo hi' (the dropped lo lo' <= 2^-24 |x y|): three v_mfma_f32_16x16x16_f16 of 8 cycles in place of four
+// v_mfma_f32_16x16x4_f32 of 32, fp32 accumulation as before.  The error per product is that of ONE fp32 rounding -- measured
+// against float64 the sums are as close as the fp32 fma chain's (tests/test_scale_parity.py) -- provided nothing under- or
+// overflows in fp16: bank rows are unit rows, scaled by 2^8 before the split; an atom's row (a lane's A operand belongs to
+// ONE atom: lane & 15) is scaled by 2^(exponent(1 / |x|) + 8), i.e. to a norm in [256, 512), and the two powers of two
+// leave through the 1 / |x| factor the epilogue multiplies with anyway (exponent field set to -16: exact).
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+struct SplitReg { h16x4 hi, lo; };
+__device__ __forceinline__ SplitReg split_f16(split_f32x4 v) {
+    SplitReg r;
+    r.hi = h16x4{(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+    r.lo = h16x4{(_Float16)(v[0] - (float)r.hi[0]), (_Float16)(v[1] - (float)r.hi[1]), (_Float16)(v[2] - (float)r.hi[2]), (_Float16)(v[3] - (float)r.hi[3])};
+    return r;
+}
+// The split of v * s (s a power of two) in ten instructions per four values: two v_pk_mul_f32, two v_cvt_pk_f16_f32 (hi), four
+// v_fma_mix_f32 (r = v s - hi with hi taken straight from its fp16 half: exact), two v_cvt_pk_f16_f32 (lo).  Left to the compiler
+// the residual alone is a v_cvt_f32_f16 and a subtraction per value (17 instructions), and on this chip vector instructions do
+// not hide behind the other wave's matrix instructions.  Only the v_fma_mix_f32 is inline asm, and what it
+// writes is read by ordinary vector instructions: the operands of the matrix instructions come out of compiler-visible
+// v_cvt_pk_f16_f32.  (A first version built hi and lo with v_fma_mixlo_f16 / v_fma_mixhi_f16 -- eight instructions -- and was
+// WRONG on the hardware: a matrix instruction that reads a register a few cycles after a 16-bit partial write of an inline-asm
+// instruction gets the old half; the hazard recognizer puts one wait state there, eight made it right.  Found by
+// tests/test_scale_parity.py::test_split_fp16_products_are_fp32_grade.)
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float residual_lo(float xs, h16x2 hi) {     // xs - (float)hi[0]
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(xs), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ float residual_hi(float xs, h16x2 hi) {     // xs - (float)hi[1]
+    float r;
+    asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(xs), "v"(hi));
+    return r;
+}
+__device__ __forceinline__ SplitReg split_exact(split_f32x4 xs) {         // (the caller has scaled: eight instructions)
+    const h16x2 h0 = {(_Float16)xs[0], (_Float16)xs[1]}, h1 = {(_Float16)xs[2], (_Float16)xs[3]};
+    const h16x2 l0 = {(_Float16)residual_lo(xs[0], h0), (_Float16)residual_hi(xs[1], h0)};
+    const h16x2 l1 = {(_Float16)residual_lo(xs[2], h1), (_Float16)residual_hi(xs[3], h1)};
+    SplitReg r;
+    r.hi = h16x4{h0[0], h0[1], h1[0], h1[1]};
+    r.lo = h16x4{l0[0], l0[1], l1[0], l1[1]};
+    return r;
+}
+__device__ __forceinline__ SplitReg split_scaled(split_f32x4 v, float s) { return split_exact(v * s); }
+__device__ __forceinline__ SplitReg split_scaled(split_f32x4 v, split_f32x4 s) { return split_exact(v * s); }      // a scale per value
+
+// three matrix instructions for one exact-split product tile: acc += a b with a, b split (lo lo' dropped: 2^-24 of |a b|)
+__device__ __forceinline__ split_f32x4 split_mfma(const SplitReg& a, const SplitReg& b, split_f32x4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a.lo, b.hi, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a.hi, b.lo, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x16f16(a.hi, b.hi, acc, 0, 0, 0);
+    return acc;
+}
+
+// Power-of-two scale that brings a magnitude `amax` to [2^TARGET, 2^(TARGET+1)) and its reciprocal times 2^-EXTRA, both exact
+// (exponent-field arithmetic; amax = 0 or tiny: the scale saturates at 2^103, still a power of two, still undone exactly)
+template <int TARGET> __device__ __forceinline__ float split_scale_for(float amax) {
+    const int eb = (int)((__float_as_uint(amax) >> 23) & 0xffu);          // biased exponent of amax
+    int f = 254 + TARGET - eb;                                             // biased exponent of 2^(TARGET - e)
+    f = f > 230 ? 230 : (f < 24 ? 24 : f);
+    return __uint_as_float((uint32_t)f << 23);
+}
+template <int EXTRA> __device__ __forceinline__ float split_unscale_of(float scale) {      // 2^-EXTRA / scale
+    const int f = (int)(__float_as_uint(scale) >> 23);
+    return __uint_as_float((uint32_t)(254 - EXTRA - f) << 23);
+}
+
+}  // namespace mkgnn
