@@ -161,7 +161,7 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 rg[q] = rec[4 * q];
-                ridx[q] = __float_as_int(rec[256 + 4 * q]);
+                ridx[q] = __float_as_int(rec[256 + 4 * q]) & 0xff;      // (above the id: the record's largest exponent, for the bank kernel)
                 rch[q] = 1;
             }
             return;
@@ -434,6 +434,12 @@ static hipError_t launch_rows_pass(const BwdArgs a4[4], const bool use[4], float
         const int64_t ntiles = (s.n + 15) / 16;
         // a wave's time per tile (units of 32 cycles): matrix instructions + per-slot exchange and stores
         cost[ng] = (d * d + 1) * 4.0 * KC + (d + 1) * 30.0 + 40.0;
+        if (KC <= 7 && bwd_split_mode() != 0) {
+            // the split-fp16 products: measured per tile (tools/bwd_stream_stamps.py, batch 4096, two waves per SIMD) at F = 110
+            // and F = 28, other chunk counts interpolated
+            static const double sp7[4] = {216.0, 320.0, 462.0, 769.0}, sp2[4] = {106.0, 173.0, 220.0, 310.0};
+            cost[ng] = sp2[i] + (sp7[i] - sp2[i]) * (KC - 2) / 5.0;
+        }
         tiles_of[ng] = ntiles;
         cap[ng] = (ntiles + nstream - 1) / nstream;
         nstream_of[ng] = nstream;

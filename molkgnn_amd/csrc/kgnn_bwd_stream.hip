@@ -154,6 +154,7 @@ template <int D, int KC> constexpr int young_batches(int s, int role) {
 // ------------------------------------------------------------- pre-pass ---
 // One thread per (atom of a tile, column of a column tile): the pair's dL/dsc (times the chirality sign) and
 // permutation id into tile order, zeros for padding; the three score-weight partials summed per block in a fixed order.
+typedef unsigned short pk_u16 __attribute__((ext_vector_type(2)));
 constexpr int PREP_RPB = 4;                              // records per block: four independent load chains per thread
 __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
     int di = 0;
@@ -213,6 +214,8 @@ __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
         S[r] = pr[0]; C[r] = pr[1]; Ed[r] = pr[2];
     }
     float p0 = 0.f, p1 = 0.f, p2 = 0.f;
+    static_assert(PREP_RPB == 4, "the records' exponent maxima travel as two pairs of 16-bit fields");
+    pk_u16 em01 = {0, 0}, em23 = {0, 0};                 // biased exponents of |g| of the block's four records
 #pragma unroll
     for (int r = 0; r < PREP_RPB; ++r) {
         const int64_t rec = blk * PREP_RPB + r;
@@ -220,8 +223,9 @@ __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
         if (rec < nrec) {
             float* out = g.coefq + (size_t)rec * 512;
             out[tid] = gg;
-            ((int*)out)[256 + tid] = ok[r] ? idx[r] : 0;
         }
+        const unsigned short eb = (unsigned short)((__float_as_uint(gg) >> 23) & 0xffu);
+        if (r < 2) em01[r & 1] = eb; else em23[r & 1] = eb;
         if (ok[r]) {
             const float sc = (S[r] * w_s + C[r] * w_c + Ed[r] * w_e) / w_sum;
             p0 = fmaf(gg * (w_s / w_sum), S[r] - sc, p0);
@@ -229,11 +233,36 @@ __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
             p2 = fmaf(gg * (w_e / w_sum), Ed[r] - sc, p2);
         }
     }
-    // fixed-order block sums
+    // fixed-order block sums; the records' largest exponents (a maximum: order-free)
     __shared__ float red[3][4];
+    __shared__ uint32_t emx[2][4];
     p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
-    if ((tid & 63) == 0) { red[0][tid >> 6] = p0; red[1][tid >> 6] = p1; red[2][tid >> 6] = p2; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        em01 = __builtin_elementwise_max(em01, __builtin_bit_cast(pk_u16, __shfl_xor(__builtin_bit_cast(uint32_t, em01), o, 64)));
+        em23 = __builtin_elementwise_max(em23, __builtin_bit_cast(pk_u16, __shfl_xor(__builtin_bit_cast(uint32_t, em23), o, 64)));
+    }
+    if ((tid & 63) == 0) {
+        red[0][tid >> 6] = p0; red[1][tid >> 6] = p1; red[2][tid >> 6] = p2;
+        emx[0][tid >> 6] = __builtin_bit_cast(uint32_t, em01); emx[1][tid >> 6] = __builtin_bit_cast(uint32_t, em23);
+    }
     __syncthreads();
+    {
+        // idx words: the permutation id in the low byte, the record's largest exponent above it (what the bank kernel's
+        // split-fp16 products scale by: kgnn_split.h) -- every word of a record carries it, no reduction where it is read
+        pk_u16 m01 = __builtin_bit_cast(pk_u16, emx[0][0]), m23 = __builtin_bit_cast(pk_u16, emx[1][0]);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            m01 = __builtin_elementwise_max(m01, __builtin_bit_cast(pk_u16, emx[0][w]));
+            m23 = __builtin_elementwise_max(m23, __builtin_bit_cast(pk_u16, emx[1][w]));
+        }
+#pragma unroll
+        for (int r = 0; r < PREP_RPB; ++r) {
+            const int64_t rec = blk * PREP_RPB + r;
+            const int me = r < 2 ? m01[r & 1] : m23[r & 1];
+            if (rec < nrec) ((int*)(g.coefq + (size_t)rec * 512))[256 + tid] = (ok[r] ? idx[r] : 0) | (me << 8);
+        }
+    }
     if (tid < 3) g.theta_slab[(size_t)blk * 4 + tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
 }
 
@@ -242,16 +271,11 @@ __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
 // stands for atom 4 i + (lane >> 4): the four values a lane holds today -- coefficients of kernel ci, feature ci of the rows,
 // atoms 4 q + kq -- are its A and B operands as they are.  Scales: a row (B, atom k) by 2^(exponent(1 / |x_k|) + 8), its
 // inverse moved into the coefficient of the same atom (A: g w mantissa(1 / |x_k|) 2^-8); the coefficients by ONE power of
-// two per wave, G, chosen so that the largest coefficient seen so far sits at 2^18 before the mantissa factor -- when a tile
+// two per wave, G, chosen so that the largest coefficient seen so far (the pre-pass leaves every record's largest exponent in
+// its idx words) sits below 2^19 before the mantissa factor -- when a tile
 // brings a larger one, G drops and the accumulators (which live in registers for the whole launch) are multiplied by the
 // ratio, exactly; the slab slice is divided by G at the end.  Bit-reproducible: G depends on the wave's own tiles in order.
 constexpr int BANK_COEF_EXP = 18;
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-
 template <int D, int KC, bool SP>
 __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const BankStreamDeg& dg, const int cp, const int rank,
                                                  const int count, float* lds) {
@@ -372,7 +396,8 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
     for (int b = 0; b < NBS; ++b) accE[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     [[maybe_unused]] float G = __uint_as_float(230u << 23);      // (SP) 2^103: no coefficient seen yet
-    [[maybe_unused]] const float wmax = fmaxf(fabsf(ws_n), fabsf(wc_n));
+    // (exponent of the larger weight, + 1 for the mantissas' product, re-biased: added to a record's largest exponent)
+    [[maybe_unused]] const int wexp = (int)((__float_as_uint(fmaxf(fabsf(ws_n), fabsf(wc_n))) >> 23) & 0xffu) + 1 - 127;
 
     // ---- prologue
     if (role == 0) issue_ids(tile_at(0), meta);
@@ -403,6 +428,7 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
         // the tile's coefficients for this lane: kernel ci, atoms 4 q + kq
         float gq[4];
         int iq[4];
+        [[maybe_unused]] int rec_exp = 0;
         {
             float raw[8];
             const uint32_t cl_b = cb_b + 4u * (kq * 16 + ci);
@@ -416,13 +442,13 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 gq[q] = (real && ct_ok) ? raw[q] : 0.f;
-                iq[q] = __float_as_int(raw[4 + q]);
+                iq[q] = __float_as_int(raw[4 + q]) & 0xff;
             }
+            if constexpr (SP) rec_exp = (__float_as_int(raw[4]) >> 8) & 0xff;     // (every idx word of the record carries it)
         }
         if constexpr (SP) {
-            // the wave's scale: never larger than what this tile's largest coefficient allows
-            const float tm = wave_max(fmaxf(fmaxf(fabsf(gq[0]), fabsf(gq[1])), fmaxf(fabsf(gq[2]), fabsf(gq[3])))) * wmax;
-            const float need = split_scale_for<BANK_COEF_EXP>(tm);
+            // the wave's scale: never larger than what this tile's largest coefficient (times the weights) allows
+            const float need = split_scale_for_exponent<BANK_COEF_EXP>(rec_exp + wexp);
             if (need < G) {                              // (wave-uniform; a handful of times per launch)
                 const float ratio = need / G;            // both powers of two: exact
 #pragma unroll
@@ -503,16 +529,24 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
                 // for even t and down for odd t -- two per-lane bases, the offsets stay immediates)
                 const uint32_t xl_b = rb_b + 4u * (kq * RF + ci + (SWZ ? (kq & 1) * 16 : 0));
                 [[maybe_unused]] const uint32_t xl_o = rb_b + 4u * (kq * RF + ci) - (SWZ ? 4u * ((kq & 1) * 16) : 0u);
-                static_for<0, KC>([&](auto tc) {
+                auto read_bx = [&](auto tc, float (&bx)[4]) {
                     constexpr int t = decltype(tc)::value;
-                    float bx[4];
                     static_for<0, 4>([&](auto qc) {
                         constexpr int q = decltype(qc)::value;
                         if constexpr (SWZ && (t & 1)) bx[q] = lds_read_raw_at<4 * (4 * q * RF + 16 * t)>(xl_o);
                         else bx[q] = lds_read_raw_at<4 * (4 * q * RF + 16 * t)>(xl_b);
                     });
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bx[0]), "+v"(bx[1]), "+v"(bx[2]), "+v"(bx[3]) : : "memory");
-                    if constexpr (SP) {
+                };
+                if constexpr (SP) {
+                    // a feature tile is three short matrix instructions per support now: the next tile's four reads are issued
+                    // before this tile's conversion and products (they were hidden behind 4 x 32-cycle instructions before)
+                    float bxp[2][4];
+                    read_bx(IC<0>{}, bxp[0]);
+                    static_for<0, KC>([&](auto tc) {
+                        constexpr int t = decltype(tc)::value;
+                        float (&bx)[4] = bxp[t & 1];
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bx[0]), "+v"(bx[1]), "+v"(bx[2]), "+v"(bx[3]) : : "memory");
+                        if constexpr (t + 1 < KC) read_bx(IC<t + 1>{}, bxp[(t + 1) & 1]);
                         const SplitReg xb = split_scaled(f32x4{bx[0], bx[1], bx[2], bx[3]}, rsc);
                         if constexpr (s < D) {
 #pragma unroll
@@ -524,16 +558,24 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
                         } else {
                             accC[t] = split_mfma(avs[0], xb, accC[t]);
                         }
-                    } else if constexpr (s < D) {
+                    });
+                } else {
+                    static_for<0, KC>([&](auto tc) {
+                        constexpr int t = decltype(tc)::value;
+                        float bx[4];
+                        read_bx(tc, bx);
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(bx[0]), "+v"(bx[1]), "+v"(bx[2]), "+v"(bx[3]) : : "memory");
+                        if constexpr (s < D) {
 #pragma unroll
-                        for (int b = 0; b < NBS; ++b)
+                            for (int b = 0; b < NBS; ++b)
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[b][q], bx[q], acc[b][t], 0, 0, 0);
-                    } else {
+                                for (int q = 0; q < 4; ++q) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[b][q], bx[q], acc[b][t], 0, 0, 0);
+                        } else {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) accC[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[q], bx[q], accC[t], 0, 0, 0);
-                    }
-                });
+                            for (int q = 0; q < 4; ++q) accC[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[q], bx[q], accC[t], 0, 0, 0);
+                        }
+                    });
+                }
             }
             MKGNN_BPHASE(2);
             // ---- retire / barrier / issue: as in the forward
@@ -678,6 +720,11 @@ void plan_backward_bank_stream(const BwdArgs a4[4], const bool use[4], const flo
             // a wave's time per tile (units of 32 cycles): matrix work + DMA issue, no per-tile epilogue
             const int nbs = d == 4 ? 2 : d;
             cost[ng] = (d * nbs + 1) * 4.0 * KC + 4.0 * d * nbs + 12.0 * d + 60.0;
+            if (KC <= 7 && bwd_split_mode() != 0) {
+                // the split-fp16 products: measured per tile (tools/bwd_stream_stamps.py, batch 4096) at F = 110 and F = 28
+                static const double sp7[4] = {196.0, 317.0, 503.0, 535.0}, sp2[4] = {126.0, 193.0, 298.0, 338.0};
+                cost[ng] = sp2[i] + (sp7[i] - sp2[i]) * (KC - 2) / 5.0;
+            }
             tiles_of[ng] = ntiles;
             cap[ng] = (ntiles + nstream - 1) / nstream;
             nstream_of[ng] = nstream;

@@ -73,6 +73,12 @@ template <int TARGET> __device__ __forceinline__ float split_scale_for(float ama
     f = f > 230 ? 230 : (f < 24 ? 24 : f);
     return __uint_as_float((uint32_t)f << 23);
 }
+// ... from an upper bound of the magnitude's biased exponent
+template <int TARGET> __device__ __forceinline__ float split_scale_for_exponent(int eb) {
+    int f = 254 + TARGET - eb;
+    f = f > 230 ? 230 : (f < 24 ? 24 : f);
+    return __uint_as_float((uint32_t)f << 23);
+}
 template <int EXTRA> __device__ __forceinline__ float split_unscale_of(float scale) {      // 2^-EXTRA / scale
     const int f = (int)(__float_as_uint(scale) >> 23);
     return __uint_as_float((uint32_t)(254 - EXTRA - f) << 23);
