@@ -96,8 +96,7 @@ struct RowsStreamArgs {
 // SP = true (round 5): the products as split fp16 (kgnn_split.h): the masked coefficient tile is the A operand, a lane's four
 // values belong to ONE atom (lane & 15) and are scaled by a power of two taken from the atom's largest coefficient; the bank
 // rows (B operand, register-resident) are split once; the partial tile is scaled back, per atom, where it is written into
-// the exchange image.  k-position (lane >> 4, i) of the 16-deep product stands for kernel 4 i + (lane >> 4): the values a lane
-// holds today (kernels 4 q + kq of atom ci; kernels 4 q + kq of feature 16 t + ci) are its operands as they are.
+// the exchange image.  k-position (lane >> 4, i) of the 16-deep product stands for kernel 4 (lane >> 4) + i (see kix below).
 constexpr int ROWS_COEF_EXP = 10, ROWS_BANK_EXP = 12;
 
 template <int D, int KC, bool SP>
@@ -145,7 +144,10 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
     const float ratio_c = w_c * (float)D / w_s;
     const int8_t* const chp = dg.chir ? dg.chir : (const int8_t*)dg.pair;        // always loadable; ignored without signs
 
-    // coefficient inputs of a tile for this lane: atom ci, kernels 4 q + kq of the wave's column tile (clamped, masked later)
+    // coefficient inputs of a tile for this lane: atom ci, kernels kix(q) of the wave's column tile (clamped, masked later).
+    // fp32 instructions: k-step q holds kernel 4 q + kq.  Split products: the labelling of the 16-deep product's k-positions is
+    // free, and (kq, q) <-> kernel 4 kq + q makes the lane's four coefficients (and ids) ONE 16-byte load of the record row.
+    auto kix = [&](int q) -> int { return SP ? 4 * kq + q : 4 * q + kq; };
     float rg[4];
     int ridx[4], rch[4];
     auto focal_of = [&](int64_t tile) -> int64_t {
@@ -157,11 +159,22 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
         if (records) {
             // the pre-pass (coef_prepare_kernel) has put dL/dsc (signed, zero for padding) and the permutation ids into
             // tile order: two contiguous 1 KB images per (tile, column tile), this lane's entries at atom ci, kernel 4 q + kq
+            if constexpr (SP) {
+                const float* rec = dg.coefq + ((size_t)tile * dg.nct + ctc) * 512 + ci * 16 + 4 * kq;
+                const f32x4 g4 = *(const f32x4*)rec, i4 = *(const f32x4*)(rec + 256);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    rg[q] = g4[q];
+                    ridx[q] = __float_as_int(i4[q]) & 0xff;  // (above the id: the record's largest exponent, for the bank kernel)
+                    rch[q] = 1;
+                }
+                return;
+            }
             const float* rec = dg.coefq + ((size_t)tile * dg.nct + ctc) * 512 + ci * 16 + kq;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 rg[q] = rec[4 * q];
-                ridx[q] = __float_as_int(rec[256 + 4 * q]) & 0xff;      // (above the id: the record's largest exponent, for the bank kernel)
+                ridx[q] = __float_as_int(rec[256 + 4 * q]) & 0xff;
                 rch[q] = 1;
             }
             return;
@@ -170,7 +183,7 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
         const int64_t nc = n < dg.n ? n : dg.n - 1;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int l = ctc * kpt + 4 * q + kq;
+            const int l = ctc * kpt + kix(q);
             const int lc = l < L ? l : L - 1;
             rg[q] = a.gout[focal * a.gs + dg.off + lc];
             ridx[q] = pair_index(dg.pair, (size_t)nc * L + lc);
@@ -191,7 +204,7 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
         int lc[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int i = 4 * q + kq, l = ct * kpt + i;
+            const int i = kix(q), l = ct * kpt + i;
             ok[q] = ct_ok && i < kpt && l < L;
             lc[q] = ok[q] ? l : 0;
         }
@@ -222,7 +235,7 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
         int ix[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int i = 4 * q + kq;
+            const int i = kix(q);
             const bool ok = real && ct_ok && n_mine < dg.n && i < kpt && ct * kpt + i < L;
             const float g = (dg.chir && !records) ? rg[q] * (float)rch[q] : rg[q];
             cf[q] = ok ? g * ws_n : 0.f;

@@ -155,7 +155,10 @@ template <int D, int KC> constexpr int young_batches(int s, int role) {
 // One thread per (atom of a tile, column of a column tile): the pair's dL/dsc (times the chirality sign) and
 // permutation id into tile order, zeros for padding; the three score-weight partials summed per block in a fixed order.
 typedef unsigned short pk_u16 __attribute__((ext_vector_type(2)));
-constexpr int PREP_RPB = 4;                              // records per block: four independent load chains per thread
+#ifndef MKGNN_PREP_RPB
+#define MKGNN_PREP_RPB 4
+#endif
+constexpr int PREP_RPB = MKGNN_PREP_RPB;                              // records per block: four independent load chains per thread
 __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
     int di = 0;
 #pragma unroll
@@ -214,8 +217,10 @@ __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
         S[r] = pr[0]; C[r] = pr[1]; Ed[r] = pr[2];
     }
     float p0 = 0.f, p1 = 0.f, p2 = 0.f;
-    static_assert(PREP_RPB == 4, "the records' exponent maxima travel as two pairs of 16-bit fields");
-    pk_u16 em01 = {0, 0}, em23 = {0, 0};                 // biased exponents of |g| of the block's four records
+    constexpr int NEM = (PREP_RPB + 1) / 2;
+    pk_u16 em[NEM];                                      // biased exponents of |g| of the block's records, two per register
+#pragma unroll
+    for (int i = 0; i < NEM; ++i) em[i] = pk_u16{0, 0};
 #pragma unroll
     for (int r = 0; r < PREP_RPB; ++r) {
         const int64_t rec = blk * PREP_RPB + r;
@@ -225,7 +230,7 @@ __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
             out[tid] = gg;
         }
         const unsigned short eb = (unsigned short)((__float_as_uint(gg) >> 23) & 0xffu);
-        if (r < 2) em01[r & 1] = eb; else em23[r & 1] = eb;
+        em[r >> 1][r & 1] = eb;
         if (ok[r]) {
             const float sc = (S[r] * w_s + C[r] * w_c + Ed[r] * w_e) / w_sum;
             p0 = fmaf(gg * (w_s / w_sum), S[r] - sc, p0);
@@ -235,31 +240,33 @@ __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
     }
     // fixed-order block sums; the records' largest exponents (a maximum: order-free)
     __shared__ float red[3][4];
-    __shared__ uint32_t emx[2][4];
+    __shared__ uint32_t emx[NEM][4];
     p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        em01 = __builtin_elementwise_max(em01, __builtin_bit_cast(pk_u16, __shfl_xor(__builtin_bit_cast(uint32_t, em01), o, 64)));
-        em23 = __builtin_elementwise_max(em23, __builtin_bit_cast(pk_u16, __shfl_xor(__builtin_bit_cast(uint32_t, em23), o, 64)));
-    }
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int i = 0; i < NEM; ++i)
+            em[i] = __builtin_elementwise_max(em[i], __builtin_bit_cast(pk_u16, __shfl_xor(__builtin_bit_cast(uint32_t, em[i]), o, 64)));
     if ((tid & 63) == 0) {
         red[0][tid >> 6] = p0; red[1][tid >> 6] = p1; red[2][tid >> 6] = p2;
-        emx[0][tid >> 6] = __builtin_bit_cast(uint32_t, em01); emx[1][tid >> 6] = __builtin_bit_cast(uint32_t, em23);
+#pragma unroll
+        for (int i = 0; i < NEM; ++i) emx[i][tid >> 6] = __builtin_bit_cast(uint32_t, em[i]);
     }
     __syncthreads();
     {
         // idx words: the permutation id in the low byte, the record's largest exponent above it (what the bank kernel's
         // split-fp16 products scale by: kgnn_split.h) -- every word of a record carries it, no reduction where it is read
-        pk_u16 m01 = __builtin_bit_cast(pk_u16, emx[0][0]), m23 = __builtin_bit_cast(pk_u16, emx[1][0]);
+        pk_u16 mx[NEM];
 #pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            m01 = __builtin_elementwise_max(m01, __builtin_bit_cast(pk_u16, emx[0][w]));
-            m23 = __builtin_elementwise_max(m23, __builtin_bit_cast(pk_u16, emx[1][w]));
+        for (int i = 0; i < NEM; ++i) {
+            mx[i] = __builtin_bit_cast(pk_u16, emx[i][0]);
+#pragma unroll
+            for (int w = 1; w < 4; ++w) mx[i] = __builtin_elementwise_max(mx[i], __builtin_bit_cast(pk_u16, emx[i][w]));
         }
 #pragma unroll
         for (int r = 0; r < PREP_RPB; ++r) {
             const int64_t rec = blk * PREP_RPB + r;
-            const int me = r < 2 ? m01[r & 1] : m23[r & 1];
+            const int me = mx[r >> 1][r & 1];
             if (rec < nrec) ((int*)(g.coefq + (size_t)rec * 512))[256 + tid] = (ok[r] ? idx[r] : 0) | (me << 8);
         }
     }
