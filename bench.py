@@ -27,6 +27,16 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guides/MI355X_MICROARCH
 FP32_VECTOR_PEAK_TFLOPS = 157.3
 
 
+def products_mode(variant: str) -> dict:
+    """What the streamed kernels multiply with (read from the same environment switches the library reads)."""
+    fwd = "bf16 operands (similarity variant)" if variant == "bf16" else (
+        "fp32 out of split fp16: 3 x v_mfma_f32_16x16x16_f16 on exact hi + lo operands, fp32 accumulation"
+        if os.environ.get("MKGNN_FWD_SPLIT", "1") != "0" else "v_mfma_f32_16x16x4_f32")
+    bwd = ("fp32 out of split fp16 (as the forward)" if os.environ.get("MKGNN_BWD_SPLIT", "1") != "0" else "v_mfma_f32_16x16x4_f32")
+    return {"forward": fwd, "backward": bwd, "accuracy": "fp32-grade: tests/test_scale_parity.py::test_split_fp16_products_are_fp32_grade "
+            "(against float64: no worse than the fp32 matrix instructions)", "switches": "MKGNN_FWD_SPLIT=0 / MKGNN_BWD_SPLIT=0 restore the fp32 instructions"}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -953,6 +963,10 @@ def main():
                     "algorithmic_bytes": by, "algorithmic_flops": fl,
                     "fp32_tflops": round(fl / (ms * 1e-3) / 1e12, 3),
                     "fp32_vector_frac": round(fl / (ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 5),
+                    # how the node-feature products are computed: fp32_frac / fp32_vector_frac are the rate of
+                    # useful fp32 multiply-adds against the fp32 peak, not a pipe utilisation -- the split products run at
+                    # the fp16 matrix rate, three instructions of 8 cycles in place of four of 32
+                    "products": products_mode(args.variant),
                     "kernels": kernels}
         out = {"metric": "molecules/sec fwd+bwd, 3-layer MolKGNN on AID 1798", "value": round(value, 1),
                "unit": "molecules/s", "n_gpus": (ranks_seen if ranks_seen is not None else world), "steps": args.steps, "warmup": args.warmup,
