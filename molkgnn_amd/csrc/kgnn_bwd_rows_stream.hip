@@ -33,6 +33,11 @@
 #include "kgnn_launch.h"
 #include "kgnn_split.h"
 
+// (A/B build: degree 1, whose stream is one wave, stores its chunks straight from the registers instead of going through the
+// exchange image -- 64-byte pieces of a row per instruction instead of whole 448-byte rows: measured 62-67 us against 57)
+#ifndef MKGNN_ROWS_DIRECT
+#define MKGNN_ROWS_DIRECT 0
+#endif
 #ifndef MKGNN_ROWS_RS_PAD                    // (A/B builds: make VARIANT=rspad0 EXTRA=-DMKGNN_ROWS_RS_PAD=0 is a linear image)
 #define MKGNN_ROWS_RS_PAD 4
 #endif
@@ -95,8 +100,9 @@ struct RowsStreamArgs {
 
 // SP = true (round 5): the products as split fp16 (kgnn_split.h): the masked coefficient tile is the A operand, a lane's four
 // values belong to ONE atom (lane & 15) and are scaled by a power of two taken from the atom's largest coefficient; the bank
-// rows (B operand, register-resident) are split once; the partial tile is scaled back, per atom, where it is written into
-// the exchange image.  k-position (lane >> 4, i) of the 16-deep product stands for kernel 4 (lane >> 4) + i (see kix below).
+// rows (register-resident) are split once; the tile is computed TRANSPOSED (bank as A, coefficients as B), so that a lane
+// holds sixteen contiguous bytes of its own atom's row: scaled back by the lane's own factor, written to the exchange image
+// with one 16-byte LDS write per feature tile (degree 1, a single column tile: straight to memory).  k-position (lane >> 4, i) of the 16-deep product stands for kernel 4 (lane >> 4) + i (see kix below).
 constexpr int ROWS_COEF_EXP = 10, ROWS_BANK_EXP = 12;
 
 template <int D, int KC, bool SP>
@@ -125,7 +131,6 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
     // kernel's time -- 72.4 / 72.8 us: the exchange is ~4 % of its wave cycles.)
     constexpr int RS = FP + MKGNN_ROWS_RS_PAD;
     float* const xbuf = lds + (size_t)stream * (2 * NS * 16 * RS);
-    [[maybe_unused]] float* const ubuf = lds + (size_t)NSTREAM * (2 * NS * 16 * RS) + wave * 16;     // (SP) 1 / scale of the tile's atoms
 
     const int64_t ntiles = (dg.n + 15) / 16;
     const int64_t nstreams = (int64_t)count * NSTREAM;
@@ -244,20 +249,16 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
         // next tile's inputs: in flight during this tile's matrix work
         issue(tile_at(it + 1), focal_next);
         if (!records) focal_next = focal_of(tile_at(it + 2));
-        // (SP) the atom's scale: its largest coefficient (the centre's ratio included) to [2^10, 2^11); the reciprocals of
-        // the four atoms this lane's result rows belong to (rows 4 kq + r) come back through LDS
-        [[maybe_unused]] float sca = 1.f;
-        [[maybe_unused]] f32x4 unsc = {1.f, 1.f, 1.f, 1.f};
+        // (SP) the atom's scale: its largest coefficient (the centre's ratio included) to [2^10, 2^11); the result the lane
+        // holds is the same atom's (transposed tile, below), so it undoes its own scale
+        [[maybe_unused]] float sca = 1.f, unsc = 1.f;
         if constexpr (SP) {
             float am = fmaxf(fmaxf(fabsf(cf[0]), fabsf(cf[1])), fmaxf(fabsf(cf[2]), fabsf(cf[3])));
             am = fmaxf(am, __shfl_xor(am, 16));
             am = fmaxf(am, __shfl_xor(am, 32));
             am *= fmaxf(1.f, fabsf(ratio_c));
             sca = split_scale_for<ROWS_COEF_EXP>(am);
-            if (kq == 0) ubuf[ci] = split_unscale_of<ROWS_BANK_EXP>(sca);
-            __builtin_amdgcn_wave_barrier();
-            unsc = *(const f32x4*)(ubuf + 4 * kq);
-            __builtin_amdgcn_wave_barrier();             // (the next tile's write stays behind this read)
+            unsc = split_unscale_of<ROWS_BANK_EXP>(sca);
         }
         MKGNN_RPHASE(0);
 
@@ -267,13 +268,17 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
 #pragma unroll
             for (int t = 0; t < KC; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (SP) {
-                auto multiply = [&](const SplitReg& av, const SplitReg* row) {      // three instructions per feature tile, KC independent chains
+                // The TRANSPOSED tile: the bank registers as the A operand (feature 16 t + ci x kernels), the coefficients as B
+                // (kernels x atom ci) -- the same registers either way round -- so that a lane ends up with features
+                // 16 t + 4 kq .. + 3 of atom ci: sixteen contiguous bytes of that atom's contribution row, and the atom's scale is
+                // the lane's own.  Three instructions per feature tile, KC independent chains.
+                auto multiply = [&](const SplitReg& av, const SplitReg* row) {
 #pragma unroll
-                    for (int t = 0; t < KC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(av.lo, row[t].hi, acc[t], 0, 0, 0);
+                    for (int t = 0; t < KC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(row[t].hi, av.lo, acc[t], 0, 0, 0);
 #pragma unroll
-                    for (int t = 0; t < KC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(av.hi, row[t].lo, acc[t], 0, 0, 0);
+                    for (int t = 0; t < KC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(row[t].lo, av.hi, acc[t], 0, 0, 0);
 #pragma unroll
-                    for (int t = 0; t < KC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(av.hi, row[t].hi, acc[t], 0, 0, 0);
+                    for (int t = 0; t < KC; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(row[t].hi, av.hi, acc[t], 0, 0, 0);
                 };
                 if constexpr (s == 0) {
                     multiply(split_scaled(f32x4{cf[0] * ratio_c, cf[1] * ratio_c, cf[2] * ratio_c, cf[3] * ratio_c}, sca), bk[D]);
@@ -314,15 +319,34 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
             // share of the atoms 16 bytes at a time and stores whole 16-byte chunks of contiguous 448-byte rows.
             MKGNN_RPHASE(1);
             float* const mine = xbuf + (size_t)((par * NS + role) * 16) * RS;
+            if constexpr (SP && NS == 1 && MKGNN_ROWS_DIRECT) {
+                // one column tile per degree: the lane's chunks ARE the contribution row's -- straight to memory, no exchange
+                const int64_t nn = tile * 16 + ci;
+                if (real && nn < dg.n) {
+                    float* const row = dg.contrib + (size_t)(dg.contrib_base + nn * S1 + s) * a.CS + 4 * kq;
+                    const int F4 = (a.F + 3) / 4;
 #pragma unroll
-            for (int t = 0; t < KC; ++t)
+                    for (int t = 0; t < KC; ++t)
+                        if (4 * t + kq < F4) {
+                            f32x4 v = acc[t];
+                            if (add) v += *(const f32x4*)(row + 16 * t);
+                            *(f32x4*)(row + 16 * t) = v;
+                        }
+                }
+            } else if constexpr (SP) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) mine[(kq * 4 + r) * RS + 16 * t + ci] = acc[t][r];
+                for (int t = 0; t < KC; ++t) *(f32x4*)(mine + ci * RS + 16 * t + 4 * kq) = acc[t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < KC; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) mine[(kq * 4 + r) * RS + 16 * t + ci] = acc[t][r];
+            }
             MKGNN_RPHASE(2);
             if constexpr (NS > 1) __syncthreads();
             else __builtin_amdgcn_wave_barrier();        // (own image: LDS accesses of one wave are ordered)
             MKGNN_RPHASE(3);
-            {
+            if constexpr (!(SP && NS == 1 && MKGNN_ROWS_DIRECT)) {
                 constexpr int APW = 16 / NS;             // atoms this wave finishes
                 constexpr int CPR = FP / 4;              // 16-byte chunks per row
                 static_assert(CPR <= 64, "at most one wave per row");
@@ -505,8 +529,8 @@ static hipError_t launch_rows_pass(const BwdArgs a4[4], const bool use[4], float
     for (int g = 0; g < ng; ++g) a.grp_count[g] = (uint16_t)count[g];
     if (cp == 0) note_plan(1, nb, ng, tiles_of, count, nstream_of);
     g_last_plan[1].launches.fetch_add(1);
-    // NSTREAM * NS = 4 wave images of 16 rows, two parities; + 4 x 16 reciprocal scales (split products)
-    const size_t lds_bytes = (size_t)4 * 2 * 16 * (16 * KC + MKGNN_ROWS_RS_PAD) * 4 + 256;
+    // NSTREAM * NS = 4 wave images of 16 rows, two parities
+    const size_t lds_bytes = (size_t)4 * 2 * 16 * (16 * KC + MKGNN_ROWS_RS_PAD) * 4;
     if (KC <= 7 && bwd_split_mode() != 0) {
         switch (KC) {
             case 1: return launch_rows_kc<1, true>(a, nb, lds_bytes, st);
