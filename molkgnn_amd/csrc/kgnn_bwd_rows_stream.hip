@@ -223,7 +223,7 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
                     const float e = dg.padded[((size_t)b * L + lc[q]) * FPB + 16 * t + ci];
                     v[q] = ok[q] ? e : 0.f;
                 }
-                if constexpr (SP) bk[b][t] = split_f16(v * (float)(1 << ROWS_BANK_EXP));
+                if constexpr (SP) bk[b][t] = split_scaled(v, (float)(1 << ROWS_BANK_EXP));
                 else bk[b][t] = v;
             }
     }

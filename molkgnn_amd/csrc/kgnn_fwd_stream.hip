@@ -339,7 +339,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
             for (int t = 0; t < KC; ++t) {
                 f32x4 v = *(const f32x4*)(dg.padded + ((size_t)b * L + l) * FPB + 16 * t + 4 * kq);
                 if (zero) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (BF == 2) bk[bl][t] = split_f16(v * (float)(1 << SPLIT_BANK_EXP));
+                if constexpr (BF == 2) bk[bl][t] = split_scaled(v, (float)(1 << SPLIT_BANK_EXP));     // (10 instructions; the compiler's split_f16: 17)
                 else if constexpr (BF == 1) bk[bl][t] = to_bf16x4s(v);
                 else bk[bl][t] = v;
             }
@@ -445,6 +445,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
     }
 #ifdef MKGNN_FWD_STAMPS
     unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_phase = __builtin_readcyclecounter();
+    phase[7] = t_phase - t_start;                        // the prologue: bank into registers, tile 0's ids, rows and record
 #endif
     for (int it = 0; it < iters; ++it) {
         const int tile = tile_at(it);

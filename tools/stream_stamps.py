@@ -60,5 +60,5 @@ for g in sorted(set(s[:, 2].tolist())):
           f"end {end.min():.2f}..{end.max():.2f} us (mean {end.mean():.2f}); lifetime cycles mean {lf.mean():.0f} max {lf.max():.0f}")
     if int(m[:, 4:12].sum()) > 0:                    # make STAMPS=1: cycles per phase, mean over the group's waves
         ph = m[:, 4:12].float().mean(dim=0).tolist()
-        print("        multiply %.0f  counted wait %.0f  barrier %.0f  DMA issue %.0f  epilogue: scan %.0f  bonds %.0f  mix+stores %.0f" %
-              (ph[0], ph[1], ph[2], ph[3], ph[5], ph[6], ph[4]))
+        print("        prologue %.0f  multiply %.0f  counted wait %.0f  barrier %.0f  DMA issue %.0f  epilogue: scan %.0f  bonds %.0f  mix+stores %.0f" %
+              (ph[7], ph[0], ph[1], ph[2], ph[3], ph[5], ph[6], ph[4]))
