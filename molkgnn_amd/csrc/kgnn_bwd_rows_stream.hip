@@ -132,15 +132,16 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
     constexpr int RS = FP + MKGNN_ROWS_RS_PAD;
     float* const xbuf = lds + (size_t)stream * (2 * NS * 16 * RS);
 
-    const int64_t ntiles = (dg.n + 15) / 16;
-    const int64_t nstreams = (int64_t)count * NSTREAM;
-    const int64_t sg = (int64_t)rank * NSTREAM + stream;
-    const int64_t tile_first = sg * ntiles / nstreams;
-    const int64_t tile_end = (sg + 1) * ntiles / nstreams;
-    const int64_t iters = (ntiles + nstreams - 1) / nstreams;
-    const int64_t tile_hi = (tile_end > tile_first ? tile_end : (tile_first + 1 < ntiles ? tile_first + 1 : ntiles)) - 1;
-    auto tile_at = [&](int64_t i) -> int64_t {
-        const int64_t t = tile_first + i;
+    // (tile bookkeeping in 32 bits -- the streamed kernels take n_atoms * stride < 2^30 only; addresses stay 64-bit)
+    const int ntiles = (int)((dg.n + 15) / 16);
+    const int nstreams = count * NSTREAM;
+    const int sg = rank * NSTREAM + stream;
+    const int tile_first = (int)((int64_t)sg * ntiles / nstreams);
+    const int tile_end = (int)((int64_t)(sg + 1) * ntiles / nstreams);
+    const int iters = (ntiles + nstreams - 1) / nstreams;
+    const int tile_hi = (tile_end > tile_first ? tile_end : (tile_first + 1 < ntiles ? tile_first + 1 : ntiles)) - 1;
+    auto tile_at = [&](int i) -> int {
+        const int t = tile_first + i;
         return t > tile_hi ? tile_hi : t;
     };
 
@@ -159,7 +160,8 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
         const int64_t n = tile * 16 + ci;
         return dg.sel[n < dg.n ? n : dg.n - 1];
     };
-    const bool records = dg.coefq != nullptr;
+    // (the split body is launched with the pre-pass's records only: launch_rows_pass -- no gather path, fewer registers)
+    const bool records = SP ? true : (dg.coefq != nullptr);
     auto issue = [&](int64_t tile, int64_t focal) {
         if (records) {
             // the pre-pass (coef_prepare_kernel) has put dL/dsc (signed, zero for padding) and the permutation ids into
@@ -232,7 +234,7 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
     const unsigned long long t_start = __builtin_readcyclecounter();
     unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_phase = t_start;
 #endif
-    for (int64_t it = 0; it < iters; ++it) {
+    for (int it = 0; it < iters; ++it) {
         const int64_t tile = tile_at(it);
         const bool real = tile_first + it < tile_end;
         const int64_t n_mine = tile * 16 + ci;
@@ -531,7 +533,7 @@ static hipError_t launch_rows_pass(const BwdArgs a4[4], const bool use[4], float
     g_last_plan[1].launches.fetch_add(1);
     // NSTREAM * NS = 4 wave images of 16 rows, two parities
     const size_t lds_bytes = (size_t)4 * 2 * 16 * (16 * KC + MKGNN_ROWS_RS_PAD) * 4;
-    if (KC <= 7 && bwd_split_mode() != 0) {
+    if (KC <= 7 && bwd_split_mode() != 0 && coefq) {
         switch (KC) {
             case 1: return launch_rows_kc<1, true>(a, nb, lds_bytes, st);
             case 2: return launch_rows_kc<2, true>(a, nb, lds_bytes, st);
