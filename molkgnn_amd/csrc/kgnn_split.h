@@ -13,9 +13,9 @@ typedef float split_f32x4 __attribute__((ext_vector_type(4)));
 // hi hi' + hi lo' + lo hi' (the dropped lo lo' <= 2^-24 |x y|): three v_mfma_f32_16x16x16_f16 of 8 cycles in place of four
 // v_mfma_f32_16x16x4_f32 of 32, fp32 accumulation as before.  The error per product is that of ONE fp32 rounding -- measured
 // against float64 the sums are as close as the fp32 fma chain's (tests/test_scale_parity.py) -- provided nothing under- or
-// overflows in fp16: bank rows are unit rows, scaled by 2^8 before the split; an atom's row (a lane's A operand belongs to
-// ONE atom: lane & 15) is scaled by 2^(exponent(1 / |x|) + 8), i.e. to a norm in [256, 512), and the two powers of two
-// leave through the 1 / |x| factor the epilogue multiplies with anyway (exponent field set to -16: exact).
+// overflows in fp16 (normal numbers: 2^-14 .. 2^16): every user scales its operands by exact powers of two first and takes
+// them out of the result again -- the forward per atom row and per bank row (kgnn_fwd_stream.hip, BF = 2), the rows kernel
+// per atom (kgnn_bwd_rows_stream.hip), the bank kernel per atom row and per wave (kgnn_bwd_stream.hip).
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 struct SplitReg { h16x4 hi, lo; };
 __device__ __forceinline__ SplitReg split_f16(split_f32x4 v) {
