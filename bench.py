@@ -978,6 +978,9 @@ def main():
                "graph_replay": graphs is not None,       # False: the capture failed (or --no-graph) and the steps were launched eagerly
                "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "bf16 dot products, f32 otherwise" if args.variant == "bf16" else "f32",
+               # (f32 in, f32 out, f32 accumulation; the node-feature products are formed from exact fp16 halves of the f32
+               # operands unless MKGNN_FWD_SPLIT=0 / MKGNN_BWD_SPLIT=0 -- roofline.products; fp32-grade against float64)
+               "dtype_note": products_mode(args.variant)["forward"],
                "data": "synthetic",
                **({"dp_replicas_max_abs_diff": replicas_diff} if replicas_diff is not None else {}),
                **dp_info,
