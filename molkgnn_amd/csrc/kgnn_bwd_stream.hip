@@ -159,10 +159,13 @@ typedef unsigned short pk_u16 __attribute__((ext_vector_type(2)));
 #define MKGNN_PREP_RPB 4
 #endif
 constexpr int PREP_RPB = MKGNN_PREP_RPB;                              // records per block: four independent load chains per thread
-__global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
-    int di = 0;
-#pragma unroll
-    for (int k = 1; k < 4; ++k) if (a.deg[k].prep_blocks > 0 && (int)blockIdx.x >= a.deg[k].prep_blk0) di = k;
+// NSRC: rows of grad_out a pair's dL/dsc is summed from -- 1 (the focal atom's) or, through_nei, the degree's D neighbours'.
+// A template parameter since round 5: with a run-time count the four clamped loads of ids and of rows were issued for every
+// degree (the kernel is bound by its vector-memory instructions: TA busy 60 %), two of three of them redundant at degree 1 and
+// half of them at degree 2, the largest group.
+// CH: the degree keeps chirality signs (degree 4 of the last layer) -- otherwise their load is not issued at all.
+template <int NSRC, bool CH>
+__device__ __forceinline__ void coef_prepare_body(const BankStreamArgs& a, const int di) {
     const BankStreamDeg& g = a.deg[di];
     const int tid = threadIdx.x;
     const int64_t blk = (int64_t)blockIdx.x - g.prep_blk0;
@@ -177,8 +180,8 @@ __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
     // the rows of grad_out this pair's dL/dsc comes from: the focal atom's, or (through_nei: the propagate step's
     // gradient folded in, KernelLayer.py:119-123) the rows of its D neighbours, summed in slot order
     const int D = di + 1;
-    const int nsrc = a.through_nei ? D : 1;
-    int64_t src[PREP_RPB][MKGNN_MAX_DEGREE];
+    constexpr int nsrc = NSRC;
+    int64_t src[PREP_RPB][NSRC];
 #pragma unroll
     for (int r = 0; r < PREP_RPB; ++r) {
         const int64_t rec = blk * PREP_RPB + r;
@@ -190,10 +193,7 @@ __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
         const int l = ct * g.kpt + k;
         ok[r] = rec < nrec && n < g.n && k < g.kpt && l < g.L;
 #pragma unroll
-        for (int s = 0; s < MKGNN_MAX_DEGREE; ++s) {
-            const int sc = s < nsrc ? s : nsrc - 1;      // (clamped: the loads are unconditional, the sum below is not)
-            src[r][s] = a.through_nei ? g.nei[nc * D + sc] : g.sel[nc];
-        }
+        for (int s = 0; s < NSRC; ++s) src[r][s] = a.through_nei ? g.nei[nc * D + s] : g.sel[nc];
     }
 #pragma unroll
     for (int r = 0; r < PREP_RPB; ++r) {
@@ -205,15 +205,15 @@ __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
         const int64_t nc = n < g.n ? n : g.n - 1;
         const int l = ct * g.kpt + k, lc = l < g.L ? l : g.L - 1;
         const size_t o = (size_t)nc * g.L + lc;
-        float gs4[MKGNN_MAX_DEGREE];
+        float gs4[NSRC];
 #pragma unroll
-        for (int s = 0; s < MKGNN_MAX_DEGREE; ++s) gs4[s] = a.gout[src[r][s] * a.gs + g.off + lc];
+        for (int s = 0; s < NSRC; ++s) gs4[s] = a.gout[src[r][s] * a.gs + g.off + lc];
         gv[r] = gs4[0];
 #pragma unroll
-        for (int s = 1; s < MKGNN_MAX_DEGREE; ++s) if (s < nsrc) gv[r] += gs4[s];
+        for (int s = 1; s < NSRC; ++s) gv[r] += gs4[s];                  // (slot order, as before)
         const mkgnn_f32x4 pr = pair_load(g.pair, o);
         idx[r] = pair_index(pr);
-        ch[r] = chp[o];
+        ch[r] = CH ? (int)chp[o] : 1;
         S[r] = pr[0]; C[r] = pr[1]; Ed[r] = pr[2];
     }
     float p0 = 0.f, p1 = 0.f, p2 = 0.f;
@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
 #pragma unroll
     for (int r = 0; r < PREP_RPB; ++r) {
         const int64_t rec = blk * PREP_RPB + r;
-        float gg = ok[r] ? (g.chir ? gv[r] * (float)ch[r] : gv[r]) : 0.f;
+        float gg = ok[r] ? (CH ? gv[r] * (float)ch[r] : gv[r]) : 0.f;
         if (rec < nrec) {
             float* out = g.coefq + (size_t)rec * 512;
             out[tid] = gg;
@@ -271,6 +271,28 @@ __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
         }
     }
     if (tid < 3) g.theta_slab[(size_t)blk * 4 + tid] = (red[tid][0] + red[tid][1]) + (red[tid][2] + red[tid][3]);
+}
+
+__global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
+    int di = 0;
+#pragma unroll
+    for (int k = 1; k < 4; ++k) if (a.deg[k].prep_blocks > 0 && (int)blockIdx.x >= a.deg[k].prep_blk0) di = k;
+    const int nsrc = a.through_nei ? di + 1 : 1;         // (block-uniform, like the sign test)
+    if (a.deg[di].chir) {
+        switch (nsrc) {
+            case 1: coef_prepare_body<1, true>(a, di); break;
+            case 2: coef_prepare_body<2, true>(a, di); break;
+            case 3: coef_prepare_body<3, true>(a, di); break;
+            default: coef_prepare_body<4, true>(a, di); break;
+        }
+        return;
+    }
+    switch (nsrc) {
+        case 1: coef_prepare_body<1, false>(a, di); break;
+        case 2: coef_prepare_body<2, false>(a, di); break;
+        case 3: coef_prepare_body<3, false>(a, di); break;
+        default: coef_prepare_body<4, false>(a, di); break;
+    }
 }
 
 // ------------------------------------------------------------ main body ---
