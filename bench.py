@@ -33,7 +33,13 @@ def products_mode(variant: str) -> dict:
         "fp32 out of split fp16: 3 x v_mfma_f32_16x16x16_f16 on exact hi + lo operands, fp32 accumulation"
         if os.environ.get("MKGNN_FWD_SPLIT", "1") != "0" else "v_mfma_f32_16x16x4_f32")
     bwd = ("fp32 out of split fp16 (as the forward)" if os.environ.get("MKGNN_BWD_SPLIT", "1") != "0" else "v_mfma_f32_16x16x4_f32")
-    return {"forward": fwd, "backward": bwd, "accuracy": "fp32-grade: tests/test_scale_parity.py::test_split_fp16_products_are_fp32_grade "
+    split_rows = (variant in ("auto", "mfma") and os.environ.get("MKGNN_ROWS_SPLIT", "1") != "0"
+                  and os.environ.get("MKGNN_FWD_SPLIT", "1") != "0" and os.environ.get("MKGNN_BWD_SPLIT", "1") != "0")
+    return {"forward": fwd, "backward": bwd,
+            "rows": ("h between two layers is written by propagate as the fp16 hi | lo halves the matrix instructions take "
+                     "(pre-split rows, DESIGN 4.1f): same bytes, the forward's scores bit for bit; MKGNN_ROWS_SPLIT=0 keeps fp32 rows"
+                     if split_rows else "fp32"),
+            "accuracy": "fp32-grade: tests/test_scale_parity.py::test_split_fp16_products_are_fp32_grade "
             "(against float64: no worse than the fp32 matrix instructions)", "switches": "MKGNN_FWD_SPLIT=0 / MKGNN_BWD_SPLIT=0 restore the fp32 instructions"}
 
 
@@ -149,6 +155,79 @@ def time_backward_kernels(lib, Fn, h, plan, params, E, variant, reps):
             p_.grad = None
     names = ("coef_prepare_kernel", "kc_backward_rows_stream", "kc_backward_bank_stream", "kc_backward_bank_reduce", "csr_rows_kernel<gather>")
     return {n_: (acc[k] / cnt[k] if cnt[k] else None) for k, n_ in enumerate(names)}
+
+
+def exact_fp32_leg(args, model, opt, dev, batches, log):
+    """The same step with the node-feature products on the exact fp32 matrix instructions (v_mfma_f32_16x16x4_f32, bit for bit an
+    fmaf chain: rounds 1-4's arithmetic; MKGNN_FWD_SPLIT=0 MKGNN_BWD_SPLIT=0) instead of three fp16 ones on exactly split
+    operands -- what the split buys, timed by the same clock in the same run (missing 4).  Graphs of the same
+    resident batches, captured with the run-time switches set; the N-hop forward kernel alone by HIP events as in `roofline`."""
+    import ctypes
+    from molkgnn_amd import _lib
+    from molkgnn_amd import functional as Fn
+    from molkgnn_amd.plan import plan_from_data
+    from molkgnn_amd.train import backward as train_backward
+    lib = _lib.load()
+    lib.mkgnn_debug_last_fused_forward_ms.restype = ctypes.c_float
+    Fn.debug_set_products(0, 0)
+    try:
+        graphs = []
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for b in batches[:2]:
+                model.zero_grad(set_to_none=True)
+                train_backward(model.loss(b))
+                if opt is not None:
+                    opt.step()
+            for b in batches:
+                model.zero_grad(set_to_none=True)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=side):
+                    train_backward(model.loss(b))
+                    if opt is not None:
+                        opt.step()
+                graphs.append(g)
+        torch.cuda.current_stream().wait_stream(side)
+        for g in graphs:
+            g.replay()
+        torch.cuda.synchronize()
+        wins = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(args.steps):
+                graphs[i % len(graphs)].replay()
+            torch.cuda.synchronize()
+            wins.append((time.perf_counter() - t0) / args.steps)
+        wins.sort()
+        del graphs
+        # the N-hop forward kernel alone, as in `roofline`
+        b = batches[0]
+        plan = plan_from_data(b)
+        layer = model.gnn_model.gnn.layers[1]
+        params, E = layer._bank_params("train", b.x)
+        K_in = model.gnn_model.gnn.num_kernels(0)
+        gen = torch.Generator(device=dev).manual_seed(1)
+        h_store = torch.zeros(b.x.shape[0], K_in + (-K_in) % 4, device=dev)
+        h_store[:, :K_in] = torch.rand(b.x.shape[0], K_in, generator=gen, device=dev) * 2 - 1
+        h = h_store[:, :K_in]
+        for _ in range(3):
+            Fn.kernelsetconv_details(h, plan, False, params, E, args.variant, raw=True)
+        lib.mkgnn_debug_time_fused_forward(max(2, args.roofline_reps))
+        samples = []
+        for _ in range(9):
+            Fn.kernelsetconv_details(h, plan, False, params, E, args.variant, raw=True)
+            samples.append(float(lib.mkgnn_debug_last_fused_forward_ms()))
+        lib.mkgnn_debug_time_fused_forward(0)
+        fwd_ms = sorted(samples)[len(samples) // 2]
+        return {"what": "the same step and the same N-hop forward kernel with the node-feature products on v_mfma_f32_16x16x4_f32 "
+                        "(exact fp32: MKGNN_FWD_SPLIT=0 MKGNN_BWD_SPLIT=0), h between layers as fp32 rows",
+                "ms_per_step": round(1e3 * wins[len(wins) // 2], 4), "ms_per_step_min": round(1e3 * wins[0], 4),
+                "forward_kernel_ms": round(fwd_ms, 5),
+                "products": {"forward": "v_mfma_f32_16x16x4_f32", "backward": "v_mfma_f32_16x16x4_f32", "rows": "fp32"}}
+    finally:
+        Fn.debug_set_products(-1, -1)
 
 
 def small_batch_leg(args, model, opt, dev, log):
@@ -1002,6 +1081,11 @@ def main():
             leg_model.gnn_model.gnn.set_variant(args.variant)
             leg_model.train()
             leg_opt = None if args.no_optimizer else configure_optimizer(leg_model, lr=1e-3, capturable=not args.no_graph)
+        if args.variant in ("auto", "mfma") and not os.environ.get("MKGNN_NO_EXACT_LEG"):
+            try:
+                out["exact_fp32_instructions"] = exact_fp32_leg(args, leg_model, leg_opt, dev, batches, log)
+            except Exception as exc:                         # (reported, not fatal)
+                out["exact_fp32_instructions"] = {"error": f"{type(exc).__name__}: {exc}"}
         if args.fresh_batches > 0:
             try:
                 out["fresh_batches"] = fresh_batches_leg(args, leg_model, leg_opt, dev, log)

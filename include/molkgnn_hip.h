@@ -38,7 +38,7 @@ extern "C" {
 #endif
 
 #define MKGNN_MAX_DEGREE 4
-#define MKGNN_ABI_VERSION 5
+#define MKGNN_ABI_VERSION 6
 
 /* One KernelConv's parameters (reference kernels.py:50-84).  The three score
  * weights are the 0-d parameters support_attr_sc_weight, center_attr_sc_weight
@@ -132,6 +132,14 @@ size_t mkgnn_workspace_bytes(const int32_t num_kernels[MKGNN_MAX_DEGREE], int32_
 /*          | MKGNN_VARIANT_BANK_PREPARED: `workspace` already holds this call's normalised kernel bank, written by
  *              mkgnn_bank_prepare for these banks, F and E since the parameters last changed. */
 #define MKGNN_VARIANT_BANK_PREPARED 0x200
+/*          | MKGNN_VARIANT_ROWS_SPLIT (ABI v6): the rows of `x` are PRE-SPLIT -- written by mkgnn_segment_sum_block_rows mode 3 (or
+ *              mkgnn_batchnorm_forward* with MKGNN_BN_SPLIT_ROWS): every four consecutive floats x[4 g .. 4 g + 3] of a row are stored
+ *              as the sixteen bytes  fp16 hi(0..3) | fp16 lo(0..3)  of x * 2^(exponent(inv_norm[n]) + 8), hi = fp16(.), lo =
+ *              fp16(. - hi) -- the operand the streamed kernels' matrix instructions take, so that no wave converts a row again
+ *              (same bytes per row, same strides; the forward's scores are bit for bit those of the fp32 rows).  Such rows
+ *              exist only between two calls of this library (the reference's h = propagate(sim_sc), KernelLayer.py:119-123,
+ *              kernels.py:527,543).  Needs mkgnn_rows_split_supported(..) == 1; fails otherwise. */
+#define MKGNN_VARIANT_ROWS_SPLIT 0x400
 /* The parameter-only part of `count` (<= 4 per call) forward calls -- unit-normalised kernel rows in the layouts the
  * kernels read, their norms, the chirality sign tables, the mixing weights: reference kernels.py:189, 279-350,
  * 386-395 -- in ONE launch: call k has banks[4 k .. 4 k + 3], feature width F[k], and gets the head of workspaces[k]
@@ -179,6 +187,10 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
  *             the propagate step's own gradient pass.  Needs the streamed kernels for every degree
  *             (mkgnn_backward_streams); fails otherwise. */
 #define MKGNN_BACKWARD_THROUGH_NEIGHBOURS 0x200
+/*             | MKGNN_BACKWARD_ROWS_SPLIT (ABI v6): `x` is pre-split as in the forward call (MKGNN_VARIANT_ROWS_SPLIT): the bank
+ *             kernel takes the halves as they are, the gather that undoes the row normalisation reads x / |x| as (hi + lo)
+ *             mantissa(inv_norm) 2^-8.  grad_x is ordinary fp32.  Needs mkgnn_rows_split_supported(..) == 1. */
+#define MKGNN_BACKWARD_ROWS_SPLIT 0x400
 int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
                                  const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],
                                  const float* x, int64_t x_stride, const float* inv_norm,
@@ -196,6 +208,13 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
 int mkgnn_backward_streams(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
                            const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],
                            const float* x, int64_t x_stride, int64_t n_atoms, int32_t F, int32_t E);
+
+/* 1 when both the forward and the backward call with these banks, buckets and strides take pre-split rows
+ * (MKGNN_VARIANT_ROWS_SPLIT / MKGNN_BACKWARD_ROWS_SPLIT): every degree with atoms and kernels on the streamed kernels with the
+ * split-fp16 products (rows of at most 112 floats, 16-byte aligned, unit bond rows present).  Launches nothing. */
+int mkgnn_rows_split_supported(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
+                               const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],
+                               int64_t x_stride, int64_t out_stride, int64_t n_atoms, int32_t F, int32_t E);
 
 /* Makes `stream` wait for every bank-gradient chain that calls with MKGNN_BACKWARD_DEFER_BANK left on this device's
  * helper stream (no-op when there is none).  Graph-capturable: captured, it is the edge that joins the helper branch. */
@@ -223,6 +242,8 @@ int mkgnn_segment_sum_rows(const float* in, int64_t in_stride, const int32_t* ro
  *   mode 2  the written rows `out` are block rows (its backward: d sim_sc = sum of the targets' dense d h rows, of
  *           which the convolution's backward reads only atom n's own block).  degree: [n_rows] int8, 0..4; only
  *           that block of out[n] is summed and written, the rest of the row is left untouched.  inv_norm unused.
+ *   mode 3  (ABI v6) mode 1 with `out` written PRE-SPLIT (MKGNN_VARIANT_ROWS_SPLIT above; inv_norm required): for a caller whose
+ *           only reader of out is the next mkgnn_kernelsetconv_forward / _backward.
  * Rows must be 16-byte aligned (strides multiples of 4 floats); K <= 255; n_rows < 2^28. */
 int mkgnn_segment_sum_block_rows(const float* in, int64_t in_stride, const int32_t* rowptr, const int32_t* col,
                                  const int8_t* degree, int64_t n_rows, const int32_t num_kernels[MKGNN_MAX_DEGREE],
@@ -298,6 +319,53 @@ int mkgnn_readout_blocks_backward(const mkgnn_readout_params* params, const floa
                                   float* dz, float* grad_sim, int64_t grad_sim_stride,
                                   float* grad_lin1_weight, float* grad_lin1_bias, float* grad_lin2_weight,
                                   float* grad_lin2_bias, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- the tail of a training step in one launch (ABI v6) ---------------------------------------------------------------
+ * Everything behind the last kernel convolution, forward AND backward:
+ *     h = propagate(sim)                                  KernelLayer.py:119-123
+ *     emb_g = pool_g( lin2( swish( lin1(h) ) ) )          MolKGNNNet.py:144-146   (no dropout inside the readout)
+ *     loss = mean_g BCEWithLogits( ffn( dropout(emb_g) ), target_g )     model.py:147-150, 169, 190-198; data.py:37
+ * and, for d loss = 1, d loss / d sim (block rows: only every atom's own column block is written -- what the last
+ * convolution's backward reads) and the six parameter gradients.  The loss is a mean over molecules, so a molecule's whole
+ * chain back is taken while it sits in LDS: one kernel over chunks of whole molecules + one fixed-order reduction of the
+ * per-block gradient slabs, in place of mkgnn_readout_blocks_forward / mkgnn_bce_head_fused / mkgnn_readout_blocks_backward
+ * (nine launches).  Same formulas, same re-associations (project before propagate, pool before lin2), the same dropout mask
+ * as mkgnn_bce_head_fused for the same rng_state.
+ *   sim         [n_atoms, K] block rows of the last mkgnn_kernelsetconv_forward (MKGNN_VARIANT_BLOCK_ROWS), K = readout.F
+ *   degree      [n_atoms] int8, 0..4 (0: in no bucket -- no block, the atom still receives from its neighbours and is pooled)
+ *   in_* / out_*  the edges grouped by target (columns = sources) / by source (columns = targets), int32, as for
+ *               mkgnn_segment_sum_rows; mol_ptr [n_mols + 1], atom_mol [n_atoms]: atoms of a molecule contiguous, edges inside
+ *   n_loss_mols the leading molecules that enter the loss (the rest -- padding molecules -- get zero gradients)
+ *   rng_state   {seed, offset} int64, read and advanced by one when dropout_p > 0; rng_used receives what was read
+ *   emb         [n_mols, G] or NULL;  pred [n_loss_mols];  loss [1];  grad_sim [n_atoms, K] block rows; grad_* may be NULL
+ * Limits: mkgnn_tail_supported (K <= 112, every block <= 52, H <= 32, G <= 32); and NO MOLECULE with more than
+ * MKGNN_TAIL_MAX_ATOMS atoms or MKGNN_TAIL_MAX_EDGES edges (each way) -- the caller, who knows the molecule sizes, checks;
+ * a molecule that breaks the promise is skipped and the loss comes back NaN.
+ * workspace: mkgnn_tail_workspace_bytes; its first 16 bytes must be ZERO on entry (a status word; the call leaves them zero). */
+#define MKGNN_TAIL_MAX_ATOMS 128
+#define MKGNN_TAIL_MAX_EDGES 512
+typedef struct mkgnn_tail_args {
+    const float* sim; int64_t sim_stride;
+    const int8_t* degree;
+    int32_t num_kernels[MKGNN_MAX_DEGREE];
+    const int32_t* in_rowptr; const int32_t* in_col;
+    const int32_t* out_rowptr; const int32_t* out_col;
+    const int32_t* mol_ptr; const int32_t* atom_mol;
+    int64_t n_atoms, n_mols, n_loss_mols;
+    mkgnn_readout_params readout;
+    const float* head_weight;   /* [G] ffn.weight */
+    const float* head_bias;     /* [1] or NULL */
+    const float* target;        /* [n_loss_mols] */
+    float dropout_p;
+    int64_t* rng_state; int64_t* rng_used;
+    float* emb; int64_t emb_stride;
+    float* pred; float* loss;
+    float* grad_sim; int64_t grad_sim_stride;
+    float *grad_lin1_weight, *grad_lin1_bias, *grad_lin2_weight, *grad_lin2_bias, *grad_head_weight, *grad_head_bias;
+} mkgnn_tail_args;
+int mkgnn_tail_supported(int32_t K, int32_t H, int32_t G, const int32_t num_kernels[MKGNN_MAX_DEGREE]);
+size_t mkgnn_tail_workspace_bytes(int32_t K, int32_t H, int64_t n_mols);
+int mkgnn_tail_fused(const mkgnn_tail_args* args, void* workspace, size_t workspace_bytes, void* stream);
 
 /* BatchNorm1d over atom rows, reference MolKGNNNet.py:115 (torch.nn.BatchNorm1d semantics: biased
  * variance for the normalisation, unbiased for running_var, running <- running + momentum (batch - running)).

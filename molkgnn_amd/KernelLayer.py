@@ -20,6 +20,9 @@ from .receptive_field import GraphBatch
 # diagnostics: MKGNN_DENSE_PROPAGATE=1 keeps sim_sc dense (zero-filled rows, dense sums) between convolution and propagate
 _BLOCK_ROWS = os.environ.get("MKGNN_DENSE_PROPAGATE") is None
 _FUSE_PROPAGATE = _BLOCK_ROWS and os.environ.get("MKGNN_SPLIT_PROPAGATE") is None
+# h between two layers written as the pre-split rows the next layer's matrix instructions take (functional.ROWS_SPLIT, round 6);
+# MKGNN_ROWS_SPLIT=0: ordinary fp32 rows (A/B, diagnostics)
+_ROWS_SPLIT = _FUSE_PROPAGATE and os.environ.get("MKGNN_ROWS_SPLIT", "1") != "0"
 _PREPARE_ONCE = os.environ.get("MKGNN_PREPARE_PER_LAYER") is None
 
 try:
@@ -132,8 +135,13 @@ class MolGCN(MessagePassing):
                 # sim_sc goes nowhere but into propagate: block rows (no zero fill, block-sparse sums both ways)
                 # ... and convolution + propagate as one operator where that applies (its backward folds the propagate
                 # step's gradient into the kernels' pre-pass); MKGNN_SPLIT_PROPAGATE=1: two operators (diagnostics)
+                # (an h that only the next layer reads is written pre-split where that layer takes it: never the last one's,
+                # which is handed out)
+                split_next = (_ROWS_SPLIT and not is_last_layer and not save_score and h.is_cuda
+                              and self.layers[i + 1]._accepts_split_rows(self._plan, h))
                 sim_sc, propagated = self.layers[i]._run(h, self._plan, is_last_layer, save_score, block_rows=_BLOCK_ROWS,
-                                                         fuse_propagate=_FUSE_PROPAGATE, prepared=prepared[i])
+                                                         fuse_propagate=_FUSE_PROPAGATE, prepared=prepared[i],
+                                                         split_next=split_next)
                 h = sim_sc if propagated else self.propagate(edge_index=edge_index, sim_sc=sim_sc)
         finally:
             self._plan = None

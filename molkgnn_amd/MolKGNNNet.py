@@ -77,7 +77,7 @@ class MolKGNNNet(torch.nn.Module):
         src = data.edge_index[0]
         return (ea, bn, src if src.is_contiguous() else src.contiguous(), nv)
 
-    def forward(self, *argv, save_score=False):
+    def forward(self, *argv, save_score=False, _tail=None):
         if len(argv) != 1:
             # the reference's 33-positional-argument form reads ``data`` afterwards and cannot work
             # (MolKGNNNet.py:70-89 then :115); only the single-``data`` form is meaningful
@@ -127,6 +127,13 @@ class MolKGNNNet(torch.nn.Module):
                                        save_score=save_score, **kw, **({'_defer_last_propagate': blocks_out} if want else {}))
         if node_representation is None:                     # the last propagate was left to the readout
             sim_sc, plan, Ls = blocks_out[0]
+            # (private: train.GNNModel.loss asks for the loss itself -- readout, head, loss and all their gradients in one
+            # launch, readout.tail_loss -- where that applies; it gets ("loss", value) back, or the embedding as usual)
+            if _tail is not None and R._FUSED_TAIL and torch.is_grad_enabled() and sim_sc.requires_grad:
+                ffn, target, p_head, n_rows = _tail
+                no_drop = self.dropout is None or not self.dropout.training or self.dropout.p == 0.0
+                if no_drop and R.tail_supported(*dims, Ls) and R._tail_limits_ok(seg, plan):
+                    return ("loss", R.tail_loss(sim_sc, plan, Ls, lin1, lin2, ffn, target, seg, p_head, n_rows))
             return R.readout_blocks(sim_sc, plan, Ls, lin1, lin2, self.dropout, seg)
         # pool(lin2(dropout(act(lin1(h)))), batch) -- MolKGNNNet.py:144-146 -- as one operator
         return R.readout(node_representation, lin1, lin2, self.dropout, data.batch, getattr(data, 'num_graphs', None), segments=seg)

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MKGNN_LIB: a diagnostic build of the same library (make VARIANT=... in csrc/), e.g. with cycle stamps compiled in
 LIB_PATH = os.environ.get("MKGNN_LIB") or os.path.join(_HERE, "libmolkgnn_hip.so")
 MAX_DEGREE = 4
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class KernelBank(C.Structure):
@@ -45,6 +45,22 @@ class Saved(C.Structure):
 class ReadoutParams(C.Structure):
     _fields_ = [("lin1_weight", C.c_void_p), ("lin1_bias", C.c_void_p), ("lin2_weight", C.c_void_p),
                 ("lin2_bias", C.c_void_p), ("F", C.c_int32), ("H", C.c_int32), ("G", C.c_int32)]
+
+
+class TailArgs(C.Structure):
+    """``mkgnn_tail_args`` (include/molkgnn_hip.h): the fused tail of a training step."""
+    _fields_ = [("sim", C.c_void_p), ("sim_stride", C.c_int64), ("degree", C.c_void_p), ("num_kernels", C.c_int32 * 4),
+                ("in_rowptr", C.c_void_p), ("in_col", C.c_void_p), ("out_rowptr", C.c_void_p), ("out_col", C.c_void_p),
+                ("mol_ptr", C.c_void_p), ("atom_mol", C.c_void_p), ("n_atoms", C.c_int64), ("n_mols", C.c_int64),
+                ("n_loss_mols", C.c_int64), ("readout", ReadoutParams), ("head_weight", C.c_void_p), ("head_bias", C.c_void_p),
+                ("target", C.c_void_p), ("dropout_p", C.c_float), ("rng_state", C.c_void_p), ("rng_used", C.c_void_p),
+                ("emb", C.c_void_p), ("emb_stride", C.c_int64), ("pred", C.c_void_p), ("loss", C.c_void_p),
+                ("grad_sim", C.c_void_p), ("grad_sim_stride", C.c_int64), ("grad_lin1_weight", C.c_void_p),
+                ("grad_lin1_bias", C.c_void_p), ("grad_lin2_weight", C.c_void_p), ("grad_lin2_bias", C.c_void_p),
+                ("grad_head_weight", C.c_void_p), ("grad_head_bias", C.c_void_p)]
+
+
+TAIL_MAX_ATOMS, TAIL_MAX_EDGES = 128, 512      # MKGNN_TAIL_MAX_ATOMS / _EDGES
 
 
 class AdamWTensor(C.Structure):
@@ -120,7 +136,8 @@ EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn
            "mkgnn_readout_blocks_supported", "mkgnn_readout_blocks_forward", "mkgnn_readout_blocks_backward",
            "mkgnn_readout_blocks_workspace_bytes", "mkgnn_molecule_supported", "mkgnn_molecule_workspace_bytes",
            "mkgnn_molecule_step", "mkgnn_batchnorm_stats_workspace_bytes", "mkgnn_batchnorm_update_stats",
-           "mkgnn_batchnorm_forward_with_stats", "mkgnn_index_workspace_bytes", "mkgnn_index_build")
+           "mkgnn_batchnorm_forward_with_stats", "mkgnn_index_workspace_bytes", "mkgnn_index_build",
+           "mkgnn_rows_split_supported", "mkgnn_tail_supported", "mkgnn_tail_workspace_bytes", "mkgnn_tail_fused")
 
 _lib: Optional[C.CDLL] = None
 TORCH_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libmolkgnn_torch.so")
@@ -178,6 +195,14 @@ def load() -> C.CDLL:
         C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_void_p]
     lib.mkgnn_backward_streams.restype = C.c_int
     lib.mkgnn_backward_streams.argtypes = [Banks4, Buckets4, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32]
+    lib.mkgnn_tail_supported.restype = C.c_int
+    lib.mkgnn_tail_supported.argtypes = [C.c_int32, C.c_int32, C.c_int32, Int32x4]
+    lib.mkgnn_tail_workspace_bytes.restype = C.c_size_t
+    lib.mkgnn_tail_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int64]
+    lib.mkgnn_tail_fused.restype = C.c_int
+    lib.mkgnn_tail_fused.argtypes = [C.POINTER(TailArgs), C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.mkgnn_rows_split_supported.restype = C.c_int
+    lib.mkgnn_rows_split_supported.argtypes = [Banks4, Buckets4, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32]
     lib.mkgnn_bank_prepare.restype = C.c_int
     lib.mkgnn_bank_prepare.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mkgnn_collate_compact_bytes.restype = C.c_size_t

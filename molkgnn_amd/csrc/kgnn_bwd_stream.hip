@@ -97,6 +97,14 @@ template <int OFF> __device__ __forceinline__ float lds_read_raw_at(uint32_t byt
     return v;
 }
 
+// a 16-bit LDS read, zero-extended.  (Not ds_read_u16_d16 / _d16_hi into the two halves of ONE register: with SRAM ECC on --
+// every MI300 / MI355 -- a d16 load rewrites the whole register, the "kept" half comes back as zero; found by
+// tests/test_hip_parity.py::test_three_layer_network_tie_aware, layer 1's bank gradients.  Two reads and one v_lshl_or_b32.)
+template <int OFF> __device__ __forceinline__ void lds_read_h16(uint32_t& dst, uint32_t byte_addr) {
+    static_assert(OFF >= 0 && OFF < 65536, "ds_read offset field");
+    asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(dst) : "v"(byte_addr), "n"(OFF) : "memory");
+}
+
 template <typename V> __device__ __forceinline__ void lds_fence(V& v) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v) : : "memory"); }
 
 template <int D, int A> __device__ __forceinline__ int perm_entry(int p) {
@@ -304,8 +312,12 @@ __global__ void __launch_bounds__(256) coef_prepare_kernel(BankStreamArgs a) {
 // its idx words) sits below 2^19 before the mantissa factor -- when a tile
 // brings a larger one, G drops and the accumulators (which live in registers for the whole launch) are multiplied by the
 // ratio, exactly; the slab slice is divided by G at the end.  Bit-reproducible: G depends on the wave's own tiles in order.
+// SP = 2 (round 6): the atom rows arrive pre-split (kgnn_split.h, split_row_store: hi(0..3) | lo(0..3) per four floats, scaled by
+// the same 2^(exponent(1 / |x|) + 8)): the B operand's halves are read straight out of the slot image with 16-bit LDS loads
+// (ds_read_u16: eight per feature tile instead of four 32-bit ones, paired by four v_lshl_or_b32) and the ten conversion
+// instructions per tile go.
 constexpr int BANK_COEF_EXP = 18;
-template <int D, int KC, bool SP>
+template <int D, int KC, int SP>
 __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const BankStreamDeg& dg, const int cp, const int rank,
                                                  const int count, float* lds) {
     using namespace bs;
@@ -518,7 +530,7 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
                 if constexpr (SP) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        rsc[q] = __uint_as_float((__float_as_uint(iv[q]) & 0x7f800000u) + (8u << 23));
+                        if constexpr (SP == 1) rsc[q] = __uint_as_float((__float_as_uint(iv[q]) & 0x7f800000u) + (8u << 23));
                         iv[q] = __uint_as_float((__float_as_uint(iv[q]) & 0x007fffffu) | ((127u - 8u) << 23)) * G;     // mantissa 2^-8 G
                     }
                 }
@@ -566,7 +578,45 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
                         else bx[q] = lds_read_raw_at<4 * (4 * q * RF + 16 * t)>(xl_b);
                     });
                 };
-                if constexpr (SP) {
+                if constexpr (SP == 2) {
+                    // pre-split rows: element (row 4 q + kq, feature 16 t + ci) is half-word ci & 3 of the 16-byte chunk
+                    // 4 t + (ci >> 2) of its row -- hi halves in the chunk's first eight bytes, lo halves in the last eight.
+                    // The swizzle moves whole chunks, so the two per-lane bases of the 32-bit form carry over.
+                    const uint32_t hb_b = rb_b + 4u * (kq * RF) + 16u * (ci >> 2) + 2u * (ci & 3) + (SWZ ? (kq & 1) * 64u : 0u);
+                    [[maybe_unused]] const uint32_t hb_o = rb_b + 4u * (kq * RF) + 16u * (ci >> 2) + 2u * (ci & 3) - (SWZ ? (kq & 1) * 64u : 0u);
+                    auto read_hx = [&](auto tc, uint32_t (&hx)[8]) {          // hx: hi of atoms q = 0..3, lo of atoms q = 0..3
+                        constexpr int t = decltype(tc)::value;
+                        const uint32_t base = (SWZ && (t & 1)) ? hb_o : hb_b;
+                        static_for<0, 4>([&](auto qc) {
+                            constexpr int q = decltype(qc)::value;
+                            lds_read_h16<4 * (4 * q * RF + 16 * t)>(hx[q], base);
+                            lds_read_h16<4 * (4 * q * RF + 16 * t) + 8>(hx[4 + q], base);
+                        });
+                    };
+                    uint32_t hxp[2][8];
+                    read_hx(IC<0>{}, hxp[0]);
+                    static_for<0, KC>([&](auto tc) {
+                        constexpr int t = decltype(tc)::value;
+                        uint32_t (&hx)[8] = hxp[t & 1];
+                        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hx[0]), "+v"(hx[1]), "+v"(hx[2]), "+v"(hx[3]), "+v"(hx[4]), "+v"(hx[5]),
+                                     "+v"(hx[6]), "+v"(hx[7]) : : "memory");
+                        if constexpr (t + 1 < KC) read_hx(IC<t + 1>{}, hxp[(t + 1) & 1]);
+                        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+                        SplitReg xb;                               // (whole-register writes: v_lshl_or_b32)
+                        xb.hi = __builtin_bit_cast(h16x4, u32x2{hx[0] | (hx[1] << 16), hx[2] | (hx[3] << 16)});
+                        xb.lo = __builtin_bit_cast(h16x4, u32x2{hx[4] | (hx[5] << 16), hx[6] | (hx[7] << 16)});
+                        if constexpr (s < D) {
+#pragma unroll
+                            for (int b = 0; b < NBS; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(avs[b].lo, xb.hi, acc[b][t], 0, 0, 0);
+#pragma unroll
+                            for (int b = 0; b < NBS; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(avs[b].hi, xb.lo, acc[b][t], 0, 0, 0);
+#pragma unroll
+                            for (int b = 0; b < NBS; ++b) acc[b][t] = __builtin_amdgcn_mfma_f32_16x16x16f16(avs[b].hi, xb.hi, acc[b][t], 0, 0, 0);
+                        } else {
+                            accC[t] = split_mfma(avs[0], xb, accC[t]);
+                        }
+                    });
+                } else if constexpr (SP) {
                     // a feature tile is three short matrix instructions per support now: the next tile's four reads are issued
                     // before this tile's conversion and products (they were hidden behind 4 x 32-cycle instructions before)
                     float bxp[2][4];
@@ -680,7 +730,7 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
 #endif
 }
 
-template <int KC, bool SP = false>
+template <int KC, int SP = 0>
 __global__ void __launch_bounds__(256, (KC >= 8 ? 1 : 2)) kc_backward_bank_stream(BankStreamArgs a) {
     extern __shared__ __align__(16) float lds[];
     const int grp = a.blk_group[blockIdx.x];
@@ -708,6 +758,7 @@ extern "C" int mkgnn_debug_set_bank_stream_stamps(void* device_ptr) {
 }
 
 // Same conditions as the forward's streamed kernel (the pre-pass and the slab chunk capacity added).
+bool bank_stream_rows_split_supported(int F) { return (F + 15) / 16 <= 7 && bwd_split_mode() != 0; }
 bool bank_stream_supported(int d, int F, int E, int L, int64_t n_atoms, int64_t x_stride, const float* e_unit) {
     return stream_forward_supported(d, F, E, L, n_atoms, x_stride, x_stride, e_unit);
 }
@@ -833,7 +884,7 @@ hipError_t launch_coef_prepare(const BankStreamLaunch& p, hipStream_t st) {
     return hipGetLastError();
 }
 
-template <int KC, bool SP = false> static hipError_t launch_bank_kc(const BankStreamLaunch& p, hipStream_t st) {
+template <int KC, int SP = 0> static hipError_t launch_bank_kc(const BankStreamLaunch& p, hipStream_t st) {
     if (p.lds_bytes > 64 * 1024) {
         static PerDeviceOnce attr_set;
         if (const int slot = attr_set.pending(); slot >= 0) {
@@ -851,6 +902,18 @@ hipError_t launch_backward_bank_stream(const BankStreamLaunch& p, hipStream_t st
     if (p.nb == 0) return hipSuccess;
     if (p.lds_bytes > (size_t)(p.KC >= 8 ? 128 : 80) * 1024) return hipErrorInvalidValue;
     g_last_plan[2].launches.fetch_add(1);
+    if (p.x_split) {                                     // pre-split atom rows (the caller has asked bank_stream_rows_split_supported)
+        if (!(p.KC <= 7 && bwd_split_mode() != 0)) return hipErrorInvalidValue;
+        switch (p.KC) {
+            case 1: return launch_bank_kc<1, 2>(p, st);
+            case 2: return launch_bank_kc<2, 2>(p, st);
+            case 3: return launch_bank_kc<3, 2>(p, st);
+            case 4: return launch_bank_kc<4, 2>(p, st);
+            case 5: return launch_bank_kc<5, 2>(p, st);
+            case 6: return launch_bank_kc<6, 2>(p, st);
+            default: return launch_bank_kc<7, 2>(p, st);
+        }
+    }
     if (p.KC <= 7 && bwd_split_mode() != 0) {
         switch (p.KC) {
             case 1: return launch_bank_kc<1, true>(p, st);

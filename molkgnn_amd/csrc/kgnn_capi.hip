@@ -170,6 +170,32 @@ static bool fwd_stream_enabled() {              // MKGNN_FWD_STREAM=0: round 1's
     return !(env_stream && env_stream[0] == '0');
 }
 
+// pre-split rows (MKGNN_VARIANT_ROWS_SPLIT / MKGNN_BACKWARD_ROWS_SPLIT): the forward dispatch puts every degree with atoms and
+// kernels on the streamed kernel with split-fp16 products, and the backward on the streamed pair
+static bool rows_split_covered(const mkgnn_kernel_bank banks[4], const mkgnn_degree_bucket buckets[4], const float* x, int64_t x_stride,
+                               int64_t out_stride, int64_t n_atoms, int F, int E) {
+    static const char* env_off = getenv("MKGNN_ROWS_SPLIT");                     // MKGNN_ROWS_SPLIT=0: never (A/B, diagnostics)
+    if (env_off && env_off[0] == '0') return false;
+    static const char* env_pp = getenv("MKGNN_FWD_PP");
+    if (env_pp && atoi(env_pp) != 0) return false;
+    if (!fwd_stream_enabled() || !stream_rows_split_supported(F) || !bank_stream_rows_split_supported(F)) return false;
+    if ((x_stride % 4) != 0 || (x && (((uintptr_t)x) & 15) != 0)) return false;
+    if ((uint64_t)n_atoms * (uint64_t)x_stride >= (1ull << 32)) return false;
+    int Ls[4];
+    bool use[4], any = false;
+    for (int i = 0; i < 4; ++i) {
+        Ls[i] = banks[i].num_kernels;
+        use[i] = buckets[i].count > 0 && Ls[i] > 0;
+        if (!use[i]) continue;
+        any = true;
+        if ((uint64_t)buckets[i].count * (uint64_t)Ls[i] >= (1ull << 32)) return false;
+        if (!stream_forward_supported(i + 1, F, E, Ls[i], n_atoms, x_stride, out_stride, buckets[i].nei_edge_unit)) return false;
+    }
+    if (!any || stream_forward_groups(Ls, use) > FUSED_MAX_GROUPS) return false;
+    // (a dummy aligned pointer where the caller has none yet: streamed_pair_covers only looks at its alignment)
+    return streamed_pair_covers(banks, buckets, x ? x : (const float*)(uintptr_t)16, x_stride, n_atoms, F, E);
+}
+
 // degree index (0..3) -> concurrency slot, most expensive bucket first (N_d * L_d * (d*d + 1))
 static void degree_slots(const mkgnn_kernel_bank banks[4], const mkgnn_degree_bucket buckets[4], int slot_of[4]) {
     double cost[4];
@@ -352,8 +378,12 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
         return fail("%s: workspace of %zu bytes, need %zu", who, workspace_bytes, w.fwd_end);
     const bool block_rows_only = (variant & MKGNN_VARIANT_BLOCK_ROWS) != 0;     // the caller reads only each atom's own block
     const bool bank_prepared = (variant & MKGNN_VARIANT_BANK_PREPARED) != 0;    // mkgnn_bank_prepare has filled the workspace's head
-    variant &= ~(MKGNN_VARIANT_BLOCK_ROWS | MKGNN_VARIANT_BANK_PREPARED);
+    const bool rows_split = (variant & MKGNN_VARIANT_ROWS_SPLIT) != 0;          // x is pre-split (kgnn_split.h)
+    variant &= ~(MKGNN_VARIANT_BLOCK_ROWS | MKGNN_VARIANT_BANK_PREPARED | MKGNN_VARIANT_ROWS_SPLIT);
     if (variant < 0 || variant > 3) return fail("%s: variant %d", who, variant);
+    if (rows_split && (variant == 1 || variant == 3 || !rows_split_covered(banks, buckets, x, x_stride, out_stride, n_atoms, F, E)))
+        return fail("%s: MKGNN_VARIANT_ROWS_SPLIT needs the streamed kernels with split-fp16 products for every degree "
+                    "(mkgnn_rows_split_supported(..) tells)", who);
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)workspace;
     hipError_t e = bank_prepared ? hipSuccess : launch_bank_prepare(banks, w, ws, F, E, st);
@@ -375,6 +405,7 @@ int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
     fa.x = x; fa.xs = x_stride; fa.inv = inv_norm; fa.out = out; fa.os = out_stride;
     fa.K = K; fa.F = F; fa.E = E; fa.last = is_last_layer ? 1 : 0; fa.n_atoms = n_atoms;
     fa.bf16 = variant == 3 ? 1 : 0;
+    fa.x_split = rows_split ? 1 : 0;
     bool use[4] = {false, false, false, false};
     bool any_fused = false;
     // which degrees ride in the fused launch: every covered shape, as long as their (degree, column part) groups fit
@@ -467,7 +498,8 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
     const char* who = "mkgnn_kernelsetconv_backward";
     const bool defer_bank = (variant & MKGNN_BACKWARD_DEFER_BANK) != 0;
     const bool through_nei = (variant & MKGNN_BACKWARD_THROUGH_NEIGHBOURS) != 0;
-    variant &= ~(MKGNN_BACKWARD_DEFER_BANK | MKGNN_BACKWARD_THROUGH_NEIGHBOURS);
+    const bool rows_split = (variant & MKGNN_BACKWARD_ROWS_SPLIT) != 0;         // x is pre-split (kgnn_split.h)
+    variant &= ~(MKGNN_BACKWARD_DEFER_BANK | MKGNN_BACKWARD_THROUGH_NEIGHBOURS | MKGNN_BACKWARD_ROWS_SPLIT);
     if (variant < 0 || variant > 2) return fail("%s: variant %d (0 = automatic, 1 = generic kernels, 2 = fast kernels)", who, variant);
     const bool force_generic = variant == 1, force_fast = variant == 2;
     int64_t n_edges = 0;
@@ -624,12 +656,21 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
         if (!all) return fail("%s: MKGNN_BACKWARD_THROUGH_NEIGHBOURS needs the streamed kernels for every degree "
                               "(mkgnn_backward_streams(..) tells)", who);
     }
+    if (rows_split) {
+        // pre-split rows: only the streamed bank kernel and the pipelined gather read them
+        bool all = streamed && rows_streamed && !force_generic && bank_stream_rows_split_supported(F) &&
+                   (!grad_x || (grad_x_stride % 4 == 0 && ((uintptr_t)grad_x & 15) == 0));
+        for (int i = 0; i < 4; ++i) if (buckets[i].count > 0 && L[i] > 0 && !bank_use[i]) all = false;
+        if (!all) return fail("%s: MKGNN_BACKWARD_ROWS_SPLIT needs the streamed kernels with split-fp16 products for every degree "
+                              "(mkgnn_rows_split_supported(..) tells)", who);
+    }
     BankStreamLaunch bsl;
     int nchunk4[4] = {0, 0, 0, 0}, ntheta4[4] = {0, 0, 0, 0};
     if (streamed) {
         // the pre-pass first, on the caller's stream: its records (dL/dsc and permutation ids in tile order) feed both
         // the rows kernel here and the bank kernel on the helper
         plan_backward_bank_stream(bank_a, bank_use, e_unit4, coefq4, nchunk4, ntheta4, through_nei, &bsl);
+        bsl.x_split = rows_split ? 1 : 0;
         { BwdTimer t(st, 0); e = launch_coef_prepare(bsl, st); }
         if (e != hipSuccess) return hip_fail("coefficient pre-pass launch", e);
         e = fj.refork(1);
@@ -671,7 +712,7 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
     if (grad_x) {
         BwdTimer t(st, 4);
         e = launch_backward_gather((const float*)(ws + w.contrib), (F + 3) / 4 * 4, base, scatter_rowptr, scatter_rows, x,
-                                   x_stride, inv_norm, n_atoms, F, grad_x, grad_x_stride, !force_generic, st);
+                                   x_stride, inv_norm, n_atoms, F, grad_x, grad_x_stride, !force_generic, st, rows_split);
         if (e != hipSuccess) return hip_fail("backward gather launch", e);
     }
     if (split && defer_bank && fj.used[0] && !fj.used[1] && !fj.used[2]) {
@@ -687,6 +728,12 @@ int mkgnn_backward_streams(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE], cons
                            const float* x, int64_t x_stride, int64_t n_atoms, int32_t F, int32_t E) {
     if (!banks || !buckets) return 0;
     return streamed_pair_covers(banks, buckets, x, x_stride, n_atoms, F, E) ? 1 : 0;
+}
+
+int mkgnn_rows_split_supported(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE], const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],
+                               int64_t x_stride, int64_t out_stride, int64_t n_atoms, int32_t F, int32_t E) {
+    if (!banks || !buckets || F < 1 || E < 1) return 0;
+    return rows_split_covered(banks, buckets, nullptr, x_stride, out_stride, n_atoms, F, E) ? 1 : 0;
 }
 
 int mkgnn_backward_join(void* stream) {
@@ -711,7 +758,8 @@ int mkgnn_segment_sum_block_rows(const float* in, int64_t in_stride, const int32
                                  const int8_t* degree, int64_t n_rows, const int32_t num_kernels[MKGNN_MAX_DEGREE],
                                  int32_t mode, float* out, int64_t out_stride, float* inv_norm, void* stream) {
     const char* who = "mkgnn_segment_sum_block_rows";
-    if (mode != 1 && mode != 2) return fail("%s: mode %d (1 = block-row sources, 2 = block-row destinations)", who, mode);
+    if (mode < 1 || mode > 3) return fail("%s: mode %d (1 = block-row sources, 2 = block-row destinations, 3 = 1 with pre-split output)", who, mode);
+    if (mode == 3 && !inv_norm) return fail("%s: mode 3 (pre-split rows) needs inv_norm", who);
     if (!num_kernels) return fail("%s: num_kernels is null", who);
     int width = 0;
     for (int i = 0; i < MKGNN_MAX_DEGREE; ++i) {

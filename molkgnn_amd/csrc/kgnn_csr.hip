@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include "kgnn_common.h"
 #include "kgnn_launch.h"
+#include "kgnn_split.h"
 
 #include <type_traits>
 
@@ -38,6 +39,10 @@ struct CsrArgs {
     const int8_t* deg8;                    // BLK == 2: degree of every destination row
     uint64_t blk_off, blk_len;
     int fixed4;                            // diagnostics (MKGNN_CSR_FIXED4=1): four row loads per group whatever the segments hold
+    // round 6, pre-split rows (kgnn_split.h, split_row_store): a row kept as the fp16 halves hi | lo of x * 2^(exponent(1 / |x|) + 8),
+    // sixteen bytes per four floats -- exactly what the streamed kernels' matrix instructions take
+    int split_out;                         // segment sum with inv_out: the written rows are pre-split
+    int x_split;                           // gather: the forward's rows x are pre-split
 };
 
 template <int LPR>
@@ -218,7 +223,9 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(CsrArgs a) {
         const bool row_ok = g * RPW + sub < n;
         if constexpr (GATHER) {
             // d/dx of x / max(|x|, eps): (acc - (acc . xh) xh) * inv, or acc * inv where the clamp is active
-            f32x4 xh = mask_cols(xv, active ? col : a.width, a.width) * iv;
+            // (pre-split rows: hi + lo is the scaled row to 2^-22 of an element; the power of two leaves through 1 / |x|)
+            if (a.x_split) { xv = split_row_value(xv); }
+            f32x4 xh = mask_cols(xv, active ? col : a.width, a.width) * (a.x_split ? split_row_inv(iv) : iv);
             float dotp = acc[0] * xh[0];
             dotp = fmaf(acc[1], xh[1], dotp); dotp = fmaf(acc[2], xh[2], dotp); dotp = fmaf(acc[3], xh[3], dotp);
             dotp = group_sum<LPR>(dotp);
@@ -239,13 +246,16 @@ __global__ void __launch_bounds__(256) csr_rows_kernel(CsrArgs a) {
                 }
             }
         } else {
-            if (row_ok && active) *(f32x4*)(a.out + (uint64_t)(uint32_t)j_c * (uint32_t)a.os + col) = acc;     // alignment padding is written as zero
+            f32x4 stored = acc;                                     // alignment padding is written as zero
             if (a.inv_out) {
                 float ss = acc[0] * acc[0];
                 ss = fmaf(acc[1], acc[1], ss); ss = fmaf(acc[2], acc[2], ss); ss = fmaf(acc[3], acc[3], ss);
                 ss = group_sum<LPR>(ss);
-                if (row_ok && l == 0) a.inv_out[j_c] = 1.f / fmaxf(sqrtf(ss), MKGNN_EPS);
+                const float inv = 1.f / fmaxf(sqrtf(ss), MKGNN_EPS);
+                if (row_ok && l == 0) a.inv_out[j_c] = inv;
+                if (a.split_out) stored = split_row_store(acc, inv);
             }
+            if (row_ok && active) *(f32x4*)(a.out + (uint64_t)(uint32_t)j_c * (uint32_t)a.os + col) = stored;
         }
     };
     for (; g < ngroups; g += nwaves) {
@@ -351,7 +361,8 @@ hipError_t launch_segment_sum_blocks(const float* in, int64_t is, const int32_t*
                                      float* inv_norm, hipStream_t st) {
     CsrArgs a{};
     a.src = in; a.ss = is; a.rowptr = rowptr; a.idx = col; a.n = n; a.width = width; a.out = out; a.os = os;
-    a.inv_out = mode == 1 ? inv_norm : nullptr;
+    a.inv_out = (mode == 1 || mode == 3) ? inv_norm : nullptr;
+    a.split_out = mode == 3 ? 1 : 0;
     a.deg8 = deg8;
     int off = 0;
     for (int d = 1; d <= 4; ++d) {
@@ -359,7 +370,7 @@ hipError_t launch_segment_sum_blocks(const float* in, int64_t is, const int32_t*
         a.blk_len |= (uint64_t)L[d - 1] << (8 * d);
         off += L[d - 1];
     }
-    return mode == 1 ? launch_csr_blocks<1>(a, st) : launch_csr_blocks<2>(a, st);
+    return mode != 2 ? launch_csr_blocks<1>(a, st) : launch_csr_blocks<2>(a, st);
 }
 
 // Fast paths; the callers fall back to the one-row-per-wave kernels when these decline (return false).
@@ -375,12 +386,12 @@ bool try_segment_sum_aligned(const float* in, int64_t is, const int32_t* rowptr,
 
 bool try_backward_gather_aligned(const float* contrib, int64_t cs, const int32_t* rowptr, const int32_t* rows, const float* x,
                                  int64_t xs, const float* inv, int64_t n, int F, float* gx, int64_t gxs, hipStream_t st,
-                                 hipError_t* err) {
+                                 hipError_t* err, bool x_split) {
     if (n == 0 || n >= (1 << 30) || !rows || F > 256 || !aligned_rows(contrib, cs, F) || !aligned_rows(x, xs, F) || !aligned_rows(gx, gxs, F))
         return false;
     CsrArgs a{};
     a.src = contrib; a.ss = cs; a.rowptr = rowptr; a.idx = rows; a.n = n; a.width = F; a.out = gx; a.os = gxs;
-    a.x = x; a.xs = xs; a.inv = inv;
+    a.x = x; a.xs = xs; a.inv = inv; a.x_split = x_split ? 1 : 0;
     *err = launch_csr<true>(a, st);
     return true;
 }

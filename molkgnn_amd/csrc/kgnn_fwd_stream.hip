@@ -324,8 +324,11 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
         }
     }
     // ---- one-time: this wave's share of the bank -> registers (unit rows, zero beyond F; idle columns all zero)
-    static_assert(BF == 0 || BF == 1 || (BF == 2 && !PP), "BF: 0 fp32, 1 bf16 similarity, 2 fp32 out of split fp16 (4-wave blocks)");
-    using BankReg = std::conditional_t<BF == 2, SplitReg, std::conditional_t<BF == 1, s16x4s, f32x4>>;
+    static_assert(BF == 0 || BF == 1 || ((BF == 2 || BF == 3) && !PP),
+                  "BF: 0 fp32, 1 bf16 similarity, 2 fp32 out of split fp16 (4-wave blocks), 3 the same on pre-split atom rows");
+    constexpr bool SPL = (BF == 2 || BF == 3);           // split-fp16 products
+    constexpr bool PRE = (BF == 3);                      // the atom rows arrive pre-split (kgnn_split.h, split_row_store): no conversion here
+    using BankReg = std::conditional_t<SPL, SplitReg, std::conditional_t<BF == 1, s16x4s, f32x4>>;
     BankReg bk[NB][KC];
     float2 bv[D];
     {
@@ -339,7 +342,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
             for (int t = 0; t < KC; ++t) {
                 f32x4 v = *(const f32x4*)(dg.padded + ((size_t)b * L + l) * FPB + 16 * t + 4 * kq);
                 if (zero) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                if constexpr (BF == 2) bk[bl][t] = split_scaled(v, (float)(1 << SPLIT_BANK_EXP));     // (10 instructions; the compiler's split_f16: 17)
+                if constexpr (SPL) bk[bl][t] = split_scaled(v, (float)(1 << SPLIT_BANK_EXP));     // (10 instructions; the compiler's split_f16: 17)
                 else if constexpr (BF == 1) bk[bl][t] = to_bf16x4s(v);
                 else bk[bl][t] = v;
             }
@@ -616,13 +619,23 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
 #endif
                     if constexpr (t == KC - 1) {         // only the last chunk of a row can be partial or empty
                         const int col = 16 * t + 4 * kq;
-                        if (col >= F) cur.x = 0.f;
-                        if (col + 1 >= F) cur.y = 0.f;
-                        if (col + 2 >= F) cur.z = 0.f;
-                        if (col + 3 >= F) cur.w = 0.f;
+                        if constexpr (PRE) {
+                            // the sixteen bytes are hi(0..3) | lo(0..3): element e is half-word e of both halves
+                            const uint32_t m01 = (col < F ? 0x0000ffffu : 0u) | (col + 1 < F ? 0xffff0000u : 0u);
+                            const uint32_t m23 = (col + 2 < F ? 0x0000ffffu : 0u) | (col + 3 < F ? 0xffff0000u : 0u);
+                            cur.x = __uint_as_float(__float_as_uint(cur.x) & m01); cur.z = __uint_as_float(__float_as_uint(cur.z) & m01);
+                            cur.y = __uint_as_float(__float_as_uint(cur.y) & m23); cur.w = __uint_as_float(__float_as_uint(cur.w) & m23);
+                        } else {
+                            if (col >= F) cur.x = 0.f;
+                            if (col + 1 >= F) cur.y = 0.f;
+                            if (col + 2 >= F) cur.z = 0.f;
+                            if (col + 3 >= F) cur.w = 0.f;
+                        }
                     }
-                    if constexpr (BF == 2) {
-                        const SplitReg a4 = split_scaled(cur, sca_s);
+                    if constexpr (SPL) {
+                        SplitReg a4;
+                        if constexpr (PRE) a4 = __builtin_bit_cast(SplitReg, cur);       // the producer's split of the same scaled row
+                        else a4 = split_scaled(cur, sca_s);
                         if constexpr (s < D) {
 #pragma unroll
                             for (int b = 0; b < NBS; ++b) cm[s][b] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4.lo, bk[b][t].hi, cm[s][b], 0, 0, 0);
@@ -744,7 +757,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
 #pragma unroll
             for (int s = 0; s < S1; ++s) {
                 inv4[s] = *(const f32x4*)(mrec + T::OFF_INV + s * 16 + kq * 4);
-                if constexpr (BF == 2) {
+                if constexpr (SPL) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) inv4[s][j] = split_inv(inv4[s][j]);
                 }
@@ -758,7 +771,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
             for (int s = 0; s < D; ++s) {
                 if constexpr (HS) {
                     float iv = mrec[T::OFF_INV + s * 16 + kq * 4 + jj];
-                    if constexpr (BF == 2) iv = split_inv(iv);
+                    if constexpr (SPL) iv = split_inv(iv);
                     const float own0 = half ? cm[s][0][2 + j] : cm[s][0][j], own1 = half ? cm[s][1][2 + j] : cm[s][1][j];
                     m[s][0] = (half ? px[j][s][0] : own0) * iv;
                     m[s][1] = (half ? px[j][s][1] : own1) * iv;
@@ -773,7 +786,7 @@ __device__ __forceinline__ void stream_body(const FusedFwdArgs& a, const FusedDe
             best_permutation<D>(m, best4[j], idx4[j]);
             if constexpr (HS) {
                 float ivc = mrec[T::OFF_INV + D * 16 + kq * 4 + jj];
-                if constexpr (BF == 2) ivc = split_inv(ivc);
+                if constexpr (SPL) ivc = split_inv(ivc);
                 cen4[j] = (half ? pcc[j] : cc[j]) * ivc;
             }
             else cen4[j] = cc[j] * inv4[D][j];
@@ -1180,12 +1193,15 @@ static int fwd_split_mode() {
 // tests: 1 / 0 = split-fp16 / fp32 matrix instructions from the next launch on, -1 = what the environment says
 extern "C" int mkgnn_debug_set_forward_products(int32_t mode) { g_fwd_split_override.store(mode < 0 ? -1 : (mode ? 1 : 0)); return 0; }
 
+// pre-split atom rows (kgnn_split.h): the streamed kernel with split-fp16 products is the only forward that reads them
+bool stream_rows_split_supported(int F) { return (F + 15) / 16 <= 7 && fwd_split_mode() != 0; }
+
 hipError_t launch_forward_stream(FusedFwdArgs& a, const bool use[4], hipStream_t st) {
     const int KC = (a.F + 15) / 16;
     a.stamps = g_stream_stamps;
     a.FPB = bank_pitch(a.F);
     int nb = 0;
-    if (KC <= 7 && fwd_pp_mode() != 0) {
+    if (KC <= 7 && fwd_pp_mode() != 0 && !a.x_split) {
         const size_t lds_pp = plan_stream(a, use, KC, &nb, true);
         if (nb == 0) return hipSuccess;
         if (nb > 0 && lds_pp <= (size_t)160 * 1024) {
@@ -1216,6 +1232,18 @@ hipError_t launch_forward_stream(FusedFwdArgs& a, const bool use[4], hipStream_t
         if (KC == 2) return launch_stream_kc<2, 1>(a, nb, lds_bytes, st);
         if (KC == 7) return launch_stream_kc<7, 1>(a, nb, lds_bytes, st);
         return hipErrorInvalidValue;                     // (the caller asks stream_forward_bf16_supported first)
+    }
+    if (a.x_split) {                                     // (the caller has asked stream_rows_split_supported)
+        if (!split) return hipErrorInvalidValue;
+        switch (KC) {
+            case 1: return launch_stream_kc<1, 3>(a, nb, lds_bytes, st);
+            case 2: return launch_stream_kc<2, 3>(a, nb, lds_bytes, st);
+            case 3: return launch_stream_kc<3, 3>(a, nb, lds_bytes, st);
+            case 4: return launch_stream_kc<4, 3>(a, nb, lds_bytes, st);
+            case 5: return launch_stream_kc<5, 3>(a, nb, lds_bytes, st);
+            case 6: return launch_stream_kc<6, 3>(a, nb, lds_bytes, st);
+            default: return launch_stream_kc<7, 3>(a, nb, lds_bytes, st);
+        }
     }
     if (split) {
         switch (KC) {

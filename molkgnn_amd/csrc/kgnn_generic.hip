@@ -674,10 +674,11 @@ hipError_t launch_bank_reduce_all(const BankReduceArgs r[4], hipStream_t st) {
 
 hipError_t launch_backward_gather(const float* contrib, int64_t cs, int64_t n_contrib_rows, const int32_t* rowptr,
                                   const int32_t* rows, const float* x, int64_t xs, const float* inv, int64_t n, int F,
-                                  float* gx, int64_t gxs, bool allow_fast, hipStream_t st) {
+                                  float* gx, int64_t gxs, bool allow_fast, hipStream_t st, bool x_split) {
     if (n == 0) return hipSuccess;
     hipError_t e = hipSuccess;
-    if (allow_fast && n_contrib_rows > 0 && try_backward_gather_aligned(contrib, cs, rowptr, rows, x, xs, inv, n, F, gx, gxs, st, &e)) return e;
+    if (allow_fast && n_contrib_rows > 0 && try_backward_gather_aligned(contrib, cs, rowptr, rows, x, xs, inv, n, F, gx, gxs, st, &e, x_split)) return e;
+    if (x_split) return hipErrorInvalidValue;              // (pre-split rows: only the pipelined gather reads them; the caller checks the shapes first)
     kc_backward_gather<<<grid_for_waves(n), 256, 0, st>>>(contrib, cs, rowptr, rows, x, xs, inv, n, F, gx, gxs);
     return hipGetLastError();
 }

@@ -60,6 +60,7 @@ struct FusedFwdArgs {
     int K, F, E, last;
     int64_t n_atoms;
     int bf16;                                // node-feature dot products with bf16 operands (variant 3)
+    int x_split;                             // the rows of x are pre-split (MKGNN_VARIANT_ROWS_SPLIT; kgnn_split.h)
     int FPB;                                 // row pitch (floats) of the padded bank copies (streamed kernel; = mfma_padded_width(F))
     FusedDeg deg[MKGNN_MAX_DEGREE];
     uint8_t grp_degree[FUSED_MAX_GROUPS];   // group -> degree index (0..3)
@@ -109,6 +110,7 @@ bool stream_forward_supported(int d, int F, int E, int L, int64_t n_atoms, int64
 hipError_t launch_forward_stream(FusedFwdArgs& a, const bool use[4], hipStream_t st);
 int stream_tiles_per_part(int d);
 int stream_column_parts(int d, int L);
+bool stream_rows_split_supported(int F);             // pre-split atom rows: KC <= 7 and the split-fp16 products on
 bool stream_forward_bf16_supported(int F);           // the bf16 similarity variant on the streamed kernel (KC = 2 or 7)
 int stream_forward_groups(const int L[4], const bool use[4]);
 hipError_t launch_unit_rows8(const float* in, int64_t n_rows, int E, float* out, hipStream_t st);
@@ -122,6 +124,7 @@ int bank_blocks_for(int d, int64_t n);
 hipError_t launch_backward_bank_fused(const BwdArgs a4[4], const bool use[4], int nchunk_out[4], int ntheta_out[4], hipStream_t st);
 // kgnn_bwd_stream.hip: streamed MFMA bank-gradient kernel (+ its coefficient pre-pass), all degrees in one launch
 bool bank_stream_supported(int d, int F, int E, int L, int64_t n_atoms, int64_t x_stride, const float* e_unit);
+bool bank_stream_rows_split_supported(int F);        // pre-split atom rows: KC <= 7 and the split-fp16 products on
 struct BankStreamDeg {
     const int64_t* sel; const int64_t* nei; const float* e_unit;
     const float* pair; const int8_t* chir;
@@ -147,7 +150,7 @@ struct BankStreamArgs {
     uint16_t blk_rank[FUSED_MAX_BLOCKS];
 };
 
-struct BankStreamLaunch { BankStreamArgs a; int nb, prep_blocks, KC; size_t lds_bytes; };
+struct BankStreamLaunch { BankStreamArgs a; int nb, prep_blocks, KC; size_t lds_bytes; int x_split; };
 // block split and arguments once; then the pre-pass (coefficient records in tile order, score-weight partials) and the
 // bank kernel, each on the stream the caller chooses
 void plan_backward_bank_stream(const BwdArgs a4[4], const bool use[4], const float* const e_unit[4], float* const coefq[4],
@@ -163,7 +166,7 @@ bool mfma_backward_supported(int d, int F, int E, int L, int64_t xs, const void*
 hipError_t launch_backward_rows_mfma(int d, const BwdArgs& a, int* ntheta_out, hipStream_t st);
 hipError_t launch_backward_gather(const float* contrib, int64_t cs, int64_t n_contrib_rows, const int32_t* rowptr,
                                   const int32_t* rows, const float* x, int64_t xs, const float* inv, int64_t n, int F,
-                                  float* gx, int64_t gxs, bool allow_fast, hipStream_t st);
+                                  float* gx, int64_t gxs, bool allow_fast, hipStream_t st, bool x_split = false);
 // kgnn_csr.hip: pipelined variants for 16-byte aligned rows of <= 256 floats; false = not applicable
 bool segment_sum_blocks_supported(const float* in, int64_t is, int64_t n, int width, const float* out, int64_t os);
 hipError_t launch_segment_sum_blocks(const float* in, int64_t is, const int32_t* rowptr, const int32_t* col, const int8_t* deg8,
@@ -173,7 +176,7 @@ bool try_segment_sum_aligned(const float* in, int64_t is, const int32_t* rowptr,
                              float* out, int64_t os, float* inv_norm, hipStream_t st, hipError_t* err);
 bool try_backward_gather_aligned(const float* contrib, int64_t cs, const int32_t* rowptr, const int32_t* rows, const float* x,
                                  int64_t xs, const float* inv, int64_t n, int F, float* gx, int64_t gxs, hipStream_t st,
-                                 hipError_t* err);
+                                 hipError_t* err, bool x_split = false);
 bool try_row_inv_norm_aligned(const float* x, int64_t xs, int64_t n, int width, float* inv, hipStream_t st, hipError_t* err);
 hipError_t launch_segment_sum(const float* in, int64_t is, const int32_t* rowptr, const int32_t* col, int64_t n,
                               int width, float* out, int64_t os, float* inv_norm, hipStream_t st);

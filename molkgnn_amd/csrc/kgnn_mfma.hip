@@ -482,8 +482,13 @@ __global__ void __launch_bounds__(256, 2) kc_forward_fused(FusedFwdArgs a) {
 // (kernels.py:310-317: such an atom is not chiral).  One wave per atom.
 __global__ void __launch_bounds__(256) rows_equal_kernel(const float* __restrict__ x, int64_t xs, const int64_t* __restrict__ nei,
                                                          const float* __restrict__ p_focal, const float* __restrict__ p_nei,
-                                                         int64_t n, int F, int8_t* __restrict__ eq, int8_t* __restrict__ sgn) {
+                                                         int64_t n, int F, int8_t* __restrict__ eq, int8_t* __restrict__ sgn, int x_split) {
     const int lane = threadIdx.x & 63;
+    // pre-split rows (kgnn_split.h): a row's F floats are the same F (rounded up to 4: zero padding) dwords, each two fp16
+    // halves of the scaled row; two rows of equal norm are equal exactly when their halves are (+0 and -0 being equal values,
+    // as under torch.equal) -- rows of different norms differ in some half, or are scaled copies of each other by a power of
+    // two, which h = propagate(sim_sc) does not produce short of an all-zero row
+    if (x_split) F = (F + 3) / 4 * 4;
     int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t r = wave; r < n; r += nwaves) {
@@ -512,8 +517,19 @@ __global__ void __launch_bounds__(256) rows_equal_kernel(const float* __restrict
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = i + 1; j < 4; ++j, ++k) {
-                    if (fa < F && !(va[i] == va[j])) diff |= 1u << k;
-                    if (fb < F && !(vb[i] == vb[j])) diff |= 1u << k;
+                    if (x_split) {
+                        auto same = [](float p, float q) {
+                            const uint32_t a = __float_as_uint(p), b = __float_as_uint(q);
+                            const bool lo_ok = ((a ^ b) & 0xffffu) == 0 || ((a | b) & 0x7fffu) == 0;
+                            const bool hi_ok = ((a ^ b) >> 16) == 0 || ((a | b) & 0x7fff0000u) == 0;
+                            return lo_ok && hi_ok;
+                        };
+                        if (fa < F && !same(va[i], va[j])) diff |= 1u << k;
+                        if (fb < F && !same(vb[i], vb[j])) diff |= 1u << k;
+                    } else {
+                        if (fa < F && !(va[i] == va[j])) diff |= 1u << k;
+                        if (fb < F && !(vb[i] == vb[j])) diff |= 1u << k;
+                    }
                 }
         }
 #pragma unroll
@@ -693,7 +709,7 @@ hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t 
         int64_t blocks = (a.deg[3].n + 3) / 4;
         if (blocks > 2048) blocks = 2048;
         rows_equal_kernel<<<(int)blocks, 256, 0, st>>>(a.x, a.xs, a.deg[3].nei, a.deg[3].p_focal, a.deg[3].p_nei, a.deg[3].n, a.F,
-                                                      (int8_t*)a.deg[3].eqflag, (int8_t*)a.deg[3].signflag);
+                                                      (int8_t*)a.deg[3].eqflag, (int8_t*)a.deg[3].signflag, a.x_split);
     }
     // The reference's bank shapes take the streamed kernel (kgnn_fwd_stream.hip); every other covered shape, and the
     // bf16 variant, the LDS-bank kernel below.  MKGNN_FWD_STREAM=0: A/B switch (diagnostics).
@@ -731,7 +747,7 @@ hipError_t launch_forward_fused(FusedFwdArgs& a, const bool use[4], hipStream_t 
         if (e != hipSuccess) return e;
     }
     if (any_bank) {
-        if (KC == 0) return hipErrorInvalidValue;
+        if (KC == 0 || a.x_split) return hipErrorInvalidValue;      // (pre-split rows: the streamed kernel only; the C ABI checks first)
         int nb = 0;
         const size_t lds_bytes = plan_fused(a, use_bank, KC, &nb);
         if (nb > 0) {

@@ -21,6 +21,7 @@
 #include <cstdint>
 #include "kgnn_common.h"
 #include "kgnn_launch.h"
+#include "kgnn_philox.h"
 #include "../../include/molkgnn_hip.h"
 
 namespace mkgnn {
@@ -731,12 +732,13 @@ __global__ void __launch_bounds__(256) block_project_bwd_mfma_kernel(BlockProjAr
 // Statistics-only companion of a batch norm (mkgnn_bn_stats): the reference runs edge_batch_norm(data.edge_attr) in every
 // forward (MolKGNNNet.py:116) although its output never reaches the kernel convolution; what remains of the
 // call is its side effect in training mode -- running_mean / running_var / num_batches_tracked move.  The rows are summed
-// by extra blocks of the node batch norm's own three launches (no launch of their own in a step), or by
-// mkgnn_batchnorm_update_stats alone.  part: [3][nblk][C] = column sums | centred squares | (column 0) counted rows.
+// by extra blocks of the node batch norm's own two launches (no launch of their own in a step), or by
+// mkgnn_batchnorm_update_stats alone.  part: [3][nblk][C] = column sums | squares about the block's own means | counted rows.
 constexpr int BN_MAIN_BLOCKS = 256;                    // (= BN_BLOCKS: the grid of the batch norm's own passes)
-constexpr int BN_SIDE_BLOCKS = 256;                    // companion blocks at most (a block takes two loop trips or more)
+constexpr int BN_SIDE_BLOCKS = 1024;                   // companion blocks at most (one loop trip per pass each where that is enough)
 struct BnSide {
     const float* x; int64_t xs; int64_t n; int C, CL, nblk;
+    int flat;                                          // contiguous narrow rows: the 16-byte form (bn_side_block_stats_flat)
     float *running_mean, *running_var; float momentum;
     int64_t* nbt;
     const int64_t* key; const int64_t* key_limit;      // both or neither: row r counts iff key[r] < *key_limit
@@ -780,62 +782,173 @@ __device__ __forceinline__ void bn_rows(const BnArgs& a, int64_t& lo, int64_t& h
     if (lo > hi) lo = hi;
 }
 
-// column sums of f(row) over the block's rows into dst[blockIdx.x][c]; CL = padded column count (power of two)
-template <int MODE>   // 0: x   1: (x - mean)^2   2: (dy, dy * xhat) -> part1, part2
-__device__ __forceinline__ void bn_block_colsum(const BnArgs& a, int CL, const float* mean, const float* invstd, float* sh) {
-    const int c = threadIdx.x & (CL - 1), rsub = threadIdx.x / CL, RS = 256 / CL;
+// ---- round 6: statistics in ONE launch, 16-byte row passes ------------------------------------------------------------------
+// Rounds 1-5 took the batch statistics in two launches (column sums; then, with the batch mean known, centred squares) and
+// applied them in a third; every row pass was 4-byte loads, eight in flight per thread -- 8.6 + 8.9 + 14.2 us for an 11.5 MB
+// tensor at batch 4096, bound by load latency times loop trips.  Now a block sums its share of the counted rows (pass A), takes
+// ITS OWN mean, and sums the squares about that (pass B: the rows the block has just pulled into L2).  The batch statistics
+// follow exactly from the block triples (count_b, sum_b, M2_b):
+//     mean = (sum_b sum_b) / n,     M2 = sum_b [ M2_b + count_b (sum_b / count_b - mean)^2 ]          (Chan, Golub, LeVeque 1979)
+// evaluated in a fixed order by every block of the apply launch -- centred sums throughout, like the two-pass form over the
+// whole batch it replaces; one launch less, and the mean itself is bit for bit the old one (the same partial sums).  Rows that
+// are 16-byte aligned with C a multiple of 4 are read as float4, BN_U rows in flight per thread.
+constexpr int BN_U = 16;                               // float4 row loads in flight per thread (statistics passes)
+constexpr int BN_UA = 8;                               // ... in the passes that also write rows
+
+__device__ __forceinline__ float bn_shfl_xor(float v, int o) { return __shfl_xor(v, o, 64); }
+__device__ __forceinline__ f32x4 bn_shfl_xor(f32x4 v, int o) {
+    return f32x4{__shfl_xor(v[0], o, 64), __shfl_xor(v[1], o, 64), __shfl_xor(v[2], o, 64), __shfl_xor(v[3], o, 64)};
+}
+__device__ __forceinline__ void bn_zero(float& v) { v = 0.f; }
+__device__ __forceinline__ void bn_zero(f32x4& v) { v = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+// Sum of v over the threads of the block that share threadIdx.x % LW (LW a power of two, 1 .. 256), in a fixed order: an xor
+// tree over the lanes of a wave, then the waves (or row lanes) in ascending order.  Valid in threads < LW.  shv: 256 V's.
+template <typename V> __device__ __forceinline__ V bn_reduce_rows(V v, int LW, V* shv) {
+    const int t = threadIdx.x;
+    for (int o = 32; o >= LW; o >>= 1) v = v + bn_shfl_xor(v, o);
+    __syncthreads();                                     // (shv may still be read from an earlier reduction)
+    int parts;
+    if (LW <= 64) {
+        if ((t & 63) < LW) shv[(t >> 6) * LW + (t & 63)] = v;
+        parts = 4;
+    } else {
+        shv[t] = v;
+        parts = 256 / LW;
+    }
+    __syncthreads();
+    V r;
+    bn_zero(r);
+    if (t < LW)
+        for (int k = 0; k < parts; ++k) r = r + shv[k * LW + t];
+    return r;
+}
+
+// rows of block b of nblk, the counted rows [0, nv) dealt in equal runs: [lo, hi)
+__device__ __forceinline__ void bn_share(int64_t nv, int nblk, int b, int64_t& lo, int64_t& hi) {
+    const int64_t per = (nv + nblk - 1) / nblk;
+    lo = per * b;
+    hi = lo + per < nv ? lo + per : nv;
+    if (lo > hi) lo = hi;
+}
+
+// One pass over rows [lo, hi) of x (and g): per-thread partial sums.  MODE 0: s0 += x;  1: s0 += (x - mu)^2;  2: s0 += g,
+// s1 += g (x - mu) is.  VEC: thread = (row lane rsub of RS, column group col .. col + 3), float4 loads; else one column c.
+// All loads of a trip are issued before anything is consumed (clamped addresses, masked use).
+template <int MODE, int U>
+__device__ __forceinline__ void bn_pass_vec(const float* x, int64_t xs, const float* g, int64_t gs, int64_t lo, int64_t hi, int rsub, int RS,
+                                            int col, f32x4 mu, f32x4 is, f32x4& s0, f32x4& s1) {
+    for (int64_t r0 = lo + rsub; r0 < hi; r0 += (int64_t)U * RS) {
+        f32x4 v[U], gg[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t rr = r0 + (int64_t)u * RS < hi ? r0 + (int64_t)u * RS : hi - 1;
+            v[u] = *(const f32x4*)(x + rr * xs + col);
+            if (MODE == 2) gg[u] = *(const f32x4*)(g + rr * gs + col);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (r0 + (int64_t)u * RS < hi) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (MODE == 0) s0[e] += v[u][e];
+                    if (MODE == 1) { const float d = v[u][e] - mu[e]; s0[e] = fmaf(d, d, s0[e]); }
+                    if (MODE == 2) { s0[e] += gg[u][e]; s1[e] = fmaf(gg[u][e], (v[u][e] - mu[e]) * is[e], s1[e]); }
+                }
+            }
+        }
+    }
+}
+template <int MODE>
+__device__ __forceinline__ void bn_pass_col(const float* x, int64_t xs, const float* g, int64_t gs, int64_t lo, int64_t hi, int rsub, int RS,
+                                            int c, float mu, float is, float& s0, float& s1) {
+    for (int64_t r0 = lo + rsub; r0 < hi; r0 += 8 * RS) {
+        float v[8], gg[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t rr = r0 + u * RS < hi ? r0 + u * RS : hi - 1;
+            v[u] = x[rr * xs + c];
+            if (MODE == 2) gg[u] = g[rr * gs + c];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (r0 + u * RS < hi) {
+                if (MODE == 0) s0 += v[u];
+                if (MODE == 1) { const float d = v[u] - mu; s0 = fmaf(d, d, s0); }
+                if (MODE == 2) { s0 += gg[u]; s1 = fmaf(gg[u], (v[u] - mu) * is, s1); }
+            }
+        }
+    }
+}
+
+// can the rows of a [*, C] tensor be read as float4?
+static inline bool bn_vec_rows(const void* p, int64_t stride, int C) { return p && C % 4 == 0 && stride % 4 == 0 && ((uintptr_t)p & 15) == 0; }
+
+// Forward statistics of block blockIdx.x: part1[b][c] = column sums of its counted rows, part2[b][c] = squares about the
+// block's own column means.  sh: 1024 floats.
+template <bool VEC>
+__device__ __forceinline__ void bn_block_stats(const BnArgs& a, int CL, float* sh) {
+    __shared__ float bmean[256];
+    const int t = threadIdx.x;
+    int64_t lo, hi;
     // the block's share of the rows that COUNT (not of all rows): the partial sums, and with them the statistics, are then
     // bit for bit those of the same batch without its padding rows -- a padded batch (molkgnn_amd.padding) reproduces the
     // unpadded forward exactly, which matters more than it looks: an ulp in x decides thousands of mathematically tied
     // neighbour orders the other way two layers later
-    const int64_t nv = bn_valid(a);
-    const int64_t per = (nv + bn_nblk() - 1) / bn_nblk();
-    int64_t lo = per * blockIdx.x, hi = lo + per < nv ? lo + per : nv;
-    if (lo > hi) lo = hi;
-    const bool act = c < a.C;
-    const int cc = act ? c : 0;
-    const float mu = (MODE >= 1) ? mean[cc] : 0.f, is = (MODE == 2) ? invstd[cc] : 0.f;
-    float s0 = 0.f, s1 = 0.f;
-    for (int64_t r0 = lo + rsub; r0 < hi; r0 += 8 * RS) {
-        float v[8], g[8];
+    bn_share(bn_valid(a), bn_nblk(), blockIdx.x, lo, hi);
+    const float cnt = (float)(hi - lo);
+    float* const p1 = a.part1 + (int64_t)blockIdx.x * a.C;
+    float* const p2 = a.part2 + (int64_t)blockIdx.x * a.C;
+    if constexpr (VEC) {
+        const int LW = CL >= 4 ? CL / 4 : 1, g = t % LW, rsub = t / LW, RS = 256 / LW, col = 4 * g;
+        const bool act = col < a.C;
+        const int cb = act ? col : 0;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        f32x4 s0 = z, s1 = z;
+        bn_pass_vec<0, BN_U>(a.x, a.xs, nullptr, 0, lo, hi, rsub, RS, cb, z, z, s0, s1);
+        const f32x4 tot = bn_reduce_rows(s0, LW, (f32x4*)sh);
+        if (t < LW && act) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int64_t rr = r0 + u * RS < hi ? r0 + u * RS : hi - 1;
-            v[u] = a.x[rr * a.xs + cc];
-            if (MODE == 2) g[u] = a.gout[rr * a.gos + cc];
+            for (int e = 0; e < 4; ++e) { p1[col + e] = tot[e]; bmean[col + e] = cnt > 0.f ? tot[e] / cnt : 0.f; }
         }
+        __syncthreads();
+        const f32x4 mu = {bmean[cb], bmean[cb + 1], bmean[cb + 2], bmean[cb + 3]};
+        s0 = z;
+        bn_pass_vec<1, BN_U>(a.x, a.xs, nullptr, 0, lo, hi, rsub, RS, cb, mu, z, s0, s1);
+        const f32x4 m2 = bn_reduce_rows(s0, LW, (f32x4*)sh);
+        if (t < LW && act) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (r0 + u * RS < hi && r0 + u * RS < nv) {
-                if (MODE == 0) s0 += v[u];
-                if (MODE == 1) { const float d = v[u] - mu; s0 = fmaf(d, d, s0); }
-                if (MODE == 2) { s0 += g[u]; s1 = fmaf(g[u], (v[u] - mu) * is, s1); }
-            }
+            for (int e = 0; e < 4; ++e) p2[col + e] = m2[e];
         }
-    }
-    // combine the RS row-lanes of each column in a fixed order
-    sh[threadIdx.x] = s0;
-    if (MODE == 2) sh[256 + threadIdx.x] = s1;
-    __syncthreads();
-    if (rsub == 0 && act) {
-        float t0 = 0.f, t1 = 0.f;
-        for (int k = 0; k < RS; ++k) { t0 += sh[k * CL + c]; if (MODE == 2) t1 += sh[256 + k * CL + c]; }
-        float* p1 = (MODE == 1) ? a.part2 : a.part1;
-        p1[(int64_t)blockIdx.x * a.C + c] = t0;
-        if (MODE == 2) a.part2[(int64_t)blockIdx.x * a.C + c] = t1;
+    } else {
+        const int c = t & (CL - 1), rsub = t / CL, RS = 256 / CL;
+        const bool act = c < a.C;
+        const int cc = act ? c : 0;
+        float s0 = 0.f, s1 = 0.f;
+        bn_pass_col<0>(a.x, a.xs, nullptr, 0, lo, hi, rsub, RS, cc, 0.f, 0.f, s0, s1);
+        const float tot = bn_reduce_rows(s0, CL, sh);
+        if (t < CL && act) { p1[c] = tot; bmean[c] = cnt > 0.f ? tot / cnt : 0.f; }
+        __syncthreads();
+        const float mu = bmean[cc];
+        s0 = 0.f;
+        bn_pass_col<1>(a.x, a.xs, nullptr, 0, lo, hi, rsub, RS, cc, mu, 0.f, s0, s1);
+        const float m2 = bn_reduce_rows(s0, CL, sh);
+        if (t < CL && act) p2[c] = m2;
     }
 }
 
-// sum over blocks of part[b][c] for every column, identically in every block (fixed order), result in sh_out[c]
-__device__ __forceinline__ void bn_total(const float* part, int nblk, int C, int CL, float* sh, float* sh_out) {
+// sum over blocks b of term(b, c) for every column c, identically in every block (fixed order), result in sh_out[c];
+// sh: 256 floats
+template <typename Term>
+__device__ __forceinline__ void bn_total_of(int nblk, int C, int CL, float* sh, float* sh_out, Term&& term) {
     const int c = threadIdx.x & (CL - 1), rsub = threadIdx.x / CL, RS = 256 / CL;
     float s = 0.f;
     if (c < C) {
-        // eight loads in flight (every block repeats this sum: serial loads made it the slowest part of the pass)
+        // eight terms in flight (every block repeats this sum: serial loads made it the slowest part of the pass)
         float v[8], t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         for (int b = rsub; b < nblk; b += 8 * RS) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = part[(int64_t)(b + u * RS < nblk ? b + u * RS : b) * C + c];
+            for (int u = 0; u < 8; ++u) v[u] = term(b + u * RS < nblk ? b + u * RS : b, c);
 #pragma unroll
             for (int u = 0; u < 8; ++u) if (b + u * RS < nblk) t[u] += v[u];
         }
@@ -851,67 +964,205 @@ __device__ __forceinline__ void bn_total(const float* part, int nblk, int C, int
     }
     __syncthreads();
 }
+__device__ __forceinline__ void bn_total(const float* part, int nblk, int C, int CL, float* sh, float* sh_out) {
+    bn_total_of(nblk, C, CL, sh, sh_out, [&](int b, int c) { return part[(int64_t)b * C + c]; });
+}
+// squares about the BATCH mean (mean[c]) out of the blocks' (count, sum, squares about their own means)
+__device__ __forceinline__ void bn_total_m2(const float* part1, const float* part2, int nblk, int64_t nv, int C, int CL, const float* mean,
+                                            float* sh, float* sh_out) {
+    const int64_t per = (nv + nblk - 1) / nblk;          // (one 64-bit division per thread, not one per term)
+    const float mu = mean[(threadIdx.x & (CL - 1)) < C ? (threadIdx.x & (CL - 1)) : 0];
+    bn_total_of(nblk, C, CL, sh, sh_out, [&](int b, int c) {
+        int64_t left = nv - per * b;                     // rows of block b: what bn_share deals it
+        left = left < 0 ? 0 : (left > per ? per : left);
+        // (both loads unconditional: a load under a condition would be issued -- and waited for -- on its own, term after term)
+        const float p1 = part1[(int64_t)b * C + c], p2 = part2[(int64_t)b * C + c];
+        const float cnt = (float)left;
+        const float d = p1 / fmaxf(cnt, 1.f) - mu;       // (an empty block: p1 = 0, weight 0)
+        return fmaf(cnt * d, d, p2);
+    });
+}
 
-
-// companion statistics, block `blk` of s.nblk.  MODE 0: column sums + counted rows; MODE 1: centred squares (mean from the
-// totals of MODE 0).  Fixed order everywhere (rows of a block by row lane, row lanes ascending, blocks by bn_total).
-template <int MODE>
-__device__ __forceinline__ void bn_side_colsum(const BnSide& s, int blk, float* sh) {
-    const int CL = s.CL, c = threadIdx.x & (CL - 1), rsub = threadIdx.x / CL, RS = 256 / CL;
+// Companion statistics, block `blk` of s.nblk: plane 0 column sums, plane 1 squares about the block's own column means,
+// plane 2 counted rows (every column of the plane holds the count).  Fixed order everywhere.  sh: 1024 floats
+__device__ __forceinline__ void bn_side_block_stats(const BnSide& s, int blk, float* sh) {
+    __shared__ float smean[256];
+    const int CL = s.CL, t = threadIdx.x, c = t & (CL - 1), rsub = t / CL, RS = 256 / CL;
     const bool act = c < s.C;
     const int cc = act ? c : 0;
-    float mu = 0.f;
-    if (MODE == 1) {                                     // the mean of every column, from the totals
-        __shared__ float tot_sh[256], cnt_sh[256];
-        bn_total(s.part, s.nblk, s.C, CL, sh, tot_sh);
-        bn_total(s.part + (size_t)2 * s.nblk * s.C, s.nblk, s.C, CL, sh, cnt_sh);       // (column 0 holds the counts)
-        mu = tot_sh[cc] / fmaxf(cnt_sh[0], 1.f);
-    }
-    const int64_t per = (s.n + s.nblk - 1) / s.nblk;
-    int64_t lo = per * blk, hi = lo + per < s.n ? lo + per : s.n;
-    if (lo > hi) lo = hi;
+    int64_t lo, hi;
+    bn_share(s.n, s.nblk, blk, lo, hi);
     const int64_t lim = s.key ? *s.key_limit : 0;
-    float s0 = 0.f, cnt = 0.f;
-    for (int64_t r0 = lo + rsub; r0 < hi; r0 += 8 * RS) {
-        float v[8];
-        bool ok[8];
+    float mu = 0.f, m2 = 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int64_t rr = r0 + u * RS < hi ? r0 + u * RS : hi - 1;
-            v[u] = s.x[rr * s.xs + cc];
-            ok[u] = r0 + u * RS < hi && (!s.key || s.key[rr] < lim);
-        }
+    for (int pass = 0; pass < 2; ++pass) {
+        float s0 = 0.f, cnt = 0.f;
+        for (int64_t r0 = lo + rsub; r0 < hi; r0 += 8 * RS) {
+            float v[8];
+            bool ok[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (ok[u]) {
-                if (MODE == 0) { s0 += v[u]; cnt += 1.f; }
-                else { const float d = v[u] - mu; s0 = fmaf(d, d, s0); }
+            for (int u = 0; u < 8; ++u) {
+                const int64_t rr = r0 + u * RS < hi ? r0 + u * RS : hi - 1;
+                v[u] = s.x[rr * s.xs + cc];
+                ok[u] = r0 + u * RS < hi && (!s.key || s.key[rr] < lim);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (ok[u]) {
+                    if (pass == 0) { s0 += v[u]; cnt += 1.f; }
+                    else { const float d = v[u] - mu; s0 = fmaf(d, d, s0); }
+                }
             }
         }
+        const float tot = bn_reduce_rows(s0, CL, sh);
+        if (pass == 0) {
+            const float n_b = bn_reduce_rows(cnt, CL, sh);          // counts: exact below 2^24 rows per block
+            if (t < CL && act) {
+                s.part[((size_t)0 * s.nblk + blk) * s.C + c] = tot;
+                s.part[((size_t)2 * s.nblk + blk) * s.C + c] = n_b;
+                smean[c] = n_b > 0.f ? tot / n_b : 0.f;
+            }
+            __syncthreads();
+            mu = smean[cc];
+        } else {
+            m2 = tot;
+            if (t < CL && act) s.part[((size_t)1 * s.nblk + blk) * s.C + c] = m2;
+        }
     }
-    __syncthreads();
-    sh[threadIdx.x] = s0;
-    if (MODE == 0) sh[256 + threadIdx.x] = cnt;
-    __syncthreads();
-    if (rsub == 0) {
-        float t0 = 0.f, t1 = 0.f;
-        for (int k = 0; k < RS; ++k) { t0 += sh[k * CL + c]; if (MODE == 0) t1 += sh[256 + k * CL + c]; }
-        if (act) s.part[((size_t)MODE * s.nblk + blk) * s.C + c] = t0;
-        // counts: every column of the plane is written (bn_total reads them all); exact below 2^24 rows per block
-        if (MODE == 0 && act) s.part[((size_t)2 * s.nblk + blk) * s.C + c] = t1;
+}
+
+// The same for narrow contiguous rows (x_stride == C <= 8, 16-byte aligned base: the reference's bond rows, [n, 7]): four rows
+// are C whole float4s, so a thread takes groups of four rows with C 16-byte loads each, SIDE_G groups in flight -- 4 096 rows per
+// block and loop trip where the column-per-thread form above takes 256 (a batch of 4 096 molecules has 216 k bond rows: 53
+// blocks of one trip per pass instead of 844, and a final merge over 53 partials instead of 844).
+constexpr int SIDE_G = 4;
+constexpr int SIDE_FLAT_ROWS = 256 * 4 * SIDE_G;       // rows per block and loop trip
+template <int C>
+__device__ __forceinline__ void bn_side_block_stats_flat(const BnSide& s, int blk, float* sh) {
+    __shared__ float smean[8];
+    const int t = threadIdx.x;
+    int64_t lo, hi;
+    bn_share(s.n / 4, s.nblk, blk, lo, hi);              // in units of four rows: the whole groups; the last n % 4 rows below
+    const int64_t lim = s.key ? *s.key_limit : 0;
+    float mu[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) mu[c] = 0.f;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        float acc[C], cnt = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] = 0.f;
+        for (int64_t q0 = lo + t; q0 - t < hi && lo < hi; q0 += 256 * SIDE_G) {
+            f32x4 v[SIDE_G][C];
+            bool ok[SIDE_G][4];
+#pragma unroll
+            for (int g = 0; g < SIDE_G; ++g) {
+                const int64_t q = q0 + 256 * g;                       // rows 4 q .. 4 q + 3
+                const int64_t qc = q < hi ? q : hi - 1;
+#pragma unroll
+                for (int c = 0; c < C; ++c) v[g][c] = *(const f32x4*)(s.x + 4 * qc * C + 4 * c);      // (all loads unconditional)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) ok[g][r] = q < hi && (!s.key || s.key[4 * qc + r] < lim);
+            }
+#pragma unroll
+            for (int g = 0; g < SIDE_G; ++g)
+#pragma unroll
+                for (int e = 0; e < 4 * C; ++e) {                     // element e of the group: row e / C, column e % C
+                    if (ok[g][e / C]) {
+                        const float x = v[g][e / 4][e % 4];
+                        if (pass == 0) { acc[e % C] += x; if (e % C == 0) cnt += 1.f; }
+                        else { const float d = x - mu[e % C]; acc[e % C] = fmaf(d, d, acc[e % C]); }
+                    }
+                }
+        }
+        if (blk == s.nblk - 1 && t == 0) {                            // the tensor's last n % 4 rows: a few scalar loads of one thread
+            for (int64_t row = s.n / 4 * 4; row < s.n; ++row) {
+                if (s.key && !(s.key[row] < lim)) continue;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float x = s.x[row * C + c];
+                    if (pass == 0) acc[c] += x;
+                    else { const float d = x - mu[c]; acc[c] = fmaf(d, d, acc[c]); }
+                }
+                if (pass == 0) cnt += 1.f;
+            }
+        }
+        // every thread holds every column: an xor tree over the wave, the four waves in order -- all C + 1 sums behind ONE pair of
+        // barriers (one reduction per column cost more than the row pass itself)
+        float tot[C], n_b = cnt;
+#pragma unroll
+        for (int c = 0; c < C; ++c) tot[c] = acc[c];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) tot[c] += __shfl_xor(tot[c], o, 64);
+            n_b += __shfl_xor(n_b, o, 64);
+        }
+        __syncthreads();
+        if ((t & 63) == 0) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) sh[(t >> 6) * 16 + c] = tot[c];
+            sh[(t >> 6) * 16 + 8] = n_b;
+        }
+        __syncthreads();
+        if (t == 0) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) tot[c] = ((sh[c] + sh[16 + c]) + sh[32 + c]) + sh[48 + c];
+            n_b = ((sh[8] + sh[24]) + sh[40]) + sh[56];
+        }
+        if (t == 0) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                if (pass == 0) {
+                    s.part[((size_t)0 * s.nblk + blk) * C + c] = tot[c];
+                    s.part[((size_t)2 * s.nblk + blk) * C + c] = n_b;
+                    smean[c] = n_b > 0.f ? tot[c] / n_b : 0.f;
+                } else {
+                    s.part[((size_t)1 * s.nblk + blk) * C + c] = tot[c];
+                }
+            }
+        }
+        __syncthreads();
+        if (pass == 0) {
+#pragma unroll
+            for (int c = 0; c < C; ++c) mu[c] = smean[c];
+        }
+    }
+}
+__device__ __forceinline__ bool bn_side_is_flat(const BnSide& s) { return s.flat != 0; }
+__device__ __forceinline__ void bn_side_stats_any(const BnSide& s, int blk, float* sh) {
+    if (!bn_side_is_flat(s)) { bn_side_block_stats(s, blk, sh); return; }
+    switch (s.C) {
+        case 1: bn_side_block_stats_flat<1>(s, blk, sh); break;
+        case 2: bn_side_block_stats_flat<2>(s, blk, sh); break;
+        case 3: bn_side_block_stats_flat<3>(s, blk, sh); break;
+        case 4: bn_side_block_stats_flat<4>(s, blk, sh); break;
+        case 5: bn_side_block_stats_flat<5>(s, blk, sh); break;
+        case 6: bn_side_block_stats_flat<6>(s, blk, sh); break;
+        case 7: bn_side_block_stats_flat<7>(s, blk, sh); break;
+        default: bn_side_block_stats_flat<8>(s, blk, sh); break;
     }
 }
 
 // running <- running + momentum (batch - running), unbiased variance, counter + 1 (one block)
 __device__ __forceinline__ void bn_side_final(const BnSide& s, float* sh) {
-    __shared__ float tot_sh[256], sq_sh[256], cnt_sh[256];
-    bn_total(s.part, s.nblk, s.C, s.CL, sh, tot_sh);
-    bn_total(s.part + (size_t)s.nblk * s.C, s.nblk, s.C, s.CL, sh, sq_sh);
-    bn_total(s.part + (size_t)2 * s.nblk * s.C, s.nblk, s.C, s.CL, sh, cnt_sh);
+    __shared__ float tot_sh[256], sq_sh[256], cnt_sh[256], mu_sh[256];
+    const float* const sums = s.part;
+    const float* const sqs = s.part + (size_t)s.nblk * s.C;
+    const float* const cnts = s.part + (size_t)2 * s.nblk * s.C;
+    bn_total(sums, s.nblk, s.C, s.CL, sh, tot_sh);
+    bn_total(cnts, s.nblk, s.C, s.CL, sh, cnt_sh);
     const int col = threadIdx.x;
     const float cnt = cnt_sh[0];
+    if (col < s.C) mu_sh[col] = cnt > 0.f ? tot_sh[col] / cnt : 0.f;
+    __syncthreads();
+    bn_total_of(s.nblk, s.C, s.CL, sh, sq_sh, [&](int b, int c) {
+        const float n_b = cnts[(size_t)b * s.C + c], s_b = sums[(size_t)b * s.C + c], q_b = sqs[(size_t)b * s.C + c];     // (unconditional loads)
+        const float d = s_b / fmaxf(n_b, 1.f) - mu_sh[c];
+        return fmaf(n_b * d, d, q_b);
+    });
     if (col < s.C && cnt > 0.f) {
-        const float mu = tot_sh[col] / cnt, var = sq_sh[col] / cnt;
+        const float mu = mu_sh[col], var = sq_sh[col] / cnt;
         if (s.running_mean) s.running_mean[col] = fmaf(s.momentum, mu - s.running_mean[col], s.running_mean[col]);
         if (s.running_var) {
             const float unbiased = cnt > 1.f ? var * (cnt / (cnt - 1.f)) : var;
@@ -921,53 +1172,41 @@ __device__ __forceinline__ void bn_side_final(const BnSide& s, float* sh) {
     if (threadIdx.x == 0 && s.nbt) s.nbt[0] += 1;
 }
 
-// the companion alone: three launches, or -- one block's worth of rows -- one
+// the companion alone: two launches (phase 0: block statistics, phase 2: totals), or -- one block's worth of rows -- one (phase 3)
 __global__ void __launch_bounds__(256) bn_side_kernel(BnSide s, int phase) {
-    __shared__ float sh[512];
-    if (phase == 0 || phase == 3) bn_side_colsum<0>(s, blockIdx.x, sh);
+    __shared__ float sh[1024];
+    if (phase == 0 || phase == 3) bn_side_stats_any(s, blockIdx.x, sh);
     if (phase == 3) __syncthreads();                     // (one block: its own global stores are visible to it behind a barrier)
-    if (phase == 1 || phase == 3) bn_side_colsum<1>(s, blockIdx.x, sh);
-    if (phase == 3) __syncthreads();
     if (phase == 2 || phase == 3) bn_side_final(s, sh);
 }
 
-__global__ void __launch_bounds__(256) bn_sum_kernel(BnArgs a, int CL) {
-    __shared__ float sh[512];
+template <bool VEC>
+__global__ void __launch_bounds__(256) bn_stats_kernel(BnArgs a, int CL) {
+    __shared__ float sh[1024];
     if (blockIdx.x >= BN_MAIN_BLOCKS) {
-        bn_side_colsum<0>(a.side, blockIdx.x - BN_MAIN_BLOCKS, sh);
+        bn_side_stats_any(a.side, blockIdx.x - BN_MAIN_BLOCKS, sh);
         if (a.side.nblk == 1) {                          // a companion of one block's worth of rows: all of it here, in this launch
             __syncthreads();                             // (its own global stores are visible to the block behind a barrier)
-            bn_side_colsum<1>(a.side, 0, sh);
-            __syncthreads();
             bn_side_final(a.side, sh);
         }
         return;
     }
-    bn_block_colsum<0>(a, CL, nullptr, nullptr, sh);
-}
-
-__global__ void __launch_bounds__(256) bn_var_kernel(BnArgs a, int CL) {
-    __shared__ float sh[512];
-    __shared__ float mean[256];
-    if (blockIdx.x >= BN_MAIN_BLOCKS) { bn_side_colsum<1>(a.side, blockIdx.x - BN_MAIN_BLOCKS, sh); return; }
-    bn_total(a.part1, bn_nblk(), a.C, CL, sh, mean);
-    if (threadIdx.x < a.C) mean[threadIdx.x] = mean[threadIdx.x] / (float)bn_valid(a);
-    __syncthreads();
-    bn_block_colsum<1>(a, CL, mean, nullptr, sh);
+    bn_block_stats<VEC>(a, CL, sh);
 }
 
 __global__ void __launch_bounds__(256) bn_apply_kernel(BnArgs a, int CL) {
-    __shared__ float sh[512];
+    __shared__ float sh[1024];
     __shared__ float mean[256], invstd[256], scale[256], shift[256];
     const int t = threadIdx.x;
     if (blockIdx.x >= BN_MAIN_BLOCKS) { bn_side_final(a.side, sh); return; }      // (one extra block, training mode only)
     if (a.training) {
+        const int64_t nv = bn_valid(a);
         bn_total(a.part1, bn_nblk(), a.C, CL, sh, mean);
-        bn_total(a.part2, bn_nblk(), a.C, CL, sh, invstd);
+        if (t < a.C) mean[t] = mean[t] / (float)nv;
+        __syncthreads();
+        bn_total_m2(a.part1, a.part2, bn_nblk(), nv, a.C, CL, mean, sh, invstd);
         if (t < a.C) {
-            const int64_t nv = bn_valid(a);
-            const float mu = mean[t] / (float)nv, var = invstd[t] / (float)nv;
-            mean[t] = mu;
+            const float mu = mean[t], var = invstd[t] / (float)nv;
             invstd[t] = 1.f / sqrtf(var + a.eps);
             if (blockIdx.x == 0) {
                 a.save_mean[t] = mu;
@@ -1006,12 +1245,12 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(BnArgs a, int CL) {
         f32x4 mu4, sc4, sh4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { mu4[e] = mean[cb + e]; sc4[e] = scale[cb + e]; sh4[e] = shift[cb + e]; }
-        for (int64_t r0 = lo + rs8; r0 - rs8 < hi; r0 += 4 * 32) {
-            f32x4 v[4];
+        for (int64_t r0 = lo + rs8; r0 - rs8 < hi; r0 += BN_UA * 32) {
+            f32x4 v[BN_UA];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) v[u] = *(const f32x4*)(a.x + (r0 + u * 32 < hi ? r0 + u * 32 : hi - 1) * a.xs + cb);
+            for (int u = 0; u < BN_UA; ++u) v[u] = *(const f32x4*)(a.x + (r0 + u * 32 < hi ? r0 + u * 32 : hi - 1) * a.xs + cb);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < BN_UA; ++u) {
                 const bool ok = r0 + u * 32 < hi;
                 f32x4 o;
 #pragma unroll
@@ -1036,11 +1275,42 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(BnArgs a, int CL) {
     }
 }
 
+// backward: per-block column sums of dy and dy * xhat over the block's counted rows -> part1, part2
+template <bool VEC>
 __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(BnArgs a, int CL) {
-    __shared__ float sh[512];
-    bn_block_colsum<2>(a, CL, a.save_mean, a.save_invstd, sh);
+    __shared__ float sh[1024];
+    const int t = threadIdx.x;
+    int64_t lo, hi;
+    bn_share(bn_valid(a), bn_nblk(), blockIdx.x, lo, hi);
+    float* const p1 = a.part1 + (int64_t)blockIdx.x * a.C;
+    float* const p2 = a.part2 + (int64_t)blockIdx.x * a.C;
+    if constexpr (VEC) {
+        const int LW = CL >= 4 ? CL / 4 : 1, g = t % LW, rsub = t / LW, RS = 256 / LW, col = 4 * g;
+        const bool act = col < a.C;
+        const int cb = act ? col : 0;
+        const f32x4 mu = {a.save_mean[cb], a.save_mean[cb + 1], a.save_mean[cb + 2], a.save_mean[cb + 3]};
+        const f32x4 is = {a.save_invstd[cb], a.save_invstd[cb + 1], a.save_invstd[cb + 2], a.save_invstd[cb + 3]};
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+        bn_pass_vec<2, BN_UA>(a.x, a.xs, a.gout, a.gos, lo, hi, rsub, RS, cb, mu, is, s0, s1);
+        const f32x4 t0 = bn_reduce_rows(s0, LW, (f32x4*)sh);
+        const f32x4 t1 = bn_reduce_rows(s1, LW, (f32x4*)sh);
+        if (t < LW && act) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { p1[col + e] = t0[e]; p2[col + e] = t1[e]; }
+        }
+    } else {
+        const int c = t & (CL - 1), rsub = t / CL, RS = 256 / CL;
+        const bool act = c < a.C;
+        const int cc = act ? c : 0;
+        float s0 = 0.f, s1 = 0.f;
+        bn_pass_col<2>(a.x, a.xs, a.gout, a.gos, lo, hi, rsub, RS, cc, a.save_mean[cc], a.save_invstd[cc], s0, s1);
+        const float t0 = bn_reduce_rows(s0, CL, sh);
+        const float t1 = bn_reduce_rows(s1, CL, sh);
+        if (t < CL && act) { p1[c] = t0; p2[c] = t1; }
+    }
 }
 
+template <bool VEC>
 __global__ void __launch_bounds__(256) bn_bwd_final_kernel(BnArgs a, int CL, int nblk_part) {
     __shared__ float sh[512];
     __shared__ float sdy[256], sdyx[256];
@@ -1055,24 +1325,58 @@ __global__ void __launch_bounds__(256) bn_bwd_final_kernel(BnArgs a, int CL, int
     int64_t lo, hi;
     bn_rows(a, lo, hi);
     const float invn = 1.f / (float)bn_valid(a);
-    const int c = t & (CL - 1), rsub = t / CL, RS = 256 / CL;
-    if (c < a.C) {
-        const float w = a.weight ? a.weight[c] : 1.f;
-        const float is = a.save_invstd[c], mu = a.save_mean[c];
-        const float k0 = w * is, s0 = sdy[c] * invn, s1 = sdyx[c] * invn;
-        for (int64_t r0 = lo + rsub; r0 < hi; r0 += 4 * RS) {
-            float dy[4], xv[4];
+    if constexpr (VEC) {
+        const int LW = CL >= 4 ? CL / 4 : 1, g = t % LW, rsub = t / LW, RS = 256 / LW, col = 4 * g;
+        const bool act = col < a.C;
+        const int cb = act ? col : 0;
+        f32x4 k0, is, mu, s0, s1;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int64_t rr = r0 + u * RS < hi ? r0 + u * RS : hi - 1;
-                dy[u] = a.gout[rr * a.gos + c];
-                xv[u] = a.x[rr * a.xs + c];
+        for (int e = 0; e < 4; ++e) {
+            const float w = a.weight ? a.weight[cb + e] : 1.f;
+            is[e] = a.save_invstd[cb + e]; mu[e] = a.save_mean[cb + e];
+            k0[e] = w * is[e]; s0[e] = sdy[cb + e] * invn; s1[e] = sdyx[cb + e] * invn;
+        }
+        for (int64_t r0 = lo + rsub; r0 < hi; r0 += (int64_t)BN_UA * RS) {
+            f32x4 dy[BN_UA], xv[BN_UA];
+#pragma unroll
+            for (int u = 0; u < BN_UA; ++u) {
+                const int64_t rr = r0 + (int64_t)u * RS < hi ? r0 + (int64_t)u * RS : hi - 1;
+                dy[u] = *(const f32x4*)(a.gout + rr * a.gos + cb);
+                xv[u] = *(const f32x4*)(a.x + rr * a.xs + cb);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (r0 + u * RS < hi) {
-                    const float xh = (xv[u] - mu) * is;
-                    a.gx[(r0 + u * RS) * a.gxs + c] = a.training ? k0 * (dy[u] - (s0 + xh * s1)) : k0 * dy[u];
+            for (int u = 0; u < BN_UA; ++u) {
+                if (r0 + (int64_t)u * RS < hi && act) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xh = (xv[u][e] - mu[e]) * is[e];
+                        o[e] = a.training ? k0[e] * (dy[u][e] - (s0[e] + xh * s1[e])) : k0[e] * dy[u][e];
+                    }
+                    *(f32x4*)(a.gx + (r0 + (int64_t)u * RS) * a.gxs + col) = o;
+                }
+            }
+        }
+    } else {
+        const int c = t & (CL - 1), rsub = t / CL, RS = 256 / CL;
+        if (c < a.C) {
+            const float w = a.weight ? a.weight[c] : 1.f;
+            const float is = a.save_invstd[c], mu = a.save_mean[c];
+            const float k0 = w * is, s0 = sdy[c] * invn, s1 = sdyx[c] * invn;
+            for (int64_t r0 = lo + rsub; r0 < hi; r0 += 4 * RS) {
+                float dy[4], xv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int64_t rr = r0 + u * RS < hi ? r0 + u * RS : hi - 1;
+                    dy[u] = a.gout[rr * a.gos + c];
+                    xv[u] = a.x[rr * a.xs + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (r0 + u * RS < hi) {
+                        const float xh = (xv[u] - mu) * is;
+                        a.gx[(r0 + u * RS) * a.gxs + c] = a.training ? k0 * (dy[u] - (s0 + xh * s1)) : k0 * dy[u];
+                    }
                 }
             }
         }
@@ -1094,27 +1398,6 @@ struct HeadArgs {
     int64_t* rng_used;             // forward writes / backward reads the {seed, offset} of this call's mask
 };
 constexpr int HEAD_ROWS = 16;       // rows per block (two per half-wave: the block's latency is one row's chain, mostly its Philox rounds)
-
-// Philox4x32-10 (Salmon et al., SC'11): counter-based, so the backward regenerates the forward's mask instead of
-// storing it.  counter = (element / 4, offset), key = seed; element e takes word e % 4.
-__device__ __forceinline__ uint32_t philox_word(uint64_t seed, uint64_t offset, uint64_t element) {
-    uint32_t c0 = (uint32_t)(element >> 2), c1 = (uint32_t)(element >> 34), c2 = (uint32_t)offset, c3 = (uint32_t)(offset >> 32);
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    const uint32_t w[4] = {c0, c1, c2, c3};
-    return w[element & 3];
-}
-// dropout multiplier of element e: 0 with probability p, else 1 / (1 - p)
-__device__ __forceinline__ float keep_scale_of(uint64_t seed, uint64_t offset, uint64_t element, float p) {
-    const float u = (float)(philox_word(seed, offset, element) >> 8) * (1.f / 16777216.f);     // [0, 1)
-    return u >= p ? 1.f / (1.f - p) : 0.f;
-}
 
 __device__ __forceinline__ float half_wave_sum(float v) {   // xor tree over the 32 lanes of a row
 #pragma unroll
@@ -1753,8 +2036,9 @@ static int bn_side_setup(const char* who, const mkgnn_bn_stats* c, void* ws, siz
     while (s.CL < s.C) s.CL <<= 1;
     s.running_mean = c->running_mean; s.running_var = c->running_var; s.momentum = c->momentum; s.nbt = c->num_batches_tracked;
     s.key = c->row_key; s.key_limit = c->key_limit; s.part = (float*)ws;
-    const int64_t rows_per_pass = 8 * (256 / s.CL);      // rows a block takes per loop trip
-    int64_t nb = (c->n_rows + 2 * rows_per_pass - 1) / (2 * rows_per_pass);
+    s.flat = (c->C <= 8 && c->x_stride == c->C && ((uintptr_t)c->x & 15) == 0) ? 1 : 0;
+    const int64_t rows_per_pass = s.flat ? SIDE_FLAT_ROWS : 8 * (256 / s.CL);      // rows a block takes per loop trip
+    int64_t nb = (c->n_rows + rows_per_pass - 1) / rows_per_pass;
     s.nblk = (int)(nb < 1 ? 1 : (nb > BN_SIDE_BLOCKS ? BN_SIDE_BLOCKS : nb));
     return 0;
 }
@@ -1770,7 +2054,6 @@ int mkgnn_batchnorm_update_stats(const mkgnn_bn_stats* c, void* ws, size_t ws_by
         bn_side_kernel<<<1, 256, 0, st>>>(s, 3);
     } else {
         bn_side_kernel<<<s.nblk, 256, 0, st>>>(s, 0);
-        bn_side_kernel<<<s.nblk, 256, 0, st>>>(s, 1);
         bn_side_kernel<<<1, 256, 0, st>>>(s, 2);
     }
     hipError_t e = hipGetLastError();
@@ -1814,9 +2097,9 @@ int mkgnn_batchnorm_forward_with_stats(const float* x, int64_t x_stride, int64_t
         if (int rc = bn_side_setup("mkgnn_batchnorm_forward", companion, companion_ws, companion_ws_bytes, a.side)) return rc;
         if ((int64_t)companion->n_rows * a.side.CL <= 64 * 1024) { a.side.nblk = 1; side_single = true; }
     }
-    if (training) {
-        bn_sum_kernel<<<BN_BLOCKS + a.side.nblk, 256, 0, st>>>(a, CL);
-        bn_var_kernel<<<BN_BLOCKS + (side_single ? 0 : a.side.nblk), 256, 0, st>>>(a, CL);
+    if (training) {                                      // block statistics (the companion's blocks behind the batch norm's own)
+        if (bn_vec_rows(x, x_stride, C)) bn_stats_kernel<true><<<BN_BLOCKS + a.side.nblk, 256, 0, st>>>(a, CL);
+        else bn_stats_kernel<false><<<BN_BLOCKS + a.side.nblk, 256, 0, st>>>(a, CL);
     }
     bn_apply_kernel<<<BN_BLOCKS + ((a.side.nblk && !side_single) ? 1 : 0), 256, 0, st>>>(a, CL);
     hipError_t e = hipGetLastError();
@@ -1841,8 +2124,13 @@ int mkgnn_batchnorm_backward(const float* grad_out, int64_t grad_out_stride, con
     a.part1 = (float*)ws; a.part2 = a.part1 + (size_t)BN_BLOCKS * C;
     a.gout = grad_out; a.gos = grad_out_stride; a.gx = grad_x; a.gxs = grad_x_stride;
     a.gweight = grad_weight; a.gbias = grad_bias; a.nvalid = n_valid_rows;
-    bn_bwd_partial_kernel<<<BN_BLOCKS, 256, 0, st>>>(a, CL);
-    bn_bwd_final_kernel<<<grad_x ? BN_BLOCKS : 1, 256, 0, st>>>(a, CL, BN_BLOCKS);
+    if (bn_vec_rows(x, x_stride, C) && bn_vec_rows(grad_out, grad_out_stride, C) && (!grad_x || bn_vec_rows(grad_x, grad_x_stride, C))) {
+        bn_bwd_partial_kernel<true><<<BN_BLOCKS, 256, 0, st>>>(a, CL);
+        bn_bwd_final_kernel<true><<<grad_x ? BN_BLOCKS : 1, 256, 0, st>>>(a, CL, BN_BLOCKS);
+    } else {
+        bn_bwd_partial_kernel<false><<<BN_BLOCKS, 256, 0, st>>>(a, CL);
+        bn_bwd_final_kernel<false><<<grad_x ? BN_BLOCKS : 1, 256, 0, st>>>(a, CL, BN_BLOCKS);
+    }
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : api_hip_fail("mkgnn_batchnorm_backward", e);
 }

@@ -115,6 +115,48 @@ def row_inv_norm(x: torch.Tensor) -> torch.Tensor:
 
 
 BANK_PREPARED = 0x200        # MKGNN_VARIANT_BANK_PREPARED
+ROWS_SPLIT = 0x400           # MKGNN_VARIANT_ROWS_SPLIT / MKGNN_BACKWARD_ROWS_SPLIT
+# Pre-split rows (round 6; csrc/kgnn_split.h): a tensor that only the next kernel convolution reads -- h = propagate(sim_sc)
+# between two layers (reference KernelLayer.py:119-123 -> kernels.py:527,543), the batch norm's output in front of the
+# first -- is written by its producer as the fp16 hi | lo halves the matrix instructions take (same bytes, same strides), so
+# that no wave converts a row again.  Such a tensor carries this attribute; its float32 VALUES are meaningless to anybody
+# but `kernelsetconv`, which is why only MolGCN.forward / MolKGNNNet.forward ask for it, for tensors they never hand out.
+# MKGNN_ROWS_SPLIT=0 turns it off (the library answers mkgnn_rows_split_supported with 0).
+_SPLIT_ATTR = "_mkgnn_rows_split"
+
+
+_PRODUCTS_EPOCH = 0          # bumped by debug_set_products: answers remembered per batch (kernels._accepts_split_rows) go stale
+
+
+def debug_set_products(forward: int = -1, backward: int = -1) -> None:
+    """Diagnostics / bench.py's exact-fp32 leg: 1 / 0 = split-fp16 / fp32 matrix instructions for the node-feature products of
+    the streamed forward and backward kernels from the next launch on, -1 = what the environment says
+    (``mkgnn_debug_set_forward_products`` / ``_backward_products``).  Pre-split rows follow: they exist only with both on."""
+    global _PRODUCTS_EPOCH
+    lib = _lib.load()
+    _lib.check(lib.mkgnn_debug_set_forward_products(int(forward)), "mkgnn_debug_set_forward_products")
+    _lib.check(lib.mkgnn_debug_set_backward_products(int(backward)), "mkgnn_debug_set_backward_products")
+    _PRODUCTS_EPOCH += 1
+
+
+def is_rows_split(x: torch.Tensor) -> bool:
+    """``x`` holds pre-split rows (and has not been modified since its producer wrote them)."""
+    tag = getattr(x, _SPLIT_ATTR, None)
+    return tag is not None and tag == x._version
+
+
+def mark_rows_split(x: torch.Tensor) -> torch.Tensor:
+    setattr(x, _SPLIT_ATTR, x._version)
+    return x
+
+
+def rows_split_supported(plan: BatchPlan, params: Sequence[torch.Tensor], F: int, E: int, n_atoms: int) -> bool:
+    """``mkgnn_rows_split_supported``: would a ``kernelsetconv`` over these banks and buckets, on rows of ``F`` floats in
+    16-byte aligned storage, take pre-split rows in its forward and its backward?"""
+    banks, Ls, keep = _banks([p.detach() for p in params], F, E)
+    buckets = _buckets(plan, E, False)
+    F4, K4 = F + (-F) % 4, sum(Ls) + (-sum(Ls)) % 4
+    return bool(_lib.load().mkgnn_rows_split_supported(banks, buckets, F4, K4, n_atoms, F, E))
 
 
 class PreparedBank:
@@ -168,7 +210,13 @@ def _forward_impl(x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad
                   inv=None, prepared: Optional[PreparedBank] = None):
     lib = _lib.load()
     _lib.require_gpu_tensor(x, "x")
-    x = _row_major(x) if (variant & 0xFF) == VARIANTS["generic"] else _aligned_rows(x)
+    x_split = is_rows_split(x)
+    if x_split:
+        if _stride0(x) % 4 or x.data_ptr() % 16 or x.stride(1) != 1 or inv is None:
+            raise _lib.MolKGNNLibraryError("pre-split rows must stay in the storage their producer wrote (with their row norms)")
+        variant |= ROWS_SPLIT
+    else:
+        x = _row_major(x) if (variant & 0xFF) == VARIANTS["generic"] else _aligned_rows(x)
     n, F = x.shape
     dev = x.device
     banks, Ls, keep = _banks(params, F, E)
@@ -215,7 +263,7 @@ def _forward_impl(x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad
                 banks, buckets, x.data_ptr(), _stride0(x), inv.data_ptr(), n, F, E, int(bool(is_last_layer)),
                 out_full.data_ptr(), out_w, saved, ws.data_ptr(), ws_bytes, variant, st),
                 "mkgnn_kernelsetconv_forward")
-    return x, out_full, inv, saved_t, Ls, ws
+    return x, out_full, inv, saved_t, Ls, ws, x_split
 
 
 # MKGNN_TORCH_OPS=1: the forward / backward calls go through the registered operators (torch.ops.molkgnn.*,
@@ -265,8 +313,8 @@ def kernelsetconv_details(x, plan: BatchPlan, is_last_layer: bool, params, edge_
     ``(pair_state [N_d, L_d, 4], chirality [N_d, L_d])``, without any further device work).  Used by the parity tests for
     the tie-aware criterion and by bench.py's forward timing."""
     with torch.no_grad():
-        _, out, _, saved_t, _, _ = _forward_impl(x, plan, is_last_layer, VARIANTS[variant], 0, edge_attr_dim,
-                                              [p.detach() for p in params], True, _handed_inv_norm(x))
+        _, out, _, saved_t, _, _, _ = _forward_impl(x, plan, is_last_layer, VARIANTS[variant], 0, edge_attr_dim,
+                                                 [p.detach() for p in params], True, _handed_inv_norm(x))
     if raw:
         return out, saved_t
 
@@ -321,11 +369,12 @@ class _KernelSetConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad: int, E: int, inv, bwd_variant: int,
-                propagate: bool, prepared, *params):
+                propagate, prepared, *params):
         need_grad = any(ctx.needs_input_grad)
         ctx.bwd_variant = int(bwd_variant)
-        x, out_full, inv, saved_t, Ls, ws = _forward_impl(x, plan, is_last_layer, variant, out_pad, E, params, need_grad, inv,
-                                                          prepared)
+        x, out_full, inv, saved_t, Ls, ws, x_split = _forward_impl(x, plan, is_last_layer, variant, out_pad, E, params, need_grad,
+                                                                   inv, prepared)
+        ctx.x_split = x_split
         ctx.plan, ctx.is_last, ctx.E, ctx.Ls = plan, bool(is_last_layer), E, Ls
         # the workspace holds the normalised kernel bank: backward reuses it (and the buffer) instead of redoing it
         ctx.ws = ws if need_grad else None
@@ -340,8 +389,9 @@ class _KernelSetConvFn(torch.autograd.Function):
         # ... followed by MolGCN.propagate (KernelLayer.py:119-123) on the block rows, as ONE differentiable operator: its
         # backward hands the gradient of h straight to the kernels (MKGNN_BACKWARD_THROUGH_NEIGHBOURS) where they can
         # fold the propagate step's gradient in, instead of making a pass over the edges for it
+        # (propagate == "split": h is written pre-split -- mode 3 -- for a caller whose only reader is the next convolution)
         inv_h = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
-        h = _segment_sum_blocks(sim_sc, plan.csr_in_packed, None, tuple(Ls), 1, (-K) % 4, inv_h)
+        h = _segment_sum_blocks(sim_sc, plan.csr_in_packed, None, tuple(Ls), 3 if propagate == "split" else 1, (-K) % 4, inv_h)
         ctx.mark_non_differentiable(inv_h)
         ctx.set_materialize_grads(False)
         return h, inv_h
@@ -412,7 +462,7 @@ class _KernelSetConvFn(torch.autograd.Function):
                 all(p._version == v for p, v in zip(params, ctx.param_versions))
             if not reuse:
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            bwd_variant = ctx.bwd_variant | through
+            bwd_variant = ctx.bwd_variant | through | (ROWS_SPLIT if ctx.x_split else 0)
             live = [p for p in params if p.requires_grad]
             defer = _Deferred.active and all(p.grad is None and id(p) not in _Deferred.seen for p in live)
             if defer:
@@ -467,9 +517,13 @@ def kernelsetconv(x: torch.Tensor, plan: BatchPlan, is_last_layer: bool, params:
     if propagate:
         if not block_rows:
             raise ValueError("propagate=True continues on block rows: block_rows=True is required")
+        if propagate not in (True, "split"):
+            raise ValueError('propagate: False, True, or "split" (h written pre-split for the next kernelsetconv)')
         h, inv_h = _KernelSetConvFn.apply(x, plan, is_last_layer, VARIANTS[variant] | BLOCK_ROWS, out_pad, edge_attr_dim,
-                                          _handed_inv_norm(x), BACKWARD_VARIANTS[backward_variant], True, prepared, *params)
+                                          _handed_inv_norm(x), BACKWARD_VARIANTS[backward_variant], propagate, prepared, *params)
         setattr(h, _INV_ATTR, (inv_h, h._version))
+        if propagate == "split":
+            mark_rows_split(h)
         return h
     out = _KernelSetConvFn.apply(x, plan, is_last_layer, VARIANTS[variant] | (BLOCK_ROWS if block_rows else 0), out_pad,
                                  edge_attr_dim, _handed_inv_norm(x), BACKWARD_VARIANTS[backward_variant], False, prepared,
@@ -530,7 +584,7 @@ def _segment_sum_blocks(v, csr, deg8, blocks, mode: int, out_pad: int, inv) -> t
     n, w = v.shape
     if sum(blocks) != w or (w + out_pad) % 4 or _stride0(v) % 4 or v.data_ptr() % 16:
         raise _lib.MolKGNNLibraryError("block-row propagate needs 16-byte aligned rows whose width is the sum of the blocks")
-    # mode 1 writes whole rows (alignment padding included); mode 2 leaves everything outside the blocks undefined --
+    # mode 1 (and 3: the same rows, pre-split) writes whole rows (alignment padding included); mode 2 leaves everything outside the blocks undefined --
     # the padding too: its only reader is the convolution's backward, which reads blocks
     out = torch.empty((n, w + out_pad), dtype=torch.float32, device=v.device)
     with torch.cuda.device(v.device):

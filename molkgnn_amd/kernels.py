@@ -201,12 +201,30 @@ class BaseKernelSetConv(Module):
         """One trainable KernelConv per degree and no fixed ones (the reference's KernelSetConv): one bank per call."""
         return all(k is not None for k in self.trainable_kernelconv_set) and all(k is None for k in self.fixed_kernelconv_set)
 
-    def _run(self, x, plan: BatchPlan, is_last_layer, save_score=False, block_rows=False, fuse_propagate=False, prepared=None):
+    def _run(self, x, plan: BatchPlan, is_last_layer, save_score=False, block_rows=False, fuse_propagate=False, prepared=None,
+             split_next=False):
         """``sim_sc`` of this layer; with ``fuse_propagate`` (and block rows applicable) ``(h, True)`` where
         ``h = propagate(sim_sc)`` came out of the same operator (functional.kernelsetconv(propagate=True)), else
-        ``(sim_sc, False)``."""
-        out = self._run_impl(x, plan, is_last_layer, save_score, block_rows, fuse_propagate, prepared)
+        ``(sim_sc, False)``.  ``split_next``: the only reader of that ``h`` is a layer that takes pre-split rows
+        (``_accepts_split_rows``): it is written in that form (functional.ROWS_SPLIT)."""
+        out = self._run_impl(x, plan, is_last_layer, save_score, block_rows, fuse_propagate, prepared, split_next)
         return out if fuse_propagate else out[0]
+
+    def _accepts_split_rows(self, plan: BatchPlan, template: torch.Tensor) -> bool:
+        """Would this layer's forward and backward take its input as pre-split rows (functional.ROWS_SPLIT)?  One
+        trainable bank per degree, the default kernels, and the library's own answer for these shapes."""
+        if not template.is_cuda or self.variant not in ("auto", "mfma") or self.backward_variant not in (None, "auto", "fast"):
+            return False
+        if not self._can_prepare():
+            return False
+        params, E = self._bank_params("train", template)
+        F = int(params[0].shape[1])
+        # (the answer depends on shapes only: remembered on the plan, which lives as long as its batch)
+        cache = plan.__dict__.setdefault("_rows_split_ok", {})
+        key = (F, E, tuple(int(p.shape[0]) for p in params[0::7]), Fn._PRODUCTS_EPOCH)
+        if key not in cache:
+            cache[key] = Fn.rows_split_supported(plan, params, F, E, plan.n_atoms)
+        return cache[key]
 
     def _run_block_rows(self, x, plan: BatchPlan, is_last_layer, prepared=None):
         """The block rows of this layer's output for a consumer that is not ``propagate_add`` (the block-row readout), or
@@ -224,7 +242,7 @@ class BaseKernelSetConv(Module):
         return Fn.kernelsetconv(x, plan, is_last_layer, params, E, self.variant, self.out_pad, block_rows=True,
                                 backward_variant=self.backward_variant, prepared=prepared)
 
-    def _run_impl(self, x, plan: BatchPlan, is_last_layer, save_score, block_rows, fuse_propagate, prepared=None):
+    def _run_impl(self, x, plan: BatchPlan, is_last_layer, save_score, block_rows, fuse_propagate, prepared=None, split_next=False):
         for d in range(1, 5):
             if plan.buckets[d - 1].count and self.fixed_kernelconv_set[d - 1] is None \
                     and self.trainable_kernelconv_set[d - 1] is None:
@@ -238,7 +256,8 @@ class BaseKernelSetConv(Module):
                           and plan.block_rows_ok(sum(int(p.shape[0]) for p in params[0::7])))
             if block_rows and fuse_propagate:
                 return Fn.kernelsetconv(x, plan, is_last_layer, params, E, self.variant, self.out_pad, block_rows=True,
-                                        backward_variant=self.backward_variant, propagate=True, prepared=prepared), True
+                                        backward_variant=self.backward_variant, propagate="split" if split_next else True,
+                                        prepared=prepared), True
             sc = Fn.kernelsetconv(x, plan, is_last_layer, params, E, self.variant, self.out_pad, block_rows=block_rows,
                                   backward_variant=self.backward_variant, prepared=prepared)
         else:

@@ -587,3 +587,113 @@ def bce_head_loss(emb: torch.Tensor, ffn: torch.nn.Linear, target: torch.Tensor,
     if not 0.0 <= dropout_p < 1.0:
         raise ValueError(f"dropout probability {dropout_p} outside [0, 1)")
     return _BceHeadFn.apply(emb, ffn.weight, ffn.bias, target, float(dropout_p), n_rows)
+
+
+# ------------------------------------------------------------------- the tail of a training step, fused --
+# MKGNN_FUSED_TAIL=0: readout_blocks + bce_head_loss as separate operators (nine launches; A/B, diagnostics)
+_FUSED_TAIL = os.environ.get("MKGNN_FUSED_TAIL", "1") != "0"
+_TAIL_WS: dict = {}
+
+
+def _tail_workspace(dev, nbytes: int) -> torch.Tensor:
+    """Per-device scratch of the fused tail (gradient slabs behind a status word that must be zero on entry and is left zero):
+    zero-filled once; never released (a captured graph has its address baked in)."""
+    held = _TAIL_WS.setdefault(str(dev), [])
+    if not held or held[-1].numel() < nbytes:
+        held.append(torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev))
+    return held[-1]
+
+
+def _tail_limits_ok(seg: "MoleculeSegments", plan) -> bool:
+    """No molecule beyond a chunk of the fused tail (``MKGNN_TAIL_MAX_ATOMS`` atoms, ``MKGNN_TAIL_MAX_EDGES`` edges each way).
+    Needs the molecule sizes on the host: one synchronisation the first time a batch is seen, remembered on its segments
+    (``max_atoms`` / ``max_edges`` may also be handed over by a loader that knows them).  Inside a capture an unknown
+    batch is answered with False: the separate operators take it."""
+    ma, me = getattr(seg, "max_atoms", None), getattr(seg, "max_edges", None)
+    if ma is None or me is None:
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        ptr = seg.mol_ptr.long()
+        sizes = ptr[1:] - ptr[:-1]
+        rin, rout = plan.csr_in[0].long(), plan.csr_out[0].long()
+        ein, eout = rin[ptr[1:]] - rin[ptr[:-1]], rout[ptr[1:]] - rout[ptr[:-1]]
+        ma, me = int(sizes.max().item()), int(torch.maximum(ein.max(), eout.max()).item())
+        seg.max_atoms, seg.max_edges = ma, me
+    return ma <= _lib.TAIL_MAX_ATOMS and me <= _lib.TAIL_MAX_EDGES
+
+
+def tail_supported(K: int, H: int, G: int, blocks) -> bool:
+    return bool(_lib.load().mkgnn_tail_supported(int(K), int(H), int(G), _lib.Int32x4(*[int(b) for b in blocks])))
+
+
+class _TailFn(torch.autograd.Function):
+    """``BCEWithLogitsLoss()(ffn(dropout(readout(propagate(sim)))), y)`` with every gradient for d loss = 1 in the same launch
+    (``mkgnn_tail_fused``); the backward hands them out (scaled, if the incoming gradient is not the registered unit seed)."""
+
+    @staticmethod
+    def forward(ctx, sim, w1, b1, w2, b2, wh, bh, target, seg, plan, blocks, p_drop, n_rows):
+        lib = _lib.load()
+        _lib.require_gpu_tensor(sim, "sim_sc")
+        n, K = sim.shape
+        dev = sim.device
+        w1c, w2c = w1.contiguous(), w2.contiguous()
+        H, G = w1c.shape[0], w2c.shape[0]
+        whc = wh.reshape(-1).contiguous()
+        y = target.reshape(-1).float().contiguous()
+        B = int(n_rows)
+        pred = torch.empty(B, dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        K4 = K + (-K) % 4
+        gsim = torch.empty((n, K4), dtype=torch.float32, device=dev)[:, :K]     # block rows: only every atom's own block is written
+        gw1, gw2, gwh = torch.empty_like(w1c), torch.empty_like(w2c), torch.empty_like(whc)
+        gb1 = torch.empty_like(b1) if b1 is not None else None
+        gb2 = torch.empty_like(b2) if b2 is not None else None
+        gbh = torch.empty(1, dtype=torch.float32, device=dev) if bh is not None else None
+        rng = head_rng_state(dev) if p_drop > 0.0 else None
+        used = torch.empty(2, dtype=torch.int64, device=dev) if p_drop > 0.0 else None
+        a = _lib.TailArgs()
+        a.sim, a.sim_stride, a.degree = sim.data_ptr(), _stride0(sim), plan.deg8.data_ptr()
+        for i, L in enumerate(blocks):
+            a.num_kernels[i] = int(L)
+        (rin, cin), (rout, cout) = plan.csr_in, plan.csr_out
+        a.in_rowptr, a.in_col, a.out_rowptr, a.out_col = rin.data_ptr(), cin.data_ptr(), rout.data_ptr(), cout.data_ptr()
+        a.mol_ptr, a.atom_mol = seg.mol_ptr.data_ptr(), seg.atom_mol.data_ptr()
+        a.n_atoms, a.n_mols, a.n_loss_mols = n, seg.size, B
+        a.readout = _params(w1c, b1, w2c, b2)
+        a.head_weight, a.head_bias, a.target = whc.data_ptr(), _lib.ptr(bh), y.data_ptr()
+        a.dropout_p, a.rng_state, a.rng_used = float(p_drop), _lib.ptr(rng), _lib.ptr(used)
+        a.emb, a.emb_stride = None, 0
+        a.pred, a.loss = pred.data_ptr(), loss.data_ptr()
+        a.grad_sim, a.grad_sim_stride = gsim.data_ptr(), K4
+        a.grad_lin1_weight, a.grad_lin1_bias = gw1.data_ptr(), _lib.ptr(gb1)
+        a.grad_lin2_weight, a.grad_lin2_bias = gw2.data_ptr(), _lib.ptr(gb2)
+        a.grad_head_weight, a.grad_head_bias = gwh.data_ptr(), _lib.ptr(gbh)
+        with torch.cuda.device(dev):
+            ws = _tail_workspace(dev, int(lib.mkgnn_tail_workspace_bytes(K, H, seg.size)))
+            _lib.check(lib.mkgnn_tail_fused(ctypes.byref(a), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "mkgnn_tail_fused")
+        ctx.unit = (gsim, gw1, gb1, gw2, gb2, gwh.reshape(wh.shape), gbh)
+        ctx.pred = pred
+        return loss
+
+    @staticmethod
+    def backward(ctx, grad_loss):
+        if ctx.unit is None:
+            raise RuntimeError("the fused tail keeps its gradients for ONE backward (retain_graph is not supported: "
+                               "MKGNN_FUSED_TAIL=0 runs the separate operators)")
+        grads, ctx.unit = ctx.unit, None
+        if not _is_unit_seed(grad_loss):                     # d loss is not the registered 1: scale
+            gl = grad_loss.reshape(()).float()
+            grads = tuple(None if g is None else g * gl for g in grads)
+        return (*grads, None, None, None, None, None, None)
+
+
+def tail_loss(sim: torch.Tensor, plan, blocks, lin1: torch.nn.Linear, lin2: torch.nn.Linear, ffn: torch.nn.Linear,
+              target: torch.Tensor, seg: "MoleculeSegments", dropout_p: float = 0.0, n_rows: Optional[int] = None) -> torch.Tensor:
+    """``bce_head_loss(readout_blocks(sim, ...), ffn, target, dropout_p, n_rows)`` as ONE operator whose forward also takes
+    every gradient (``_TailFn``).  The caller has checked ``tail_supported``, ``_tail_limits_ok`` and that the readout has
+    no dropout of its own."""
+    n_rows = seg.size if n_rows is None else int(n_rows)
+    if ffn.out_features != 1 or n_rows <= 0 or n_rows > seg.size or target.numel() != n_rows:
+        raise ValueError("tail_loss needs a one-output linear layer and one target per (leading) molecule")
+    return _TailFn.apply(sim, lin1.weight, lin1.bias, lin2.weight, lin2.bias, ffn.weight, ffn.bias, target, seg, plan,
+                         tuple(blocks), float(dropout_p), n_rows)

@@ -57,8 +57,13 @@ class GNNModel(torch.nn.Module):
                 fused = _mol.loss_forward(self, data, p)
                 if fused is not None:
                     return fused
-            graph_embedding = self.gnn_model(data)
             nreal = getattr(data, 'n_valid_molecules', None)
+            # large batches: everything behind the last convolution -- readout, head, loss and their gradients -- in one launch
+            # (readout.tail_loss) where the model and the batch qualify; the embedding otherwise
+            tail = None if (self.training and self.dropout.p >= 1.0) else (self.ffn, data.y, p, nreal)
+            graph_embedding = self.gnn_model(data, _tail=tail)
+            if isinstance(graph_embedding, tuple):
+                return graph_embedding[1]
             if self.training and self.dropout.p >= 1.0:
                 graph_embedding = self.dropout(graph_embedding)
             # (a padded batch: the padding molecules' rows take no part in the loss -- the head reads the first nreal rows)

@@ -1351,9 +1351,13 @@ def test_block_row_propagate_matches_dense_bitwise():
                            torch.where(inblock, g_blk, torch.zeros((), device=dev)))
 
 
-def test_molgcn_block_rows_equals_dense_path():
+def test_molgcn_block_rows_equals_dense_path(monkeypatch):
     """The 3-layer MolGCN with sim_sc kept as block rows between convolution and propagate (the default) against the
-    dense form (zero-filled rows, dense sums; MKGNN_DENSE_PROPAGATE): output and every gradient bit for bit."""
+    dense form (zero-filled rows, dense sums; MKGNN_DENSE_PROPAGATE): output and every gradient bit for bit.  (h between the
+    layers as fp32 rows in both: the pre-split rows of round 6 -- the block-row path's default, tests/test_rows_split.py --
+    change the row the backward gather un-normalises with by 2^-22.)"""
+    from molkgnn_amd import KernelLayer as _KL
+    monkeypatch.setattr(_KL, "_ROWS_SPLIT", False)
     import copy
     from molkgnn_amd import KernelLayer as KL
     from molkgnn_amd.synthetic import make_batch
