@@ -350,13 +350,16 @@ def small_batch_leg(args, model, opt, dev, log):
                 mwins = mfwd = meag = None
                 log(f"molecule-resident step unavailable ({type(exc).__name__}: {exc})")
             # the path a run takes by default at this batch size (molkgnn_amd.molecule: up to 32 molecules the one-launch step)
-            # (a captured step: up to 32 molecules; an eager step also takes it up to 512 -- eager_ms_per_step below)
+            # (a captured step: up to 32 molecules; an EAGER step above that takes it only for a batch marked data.resident = True
+            # -- round 6: the choice is a function of the batch, not of how often it has been seen; eager_ms_per_step below
+            # times both paths by forcing them)
             default_mol = mwins is not None and mode0 != "0" and B <= (Mol._MAX_MOLS_FORCED if mode0 == "1" else Mol._MAX_MOLS_AUTO)
             wins = mwins if default_mol else pwins
             mol = {"default_path": "molecule_resident" if default_mol else "per_operator",
                    "per_operator_ms_per_step": round(1e3 * pwins[2], 4),
                    "molecule_resident_ms_per_step": None if mwins is None else round(1e3 * mwins[2], 4),
-                   "eager_ms_per_step": {"what": "the same step launched eagerly, host overhead included (no hipGraph)",
+                   "eager_ms_per_step": {"what": "the same step launched eagerly, host overhead included (no hipGraph); the default eager "
+                                                 "path above 32 molecules is per_operator unless the batch carries resident = True",
                                          "per_operator": round(1e3 * peag, 4),
                                          "molecule_resident": None if meag is None else round(1e3 * meag, 4)},
                    "forward_only_ms": {"what": "MolKGNNNet.forward in eval mode, no gradient (scoring a batch), graph replay",

@@ -320,34 +320,34 @@ int mkgnn_readout_blocks_backward(const mkgnn_readout_params* params, const floa
                                   float* grad_lin1_weight, float* grad_lin1_bias, float* grad_lin2_weight,
                                   float* grad_lin2_bias, void* workspace, size_t workspace_bytes, void* stream);
 
-/* ---- the tail of a training step in one launch (ABI v6) ---------------------------------------------------------------
+/* ---- the tail of a training step, fused (ABI v6) ----------------------------------------------------------------------
  * Everything behind the last kernel convolution, forward AND backward:
  *     h = propagate(sim)                                  KernelLayer.py:119-123
  *     emb_g = pool_g( lin2( swish( lin1(h) ) ) )          MolKGNNNet.py:144-146   (no dropout inside the readout)
  *     loss = mean_g BCEWithLogits( ffn( dropout(emb_g) ), target_g )     model.py:147-150, 169, 190-198; data.py:37
  * and, for d loss = 1, d loss / d sim (block rows: only every atom's own column block is written -- what the last
- * convolution's backward reads) and the six parameter gradients.  The loss is a mean over molecules, so a molecule's whole
- * chain back is taken while it sits in LDS: one kernel over chunks of whole molecules + one fixed-order reduction of the
- * per-block gradient slabs, in place of mkgnn_readout_blocks_forward / mkgnn_bce_head_fused / mkgnn_readout_blocks_backward
- * (nine launches).  Same formulas, same re-associations (project before propagate, pool before lin2), the same dropout mask
- * as mkgnn_bce_head_fused for the same rng_state.
- *   sim         [n_atoms, K] block rows of the last mkgnn_kernelsetconv_forward (MKGNN_VARIANT_BLOCK_ROWS), K = readout.F
- *   degree      [n_atoms] int8, 0..4 (0: in no bucket -- no block, the atom still receives from its neighbours and is pooled)
+ * convolution's backward reads) and the six parameter gradients.  The loss is a mean over molecules, so a molecule's chain
+ * back to d loss / d z is taken while it sits in LDS: FOUR launches -- z = W1 sim on the matrix cores; one kernel over chunks
+ * of whole molecules for propagate, swish, pool, lin2, head, loss, their gradients and propagate^T; d sim = W1^T d z with the
+ * dW1 partials on the matrix cores; one fixed-order reduction of all partial slabs -- in place of the nine of
+ * mkgnn_readout_blocks_forward + mkgnn_bce_head_fused + mkgnn_readout_blocks_backward.  Same formulas, same re-associations
+ * (project before propagate, pool before lin2), the same dropout mask as mkgnn_bce_head_fused for the same rng_state.
+ *   sim         [n_atoms, K] block rows of the last mkgnn_kernelsetconv_forward (MKGNN_VARIANT_BLOCK_ROWS), K = readout.F,
+ *               16-byte aligned rows; buckets [MKGNN_MAX_DEGREE]: count and selected_index are read (as the block-row readout)
  *   in_* / out_*  the edges grouped by target (columns = sources) / by source (columns = targets), int32, as for
  *               mkgnn_segment_sum_rows; mol_ptr [n_mols + 1], atom_mol [n_atoms]: atoms of a molecule contiguous, edges inside
  *   n_loss_mols the leading molecules that enter the loss (the rest -- padding molecules -- get zero gradients)
  *   rng_state   {seed, offset} int64, read and advanced by one when dropout_p > 0; rng_used receives what was read
  *   emb         [n_mols, G] or NULL;  pred [n_loss_mols];  loss [1];  grad_sim [n_atoms, K] block rows; grad_* may be NULL
- * Limits: mkgnn_tail_supported (K <= 112, every block <= 52, H <= 32, G <= 32); and NO MOLECULE with more than
+ * Limits: mkgnn_tail_supported (the block-row readout's shapes with H <= 32 and G <= 32); and NO MOLECULE with more than
  * MKGNN_TAIL_MAX_ATOMS atoms or MKGNN_TAIL_MAX_EDGES edges (each way) -- the caller, who knows the molecule sizes, checks;
- * a molecule that breaks the promise is skipped and the loss comes back NaN.
- * workspace: mkgnn_tail_workspace_bytes; its first 16 bytes must be ZERO on entry (a status word; the call leaves them zero). */
+ * a molecule that breaks the promise is skipped and the loss comes back NaN.  workspace: mkgnn_tail_workspace_bytes. */
 #define MKGNN_TAIL_MAX_ATOMS 128
 #define MKGNN_TAIL_MAX_EDGES 512
 typedef struct mkgnn_tail_args {
     const float* sim; int64_t sim_stride;
-    const int8_t* degree;
     int32_t num_kernels[MKGNN_MAX_DEGREE];
+    const mkgnn_degree_bucket* buckets;      /* [MKGNN_MAX_DEGREE] */
     const int32_t* in_rowptr; const int32_t* in_col;
     const int32_t* out_rowptr; const int32_t* out_col;
     const int32_t* mol_ptr; const int32_t* atom_mol;
@@ -364,7 +364,7 @@ typedef struct mkgnn_tail_args {
     float *grad_lin1_weight, *grad_lin1_bias, *grad_lin2_weight, *grad_lin2_bias, *grad_head_weight, *grad_head_bias;
 } mkgnn_tail_args;
 int mkgnn_tail_supported(int32_t K, int32_t H, int32_t G, const int32_t num_kernels[MKGNN_MAX_DEGREE]);
-size_t mkgnn_tail_workspace_bytes(int32_t K, int32_t H, int64_t n_mols);
+size_t mkgnn_tail_workspace_bytes(int32_t K, int32_t H, int32_t G, int64_t n_atoms, int64_t n_mols);
 int mkgnn_tail_fused(const mkgnn_tail_args* args, void* workspace, size_t workspace_bytes, void* stream);
 
 /* BatchNorm1d over atom rows, reference MolKGNNNet.py:115 (torch.nn.BatchNorm1d semantics: biased

@@ -19,6 +19,9 @@ from .receptive_field import GraphBatch
 
 # diagnostics: MKGNN_DENSE_PROPAGATE=1 keeps sim_sc dense (zero-filled rows, dense sums) between convolution and propagate
 _BLOCK_ROWS = os.environ.get("MKGNN_DENSE_PROPAGATE") is None
+# (measured, round 6: the fork / join around the side stream costs the captured step what the overlap buys -- bank_prepare 5 us
+# beside the batch norm, 10 us of gap in front of the first convolution: 0.7307 against 0.7295 ms.  Kept as an opt-in.)
+_PREPARE_EARLY = os.environ.get("MKGNN_PREPARE_EARLY", "0") == "1"
 _FUSE_PROPAGATE = _BLOCK_ROWS and os.environ.get("MKGNN_SPLIT_PROPAGATE") is None
 # h between two layers written as the pre-split rows the next layer's matrix instructions take (functional.ROWS_SPLIT, round 6);
 # MKGNN_ROWS_SPLIT=0: ordinary fp32 rows (A/B, diagnostics)
@@ -78,6 +81,24 @@ class MolGCN(MessagePassing):
     def num_kernels(self, layer):
         return self.num_kernels_list[layer]
 
+    def prepare_banks_early(self, x, n_slots: int) -> None:
+        """Round 6: normalise the kernel banks of all layers NOW, on the device's side stream (``plan.index_stream``), for the
+        ``forward`` that follows on rows shaped like ``x`` -- a caller that has something else to run first (MolKGNNNet: the
+        batch norm) overlaps the two; ``forward`` joins the stream in front of the first convolution.  A no-op where the
+        one-launch preparation does not apply.  Opt-in, ``MKGNN_PREPARE_EARLY=1`` (in a captured step the fork / join costs what
+        the overlap buys: see ``_PREPARE_EARLY``)."""
+        self._early = None
+        if not (x.is_cuda and _PREPARE_ONCE and _PREPARE_EARLY and all(layer._can_prepare() for layer in self.layers)):
+            return
+        from .plan import index_stream
+        side = index_stream(x.device)
+        if side is None:
+            return
+        pl = [layer._bank_params("train", x) for layer in self.layers]
+        prepared = Fn.prepare_banks([p for p, _ in pl], [x.shape[1]] + [self.num_kernels(i) for i in range(self.num_layers - 1)],
+                                    pl[0][1], x.shape[0], n_slots, side=side)
+        self._early = ((x.shape[0], x.shape[1], x.device), prepared, side)
+
     def set_variant(self, variant: str, backward_variant=None):
         for layer in self.layers:
             layer.variant = variant
@@ -113,7 +134,12 @@ class MolGCN(MessagePassing):
         # the kernel banks of ALL layers are normalised by one launch (they depend on the parameters only; layer i reads rows
         # of width F_i = K_{i-1}): MKGNN_PREPARE_PER_LAYER=1 keeps one launch per layer (diagnostics)
         prepared = [None] * self.num_layers
-        if x.is_cuda and _PREPARE_ONCE and all(layer._can_prepare() for layer in self.layers):
+        early, self._early = getattr(self, "_early", None), None
+        if early is not None and early[0] == (x.shape[0], x.shape[1], x.device):
+            # prepared beside the batch norm (prepare_banks_early): join the side stream here, in front of the first convolution
+            prepared, side = early[1], early[2]
+            torch.cuda.current_stream(x.device).wait_stream(side)
+        elif x.is_cuda and _PREPARE_ONCE and all(layer._can_prepare() for layer in self.layers):
             n_slots = sum(int(fields[f'nei_index_deg{d}'].numel()) for d in range(1, 5))
             pl = [layer._bank_params("train", x) for layer in self.layers]
             prepared = Fn.prepare_banks([p for p, _ in pl], [x.shape[1]] + [self.num_kernels(i) for i in range(self.num_layers - 1)],

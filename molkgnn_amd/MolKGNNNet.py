@@ -94,6 +94,9 @@ class MolKGNNNet(torch.nn.Module):
         # edge_batch_norm(data.edge_attr) (reference MolKGNNNet.py:116): its output never reaches the kernel convolution
         # (SURVEY 8 a-1), but in training mode the call moves the module's running statistics and num_batches_tracked, which
         # are state-dict contents -- that side effect rides along in the node batch norm's launches (readout.batch_norm)
+        if data.x.is_cuda and not save_score:
+            # (the banks depend on the parameters only: their one launch runs beside the batch norm, on the side stream)
+            self.gnn.prepare_banks_early(data.x, sum(int(getattr(data, f'nei_index_deg{d}').numel()) for d in range(1, 5)))
         x = R.batch_norm(data.x, self.node_batch_norm, getattr(data, 'n_valid_atoms', None), companion=self._edge_stats(data))
         if getattr(data, '_rf_ready', None) is not None:     # degree buckets still being built on the index stream
             from .receptive_field import await_receptive_fields
@@ -116,8 +119,12 @@ class MolKGNNNet(torch.nn.Module):
         dims = (sum(Ls), lin1.weight.shape[0], lin2.weight.shape[0])
         # (from _PROJECT_FIRST_ATOMS atoms on -- or at any size where the dense readout kernels do not take the shape, e.g. 160
         # kernels per layer: the block-row form takes up to 255 columns and keeps such a model off the PyTorch-operator path)
+        # (... or at any size when the caller wants the loss itself: the fused tail -- readout.tail_loss -- starts from block rows)
+        no_drop = self.dropout is None or not self.dropout.training or self.dropout.p == 0.0
+        want_tail = (_tail is not None and R._FUSED_TAIL and torch.is_grad_enabled() and no_drop and x.is_cuda
+                     and R.tail_supported(*dims, Ls))
         want = x.is_cuda and not save_score and (_PROJECT_FIRST == '1' or (_PROJECT_FIRST != '0' and (
-            x.shape[0] >= _PROJECT_FIRST_ATOMS or not R.readout_supported(*dims))))
+            x.shape[0] >= _PROJECT_FIRST_ATOMS or not R.readout_supported(*dims) or want_tail)))
         if want:
             want = R.readout_blocks_supported(*dims, Ls)
         if want and seg is None:
@@ -129,11 +136,9 @@ class MolKGNNNet(torch.nn.Module):
             sim_sc, plan, Ls = blocks_out[0]
             # (private: train.GNNModel.loss asks for the loss itself -- readout, head, loss and all their gradients in one
             # launch, readout.tail_loss -- where that applies; it gets ("loss", value) back, or the embedding as usual)
-            if _tail is not None and R._FUSED_TAIL and torch.is_grad_enabled() and sim_sc.requires_grad:
+            if want_tail and sim_sc.requires_grad and R._tail_limits_ok(seg, plan):
                 ffn, target, p_head, n_rows = _tail
-                no_drop = self.dropout is None or not self.dropout.training or self.dropout.p == 0.0
-                if no_drop and R.tail_supported(*dims, Ls) and R._tail_limits_ok(seg, plan):
-                    return ("loss", R.tail_loss(sim_sc, plan, Ls, lin1, lin2, ffn, target, seg, p_head, n_rows))
+                return ("loss", R.tail_loss(sim_sc, plan, Ls, lin1, lin2, ffn, target, seg, p_head, n_rows))
             return R.readout_blocks(sim_sc, plan, Ls, lin1, lin2, self.dropout, seg)
         # pool(lin2(dropout(act(lin1(h)))), batch) -- MolKGNNNet.py:144-146 -- as one operator
         return R.readout(node_representation, lin1, lin2, self.dropout, data.batch, getattr(data, 'num_graphs', None), segments=seg)

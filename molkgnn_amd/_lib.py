@@ -49,7 +49,7 @@ class ReadoutParams(C.Structure):
 
 class TailArgs(C.Structure):
     """``mkgnn_tail_args`` (include/molkgnn_hip.h): the fused tail of a training step."""
-    _fields_ = [("sim", C.c_void_p), ("sim_stride", C.c_int64), ("degree", C.c_void_p), ("num_kernels", C.c_int32 * 4),
+    _fields_ = [("sim", C.c_void_p), ("sim_stride", C.c_int64), ("num_kernels", C.c_int32 * 4), ("buckets", C.c_void_p),
                 ("in_rowptr", C.c_void_p), ("in_col", C.c_void_p), ("out_rowptr", C.c_void_p), ("out_col", C.c_void_p),
                 ("mol_ptr", C.c_void_p), ("atom_mol", C.c_void_p), ("n_atoms", C.c_int64), ("n_mols", C.c_int64),
                 ("n_loss_mols", C.c_int64), ("readout", ReadoutParams), ("head_weight", C.c_void_p), ("head_bias", C.c_void_p),
@@ -198,7 +198,7 @@ def load() -> C.CDLL:
     lib.mkgnn_tail_supported.restype = C.c_int
     lib.mkgnn_tail_supported.argtypes = [C.c_int32, C.c_int32, C.c_int32, Int32x4]
     lib.mkgnn_tail_workspace_bytes.restype = C.c_size_t
-    lib.mkgnn_tail_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int64]
+    lib.mkgnn_tail_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64]
     lib.mkgnn_tail_fused.restype = C.c_int
     lib.mkgnn_tail_fused.argtypes = [C.POINTER(TailArgs), C.c_void_p, C.c_size_t, C.c_void_p]
     lib.mkgnn_rows_split_supported.restype = C.c_int

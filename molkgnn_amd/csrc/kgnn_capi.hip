@@ -8,6 +8,7 @@
 #include <mutex>
 
 #include "kgnn_launch.h"
+#include "kgnn_split.h"
 
 using namespace mkgnn;
 
@@ -270,6 +271,22 @@ int mkgnn_debug_last_plans(int32_t out[12]) {
         out[3 * k] = g_last_plan[k].blocks.load(); out[3 * k + 1] = g_last_plan[k].min_iters.load(); out[3 * k + 2] = g_last_plan[k].max_iters.load();
         out[9 + k] = g_last_plan[k].launches.load();        // launches of the streamed kernel since the library was loaded
     }
+    return 0;
+}
+
+// The power-of-two scales of the split-fp16 products (kgnn_split.h), evaluated on the HOST -- the same inline functions the kernels
+// compile, plain exponent-field arithmetic -- for the exhaustive property test of tests/test_host_cpu.py (no GPU needed):
+// out = bits of { split_scale_for<10>(amax), split_unscale_of<12>(that)   [the rows kernel's pair],
+//                 split_scale_for_exponent<18>(exponent of amax), split_unscale_of<0>(that)   [the bank kernel's],
+//                 split_row_scale_of(amax), split_row_inv(amax)   [pre-split rows / the forward's row scale, amax read as 1 / |x|] }
+int mkgnn_debug_split_scales(uint32_t amax_bits, uint32_t out[6]) {
+    if (!out) return fail("mkgnn_debug_split_scales: null pointer");
+    const float amax = split_bits_to_float(amax_bits);
+    const float s_rows = split_scale_for<10>(amax), u_rows = split_unscale_of<12>(s_rows);
+    const float s_bank = split_scale_for_exponent<18>((int)((amax_bits >> 23) & 0xffu)), u_bank = split_unscale_of<0>(s_bank);
+    out[0] = split_float_to_bits(s_rows); out[1] = split_float_to_bits(u_rows);
+    out[2] = split_float_to_bits(s_bank); out[3] = split_float_to_bits(u_bank);
+    out[4] = split_float_to_bits(split_row_scale_of(amax)); out[5] = split_float_to_bits(split_row_inv(amax));
     return 0;
 }
 

@@ -150,6 +150,25 @@ struct BankStreamArgs {
     uint16_t blk_rank[FUSED_MAX_BLOCKS];
 };
 
+// kgnn_tail.hip: the middle of the fused tail (mkgnn_tail_fused, kgnn_readout.hip) -- per chunk of whole molecules, on H-wide rows
+struct TailMidArgs {
+    const float* z; float* dz;              // [n_atoms, 32]: W1 sim (in), d loss / d z (out)
+    const int32_t *rin, *cin, *rout, *cout;
+    const int32_t *mol_ptr, *atom_mol;
+    int64_t n_atoms, n_mols, n_loss;
+    const float *b1, *w2, *b2, *wh, *bh, *y;
+    int H, G;
+    float drop_p; const int64_t* rng;
+    float* emb; int64_t es;                 // [n_mols, G] or null
+    float* pred;
+    float* slab; int slab_stride;           // [blocks][slab_stride]: TAIL_* below
+};
+// a workgroup's slab (floats): b1 [32] | W2 [32][32] | b2 [32] | wh [32] | bh | loss
+constexpr int TAIL_B1 = 0, TAIL_W2 = 32, TAIL_B2 = 32 + 1024, TAIL_WH = TAIL_B2 + 32, TAIL_BH = TAIL_WH + 32, TAIL_LOSS = TAIL_BH + 1,
+              TAIL_SLAB = (TAIL_LOSS + 1 + 3) / 4 * 4;
+int tail_middle_blocks(int64_t n_mols);
+hipError_t launch_tail_middle(const TailMidArgs& a, int nb, hipStream_t st);
+
 struct BankStreamLaunch { BankStreamArgs a; int nb, prep_blocks, KC; size_t lds_bytes; int x_split; };
 // block split and arguments once; then the pre-pass (coefficient records in tile order, score-weight partials) and the
 // bank kernel, each on the stream the caller chooses

@@ -416,7 +416,10 @@ struct SlabSeg {
     int blk_start;
     int dst_stride;                             // row stride of dst (0: dst_cols -- contiguous)
 };
-struct SlabReduceArgs { SlabSeg seg[8]; int nseg; };
+struct SlabReduceArgs {
+    SlabSeg seg[12]; int nseg;
+    float drop_p; int64_t* rng; int64_t* rng_used;      // the fused tail: the head's dropout generator advances here, once per step
+};
 
 __global__ void __launch_bounds__(256) slab_reduce_kernel(SlabReduceArgs a) {
     __shared__ float part[8][32];
@@ -445,6 +448,11 @@ __global__ void __launch_bounds__(256) slab_reduce_kernel(SlabReduceArgs a) {
 #pragma unroll
         for (int k = 1; k < 8; ++k) t += part[k][threadIdx.x];
         g.dst[g.dst_stride ? (size_t)row * g.dst_stride + col : (size_t)e] = t;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.drop_p > 0.f && a.rng) {      // (as behind mkgnn_bce_head_fused)
+        const int64_t seed = a.rng[0], offset = a.rng[1];
+        a.rng_used[0] = seed; a.rng_used[1] = offset;
+        a.rng[1] = offset + 1;
     }
 }
 
@@ -2009,6 +2017,137 @@ int mkgnn_readout_blocks_backward(const mkgnn_readout_params* p, const float* si
     add(a.slab_mol + p->G * p->H + p->G, a.slab_mol_stride, a.nblk_mol, d.HP, 1, p->H, grad_lin1_bias, 0);
     add(a.slab_mol, a.slab_mol_stride, a.nblk_mol, p->H, p->G, p->H, grad_lin2_weight, 0);
     add(a.slab_mol + p->G * p->H, a.slab_mol_stride, a.nblk_mol, p->G, 1, p->G, grad_lin2_bias, 0);
+    if (blk > 0) slab_reduce_kernel<<<blk, 256, 0, st>>>(r);
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : api_hip_fail(who, e);
+}
+
+// ---- the fused tail (ABI v6; kgnn_tail.hip): project | per-molecule middle | project^T + dW1 | one reduction ----
+struct TailWs { size_t z, dz, slab_atoms, slab_tail, total; int slab_atoms_stride; };
+static TailWs tail_ws(const ReadoutDims& d, int64_t n_atoms, int64_t n_mols) {
+    TailWs w;
+    auto up = [](size_t v) { return (v + 255) / 256 * 256; };
+    w.slab_atoms_stride = d.HP * d.FP + d.HP;
+    w.z = 0;
+    w.dz = up(w.z + (size_t)n_atoms * 32 * 4);
+    w.slab_atoms = up(w.dz + (size_t)n_atoms * 32 * 4);
+    w.slab_tail = up(w.slab_atoms + (size_t)2 * RO_ATOM_BLOCKS * w.slab_atoms_stride * 4);
+    w.total = up(w.slab_tail + (size_t)tail_middle_blocks(n_mols) * TAIL_SLAB * 4);
+    return w;
+}
+
+int mkgnn_tail_supported(int32_t K, int32_t H, int32_t G, const int32_t num_kernels[MKGNN_MAX_DEGREE]) {
+    ReadoutDims d;
+    if (!num_kernels || !blocks_dims(K, H, G, d) || H > 32 || G > 32) return 0;
+    return mkgnn_readout_blocks_supported(K, H, G, num_kernels);
+}
+
+size_t mkgnn_tail_workspace_bytes(int32_t K, int32_t H, int32_t G, int64_t n_atoms, int64_t n_mols) {
+    ReadoutDims d;
+    if (!blocks_dims(K, H, G, d) || n_atoms < 1 || n_mols < 1) return 0;
+    return tail_ws(d, n_atoms, n_mols).total;
+}
+
+int mkgnn_tail_fused(const mkgnn_tail_args* p, void* ws, size_t ws_bytes, void* stream) {
+    const char* who = "mkgnn_tail_fused";
+    if (!p) return api_fail("%s: null argument", who);
+    const mkgnn_readout_params* ro = &p->readout;
+    ReadoutDims d;
+    if (!mkgnn_tail_supported(ro->F, ro->H, ro->G, p->num_kernels) || !blocks_dims(ro->F, ro->H, ro->G, d))
+        return api_fail("%s: K=%d H=%d G=%d outside the fused tail (the block-row readout's shapes with H, G <= 32)", who, ro->F, ro->H, ro->G);
+    if (p->n_atoms < 1 || p->n_mols < 1 || p->n_loss_mols < 1 || p->n_loss_mols > p->n_mols || p->n_atoms >= (int64_t)1 << 31)
+        return api_fail("%s: bad sizes", who);
+    if (!p->in_rowptr || !p->in_col || !p->out_rowptr || !p->out_col || !p->mol_ptr || !p->atom_mol || !ro->lin1_weight ||
+        !ro->lin2_weight || !p->head_weight || !p->target || !p->pred || !p->loss || !p->grad_sim)
+        return api_fail("%s: null pointer", who);
+    if (p->dropout_p < 0.f || p->dropout_p >= 1.f) return api_fail("%s: dropout probability %g outside [0, 1)", who, (double)p->dropout_p);
+    if (p->dropout_p > 0.f && (!p->rng_state || !p->rng_used)) return api_fail("%s: dropout needs rng_state and rng_used", who);
+    if (p->emb && p->emb_stride < ro->G) return api_fail("%s: bad emb stride", who);
+    BlockProjArgs b{};
+    int64_t n_focal = 0;
+    if (int rc = check_blocks(who, ro, p->num_kernels, p->buckets, p->n_atoms, p->sim_stride, p->sim, b, d, &n_focal)) return rc;
+    if (p->grad_sim_stride < b.K) return api_fail("%s: bad grad_sim stride", who);
+    const TailWs w = tail_ws(d, p->n_atoms, p->n_mols);
+    if (!ws || ws_bytes < w.total) return api_fail("%s: workspace too small (%zu < %zu)", who, ws_bytes, w.total);
+    hipStream_t st = (hipStream_t)stream;
+    float* const z = (float*)((char*)ws + w.z);
+    float* const dz = (float*)((char*)ws + w.dz);
+    hipError_t e = hipSuccess;
+    // (1) z = W1[:, block] sim[block]   (d.HP = 32: H <= 32)
+    b.sim = p->sim; b.ss = p->sim_stride; b.n = p->n_atoms; b.z = z;
+    if (n_focal < p->n_atoms) {                          // atoms in no bucket: their sim row is zero, and so is their z row
+        e = hipMemsetAsync(z, 0, (size_t)p->n_atoms * d.HP * 4, st);
+        if (e != hipSuccess) return api_hip_fail(who, e);
+    }
+    int64_t grid = 0;
+    for (int i = 0; i < MKGNN_MAX_DEGREE; ++i) if (b.L[i] > 0) grid += ((b.cnt[i] + 15) / 16 + 3) / 4;
+    if (grid > 0) {
+        const size_t lds = ((size_t)d.HP * 68 + 4 * 16 * (d.HP + 4)) * 4;
+        block_project_mfma_kernel<2><<<(unsigned)grid, 256, lds, st>>>(b);
+    }
+    // (2) the middle: propagate, swish, pool, lin2, head, loss and the way back to d z, per chunk of whole molecules
+    TailMidArgs m{};
+    m.z = z; m.dz = dz; m.rin = p->in_rowptr; m.cin = p->in_col; m.rout = p->out_rowptr; m.cout = p->out_col;
+    m.mol_ptr = p->mol_ptr; m.atom_mol = p->atom_mol; m.n_atoms = p->n_atoms; m.n_mols = p->n_mols; m.n_loss = p->n_loss_mols;
+    m.b1 = ro->lin1_bias; m.w2 = ro->lin2_weight; m.b2 = ro->lin2_bias; m.wh = p->head_weight; m.bh = p->head_bias; m.y = p->target;
+    m.H = ro->H; m.G = ro->G; m.drop_p = p->dropout_p; m.rng = p->rng_state;
+    m.emb = p->emb; m.es = p->emb_stride; m.pred = p->pred;
+    m.slab = (float*)((char*)ws + w.slab_tail); m.slab_stride = TAIL_SLAB;
+    const int nbm = tail_middle_blocks(p->n_mols);
+    e = launch_tail_middle(m, nbm, st);
+    if (e != hipSuccess) return api_hip_fail(who, e);
+    // (3) d sim[block] = W1[:, block]^T d z,  dW1 partials   (as mkgnn_readout_blocks_backward)
+    b.dz = dz; b.dsim = p->grad_sim; b.dss = p->grad_sim_stride;
+    int64_t tiles_all = 0;
+    for (int i = 0; i < MKGNN_MAX_DEGREE; ++i) if (b.L[i] > 0) tiles_all += (b.cnt[i] + 15) / 16;
+    int tpw = (int)((tiles_all + 4 * (2 * RO_ATOM_BLOCKS - 4) - 1) / (4 * (2 * RO_ATOM_BLOCKS - 4)));
+    if (tpw < 1) tpw = 1;
+    int64_t nb_of[MKGNN_MAX_DEGREE], nb = 0;
+    for (int i = 0; i < MKGNN_MAX_DEGREE; ++i) {
+        const int64_t tiles = (b.cnt[i] + 15) / 16, per = 4 * (int64_t)tpw;
+        nb_of[i] = b.L[i] > 0 ? (tiles + per - 1) / per : 0;
+        nb += nb_of[i];
+    }
+    if (nb > 2 * RO_ATOM_BLOCKS) return api_fail("%s: internal: %lld blocks for %d slabs", who, (long long)nb, 2 * RO_ATOM_BLOCKS);
+    float* const slab_atoms = (float*)((char*)ws + w.slab_atoms);
+    b.slab = slab_atoms; b.slab_stride = w.slab_atoms_stride;
+    if (nb > 0) {
+        const size_t img = (size_t)4 * (16 * (d.HP + 4) + 16 * 68);
+        const size_t lds = ((size_t)d.HP * 68 + (img > 4096 ? img : 4096)) * 4;
+        block_project_bwd_mfma_kernel<2><<<(unsigned)nb, 256, lds, st>>>(b, tpw);
+    }
+    // (4) every partial slab -> its gradient, the loss; the dropout generator advances
+    SlabReduceArgs r{};
+    int blk = 0;
+    auto add = [&](const float* src, int stride, int count, int src_cols, int rows, int cols, float* dst, int dst_stride) {
+        if (!dst || count < 1 || rows * cols < 1) return;
+        SlabSeg& sg = r.seg[r.nseg++];
+        sg.src = src; sg.stride = stride; sg.count = count; sg.src_cols = src_cols; sg.dst_rows = rows; sg.dst_cols = cols;
+        sg.dst = dst; sg.blk_start = blk; sg.dst_stride = dst_stride;
+        blk += (rows * cols + 31) / 32;
+    };
+    bool absent = false;
+    {
+        int64_t b0 = 0;
+        for (int i = 0; i < MKGNN_MAX_DEGREE; ++i) {
+            if (b.L[i] > 0 && nb_of[i] == 0) absent = true;
+            if (nb_of[i] > 0)
+                add(slab_atoms + (size_t)b0 * w.slab_atoms_stride + b.off[i], w.slab_atoms_stride, (int)nb_of[i], d.FP, ro->H, b.L[i],
+                    p->grad_lin1_weight ? p->grad_lin1_weight + b.off[i] : nullptr, b.K);
+            b0 += nb_of[i];
+        }
+    }
+    if (absent && p->grad_lin1_weight) {                 // a degree without atoms: its columns of the gradient are zero
+        e = hipMemsetAsync(p->grad_lin1_weight, 0, (size_t)ro->H * b.K * 4, st);
+        if (e != hipSuccess) return api_hip_fail(who, e);
+    }
+    add(m.slab + TAIL_B1, TAIL_SLAB, nbm, 32, 1, ro->H, p->grad_lin1_bias, 0);
+    add(m.slab + TAIL_W2, TAIL_SLAB, nbm, 32, ro->G, ro->H, p->grad_lin2_weight, 0);
+    add(m.slab + TAIL_B2, TAIL_SLAB, nbm, 32, 1, ro->G, p->grad_lin2_bias, 0);
+    add(m.slab + TAIL_WH, TAIL_SLAB, nbm, 32, 1, ro->G, p->grad_head_weight, 0);
+    add(m.slab + TAIL_BH, TAIL_SLAB, nbm, 1, 1, 1, p->grad_head_bias, 0);
+    add(m.slab + TAIL_LOSS, TAIL_SLAB, nbm, 1, 1, 1, p->loss, 0);
+    r.drop_p = p->dropout_p; r.rng = p->rng_state; r.rng_used = p->rng_used;
     if (blk > 0) slab_reduce_kernel<<<blk, 256, 0, st>>>(r);
     e = hipGetLastError();
     return e == hipSuccess ? 0 : api_hip_fail(who, e);

@@ -7,6 +7,10 @@
 namespace mkgnn {
 
 typedef float split_f32x4 __attribute__((ext_vector_type(4)));
+// (bit casts that exist on the host too: the power-of-two scale functions below are plain integer arithmetic on exponent fields,
+// and tests/test_host_cpu.py checks them exhaustively through mkgnn_debug_split_scales without a GPU)
+__host__ __device__ __forceinline__ float split_bits_to_float(uint32_t u) { return __builtin_bit_cast(float, u); }
+__host__ __device__ __forceinline__ uint32_t split_float_to_bits(float f) { return __builtin_bit_cast(uint32_t, f); }
 
 // fp32 products out of fp16 matrix instructions (round 5).  A float is split into hi = fp16(x), lo = fp16(x - hi): two roundings
 // to nearest with unit roundoff 2^-11 (fp16 keeps 11 significant bits).  x - hi is exact in fp32 and at most 2^-11 |x|; it has up
@@ -74,12 +78,12 @@ __device__ __forceinline__ SplitReg split_scaled(split_f32x4 v, split_f32x4 s) {
 // value back takes (hi + lo) / s: exact in fp32 (hi holds the top 11 bits, lo the next 11 of the 13 that remain), i.e. x to
 // 2^-22 |x| -- the gather that undoes the row normalisation and the raw-row equality test of the chirality branch.
 constexpr int SPLIT_ROW_EXP_BITS = 8;
-__device__ __forceinline__ float split_row_scale_of(float inv) {           // 2^(exponent(inv) + 8)   (inv <= 1e8: no overflow)
-    return __uint_as_float((__float_as_uint(inv) & 0x7f800000u) + ((uint32_t)SPLIT_ROW_EXP_BITS << 23));
+__host__ __device__ __forceinline__ float split_row_scale_of(float inv) {  // 2^(exponent(inv) + 8)   (inv <= 1e8: no overflow)
+    return split_bits_to_float((split_float_to_bits(inv) & 0x7f800000u) + ((uint32_t)SPLIT_ROW_EXP_BITS << 23));
 }
 // inv / scale: inv's mantissa with the exponent -8
-__device__ __forceinline__ float split_row_inv(float inv) {
-    return __uint_as_float((__float_as_uint(inv) & 0x007fffffu) | ((uint32_t)(127 - SPLIT_ROW_EXP_BITS) << 23));
+__host__ __device__ __forceinline__ float split_row_inv(float inv) {
+    return split_bits_to_float((split_float_to_bits(inv) & 0x007fffffu) | ((uint32_t)(127 - SPLIT_ROW_EXP_BITS) << 23));
 }
 // four floats of a row -> their sixteen bytes in the pre-split form (returned as the four dwords to store)
 __device__ __forceinline__ split_f32x4 split_row_store(split_f32x4 v, float inv) {
@@ -103,21 +107,21 @@ __device__ __forceinline__ split_f32x4 split_mfma(const SplitReg& a, const Split
 
 // Power-of-two scale that brings a magnitude `amax` to [2^TARGET, 2^(TARGET+1)) and its reciprocal times 2^-EXTRA, both exact
 // (exponent-field arithmetic; amax = 0 or tiny: the scale saturates at 2^103, still a power of two, still undone exactly)
-template <int TARGET> __device__ __forceinline__ float split_scale_for(float amax) {
-    const int eb = (int)((__float_as_uint(amax) >> 23) & 0xffu);          // biased exponent of amax
+template <int TARGET> __host__ __device__ __forceinline__ float split_scale_for(float amax) {
+    const int eb = (int)((split_float_to_bits(amax) >> 23) & 0xffu);      // biased exponent of amax
     int f = 254 + TARGET - eb;                                             // biased exponent of 2^(TARGET - e)
     f = f > 230 ? 230 : (f < 24 ? 24 : f);
-    return __uint_as_float((uint32_t)f << 23);
+    return split_bits_to_float((uint32_t)f << 23);
 }
 // ... from an upper bound of the magnitude's biased exponent
-template <int TARGET> __device__ __forceinline__ float split_scale_for_exponent(int eb) {
+template <int TARGET> __host__ __device__ __forceinline__ float split_scale_for_exponent(int eb) {
     int f = 254 + TARGET - eb;
     f = f > 230 ? 230 : (f < 24 ? 24 : f);
-    return __uint_as_float((uint32_t)f << 23);
+    return split_bits_to_float((uint32_t)f << 23);
 }
-template <int EXTRA> __device__ __forceinline__ float split_unscale_of(float scale) {      // 2^-EXTRA / scale
-    const int f = (int)(__float_as_uint(scale) >> 23);
-    return __uint_as_float((uint32_t)(254 - EXTRA - f) << 23);
+template <int EXTRA> __host__ __device__ __forceinline__ float split_unscale_of(float scale) {      // 2^-EXTRA / scale
+    const int f = (int)(split_float_to_bits(scale) >> 23);
+    return split_bits_to_float((uint32_t)(254 - EXTRA - f) << 23);
 }
 
 }  // namespace mkgnn

@@ -1,33 +1,32 @@
-// The tail of a training step in ONE launch (round 6): everything behind the last kernel convolution --
+// The tail of a training step (round 6): everything behind the last kernel convolution --
 //
 //   h = propagate(sim_sc)                                   reference KernelLayer.py:119-123
 //   emb_g = pool_g( lin2( swish( lin1(h) ) ) )              reference MolKGNNNet.py:144-146
 //   loss = BCEWithLogits( ffn( dropout(emb) ), y )          reference model.py:147-150, 169, 190-198; data.py:37
 //
-// -- forward AND backward: the loss is a mean over molecules, so d loss / d logit_g = (sigmoid(logit_g) - y_g) / B needs nothing
-// but the molecule's own logit, and the whole chain back to d loss / d sim_sc (block rows, what the last convolution's backward
-// reads) and the six parameter gradients can be taken while the molecule is still in LDS.  Rounds 3-5 ran this as NINE launches
-// (project, propagate, pool, head, head reduce | molecule gradients, propagate^T, project^T + dW1, slab reduce: 102 us of a 725 us
-// step at batch 4096, about half of it launch latency -- a dependent kernel costs ~5 us in a captured graph on this chip whatever
-// it does); the same arithmetic here is one launch plus the fixed-order reduction of the per-block gradient slabs.
+// -- forward AND backward in FOUR launches instead of nine (mkgnn_tail_fused, kgnn_readout.hip).  The loss is a mean over
+// molecules, so d loss / d logit_g = (sigmoid(logit_g) - y_g) / B needs nothing but the molecule's own logit, and the chain back
+// to d loss / d z can be taken while the molecule is still in LDS.  Rounds 3-5 ran: project, propagate, pool, head, head reduce |
+// molecule gradients, propagate^T, project^T + dW1, slab reduce -- 102 us of a 725 us step at batch 4096, about half of it launch
+// latency (a dependent kernel costs ~5 us in a captured graph on this chip whatever it does).  Now:
+//     z = W1[:, block] sim[block]                                        block_project_mfma_kernel        (matrix cores, as before)
+//     THIS FILE: per chunk of whole molecules, on the H-wide rows --     tail_middle_kernel
+//         pre = b1 + sum of z over the in-edges;  e_g = sum_n swish(pre_n);  emb_g = W2 e_g + |g| b2;  logit, loss, d logit;
+//         d emb, d e_g;  d pre = d e_g * swish'(pre);  d z = sum of d pre over the out-edges;  partial dW2, db1, db2, d head
+//     d sim[block] = W1[:, block]^T d z,  dW1 += d z (x) sim              block_project_bwd_mfma_kernel    (matrix cores, as before)
+//     all partial slabs -> the gradients, the loss                       slab_reduce_kernel
+// (A first version did the two projections here too, on the vector pipe out of LDS: 530 us -- three 98 MFLOP products with an
+// LDS read per multiply-add at one wave per SIMD.  They stay on the matrix cores.)
 //
-// A workgroup takes a contiguous run of whole molecules and walks it in CHUNKS of molecules that fit LDS (<= AC atoms, <= EC
-// edges each way, <= MC molecules): bulk loads of the chunk's indices and of every atom's OWN column block of sim (a row of a
-// kernel convolution's output is non-zero only there: 10 / 20 / 30 / 50 of 110 floats), then
-//     z = W1[:, block] sim[block]            per atom                (lin1 commutes with the neighbour sum: project first)
-//     pre = b1 + sum of z over the in-edges  per atom, from LDS      (propagate on H-wide rows)
-//     e_g = sum_n swish(pre_n)               per molecule            (lin2 commutes with the pool: one row per molecule)
-//     emb_g = W2 e_g + |g| b2,  logit, loss, d logit;  d emb, d e_g  per molecule
-//     d pre = d e_g * swish'(pre);  d z = sum of d pre over the out-edges;  d sim[block] = W1[:, block]^T d z;  dW1 += d z (x) sim
-// with block-wide barriers between the phases.  Molecules never share atoms or edges, so a chunk needs nothing from outside.
-// No float atomics: every sum runs in a fixed order, the per-workgroup partial gradients go to slabs that a second small
-// kernel adds up in block order.  The dropout mask of the head comes from the same counter-based generator, element for
-// element, as mkgnn_bce_head_fused (kgnn_philox.h).
+// A workgroup takes a contiguous run of whole molecules and walks it in CHUNKS that fit LDS (<= AC atoms, <= EC edges each way,
+// <= MC molecules): bulk loads of the chunk's indices and z rows, block-wide barriers between the phases.  Molecules never
+// share atoms or edges, so a chunk needs nothing from outside.  No float atomics: every sum runs in a fixed order, the
+// per-workgroup partial gradients go to slabs that the reduction adds up in block order.  The dropout mask of the head comes
+// from the same counter-based generator, element for element, as mkgnn_bce_head_fused (kgnn_philox.h).
 //
-// Limits (mkgnn_tail_supported; the host falls back to the nine launches otherwise): K <= 112 columns, every degree's block
-// <= 52, H <= 32, G <= 32, no dropout inside the readout, and -- checked per batch by the host, which knows the molecule
-// sizes -- no single molecule beyond a chunk (128 atoms, 512 edges).  A molecule that breaks the last promise is skipped and
-// the loss comes back NaN: loud, not wrong.
+// Limits (mkgnn_tail_supported; the host falls back to the nine launches otherwise): H <= 32, G <= 32, no dropout inside the
+// readout, and -- checked per batch by the host, which knows the molecule sizes -- no single molecule beyond a chunk (128
+// atoms, 512 edges).  A molecule that breaks the last promise is skipped and the loss comes back NaN: loud, not wrong.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <math.h>
@@ -41,28 +40,19 @@ namespace mkgnn {
 namespace tail {
 
 constexpr int NT = 256;                 // threads per workgroup: 8 row slots x 32 hidden lanes
-constexpr int AC = MKGNN_TAIL_MAX_ATOMS, EC = MKGNN_TAIL_MAX_EDGES, MC = 32;      // chunk capacity: atoms, edges (each way), molecules
-constexpr int LB = 52, LBP = 53;        // widest column block; its LDS pitch (odd: a column walk is conflict-free)
-constexpr int KMAX = 112, HP = 33;      // columns of sim; pitch of the 32-wide rows
-constexpr int CG = 14;                  // dW1 columns per thread: 8 slots x 14 = 112
+constexpr int AC = MKGNN_TAIL_MAX_ATOMS, EC = MKGNN_TAIL_MAX_EDGES, MC = 12;      // chunk capacity: atoms, edges (each way), molecules
+constexpr int HP = 36;                  // LDS pitch of the 32-wide rows: 16-byte aligned rows, 4 banks apart
+constexpr int WP = 33;                  // ... of W2's rows (read one float per lane: odd, conflict-free)
+typedef mkgnn_f32x4 f32x4;
 
-struct Args {
-    const float* sim; int64_t ss;
-    const int8_t* deg;
-    const int32_t *rin, *cin, *rout, *cout;
-    const int32_t *mol_ptr, *atom_mol;
-    int64_t n_atoms, n_mols, n_loss;
-    const float *w1, *b1, *w2, *b2, *wh, *bh, *y;
-    int K, H, G;
-    uint32_t blk_off, blk_len;          // byte d: first column / width of degree d's block (d = 1..4 -> bytes 0..3)
-    float drop_p; const int64_t* rng;
-    float* emb; int64_t es;             // [n_mols, G] or null
-    float* pred; float* gsim; int64_t gs;
-    float* slab; int slab_stride;       // [gridDim.x][slab_stride]: W1 [H][K] | b1 [32] | W2 [32][32] | b2 [32] | wh [32] | bh | loss
-    int* status;                        // != 0 after the launch: a molecule did not fit a chunk
-};
-
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.f / (1.f + expf(-v)); }
+// sigmoid on the transcendental unit: v_exp_f32 and v_rcp_f32 (1 ulp each) instead of the library's expf and an IEEE division --
+// ~6 instructions for ~60.  This kernel evaluates two of them per (atom, hidden unit) and, measured by compiling the phases out,
+// was BOUND by them (31 of its 64 us).  Relative error <= 2^-22 + |v| 2^-23: 2e-6 at |v| = 16, against the 1e-5 the readout is
+// held to (tests/test_tail.py: against float64 autograd of the reference's formula).
+__device__ __forceinline__ float sigmoidf_(float v) {
+    const float e = __builtin_amdgcn_exp2f(-1.44269504088896340736f * v);      // e^-v  (inf for v << 0: the reciprocal is then 0)
+    return __builtin_amdgcn_rcpf(1.f + e);
+}
 __device__ __forceinline__ float half_sum(float v) {       // xor tree over the 32 lanes of a row slot
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -70,22 +60,55 @@ __device__ __forceinline__ float half_sum(float v) {       // xor tree over the 
 }
 __device__ __forceinline__ float lane_of(float v, int k) { return __shfl(v, (int)(threadIdx.x & 32) | k, 64); }    // lane k of my row slot
 
-__host__ __device__ constexpr int lds_floats() {
-    return KMAX * HP + 32 * HP + AC * LBP + 2 * AC * HP + MC * HP + 96;
+// out[u] = sum over the edges of atom at0 + 32 u of rows[col][4 l .. 4 l + 3]  (rp: local edge offsets, ec: local atom of every
+// edge, -1 = none; a thread is (atom slot, lane l of 8): 16 bytes of a 32-wide row).  The first four edges of all NA atoms in
+// one batch of reads -- offsets, then columns, then rows -- and a serial tail for the rare atom with more (atoms outside the
+// degree buckets); an atom beyond A contributes nothing.  Fixed order: edge by edge.
+template <int NA>
+__device__ __forceinline__ void gather_rows(const int* rp, const int* ec, const float* rows, int at0, int A, int l, f32x4 (&out)[NA]) {
+    int lo[NA], hi[NA], col[NA][4];
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+        const int at = at0 + 32 * u, ac = at < A ? at : A - 1;
+        lo[u] = rp[ac]; hi[u] = at < A ? rp[ac + 1] : lo[u];
+    }
+#pragma unroll
+    for (int u = 0; u < NA; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) col[u][k] = ec[lo[u] + k < hi[u] ? lo[u] + k : (hi[u] > lo[u] ? lo[u] : 0)];
+    f32x4 v[NA][4];
+#pragma unroll
+    for (int u = 0; u < NA; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[u][k] = *(const f32x4*)(rows + ((unsigned)col[u][k] < (unsigned)A ? col[u][k] : 0) * HP + 4 * l);
+#pragma unroll
+    for (int u = 0; u < NA; ++u) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (lo[u] + k < hi[u] && col[u][k] >= 0) s += v[u][k];
+        for (int e = lo[u] + 4; e < hi[u]; ++e) { const int c = ec[e]; if (c >= 0) s += *(const f32x4*)(rows + c * HP + 4 * l); }
+        out[u] = s;
+    }
 }
-__host__ __device__ constexpr int lds_ints() { return 2 * AC + 2 * (AC + 1) + 2 * EC + 3 * (MC + 1) + 4; }
 
-__global__ void __launch_bounds__(NT) tail_fused_kernel(Args a) {
-    extern __shared__ __align__(16) float lds[];
-    float* const W1t = lds;                              // [K][HP]: W1t[c][j] = W1[j][c]
-    float* const W2s = W1t + KMAX * HP;                  // [32][HP]
-    float* const simb = W2s + 32 * HP;                   // [AC][LBP]: every atom's own column block
-    float* const zp = simb + AC * LBP;                   // [AC][HP]: pre, later d pre
+// Diagnostics (always compiled, off unless mkgnn_debug_set_tail_stamps gave a buffer): cycle totals of the middle kernel's phases,
+// thread 0 of every workgroup -> [block][16] (tools/tail_stamps.py)
+__device__ unsigned long long* g_tail_stamps = nullptr;
+#define TAIL_PHASE(i) do { if (stamps) { const unsigned long long t_ = __builtin_readcyclecounter(); ph[i] += t_ - t_ph; t_ph = t_; } } while (0)
+
+constexpr int LDS_FLOATS = 32 * WP + 2 * AC * HP + 3 * MC * HP + 96;
+constexpr int LDS_INTS = AC + 2 * (AC + 1) + 2 * EC + 3 * (MC + 1) + 4;
+
+__global__ void __launch_bounds__(NT, 3) tail_middle_kernel(TailMidArgs a) {
+    __shared__ __align__(16) float lds[LDS_FLOATS + LDS_INTS];
+    float* const W2s = lds;                              // [32][HP]
+    float* const zp = W2s + 32 * WP;                     // [AC][HP]: pre, later d pre   (32 * 33 floats = 4 224 bytes: 16-byte aligned)
     float* const dzb = zp + AC * HP;                     // [AC][HP]: z, then swish(pre), then d z
     float* const emol = dzb + AC * HP;                   // [MC][HP]: d e_g
-    float* const vec = emol + MC * HP;                   // b1 | b2 | wh
-    int* const info = (int*)(vec + 96);                  // [AC] off | len << 8
-    int* const amol = info + AC;                         // [AC] molecule of the chunk
+    float* const emol_e = emol + MC * HP;                // [MC][HP]: e_g
+    float* const emol_d = emol_e + MC * HP;              // [MC][HP]: d emb_g
+    float* const vec = emol_d + MC * HP;                 // b1 | b2 | wh
+    int* const amol = (int*)(vec + 96);                  // [AC] molecule of the chunk
     int* const rpin = amol + AC;                         // [AC + 1] local edge offsets, by target
     int* const rpout = rpin + AC + 1;                    // [AC + 1] by source
     int* const ecin = rpout + AC + 1;                    // [EC] local source of every in-edge (-1: outside the chunk)
@@ -94,47 +117,45 @@ __global__ void __launch_bounds__(NT) tail_fused_kernel(Args a) {
     int* const mein = mptr + MC + 1;                     // [MC + 1] first in-edge
     int* const meout = mein + MC + 1;                    // [MC + 1] first out-edge
     int* const ctl = meout + MC + 1;                     // [0] molecules of this chunk
-    const int t = threadIdx.x, j = t & 31, slot = t >> 5;
-    const int K = a.K, H = a.H, G = a.G;
+    const int t = threadIdx.x, j = t & 31, slot = t >> 5;      // the per-molecule phase: (row slot of 8, hidden unit)
+    const int l = t & 7, as = t >> 3;                          // the per-atom phases: (atom slot of 32, 16-byte lane of 8)
+    const int H = a.H, G = a.G;
+    unsigned long long* const stamps = g_tail_stamps;
+    unsigned long long ph[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_ph = stamps ? __builtin_readcyclecounter() : 0ull;
 
-    // ---- once: the weights.  Zero first (rows / lanes beyond H, G, K stay zero), then fill
-    for (int i = t; i < KMAX * HP + 32 * HP; i += NT) lds[i] = 0.f;
-    if (t < 96) vec[t] = 0.f;
-    __syncthreads();
-    for (int base = 0; base < H * K; base += NT * 8) {
-        float tmp[8];
+    // ---- once: the weights.  Zero first (rows / lanes beyond H, G stay zero), then fill
+    // (every load first -- unconditional, clamped -- then the stores: written as "lds[i] = ok ? w[i] : 0" in a loop the compiler keeps
+    // one load in flight at a time, and this kernel is nothing but latency)
+    float w2r[4], vr = 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int i = base + t + NT * u; tmp[u] = a.w1[i < H * K ? i : 0]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = base + t + NT * u;
-            if (i < H * K) { const int r = i / K, c = i - r * K; W1t[c * HP + r] = tmp[u]; }
-        }
+    for (int u = 0; u < 4; ++u) { const int i = t + NT * u; w2r[u] = a.w2[i < G * H ? i : 0]; }
+    {
+        const float* vp = t < 32 ? a.b1 : (t < 64 ? a.b2 : a.wh);
+        const int lim = t < 32 ? H : G, k = t & 31;
+        if (t < 96 && vp && k < lim) vr = vp[k];         // (three short segments: one load each, no chain)
     }
-    for (int i = t; i < G * H; i += NT) { const int r = i / H, c = i - r * H; W2s[r * HP + c] = a.w2[i]; }
-    if (t < H && a.b1) vec[t] = a.b1[t];
-    if (t < G && a.b2) vec[32 + t] = a.b2[t];
-    if (t < G) vec[64 + t] = a.wh[t];
     const float bh = a.bh ? a.bh[0] : 0.f;
     const bool drop = a.drop_p > 0.f;
     const uint64_t seed = drop ? (uint64_t)a.rng[0] : 0, offset = drop ? (uint64_t)a.rng[1] : 0;
     const float invB = 1.f / (float)a.n_loss;
+    for (int i = t; i < 32 * WP; i += NT) W2s[i] = 0.f;
+    if (t < 96) vec[t] = vr;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int i = t + NT * u; if (i < G * H) { const int r = i / H, c = i - r * H; W2s[r * WP + c] = w2r[u]; } }
 
     // this workgroup's molecules: an equal share of a contiguous run
     const int64_t per = (a.n_mols + gridDim.x - 1) / gridDim.x;
     int64_t m_next = per * blockIdx.x;
     const int64_t m_hi = m_next + per < a.n_mols ? m_next + per : a.n_mols;
 
-    // gradient accumulators that live across the chunks
-    float accW1[CG];                                     // dW1[j][CG * slot + k]
-#pragma unroll
-    for (int k = 0; k < CG; ++k) accW1[k] = 0.f;
-    float accW2[32];                                     // dW2[i = j][k]   (this slot's molecules)
-#pragma unroll
-    for (int k = 0; k < 32; ++k) accW2[k] = 0.f;
-    float acc_b1 = 0.f, acc_b2 = 0.f, acc_wh = 0.f, acc_bh = 0.f, acc_loss = 0.f;
+    float accW2[4] = {0.f, 0.f, 0.f, 0.f};               // dW2[i][k], element t + 256 u of the [32][32] image: summed per chunk from the
+                                                         // molecules' (d emb, e) pairs kept in LDS (32 accumulators per thread cost 60 VGPRs)
+    f32x4 acc_b1 = {0.f, 0.f, 0.f, 0.f};                  // d b1[4 l .. 4 l + 3], this atom slot's atoms
+    float acc_b2 = 0.f, acc_wh = 0.f, acc_bh = 0.f, acc_loss = 0.f;
 
     __syncthreads();
+    TAIL_PHASE(0);                                       // prologue
     while (m_next < m_hi) {
         const int64_t m0 = m_next;
         // ---- the window: first atom and first edges of the next MC + 1 molecules (two dependent loads for all of them)
@@ -150,12 +171,15 @@ __global__ void __launch_bounds__(NT) tail_fused_kernel(Args a) {
             int nm = 0;
             const int lim = (int)(m_hi - m0 < MC ? m_hi - m0 : MC);
             while (nm < lim && mptr[nm + 1] - mptr[0] <= AC && mein[nm + 1] - mein[0] <= EC && meout[nm + 1] - meout[0] <= EC) ++nm;
-            if (nm == 0) { nm = -1; atomicExch(a.status, 1); }          // one molecule beyond a chunk: skipped, reported
             ctl[0] = nm;
         }
         __syncthreads();
-        int nm = ctl[0];
-        if (nm < 0) {                                    // (block-uniform)
+        TAIL_PHASE(1);                                   // window
+        const int nm = ctl[0];
+        if (nm == 0) {                                   // (block-uniform) one molecule beyond a chunk: skipped, reported as NaN.
+            // Its atoms still get a d z row (zero): the projection kernel behind this one reads every row.
+            const int a0 = mptr[0], A = mptr[1] - a0;
+            for (int i = t; i < A * 32; i += NT) a.dz[(int64_t)a0 * 32 + i] = 0.f;
             if (t == 0) acc_loss = __builtin_nanf("");
             m_next = m0 + 1;
             __syncthreads();
@@ -164,74 +188,88 @@ __global__ void __launch_bounds__(NT) tail_fused_kernel(Args a) {
         m_next = m0 + nm;
         const int a0 = mptr[0], A = mptr[nm] - a0;
         const int ein0 = mein[0], nin = mein[nm] - ein0, eout0 = meout[0], nout = meout[nm] - eout0;
-        // ---- P1: per atom -- degree block, molecule, edge offsets
+        // ---- P1: per atom -- molecule, edge offsets; the z rows (one coalesced 128-byte row per slot and pass)
         if (t <= A) {
             const int n = a0 + (t < A ? t : A - 1);
-            const int d = (int)a.deg[n];
-            const int off = d >= 1 && d <= 4 ? (int)((a.blk_off >> (8 * (d - 1))) & 0xFF) : 0;
-            const int len = d >= 1 && d <= 4 ? (int)((a.blk_len >> (8 * (d - 1))) & 0xFF) : 0;
             const int mol = a.atom_mol[n] - (int)m0;
             const int ri = a.rin[a0 + t] - ein0, ro = a.rout[a0 + t] - eout0;      // (t == A: the end of the last atom's edges)
-            if (t < A) { info[t] = off | (len << 8); amol[t] = mol; }
+            if (t < A) amol[t] = mol;
             rpin[t] = ri; rpout[t] = ro;
         }
-        __syncthreads();
-        // ---- P2: the edges (local atom numbers) and every atom's own block of sim
-        for (int i = t; i < nin; i += NT) { const int s = a.cin[ein0 + i] - a0; ecin[i] = (s >= 0 && s < A) ? s : -1; }
-        for (int i = t; i < nout; i += NT) { const int s = a.cout[eout0 + i] - a0; ecout[i] = (s >= 0 && s < A) ? s : -1; }
-        for (int base = 0; base < A * LB; base += NT * 13) {
-            float tmp[13];
+        {
+            f32x4 zr[AC / 32];
 #pragma unroll
-            for (int u = 0; u < 13; ++u) {
-                const int i = base + t + NT * u, ic = i < A * LB ? i : A * LB - 1;
-                const int at = ic / LB, c = ic - at * LB;
-                const int off = info[at] & 0xFF, len = info[at] >> 8;
-                tmp[u] = a.sim[(int64_t)(a0 + at) * a.ss + off + (c < len ? c : 0)];          // unconditional, masked below
+            for (int q = 0; q < AC / 32; ++q) { const int at = as + 32 * q; zr[q] = *(const f32x4*)(a.z + (int64_t)(a0 + (at < A ? at : A - 1)) * 32 + 4 * l); }
+#pragma unroll
+            for (int q = 0; q < AC / 32; ++q) { const int at = as + 32 * q; if (at < A) *(f32x4*)(dzb + at * HP + 4 * l) = zr[q]; }
+        }
+        {
+            int ci[EC / NT], co[EC / NT];                // (all four loads in flight: EC / NT = 2 edges each way per thread)
+#pragma unroll
+            for (int u = 0; u < EC / NT; ++u) {
+                const int i = t + NT * u;
+                ci[u] = a.cin[ein0 + (i < nin ? i : 0)];
+                co[u] = a.cout[eout0 + (i < nout ? i : 0)];
             }
 #pragma unroll
-            for (int u = 0; u < 13; ++u) {
-                const int i = base + t + NT * u;
-                if (i < A * LB) {
-                    const int at = i / LB, c = i - at * LB;
-                    simb[at * LBP + c] = c < (info[at] >> 8) ? tmp[u] : 0.f;
+            for (int u = 0; u < EC / NT; ++u) {
+                const int i = t + NT * u;
+                if (i < nin) { const int s = ci[u] - a0; ecin[i] = (s >= 0 && s < A) ? s : -1; }
+                if (i < nout) { const int s = co[u] - a0; ecout[i] = (s >= 0 && s < A) ? s : -1; }
+            }
+        }
+        __syncthreads();
+        TAIL_PHASE(2);                                   // chunk loads
+#if defined(MKGNN_TAIL_ABLATE) && MKGNN_TAIL_ABLATE == 1      // (timing experiment: the loads and the stores only)
+        for (int at = slot; at < A; at += 8) a.dz[(int64_t)(a0 + at) * 32 + j] = dzb[at * HP + j];
+        __syncthreads();
+        continue;
+#endif
+        // ---- P3: pre = b1 + sum of z over the in-edges; swish
+        f32x4 sw[AC / 32];
+        {
+            // (all of a pass's index reads, then all of its row reads, then the sums: written atom by atom the two dependent LDS
+            // round trips of every edge were paid one after the other; sixteen bytes per lane: a quarter of the LDS instructions)
+            const f32x4 b1v = *(const f32x4*)(vec + 4 * l);
+            f32x4 p[AC / 32];
+            gather_rows<AC / 32>(rpin, ecin, dzb, as, A, l, p);
+#pragma unroll
+            for (int u = 0; u < AC / 32; ++u) {
+                const int at = as + 32 * u;
+                const f32x4 pv = b1v + p[u];
+                sw[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (at < A) {
+                    *(f32x4*)(zp + at * HP + 4 * l) = pv;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) sw[u][c] = pv[c] * sigmoidf_(pv[c]);
                 }
             }
         }
         __syncthreads();
-        // ---- P3a: z = W1[:, block] sim[block]
-        for (int at = slot; at < A; at += 8) {
-            const int off = info[at] & 0xFF, len = info[at] >> 8;
-            float z = 0.f;
-            for (int c = 0; c < len; ++c) z = fmaf(W1t[(off + c) * HP + j], simb[at * LBP + c], z);
-            dzb[at * HP + j] = z;
-        }
-        __syncthreads();
-        // ---- P3b: pre = b1 + sum over the in-edges; swish
-        float sw[AC / 8];
 #pragma unroll
-        for (int q = 0; q < AC / 8; ++q) {
-            const int at = slot + 8 * q;
-            sw[q] = 0.f;
-            if (at < A) {
-                float p = vec[j];
-                for (int e = rpin[at]; e < rpin[at + 1]; ++e) { const int s = ecin[e]; if (s >= 0) p += dzb[s * HP + j]; }
-                zp[at * HP + j] = p;
-                sw[q] = p * sigmoidf_(p);
-            }
-        }
+        for (int q = 0; q < AC / 32; ++q) { const int at = as + 32 * q; if (at < A) *(f32x4*)(dzb + at * HP + 4 * l) = sw[q]; }
         __syncthreads();
-#pragma unroll
-        for (int q = 0; q < AC / 8; ++q) { const int at = slot + 8 * q; if (at < A) dzb[at * HP + j] = sw[q]; }
-        __syncthreads();
+        TAIL_PHASE(3);                                   // P3
         // ---- P4: per molecule -- pool, lin2, head, loss, and the way back to d e_g
+#if defined(MKGNN_TAIL_ABLATE) && MKGNN_TAIL_ABLATE == 2      // (timing experiment: no per-molecule phase)
+        for (int g = slot; g < nm; g += 8) { emol[g * HP + j] = 1.f; emol_e[g * HP + j] = 1.f; emol_d[g * HP + j] = 1.f; }
+        for (int g = slot; false && g < nm; g += 8) {
+#else
         for (int g = slot; g < nm; g += 8) {
+#endif
             const int b0 = mptr[g] - a0, b1_ = mptr[g + 1] - a0;
             float e = 0.f;
-            for (int at = b0; at < b1_; ++at) e += dzb[at * HP + j];
+            for (int at = b0; at < b1_; at += 8) {       // (eight reads in flight; the order of the sum stays atom by atom)
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = dzb[(at + u < b1_ ? at + u : b1_ - 1) * HP + j];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (at + u < b1_) e += v[u];
+            }
             const float cnt = (float)(b1_ - b0);
             float emb = vec[32 + j] * cnt;
 #pragma unroll
-            for (int k = 0; k < 32; ++k) emb = fmaf(W2s[j * HP + k], lane_of(e, k), emb);
+            for (int k = 0; k < 32; ++k) emb = fmaf(W2s[j * WP + k], lane_of(e, k), emb);
             const int64_t gi = m0 + g;
             if (a.emb && j < G) a.emb[gi * a.es + j] = emb;
             const bool counted = gi < a.n_loss;
@@ -251,233 +289,113 @@ __global__ void __launch_bounds__(NT) tail_fused_kernel(Args a) {
             acc_wh = fmaf(d, emb * ks, acc_wh);
             const float demb = j < G ? d * wv * ks : 0.f;
             acc_b2 = fmaf(demb, cnt, acc_b2);
-#pragma unroll
-            for (int k = 0; k < 32; ++k) accW2[k] = fmaf(demb, lane_of(e, k), accW2[k]);
             float de = 0.f;                              // d e_g[j] = sum_i W2[i][j] d emb_i
 #pragma unroll
-            for (int i = 0; i < 32; ++i) de = fmaf(W2s[i * HP + j], lane_of(demb, i), de);
+            for (int i = 0; i < 32; ++i) de = fmaf(W2s[i * WP + j], lane_of(demb, i), de);
             emol[g * HP + j] = de;
+            emol_e[g * HP + j] = e;
+            emol_d[g * HP + j] = demb;
         }
         __syncthreads();
+        TAIL_PHASE(4);                                   // P4
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {                    // dW2[i][k] += sum over the chunk's molecules of d emb_g[i] e_g[k]
+            const int i = (t + NT * u) >> 5, k = (t + NT * u) & 31;
+            for (int g = 0; g < nm; ++g) accW2[u] = fmaf(emol_d[g * HP + i], emol_e[g * HP + k], accW2[u]);
+        }
         // ---- P5: d pre = d e_g * swish'(pre)   (in place of pre)
-        for (int at = slot; at < A; at += 8) {
-            const float p = zp[at * HP + j], sg = sigmoidf_(p);
-            const float dp = emol[amol[at] * HP + j] * (sg * (1.f + p * (1.f - sg)));
-            zp[at * HP + j] = dp;
-            acc_b1 += dp;
-        }
-        __syncthreads();
-        // ---- P6: d z = sum of d pre over the out-edges
-        for (int at = slot; at < A; at += 8) {
-            float v = 0.f;
-            for (int e = rpout[at]; e < rpout[at + 1]; ++e) { const int s = ecout[e]; if (s >= 0) v += zp[s * HP + j]; }
-            dzb[at * HP + j] = v;
-        }
-        __syncthreads();
-        // ---- P7a: d sim[block] = W1[:, block]^T d z
-        for (int i = t; i < A * LB; i += NT) {
-            const int at = i / LB, c = i - at * LB;
-            const int off = info[at] & 0xFF, len = info[at] >> 8;
-            if (c < len) {
-                float v = 0.f;
-#pragma unroll
-                for (int k = 0; k < 32; ++k) v = fmaf(W1t[(off + c) * HP + k], dzb[at * HP + k], v);
-                a.gsim[(int64_t)(a0 + at) * a.gs + off + c] = v;
-            }
-        }
-        // ---- P7b: dW1[j][col] += d z[j] sim[col]   (a thread's CG columns; an atom's block meets them or not)
         {
-            const int c0 = CG * slot;
-            for (int at = 0; at < A; ++at) {
-                const int off = info[at] & 0xFF, len = info[at] >> 8;
-                if (off < c0 + CG && off + len > c0) {
-                    const float dzv = dzb[at * HP + j];
+            f32x4 p[AC / 32], de[AC / 32];
 #pragma unroll
-                    for (int k = 0; k < CG; ++k) {
-                        const int c = c0 + k - off;
-                        if (c >= 0 && c < len) accW1[k] = fmaf(dzv, simb[at * LBP + c], accW1[k]);
-                    }
+            for (int u = 0; u < AC / 32; ++u) {
+                const int at = as + 32 * u, ac = at < A ? at : A - 1;
+                p[u] = *(const f32x4*)(zp + ac * HP + 4 * l);
+                de[u] = *(const f32x4*)(emol + amol[ac] * HP + 4 * l);
+            }
+#pragma unroll
+            for (int u = 0; u < AC / 32; ++u) {
+                const int at = as + 32 * u;
+                if (at < A) {
+                    f32x4 dp;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { const float sg = sigmoidf_(p[u][c]); dp[c] = de[u][c] * (sg * (1.f + p[u][c] * (1.f - sg))); }
+                    *(f32x4*)(zp + at * HP + 4 * l) = dp;
+                    acc_b1 += dp;
                 }
             }
         }
         __syncthreads();
+        TAIL_PHASE(5);                                   // dW2 + P5
+        // ---- P6: d z = sum of d pre over the out-edges, straight to memory (a coalesced row per slot and pass)
+        {
+            f32x4 v[AC / 32];
+            gather_rows<AC / 32>(rpout, ecout, zp, as, A, l, v);
+#pragma unroll
+            for (int u = 0; u < AC / 32; ++u) {
+                const int at = as + 32 * u;
+                if (at < A) *(f32x4*)(a.dz + (int64_t)(a0 + at) * 32 + 4 * l) = v[u];
+            }
+        }
+        // (the LDS images are free for the next chunk once everybody has READ them: a barrier that does not wait for the d z
+        // stores -- __syncthreads() would, a full memory round trip per chunk)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        TAIL_PHASE(6);                                   // P6
     }
+    __syncthreads();
+    TAIL_PHASE(7);
 
-    // ---- the workgroup's slab: dW1 as it is; the rest summed over the eight row slots in slot order
-    float* const slab = a.slab + (size_t)blockIdx.x * a.slab_stride;
-    if (j < H) {
+    // ---- the workgroup's slab: everything summed over the eight row slots in slot order
+    float* const so = a.slab + (size_t)blockIdx.x * a.slab_stride;
 #pragma unroll
-        for (int k = 0; k < CG; ++k) { const int c = CG * slot + k; if (c < K) slab[j * K + c] = accW1[k]; }
-    }
-    float* const red = simb;                             // [8][32 * 36] >= what follows (AC * LBP floats = 6784 < 8 * 1152: use zp too)
-    // (simb, zp and dzb are contiguous: 6784 + 2 * 4224 floats)
-#pragma unroll
-    for (int k = 0; k < 32; ++k) red[(slot * 32 + j) * 36 + k] = accW2[k];
-    red[(slot * 32 + j) * 36 + 32] = acc_b1;
-    red[(slot * 32 + j) * 36 + 33] = acc_b2;
-    red[(slot * 32 + j) * 36 + 34] = acc_wh;
-    red[(slot * 32 + j) * 36 + 35] = (j == 0) ? acc_bh : 0.f;
+    for (int u = 0; u < 4; ++u) so[TAIL_W2 + t + NT * u] = accW2[u];
+    float* const red = zp;                               // [8 slots][32][4]: b2, wh, bh of the per-molecule phase
+    float* const redb = dzb;                             // [32 atom slots][32]: b1 of the per-atom phases
+    red[(slot * 32 + j) * 4 + 1] = acc_b2;
+    red[(slot * 32 + j) * 4 + 2] = acc_wh;
+    red[(slot * 32 + j) * 4 + 3] = (j == 0) ? acc_bh : 0.f;
+    *(f32x4*)(redb + as * 32 + 4 * l) = acc_b1;
     if (j == 0) vec[slot] = acc_loss;                    // (b1's copy is no longer needed)
     __syncthreads();
-    float* const so = slab + H * K;
-    for (int i = t; i < 32 * 36; i += NT) {
-        const int r = i / 36, c = i - r * 36;
+    if (t < 128) {
+        const int r = t >> 2, c = t & 3;
         float v = 0.f;
-        for (int s8 = 0; s8 < 8; ++s8) v += red[(s8 * 32 + r) * 36 + c];
-        if (c < 32) so[32 + r * 32 + c] = v;             // W2 [32][32]
-        else if (c == 32) so[r] = v;                     // b1 [32]
-        else if (c == 33) so[32 + 1024 + r] = v;         // b2 [32]
-        else if (c == 34) so[32 + 1024 + 32 + r] = v;    // wh [32]
-        else if (r == 0) so[32 + 1024 + 64] = v;         // bh
+        if (c == 0) {
+#pragma unroll
+            for (int s32 = 0; s32 < 32; ++s32) v += redb[s32 * 32 + r];
+            so[TAIL_B1 + r] = v;
+        } else {
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) v += red[(s8 * 32 + r) * 4 + c];
+            if (c == 1) so[TAIL_B2 + r] = v;
+            else if (c == 2) so[TAIL_WH + r] = v;
+            else if (r == 0) so[TAIL_BH] = v;
+        }
     }
     if (t == 0) {
         float v = 0.f;
         for (int s8 = 0; s8 < 8; ++s8) v += vec[s8];
-        so[32 + 1024 + 65] = v;                          // loss (already divided by B)
+        so[TAIL_LOSS] = v;                               // (already divided by B)
     }
-}
-
-constexpr int SLAB_TAIL = 32 + 1024 + 32 + 32 + 2;      // floats behind dW1 in a slab
-
-struct RedArgs {
-    const float* slab; int stride, count;
-    int K, H, G;
-    float *gw1, *gb1, *gw2, *gb2, *gwh, *gbh, *loss;
-    float drop_p; int64_t* rng; int64_t* rng_used;
-    int* status;
-};
-
-// element e of the reduced slab -> its destination; 32 elements per block, eight slab parts per element, fixed order
-__global__ void __launch_bounds__(256) tail_reduce_kernel(RedArgs a) {
-    __shared__ float part[8][32];
-    const int total = a.H * a.K + SLAB_TAIL;
-    const int e = blockIdx.x * 32 + (threadIdx.x & 31), p = threadIdx.x >> 5;
-    const int ec = e < total ? e : total - 1;
-    const int per = (a.count + 7) / 8;
-    const int b0 = p * per, b1 = (b0 + per < a.count) ? b0 + per : a.count;
-    float s = 0.f;
-    for (int b = b0; b < b1; b += 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = a.slab[(int64_t)(b + u < b1 ? b + u : b1 - 1) * a.stride + ec];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) if (b + u < b1) s += v[u];
-    }
-    part[p][threadIdx.x & 31] = s;
-    __syncthreads();
-    if (p == 0 && e < total) {
-        float v = part[0][threadIdx.x];
-#pragma unroll
-        for (int k = 1; k < 8; ++k) v += part[k][threadIdx.x];
-        const int hk = a.H * a.K;
-        if (e < hk) { if (a.gw1) a.gw1[e] = v; }
-        else {
-            const int r = e - hk;
-            if (r < 32) { if (a.gb1 && r < a.H) a.gb1[r] = v; }
-            else if (r < 32 + 1024) { const int i = (r - 32) >> 5, k = (r - 32) & 31; if (a.gw2 && i < a.G && k < a.H) a.gw2[i * a.H + k] = v; }
-            else if (r < 32 + 1024 + 32) { const int i = r - 32 - 1024; if (a.gb2 && i < a.G) a.gb2[i] = v; }
-            else if (r < 32 + 1024 + 64) { const int i = r - 32 - 1024 - 32; if (a.gwh && i < a.G) a.gwh[i] = v; }
-            else if (r == 32 + 1024 + 64) { if (a.gbh) a.gbh[0] = v; }
-            else {
-                const int bad = *a.status;                // a molecule beyond a chunk: NaN, and the word is left zero for the next call
-                a.loss[0] = bad ? __builtin_nanf("") : v;
-                if (bad) *a.status = 0;
-            }
-        }
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.drop_p > 0.f) {      // the generator advances once per step, as after mkgnn_bce_head_fused
-        const int64_t seed = a.rng[0], offset = a.rng[1];
-        a.rng_used[0] = seed; a.rng_used[1] = offset;
-        a.rng[1] = offset + 1;
-    }
-}
-
-static int grid_for(int64_t n_mols) {
-    int64_t nb = (n_mols + 7) / 8;                       // ~8 molecules (two chunks) per workgroup ...
-    if (nb > 512) nb = 512;                              // ... and no more slabs than the reduction reads in ~5 us
-    return (int)(nb < 1 ? 1 : nb);
+    TAIL_PHASE(8);                                       // epilogue
+    if (stamps && t == 0)
+        for (int i = 0; i < 12; ++i) stamps[(size_t)blockIdx.x * 16 + i] = ph[i];
 }
 
 }  // namespace tail
+
+int tail_middle_blocks(int64_t n_mols) {
+    int64_t nb = (n_mols + 7) / 8;                       // ~8 molecules (two chunks) per workgroup, two or three workgroups per CU;
+    if (nb > 512) nb = 512;                              // no more slabs than the reduction reads in a few batches
+    return (int)(nb < 1 ? 1 : nb);
+}
+
+extern "C" int mkgnn_debug_set_tail_stamps(void* device_ptr) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(tail::g_tail_stamps), &device_ptr, sizeof(void*));
+}
+
+hipError_t launch_tail_middle(const TailMidArgs& a, int nb, hipStream_t st) {
+    tail::tail_middle_kernel<<<nb, tail::NT, 0, st>>>(a);
+    return hipGetLastError();
+}
+
 }  // namespace mkgnn
-
-using namespace mkgnn;
-
-extern "C" {
-
-int mkgnn_tail_supported(int32_t K, int32_t H, int32_t G, const int32_t num_kernels[MKGNN_MAX_DEGREE]) {
-    if (!num_kernels || K < 1 || K > tail::KMAX || H < 1 || H > 32 || G < 1 || G > 32) return 0;
-    int sum = 0;
-    for (int i = 0; i < MKGNN_MAX_DEGREE; ++i) {
-        if (num_kernels[i] < 0 || num_kernels[i] > tail::LB) return 0;
-        sum += num_kernels[i];
-    }
-    return sum == K ? 1 : 0;
-}
-
-size_t mkgnn_tail_workspace_bytes(int32_t K, int32_t H, int64_t n_mols) {
-    if (K < 1 || H < 1 || n_mols < 1) return 0;
-    return 16 + (size_t)tail::grid_for(n_mols) * (size_t)((H * K + tail::SLAB_TAIL + 3) / 4 * 4) * 4;
-}
-
-int mkgnn_tail_fused(const mkgnn_tail_args* p, void* workspace, size_t workspace_bytes, void* stream) {
-    const char* who = "mkgnn_tail_fused";
-    if (!p) return api_fail("%s: null argument", who);
-    const mkgnn_readout_params& ro = p->readout;
-    if (!mkgnn_tail_supported(ro.F, ro.H, ro.G, p->num_kernels))
-        return api_fail("%s: K=%d H=%d G=%d outside the fused tail (K <= %d, blocks <= %d, H, G <= 32)", who, ro.F, ro.H, ro.G, tail::KMAX, tail::LB);
-    if (p->n_atoms < 1 || p->n_mols < 1 || p->n_loss_mols < 1 || p->n_loss_mols > p->n_mols) return api_fail("%s: bad sizes", who);
-    if (!p->sim || !p->degree || !p->in_rowptr || !p->in_col || !p->out_rowptr || !p->out_col || !p->mol_ptr || !p->atom_mol ||
-        !ro.lin1_weight || !ro.lin2_weight || !p->head_weight || !p->target || !p->pred || !p->loss || !p->grad_sim)
-        return api_fail("%s: null pointer", who);
-    if (p->sim_stride < ro.F || p->grad_sim_stride < ro.F) return api_fail("%s: bad strides", who);
-    if (p->dropout_p < 0.f || p->dropout_p >= 1.f) return api_fail("%s: dropout probability %g outside [0, 1)", who, (double)p->dropout_p);
-    if (p->dropout_p > 0.f && (!p->rng_state || !p->rng_used)) return api_fail("%s: dropout needs rng_state and rng_used", who);
-    if (p->emb && p->emb_stride < ro.G) return api_fail("%s: bad emb stride", who);
-    const size_t need = mkgnn_tail_workspace_bytes(ro.F, ro.H, p->n_mols);
-    if (!workspace || workspace_bytes < need) return api_fail("%s: workspace of %zu bytes, need %zu", who, workspace_bytes, need);
-    hipStream_t st = (hipStream_t)stream;
-    tail::Args a{};
-    a.sim = p->sim; a.ss = p->sim_stride; a.deg = p->degree;
-    a.rin = p->in_rowptr; a.cin = p->in_col; a.rout = p->out_rowptr; a.cout = p->out_col;
-    a.mol_ptr = p->mol_ptr; a.atom_mol = p->atom_mol;
-    a.n_atoms = p->n_atoms; a.n_mols = p->n_mols; a.n_loss = p->n_loss_mols;
-    a.w1 = ro.lin1_weight; a.b1 = ro.lin1_bias; a.w2 = ro.lin2_weight; a.b2 = ro.lin2_bias;
-    a.wh = p->head_weight; a.bh = p->head_bias; a.y = p->target;
-    a.K = ro.F; a.H = ro.H; a.G = ro.G;
-    int off = 0;
-    for (int i = 0; i < MKGNN_MAX_DEGREE; ++i) {
-        a.blk_off |= (uint32_t)off << (8 * i);
-        a.blk_len |= (uint32_t)p->num_kernels[i] << (8 * i);
-        off += p->num_kernels[i];
-    }
-    a.drop_p = p->dropout_p; a.rng = p->rng_state;
-    a.emb = p->emb; a.es = p->emb_stride;
-    a.pred = p->pred; a.gsim = p->grad_sim; a.gs = p->grad_sim_stride;
-    a.status = (int*)workspace;
-    a.slab = (float*)((char*)workspace + 16);
-    a.slab_stride = (ro.H * ro.F + tail::SLAB_TAIL + 3) / 4 * 4;
-    const int nb = tail::grid_for(p->n_mols);
-    hipError_t e = hipSuccess;
-    const size_t lds_bytes = (size_t)tail::lds_floats() * 4 + (size_t)tail::lds_ints() * 4;
-    static PerDeviceOnce attr_set;
-    if (const int slot = attr_set.pending(); slot >= 0) {
-        e = hipFuncSetAttribute((const void*)tail::tail_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return api_hip_fail(who, e);
-        attr_set.set(slot);
-    }
-    tail::tail_fused_kernel<<<nb, tail::NT, lds_bytes, st>>>(a);
-    e = hipGetLastError();
-    if (e != hipSuccess) return api_hip_fail(who, e);
-    tail::RedArgs r{};
-    r.slab = a.slab; r.stride = a.slab_stride; r.count = nb; r.K = ro.F; r.H = ro.H; r.G = ro.G;
-    r.gw1 = p->grad_lin1_weight; r.gb1 = p->grad_lin1_bias; r.gw2 = p->grad_lin2_weight; r.gb2 = p->grad_lin2_bias;
-    r.gwh = p->grad_head_weight; r.gbh = p->grad_head_bias; r.loss = p->loss;
-    r.drop_p = p->dropout_p; r.rng = p->rng_state; r.rng_used = p->rng_used; r.status = a.status;
-    const int total = ro.H * ro.F + tail::SLAB_TAIL;
-    tail::tail_reduce_kernel<<<(total + 31) / 32, 256, 0, st>>>(r);
-    e = hipGetLastError();
-    return e == hipSuccess ? 0 : api_hip_fail(who, e);
-}
-
-}  // extern "C"

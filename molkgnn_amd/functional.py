@@ -171,11 +171,14 @@ def _prepared_key(params, F, E, n_atoms, n_slots):
     return (F, E, n_atoms, n_slots) + tuple((p.data_ptr(), p._version) for p in params)
 
 
-def prepare_banks(params_per_call: Sequence[Sequence[torch.Tensor]], Fs: Sequence[int], E: int, n_atoms: int, n_slots: int):
+def prepare_banks(params_per_call: Sequence[Sequence[torch.Tensor]], Fs: Sequence[int], E: int, n_atoms: int, n_slots: int,
+                  side: Optional["torch.cuda.Stream"] = None):
     """``mkgnn_bank_prepare``: the normalised kernel banks of several forward calls (the layers of a model; call k will
     be ``kernelsetconv(x [n_atoms, Fs[k]], ..., params_per_call[k], E, prepared=result[k])``) in ONE launch on the current
     stream -- the banks depend on the parameters only, and one small dependent launch per layer leaves the step.
-    Returns one ``PreparedBank`` per call."""
+    Returns one ``PreparedBank`` per call.  ``side``: launch on that stream instead (forked from the current one; buffers are
+    still allocated on the current stream) -- the caller joins it, ``cur.wait_stream(side)``, before the first convolution: the
+    banks depend on nothing but the parameters, so the launch runs beside whatever precedes the convolutions (the batch norm)."""
     lib = _lib.load()
     dev = params_per_call[0][0].device
     out: List[PreparedBank] = []
@@ -198,9 +201,13 @@ def prepare_banks(params_per_call: Sequence[Sequence[torch.Tensor]], Fs: Sequenc
             wsarr = (C.c_void_p * cnt)(*[w.data_ptr() for w in wss])
             nbarr = (C.c_size_t * cnt)(*nbytes)
             with torch.cuda.device(dev):
-                _lib.check(lib.mkgnn_bank_prepare(cnt, C.cast(banks_all, C.c_void_p), C.cast(Farr, C.c_void_p), E,
-                                                  C.cast(wsarr, C.c_void_p), C.cast(nbarr, C.c_void_p), _lib.stream_ptr(dev)),
-                           "mkgnn_bank_prepare")
+                cur = torch.cuda.current_stream(dev)
+                if side is not None and side != cur:
+                    side.wait_stream(cur)
+                with torch.cuda.stream(side if side is not None else cur):
+                    _lib.check(lib.mkgnn_bank_prepare(cnt, C.cast(banks_all, C.c_void_p), C.cast(Farr, C.c_void_p), E,
+                                                      C.cast(wsarr, C.c_void_p), C.cast(nbarr, C.c_void_p), _lib.stream_ptr(dev)),
+                               "mkgnn_bank_prepare")
             for k, params in enumerate(chunk):
                 out.append(PreparedBank(wss[k], _prepared_key(params, Fs[lo + k], E, n_atoms, n_slots)))
     return out

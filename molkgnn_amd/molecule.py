@@ -519,17 +519,17 @@ def _ready(net, data, ffn):
         await_receptive_fields(data)
     plan = _plan_of(data)
     if _MODE != "1" and n_mols is not None and int(n_mols) > _MAX_MOLS_AUTO and not torch.cuda.is_current_stream_capturing() \
-            and getattr(plan, "_molecule", None) is None:
+            and not getattr(data, "resident", False):
         # An eager step above the captured threshold.  On RESIDENT batches the one-launch step is 1.7x the faster eager step
-        # (1.07 against 1.84 ms at 64-256 molecules); on a batch seen for the FIRST time its chunk table has to be built
+        # (1.07 against 1.84 ms at 64-256 molecules, round 5); on a batch seen for the FIRST time its chunk table has to be built
         # (sorts over the edge list + one host round trip) and the step is no faster, at 512 molecules slower (4.3 against
-        # 3.1 ms: tools/diag/eager_fresh_probe.py, round 5) -- and a training loop that streams its data sees every batch once.
-        # So: the first sight of a batch goes through the per-operator kernels (which also builds their per-batch caches);
-        # a batch that comes back (same index tensors: the plan cache hits) gets its chunk table then.
-        seen = getattr(plan, "_mol_seen", 0)
-        plan._mol_seen = seen + 1
-        if seen == 0:
-            return None
+        # 3.1 ms: tools/diag/eager_fresh_probe.py) -- and a training loop that streams its data sees every batch once.
+        # Round 5 let the visit count decide (first sight per operator, the one-launch step when a batch came back): the same
+        # batch then ran through two kernel families in epochs 1 and 2, whose last-bit differences flip tied neighbour orders
+        #  -- a run was not reproducible from its inputs.  Now the choice is a function of the
+        # batch alone: the caller that KEEPS its batches says so (``data.resident = True``: the one-launch step from the first
+        # visit on, chunk table built once), everybody else gets the per-operator kernels on every visit.
+        return None
     mp = molecule_plan(plan, getattr(data, 'batch', None), n_mols)
     if mp is None or not wanted(mp.n_mols):
         return None

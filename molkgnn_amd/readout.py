@@ -596,11 +596,11 @@ _TAIL_WS: dict = {}
 
 
 def _tail_workspace(dev, nbytes: int) -> torch.Tensor:
-    """Per-device scratch of the fused tail (gradient slabs behind a status word that must be zero on entry and is left zero):
-    zero-filled once; never released (a captured graph has its address baked in)."""
+    """Per-device scratch of the fused tail (z and d z rows, gradient slabs); never released (a captured graph has its address
+    baked in)."""
     held = _TAIL_WS.setdefault(str(dev), [])
     if not held or held[-1].numel() < nbytes:
-        held.append(torch.zeros(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev))
+        held.append(torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=dev))
     return held[-1]
 
 
@@ -652,9 +652,11 @@ class _TailFn(torch.autograd.Function):
         rng = head_rng_state(dev) if p_drop > 0.0 else None
         used = torch.empty(2, dtype=torch.int64, device=dev) if p_drop > 0.0 else None
         a = _lib.TailArgs()
-        a.sim, a.sim_stride, a.degree = sim.data_ptr(), _stride0(sim), plan.deg8.data_ptr()
+        a.sim, a.sim_stride = sim.data_ptr(), _stride0(sim)
         for i, L in enumerate(blocks):
             a.num_kernels[i] = int(L)
+        bk = _sel_buckets(plan)
+        a.buckets = ctypes.cast(bk, ctypes.c_void_p)
         (rin, cin), (rout, cout) = plan.csr_in, plan.csr_out
         a.in_rowptr, a.in_col, a.out_rowptr, a.out_col = rin.data_ptr(), cin.data_ptr(), rout.data_ptr(), cout.data_ptr()
         a.mol_ptr, a.atom_mol = seg.mol_ptr.data_ptr(), seg.atom_mol.data_ptr()
@@ -669,7 +671,7 @@ class _TailFn(torch.autograd.Function):
         a.grad_lin2_weight, a.grad_lin2_bias = gw2.data_ptr(), _lib.ptr(gb2)
         a.grad_head_weight, a.grad_head_bias = gwh.data_ptr(), _lib.ptr(gbh)
         with torch.cuda.device(dev):
-            ws = _tail_workspace(dev, int(lib.mkgnn_tail_workspace_bytes(K, H, seg.size)))
+            ws = _tail_workspace(dev, int(lib.mkgnn_tail_workspace_bytes(K, H, G, n, seg.size)))
             _lib.check(lib.mkgnn_tail_fused(ctypes.byref(a), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "mkgnn_tail_fused")
         ctx.unit = (gsim, gw1, gb1, gw2, gb2, gwh.reshape(wh.shape), gbh)
         ctx.pred = pred

@@ -424,3 +424,53 @@ def test_molecule_chunk_table_and_abi_structs():
     assert lib.mkgnn_molecule_supported(ctypes.byref(net(3, (10, 20, 30, 50), x_dim=40)), 40) == 0
     assert lib.mkgnn_molecule_supported(ctypes.byref(net(3, (10, 20, 30, 50), H=65)), 28) == 0
     assert lib.mkgnn_molecule_workspace_bytes(ctypes.byref(net(3, (10, 20, 30, 50))), 28, 400, 16) > 7_000_000
+
+
+def test_split_fp16_scales_are_exact_powers_of_two_over_every_exponent():
+    """The power-of-two scales of the split-fp16 products (csrc/kgnn_split.h), evaluated on the host by the
+    very functions the kernels compile (``mkgnn_debug_split_scales``): for EVERY biased exponent and random mantissas --
+    the scale is a power of two, the unscale is exactly its reciprocal times the documented 2^-EXTRA, the scaled magnitude lands
+    in [2^TARGET, 2^(TARGET + 1)) wherever the scale is not clamped (exponents 24 .. 230), and the clamp itself is where the
+    header says; the row scale of the forward / of pre-split rows times its companion gives back 1 / |x| exactly."""
+    import struct
+    from hypothesis import given, settings, strategies as st
+    from molkgnn_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    lib.mkgnn_debug_split_scales.restype = ctypes.c_int
+    lib.mkgnn_debug_split_scales.argtypes = [ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32 * 6)]
+
+    def f32(bits):
+        return struct.unpack("<f", struct.pack("<I", bits))[0]
+
+    def check(eb, mant):
+        bits = (eb << 23) | mant
+        out = (ctypes.c_uint32 * 6)()
+        assert lib.mkgnn_debug_split_scales(bits, ctypes.byref(out)) == 0
+        s_rows, u_rows, s_bank, u_bank, s_row, i_row = [int(v) for v in out]
+        # (the row scale is 2^(exponent + 8) of 1 / max(|x|, 1e-8) <= 1e8: exponents above 127 + 27 do not occur; checked to 246)
+        for s in (s_rows, u_rows, s_bank, u_bank) + ((s_row,) if eb < 255 - 8 else ()):
+            assert s & 0x007FFFFF == 0 and 0 < (s >> 23) < 255, (eb, hex(s))          # a normal power of two
+        # rows kernel: TARGET = 10, unscale carries 2^-12
+        f = min(230, max(24, 254 + 10 - eb))
+        assert s_rows >> 23 == f and (u_rows >> 23) == 254 - 12 - f
+        assert np.float32(f32(s_rows)) * np.float32(f32(u_rows)) == np.float32(2.0 ** -12)
+        if 24 <= 254 + 10 - eb <= 230 and 0 < eb < 255:
+            scaled = np.float64(f32(bits)) * np.float64(f32(s_rows))
+            assert 2.0 ** 10 <= scaled < 2.0 ** 11, (eb, scaled)
+        # bank kernel: TARGET = 18 from the exponent, unscale = 1 / scale
+        f = min(230, max(24, 254 + 18 - eb))
+        assert s_bank >> 23 == f and np.float32(f32(s_bank)) * np.float32(f32(u_bank)) == np.float32(1.0)
+        # row scale (amax read as 1 / |x|): 2^(exponent + 8) and the mantissa at exponent -8: their product is the value itself
+        if 0 < eb < 255 - 8:
+            assert s_row >> 23 == eb + 8 and (i_row & 0x007FFFFF) == mant and (i_row >> 23) == 127 - 8
+            assert np.float32(f32(s_row)) * np.float32(f32(i_row)) == np.float32(f32(bits))
+
+    for eb in range(0, 255):                               # every exponent, both ends of the mantissa range
+        for mant in (0, 1, 0x400000, 0x7FFFFF):
+            check(eb, mant)
+
+    @settings(max_examples=300, deadline=None)
+    @given(st.integers(min_value=0, max_value=254), st.integers(min_value=0, max_value=0x7FFFFF))
+    def prop(eb, mant):
+        check(eb, mant)
+    prop()

@@ -383,20 +383,19 @@ def test_default_mode_eager_warm_up_then_capture(mols, monkeypatch):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        for _ in range(2):                                   # eager warm-up: up to 32 molecules the one-launch step at once; above,
-            step(model, opt)                                 # the first sight of a batch per operator, the one-launch step when it comes back
-        assert len(calls) == (2 if mols <= 32 else 1), calls
+        for _ in range(2):                                   # eager warm-up: up to 32 molecules the one-launch step; above, per operator
+            step(model, opt)                                 # on every visit (no ``resident`` mark on the batch: round 6)
+        assert len(calls) == (2 if mols <= 32 else 0), calls
         model.zero_grad(set_to_none=True)
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=side):               # captured: one launch up to 32 molecules, per operator above
             static_loss = step(model, opt)
     torch.cuda.current_stream().wait_stream(side)
-    assert len(calls) == (3 if mols <= 32 else 1), calls
+    assert len(calls) == (3 if mols <= 32 else 0), calls
     g.replay()
     torch.cuda.synchronize()
-    # the twin: the same three steps eagerly, each forced onto the path the model took (the batch's plan -- and with it the
-    # "seen before" mark -- is shared by the two models, so the twin's dispatch is pinned step by step)
-    for mode in (("1", "1") if mols <= 32 else ("0", "1")):
+    # the twin: the same three steps eagerly, each forced onto the path the model took
+    for mode in (("1", "1") if mols <= 32 else ("0", "0")):
         monkeypatch.setattr(M, "_MODE", mode)
         step(twin, opt_t)
     monkeypatch.setattr(M, "_MODE", "1" if mols <= 32 else "0")
@@ -437,3 +436,32 @@ def test_edge_batch_norm_buffers_move_in_the_one_launch_step(mols, monkeypatch):
     assert torch.allclose(bn.running_mean, ref.running_mean, atol=2e-6, rtol=1e-5)
     assert torch.allclose(bn.running_var, ref.running_var, atol=1e-5, rtol=2e-5)
     assert int(bn.num_batches_tracked) == 3 and int(model.gnn_model.node_batch_norm.num_batches_tracked) == 3
+
+
+def test_resident_mark_selects_the_one_launch_step_from_the_first_visit(monkeypatch):
+    """The eager dispatch above 32 molecules is a function of the batch alone: ``data.resident = True`` takes the
+    one-launch molecule step on EVERY visit, no mark takes the per-operator kernels on every visit -- the same kernels in epoch 1
+    and epoch 2 either way."""
+    dev = _dev()
+    from molkgnn_amd import molecule as M
+    from molkgnn_amd.synthetic import make_batch
+    from molkgnn_amd.train import GNNModel
+    from molkgnn_amd.train import backward as train_backward
+    monkeypatch.setattr(M, "_MODE", "")
+    torch.manual_seed(9)
+    model = GNNModel(ffn_dropout_rate=0.0).to(dev).train()
+    calls = []
+    orig = M._run
+    monkeypatch.setattr(M, "_run", lambda *a, **k: (calls.append(a[6]), orig(*a, **k))[1])
+    for resident, want in ((False, 0), (True, 3)):
+        b = make_batch(96, seed=77).to(dev)
+        b.num_graphs = 96
+        b.y = (torch.arange(96, device=dev) % 4 == 0).long()
+        if resident:
+            b.resident = True
+        calls.clear()
+        for _ in range(3):
+            model.zero_grad(set_to_none=True)
+            train_backward(model.loss(b))
+        torch.cuda.synchronize()
+        assert len(calls) == want, (resident, calls)
