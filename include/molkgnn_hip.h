@@ -377,7 +377,10 @@ int mkgnn_tail_fused(const mkgnn_tail_args* args, void* workspace, size_t worksp
  * num_batches_tracked (may be NULL): incremented when training != 0 (BatchNorm1d's counter).
  * n_valid_rows (device scalar, may be NULL): only rows [0, *n_valid_rows) enter the batch statistics; the rest of the
  * n_rows rows is padding (normalised like any row, excluded from every sum) -- a batch padded to a fixed shape so that
- * one captured graph serves every batch (molkgnn_amd.padding) keeps the statistics of its real atoms. */
+ * one captured graph serves every batch (molkgnn_amd.padding) keeps the statistics of its real atoms.
+ * training | MKGNN_BN_SPLIT_ROWS (ABI v6; with inv_norm): `out` is written PRE-SPLIT (MKGNN_VARIANT_ROWS_SPLIT above) for a caller
+ * whose only reader of it is the first mkgnn_kernelsetconv_forward / _backward. */
+#define MKGNN_BN_SPLIT_ROWS 2
 size_t mkgnn_batchnorm_workspace_bytes(int32_t C);
 int mkgnn_batchnorm_forward(const float* x, int64_t x_stride, int64_t n_rows, int32_t C,
                             const float* weight, const float* bias,

@@ -97,19 +97,33 @@ class MolKGNNNet(torch.nn.Module):
         if data.x.is_cuda and not save_score:
             # (the banks depend on the parameters only: their one launch runs beside the batch norm, on the side stream)
             self.gnn.prepare_banks_early(data.x, sum(int(getattr(data, f'nei_index_deg{d}').numel()) for d in range(1, 5)))
-        x = R.batch_norm(data.x, self.node_batch_norm, getattr(data, 'n_valid_atoms', None), companion=self._edge_stats(data))
-        if getattr(data, '_rf_ready', None) is not None:     # degree buckets still being built on the index stream
-            from .receptive_field import await_receptive_fields
-            await_receptive_fields(data)
         kw = {f'{nm}_deg{d}': getattr(data, f'{nm}_deg{d}')
               for nm in ('p_focal', 'nei_p', 'nei_edge_attr', 'selected_index', 'nei_index') for d in range(1, 5)}
         for d in range(1, 5):                          # unit bond rows built with the receptive fields (mkgnn_rf_fill), if any
             u = getattr(data, f'nei_edge_unit_deg{d}', None)
             if u is not None:
                 kw[f'nei_edge_unit_deg{d}'] = u
+        # the normalised features go nowhere but into the first kernel convolution: where that layer takes pre-split rows
+        # (functional.ROWS_SPLIT) the batch norm writes them so -- asked from shapes alone, nothing is launched or awaited
+        split_x = False
+        if data.x.is_cuda and not save_score:
+            from . import KernelLayer as _KL
+            if _KL._ROWS_SPLIT:
+                from .plan import plan_from_lists_cached
+                names = ('p_focal', 'nei_p', 'nei_edge_attr', 'selected_index', 'nei_index')
+                units = [kw.get(f'nei_edge_unit_deg{d}') for d in range(1, 5)]
+                plan0 = plan_from_lists_cached(data.x.shape[0], *[[kw[f'{nm}_deg{d}'] for d in range(1, 5)] for nm in names],
+                                               data.edge_index, units if any(u is not None for u in units) else None)
+                split_x = self.gnn.layers[0]._accepts_split_rows(plan0, data.x)
+        x = R.batch_norm(data.x, self.node_batch_norm, getattr(data, 'n_valid_atoms', None), companion=self._edge_stats(data),
+                         split_out=split_x)
+        if getattr(data, '_rf_ready', None) is not None:     # degree buckets still being built on the index stream
+            from .receptive_field import await_receptive_fields
+            await_receptive_fields(data)
         seg = None
         if getattr(data, 'mol_ptr', None) is not None and getattr(data, 'atom_mol', None) is not None:
-            seg = R.MoleculeSegments.from_tensors(data.mol_ptr, data.atom_mol)
+            seg = R.MoleculeSegments.from_tensors(data.mol_ptr, data.atom_mol, getattr(data, 'max_mol_atoms', None),
+                                                  getattr(data, 'max_mol_edges', None))
         # The last layer's output goes nowhere but through propagate into lin1: where it applies (large batches: it trades
         # two big passes for three small ones), the readout takes the last convolution's BLOCK ROWS and projects them
         # before the propagate step (readout.readout_blocks); MKGNN_PROJECT_FIRST=0 / 1 forces the choice (diagnostics)

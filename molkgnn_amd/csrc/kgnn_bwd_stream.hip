@@ -246,30 +246,33 @@ __device__ __forceinline__ void coef_prepare_body(const BankStreamArgs& a, const
             p2 = fmaf(gg * (w_e / w_sum), Ed[r] - sc, p2);
         }
     }
-    // fixed-order block sums; the records' largest exponents (a maximum: order-free)
+    // fixed-order block sums; the largest exponent of every KERNEL COLUMN of the records (a maximum: order-free).  Per column since
+    // round 6: with one exponent per record a column whose own dL/dsc are 2^-24 of a sibling's lost the lo halves
+    // of its coefficients in the bank kernel's split-fp16 products.  A thread is (atom tid >> 4, column tid & 15): the maximum
+    // over the four atoms of its wave by two xor steps, over the four waves through LDS.
     __shared__ float red[3][4];
-    __shared__ uint32_t emx[NEM][4];
+    __shared__ uint32_t emx[NEM][4][16];
     p0 = wave_sum(p0); p1 = wave_sum(p1); p2 = wave_sum(p2);
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1)
+    for (int o = 32; o >= 16; o >>= 1)
 #pragma unroll
         for (int i = 0; i < NEM; ++i)
             em[i] = __builtin_elementwise_max(em[i], __builtin_bit_cast(pk_u16, __shfl_xor(__builtin_bit_cast(uint32_t, em[i]), o, 64)));
-    if ((tid & 63) == 0) {
-        red[0][tid >> 6] = p0; red[1][tid >> 6] = p1; red[2][tid >> 6] = p2;
+    if ((tid & 63) == 0) { red[0][tid >> 6] = p0; red[1][tid >> 6] = p1; red[2][tid >> 6] = p2; }
+    if ((tid & 63) < 16) {
 #pragma unroll
-        for (int i = 0; i < NEM; ++i) emx[i][tid >> 6] = __builtin_bit_cast(uint32_t, em[i]);
+        for (int i = 0; i < NEM; ++i) emx[i][tid >> 6][tid & 15] = __builtin_bit_cast(uint32_t, em[i]);
     }
     __syncthreads();
     {
-        // idx words: the permutation id in the low byte, the record's largest exponent above it (what the bank kernel's
-        // split-fp16 products scale by: kgnn_split.h) -- every word of a record carries it, no reduction where it is read
+        // idx words: the permutation id in the low byte, the largest exponent of the word's own kernel column above it (what the
+        // bank kernel's split-fp16 products scale by: kgnn_split.h) -- every word of a column carries it, no reduction where it is read
         pk_u16 mx[NEM];
 #pragma unroll
         for (int i = 0; i < NEM; ++i) {
-            mx[i] = __builtin_bit_cast(pk_u16, emx[i][0]);
+            mx[i] = __builtin_bit_cast(pk_u16, emx[i][0][k]);
 #pragma unroll
-            for (int w = 1; w < 4; ++w) mx[i] = __builtin_elementwise_max(mx[i], __builtin_bit_cast(pk_u16, emx[i][w]));
+            for (int w = 1; w < 4; ++w) mx[i] = __builtin_elementwise_max(mx[i], __builtin_bit_cast(pk_u16, emx[i][w][k]));
         }
 #pragma unroll
         for (int r = 0; r < PREP_RPB; ++r) {
@@ -436,7 +439,9 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
 #pragma unroll
     for (int b = 0; b < NBS; ++b) accE[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    [[maybe_unused]] float G = __uint_as_float(230u << 23);      // (SP) 2^103: no coefficient seen yet
+    // (SP) the coefficients' power-of-two scale, one per KERNEL COLUMN since round 6: this lane's A operand is kernel ci's column,
+    // G is that column's scale (the same in the four lanes kq of a column: they read the same records in the same order)
+    [[maybe_unused]] float G = __uint_as_float(230u << 23);      // 2^103: no coefficient seen yet
     // (exponent of the larger weight, + 1 for the mantissas' product, re-biased: added to a record's largest exponent)
     [[maybe_unused]] const int wexp = (int)((__float_as_uint(fmaxf(fabsf(ws_n), fabsf(wc_n))) >> 23) & 0xffu) + 1 - 127;
 
@@ -488,17 +493,25 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
             if constexpr (SP) rec_exp = (__float_as_int(raw[4]) >> 8) & 0xff;     // (every idx word of the record carries it)
         }
         if constexpr (SP) {
-            // the wave's scale: never larger than what this tile's largest coefficient (times the weights) allows
+            // a column's scale: never larger than what this tile's largest coefficient of that column (times the weights) allows.
+            // The accumulators of kernel 4 kq + r sit in register element r of the lanes kq (all features ci): when some
+            // column's scale drops, every lane fetches the ratios of ITS four kernels from the lanes that hold them as columns
+            // (lane index = kernel) and rescales, exactly (powers of two) -- a few times per column and launch
             const float need = split_scale_for_exponent<BANK_COEF_EXP>(rec_exp + wexp);
-            if (need < G) {                              // (wave-uniform; a handful of times per launch)
-                const float ratio = need / G;            // both powers of two: exact
+            const float ratio_col = need < G ? need / G : 1.f;
+            if (__any(need < G)) {                       // (wave-uniform)
+                float rr[4];
 #pragma unroll
-                for (int t = 0; t < KC; ++t) {
-                    accC[t] *= ratio;
+                for (int r = 0; r < 4; ++r) rr[r] = __shfl(ratio_col, 4 * kq + r, 64);
 #pragma unroll
-                    for (int b = 0; b < NBS; ++b) acc[b][t] *= ratio;
-                }
-                G = need;
+                for (int t = 0; t < KC; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        accC[t][r] *= rr[r];
+#pragma unroll
+                        for (int b = 0; b < NBS; ++b) acc[b][t][r] *= rr[r];
+                    }
+                G = need < G ? need : G;
             }
         }
         MKGNN_BPHASE(0);
@@ -691,13 +704,18 @@ __device__ __forceinline__ void bank_stream_body(const BankStreamArgs& a, const 
 
     // ---- this wave's slice of its stream's partial slab: C layout col = feature 16 t + ci, row = kernel kq * 4 + r
     if constexpr (SP) {
-        const float ug = split_unscale_of<0>(G);         // 1 / G
+        const float ug_col = split_unscale_of<0>(G);     // 1 / G of this lane's column
+        float ug[4];
 #pragma unroll
-        for (int t = 0; t < KC; ++t) {
-            accC[t] *= ug;
+        for (int r = 0; r < 4; ++r) ug[r] = __shfl(ug_col, 4 * kq + r, 64);      // ... of the kernels whose rows this lane accumulates
 #pragma unroll
-            for (int b = 0; b < NBS; ++b) acc[b][t] *= ug;
-        }
+        for (int t = 0; t < KC; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                accC[t][r] *= ug[r];
+#pragma unroll
+                for (int b = 0; b < NBS; ++b) acc[b][t][r] *= ug[r];
+            }
     }
     float* const slab = dg.slab + (size_t)sg * bank_floats(D, L, F, a.E);
     const size_t o_sup = (size_t)L * F, o_edg = o_sup + (size_t)L * D * F;

@@ -22,6 +22,7 @@
 #include "kgnn_common.h"
 #include "kgnn_launch.h"
 #include "kgnn_philox.h"
+#include "kgnn_split.h"
 #include "../../include/molkgnn_hip.h"
 
 namespace mkgnn {
@@ -766,6 +767,7 @@ struct BnArgs {
     float* gx; int64_t gxs;
     float *gweight, *gbias;
     float* inv_out;                // forward: 1 / max(|out row|, eps) for the convolution that reads out next (17 <= C <= 32)
+    int split_out;                 // ... and the rows themselves written PRE-SPLIT for it (kgnn_split.h; MKGNN_BN_SPLIT_ROWS)
     int64_t* nbt;                  // forward, training: BatchNorm1d.num_batches_tracked, incremented
     const int64_t* nvalid;         // device scalar or null: only rows [0, *nvalid) enter the batch statistics (padded batches)
     BnSide side;                   // statistics-only companion (blocks gridDim.x - side.nblk .. of the same launches); nblk = 0: none
@@ -1263,11 +1265,12 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(BnArgs a, int CL) {
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = act ? fmaf(v[u][e] - mu4[e], sc4[e], sh4[e]) : 0.f;
-                if (ok && act) *(f32x4*)(a.out + (r0 + u * 32) * a.os + col) = o;
                 float ss = o[0] * o[0];
                 ss = fmaf(o[1], o[1], ss); ss = fmaf(o[2], o[2], ss); ss = fmaf(o[3], o[3], ss);
                 ss += __shfl_xor(ss, 4, 64); ss += __shfl_xor(ss, 2, 64); ss += __shfl_xor(ss, 1, 64);
-                if (ok && l == 0) a.inv_out[r0 + u * 32] = 1.f / fmaxf(sqrtf(ss), MKGNN_EPS);
+                const float inv = 1.f / fmaxf(sqrtf(ss), MKGNN_EPS);      // (every lane of the row holds the sum)
+                if (ok && l == 0) a.inv_out[r0 + u * 32] = inv;
+                if (ok && act) *(f32x4*)(a.out + (r0 + u * 32) * a.os + col) = a.split_out ? split_row_store(o, inv) : o;
             }
         }
     } else if (c < a.C) {
@@ -2032,7 +2035,7 @@ static TailWs tail_ws(const ReadoutDims& d, int64_t n_atoms, int64_t n_mols) {
     w.dz = up(w.z + (size_t)n_atoms * 32 * 4);
     w.slab_atoms = up(w.dz + (size_t)n_atoms * 32 * 4);
     w.slab_tail = up(w.slab_atoms + (size_t)2 * RO_ATOM_BLOCKS * w.slab_atoms_stride * 4);
-    w.total = up(w.slab_tail + (size_t)tail_middle_blocks(n_mols) * TAIL_SLAB * 4);
+    w.total = up(w.slab_tail + (size_t)tail_middle_blocks(n_mols) * TAIL_SLAB * 4);      // (n_loss_mols <= n_mols: an upper bound)
     return w;
 }
 
@@ -2093,7 +2096,7 @@ int mkgnn_tail_fused(const mkgnn_tail_args* p, void* ws, size_t ws_bytes, void* 
     m.H = ro->H; m.G = ro->G; m.drop_p = p->dropout_p; m.rng = p->rng_state;
     m.emb = p->emb; m.es = p->emb_stride; m.pred = p->pred;
     m.slab = (float*)((char*)ws + w.slab_tail); m.slab_stride = TAIL_SLAB;
-    const int nbm = tail_middle_blocks(p->n_mols);
+    const int nbm = tail_middle_blocks(p->n_loss_mols);
     e = launch_tail_middle(m, nbm, st);
     if (e != hipSuccess) return api_hip_fail(who, e);
     // (3) d sim[block] = W1[:, block]^T d z,  dW1 partials   (as mkgnn_readout_blocks_backward)
@@ -2216,6 +2219,9 @@ int mkgnn_batchnorm_forward_with_stats(const float* x, int64_t x_stride, int64_t
                             const mkgnn_bn_stats* companion, void* companion_ws, size_t companion_ws_bytes, void* stream) {
     int CL;
     if (int rc = bn_common("mkgnn_batchnorm_forward", n_rows, C, CL)) return rc;
+    const bool split_rows = (training & MKGNN_BN_SPLIT_ROWS) != 0;       // out is written pre-split (kgnn_split.h)
+    training &= 1;
+    if (split_rows && !inv_norm) return api_fail("mkgnn_batchnorm_forward: MKGNN_BN_SPLIT_ROWS needs inv_norm");
     if (companion && !training) return api_fail("mkgnn_batchnorm_forward: a statistics companion needs training mode (nothing moves in eval mode)");
     if (!x || !out || x_stride < C || out_stride < C) return api_fail("mkgnn_batchnorm_forward: bad x/out");
     if (training && (!save_mean || !save_invstd)) return api_fail("mkgnn_batchnorm_forward: save_mean/save_invstd is null");
@@ -2228,7 +2234,7 @@ int mkgnn_batchnorm_forward_with_stats(const float* x, int64_t x_stride, int64_t
     a.out = out; a.os = out_stride; a.save_mean = save_mean; a.save_invstd = save_invstd;
     if (inv_norm && (C > 32 || C % 4 || x_stride % 4 || out_stride % 4 || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)))
         return api_fail("mkgnn_batchnorm_forward: inv_norm needs C <= 32, a multiple of 4, and 16-byte aligned rows of x and out (C=%d)", C);
-    a.inv_out = inv_norm; a.nbt = num_batches_tracked; a.nvalid = n_valid_rows;
+    a.inv_out = inv_norm; a.split_out = split_rows ? 1 : 0; a.nbt = num_batches_tracked; a.nvalid = n_valid_rows;
     a.part1 = (float*)ws; a.part2 = a.part1 ? a.part1 + (size_t)BN_BLOCKS * C : nullptr;
     static_assert(BN_BLOCKS == BN_MAIN_BLOCKS, "the companion's blocks sit behind the batch norm's own");
     bool side_single = false;

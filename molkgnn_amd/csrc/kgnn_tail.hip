@@ -41,6 +41,7 @@ namespace tail {
 
 constexpr int NT = 256;                 // threads per workgroup: 8 row slots x 32 hidden lanes
 constexpr int AC = MKGNN_TAIL_MAX_ATOMS, EC = MKGNN_TAIL_MAX_EDGES, MC = 12;      // chunk capacity: atoms, edges (each way), molecules
+constexpr int MG = 8;                   // molecules per group (the unit of work distribution: two chunks of ~100 atoms)
 constexpr int HP = 36;                  // LDS pitch of the 32-wide rows: 16-byte aligned rows, 4 banks apart
 constexpr int WP = 33;                  // ... of W2's rows (read one float per lane: odd, conflict-free)
 typedef mkgnn_f32x4 f32x4;
@@ -144,10 +145,15 @@ __global__ void __launch_bounds__(NT, 3) tail_middle_kernel(TailMidArgs a) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) { const int i = t + NT * u; if (i < G * H) { const int r = i / H, c = i - r * H; W2s[r * WP + c] = w2r[u]; } }
 
-    // this workgroup's molecules: an equal share of a contiguous run
-    const int64_t per = (a.n_mols + gridDim.x - 1) / gridDim.x;
-    int64_t m_next = per * blockIdx.x;
-    const int64_t m_hi = m_next + per < a.n_mols ? m_next + per : a.n_mols;
+    // this workgroup's molecules: GROUPS of MG consecutive molecules, group g to workgroup g mod gridDim.x -- and gridDim.x a
+    // function of n_loss alone (tail_middle_blocks): which molecules share a workgroup, a chunk and a slab does not depend on
+    // how many padding molecules follow the real ones, so a batch padded to a fixed shape (molkgnn_amd.padding) gives bit for
+    // bit the loss and the gradients of the unpadded batch (the padding molecules add exact zeros)
+    const int64_t n_groups = (a.n_mols + MG - 1) / MG;
+    int64_t grp = blockIdx.x;
+    int64_t m_next = grp * MG;
+    int64_t m_hi = m_next + MG < a.n_mols ? m_next + MG : a.n_mols;
+    if (grp >= n_groups) m_next = m_hi = 0;
 
     float accW2[4] = {0.f, 0.f, 0.f, 0.f};               // dW2[i][k], element t + 256 u of the [32][32] image: summed per chunk from the
                                                          // molecules' (d emb, e) pairs kept in LDS (32 accumulators per thread cost 60 VGPRs)
@@ -156,7 +162,13 @@ __global__ void __launch_bounds__(NT, 3) tail_middle_kernel(TailMidArgs a) {
 
     __syncthreads();
     TAIL_PHASE(0);                                       // prologue
-    while (m_next < m_hi) {
+    while (true) {
+        if (m_next >= m_hi) {                            // (block-uniform) this group is done: the next one of this workgroup
+            grp += gridDim.x;
+            if (grp >= n_groups) break;
+            m_next = grp * MG;
+            m_hi = m_next + MG < a.n_mols ? m_next + MG : a.n_mols;
+        }
         const int64_t m0 = m_next;
         // ---- the window: first atom and first edges of the next MC + 1 molecules (two dependent loads for all of them)
         if (t <= MC) {
@@ -383,9 +395,9 @@ __global__ void __launch_bounds__(NT, 3) tail_middle_kernel(TailMidArgs a) {
 
 }  // namespace tail
 
-int tail_middle_blocks(int64_t n_mols) {
-    int64_t nb = (n_mols + 7) / 8;                       // ~8 molecules (two chunks) per workgroup, two or three workgroups per CU;
-    if (nb > 512) nb = 512;                              // no more slabs than the reduction reads in a few batches
+int tail_middle_blocks(int64_t n_loss_mols) {
+    int64_t nb = (n_loss_mols + tail::MG - 1) / tail::MG;      // one group of real molecules per workgroup (padding molecules' groups wrap around),
+    if (nb > 512) nb = 512;                                    // and no more slabs than the reduction reads in a few batches
     return (int)(nb < 1 ? 1 : nb);
 }
 

@@ -86,6 +86,11 @@ def pad_batch(batch: GraphBatch, shape: Dict[str, int], num_molecules: int) -> G
     out.mol_ptr, out.atom_mol = ptr, out.batch.to(torch.int32)
     out.n_valid_atoms = torch.tensor([n_real], dtype=torch.int64, device=dev)
     out.n_valid_molecules, out.num_graphs = num_molecules, num_molecules + PAD_MOLECULES
+    # the largest molecule of THIS batch, padding molecules included (atoms; directed edges leaving / entering it): what a
+    # consumer that works molecule by molecule in on-chip memory -- readout.tail_loss -- has to know before it launches
+    eb = out.batch[out.edge_index]
+    out.max_mol_atoms = int(counts.max())
+    out.max_mol_edges = int(max(torch.bincount(eb[0], minlength=1).max(), torch.bincount(eb[1], minlength=1).max()))
     out.bucket_sizes = [shape["n1"], shape["n2"], shape["n3"], shape["n4"]]
     assert out.x.shape[0] == shape["atoms"] and out.edge_index.shape[1] == shape["edges"]
     return out
@@ -132,10 +137,22 @@ class StaticBatch:
             setattr(self.data, k, view)
         self.data.n_valid_molecules, self.data.num_graphs = first.n_valid_molecules, first.num_graphs
         self.data.bucket_sizes = list(first.bucket_sizes)
+        # the molecule-size bound the consumer was shown (and a graph captured on these buffers was built for): later batches may
+        # not exceed the limits the first one stayed inside (load)
+        self.data.max_mol_atoms = getattr(first, "max_mol_atoms", None)
+        self.data.max_mol_edges = getattr(first, "max_mol_edges", None)
 
     def load(self, padded: GraphBatch) -> None:
         if list(padded.bucket_sizes) != self.data.bucket_sizes or padded.n_valid_molecules != self.data.n_valid_molecules:
             raise ValueError("batch shape differs from the static buffers'")
+        from . import _lib
+        for key, lim in (("max_mol_atoms", _lib.TAIL_MAX_ATOMS), ("max_mol_edges", _lib.TAIL_MAX_EDGES)):
+            had, now = getattr(self.data, key, None), getattr(padded, key, None)
+            if had is not None and had <= lim and (now is None or now > lim):
+                raise ValueError(f"{key} = {now}: the first batch of these buffers stayed within {lim} (a step captured on them may "
+                                 "run the fused tail, readout.tail_loss, which takes no larger molecule); set MKGNN_FUSED_TAIL=0")
+            if had is not None and now is not None:
+                setattr(self.data, key, max(had, now))
         flat = getattr(padded, "flat", None)
         if flat is not None and flat.numel() == self.flat.numel():
             self.flat.copy_(flat, non_blocking=True)

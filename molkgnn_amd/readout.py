@@ -31,15 +31,23 @@ class MoleculeSegments:
     """``batch`` (atom -> molecule id) as contiguous segments: ``mol_ptr [B+1]``, ``atom_mol [N]`` (int32)."""
 
     @classmethod
-    def from_tensors(cls, mol_ptr: torch.Tensor, atom_mol: torch.Tensor) -> "MoleculeSegments":
+    def from_tensors(cls, mol_ptr: torch.Tensor, atom_mol: torch.Tensor, max_atoms: Optional[int] = None,
+                     max_edges: Optional[int] = None) -> "MoleculeSegments":
         """Segments handed over by the loader (int32, on the GPU, atoms of a molecule contiguous): no derivation, no
-        host synchronisation; the tensors may be refilled in place between replays of a captured step."""
+        host synchronisation; the tensors may be refilled in place between replays of a captured step.  ``max_atoms`` /
+        ``max_edges``: the loader's bound on a molecule's atoms / directed edges for EVERY batch these tensors will hold
+        (``padding.pad_batch`` knows them) -- without it the fused tail (``tail_loss``), which needs the bound, is not taken:
+        the contents cannot be inspected without a host synchronisation, and must not decide differently in an eager step
+        and in a captured one."""
         if mol_ptr.dtype != torch.int32 or atom_mol.dtype != torch.int32:
             raise TypeError("mol_ptr and atom_mol must be int32")
         seg = cls.__new__(cls)
         seg.size = int(mol_ptr.numel()) - 1
         seg.sorted = True
         seg.mol_ptr, seg.atom_mol = mol_ptr, atom_mol
+        seg.from_loader = True
+        seg.max_atoms = None if max_atoms is None else int(max_atoms)
+        seg.max_edges = None if max_edges is None else int(max_edges)
         return seg
 
     def __init__(self, batch: torch.Tensor, size: int):
@@ -280,7 +288,7 @@ def readout(h: torch.Tensor, lin1: torch.nn.Linear, lin2: torch.nn.Linear, dropo
 # ------------------------------------------------------------------------------------------ batch norm --
 class _BatchNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, bn: torch.nn.BatchNorm1d, use_batch_stats: bool, n_valid=None, companion=None):
+    def forward(ctx, x, weight, bias, bn: torch.nn.BatchNorm1d, use_batch_stats: bool, n_valid=None, companion=None, split_out=False):
         lib = _lib.load()
         ctx.n_valid = n_valid
         x = _row_major(x if x.dtype == torch.float32 else x.float())
@@ -308,13 +316,15 @@ class _BatchNormFn(torch.autograd.Function):
                 cws = torch.empty(cws_bytes, dtype=torch.uint8, device=dev)
             _lib.check(lib.mkgnn_batchnorm_forward_with_stats(
                 x.data_ptr(), _stride0(x), n, C, _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(rm), _lib.ptr(rv),
-                float(bn.momentum if bn.momentum is not None else 0.0), float(bn.eps), int(use_batch_stats),
+                float(bn.momentum if bn.momentum is not None else 0.0), float(bn.eps),
+                int(use_batch_stats) | (2 if (split_out and inv is not None) else 0),       # (MKGNN_BN_SPLIT_ROWS)
                 out.data_ptr(), C, save_mean.data_ptr(), save_invstd.data_ptr(), _lib.ptr(inv), _lib.ptr(nbt),
                 _lib.ptr(n_valid), ws.data_ptr(), ws_bytes, None if st is None else ctypes.byref(st), _lib.ptr(cws), cws_bytes,
                 _lib.stream_ptr(dev)), "mkgnn_batchnorm_forward_with_stats")
             del keep
         ctx.use_batch_stats = use_batch_stats
         ctx.save_for_backward(x, weight, save_mean, save_invstd)
+        ctx.wrote_split = bool(split_out and inv is not None)
         if inv is None:
             inv = torch.empty(0, dtype=torch.float32, device=dev)
         ctx.mark_non_differentiable(inv)
@@ -325,7 +335,7 @@ class _BatchNormFn(torch.autograd.Function):
     def backward(ctx, grad_out, _g_inv=None):
         lib = _lib.load()
         if grad_out is None:
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         x, weight, save_mean, save_invstd = ctx.saved_tensors
         n, C = x.shape
         dev = x.device
@@ -340,7 +350,7 @@ class _BatchNormFn(torch.autograd.Function):
                 g.data_ptr(), _stride0(g), x.data_ptr(), _stride0(x), n, C, _lib.ptr(weight), save_mean.data_ptr(),
                 save_invstd.data_ptr(), int(ctx.use_batch_stats), _lib.ptr(gx), C, _lib.ptr(gw), _lib.ptr(gb),
                 _lib.ptr(ctx.n_valid), ws.data_ptr(), ws_bytes, _lib.stream_ptr(dev)), "mkgnn_batchnorm_backward")
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
 def _stats_supported(x: torch.Tensor, bn: torch.nn.BatchNorm1d) -> bool:
@@ -393,12 +403,15 @@ def update_running_stats(x: torch.Tensor, bn: torch.nn.BatchNorm1d, key: Optiona
 
 
 def batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm1d, n_valid: Optional[torch.Tensor] = None,
-               companion=None) -> torch.Tensor:
+               companion=None, split_out: bool = False) -> torch.Tensor:
     """``bn(x)`` for a 2-D input on the GPU, with ``torch.nn.BatchNorm1d``'s semantics (batch statistics in
     training mode or when no running statistics are tracked; running statistics updated in place).
 
     ``companion`` = ``(x2, bn2, key, key_limit)``: ``update_running_stats(x2, bn2, key, key_limit)`` done by extra blocks of
     this batch norm's own launches (training mode).
+
+    ``split_out`` (round 6): write the result as pre-split rows (``functional.ROWS_SPLIT``) where the kernels can (<= 32 channels,
+    a multiple of 4, 16-byte rows) -- for a caller whose only reader of it is a kernel convolution that takes them.
 
     ``n_valid`` (a one-element int64 CUDA tensor): only the leading ``n_valid`` rows enter the batch statistics; the
     remaining rows are padding (``molkgnn_amd.padding``) -- normalised with the same statistics, excluded from every sum.
@@ -424,10 +437,14 @@ def batch_norm(x: torch.Tensor, bn: torch.nn.BatchNorm1d, n_valid: Optional[torc
         return bn(x)
     if use_batch_stats and bn.training and x.shape[0] == 1:
         raise ValueError(f"Expected more than 1 value per channel when training, got input size {tuple(x.shape)}")
-    out, inv = _BatchNormFn.apply(x, bn.weight, bn.bias, bn, use_batch_stats, n_valid, companion)
+    out, inv = _BatchNormFn.apply(x, bn.weight, bn.bias, bn, use_batch_stats, n_valid, companion, split_out)
     if inv.numel():
-        from .functional import _INV_ATTR
+        from .functional import _INV_ATTR, mark_rows_split
         setattr(out, _INV_ATTR, (inv, out._version))
+        if split_out:
+            # (``split_out``: the caller's promise that nothing but the first kernel convolution reads the result -- its rows are
+            # the fp16 hi | lo halves that convolution's matrix instructions take, functional.ROWS_SPLIT)
+            mark_rows_split(out)
     return out
 
 
@@ -611,8 +628,8 @@ def _tail_limits_ok(seg: "MoleculeSegments", plan) -> bool:
     batch is answered with False: the separate operators take it."""
     ma, me = getattr(seg, "max_atoms", None), getattr(seg, "max_edges", None)
     if ma is None or me is None:
-        if torch.cuda.is_current_stream_capturing():
-            return False
+        if getattr(seg, "from_loader", False) or torch.cuda.is_current_stream_capturing():
+            return False                                  # (refillable tensors without a loader's bound: never -- eager or captured)
         ptr = seg.mol_ptr.long()
         sizes = ptr[1:] - ptr[:-1]
         rin, rout = plan.csr_in[0].long(), plan.csr_out[0].long()

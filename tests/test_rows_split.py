@@ -198,3 +198,54 @@ def test_network_with_and_without_presplit_rows(training, monkeypatch):
     assert set(g0) == set(g1)
     for n in g0:
         assert float((g0[n] - g1[n]).abs().max()) <= 2e-5 * max(float(g0[n].abs().max()), 1e-6), n
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_batch_norm_writes_presplit_rows_for_the_first_layer(training):
+    """readout.batch_norm(split_out=True): the normalised features as pre-split rows (28 channels: the two-chunk kernels, whose
+    bank gradient reads the swizzled slot image).  Against the fp32 rows of the same batch norm: rows decode to 2^-22, the same
+    row norms, the first layer's forward bit for bit, its bank gradients bit for bit, the batch norm's own gradients to rounding."""
+    from molkgnn_amd import functional as Fn
+    from molkgnn_amd import readout as R
+    dev, b, plan, first, _, _ = _setup(28, dup=0.0)
+    p1, E = first._bank_params("train", b.x)
+    assert Fn.rows_split_supported(plan, p1, 28, E, plan.n_atoms)
+    torch.manual_seed(2)
+    bn = torch.nn.BatchNorm1d(28).to(dev).train(training)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.uniform_(-0.2, 0.2); bn.running_var.uniform_(0.5, 2.0)
+    state = {k: v.clone() for k, v in bn.state_dict().items()}
+    raw = (torch.randn(b.x.shape[0], 28, device=dev) * 1.7 + 0.3)
+    cot = torch.randn(b.x.shape[0], 110, device=dev)
+
+    def run(split):
+        bn.load_state_dict(state)
+        for p in list(p1) + list(bn.parameters()):
+            p.grad = None
+        xin = raw.detach().clone().requires_grad_(True)
+        x = R.batch_norm(xin, bn, split_out=split)
+        assert Fn.is_rows_split(x) == split
+        inv = getattr(x, Fn._INV_ATTR)[0]
+        out = Fn.kernelsetconv(x, plan, False, p1, E, "auto", block_rows=True, propagate=True)
+        (out * cot).sum().backward()
+        torch.cuda.synchronize()
+        return (x.detach().clone(), inv.clone(), out.detach().clone(), xin.grad.clone(), [None if p.grad is None else p.grad.clone() for p in p1],
+                [p.grad.clone() for p in bn.parameters()], {k: v.clone() for k, v in bn.state_dict().items()})
+
+    x0, i0, o0, gx0, g0, gb0, s0 = run(False)
+    x1, i1, o1, gx1, g1, gb1, s1 = run(True)
+    assert torch.equal(i0, i1) and torch.equal(o0, o1)
+    back = _decode(x1, i1, 28)
+    e = (i1.view(torch.int32) >> 23) & 0xFF
+    scale = torch.exp2((e - 127 + 8).float())[:, None]
+    assert bool(((back - x0).abs() * scale <= 2.0 ** -22 * x0.abs() * scale + 2.0 ** -25).all())
+    for a, c in zip(g0, g1):
+        assert (a is None) == (c is None)
+        if a is not None:
+            assert torch.equal(a, c)
+    assert float((gx0 - gx1).abs().max()) <= 2e-6 * float(gx0.abs().max())
+    for a, c in zip(gb0, gb1):
+        assert float((a - c).abs().max()) <= 2e-5 * max(float(a.abs().max()), 1e-6)
+    for k in s0:
+        assert torch.equal(s0[k], s1[k]), k

@@ -182,3 +182,47 @@ def test_oversize_molecule_is_refused_by_the_host_and_loud_in_the_kernel():
     seg_ok = R.molecule_segments(b.batch, 40)
     loss = R.tail_loss(sim0.detach().requires_grad_(True), plan, Ls, lin1, lin2, ffn, torch.zeros(40, device=dev), seg_ok, 0.0, None)
     assert torch.isfinite(loss)
+
+
+def test_fused_tail_is_padding_invariant():
+    """A batch padded to a fixed shape (padding.pad_batch: 64 padding molecules behind the real ones, outside the loss) through
+    GNNModel.loss with the fused tail: the loss is BIT FOR BIT the unpadded batch's -- molecules are dealt to workgroups in groups
+    whose composition depends on the number of real molecules only, and the padding molecules add exact zeros -- and every
+    gradient agrees to rounding (the padded degree buckets are cut into tiles differently)."""
+    from molkgnn_amd import padding as P
+    from molkgnn_amd import readout as R
+    from molkgnn_amd.receptive_field import attach_receptive_fields
+    from molkgnn_amd.synthetic import make_batch
+    from molkgnn_amd.train import GNNModel
+    dev = _dev()
+    torch.manual_seed(3)
+    model = GNNModel(ffn_dropout_rate=0.0).to(dev).train()
+    B = 700
+    raw = make_batch(B, seed=4100, with_receptive_fields=False)
+    raw.y = (torch.arange(B) % 5 == 0).long()
+    other = make_batch(B, seed=4101, with_receptive_fields=False)
+    shape = P.fixed_shape([P.degree_histogram(raw), P.degree_histogram(other)])
+    calls = []
+    real = R.tail_loss
+
+    def spy(*a, **k):
+        calls.append(1)
+        return real(*a, **k)
+    R.tail_loss = spy
+    try:
+        res = []
+        for batch in (attach_receptive_fields(raw.to(dev)),
+                      attach_receptive_fields(P.pad_batch(raw, shape, B).to(dev), sizes=[shape[f"n{d}"] for d in range(1, 5)])):
+            state = {k: v.clone() for k, v in model.state_dict().items()}
+            model.zero_grad(set_to_none=True)
+            loss = model.loss(batch)
+            loss.backward()
+            torch.cuda.synchronize()
+            model.load_state_dict(state)
+            res.append((loss.detach().clone(), {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}))
+    finally:
+        R.tail_loss = real
+    assert len(calls) == 2                                # both through the fused tail (pad_batch hands the molecule bound over)
+    assert torch.equal(res[0][0], res[1][0]), (float(res[0][0]), float(res[1][0]))
+    for n, g in res[0][1].items():
+        assert float((g - res[1][1][n]).abs().max()) <= 2e-5 * max(float(g.abs().max()), 1e-3) + 1e-7, n
