@@ -140,6 +140,10 @@ size_t mkgnn_workspace_bytes(const int32_t num_kernels[MKGNN_MAX_DEGREE], int32_
  *              exist only between two calls of this library (the reference's h = propagate(sim_sc), KernelLayer.py:119-123,
  *              kernels.py:527,543).  Needs mkgnn_rows_split_supported(..) == 1; fails otherwise. */
 #define MKGNN_VARIANT_ROWS_SPLIT 0x400
+/* Rows from OUTSIDE the library in that form (benchmarks, tests; a training step's rows come pre-split from their producers):
+ * inv_norm[n] = 1 / max(|x[n]|, 1e-8) exactly as mkgnn_row_inv_norm, out[n] = the pre-split row.  16-byte aligned rows, F <= 256. */
+int mkgnn_rows_presplit(const float* x, int64_t x_stride, int64_t n_rows, int32_t F, float* inv_norm, float* out,
+                        int64_t out_stride, void* stream);
 /* The parameter-only part of `count` (<= 4 per call) forward calls -- unit-normalised kernel rows in the layouts the
  * kernels read, their norms, the chirality sign tables, the mixing weights: reference kernels.py:189, 279-350,
  * 386-395 -- in ONE launch: call k has banks[4 k .. 4 k + 3], feature width F[k], and gets the head of workspaces[k]

@@ -137,7 +137,7 @@ EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn
            "mkgnn_readout_blocks_workspace_bytes", "mkgnn_molecule_supported", "mkgnn_molecule_workspace_bytes",
            "mkgnn_molecule_step", "mkgnn_batchnorm_stats_workspace_bytes", "mkgnn_batchnorm_update_stats",
            "mkgnn_batchnorm_forward_with_stats", "mkgnn_index_workspace_bytes", "mkgnn_index_build",
-           "mkgnn_rows_split_supported", "mkgnn_tail_supported", "mkgnn_tail_workspace_bytes", "mkgnn_tail_fused")
+           "mkgnn_rows_split_supported", "mkgnn_rows_presplit", "mkgnn_tail_supported", "mkgnn_tail_workspace_bytes", "mkgnn_tail_fused")
 
 _lib: Optional[C.CDLL] = None
 TORCH_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libmolkgnn_torch.so")
@@ -201,6 +201,8 @@ def load() -> C.CDLL:
     lib.mkgnn_tail_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64]
     lib.mkgnn_tail_fused.restype = C.c_int
     lib.mkgnn_tail_fused.argtypes = [C.POINTER(TailArgs), C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.mkgnn_rows_presplit.restype = C.c_int
+    lib.mkgnn_rows_presplit.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mkgnn_rows_split_supported.restype = C.c_int
     lib.mkgnn_rows_split_supported.argtypes = [Banks4, Buckets4, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32]
     lib.mkgnn_bank_prepare.restype = C.c_int

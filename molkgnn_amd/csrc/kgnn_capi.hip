@@ -302,6 +302,17 @@ int mkgnn_row_inv_norm(const float* x, int64_t x_stride, int64_t n_rows, int32_t
     return e == hipSuccess ? 0 : hip_fail("mkgnn_row_inv_norm", e);
 }
 
+int mkgnn_rows_presplit(const float* x, int64_t x_stride, int64_t n_rows, int32_t F, float* inv_norm, float* out, int64_t out_stride,
+                        void* stream) {
+    if (n_rows < 0 || F <= 0 || x_stride < F || out_stride < F) return fail("mkgnn_rows_presplit: bad shape");
+    if (n_rows == 0) return 0;
+    if (!x || !inv_norm || !out) return fail("mkgnn_rows_presplit: null pointer");
+    hipError_t e = hipSuccess;
+    if (!try_rows_presplit(x, x_stride, n_rows, F, inv_norm, out, out_stride, (hipStream_t)stream, &e))
+        return fail("mkgnn_rows_presplit: rows of at most 256 floats, 16-byte aligned (strides multiples of 4 floats)");
+    return e == hipSuccess ? 0 : hip_fail("mkgnn_rows_presplit", e);
+}
+
 int mkgnn_unit_rows8(const float* in, int64_t n_rows, int32_t E, float* out, void* stream) {
     if (n_rows < 0 || E < 1 || E > 8) return fail("mkgnn_unit_rows8: %lld rows of width %d (1..8)", (long long)n_rows, E);
     if (n_rows && (!in || !out)) return fail("mkgnn_unit_rows8: null pointer");

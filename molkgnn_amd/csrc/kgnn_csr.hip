@@ -304,6 +304,32 @@ __global__ void __launch_bounds__(256) row_inv_norm_aligned_kernel(const float* 
     }
 }
 
+// 1 / max(|x[i]|, eps) AND the row itself rewritten as pre-split rows (kgnn_split.h): what a producer inside the library does in
+// its own epilogue (csr_rows_kernel, bn_apply_kernel), for rows that come from outside -- benchmarks and tests that feed the
+// streamed kernels the operand form the training step feeds them (mkgnn_rows_presplit).  Same lanes, same sums as above.
+template <int LPR>
+__global__ void __launch_bounds__(256) row_presplit_kernel(const float* __restrict__ x, int64_t xs, int64_t n, int width,
+                                                           float* __restrict__ inv, float* __restrict__ out, int64_t os) {
+    constexpr int RPW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int sub = lane / LPR, l = lane % LPR, col = 4 * l;
+    const bool active = col < width;
+    const int64_t wave0 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int64_t ngroups = (n + RPW - 1) / RPW;
+    for (int64_t g = wave0; g < ngroups; g += nwaves) {
+        const int64_t j = g * RPW + sub;
+        const int64_t jc = j < n ? j : n - 1;
+        const f32x4 m = mask_cols(*(const f32x4*)(x + jc * xs + (active ? col : 0)), active ? col : width, width);
+        float ss = m[0] * m[0];
+        ss = fmaf(m[1], m[1], ss); ss = fmaf(m[2], m[2], ss); ss = fmaf(m[3], m[3], ss);
+        ss = group_sum<LPR>(ss);
+        const float iv = 1.f / fmaxf(sqrtf(ss), MKGNN_EPS);
+        if (j < n && l == 0) inv[j] = iv;
+        if (j < n && active) *(f32x4*)(out + j * os + col) = split_row_store(m, iv);
+    }
+}
+
 static inline int csr_grid(int64_t n, int rpw) {
     int64_t groups = (n + rpw - 1) / rpw;
     int64_t blocks = (groups + 3) / 4;
@@ -318,6 +344,23 @@ static inline int lanes_per_row(int width) { return width <= 32 ? 8 : width <= 6
 
 bool aligned_rows(const void* p, int64_t stride, int width) {
     return ((uintptr_t)p & 15) == 0 && stride % 4 == 0 && stride >= (width + 3) / 4 * 4;
+}
+
+bool try_rows_presplit(const float* x, int64_t xs, int64_t n, int width, float* inv, float* out, int64_t os, hipStream_t st, hipError_t* err) {
+    if (n == 0 || width > 256 || !aligned_rows(x, xs, width) || !aligned_rows(out, os, width)) return false;
+    const int lpr = lanes_per_row(width);
+    const int64_t groups = (n + 64 / lpr - 1) / (64 / lpr);
+    int64_t blocks = (groups + 3) / 4;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    switch (lpr) {
+        case 8: row_presplit_kernel<8><<<(int)blocks, 256, 0, st>>>(x, xs, n, width, inv, out, os); break;
+        case 16: row_presplit_kernel<16><<<(int)blocks, 256, 0, st>>>(x, xs, n, width, inv, out, os); break;
+        case 32: row_presplit_kernel<32><<<(int)blocks, 256, 0, st>>>(x, xs, n, width, inv, out, os); break;
+        default: row_presplit_kernel<64><<<(int)blocks, 256, 0, st>>>(x, xs, n, width, inv, out, os); break;
+    }
+    *err = hipGetLastError();
+    return true;
 }
 
 static int csr_fixed4() {

@@ -196,6 +196,7 @@ bool try_segment_sum_aligned(const float* in, int64_t is, const int32_t* rowptr,
 bool try_backward_gather_aligned(const float* contrib, int64_t cs, const int32_t* rowptr, const int32_t* rows, const float* x,
                                  int64_t xs, const float* inv, int64_t n, int F, float* gx, int64_t gxs, hipStream_t st,
                                  hipError_t* err, bool x_split = false);
+bool try_rows_presplit(const float* x, int64_t xs, int64_t n, int width, float* inv, float* out, int64_t os, hipStream_t st, hipError_t* err);
 bool try_row_inv_norm_aligned(const float* x, int64_t xs, int64_t n, int width, float* inv, hipStream_t st, hipError_t* err);
 hipError_t launch_segment_sum(const float* in, int64_t is, const int32_t* rowptr, const int32_t* col, int64_t n,
                               int width, float* out, int64_t os, float* inv_norm, hipStream_t st);

@@ -1204,11 +1204,33 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(BnArgs a, int CL) {
     bn_block_stats<VEC>(a, CL, sh);
 }
 
-__global__ void __launch_bounds__(256) bn_apply_kernel(BnArgs a, int CL) {
-    __shared__ float sh[1024];
+// Round 6, second step: ONE launch for the training forward, one for the backward -- statistics | grid-wide barrier | apply.  The
+// two phases need every block's partial sums, which until now meant a kernel boundary (~5 us in a captured graph on this chip,
+// for kernels that take 14 and 17).  All blocks of these launches are resident at once (at most 256 + 54 blocks of 256 threads and
+// a few KB of LDS on 256 CUs), so a counter in device memory does: a block's thread 0 releases its partials (__threadfence),
+// adds 1, spins until the count is the grid's size, acquires; the last block to LEAVE resets the counters.  The spin is bounded: a
+// grid that is not resident within ~a second falls through (its output is then wrong, but it ends).
+// MEASURED (batch 4096, profiles/r06 notes in DESIGN 4.4): 47 us for the fused forward against 14 + 17 for the two launches, the step
+// 0.723 against 0.708 ms -- the agent-scope release / acquire around the counter writes back and invalidates the L2 of every XCD (the
+// apply phase then re-reads from memory the rows the statistics phase had just pulled in), and 310 waves polling one counter across
+// eight XCDs are slow to see it move.  Correct (the 56 batch-norm / network tests pass with it on), not faster: opt-in only,
+// MKGNN_BN_ONE_LAUNCH=1.
+__device__ unsigned g_bn_barrier[8];                   // {arrived, left} of the forward launch, of the backward launch
+__device__ __forceinline__ void bn_grid_barrier(unsigned* ctr) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        atomicAdd(&ctr[0], 1u);
+        for (unsigned spins = 0; atomicAdd(&ctr[0], 0u) < gridDim.x && spins < (1u << 24); ++spins) __builtin_amdgcn_s_sleep(1);
+        __threadfence();
+        if (atomicAdd(&ctr[1], 1u) == gridDim.x - 1) { atomicExch(&ctr[0], 0u); atomicExch(&ctr[1], 0u); }      // (everybody has seen the count)
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ void bn_apply_body(const BnArgs& a, int CL, float* sh) {
     __shared__ float mean[256], invstd[256], scale[256], shift[256];
     const int t = threadIdx.x;
-    if (blockIdx.x >= BN_MAIN_BLOCKS) { bn_side_final(a.side, sh); return; }      // (one extra block, training mode only)
     if (a.training) {
         const int64_t nv = bn_valid(a);
         bn_total(a.part1, bn_nblk(), a.C, CL, sh, mean);
@@ -1286,10 +1308,34 @@ __global__ void __launch_bounds__(256) bn_apply_kernel(BnArgs a, int CL) {
     }
 }
 
+__global__ void __launch_bounds__(256) bn_apply_kernel(BnArgs a, int CL) {
+    __shared__ float sh[1024];
+    if (blockIdx.x >= BN_MAIN_BLOCKS) { bn_side_final(a.side, sh); return; }      // (one extra block, training mode only)
+    bn_apply_body(a, CL, sh);
+}
+
+// statistics | barrier | apply: the grid is BN_MAIN_BLOCKS + the companion's blocks (its first block does the companion's totals)
+template <bool VEC>
+__global__ void __launch_bounds__(256) bn_forward_fused_kernel(BnArgs a, int CL) {
+    __shared__ float sh[1024];
+    const bool side = blockIdx.x >= BN_MAIN_BLOCKS;
+    if (side) {
+        bn_side_stats_any(a.side, blockIdx.x - BN_MAIN_BLOCKS, sh);
+        if (a.side.nblk == 1) { __syncthreads(); bn_side_final(a.side, sh); }
+    } else {
+        bn_block_stats<VEC>(a, CL, sh);
+    }
+    bn_grid_barrier(&g_bn_barrier[0]);
+    if (side) {
+        if (blockIdx.x == BN_MAIN_BLOCKS && a.side.nblk > 1) bn_side_final(a.side, sh);
+        return;
+    }
+    bn_apply_body(a, CL, sh);
+}
+
 // backward: per-block column sums of dy and dy * xhat over the block's counted rows -> part1, part2
 template <bool VEC>
-__global__ void __launch_bounds__(256) bn_bwd_partial_kernel(BnArgs a, int CL) {
-    __shared__ float sh[1024];
+__device__ __forceinline__ void bn_bwd_partial_body(const BnArgs& a, int CL, float* sh) {
     const int t = threadIdx.x;
     int64_t lo, hi;
     bn_share(bn_valid(a), bn_nblk(), blockIdx.x, lo, hi);
@@ -1322,8 +1368,13 @@ __global__ void __launch_bounds__(256) bn_bwd_partial_kernel(BnArgs a, int CL) {
 }
 
 template <bool VEC>
-__global__ void __launch_bounds__(256) bn_bwd_final_kernel(BnArgs a, int CL, int nblk_part) {
-    __shared__ float sh[512];
+__global__ void __launch_bounds__(256) bn_bwd_partial_kernel(BnArgs a, int CL) {
+    __shared__ float sh[1024];
+    bn_bwd_partial_body<VEC>(a, CL, sh);
+}
+
+template <bool VEC>
+__device__ __forceinline__ void bn_bwd_final_body(const BnArgs& a, int CL, int nblk_part, float* sh) {
     __shared__ float sdy[256], sdyx[256];
     bn_total(a.part1, nblk_part, a.C, CL, sh, sdy);
     bn_total(a.part2, nblk_part, a.C, CL, sh, sdyx);
@@ -1392,6 +1443,21 @@ __global__ void __launch_bounds__(256) bn_bwd_final_kernel(BnArgs a, int CL, int
             }
         }
     }
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) bn_bwd_final_kernel(BnArgs a, int CL, int nblk_part) {
+    __shared__ float sh[1024];
+    bn_bwd_final_body<VEC>(a, CL, nblk_part, sh);
+}
+
+// partial sums | barrier | gradient rows   (grad_x wanted: every block has rows to write)
+template <bool VEC>
+__global__ void __launch_bounds__(256) bn_backward_fused_kernel(BnArgs a, int CL) {
+    __shared__ float sh[1024];
+    bn_bwd_partial_body<VEC>(a, CL, sh);
+    bn_grid_barrier(&g_bn_barrier[2]);
+    bn_bwd_final_body<VEC>(a, CL, (int)gridDim.x, sh);
 }
 
 // ------------------------------------------------------------------ single-task head + BCE-with-logits ----
@@ -2242,11 +2308,17 @@ int mkgnn_batchnorm_forward_with_stats(const float* x, int64_t x_stride, int64_t
         if (int rc = bn_side_setup("mkgnn_batchnorm_forward", companion, companion_ws, companion_ws_bytes, a.side)) return rc;
         if ((int64_t)companion->n_rows * a.side.CL <= 64 * 1024) { a.side.nblk = 1; side_single = true; }
     }
-    if (training) {                                      // block statistics (the companion's blocks behind the batch norm's own)
-        if (bn_vec_rows(x, x_stride, C)) bn_stats_kernel<true><<<BN_BLOCKS + a.side.nblk, 256, 0, st>>>(a, CL);
-        else bn_stats_kernel<false><<<BN_BLOCKS + a.side.nblk, 256, 0, st>>>(a, CL);
+    static const bool one_launch = [] { const char* e = getenv("MKGNN_BN_ONE_LAUNCH"); return e && e[0] == '1'; }();      // (opt-in: it lost)
+    if (training && one_launch) {                        // statistics | grid barrier | apply  (MKGNN_BN_ONE_LAUNCH=0: two launches)
+        if (bn_vec_rows(x, x_stride, C)) bn_forward_fused_kernel<true><<<BN_BLOCKS + a.side.nblk, 256, 0, st>>>(a, CL);
+        else bn_forward_fused_kernel<false><<<BN_BLOCKS + a.side.nblk, 256, 0, st>>>(a, CL);
+    } else {
+        if (training) {                                  // block statistics (the companion's blocks behind the batch norm's own)
+            if (bn_vec_rows(x, x_stride, C)) bn_stats_kernel<true><<<BN_BLOCKS + a.side.nblk, 256, 0, st>>>(a, CL);
+            else bn_stats_kernel<false><<<BN_BLOCKS + a.side.nblk, 256, 0, st>>>(a, CL);
+        }
+        bn_apply_kernel<<<BN_BLOCKS + ((a.side.nblk && !side_single) ? 1 : 0), 256, 0, st>>>(a, CL);
     }
-    bn_apply_kernel<<<BN_BLOCKS + ((a.side.nblk && !side_single) ? 1 : 0), 256, 0, st>>>(a, CL);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : api_hip_fail("mkgnn_batchnorm_forward", e);
 }
@@ -2269,7 +2341,12 @@ int mkgnn_batchnorm_backward(const float* grad_out, int64_t grad_out_stride, con
     a.part1 = (float*)ws; a.part2 = a.part1 + (size_t)BN_BLOCKS * C;
     a.gout = grad_out; a.gos = grad_out_stride; a.gx = grad_x; a.gxs = grad_x_stride;
     a.gweight = grad_weight; a.gbias = grad_bias; a.nvalid = n_valid_rows;
-    if (bn_vec_rows(x, x_stride, C) && bn_vec_rows(grad_out, grad_out_stride, C) && (!grad_x || bn_vec_rows(grad_x, grad_x_stride, C))) {
+    static const bool one_launch = [] { const char* e = getenv("MKGNN_BN_ONE_LAUNCH"); return e && e[0] == '1'; }();      // (opt-in: it lost)
+    const bool vec = bn_vec_rows(x, x_stride, C) && bn_vec_rows(grad_out, grad_out_stride, C) && (!grad_x || bn_vec_rows(grad_x, grad_x_stride, C));
+    if (one_launch && grad_x) {                          // partial sums | grid barrier | gradient rows
+        if (vec) bn_backward_fused_kernel<true><<<BN_BLOCKS, 256, 0, st>>>(a, CL);
+        else bn_backward_fused_kernel<false><<<BN_BLOCKS, 256, 0, st>>>(a, CL);
+    } else if (vec) {
         bn_bwd_partial_kernel<true><<<BN_BLOCKS, 256, 0, st>>>(a, CL);
         bn_bwd_final_kernel<true><<<grad_x ? BN_BLOCKS : 1, 256, 0, st>>>(a, CL, BN_BLOCKS);
     } else {

@@ -150,6 +150,23 @@ def mark_rows_split(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def presplit_rows(x: torch.Tensor) -> torch.Tensor:
+    """``x`` rewritten as pre-split rows (``mkgnn_rows_presplit``), with its row norms attached: what ``kernelsetconv`` receives
+    from the layer before it inside a model.  For benchmarks and tests that time or check a single layer on the operand form
+    the training step feeds it; the result is meaningless as float32 values."""
+    _lib.require_gpu_tensor(x, "x")
+    x = _aligned_rows(x)
+    n, F = x.shape
+    F4 = F + (-F) % 4
+    out = torch.zeros((n, F4), dtype=torch.float32, device=x.device)[:, :F]
+    inv = torch.empty(n, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mkgnn_rows_presplit(x.data_ptr(), _stride0(x), n, F, inv.data_ptr(), out.data_ptr(), F4,
+                                                   _lib.stream_ptr(x.device)), "mkgnn_rows_presplit")
+    setattr(out, _INV_ATTR, (inv, out._version))
+    return mark_rows_split(out)
+
+
 def rows_split_supported(plan: BatchPlan, params: Sequence[torch.Tensor], F: int, E: int, n_atoms: int) -> bool:
     """``mkgnn_rows_split_supported``: would a ``kernelsetconv`` over these banks and buckets, on rows of ``F`` floats in
     16-byte aligned storage, take pre-split rows in its forward and its backward?"""
