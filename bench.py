@@ -114,14 +114,39 @@ def backward_algorithmic(plan, F, E, Ls):
     }
 
 
+def step_rows(Fn, h, plan, params, E):
+    """``h`` in the form the training step hands a layer its rows: pre-split (functional.presplit_rows) where the layer takes that
+    (the default since round 6: DESIGN 4.1f), else as it is.  Returns (rows, "pre-split" | "fp32")."""
+    try:
+        if os.environ.get("MKGNN_ROWS_SPLIT", "1") != "0" and Fn.rows_split_supported(plan, params, int(h.shape[1]), E, plan.n_atoms):
+            return Fn.presplit_rows(h), "pre-split"
+    except Exception:
+        pass
+    return h, "fp32"
+
+
+def forward_kernel_source_sha16():
+    """sha256 (first 16 hex digits) of the sources the streamed forward kernel is built from: a committed PMC figure names the one
+    it was collected at (tools/collect_pmc.py), so a line can say when its `traffic` no longer belongs to the kernel it times."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("kgnn_fwd_stream.hip", "kgnn_split.h"):
+        with open(os.path.join(REPO, "molkgnn_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def committed_traffic(names):
     """(HBM bytes per launch, where it comes from) of the first of these files under profiles/ that exists."""
     for name in names:
         path = os.path.join(REPO, "profiles", name)
         try:
             pmc = json.load(open(path))
+            src = pmc.get("kernel_source_sha16")
+            stale = "" if src is None else ("" if src == forward_kernel_source_sha16() else
+                                            "; STALE: the forward kernel's sources have changed since (re-collect: tools/round_profiles.sh <tag> <commit> pmc)")
             return pmc["hbm_bytes_per_launch"], (f"profiles/{name} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of commit "
-                                                + pmc.get("commit", "?") + ")")
+                                                + pmc.get("commit", "?") + ")" + stale)
         except Exception:
             continue
     return None, None
@@ -132,7 +157,12 @@ def time_backward_kernels(lib, Fn, h, plan, params, E, variant, reps):
     GPU (mkgnn_debug_time_backward keeps the call on one stream)."""
     import ctypes
     out = (ctypes.c_float * 5)()
-    x = h.detach().requires_grad_(True)
+    # (the rows as the step feeds them: pre-split where the layer takes that -- the leaf that asks for grad_x carries the form's tags)
+    hs, form = step_rows(Fn, h, plan, params, E)
+    x = hs.detach().requires_grad_(True)
+    if form == "pre-split":
+        setattr(x, Fn._INV_ATTR, (getattr(hs, Fn._INV_ATTR)[0], x._version))
+        Fn.mark_rows_split(x)
     wgt = torch.randn(h.shape[0], sum(int(p.shape[0]) for p in params[0::7]), device=h.device)
     acc, cnt = [0.0] * 5, [0] * 5
     lib.mkgnn_debug_time_backward(1)
@@ -376,7 +406,7 @@ def small_batch_leg(args, model, opt, dev, log):
         K_in = model.gnn_model.gnn.num_kernels(0)
         h_store = torch.zeros(b.x.shape[0], K_in + (-K_in) % 4, device=dev)
         h_store[:, :K_in] = torch.rand(b.x.shape[0], K_in, device=dev) * 2 - 1
-        h = h_store[:, :K_in]
+        h, _ = step_rows(Fn, h_store[:, :K_in], plan, params, E)
         samples = []
         lib.mkgnn_debug_time_fused_forward(8)
         for r in range(7):
@@ -387,7 +417,7 @@ def small_batch_leg(args, model, opt, dev, log):
         ms_f = sorted(samples)[len(samples) // 2]
         by, fl = layer_algorithmic(plan, K_in, E, layer.L, False)
         key = f"aid{assay}_b{B}"
-        tr, tr_src = committed_traffic(("r05_forward_pmc_b256.json",)) if (B == 256 and args.variant in ("auto", "mfma")) else (None, None)
+        tr, tr_src = committed_traffic(("r06_forward_pmc_b256.json", "r05_forward_pmc_b256.json")) if (B == 256 and args.variant in ("auto", "mfma")) else (None, None)
         out[key] = {"forward_kernel_traffic": tr, "forward_kernel_traffic_source": tr_src, "forward_kernel_algorithmic_bytes": by,
                     "workload": f"AID {assay} shape, batch {B} ({b.x.shape[0]} atoms), fwd+bwd+AdamW, one hipGraph per resident batch",
                     "ms_per_step": round(1e3 * wins[2], 4), "ms_per_step_min": round(1e3 * wins[0], 4),
@@ -950,7 +980,9 @@ def main():
         g = torch.Generator(device=dev).manual_seed(1)
         h_store = torch.zeros(b.x.shape[0], K_in + (-K_in) % 4, device=dev)
         h_store[:, :K_in] = torch.rand(b.x.shape[0], K_in, generator=g, device=dev) * 2 - 1
-        h = h_store[:, :K_in]
+        h_fp32 = h_store[:, :K_in]
+        # (the rows as the step feeds them: pre-split by their producer -- the kernel timed here is the one the step runs)
+        h, rows_form = step_rows(Fn, h_fp32, plan, params, E)
         import ctypes
         lib = _lib.load()
         lib.mkgnn_debug_last_fused_forward_ms.restype = ctypes.c_float
@@ -985,11 +1017,11 @@ def main():
         gbs = by / (ms * 1e-3) / 1e9
         # HBM bytes per launch from the committed rocprofv3 PMC passes (same kernel, same workload; tools/pmc.sh -- counters
         # cannot be read from inside this process: the figure is the committed one, labelled with the commit it was taken at)
-        traffic, traffic_source = (committed_traffic(("r05_forward_pmc.json", "r04_forward_pmc.json", "r03_forward_pmc.json"))
+        traffic, traffic_source = (committed_traffic(("r06_forward_pmc.json", "r05_forward_pmc.json", "r04_forward_pmc.json"))
                                    if args.batch_size == 4096 and args.variant in ("auto", "mfma") else (None, None))
         # the other kernels of the N-hop layer (the bank gradient is the step's largest line), each alone on the GPU,
         # HIP events in this run; flops / bytes are the USEFUL ones (backward_algorithmic)
-        kernels = [{"kernel": "kc_forward_stream<7, bf16 operands>" if args.variant == "bf16" else "kc_forward_stream<7>", "ms_per_launch": round(ms, 5), "algorithmic_bytes": by, "algorithmic_flops": fl,
+        kernels = [{"kernel": "kc_forward_stream<7, bf16 operands>" if args.variant == "bf16" else ("kc_forward_stream<7, pre-split rows>" if rows_form == "pre-split" else "kc_forward_stream<7>"), "ms_per_launch": round(ms, 5), "rows": rows_form, "algorithmic_bytes": by, "algorithmic_flops": fl,
                     "hbm_frac": round(gbs / HBM_PEAK_GBS, 5), "fp32_frac": round(fl / (ms * 1e-3) / 1e12 / FP32_VECTOR_PEAK_TFLOPS, 5)}]
         try:
             # the 1-hop layer's forward (reference KernelLayer.py:21-37: F = 28, ~19 flop/B by the strict count -- at the fp32
@@ -999,7 +1031,7 @@ def main():
             F0 = int(b.x.shape[1])
             x0 = torch.zeros(b.x.shape[0], F0 + (-F0) % 4, device=dev)
             x0[:, :F0] = torch.randn(b.x.shape[0], F0, generator=g, device=dev)
-            x0 = x0[:, :F0]
+            x0, _ = step_rows(Fn, x0[:, :F0], plan, params0, E0)
             s0 = []
             if args.variant != "generic":
                 for _ in range(3):
@@ -1012,7 +1044,7 @@ def main():
             if s0 and min(s0) > 0:
                 ms0 = sorted(s0)[len(s0) // 2]
                 by0, fl0 = layer_algorithmic(plan, F0, E0, layer0.L, False)
-                t0_, src0 = (committed_traffic(("r05_forward_pmc_1hop.json",)) if args.batch_size == 4096 and args.variant in ("auto", "mfma")
+                t0_, src0 = (committed_traffic(("r06_forward_pmc_1hop.json", "r05_forward_pmc_1hop.json")) if args.batch_size == 4096 and args.variant in ("auto", "mfma")
                              else (None, None))
                 kernels.append({"kernel": "kc_forward_stream<2, bf16 operands>" if args.variant == "bf16" else "kc_forward_stream<2>",
                                 "what": "KernelSetConv forward of the 1-hop layer (F=28, K=110), training configuration",
@@ -1024,7 +1056,7 @@ def main():
             log(f"1-hop forward timing unavailable ({type(exc).__name__}: {exc})")
         try:
             if args.variant in ("auto", "mfma"):
-                bt = time_backward_kernels(lib, Fn, h, plan, params, E, args.variant, max(5, args.roofline_reps // 2))
+                bt = time_backward_kernels(lib, Fn, h_fp32, plan, params, E, args.variant, max(5, args.roofline_reps // 2))
                 alg = backward_algorithmic(plan, K_in, E, Ls)
                 for name, t_ms in (bt or {}).items():
                     if t_ms:
@@ -1036,9 +1068,11 @@ def main():
             log(f"backward kernel timing unavailable ({type(exc).__name__}: {exc})")
         roofline = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(gbs / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_source,
-                    "kernel": ("kc_forward_stream<7, bf16 operands>" if args.variant == "bf16" else "kc_forward_stream<7>")
+                    "kernel": ("kc_forward_stream<7, bf16 operands>" if args.variant == "bf16" else
+                               ("kc_forward_stream<7, 3>" if rows_form == "pre-split" else "kc_forward_stream<7, 2>"))
                               + ": one launch = KernelSetConv forward of one N-hop layer (F=110, K=110), "
-                              "all four degree buckets, training configuration (saves the pair records)",
+                              "all four degree buckets, training configuration (saves the pair records)"
+                              + ("; atom rows pre-split by their producer, as in the step" if rows_form == "pre-split" else ""),
                     "ms_per_launch": round(ms, 5), "ms_whole_forward_call": round(ms_call, 5),
                     "timing": f"HIP events on the kernel's stream around {max(2, args.roofline_reps)} back-to-back launches, median of 9 samples",
                     "ms_per_launch_single_bracket": None if ms_single is None else round(ms_single, 5),

@@ -129,3 +129,70 @@ def configure_optimizer(model: torch.nn.Module, weight_decay: float = 0.0, lr: f
     if capturable:
         kw["capturable"] = True          # step counters live on the device: the step can be replayed from a hipGraph
     return torch.optim.AdamW(groups, lr=lr, **kw)
+
+
+class CapturedSteps:
+    """``loss = steps(batch)``: one training step (``model.loss`` -> ``backward`` -> ``optimizer.step``) per call, launched eagerly
+    the first ``warmup`` times a batch is seen and from a hipGraph captured on its next visit afterwards.
+
+    The reference's harness launches every operator of every step from Python (Lightning's loop around ``model.py``); with the
+    HIP operators that costs 2-3 ms of host time per step at batch 16-256, against 0.25-0.28 ms of GPU work (bench.py,
+    ``small_batch.*.paths.eager_ms_per_step``).  A loop that revisits its batches -- several epochs over resident data -- gets the
+    replayed step with two lines::
+
+        steps = CapturedSteps(model, optimizer)
+        for epoch in range(E):
+            for batch in resident_batches:
+                loss = steps(batch)            # a 0-d tensor, valid until the next call with the SAME batch
+
+    A batch is recognised by the identity of its object and of its ``x`` storage; it must stay alive and unchanged (a batch whose
+    tensors are refilled in place belongs in ``padding.StaticBatch``, which is built for that).  Each captured batch keeps its own
+    graph (and the memory of one step's activations): ``max_graphs`` bounds their number, batches beyond it stay eager.
+    ``optimizer`` must be capturable (``configure_optimizer(..., capturable=True)`` or the fused AdamW)."""
+
+    def __init__(self, model: torch.nn.Module, optimizer=None, warmup: int = 2, max_graphs: int = 64):
+        self.model, self.optimizer = model, optimizer
+        self.warmup, self.max_graphs = int(warmup), int(max_graphs)
+        self._seen: dict = {}
+        self._graphs: dict = {}
+        self._stream = None
+
+    def _key(self, batch):
+        return (id(batch), batch.x.data_ptr(), batch.x._version)
+
+    def _eager(self, batch):
+        self.model.zero_grad(set_to_none=True)
+        loss = self.model.loss(batch)
+        backward(loss)
+        if self.optimizer is not None:
+            self.optimizer.step()
+        return loss.detach()
+
+    def __call__(self, batch):
+        key = self._key(batch)
+        hit = self._graphs.get(key)
+        if hit is not None:
+            graph, static_loss, _keep = hit
+            graph.replay()
+            return static_loss
+        n = self._seen.get(key, 0)
+        self._seen[key] = n + 1
+        if n < self.warmup or len(self._graphs) >= self.max_graphs or not batch.x.is_cuda:
+            return self._eager(batch)
+        if self._stream is None:
+            self._stream = torch.cuda.Stream(device=batch.x.device)
+        side = self._stream
+        side.wait_stream(torch.cuda.current_stream(batch.x.device))
+        with torch.cuda.stream(side):
+            self.model.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                loss = self.model.loss(batch)
+                backward(loss)
+                if self.optimizer is not None:
+                    self.optimizer.step()
+                static_loss = loss.detach()
+        torch.cuda.current_stream(batch.x.device).wait_stream(side)
+        self._graphs[key] = (graph, static_loss, batch)      # (the batch object is kept: its id stays its own)
+        graph.replay()                                        # (a capture launches nothing: this visit's step)
+        return static_loss

@@ -465,3 +465,36 @@ def test_resident_mark_selects_the_one_launch_step_from_the_first_visit(monkeypa
             train_backward(model.loss(b))
         torch.cuda.synchronize()
         assert len(calls) == want, (resident, calls)
+
+
+def test_captured_steps_replay_what_the_eager_loop_computes():
+    """train.CapturedSteps: the two-line opt-in for loops that revisit their batches -- eager for the first two
+    visits of a batch, a captured graph from the third on; after three epochs over four batches the parameters are those of the
+    plain eager loop (same kernels, same order)."""
+    dev = _dev()
+    import copy
+    from molkgnn_amd.synthetic import make_batch
+    from molkgnn_amd.train import CapturedSteps, GNNModel, backward as train_backward, configure_optimizer
+    torch.manual_seed(21)
+    model = GNNModel(ffn_dropout_rate=0.0).to(dev).train()
+    twin = copy.deepcopy(model)
+    opt, opt_t = configure_optimizer(model, lr=1e-3, fused=True), configure_optimizer(twin, lr=1e-3, fused=True)
+    batches = []
+    for i in range(4):
+        b = make_batch(96, seed=300 + i).to(dev)
+        b.y = (torch.arange(96, device=dev) % 3 == 0).long()
+        batches.append(b)
+    steps = CapturedSteps(model, opt)
+    losses = []
+    for epoch in range(4):
+        for b in batches:
+            losses.append(float(steps(b)))
+            twin.zero_grad(set_to_none=True)
+            lt = twin.loss(b)
+            train_backward(lt)
+            opt_t.step()
+            assert abs(losses[-1] - float(lt.detach())) <= 1e-6 * max(1.0, abs(float(lt.detach()))), (epoch, losses[-1], float(lt.detach()))
+    torch.cuda.synchronize()
+    assert len(steps._graphs) == 4
+    for (nm, p), (_, q) in zip(model.named_parameters(), twin.named_parameters()):
+        assert torch.allclose(p, q, atol=1e-6, rtol=1e-5), nm

@@ -23,6 +23,7 @@ hit, miss = avg.get("TCC_HIT_sum"), avg.get("TCC_MISS_sum")
 res = {
     "kernel": name,
     "commit": commit,
+    "kernel_source_sha16": __import__("hashlib").sha256(b"".join(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "molkgnn_amd", "csrc", f), "rb").read() for f in ("kgnn_fwd_stream.hip", "kgnn_split.h"))).hexdigest()[:16],
     "workload": workload,
     "collected": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc TCC_HIT_sum TCC_MISS_sum, separate passes "
                  f"(tools/pmc.sh), averages over {len(counts['FETCH_SIZE'])} launches",

@@ -18,6 +18,8 @@ ap.add_argument("--reps", type=int, default=20)
 ap.add_argument("--variant", default="auto")
 ap.add_argument("--backward", action="store_true")
 ap.add_argument("--last", action="store_true")
+ap.add_argument("--fp32-rows", action="store_true", help="feed fp32 rows (kc_forward_stream<KC, 2>) instead of the pre-split rows the "
+                "training step feeds (kc_forward_stream<KC, 3>)")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -28,7 +30,13 @@ params, E = layer._bank_params("train", b.x)
 F = args.width
 store = torch.zeros(b.x.shape[0], F + (-F) % 4, device=dev)
 store[:, :F] = torch.rand(b.x.shape[0], F, device=dev) * 2 - 1
-x = store[:, :F].requires_grad_(args.backward)
+x = store[:, :F]
+if not args.fp32_rows and args.variant in ("auto", "mfma") and Fn.rows_split_supported(plan, params, F, E, plan.n_atoms):
+    xs = Fn.presplit_rows(x)                       # the operand form of the step (functional.ROWS_SPLIT)
+    x = xs.detach()
+    setattr(x, Fn._INV_ATTR, (getattr(xs, Fn._INV_ATTR)[0], x._version))
+    Fn.mark_rows_split(x)
+x = x.requires_grad_(args.backward)
 for _ in range(args.reps):
     if args.backward:
         out = Fn.kernelsetconv(x, plan, args.last, params, E, args.variant)
