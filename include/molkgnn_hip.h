@@ -462,7 +462,11 @@ size_t mkgnn_plan_workspace_bytes(int64_t n_atoms, int64_t n_edges, int64_t n_ro
  * bucket capacities up front (a batch padded to a fixed shape: molkgnn_amd.padding) -- one memset and six kernels instead of
  * two and nine, no host round trip (capturable).  Inputs as mkgnn_rf_fill; out[d-1].count = rows allocated for degree d, which
  * must equal the batch's number of atoms of out-degree d: counts[0..3] (device, int64[6]) receive the real numbers, counts[4]
- * the number of atoms that did not fit (0 for a well-formed call); rows beyond a real size are zero-filled.  Outputs as
+ * the number of atoms that did not fit (0 for a well-formed call), counts[5] = 0; rows beyond a real size are zero-filled.
+ * PRECONDITION: every capacity EQUALS the real count (what a fixed-shape batch guarantees).  With a capacity above the real count
+ * the scatter CSR covers the ranked atoms only -- scatter_rowptr[n_atoms] < the allocated rows, the tail of scatter_rows is left
+ * unwritten -- which is NOT what mkgnn_plan_build does with zero-filled rows; the caller checks counts[0..3] against its
+ * capacities (receptive_field.check_sizes) before trusting the plan.  Outputs as
  * mkgnn_rf_fill (the 20 tensors of wrapper.py:559-672 + the unit bond rows) and as mkgnn_plan_build (contribution rows
  * numbered with the allocated row counts), entry for entry what the separate calls give.  rf_ready_event (a hipEvent_t, may be
  * NULL) is recorded on the stream where the receptive fields are complete (the plan's two kernels follow): the first

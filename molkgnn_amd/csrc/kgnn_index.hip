@@ -139,6 +139,7 @@ __global__ void __launch_bounds__(256) ix_scan_kernel(IxArgs a) {
         a.counts[0] = carry[0] + mine[0]; a.counts[1] = carry[1] + mine[1];
         a.counts[2] = carry[2] + mine[2]; a.counts[3] = carry[3] + mine[3];
         a.counts[4] = 0;                                 // (atoms beyond a bucket's capacity: counted by the fill pass)
+        a.counts[5] = 0;                                 // (reserved: written so that no entry of the six is left as allocated)
     }
 }
 

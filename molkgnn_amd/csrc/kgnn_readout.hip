@@ -1171,7 +1171,9 @@ __device__ __forceinline__ void bn_side_final(const BnSide& s, float* sh) {
         const float d = s_b / fmaxf(n_b, 1.f) - mu_sh[c];
         return fmaf(n_b * d, d, q_b);
     });
-    if (col < s.C && cnt > 0.f) {
+    // (BatchNorm1d raises on fewer than two values per channel in training mode; a kernel cannot: such a degenerate batch -- a
+    // padded batch without a single real bond -- leaves the statistics AND the counter where they are: ADVICE round 5)
+    if (col < s.C && cnt > 1.f) {
         const float mu = mu_sh[col], var = sq_sh[col] / cnt;
         if (s.running_mean) s.running_mean[col] = fmaf(s.momentum, mu - s.running_mean[col], s.running_mean[col]);
         if (s.running_var) {
@@ -1179,7 +1181,7 @@ __device__ __forceinline__ void bn_side_final(const BnSide& s, float* sh) {
             s.running_var[col] = fmaf(s.momentum, unbiased - s.running_var[col], s.running_var[col]);
         }
     }
-    if (threadIdx.x == 0 && s.nbt) s.nbt[0] += 1;
+    if (threadIdx.x == 0 && s.nbt && cnt > 1.f) s.nbt[0] += 1;
 }
 
 // the companion alone: two launches (phase 0: block statistics, phase 2: totals), or -- one block's worth of rows -- one (phase 3)

@@ -388,6 +388,10 @@ def update_running_stats(x: torch.Tensor, bn: torch.nn.BatchNorm1d, key: Optiona
     _lib.require_gpu_tensor(x, "x")
     if not _stats_supported(x, bn):
         if key is not None:
+            if torch.cuda.is_current_stream_capturing():
+                # (a boolean-mask index synchronises with the host: illegal inside a capture -- say so instead of failing obscurely)
+                raise _lib.MolKGNNLibraryError("update_running_stats: a keyed batch outside the HIP kernels' limits (> 256 channels, "
+                                               "momentum None, statistics off the GPU) cannot run inside a hipGraph capture")
             x = x[key < key_limit]
         bn(x)                                             # (PyTorch's operator on the GPU: cumulative-average momentum, > 256 channels)
         return
