@@ -114,11 +114,12 @@ def backward_algorithmic(plan, F, E, Ls):
     }
 
 
-def step_rows(Fn, h, plan, params, E):
+def step_rows(Fn, h, plan, params, E, variant="auto"):
     """``h`` in the form the training step hands a layer its rows: pre-split (functional.presplit_rows) where the layer takes that
     (the default since round 6: DESIGN 4.1f), else as it is.  Returns (rows, "pre-split" | "fp32")."""
     try:
-        if os.environ.get("MKGNN_ROWS_SPLIT", "1") != "0" and Fn.rows_split_supported(plan, params, int(h.shape[1]), E, plan.n_atoms):
+        if variant in ("auto", "mfma") and os.environ.get("MKGNN_ROWS_SPLIT", "1") != "0" \
+                and Fn.rows_split_supported(plan, params, int(h.shape[1]), E, plan.n_atoms):
             return Fn.presplit_rows(h), "pre-split"
     except Exception:
         pass
@@ -158,7 +159,7 @@ def time_backward_kernels(lib, Fn, h, plan, params, E, variant, reps):
     import ctypes
     out = (ctypes.c_float * 5)()
     # (the rows as the step feeds them: pre-split where the layer takes that -- the leaf that asks for grad_x carries the form's tags)
-    hs, form = step_rows(Fn, h, plan, params, E)
+    hs, form = step_rows(Fn, h, plan, params, E, variant)
     x = hs.detach().requires_grad_(True)
     if form == "pre-split":
         setattr(x, Fn._INV_ATTR, (getattr(hs, Fn._INV_ATTR)[0], x._version))
@@ -406,7 +407,7 @@ def small_batch_leg(args, model, opt, dev, log):
         K_in = model.gnn_model.gnn.num_kernels(0)
         h_store = torch.zeros(b.x.shape[0], K_in + (-K_in) % 4, device=dev)
         h_store[:, :K_in] = torch.rand(b.x.shape[0], K_in, device=dev) * 2 - 1
-        h, _ = step_rows(Fn, h_store[:, :K_in], plan, params, E)
+        h, _ = step_rows(Fn, h_store[:, :K_in], plan, params, E, args.variant)
         samples = []
         lib.mkgnn_debug_time_fused_forward(8)
         for r in range(7):
@@ -982,7 +983,7 @@ def main():
         h_store[:, :K_in] = torch.rand(b.x.shape[0], K_in, generator=g, device=dev) * 2 - 1
         h_fp32 = h_store[:, :K_in]
         # (the rows as the step feeds them: pre-split by their producer -- the kernel timed here is the one the step runs)
-        h, rows_form = step_rows(Fn, h_fp32, plan, params, E)
+        h, rows_form = step_rows(Fn, h_fp32, plan, params, E, args.variant)
         import ctypes
         lib = _lib.load()
         lib.mkgnn_debug_last_fused_forward_ms.restype = ctypes.c_float
@@ -1031,7 +1032,7 @@ def main():
             F0 = int(b.x.shape[1])
             x0 = torch.zeros(b.x.shape[0], F0 + (-F0) % 4, device=dev)
             x0[:, :F0] = torch.randn(b.x.shape[0], F0, generator=g, device=dev)
-            x0, _ = step_rows(Fn, x0[:, :F0], plan, params0, E0)
+            x0, _ = step_rows(Fn, x0[:, :F0], plan, params0, E0, args.variant)
             s0 = []
             if args.variant != "generic":
                 for _ in range(3):

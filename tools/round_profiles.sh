@@ -15,7 +15,7 @@ if [ "$part" != pmc ]; then
 python3 bench.py --steps 50 --warmup 10 > "$O/bench_b4096.json" 2> "$O/bench_b4096.err"
 # 2. kernel statistics + one step's timeline of the same command (shorter; without the small-batch leg, whose steps would
 #    otherwise be the last ones of the trace)
-export MKGNN_NO_SMALL_BATCH=1
+export MKGNN_NO_SMALL_BATCH=1 MKGNN_NO_EXACT_LEG=1       # (the traced steps are the headline's: no leg behind them)
 tools/prof.sh "$tag/prof_b4096" bench.py --steps 20 --warmup 5 --windows 1 --fresh-batches 0 --no-cpu-baseline > "$O/kstats_b4096.txt"
 python3 tools/step_timeline.py "$O/prof_b4096" > "$O/step_timeline_graph.txt"
 find "$O/prof_b4096" -name "*kernel_trace.csv" -delete     # (gpurun brings back at most 64 MiB: the summaries stay, the raw traces go)
@@ -24,7 +24,7 @@ tools/prof.sh "$tag/prof_fresh" bench.py --steps 10 --warmup 3 --windows 1 --fre
 python3 tools/step_timeline.py "$O/prof_fresh" > "$O/step_timeline_fresh.txt"
 find "$O/prof_fresh" -name "*kernel_trace.csv" -delete
 # 4. configs[2]: AID 435008 shape, batch 256
-MKGNN_NO_SMALL_BATCH= python3 bench.py --assay 435008 --batch-size 256 --steps 200 --warmup 20 > "$O/bench_435008_b256.json" 2> "$O/bench_435008_b256.err"
+MKGNN_NO_SMALL_BATCH= MKGNN_NO_EXACT_LEG= python3 bench.py --assay 435008 --batch-size 256 --steps 200 --warmup 20 > "$O/bench_435008_b256.json" 2> "$O/bench_435008_b256.err"
 tools/prof.sh "$tag/prof_b256" bench.py --assay 435008 --batch-size 256 --steps 50 --warmup 5 --windows 1 --fresh-batches 0 --no-cpu-baseline > "$O/kstats_435008_b256.txt"
 python3 tools/step_timeline.py "$O/prof_b256" > "$O/step_timeline_435008_b256.txt"
 find "$O/prof_b256" -name "*kernel_trace.csv" -delete
