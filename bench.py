@@ -490,7 +490,9 @@ def fresh_batches_leg(args, model, opt, dev, log):
     shape = P.fixed_shape([P.degree_histogram(r) for r in raws])
     padded = [P.pack(P.pad_batch(r, shape, B).to(dev)) for r in raws]      # (packed: one copy loads a batch)
     pad_atoms = sum(shape["atoms"] - int(p.n_valid_atoms) for p in padded) / nb
-    sb = P.StaticBatch(padded[0])
+    # (the epoch's largest molecule, padding molecules included: what lets the captured step run the fused tail, readout.tail_loss)
+    sb = P.StaticBatch(padded[0], max_mol_atoms=max(getattr(p_, "max_mol_atoms", 1 << 30) for p_ in padded),
+                       max_mol_edges=max(getattr(p_, "max_mol_edges", 1 << 30) for p_ in padded))
 
     def step():
         attach_receptive_fields(sb.data, sizes=sb.data.bucket_sizes, overlap=True)

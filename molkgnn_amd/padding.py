@@ -127,7 +127,10 @@ class StaticBatch:
 
     FIELDS = ("x", "p", "edge_index", "edge_attr", "batch", "y", "mol_ptr", "atom_mol", "n_valid_atoms")
 
-    def __init__(self, first: GraphBatch):
+    def __init__(self, first: GraphBatch, max_mol_atoms=None, max_mol_edges=None):
+        """``max_mol_atoms`` / ``max_mol_edges``: the caller's bound on a molecule's atoms / directed edges for EVERY batch these
+        buffers will hold (e.g. the maxima of ``pad_batch``'s figures over the epoch) -- the promise ``readout.tail_loss`` needs
+        to run the fused tail in a step captured on them; without it the readout and the head stay separate operators."""
         self.table, total = _layout(first, self.FIELDS)
         self.flat = torch.empty(total, dtype=torch.uint8, device=first.x.device)
         self.data = GraphBatch()
@@ -137,22 +140,18 @@ class StaticBatch:
             setattr(self.data, k, view)
         self.data.n_valid_molecules, self.data.num_graphs = first.n_valid_molecules, first.num_graphs
         self.data.bucket_sizes = list(first.bucket_sizes)
-        # the molecule-size bound the consumer was shown (and a graph captured on these buffers was built for): later batches may
-        # not exceed the limits the first one stayed inside (load)
-        self.data.max_mol_atoms = getattr(first, "max_mol_atoms", None)
-        self.data.max_mol_edges = getattr(first, "max_mol_edges", None)
+        # the molecule-size bound the consumer is shown (and a graph captured on these buffers is built for): the CALLER's promise
+        # for every batch, never the first batch's own figures
+        self.data.max_mol_atoms, self.data.max_mol_edges = max_mol_atoms, max_mol_edges
 
     def load(self, padded: GraphBatch) -> None:
         if list(padded.bucket_sizes) != self.data.bucket_sizes or padded.n_valid_molecules != self.data.n_valid_molecules:
             raise ValueError("batch shape differs from the static buffers'")
-        from . import _lib
-        for key, lim in (("max_mol_atoms", _lib.TAIL_MAX_ATOMS), ("max_mol_edges", _lib.TAIL_MAX_EDGES)):
-            had, now = getattr(self.data, key, None), getattr(padded, key, None)
-            if had is not None and had <= lim and (now is None or now > lim):
-                raise ValueError(f"{key} = {now}: the first batch of these buffers stayed within {lim} (a step captured on them may "
-                                 "run the fused tail, readout.tail_loss, which takes no larger molecule); set MKGNN_FUSED_TAIL=0")
-            if had is not None and now is not None:
-                setattr(self.data, key, max(had, now))
+        for key in ("max_mol_atoms", "max_mol_edges"):
+            promised, now = getattr(self.data, key, None), getattr(padded, key, None)
+            if promised is not None and now is not None and now > promised:
+                raise ValueError(f"{key} = {now} exceeds the bound {promised} these buffers were created with (a step captured on them "
+                                 "may run the fused tail, readout.tail_loss, which relies on it)")
         flat = getattr(padded, "flat", None)
         if flat is not None and flat.numel() == self.flat.numel():
             self.flat.copy_(flat, non_blocking=True)
