@@ -1586,18 +1586,15 @@ def test_statistics_only_batch_norm_matches_torch(n, C, masked):
         R.update_running_stats(x, mine, key, lim)
         if xr.shape[0] > 1:
             ref(xr)
-        else:                                             # (torch refuses one row per channel in training mode; the formula: var = 0)
-            with torch.no_grad():
-                ref.running_mean += 0.1 * (xr[0] - ref.running_mean)
-                ref.running_var += 0.1 * (0.0 - ref.running_var)
-                ref.num_batches_tracked += 1
+        # (torch RAISES on one value per channel in training mode; a kernel cannot, so such a degenerate batch leaves the
+        # statistics and the counter where they are -- kgnn_readout.hip bn_side_final)
         assert torch.allclose(mine.running_mean, ref.running_mean, atol=2e-6, rtol=1e-5), step
         assert torch.allclose(mine.running_var, ref.running_var, atol=1e-5, rtol=2e-5), step
-        assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == step + 1
+        assert int(mine.num_batches_tracked) == int(ref.num_batches_tracked) == (step + 1 if n > 1 else 0)
     mine.eval()
-    before = mine.running_mean.clone()
+    before, count = mine.running_mean.clone(), int(mine.num_batches_tracked)
     R.update_running_stats(torch.randn(n, C, device=dev), mine)
-    assert torch.equal(mine.running_mean, before) and int(mine.num_batches_tracked) == 3      # eval mode: nothing moves
+    assert torch.equal(mine.running_mean, before) and int(mine.num_batches_tracked) == count      # eval mode: nothing moves
 
 
 @pytest.mark.parametrize("mols,padded", [(64, False), (700, False), (300, True)])
