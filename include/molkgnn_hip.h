@@ -38,7 +38,7 @@ extern "C" {
 #endif
 
 #define MKGNN_MAX_DEGREE 4
-#define MKGNN_ABI_VERSION 6
+#define MKGNN_ABI_VERSION 7
 
 /* One KernelConv's parameters (reference kernels.py:50-84).  The three score
  * weights are the 0-d parameters support_attr_sc_weight, center_attr_sc_weight
@@ -96,7 +96,9 @@ typedef struct mkgnn_saved {
  * mkgnn_adamw_state_floats(numel) = 2 numel + 3 + ceil(numel / 1024) floats (v3: 2 numel + 3) -- a caller built against
  * v3 would hand mkgnn_adamw_step a buffer its blocks write past, so the version check must refuse it; the
  * molecule-resident small-batch entry points (mkgnn_molecule_*) were added with the same version.  v5: the statistics-only
- * batch-norm companion (mkgnn_bn_stats, mkgnn_batchnorm_update_stats, mkgnn_batchnorm_forward_with_stats). */
+ * batch-norm companion (mkgnn_bn_stats, mkgnn_batchnorm_update_stats, mkgnn_batchnorm_forward_with_stats).  v6: pre-split rows
+ * (MKGNN_VARIANT_ROWS_SPLIT / MKGNN_BACKWARD_ROWS_SPLIT / MKGNN_BN_SPLIT_ROWS, mkgnn_rows_presplit, mode 3 of
+ * mkgnn_segment_sum_block_rows) and the fused tail (mkgnn_tail_*).  v7: mkgnn_touch_hint. */
 int mkgnn_abi_version(void);
 const char* mkgnn_last_error(void);
 
@@ -151,6 +153,15 @@ int mkgnn_rows_presplit(const float* x, int64_t x_stride, int64_t n_rows, int32_
  * a model prepares all its layers at the start of a step instead of one small dependent launch per layer. */
 int mkgnn_bank_prepare(int32_t count, const mkgnn_kernel_bank* banks, const int32_t* F, int32_t E,
                        void* const* workspaces, const size_t* workspace_bytes, void* stream);
+/* A hint (ABI v7): `count` (<= 16) device arrays that the NEXT call of this host thread to mkgnn_bank_prepare or to
+ * mkgnn_batchnorm_forward* (training mode) READS once and discards, with spare blocks of a launch it makes anyway -- the index
+ * arrays of the batch the convolutions that follow will gather through (mkgnn_degree_bucket.selected_index / nei_index /
+ * nei_edge_unit, the CSR of propagate).  Nothing is computed from them and no result depends on it: after a backward pass has
+ * moved a gigabyte through the caches they are cold, and the first convolution of a step -- the one with the least matrix work
+ * per fetched row to hide a miss behind -- pays 8-9 us of its 30 for them at the benchmark batch; read beside the batch norm's
+ * statistics (a launch bound by latency, not by bandwidth) they cost nothing.  The arrays must stay allocated until that next
+ * call's launch has run.  mkgnn_touch_hint(NULL, NULL, 0) withdraws a hint nobody took; returns 1 if there was one, else 0. */
+int mkgnn_touch_hint(const void* const* arrays, const size_t* bytes, int32_t count);
 
 int mkgnn_kernelsetconv_forward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE],
                                 const mkgnn_degree_bucket buckets[MKGNN_MAX_DEGREE],

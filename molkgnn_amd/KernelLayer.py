@@ -142,8 +142,12 @@ class MolGCN(MessagePassing):
         elif x.is_cuda and _PREPARE_ONCE and all(layer._can_prepare() for layer in self.layers):
             n_slots = sum(int(fields[f'nei_index_deg{d}'].numel()) for d in range(1, 5))
             pl = [layer._bank_params("train", x) for layer in self.layers]
-            prepared = Fn.prepare_banks([p for p, _ in pl], [x.shape[1]] + [self.num_kernels(i) for i in range(self.num_layers - 1)],
-                                        pl[0][1], x.shape[0], n_slots)
+            # (a caller that ran something with spare blocks in front -- MolKGNNNet's batch norm -- has had the batch's index
+            # arrays read there, functional.touch_hint, and says so on the plan; otherwise this launch reads them)
+            done, self._plan._touch_done = getattr(self._plan, "_touch_done", False), False
+            with Fn.touch_hint(None if done else Fn.plan_touch_list(self._plan)):
+                prepared = Fn.prepare_banks([p for p, _ in pl], [x.shape[1]] + [self.num_kernels(i) for i in range(self.num_layers - 1)],
+                                            pl[0][1], x.shape[0], n_slots)
         # (private: MolKGNNNet asks for the LAST layer's block rows instead of h -- its readout projects them before the
         # propagate step, readout.readout_blocks; None is returned where that does not apply and h as usual)
         defer = kwargv.get('_defer_last_propagate') is not None

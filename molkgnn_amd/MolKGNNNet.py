@@ -94,9 +94,6 @@ class MolKGNNNet(torch.nn.Module):
         # edge_batch_norm(data.edge_attr) (reference MolKGNNNet.py:116): its output never reaches the kernel convolution
         # (SURVEY 8 a-1), but in training mode the call moves the module's running statistics and num_batches_tracked, which
         # are state-dict contents -- that side effect rides along in the node batch norm's launches (readout.batch_norm)
-        if data.x.is_cuda and not save_score:
-            # (the banks depend on the parameters only: their one launch runs beside the batch norm, on the side stream)
-            self.gnn.prepare_banks_early(data.x, sum(int(getattr(data, f'nei_index_deg{d}').numel()) for d in range(1, 5)))
         kw = {f'{nm}_deg{d}': getattr(data, f'{nm}_deg{d}')
               for nm in ('p_focal', 'nei_p', 'nei_edge_attr', 'selected_index', 'nei_index') for d in range(1, 5)}
         for d in range(1, 5):                          # unit bond rows built with the receptive fields (mkgnn_rf_fill), if any
@@ -105,18 +102,26 @@ class MolKGNNNet(torch.nn.Module):
                 kw[f'nei_edge_unit_deg{d}'] = u
         # the normalised features go nowhere but into the first kernel convolution: where that layer takes pre-split rows
         # (functional.ROWS_SPLIT) the batch norm writes them so -- asked from shapes alone, nothing is launched or awaited
-        split_x = False
+        split_x, plan0 = False, None
         if data.x.is_cuda and not save_score:
             from . import KernelLayer as _KL
+            from .plan import plan_from_lists_cached
+            names = ('p_focal', 'nei_p', 'nei_edge_attr', 'selected_index', 'nei_index')
+            units = [kw.get(f'nei_edge_unit_deg{d}') for d in range(1, 5)]
+            plan0 = plan_from_lists_cached(data.x.shape[0], *[[kw[f'{nm}_deg{d}'] for d in range(1, 5)] for nm in names],
+                                           data.edge_index, units if any(u is not None for u in units) else None)
+            # (the banks depend on the parameters only: their one launch can run beside the batch norm, on the side stream)
+            self.gnn.prepare_banks_early(data.x, sum(int(kw[f'nei_index_deg{d}'].numel()) for d in range(1, 5)))
             if _KL._ROWS_SPLIT:
-                from .plan import plan_from_lists_cached
-                names = ('p_focal', 'nei_p', 'nei_edge_attr', 'selected_index', 'nei_index')
-                units = [kw.get(f'nei_edge_unit_deg{d}') for d in range(1, 5)]
-                plan0 = plan_from_lists_cached(data.x.shape[0], *[[kw[f'{nm}_deg{d}'] for d in range(1, 5)] for nm in names],
-                                               data.edge_index, units if any(u is not None for u in units) else None)
                 split_x = self.gnn.layers[0]._accepts_split_rows(plan0, data.x)
-        x = R.batch_norm(data.x, self.node_batch_norm, getattr(data, 'n_valid_atoms', None), companion=self._edge_stats(data),
-                         split_out=split_x)
+        # (round 6: spare blocks of the batch norm's statistics launch read the batch's index arrays once -- cold after the
+        # previous step's backward, and otherwise paid for by the first convolution: functional.touch_hint)
+        from . import functional as _Fn
+        with _Fn.touch_hint(_Fn.plan_touch_list(plan0) if plan0 is not None else None) as hint:
+            x = R.batch_norm(data.x, self.node_batch_norm, getattr(data, 'n_valid_atoms', None), companion=self._edge_stats(data),
+                             split_out=split_x)
+        if plan0 is not None:
+            plan0._touch_done = hint.taken
         if getattr(data, '_rf_ready', None) is not None:     # degree buckets still being built on the index stream
             from .receptive_field import await_receptive_fields
             await_receptive_fields(data)

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MKGNN_LIB: a diagnostic build of the same library (make VARIANT=... in csrc/), e.g. with cycle stamps compiled in
 LIB_PATH = os.environ.get("MKGNN_LIB") or os.path.join(_HERE, "libmolkgnn_hip.so")
 MAX_DEGREE = 4
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class KernelBank(C.Structure):
@@ -132,7 +132,7 @@ EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn
            "mkgnn_batchnorm_backward", "mkgnn_bce_head_workspace_bytes", "mkgnn_bce_head_forward",
            "mkgnn_bce_head_backward", "mkgnn_rf_workspace_bytes", "mkgnn_rf_count", "mkgnn_rf_fill", "mkgnn_adamw_step", "mkgnn_adamw_state_floats",
            "mkgnn_bce_head_dropout_forward", "mkgnn_bce_head_dropout_backward", "mkgnn_segment_sum_block_rows",
-           "mkgnn_plan_workspace_bytes", "mkgnn_plan_build", "mkgnn_backward_join", "mkgnn_backward_streams", "mkgnn_bank_prepare", "mkgnn_expand_batch", "mkgnn_bce_head_fused", "mkgnn_collate_compact", "mkgnn_collate_compact_bytes",
+           "mkgnn_plan_workspace_bytes", "mkgnn_plan_build", "mkgnn_backward_join", "mkgnn_backward_streams", "mkgnn_bank_prepare", "mkgnn_touch_hint", "mkgnn_expand_batch", "mkgnn_bce_head_fused", "mkgnn_collate_compact", "mkgnn_collate_compact_bytes",
            "mkgnn_readout_blocks_supported", "mkgnn_readout_blocks_forward", "mkgnn_readout_blocks_backward",
            "mkgnn_readout_blocks_workspace_bytes", "mkgnn_molecule_supported", "mkgnn_molecule_workspace_bytes",
            "mkgnn_molecule_step", "mkgnn_batchnorm_stats_workspace_bytes", "mkgnn_batchnorm_update_stats",
@@ -207,6 +207,8 @@ def load() -> C.CDLL:
     lib.mkgnn_rows_split_supported.argtypes = [Banks4, Buckets4, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32]
     lib.mkgnn_bank_prepare.restype = C.c_int
     lib.mkgnn_bank_prepare.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mkgnn_touch_hint.restype = C.c_int
+    lib.mkgnn_touch_hint.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.mkgnn_collate_compact_bytes.restype = C.c_size_t
     lib.mkgnn_collate_compact_bytes.argtypes = [Int64x6, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     lib.mkgnn_collate_compact.restype = C.c_int

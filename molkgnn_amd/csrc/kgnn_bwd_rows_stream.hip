@@ -112,6 +112,9 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
     constexpr int NS = column_tiles(D), NSTREAM = 4 / NS, S1 = D + 1;
     constexpr int FP = 16 * KC;
     const int tid = threadIdx.x, lane = tid & 63;
+#ifdef MKGNN_BWD_STAMPS
+    const unsigned long long t_entry = __builtin_readcyclecounter();
+#endif
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int stream = wave / NS, role = wave % NS;
     const int ci = lane & 15, kq = lane >> 4;
@@ -233,6 +236,7 @@ __device__ __forceinline__ void rows_stream_body(const RowsStreamArgs& a, const 
 #ifdef MKGNN_BWD_STAMPS
     const unsigned long long t_start = __builtin_readcyclecounter();
     unsigned long long phase[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_phase = t_start;
+    phase[5] = t_start - t_entry;                        // the prologue: the bank into registers, tile 0's coefficient loads issued
 #endif
     for (int it = 0; it < iters; ++it) {
         const int64_t tile = tile_at(it);

@@ -359,12 +359,46 @@ static int check_common(const char* who, const mkgnn_kernel_bank banks[4], const
     return 0;
 }
 
+static thread_local TouchArgs g_touch_hint;           // (count == 0: none pending)
+extern "C++" {
+namespace mkgnn {
+bool take_touch_hint(TouchArgs& out) {
+    if (g_touch_hint.count <= 0) return false;
+    out = g_touch_hint;
+    g_touch_hint.count = 0;
+    return true;
+}
+}  // namespace mkgnn
+}
+
+int mkgnn_touch_hint(const void* const* arrays, const size_t* bytes, int32_t count) {
+    if (count <= 0 || !arrays || !bytes) {
+        const int had = g_touch_hint.count > 0 ? 1 : 0;
+        g_touch_hint.count = 0;
+        return had;
+    }
+    TouchArgs ta{};
+    for (int k = 0; k < count && ta.count < TOUCH_MAX; ++k) {      // the 16-byte aligned interior of every array (at most 4 GiB - 16 of it)
+        if (!arrays[k] || bytes[k] < 32) continue;
+        const uintptr_t lo = ((uintptr_t)arrays[k] + 15) & ~(uintptr_t)15, hi = ((uintptr_t)arrays[k] + bytes[k]) & ~(uintptr_t)15;
+        if (hi <= lo) continue;
+        const size_t n = hi - lo;
+        ta.ptr[ta.count] = (const char*)lo;
+        ta.bytes[ta.count] = (uint32_t)(n > 0xfffffff0u ? 0xfffffff0u : n);
+        ++ta.count;
+    }
+    g_touch_hint = ta;
+    return 0;
+}
+
 int mkgnn_bank_prepare(int32_t count, const mkgnn_kernel_bank* banks, const int32_t* F, int32_t E, void* const* workspaces,
                        const size_t* workspace_bytes, void* stream) {
     const char* who = "mkgnn_bank_prepare";
     if (count < 0 || count > PREP_MANY_MAX) return fail("%s: %d calls (0..%d per launch)", who, count, PREP_MANY_MAX);
-    if (count == 0) return 0;
-    if (!banks || !F || !workspaces || !workspace_bytes || E <= 0) return fail("%s: bad arguments", who);
+    TouchArgs ta{};
+    (void)take_touch_hint(ta);
+    if (count == 0 && ta.count == 0) return 0;
+    if (count > 0 && (!banks || !F || !workspaces || !workspace_bytes || E <= 0)) return fail("%s: bad arguments", who);
     WorkspaceLayout w[PREP_MANY_MAX];
     char* ws[PREP_MANY_MAX];
     int Fs[PREP_MANY_MAX];
@@ -385,7 +419,7 @@ int mkgnn_bank_prepare(int32_t count, const mkgnn_kernel_bank* banks, const int3
         ws[k] = (char*)workspaces[k];
         Fs[k] = F[k];
     }
-    hipError_t e = launch_bank_prepare_many(count, banks, w, ws, Fs, E, (hipStream_t)stream);
+    hipError_t e = launch_bank_prepare_many(count, banks, w, ws, Fs, E, (hipStream_t)stream, ta.count ? &ta : nullptr);
     return e == hipSuccess ? 0 : hip_fail(who, e);
 }
 

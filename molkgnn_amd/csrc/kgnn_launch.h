@@ -96,9 +96,36 @@ struct BankReduceArgs {
 
 hipError_t launch_row_inv_norm(const float* x, int64_t stride, int64_t n, int F, float* inv, hipStream_t st);
 constexpr int PREP_MANY_MAX = 4;
-struct PrepManyArgs { PrepArgs layer[PREP_MANY_MAX]; int task_start[PREP_MANY_MAX + 1]; int count; };
+// arrays that spare blocks of a launch read once and throw away (mkgnn_touch_hint): 16-byte aligned interiors
+constexpr int TOUCH_MAX = 16, TOUCH_BLOCKS = 512;
+struct TouchArgs { const char* ptr[TOUCH_MAX]; uint32_t bytes[TOUCH_MAX]; int count; };
+bool take_touch_hint(TouchArgs& out);          // this thread's pending hint, if any (kgnn_capi.hip); clears it
+#ifdef __HIPCC__
+// block b of nb (256 threads each): eight independent loads in flight per thread (clamped, not conditional: a load under a
+// condition is issued and waited for alone); one load per trip took 12 us for 11 MB -- a chain of cold misses
+__device__ __forceinline__ void touch_body(const TouchArgs& t, uint32_t b, uint32_t nb) {
+    uint32_t acc = 0;
+    const uint32_t stride = nb * 256u;
+    for (int k = 0; k < t.count; ++k) {
+        const uint4* const p = (const uint4*)t.ptr[k];
+        const uint32_t n16 = t.bytes[k] >> 4;
+        for (uint32_t i = b * 256u + threadIdx.x; i < n16; i += 8u * stride) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t j = i + (uint32_t)u * stride;
+                v[u] = p[j < n16 ? j : n16 - 1u];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+        }
+    }
+    asm volatile("" :: "v"(acc));                        // (the loads stay)
+}
+#endif
+struct PrepManyArgs { PrepArgs layer[PREP_MANY_MAX]; int task_start[PREP_MANY_MAX + 1]; int count; int prep_blocks; TouchArgs touch; };
 hipError_t launch_bank_prepare_many(int count, const mkgnn_kernel_bank* banks /* [count][4] */, const WorkspaceLayout* w,
-                                    char* const* ws, const int* F, int E, hipStream_t st);
+                                    char* const* ws, const int* F, int E, hipStream_t st, const TouchArgs* touch = nullptr);
 hipError_t launch_bank_prepare(const mkgnn_kernel_bank banks[4], const WorkspaceLayout& w, char* ws, int F, int E,
                                hipStream_t st);
 hipError_t launch_forward_generic(int d, const FwdArgs& a, hipStream_t st);

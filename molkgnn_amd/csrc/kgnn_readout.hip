@@ -768,6 +768,8 @@ struct BnArgs {
     float *gweight, *gbias;
     float* inv_out;                // forward: 1 / max(|out row|, eps) for the convolution that reads out next (17 <= C <= 32)
     int split_out;                 // ... and the rows themselves written PRE-SPLIT for it (kgnn_split.h; MKGNN_BN_SPLIT_ROWS)
+    int touch_first;               // blocks from here on of the statistics launch read `touch` and throw it away (mkgnn_touch_hint)
+    TouchArgs touch;
     int64_t* nbt;                  // forward, training: BatchNorm1d.num_batches_tracked, incremented
     const int64_t* nvalid;         // device scalar or null: only rows [0, *nvalid) enter the batch statistics (padded batches)
     BnSide side;                   // statistics-only companion (blocks gridDim.x - side.nblk .. of the same launches); nblk = 0: none
@@ -1195,6 +1197,10 @@ __global__ void __launch_bounds__(256) bn_side_kernel(BnSide s, int phase) {
 template <bool VEC>
 __global__ void __launch_bounds__(256) bn_stats_kernel(BnArgs a, int CL) {
     __shared__ float sh[1024];
+    if (a.touch.count > 0 && (int)blockIdx.x >= a.touch_first) {     // (behind the batch norm's and the companion's own blocks)
+        touch_body(a.touch, blockIdx.x - a.touch_first, gridDim.x - a.touch_first);
+        return;
+    }
     if (blockIdx.x >= BN_MAIN_BLOCKS) {
         bn_side_stats_any(a.side, blockIdx.x - BN_MAIN_BLOCKS, sh);
         if (a.side.nblk == 1) {                          // a companion of one block's worth of rows: all of it here, in this launch
@@ -2316,8 +2322,14 @@ int mkgnn_batchnorm_forward_with_stats(const float* x, int64_t x_stride, int64_t
         else bn_forward_fused_kernel<false><<<BN_BLOCKS + a.side.nblk, 256, 0, st>>>(a, CL);
     } else {
         if (training) {                                  // block statistics (the companion's blocks behind the batch norm's own)
-            if (bn_vec_rows(x, x_stride, C)) bn_stats_kernel<true><<<BN_BLOCKS + a.side.nblk, 256, 0, st>>>(a, CL);
-            else bn_stats_kernel<false><<<BN_BLOCKS + a.side.nblk, 256, 0, st>>>(a, CL);
+            // ... and behind those the blocks of a pending mkgnn_touch_hint: this launch is bound by the latency of its two passes
+            // over 11 MB, not by bandwidth -- the batch's index arrays are read beside them for nothing
+            a.touch.count = 0;
+            a.touch_first = BN_BLOCKS + a.side.nblk;
+            const int extra = take_touch_hint(a.touch) ? TOUCH_BLOCKS : 0;
+            if (bn_vec_rows(x, x_stride, C)) bn_stats_kernel<true><<<BN_BLOCKS + a.side.nblk + extra, 256, 0, st>>>(a, CL);
+            else bn_stats_kernel<false><<<BN_BLOCKS + a.side.nblk + extra, 256, 0, st>>>(a, CL);
+            a.touch.count = 0;
         }
         bn_apply_kernel<<<BN_BLOCKS + ((a.side.nblk && !side_single) ? 1 : 0), 256, 0, st>>>(a, CL);
     }

@@ -188,6 +188,49 @@ def _prepared_key(params, F, E, n_atoms, n_slots):
     return (F, E, n_atoms, n_slots) + tuple((p.data_ptr(), p._version) for p in params)
 
 
+TOUCH = os.environ.get("MKGNN_TOUCH", "1") != "0"      # the batch's index arrays are read once ahead of the first convolution
+
+
+def plan_touch_list(plan: BatchPlan) -> List[torch.Tensor]:
+    """The index arrays of a batch that its convolutions gather through -- per degree ``selected_index``, ``nei_index`` and the unit
+    bond rows, and the CSR ``propagate`` sums over (at most 16 arrays; whatever has not been built yet is left out, nothing is
+    built for this)."""
+    out = []
+    for bk in plan.buckets:
+        if bk.count:
+            out += [bk.nei, bk.sel]
+            if bk._e_unit is not None:
+                out.append(bk._e_unit)
+    if plan._csr_in_packed is not None:
+        out += [t for t in plan._csr_in_packed if t is not None]
+    return [t for t in out if t.is_cuda and t.numel() * t.element_size() >= 4096][:16]
+
+
+class touch_hint:
+    """``with touch_hint(plan_touch_list(plan)) as h: <batch norm / prepare_banks>`` -- ``mkgnn_touch_hint``: the first of the
+    library's launches inside the block that has spare blocks (the batch norm's statistics, else the bank preparation) reads
+    these arrays once and discards them, so that the step's first convolution does not find them cold.  Leaving
+    the block withdraws a hint nobody took; ``h.taken`` tells afterwards.  The arrays belong to the batch: alive as long as it."""
+
+    def __init__(self, tensors):
+        self.tensors = [t for t in (tensors or []) if t.is_cuda][:16] if TOUCH else []
+        self.taken = False
+
+    def __enter__(self):
+        if self.tensors:
+            import ctypes as C
+            n = len(self.tensors)
+            ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in self.tensors])
+            nbytes = (C.c_size_t * n)(*[t.numel() * t.element_size() for t in self.tensors])
+            _lib.load().mkgnn_touch_hint(C.cast(ptrs, C.c_void_p), C.cast(nbytes, C.c_void_p), n)
+        return self
+
+    def __exit__(self, *exc):
+        if self.tensors:
+            self.taken = _lib.load().mkgnn_touch_hint(None, None, 0) == 0
+        return False
+
+
 def prepare_banks(params_per_call: Sequence[Sequence[torch.Tensor]], Fs: Sequence[int], E: int, n_atoms: int, n_slots: int,
                   side: Optional["torch.cuda.Stream"] = None):
     """``mkgnn_bank_prepare``: the normalised kernel banks of several forward calls (the layers of a model; call k will
@@ -195,7 +238,8 @@ def prepare_banks(params_per_call: Sequence[Sequence[torch.Tensor]], Fs: Sequenc
     stream -- the banks depend on the parameters only, and one small dependent launch per layer leaves the step.
     Returns one ``PreparedBank`` per call.  ``side``: launch on that stream instead (forked from the current one; buffers are
     still allocated on the current stream) -- the caller joins it, ``cur.wait_stream(side)``, before the first convolution: the
-    banks depend on nothing but the parameters, so the launch runs beside whatever precedes the convolutions (the batch norm)."""
+    banks depend on nothing but the parameters, so the launch runs beside whatever precedes the convolutions (the batch norm).
+    (Inside a ``touch_hint`` block that nothing has taken yet, the launch's spare blocks read the hinted arrays.)"""
     lib = _lib.load()
     dev = params_per_call[0][0].device
     out: List[PreparedBank] = []

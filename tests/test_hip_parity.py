@@ -1762,3 +1762,49 @@ def test_training_step_with_the_one_pass_index_builder(overlap, monkeypatch):
     for (l0, g0), (l1, g1) in zip(results["0"], results["1"]):
         assert torch.equal(l0, l1)
         assert g0.keys() == g1.keys() and all(torch.equal(g0[k], g1[k]) for k in g0)
+
+
+def test_touch_hint_is_taken_once_and_changes_nothing(monkeypatch):
+    """``mkgnn_touch_hint`` (ABI v7, ``functional.touch_hint``): the batch's index arrays are read by spare blocks of the batch norm's
+    statistics launch (training mode) or of the bank preparation -- by whichever comes first, once; a hint nobody takes is
+    withdrawn when the block is left; and no result depends on it: a training step's loss and gradients are bit for bit those of
+    ``MKGNN_TOUCH=0``."""
+    from molkgnn_amd import functional as Fn, readout as R
+    from molkgnn_amd.plan import plan_from_data
+    from molkgnn_amd.synthetic import make_batch
+    from molkgnn_amd.train import GNNModel, backward as train_backward
+    dev = _dev()
+    b = make_batch(300, seed=5).to(dev)
+    plan = plan_from_data(b)
+    arrays = Fn.plan_touch_list(plan)
+    assert 4 <= len(arrays) <= 16 and all(t.is_cuda for t in arrays)
+    bn = torch.nn.BatchNorm1d(28).to(dev)
+    with Fn.touch_hint(arrays) as h:                      # training mode: the statistics launch takes it
+        R.batch_norm(b.x, bn)
+    assert h.taken
+    bn.eval()
+    with Fn.touch_hint(arrays) as h:                      # eval mode: no statistics launch, nobody takes it -- withdrawn
+        R.batch_norm(b.x, bn)
+    assert not h.taken
+    with Fn.touch_hint(arrays) as h:                      # ... and a bank preparation does
+        layer = GNNModel().to(dev).gnn_model.gnn.layers[0]
+        params, E = layer._bank_params("train", b.x)
+        Fn.prepare_banks([params], [28], E, b.x.shape[0], plan.n_slots)
+    assert h.taken
+    with Fn.touch_hint([]) as h:
+        pass
+    assert not h.taken
+    torch.cuda.synchronize()
+
+    def step(touch):
+        monkeypatch.setattr(Fn, "TOUCH", touch)
+        torch.manual_seed(11)
+        model = GNNModel(ffn_dropout_rate=0.0).to(dev)
+        model.train()
+        loss = model.loss(b)
+        train_backward(loss)
+        torch.cuda.synchronize()
+        return float(loss), [p.grad.clone() for p in model.parameters() if p.grad is not None]
+    l1, g1 = step(True)
+    l0, g0 = step(False)
+    assert l1 == l0 and len(g1) == len(g0) and all(torch.equal(a, c) for a, c in zip(g1, g0))

@@ -46,7 +46,7 @@ def step():
 for _ in range(3):
     step()
 names = {"bank": ("tile coefficients", "operand preparation", "row products", "counted wait", "barrier", "DMA issue", "slab store"),
-         "rows": ("coefficients + next loads", "matrix products", "partial tile to LDS", "barrier", "finishing pass")}
+         "rows": ("coefficients + next loads", "matrix products", "partial tile to LDS", "barrier", "finishing pass", "prologue (before the lifetime)")}
 for which in ("bank", "rows"):
     buf = torch.zeros(1024 * 4 * 16, dtype=torch.int64, device=dev)
     setter = getattr(lib, f"mkgnn_debug_set_{which}_stream_stamps")
