@@ -189,10 +189,13 @@ struct TailMidArgs {
     float* emb; int64_t es;                 // [n_mols, G] or null
     float* pred;
     float* slab; int slab_stride;           // [blocks][slab_stride]: TAIL_* below
+    int mg;                                 // molecules per group: tail_group_size(n_loss)
 };
+constexpr int TAIL_MAX_BLOCKS = 768;        // (three workgroups per CU)
 // a workgroup's slab (floats): b1 [32] | W2 [32][32] | b2 [32] | wh [32] | bh | loss
 constexpr int TAIL_B1 = 0, TAIL_W2 = 32, TAIL_B2 = 32 + 1024, TAIL_WH = TAIL_B2 + 32, TAIL_BH = TAIL_WH + 32, TAIL_LOSS = TAIL_BH + 1,
               TAIL_SLAB = (TAIL_LOSS + 1 + 3) / 4 * 4;
+int tail_group_size(int64_t n_loss_mols);
 int tail_middle_blocks(int64_t n_loss_mols);
 hipError_t launch_tail_middle(const TailMidArgs& a, int nb, hipStream_t st);
 

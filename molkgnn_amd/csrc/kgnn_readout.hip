@@ -2109,7 +2109,7 @@ static TailWs tail_ws(const ReadoutDims& d, int64_t n_atoms, int64_t n_mols) {
     w.dz = up(w.z + (size_t)n_atoms * 32 * 4);
     w.slab_atoms = up(w.dz + (size_t)n_atoms * 32 * 4);
     w.slab_tail = up(w.slab_atoms + (size_t)2 * RO_ATOM_BLOCKS * w.slab_atoms_stride * 4);
-    w.total = up(w.slab_tail + (size_t)tail_middle_blocks(n_mols) * TAIL_SLAB * 4);      // (n_loss_mols <= n_mols: an upper bound)
+    w.total = up(w.slab_tail + (size_t)(n_mols < TAIL_MAX_BLOCKS ? n_mols : TAIL_MAX_BLOCKS) * TAIL_SLAB * 4);   // (an upper bound for any n_loss_mols <= n_mols)
     return w;
 }
 
@@ -2170,6 +2170,7 @@ int mkgnn_tail_fused(const mkgnn_tail_args* p, void* ws, size_t ws_bytes, void* 
     m.H = ro->H; m.G = ro->G; m.drop_p = p->dropout_p; m.rng = p->rng_state;
     m.emb = p->emb; m.es = p->emb_stride; m.pred = p->pred;
     m.slab = (float*)((char*)ws + w.slab_tail); m.slab_stride = TAIL_SLAB;
+    m.mg = tail_group_size(p->n_loss_mols);
     const int nbm = tail_middle_blocks(p->n_loss_mols);
     e = launch_tail_middle(m, nbm, st);
     if (e != hipSuccess) return api_hip_fail(who, e);

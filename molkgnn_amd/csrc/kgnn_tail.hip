@@ -41,7 +41,7 @@ namespace tail {
 
 constexpr int NT = 256;                 // threads per workgroup: 8 row slots x 32 hidden lanes
 constexpr int AC = MKGNN_TAIL_MAX_ATOMS, EC = MKGNN_TAIL_MAX_EDGES, MC = 12;      // chunk capacity: atoms, edges (each way), molecules
-constexpr int MG = 8;                   // molecules per group (the unit of work distribution: two chunks of ~100 atoms)
+constexpr int MG_MIN = 4, MG_MAX = 8;   // molecules per group (the unit of work distribution): tail_group_size below
 constexpr int HP = 36;                  // LDS pitch of the 32-wide rows: 16-byte aligned rows, 4 banks apart
 constexpr int WP = 33;                  // ... of W2's rows (read one float per lane: odd, conflict-free)
 typedef mkgnn_f32x4 f32x4;
@@ -149,6 +149,7 @@ __global__ void __launch_bounds__(NT, 3) tail_middle_kernel(TailMidArgs a) {
     // function of n_loss alone (tail_middle_blocks): which molecules share a workgroup, a chunk and a slab does not depend on
     // how many padding molecules follow the real ones, so a batch padded to a fixed shape (molkgnn_amd.padding) gives bit for
     // bit the loss and the gradients of the unpadded batch (the padding molecules add exact zeros)
+    const int MG = a.mg;
     const int64_t n_groups = (a.n_mols + MG - 1) / MG;
     int64_t grp = blockIdx.x;
     int64_t m_next = grp * MG;
@@ -395,9 +396,18 @@ __global__ void __launch_bounds__(NT, 3) tail_middle_kernel(TailMidArgs a) {
 
 }  // namespace tail
 
+// Molecules per group and workgroups, both functions of the number of REAL molecules alone (padding invariance: see the kernel).
+// Three workgroups fit a CU (52 KB of LDS each), and a workgroup's time is its group's: as many groups as there are slots -- up
+// to TAIL_MAX_BLOCKS = 3 x 256 -- of as few molecules as that allows.  Round 6 measured at 4 096 molecules: 8 per group (512
+// workgroups, two per CU) 42 us; 7 (586) and 6 (683) 36-37; 5 (820: a second round of workgroups) 43.
+int tail_group_size(int64_t n_loss_mols) {
+    const int64_t g = (n_loss_mols + TAIL_MAX_BLOCKS - 1) / TAIL_MAX_BLOCKS;
+    return (int)(g < tail::MG_MIN ? tail::MG_MIN : (g > tail::MG_MAX ? tail::MG_MAX : g));
+}
 int tail_middle_blocks(int64_t n_loss_mols) {
-    int64_t nb = (n_loss_mols + tail::MG - 1) / tail::MG;      // one group of real molecules per workgroup (padding molecules' groups wrap around),
-    if (nb > 512) nb = 512;                                    // and no more slabs than the reduction reads in a few batches
+    const int mg = tail_group_size(n_loss_mols);
+    int64_t nb = (n_loss_mols + mg - 1) / mg;                  // one group of real molecules per workgroup (padding molecules' groups wrap around),
+    if (nb > TAIL_MAX_BLOCKS) nb = TAIL_MAX_BLOCKS;            // and no more slabs than the reduction reads in a few batches
     return (int)(nb < 1 ? 1 : nb);
 }
 
@@ -406,6 +416,7 @@ extern "C" int mkgnn_debug_set_tail_stamps(void* device_ptr) {
 }
 
 hipError_t launch_tail_middle(const TailMidArgs& a, int nb, hipStream_t st) {
+    if (a.mg < tail::MG_MIN || a.mg > tail::MG_MAX || a.mg > tail::MC) return hipErrorInvalidValue;
     tail::tail_middle_kernel<<<nb, tail::NT, 0, st>>>(a);
     return hipGetLastError();
 }
