@@ -41,7 +41,7 @@ namespace tail {
 
 constexpr int NT = 256;                 // threads per workgroup: 8 row slots x 32 hidden lanes
 constexpr int AC = MKGNN_TAIL_MAX_ATOMS, EC = MKGNN_TAIL_MAX_EDGES, MC = 12;      // chunk capacity: atoms, edges (each way), molecules
-constexpr int MG_MIN = 4, MG_MAX = 8;   // molecules per group (the unit of work distribution): tail_group_size below
+constexpr int MG_MIN = 1, MG_MAX = 8;   // molecules per group (the unit of work distribution): tail_group_size below
 constexpr int HP = 36;                  // LDS pitch of the 32-wide rows: 16-byte aligned rows, 4 banks apart
 constexpr int WP = 33;                  // ... of W2's rows (read one float per lane: odd, conflict-free)
 typedef mkgnn_f32x4 f32x4;
