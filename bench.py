@@ -27,6 +27,17 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (guides/MI355X_MICROARCH
 FP32_VECTOR_PEAK_TFLOPS = 157.3
 
 
+def loss_backward(model, batch):
+    """``loss -> backward`` as one unit (readout.deferred_tail_reduce: the fused tail's last reduction rides on the backward's helper
+    stream); the loss is complete in stream order when this returns."""
+    from molkgnn_amd.readout import deferred_tail_reduce
+    from molkgnn_amd.train import backward as train_backward
+    with deferred_tail_reduce(batch.x.device):
+        loss = model.loss(batch)
+        train_backward(loss)
+    return loss
+
+
 def products_mode(variant: str) -> dict:
     """What the streamed kernels multiply with (read from the same environment switches the library reads)."""
     fwd = "bf16 operands (similarity variant)" if variant == "bf16" else (
@@ -208,14 +219,14 @@ def exact_fp32_leg(args, model, opt, dev, batches, log):
         with torch.cuda.stream(side):
             for b in batches[:2]:
                 model.zero_grad(set_to_none=True)
-                train_backward(model.loss(b))
+                loss_backward(model, b)
                 if opt is not None:
                     opt.step()
             for b in batches:
                 model.zero_grad(set_to_none=True)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=side):
-                    train_backward(model.loss(b))
+                    loss_backward(model, b)
                     if opt is not None:
                         opt.step()
                 graphs.append(g)
@@ -287,14 +298,14 @@ def small_batch_leg(args, model, opt, dev, log):
         with torch.cuda.stream(side):
             for b in batches[:2]:
                 model.zero_grad(set_to_none=True)
-                train_backward(model.loss(b))
+                loss_backward(model, b)
                 if opt is not None:
                     opt.step()
             for b in batches:
                 model.zero_grad(set_to_none=True)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=side):
-                    train_backward(model.loss(b))
+                    loss_backward(model, b)
                     if opt is not None:
                         opt.step()
                 graphs.append(g)
@@ -350,14 +361,14 @@ def small_batch_leg(args, model, opt, dev, log):
         """The same step launched eagerly (no graph: the reference's own training-loop style), host overhead included."""
         for i in range(10):
             model.zero_grad(set_to_none=True)
-            train_backward(model.loss(batches[i % 4]))
+            loss_backward(model, batches[i % 4])
             if opt is not None:
                 opt.step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(n):
             model.zero_grad(set_to_none=True)
-            train_backward(model.loss(batches[i % 4]))
+            loss_backward(model, batches[i % 4])
             if opt is not None:
                 opt.step()
         torch.cuda.synchronize()
@@ -497,8 +508,7 @@ def fresh_batches_leg(args, model, opt, dev, log):
     def step():
         attach_receptive_fields(sb.data, sizes=sb.data.bucket_sizes, overlap=True)
         model.zero_grad(set_to_none=True)
-        loss = model.loss(sb.data)
-        train_backward(loss)
+        loss = loss_backward(model, sb.data)
         if opt is not None:
             opt.step()
         return loss
@@ -558,8 +568,7 @@ def fresh_batches_leg(args, model, opt, dev, log):
                 csb.expand()
                 attach_receptive_fields(csb.data, sizes=csb.data.bucket_sizes, overlap=True)
                 model.zero_grad(set_to_none=True)
-                loss = model.loss(csb.data)
-                train_backward(loss)
+                loss = loss_backward(model, csb.data)
                 if opt is not None:
                     opt.step()
                 return loss
@@ -721,8 +730,7 @@ def main():
     def step(i):
         b = batches[i % nb]
         model.zero_grad(set_to_none=True)
-        loss = model.loss(b)
-        train_backward(loss)
+        loss = loss_backward(model, b)
         reducer.reduce()
         if opt is not None:
             opt.step()
@@ -752,7 +760,7 @@ def main():
                 if fill_in_graph and dp_path:            # (flag and zero tensors of every batch's gradient pattern are made
                     for bb in batches:                   # before the captures: a host-to-device copy cannot be captured)
                         model.zero_grad(set_to_none=True)
-                        train_backward(model.loss(bb))
+                        loss_backward(model, bb)
                         reducer.prepare_patterns([reducer.grads()])
                 # N > 1: RCCL's watchdog thread polls its events with HIP calls of its own; in the default ("global")
                 # capture mode such a call from another thread invalidates the capture
@@ -772,8 +780,8 @@ def main():
                     model.zero_grad(set_to_none=True)
                     g_fb = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g_fb, stream=side, **cap):
-                        static_loss = model.loss(batches[i])
-                        train_backward(static_loss)
+                        # (loss -> backward as one unit: the fused tail's last reduction rides on the backward's helper stream)
+                        static_loss = loss_backward(model, batches[i])
                         if opt is not None and not dp_path:
                             opt.step()
                         # this graph's gradient tensors: every captured graph writes into its own (p.grad names only the

@@ -377,10 +377,18 @@ typedef struct mkgnn_tail_args {
     float* pred; float* loss;
     float* grad_sim; int64_t grad_sim_stride;
     float *grad_lin1_weight, *grad_lin1_bias, *grad_lin2_weight, *grad_lin2_bias, *grad_head_weight, *grad_head_bias;
+    /* (ABI v7) != 0: the last launch -- the fixed-order reduction that writes loss, the six parameter gradients and advances the
+     * dropout generator; nothing before the optimiser reads any of them -- is NOT made by this call but by the calling thread's next
+     * mkgnn_kernelsetconv_backward that forks a helper stream (on that stream, in front of its bank kernel: off the chain the next
+     * layer's gradient waits for), or by mkgnn_tail_flush, whichever comes first.  grad_sim is complete when this call's launches
+     * are.  The caller MUST call mkgnn_tail_flush(stream) before anything reads those outputs on `stream`. */
+    int32_t defer_reduce;
 } mkgnn_tail_args;
 int mkgnn_tail_supported(int32_t K, int32_t H, int32_t G, const int32_t num_kernels[MKGNN_MAX_DEGREE]);
 size_t mkgnn_tail_workspace_bytes(int32_t K, int32_t H, int32_t G, int64_t n_atoms, int64_t n_mols);
 int mkgnn_tail_fused(const mkgnn_tail_args* args, void* workspace, size_t workspace_bytes, void* stream);
+/* Launches a reduction that a mkgnn_tail_fused call with defer_reduce left pending on this thread, on `stream` (no-op: none). */
+int mkgnn_tail_flush(void* stream);
 
 /* BatchNorm1d over atom rows, reference MolKGNNNet.py:115 (torch.nn.BatchNorm1d semantics: biased
  * variance for the normalisation, unbiased for running_var, running <- running + momentum (batch - running)).

@@ -57,7 +57,7 @@ class TailArgs(C.Structure):
                 ("emb", C.c_void_p), ("emb_stride", C.c_int64), ("pred", C.c_void_p), ("loss", C.c_void_p),
                 ("grad_sim", C.c_void_p), ("grad_sim_stride", C.c_int64), ("grad_lin1_weight", C.c_void_p),
                 ("grad_lin1_bias", C.c_void_p), ("grad_lin2_weight", C.c_void_p), ("grad_lin2_bias", C.c_void_p),
-                ("grad_head_weight", C.c_void_p), ("grad_head_bias", C.c_void_p)]
+                ("grad_head_weight", C.c_void_p), ("grad_head_bias", C.c_void_p), ("defer_reduce", C.c_int32)]
 
 
 TAIL_MAX_ATOMS, TAIL_MAX_EDGES = 128, 512      # MKGNN_TAIL_MAX_ATOMS / _EDGES
@@ -137,7 +137,7 @@ EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn
            "mkgnn_readout_blocks_workspace_bytes", "mkgnn_molecule_supported", "mkgnn_molecule_workspace_bytes",
            "mkgnn_molecule_step", "mkgnn_batchnorm_stats_workspace_bytes", "mkgnn_batchnorm_update_stats",
            "mkgnn_batchnorm_forward_with_stats", "mkgnn_index_workspace_bytes", "mkgnn_index_build",
-           "mkgnn_rows_split_supported", "mkgnn_rows_presplit", "mkgnn_tail_supported", "mkgnn_tail_workspace_bytes", "mkgnn_tail_fused")
+           "mkgnn_rows_split_supported", "mkgnn_rows_presplit", "mkgnn_tail_supported", "mkgnn_tail_workspace_bytes", "mkgnn_tail_fused", "mkgnn_tail_flush")
 
 _lib: Optional[C.CDLL] = None
 TORCH_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libmolkgnn_torch.so")
@@ -201,6 +201,8 @@ def load() -> C.CDLL:
     lib.mkgnn_tail_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64]
     lib.mkgnn_tail_fused.restype = C.c_int
     lib.mkgnn_tail_fused.argtypes = [C.POINTER(TailArgs), C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.mkgnn_tail_flush.restype = C.c_int
+    lib.mkgnn_tail_flush.argtypes = [C.c_void_p]
     lib.mkgnn_rows_presplit.restype = C.c_int
     lib.mkgnn_rows_presplit.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.mkgnn_rows_split_supported.restype = C.c_int

@@ -746,6 +746,10 @@ int mkgnn_kernelsetconv_backward(const mkgnn_kernel_bank banks[MKGNN_MAX_DEGREE]
     if (any_bank) {
         hipStream_t st_bank = fj.stream(1, &e);      // the helper (the caller's stream when nothing is forked)
         if (e != hipSuccess) return hip_fail("stream fork", e);
+        if (st_bank != st) {                         // a fused tail's deferred reduction rides in front of the bank kernel
+            e = launch_pending_tail_reduce(st_bank);
+            if (e != hipSuccess) return hip_fail("deferred tail reduction launch", e);
+        }
         {
             BwdTimer t(st_bank, 2);
             if (streamed) e = launch_backward_bank_stream(bsl, st_bank);

@@ -195,6 +195,8 @@ constexpr int TAIL_MAX_BLOCKS = 768;        // (three workgroups per CU)
 // a workgroup's slab (floats): b1 [32] | W2 [32][32] | b2 [32] | wh [32] | bh | loss
 constexpr int TAIL_B1 = 0, TAIL_W2 = 32, TAIL_B2 = 32 + 1024, TAIL_WH = TAIL_B2 + 32, TAIL_BH = TAIL_WH + 32, TAIL_LOSS = TAIL_BH + 1,
               TAIL_SLAB = (TAIL_LOSS + 1 + 3) / 4 * 4;
+// the fused tail's deferred reduction (mkgnn_tail_args.defer_reduce): launched on `st` if one is pending on this thread
+hipError_t launch_pending_tail_reduce(hipStream_t st, bool* launched = nullptr);
 int tail_group_size(int64_t n_loss_mols);
 int tail_middle_blocks(int64_t n_loss_mols);
 hipError_t launch_tail_middle(const TailMidArgs& a, int nb, hipStream_t st);

@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include "kgnn_common.h"
+#include <mutex>
+
 #include "kgnn_launch.h"
 #include "kgnn_philox.h"
 #include "kgnn_split.h"
@@ -421,6 +423,18 @@ struct SlabReduceArgs {
     SlabSeg seg[12]; int nseg;
     float drop_p; int64_t* rng; int64_t* rng_used;      // the fused tail: the head's dropout generator advances here, once per step
 };
+
+// (blk == 0: none) mkgnn_tail_args.defer_reduce.  Per DEVICE, not per thread: the forward that leaves it runs on the caller's
+// thread, the backward that takes it on autograd's.  (The header's rule -- one host thread per device inside these calls at a
+// time -- is what orders the two; the mutex only keeps the slot itself whole.)
+struct PendingReduce { SlabReduceArgs r; int blk; };
+static PendingReduce g_pending_reduce_dev[16];
+static std::mutex g_pending_reduce_mutex;
+static PendingReduce* pending_reduce_slot() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    return &g_pending_reduce_dev[dev];
+}
 
 __global__ void __launch_bounds__(256) slab_reduce_kernel(SlabReduceArgs a) {
     __shared__ float part[8][32];
@@ -2226,9 +2240,39 @@ int mkgnn_tail_fused(const mkgnn_tail_args* p, void* ws, size_t ws_bytes, void* 
     add(m.slab + TAIL_BH, TAIL_SLAB, nbm, 1, 1, 1, p->grad_head_bias, 0);
     add(m.slab + TAIL_LOSS, TAIL_SLAB, nbm, 1, 1, 1, p->loss, 0);
     r.drop_p = p->dropout_p; r.rng = p->rng_state; r.rng_used = p->rng_used;
+    // (a reduction an earlier call left pending and nobody took: now, in front of this one)
+    e = launch_pending_tail_reduce(st);
+    if (e != hipSuccess) return api_hip_fail(who, e);
+    if (p->defer_reduce && blk > 0) {                    // round 6: off the critical chain -- see mkgnn_tail_args.defer_reduce
+        std::lock_guard<std::mutex> lock(g_pending_reduce_mutex);
+        PendingReduce* slot = pending_reduce_slot();
+        slot->r = r; slot->blk = blk;
+        return 0;
+    }
     if (blk > 0) slab_reduce_kernel<<<blk, 256, 0, st>>>(r);
     e = hipGetLastError();
     return e == hipSuccess ? 0 : api_hip_fail(who, e);
+}
+
+extern "C++" {
+namespace mkgnn {
+hipError_t launch_pending_tail_reduce(hipStream_t st, bool* launched) {
+    if (launched) *launched = false;
+    std::lock_guard<std::mutex> lock(g_pending_reduce_mutex);
+    PendingReduce* slot = pending_reduce_slot();
+    if (slot->blk <= 0) return hipSuccess;
+    const int blk = slot->blk;
+    slot->blk = 0;
+    slab_reduce_kernel<<<blk, 256, 0, st>>>(slot->r);
+    if (launched) *launched = true;
+    return hipGetLastError();
+}
+}  // namespace mkgnn
+}
+
+extern "C" int mkgnn_tail_flush(void* stream) {
+    const hipError_t e = launch_pending_tail_reduce((hipStream_t)stream);
+    return e == hipSuccess ? 0 : api_hip_fail("mkgnn_tail_flush", e);
 }
 
 size_t mkgnn_batchnorm_workspace_bytes(int32_t C) { return C > 0 ? (size_t)2 * BN_BLOCKS * C * 4 : 0; }

@@ -647,6 +647,49 @@ def tail_supported(K: int, H: int, G: int, blocks) -> bool:
     return bool(_lib.load().mkgnn_tail_supported(int(K), int(H), int(G), _lib.Int32x4(*[int(b) for b in blocks])))
 
 
+# Round 6: inside ``deferred_tail_reduce()`` the fused tail leaves its last launch -- the fixed-order reduction that writes the loss
+# and the six parameter gradients, which nothing before the optimiser reads -- to the kernel convolution's backward, which makes it
+# on its helper stream in front of the bank kernel (``mkgnn_tail_args.defer_reduce``): 10 us off the chain the next layer's
+# gradient waits for.  Only ``train.training_step`` / ``train.CapturedSteps`` / bench.py open such a region, around
+# ``loss -> backward`` as ONE unit, and flush at its end; ``model.loss`` anywhere else returns a finished loss as before.
+_DEFER_TAIL_REDUCE = False
+_TAIL_HELD: list = []        # every tensor a pending reduction still reads or writes: referenced until the flush (the reduction runs on
+                             # another stream, later than the allocator's stream-ordered reuse of a freed block would allow)
+
+
+def tail_flush(device) -> None:
+    """``mkgnn_tail_flush``: a reduction the fused tail left pending on this thread is launched on the current stream now."""
+    try:
+        with torch.cuda.device(device):
+            _lib.check(_lib.load().mkgnn_tail_flush(_lib.stream_ptr(device)), "mkgnn_tail_flush")
+    finally:
+        _TAIL_HELD.clear()           # (launched, here or by the backward's helper stream which the caller's stream has joined)
+
+
+class deferred_tail_reduce:
+    """``with deferred_tail_reduce(device): loss = model.loss(batch); backward(loss)`` -- see ``_DEFER_TAIL_REDUCE``.  Leaving the
+    block launches whatever is still pending, on the current stream: behind it the loss and every gradient are complete in
+    stream order, exactly as without the block.  Inside it the loss tensor must not be read."""
+
+    def __init__(self, device):
+        self.device = device
+
+    def __enter__(self):
+        global _DEFER_TAIL_REDUCE
+        self.prev, _DEFER_TAIL_REDUCE = _DEFER_TAIL_REDUCE, _TAIL_DEFER_ENABLED
+        return self
+
+    def __exit__(self, *exc):
+        global _DEFER_TAIL_REDUCE
+        _DEFER_TAIL_REDUCE = self.prev
+        if not self.prev and self.device is not None and torch.device(self.device).type == "cuda":
+            tail_flush(self.device)
+        return False
+
+
+_TAIL_DEFER_ENABLED = os.environ.get("MKGNN_TAIL_DEFER", "1") != "0"
+
+
 class _TailFn(torch.autograd.Function):
     """``BCEWithLogitsLoss()(ffn(dropout(readout(propagate(sim)))), y)`` with every gradient for d loss = 1 in the same launch
     (``mkgnn_tail_fused``); the backward hands them out (scaled, if the incoming gradient is not the registered unit seed)."""
@@ -691,9 +734,18 @@ class _TailFn(torch.autograd.Function):
         a.grad_lin1_weight, a.grad_lin1_bias = gw1.data_ptr(), _lib.ptr(gb1)
         a.grad_lin2_weight, a.grad_lin2_bias = gw2.data_ptr(), _lib.ptr(gb2)
         a.grad_head_weight, a.grad_head_bias = gwh.data_ptr(), _lib.ptr(gbh)
+        # (deferred only where a backward will follow in the same region: the caller of deferred_tail_reduce promises it)
+        ctx.deferred = bool(_DEFER_TAIL_REDUCE and ctx.needs_input_grad[0])
+        a.defer_reduce = 1 if ctx.deferred else 0
+        ctx.params = (w1, b1, w2, b2, wh, bh)
+        ctx.dev = dev
         with torch.cuda.device(dev):
             ws = _tail_workspace(dev, int(lib.mkgnn_tail_workspace_bytes(K, H, G, n, seg.size)))
             _lib.check(lib.mkgnn_tail_fused(ctypes.byref(a), ws.data_ptr(), ws.numel(), _lib.stream_ptr(dev)), "mkgnn_tail_fused")
+        if ctx.deferred:
+            # (their STORAGES: a second reference to a gradient TENSOR would make autograd copy it into .grad instead of adopting
+            # it -- a copy made before the reduction has written it)
+            _TAIL_HELD.extend(t.untyped_storage() for t in (loss, gw1, gb1, gw2, gb2, gwh, gbh, rng, used, ws) if t is not None)
         ctx.unit = (gsim, gw1, gb1, gw2, gb2, gwh.reshape(wh.shape), gbh)
         ctx.pred = pred
         return loss
@@ -704,6 +756,12 @@ class _TailFn(torch.autograd.Function):
             raise RuntimeError("the fused tail keeps its gradients for ONE backward (retain_graph is not supported: "
                                "MKGNN_FUSED_TAIL=0 runs the separate operators)")
         grads, ctx.unit = ctx.unit, None
+        params, ctx.params = ctx.params, None
+        # a deferred reduction has not written the parameter gradients yet: fine as long as nothing on this stream touches them
+        # before the region's flush -- a scale by the incoming gradient or an accumulation into an existing .grad would
+        if ctx.deferred and (not _is_unit_seed(grad_loss) or torch.is_grad_enabled()
+                             or any(p is not None and p.grad is not None for p in params)):
+            tail_flush(ctx.dev)
         if not _is_unit_seed(grad_loss):                     # d loss is not the registered 1: scale
             gl = grad_loss.reshape(()).float()
             grads = tuple(None if g is None else g * gl for g in grads)

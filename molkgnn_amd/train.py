@@ -98,6 +98,21 @@ def backward(loss: torch.Tensor) -> None:
             loss.backward()
 
 
+def training_step(model, batch, optimizer=None) -> torch.Tensor:
+    """``loss = model.loss(batch); backward(loss); optimizer.step()`` as ONE unit (gradients start out as None): what a training loop
+    does per batch, with the licence that gives -- nothing reads the loss or a parameter gradient between the forward and the
+    optimiser, so the fused tail's last reduction leaves the critical chain (``readout.deferred_tail_reduce``).  Returns the loss
+    (complete, in stream order, when this returns).  Same kernels, same arithmetic, same bits as the three calls."""
+    from .readout import deferred_tail_reduce
+    model.zero_grad(set_to_none=True)
+    with deferred_tail_reduce(batch.x.device if batch.x.is_cuda else None):
+        loss = model.loss(batch)
+        backward(loss)
+    if optimizer is not None:
+        optimizer.step()
+    return loss
+
+
 def tune_torch_backends() -> None:
     """PyTorch-side knobs for the plain-PyTorch parts of the step (readout GEMMs).  The weight-gradient GEMM
     [32 x N] @ [N x 110] (N ~ 1e5) takes ~225 us through hipBLASLt and ~53 us through rocBLAS on MI355X."""
@@ -161,12 +176,7 @@ class CapturedSteps:
         return (id(batch), batch.x.data_ptr(), batch.x._version)
 
     def _eager(self, batch):
-        self.model.zero_grad(set_to_none=True)
-        loss = self.model.loss(batch)
-        backward(loss)
-        if self.optimizer is not None:
-            self.optimizer.step()
-        return loss.detach()
+        return training_step(self.model, batch, self.optimizer).detach()
 
     def __call__(self, batch):
         key = self._key(batch)
@@ -187,11 +197,7 @@ class CapturedSteps:
             self.model.zero_grad(set_to_none=True)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):
-                loss = self.model.loss(batch)
-                backward(loss)
-                if self.optimizer is not None:
-                    self.optimizer.step()
-                static_loss = loss.detach()
+                static_loss = training_step(self.model, batch, self.optimizer).detach()
         torch.cuda.current_stream(batch.x.device).wait_stream(side)
         self._graphs[key] = (graph, static_loss, batch)      # (the batch object is kept: its id stays its own)
         graph.replay()                                        # (a capture launches nothing: this visit's step)

@@ -226,3 +226,76 @@ def test_fused_tail_is_padding_invariant():
     assert torch.equal(res[0][0], res[1][0]), (float(res[0][0]), float(res[1][0]))
     for n, g in res[0][1].items():
         assert float((g - res[1][1][n]).abs().max()) <= 2e-5 * max(float(g.abs().max()), 1e-3) + 1e-7, n
+
+
+def test_deferred_tail_reduction_gives_the_same_step(monkeypatch):
+    """``train.training_step`` / ``readout.deferred_tail_reduce`` (round 6): inside the region the fused tail's last launch -- the
+    reduction that writes the loss and the six parameter gradients -- is made by the first kernel convolution backward on its helper
+    stream (spied: ``mkgnn_tail_flush`` at the region's end finds nothing left), and the step is bit for bit the three separate calls:
+    loss, every gradient, every parameter after AdamW.  A backward that must READ those gradients early -- a seed that is not the
+    registered one, a ``.grad`` that already exists -- flushes first and is still exact."""
+    from molkgnn_amd import readout as R
+    from molkgnn_amd.synthetic import make_batch
+    from molkgnn_amd.train import GNNModel, backward as train_backward, configure_optimizer, training_step
+    dev = _dev()
+    b = make_batch(600, seed=47).to(dev)
+
+    def fresh():
+        torch.manual_seed(1798)
+        model = GNNModel(ffn_dropout_rate=0.25).to(dev)
+        model.train()
+        R.reset_head_rng(dev, seed=99)
+        return model, configure_optimizer(model, lr=1e-3, capturable=True)
+
+    # (a) the three calls
+    model, opt = fresh()
+    model.zero_grad(set_to_none=True)
+    la = model.loss(b)
+    train_backward(la)
+    ga = {n: p.grad.clone() for n, p in model.named_parameters() if p.grad is not None}
+    opt.step()
+    torch.cuda.synchronize()
+    pa = {n: p.detach().clone() for n, p in model.named_parameters()}
+    # (b) one unit
+    flushed = []
+    real_flush = R.tail_flush
+
+    def spy_flush(device):
+        flushed.append(1)
+        return real_flush(device)
+    monkeypatch.setattr(R, "tail_flush", spy_flush)
+    model, opt = fresh()
+    lb = training_step(model, b, opt)
+    torch.cuda.synchronize()
+    assert flushed, "the region flushes at its end"
+    assert float(lb) == float(la)
+    for n, p in model.named_parameters():
+        assert torch.equal(p.detach(), pa[n]), n
+    # (c) gradients themselves, and the two early-read cases
+    model, opt = fresh()
+    model.zero_grad(set_to_none=True)
+    with R.deferred_tail_reduce(dev):
+        lc = model.loss(b)
+        train_backward(lc)
+    torch.cuda.synchronize()
+    gc = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    assert gc.keys() == ga.keys() and all(torch.equal(gc[n], ga[n]) for n in ga)
+    model, opt = fresh()
+    model.zero_grad(set_to_none=True)
+    with R.deferred_tail_reduce(dev):
+        ld = model.loss(b)
+        (2.0 * ld).backward()                            # not the registered unit seed: the tail's backward scales its gradients
+    torch.cuda.synchronize()
+    for n, p in model.named_parameters():
+        if n in ga:
+            assert torch.allclose(p.grad, 2.0 * ga[n], rtol=2e-5, atol=1e-7 * float(ga[n].abs().max())), n
+    model, opt = fresh()
+    for p in model.parameters():
+        p.grad = torch.ones_like(p)                      # existing gradients: autograd accumulates into them
+    with R.deferred_tail_reduce(dev):
+        le = model.loss(b)
+        le.backward()
+    torch.cuda.synchronize()
+    for n, p in model.named_parameters():
+        if n in ga:
+            assert torch.allclose(p.grad, 1.0 + ga[n], rtol=1e-6, atol=1e-6), n
