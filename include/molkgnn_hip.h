@@ -153,6 +153,17 @@ int mkgnn_rows_presplit(const float* x, int64_t x_stride, int64_t n_rows, int32_
  * a model prepares all its layers at the start of a step instead of one small dependent launch per layer. */
 int mkgnn_bank_prepare(int32_t count, const mkgnn_kernel_bank* banks, const int32_t* F, int32_t E,
                        void* const* workspaces, const size_t* workspace_bytes, void* stream);
+/* The same preparation left PENDING on the current device (ABI v7): nothing is launched; the next mkgnn_batchnorm_forward*
+ * (training mode) on this device carries its tasks in blocks behind its own statistics launch -- a launch bound by latency, where
+ * they cost nothing, instead of 5 us of launch floor on the chain in front of the first convolution -- or
+ * mkgnn_bank_prepare_flush(stream) launches it on its own, whichever comes first (mkgnn_bank_prepare flushes a pending one
+ * too).  banks, F and the workspaces are read at the LAUNCH: they must stay as they are until then.  The caller MUST flush (or
+ * mkgnn_bank_prepare_withdraw, which returns 1 if one was pending) before the first mkgnn_kernelsetconv_forward with
+ * MKGNN_VARIANT_BANK_PREPARED, and before the workspaces go.  One pending preparation per device. */
+int mkgnn_bank_prepare_deferred(int32_t count, const mkgnn_kernel_bank* banks, const int32_t* F, int32_t E,
+                                void* const* workspaces, const size_t* workspace_bytes);
+int mkgnn_bank_prepare_flush(void* stream);
+int mkgnn_bank_prepare_withdraw(void);
 /* A hint (ABI v7): `count` (<= 16) device arrays that the NEXT call of this host thread to mkgnn_bank_prepare or to
  * mkgnn_batchnorm_forward* (training mode) READS once and discards, with spare blocks of a launch it makes anyway -- the index
  * arrays of the batch the convolutions that follow will gather through (mkgnn_degree_bucket.selected_index / nei_index /

@@ -22,6 +22,9 @@ _BLOCK_ROWS = os.environ.get("MKGNN_DENSE_PROPAGATE") is None
 # (measured, round 6: the fork / join around the side stream costs the captured step what the overlap buys -- bank_prepare 5 us
 # beside the batch norm, 10 us of gap in front of the first convolution: 0.7307 against 0.7295 ms.  Kept as an opt-in.)
 _PREPARE_EARLY = os.environ.get("MKGNN_PREPARE_EARLY", "0") == "1"
+# round 6: the preparation is left PENDING in front of a caller's batch norm, whose statistics launch carries its tasks in blocks
+# of its own (functional.prepare_banks(defer=True)): the launch leaves the chain in front of the first convolution
+_PREPARE_DEFER = os.environ.get("MKGNN_PREPARE_DEFER", "1") != "0"
 _FUSE_PROPAGATE = _BLOCK_ROWS and os.environ.get("MKGNN_SPLIT_PROPAGATE") is None
 # h between two layers written as the pre-split rows the next layer's matrix instructions take (functional.ROWS_SPLIT, round 6);
 # MKGNN_ROWS_SPLIT=0: ordinary fp32 rows (A/B, diagnostics)
@@ -87,7 +90,16 @@ class MolGCN(MessagePassing):
         batch norm) overlaps the two; ``forward`` joins the stream in front of the first convolution.  A no-op where the
         one-launch preparation does not apply.  Opt-in, ``MKGNN_PREPARE_EARLY=1`` (in a captured step the fork / join costs what
         the overlap buys: see ``_PREPARE_EARLY``)."""
+        if x.is_cuda:
+            self.drop_pending_prepare(x.device)           # (one an earlier, interrupted forward left behind)
         self._early = None
+        if x.is_cuda and _PREPARE_ONCE and _PREPARE_DEFER and not _PREPARE_EARLY and self.num_layers <= 4 \
+                and all(layer._can_prepare() for layer in self.layers):
+            pl = [layer._bank_params("train", x) for layer in self.layers]
+            prepared = Fn.prepare_banks([p for p, _ in pl], [x.shape[1]] + [self.num_kernels(i) for i in range(self.num_layers - 1)],
+                                        pl[0][1], x.shape[0], n_slots, defer=True)
+            self._early = ((x.shape[0], x.shape[1], x.device), prepared, None)
+            return
         if not (x.is_cuda and _PREPARE_ONCE and _PREPARE_EARLY and all(layer._can_prepare() for layer in self.layers)):
             return
         from .plan import index_stream
@@ -98,6 +110,12 @@ class MolGCN(MessagePassing):
         prepared = Fn.prepare_banks([p for p, _ in pl], [x.shape[1]] + [self.num_kernels(i) for i in range(self.num_layers - 1)],
                                     pl[0][1], x.shape[0], n_slots, side=side)
         self._early = ((x.shape[0], x.shape[1], x.device), prepared, side)
+
+    def drop_pending_prepare(self, device) -> None:
+        """An error between ``prepare_banks_early`` and ``forward``: a preparation left pending is withdrawn (nothing else would)."""
+        early, self._early = getattr(self, "_early", None), None
+        if early is not None and early[2] is None and torch.device(device).type == "cuda":
+            Fn.prepare_withdraw(device)
 
     def set_variant(self, variant: str, backward_variant=None):
         for layer in self.layers:
@@ -135,10 +153,18 @@ class MolGCN(MessagePassing):
         # of width F_i = K_{i-1}): MKGNN_PREPARE_PER_LAYER=1 keeps one launch per layer (diagnostics)
         prepared = [None] * self.num_layers
         early, self._early = getattr(self, "_early", None), None
-        if early is not None and early[0] == (x.shape[0], x.shape[1], x.device):
-            # prepared beside the batch norm (prepare_banks_early): join the side stream here, in front of the first convolution
-            prepared, side = early[1], early[2]
-            torch.cuda.current_stream(x.device).wait_stream(side)
+        use_early = early is not None and early[0] == (x.shape[0], x.shape[1], x.device)
+        if early is not None and early[2] is None:
+            # left pending in front of the caller's batch norm (prepare_banks_early): whatever its statistics launch did not
+            # carry is launched now, in front of the first convolution (rows of another shape: dropped, prepared afresh below)
+            if use_early:
+                Fn.prepare_flush(x.device)
+            else:
+                Fn.prepare_withdraw(x.device)
+        elif use_early:                                  # prepared on the side stream: join it here
+            torch.cuda.current_stream(x.device).wait_stream(early[2])
+        if use_early:
+            prepared = early[1]
         elif x.is_cuda and _PREPARE_ONCE and all(layer._can_prepare() for layer in self.layers):
             n_slots = sum(int(fields[f'nei_index_deg{d}'].numel()) for d in range(1, 5))
             pl = [layer._bank_params("train", x) for layer in self.layers]

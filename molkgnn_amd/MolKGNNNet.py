@@ -114,43 +114,48 @@ class MolKGNNNet(torch.nn.Module):
             self.gnn.prepare_banks_early(data.x, sum(int(kw[f'nei_index_deg{d}'].numel()) for d in range(1, 5)))
             if _KL._ROWS_SPLIT:
                 split_x = self.gnn.layers[0]._accepts_split_rows(plan0, data.x)
-        # (round 6: spare blocks of the batch norm's statistics launch read the batch's index arrays once -- cold after the
-        # previous step's backward, and otherwise paid for by the first convolution: functional.touch_hint)
-        from . import functional as _Fn
-        with _Fn.touch_hint(_Fn.plan_touch_list(plan0) if plan0 is not None else None) as hint:
-            x = R.batch_norm(data.x, self.node_batch_norm, getattr(data, 'n_valid_atoms', None), companion=self._edge_stats(data),
-                             split_out=split_x)
-        if plan0 is not None:
-            plan0._touch_done = hint.taken
-        if getattr(data, '_rf_ready', None) is not None:     # degree buckets still being built on the index stream
-            from .receptive_field import await_receptive_fields
-            await_receptive_fields(data)
-        seg = None
-        if getattr(data, 'mol_ptr', None) is not None and getattr(data, 'atom_mol', None) is not None:
-            seg = R.MoleculeSegments.from_tensors(data.mol_ptr, data.atom_mol, getattr(data, 'max_mol_atoms', None),
-                                                  getattr(data, 'max_mol_edges', None))
-        # The last layer's output goes nowhere but through propagate into lin1: where it applies (large batches: it trades
-        # two big passes for three small ones), the readout takes the last convolution's BLOCK ROWS and projects them
-        # before the propagate step (readout.readout_blocks); MKGNN_PROJECT_FIRST=0 / 1 forces the choice (diagnostics)
-        blocks_out = []
-        lin1, lin2 = self.graph_embedding_lin1, self.graph_embedding_lin2
-        Ls = self.gnn.layers[-1].L
-        dims = (sum(Ls), lin1.weight.shape[0], lin2.weight.shape[0])
-        # (from _PROJECT_FIRST_ATOMS atoms on -- or at any size where the dense readout kernels do not take the shape, e.g. 160
-        # kernels per layer: the block-row form takes up to 255 columns and keeps such a model off the PyTorch-operator path)
-        # (... or at any size when the caller wants the loss itself: the fused tail -- readout.tail_loss -- starts from block rows)
-        no_drop = self.dropout is None or not self.dropout.training or self.dropout.p == 0.0
-        want_tail = (_tail is not None and R._FUSED_TAIL and torch.is_grad_enabled() and no_drop and x.is_cuda
-                     and R.tail_supported(*dims, Ls))
-        want = x.is_cuda and not save_score and (_PROJECT_FIRST == '1' or (_PROJECT_FIRST != '0' and (
-            x.shape[0] >= _PROJECT_FIRST_ATOMS or not R.readout_supported(*dims) or want_tail)))
-        if want:
-            want = R.readout_blocks_supported(*dims, Ls)
-        if want and seg is None:
-            seg = R.molecule_segments(data.batch, getattr(data, 'num_graphs', None))
-        want = want and seg.sorted and seg.size > 0
-        node_representation = self.gnn(x=x, edge_index=data.edge_index, edge_attr=data.edge_attr, p=data.p,
-                                       save_score=save_score, **kw, **({'_defer_last_propagate': blocks_out} if want else {}))
+        try:                                             # (a bank preparation may be pending from here to self.gnn: see except)
+            # (round 6: spare blocks of the batch norm's statistics launch read the batch's index arrays once -- cold after the
+            # previous step's backward, and otherwise paid for by the first convolution: functional.touch_hint)
+            from . import functional as _Fn
+            with _Fn.touch_hint(_Fn.plan_touch_list(plan0) if plan0 is not None else None) as hint:
+                x = R.batch_norm(data.x, self.node_batch_norm, getattr(data, 'n_valid_atoms', None), companion=self._edge_stats(data),
+                                 split_out=split_x)
+            if plan0 is not None:
+                plan0._touch_done = hint.taken
+            if getattr(data, '_rf_ready', None) is not None:     # degree buckets still being built on the index stream
+                from .receptive_field import await_receptive_fields
+                await_receptive_fields(data)
+            seg = None
+            if getattr(data, 'mol_ptr', None) is not None and getattr(data, 'atom_mol', None) is not None:
+                seg = R.MoleculeSegments.from_tensors(data.mol_ptr, data.atom_mol, getattr(data, 'max_mol_atoms', None),
+                                                      getattr(data, 'max_mol_edges', None))
+            # The last layer's output goes nowhere but through propagate into lin1: where it applies (large batches: it trades
+            # two big passes for three small ones), the readout takes the last convolution's BLOCK ROWS and projects them
+            # before the propagate step (readout.readout_blocks); MKGNN_PROJECT_FIRST=0 / 1 forces the choice (diagnostics)
+            blocks_out = []
+            lin1, lin2 = self.graph_embedding_lin1, self.graph_embedding_lin2
+            Ls = self.gnn.layers[-1].L
+            dims = (sum(Ls), lin1.weight.shape[0], lin2.weight.shape[0])
+            # (from _PROJECT_FIRST_ATOMS atoms on -- or at any size where the dense readout kernels do not take the shape, e.g. 160
+            # kernels per layer: the block-row form takes up to 255 columns and keeps such a model off the PyTorch-operator path)
+            # (... or at any size when the caller wants the loss itself: the fused tail -- readout.tail_loss -- starts from block rows)
+            no_drop = self.dropout is None or not self.dropout.training or self.dropout.p == 0.0
+            want_tail = (_tail is not None and R._FUSED_TAIL and torch.is_grad_enabled() and no_drop and x.is_cuda
+                         and R.tail_supported(*dims, Ls))
+            want = x.is_cuda and not save_score and (_PROJECT_FIRST == '1' or (_PROJECT_FIRST != '0' and (
+                x.shape[0] >= _PROJECT_FIRST_ATOMS or not R.readout_supported(*dims) or want_tail)))
+            if want:
+                want = R.readout_blocks_supported(*dims, Ls)
+            if want and seg is None:
+                seg = R.molecule_segments(data.batch, getattr(data, 'num_graphs', None))
+            want = want and seg.sorted and seg.size > 0
+            node_representation = self.gnn(x=x, edge_index=data.edge_index, edge_attr=data.edge_attr, p=data.p,
+                                           save_score=save_score, **kw, **({'_defer_last_propagate': blocks_out} if want else {}))
+        except BaseException:
+            # the deferred bank preparation (MolGCN.prepare_banks_early) must not outlive this call: its workspaces would
+            self.gnn.drop_pending_prepare(data.x.device)
+            raise
         if node_representation is None:                     # the last propagate was left to the readout
             sim_sc, plan, Ls = blocks_out[0]
             # (private: train.GNNModel.loss asks for the loss itself -- readout, head, loss and all their gradients in one

@@ -132,7 +132,7 @@ EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn
            "mkgnn_batchnorm_backward", "mkgnn_bce_head_workspace_bytes", "mkgnn_bce_head_forward",
            "mkgnn_bce_head_backward", "mkgnn_rf_workspace_bytes", "mkgnn_rf_count", "mkgnn_rf_fill", "mkgnn_adamw_step", "mkgnn_adamw_state_floats",
            "mkgnn_bce_head_dropout_forward", "mkgnn_bce_head_dropout_backward", "mkgnn_segment_sum_block_rows",
-           "mkgnn_plan_workspace_bytes", "mkgnn_plan_build", "mkgnn_backward_join", "mkgnn_backward_streams", "mkgnn_bank_prepare", "mkgnn_touch_hint", "mkgnn_expand_batch", "mkgnn_bce_head_fused", "mkgnn_collate_compact", "mkgnn_collate_compact_bytes",
+           "mkgnn_plan_workspace_bytes", "mkgnn_plan_build", "mkgnn_backward_join", "mkgnn_backward_streams", "mkgnn_bank_prepare", "mkgnn_bank_prepare_deferred", "mkgnn_bank_prepare_flush", "mkgnn_bank_prepare_withdraw", "mkgnn_touch_hint", "mkgnn_expand_batch", "mkgnn_bce_head_fused", "mkgnn_collate_compact", "mkgnn_collate_compact_bytes",
            "mkgnn_readout_blocks_supported", "mkgnn_readout_blocks_forward", "mkgnn_readout_blocks_backward",
            "mkgnn_readout_blocks_workspace_bytes", "mkgnn_molecule_supported", "mkgnn_molecule_workspace_bytes",
            "mkgnn_molecule_step", "mkgnn_batchnorm_stats_workspace_bytes", "mkgnn_batchnorm_update_stats",
@@ -209,6 +209,12 @@ def load() -> C.CDLL:
     lib.mkgnn_rows_split_supported.argtypes = [Banks4, Buckets4, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int32]
     lib.mkgnn_bank_prepare.restype = C.c_int
     lib.mkgnn_bank_prepare.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mkgnn_bank_prepare_deferred.restype = C.c_int
+    lib.mkgnn_bank_prepare_deferred.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.mkgnn_bank_prepare_flush.restype = C.c_int
+    lib.mkgnn_bank_prepare_flush.argtypes = [C.c_void_p]
+    lib.mkgnn_bank_prepare_withdraw.restype = C.c_int
+    lib.mkgnn_bank_prepare_withdraw.argtypes = []
     lib.mkgnn_touch_hint.restype = C.c_int
     lib.mkgnn_touch_hint.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.mkgnn_collate_compact_bytes.restype = C.c_size_t

@@ -391,12 +391,61 @@ int mkgnn_touch_hint(const void* const* arrays, const size_t* bytes, int32_t cou
     return 0;
 }
 
+// a preparation left pending by mkgnn_bank_prepare_deferred: per device (armed and taken by the forward's thread; the mutex keeps
+// the slot whole)
+struct PendingPrepare { PrepManyArgs m; bool armed; };
+static PendingPrepare g_pending_prepare[16];
+static std::mutex g_pending_prepare_mutex;
+static PendingPrepare* pending_prepare_slot() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    return &g_pending_prepare[dev];
+}
+extern "C++" {
+namespace mkgnn {
+bool take_pending_prepare(PrepManyArgs& out) {
+    std::lock_guard<std::mutex> lock(g_pending_prepare_mutex);
+    PendingPrepare* p = pending_prepare_slot();
+    if (!p->armed) return false;
+    out = p->m;
+    p->armed = false;
+    return true;
+}
+}  // namespace mkgnn
+}
+
+static int bank_prepare_impl(const char* who, int32_t count, const mkgnn_kernel_bank* banks, const int32_t* F, int32_t E,
+                             void* const* workspaces, const size_t* workspace_bytes, bool defer, void* stream);
+
+int mkgnn_bank_prepare_deferred(int32_t count, const mkgnn_kernel_bank* banks, const int32_t* F, int32_t E, void* const* workspaces,
+                                const size_t* workspace_bytes) {
+    return bank_prepare_impl("mkgnn_bank_prepare_deferred", count, banks, F, E, workspaces, workspace_bytes, true, nullptr);
+}
+
+int mkgnn_bank_prepare_flush(void* stream) {
+    PrepManyArgs m;
+    if (!take_pending_prepare(m)) return 0;
+    (void)take_touch_hint(m.touch);
+    hipError_t e = launch_bank_prepare_args(m, (hipStream_t)stream);
+    return e == hipSuccess ? 0 : hip_fail("mkgnn_bank_prepare_flush", e);
+}
+
+int mkgnn_bank_prepare_withdraw(void) {
+    PrepManyArgs m;
+    return take_pending_prepare(m) ? 1 : 0;
+}
+
 int mkgnn_bank_prepare(int32_t count, const mkgnn_kernel_bank* banks, const int32_t* F, int32_t E, void* const* workspaces,
                        const size_t* workspace_bytes, void* stream) {
-    const char* who = "mkgnn_bank_prepare";
+    if (int rc = mkgnn_bank_prepare_flush(stream)) return rc;        // (one left pending and never taken: first, in order)
+    return bank_prepare_impl("mkgnn_bank_prepare", count, banks, F, E, workspaces, workspace_bytes, false, stream);
+}
+
+static int bank_prepare_impl(const char* who, int32_t count, const mkgnn_kernel_bank* banks, const int32_t* F, int32_t E,
+                             void* const* workspaces, const size_t* workspace_bytes, bool defer, void* stream) {
     if (count < 0 || count > PREP_MANY_MAX) return fail("%s: %d calls (0..%d per launch)", who, count, PREP_MANY_MAX);
     TouchArgs ta{};
-    (void)take_touch_hint(ta);
+    if (!defer) (void)take_touch_hint(ta);
     if (count == 0 && ta.count == 0) return 0;
     if (count > 0 && (!banks || !F || !workspaces || !workspace_bytes || E <= 0)) return fail("%s: bad arguments", who);
     WorkspaceLayout w[PREP_MANY_MAX];
@@ -418,6 +467,15 @@ int mkgnn_bank_prepare(int32_t count, const mkgnn_kernel_bank* banks, const int3
             return fail("%s: call %d: workspace of %zu bytes, the banks need %zu", who, k, workspace_bytes[k], w[k].bank[3].end);
         ws[k] = (char*)workspaces[k];
         Fs[k] = F[k];
+    }
+    if (defer) {
+        if (count > PREP_MANY_MAX) return fail("%s: at most %d calls", who, PREP_MANY_MAX);
+        std::lock_guard<std::mutex> lock(g_pending_prepare_mutex);
+        PendingPrepare* p = pending_prepare_slot();
+        if (p->armed) return fail("%s: a deferred preparation is already pending on this device (mkgnn_bank_prepare_flush)", who);
+        build_bank_prepare_many(count, banks, w, ws, Fs, E, &p->m);
+        p->armed = p->m.prep_blocks > 0;
+        return 0;
     }
     hipError_t e = launch_bank_prepare_many(count, banks, w, ws, Fs, E, (hipStream_t)stream, ta.count ? &ta : nullptr);
     return e == hipSuccess ? 0 : hip_fail(who, e);

@@ -126,6 +126,12 @@ __device__ __forceinline__ void touch_body(const TouchArgs& t, uint32_t b, uint3
 struct PrepManyArgs { PrepArgs layer[PREP_MANY_MAX]; int task_start[PREP_MANY_MAX + 1]; int count; int prep_blocks; TouchArgs touch; };
 hipError_t launch_bank_prepare_many(int count, const mkgnn_kernel_bank* banks /* [count][4] */, const WorkspaceLayout* w,
                                     char* const* ws, const int* F, int E, hipStream_t st, const TouchArgs* touch = nullptr);
+// the same preparation as arguments only (tasks and blocks filled in): for a launch that carries it in blocks of its own
+void build_bank_prepare_many(int count, const mkgnn_kernel_bank* banks, const WorkspaceLayout* w, char* const* ws, const int* F,
+                             int E, PrepManyArgs* out);
+hipError_t launch_bank_prepare_args(const PrepManyArgs& m, hipStream_t st);
+// a preparation mkgnn_bank_prepare_deferred left pending on this device (kgnn_capi.hip); clears it
+bool take_pending_prepare(PrepManyArgs& out);
 hipError_t launch_bank_prepare(const mkgnn_kernel_bank banks[4], const WorkspaceLayout& w, char* ws, int F, int E,
                                hipStream_t st);
 hipError_t launch_forward_generic(int d, const FwdArgs& a, hipStream_t st);

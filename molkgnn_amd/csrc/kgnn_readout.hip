@@ -24,6 +24,7 @@
 
 #include "kgnn_launch.h"
 #include "kgnn_philox.h"
+#include "kgnn_prepare.h"
 #include "kgnn_split.h"
 #include "../../include/molkgnn_hip.h"
 
@@ -1208,6 +1209,9 @@ __global__ void __launch_bounds__(256) bn_side_kernel(BnSide s, int phase) {
     if (phase == 2 || phase == 3) bn_side_final(s, sh);
 }
 
+// what rides behind the statistics launch's own blocks: [touch_first, prep_first) read the hinted arrays (mkgnn_touch_hint),
+// [prep_first, grid) run a pending bank preparation (mkgnn_bank_prepare_deferred) -- both independent of the batch norm, both
+// otherwise paid for on the chain in front of the first convolution
 template <bool VEC>
 __global__ void __launch_bounds__(256) bn_stats_kernel(BnArgs a, int CL) {
     __shared__ float sh[1024];
@@ -1219,6 +1223,25 @@ __global__ void __launch_bounds__(256) bn_stats_kernel(BnArgs a, int CL) {
         bn_side_stats_any(a.side, blockIdx.x - BN_MAIN_BLOCKS, sh);
         if (a.side.nblk == 1) {                          // a companion of one block's worth of rows: all of it here, in this launch
             __syncthreads();                             // (its own global stores are visible to the block behind a barrier)
+            bn_side_final(a.side, sh);
+        }
+        return;
+    }
+    bn_block_stats<VEC>(a, CL, sh);
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(256) bn_stats_prep_kernel(BnArgs a, int CL, PrepManyArgs pm, int prep_first) {
+    __shared__ float sh[1024];
+    if ((int)blockIdx.x >= prep_first) { bank_prepare_many_block(pm, blockIdx.x - prep_first); return; }
+    if ((int)blockIdx.x >= a.touch_first) {
+        touch_body(a.touch, blockIdx.x - a.touch_first, prep_first - a.touch_first);
+        return;
+    }
+    if (blockIdx.x >= BN_MAIN_BLOCKS) {
+        bn_side_stats_any(a.side, blockIdx.x - BN_MAIN_BLOCKS, sh);
+        if (a.side.nblk == 1) {
+            __syncthreads();
             bn_side_final(a.side, sh);
         }
         return;
@@ -2372,7 +2395,13 @@ int mkgnn_batchnorm_forward_with_stats(const float* x, int64_t x_stride, int64_t
             a.touch.count = 0;
             a.touch_first = BN_BLOCKS + a.side.nblk;
             const int extra = take_touch_hint(a.touch) ? TOUCH_BLOCKS : 0;
-            if (bn_vec_rows(x, x_stride, C)) bn_stats_kernel<true><<<BN_BLOCKS + a.side.nblk + extra, 256, 0, st>>>(a, CL);
+            PrepManyArgs pm;
+            if (take_pending_prepare(pm)) {              // ... and behind those a pending bank preparation's tasks
+                pm.touch.count = 0;
+                const int prep_first = a.touch_first + extra;
+                if (bn_vec_rows(x, x_stride, C)) bn_stats_prep_kernel<true><<<prep_first + pm.prep_blocks, 256, 0, st>>>(a, CL, pm, prep_first);
+                else bn_stats_prep_kernel<false><<<prep_first + pm.prep_blocks, 256, 0, st>>>(a, CL, pm, prep_first);
+            } else if (bn_vec_rows(x, x_stride, C)) bn_stats_kernel<true><<<BN_BLOCKS + a.side.nblk + extra, 256, 0, st>>>(a, CL);
             else bn_stats_kernel<false><<<BN_BLOCKS + a.side.nblk + extra, 256, 0, st>>>(a, CL);
             a.touch.count = 0;
         }

@@ -232,14 +232,19 @@ class touch_hint:
 
 
 def prepare_banks(params_per_call: Sequence[Sequence[torch.Tensor]], Fs: Sequence[int], E: int, n_atoms: int, n_slots: int,
-                  side: Optional["torch.cuda.Stream"] = None):
+                  side: Optional["torch.cuda.Stream"] = None, defer: bool = False):
     """``mkgnn_bank_prepare``: the normalised kernel banks of several forward calls (the layers of a model; call k will
     be ``kernelsetconv(x [n_atoms, Fs[k]], ..., params_per_call[k], E, prepared=result[k])``) in ONE launch on the current
     stream -- the banks depend on the parameters only, and one small dependent launch per layer leaves the step.
     Returns one ``PreparedBank`` per call.  ``side``: launch on that stream instead (forked from the current one; buffers are
     still allocated on the current stream) -- the caller joins it, ``cur.wait_stream(side)``, before the first convolution: the
     banks depend on nothing but the parameters, so the launch runs beside whatever precedes the convolutions (the batch norm).
-    (Inside a ``touch_hint`` block that nothing has taken yet, the launch's spare blocks read the hinted arrays.)"""
+    (Inside a ``touch_hint`` block that nothing has taken yet, the launch's spare blocks read the hinted arrays.)
+    ``defer`` (round 6, ``mkgnn_bank_prepare_deferred``; at most 4 calls): nothing is launched -- the preparation is left pending for
+    the batch norm's statistics launch that follows (it carries the tasks in blocks of its own), or for ``prepare_flush``; the caller
+    MUST call ``prepare_flush`` before the first convolution reads a prepared bank (``prepare_withdraw`` on an error path)."""
+    if defer and len(params_per_call) > 4:
+        defer = False
     lib = _lib.load()
     dev = params_per_call[0][0].device
     out: List[PreparedBank] = []
@@ -265,6 +270,14 @@ def prepare_banks(params_per_call: Sequence[Sequence[torch.Tensor]], Fs: Sequenc
                 cur = torch.cuda.current_stream(dev)
                 if side is not None and side != cur:
                     side.wait_stream(cur)
+                if defer:
+                    _lib.check(lib.mkgnn_bank_prepare_deferred(cnt, C.cast(banks_all, C.c_void_p), C.cast(Farr, C.c_void_p), E,
+                                                               C.cast(wsarr, C.c_void_p), C.cast(nbarr, C.c_void_p)),
+                               "mkgnn_bank_prepare_deferred")
+                    _PREPARE_HELD[:] = [keep, wss]       # (read at the launch: alive until the flush)
+                    for k, params in enumerate(chunk):
+                        out.append(PreparedBank(wss[k], _prepared_key(params, Fs[lo + k], E, n_atoms, n_slots)))
+                    continue
                 with torch.cuda.stream(side if side is not None else cur):
                     _lib.check(lib.mkgnn_bank_prepare(cnt, C.cast(banks_all, C.c_void_p), C.cast(Farr, C.c_void_p), E,
                                                       C.cast(wsarr, C.c_void_p), C.cast(nbarr, C.c_void_p), _lib.stream_ptr(dev)),
@@ -272,6 +285,28 @@ def prepare_banks(params_per_call: Sequence[Sequence[torch.Tensor]], Fs: Sequenc
             for k, params in enumerate(chunk):
                 out.append(PreparedBank(wss[k], _prepared_key(params, Fs[lo + k], E, n_atoms, n_slots)))
     return out
+
+
+_PREPARE_HELD: list = []     # what a pending (deferred) bank preparation will read
+
+
+def prepare_flush(device) -> None:
+    """``mkgnn_bank_prepare_flush``: a deferred bank preparation nobody has carried yet is launched on the current stream (no-op:
+    none pending)."""
+    try:
+        with torch.cuda.device(device):
+            _lib.check(_lib.load().mkgnn_bank_prepare_flush(_lib.stream_ptr(device)), "mkgnn_bank_prepare_flush")
+    finally:
+        _PREPARE_HELD.clear()
+
+
+def prepare_withdraw(device) -> bool:
+    """``mkgnn_bank_prepare_withdraw``: drop a pending preparation (an error path: its workspaces are about to go)."""
+    try:
+        with torch.cuda.device(device):
+            return bool(_lib.load().mkgnn_bank_prepare_withdraw())
+    finally:
+        _PREPARE_HELD.clear()
 
 
 def _forward_impl(x, plan: BatchPlan, is_last_layer: bool, variant: int, out_pad: int, E: int, params, want_saved: bool,

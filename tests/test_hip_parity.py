@@ -1808,3 +1808,57 @@ def test_touch_hint_is_taken_once_and_changes_nothing(monkeypatch):
     l1, g1 = step(True)
     l0, g0 = step(False)
     assert l1 == l0 and len(g1) == len(g0) and all(torch.equal(a, c) for a, c in zip(g1, g0))
+
+
+def test_deferred_bank_preparation_is_carried_by_the_batch_norm_and_changes_nothing(monkeypatch):
+    """``mkgnn_bank_prepare_deferred`` (ABI v7, ``functional.prepare_banks(defer=True)``): the preparation left pending is carried by
+    blocks of the next training-mode batch norm's statistics launch (``mkgnn_bank_prepare_flush`` then finds nothing), or launched by
+    the flush (eval-mode batch norm: no statistics launch); either way the prepared workspaces are byte for byte those of the
+    immediate launch, and a training step of the model is bit for bit the step with ``MKGNN_PREPARE_DEFER=0``."""
+    from molkgnn_amd import KernelLayer as KL, functional as Fn, readout as R
+    from molkgnn_amd.plan import plan_from_data
+    from molkgnn_amd.synthetic import make_batch
+    from molkgnn_amd.train import GNNModel, backward as train_backward
+    dev = _dev()
+    b = make_batch(300, seed=5).to(dev)
+    plan = plan_from_data(b)
+    torch.manual_seed(3)
+    gnn = GNNModel().to(dev).gnn_model.gnn
+    pl = [layer._bank_params("train", b.x) for layer in gnn.layers]
+    Fs = [28, 110, 110]
+    args = ([p for p, _ in pl], Fs, pl[0][1], b.x.shape[0], plan.n_slots)
+    lib = R._lib.load()
+    xs = [b.x] + [torch.randn(b.x.shape[0], 112, device=dev)[:, :110] for _ in range(2)]
+
+    def outputs(prepared):
+        """every layer's forward on the prepared banks (the kernels read nothing of the parameters but what the preparation wrote)"""
+        with torch.no_grad():
+            return [Fn._forward_impl(xs[k], plan, k == 2, Fn.VARIANTS["auto"], 0, pl[k][1], [p.detach() for p in pl[k][0]], False,
+                                     None, prepared[k])[1].clone() for k in range(3)]
+    want = outputs(Fn.prepare_banks(*args))
+    for training in (True, False):
+        bn = torch.nn.BatchNorm1d(28).to(dev)
+        bn.train(training)
+        got = Fn.prepare_banks(*args, defer=True)
+        R.batch_norm(b.x, bn)
+        pending = int(lib.mkgnn_bank_prepare_withdraw())
+        assert pending == (0 if training else 1), (training, pending)
+        if not training:                                  # nobody carried it: arm again and flush
+            got = Fn.prepare_banks(*args, defer=True)
+            Fn.prepare_flush(dev)
+            assert int(lib.mkgnn_bank_prepare_withdraw()) == 0
+        for k, (w, g) in enumerate(zip(want, outputs(got))):
+            assert torch.equal(w, g), (training, k)
+
+    def step(defer):
+        monkeypatch.setattr(KL, "_PREPARE_DEFER", defer)
+        torch.manual_seed(11)
+        model = GNNModel(ffn_dropout_rate=0.0).to(dev)
+        model.train()
+        loss = model.loss(b)
+        train_backward(loss)
+        torch.cuda.synchronize()
+        return float(loss), [p.grad.clone() for p in model.parameters() if p.grad is not None]
+    l1, g1 = step(True)
+    l0, g0 = step(False)
+    assert l1 == l0 and len(g1) == len(g0) and all(torch.equal(a, c) for a, c in zip(g1, g0))

@@ -10,7 +10,7 @@ path = sys.argv[1]
 if os.path.isdir(path):
     path = sorted(glob.glob(os.path.join(path, "**", "*kernel_trace.csv"), recursive=True))[-1]
 rows = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if any(k in r["Kernel_Name"] for k in ("bn_forward_fused_kernel", "bn_stats_kernel", "bn_sum_kernel"))]
+marks = [i for i, r in enumerate(rows) if any(k in r["Kernel_Name"] for k in ("bn_forward_fused_kernel", "bn_stats_kernel", "bn_stats_prep_kernel", "bn_sum_kernel"))]
 s, e = marks[-3], marks[-2]
 t0 = int(rows[s]["Start_Timestamp"])
 print("# start_us  duration_us  queue  kernel")
