@@ -758,7 +758,10 @@ __global__ void __launch_bounds__(256) block_project_bwd_mfma_kernel(BlockProjAr
 // call is its side effect in training mode -- running_mean / running_var / num_batches_tracked move.  The rows are summed
 // by extra blocks of the node batch norm's own two launches (no launch of their own in a step), or by
 // mkgnn_batchnorm_update_stats alone.  part: [3][nblk][C] = column sums | squares about the block's own means | counted rows.
-constexpr int BN_MAIN_BLOCKS = 256;                    // (= BN_BLOCKS: the grid of the batch norm's own passes)
+#ifndef MKGNN_BN_BLOCKS                  // (A/B builds)
+#define MKGNN_BN_BLOCKS 256
+#endif
+constexpr int BN_MAIN_BLOCKS = MKGNN_BN_BLOCKS;        // (= BN_BLOCKS: the grid of the batch norm's own passes)
 constexpr int BN_SIDE_BLOCKS = 1024;                   // companion blocks at most (one loop trip per pass each where that is enough)
 struct BnSide {
     const float* x; int64_t xs; int64_t n; int C, CL, nblk;
@@ -1834,7 +1837,7 @@ bool readout_dims(int F, int H, int G, ReadoutDims& d) {
 
 constexpr int RO_ATOM_BLOCKS = 256;
 constexpr int RO_MOL_BLOCKS = 256;      // 16 molecules per block at batch 4096: one LDS chunk each
-constexpr int BN_BLOCKS = 256;
+constexpr int BN_BLOCKS = BN_MAIN_BLOCKS;
 
 struct ReadoutWs { size_t dA, slab_atoms, slab_mol, total; int slab_atoms_stride, slab_mol_stride; };
 
