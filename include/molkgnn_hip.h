@@ -572,6 +572,12 @@ int mkgnn_bce_head_fused(const float* emb, int64_t emb_stride, int64_t n_rows, i
  * learning rate either by value (lr_device NULL) or read from a device float at run time (so that a captured graph
  * follows a scheduler), betas, eps, decoupled weight_decay, maximize, grad_scale.  The update is torch's fused AdamW formula
  * (bias corrections 1 - beta^step).  At most 4 groups; any number of tensors (80 per launch). */
+/* (ABI v7) n_items small float tensors, each into its destination, in one launch (ceil(numel / 1024) blocks each): the
+ * data-parallel step's gradients into the flat buffer one collective sums (dp.FlatGradAllReduce), where torch._foreach_copy_
+ * takes two multi-tensor launches.  Sources and destinations must not overlap; graph-capturable (pointers are baked in). */
+typedef struct mkgnn_copy_item { float* dst; const float* src; int64_t numel; } mkgnn_copy_item;
+int mkgnn_flat_copy(const mkgnn_copy_item* items, int32_t n_items, void* stream);
+
 typedef struct mkgnn_adamw_tensor {
     float* param;
     const float* grad;

@@ -63,6 +63,11 @@ class TailArgs(C.Structure):
 TAIL_MAX_ATOMS, TAIL_MAX_EDGES = 128, 512      # MKGNN_TAIL_MAX_ATOMS / _EDGES
 
 
+class CopyItem(C.Structure):
+    """``mkgnn_copy_item``."""
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("numel", C.c_int64)]
+
+
 class AdamWTensor(C.Structure):
     _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("state", C.c_void_p), ("numel", C.c_int64),
                 ("group", C.c_int32), ("reserved", C.c_int32), ("active", C.c_void_p)]
@@ -137,7 +142,7 @@ EXPORTS = ("mkgnn_abi_version", "mkgnn_last_error", "mkgnn_row_inv_norm", "mkgnn
            "mkgnn_readout_blocks_workspace_bytes", "mkgnn_molecule_supported", "mkgnn_molecule_workspace_bytes",
            "mkgnn_molecule_step", "mkgnn_batchnorm_stats_workspace_bytes", "mkgnn_batchnorm_update_stats",
            "mkgnn_batchnorm_forward_with_stats", "mkgnn_index_workspace_bytes", "mkgnn_index_build",
-           "mkgnn_rows_split_supported", "mkgnn_rows_presplit", "mkgnn_tail_supported", "mkgnn_tail_workspace_bytes", "mkgnn_tail_fused", "mkgnn_tail_flush")
+           "mkgnn_rows_split_supported", "mkgnn_rows_presplit", "mkgnn_tail_supported", "mkgnn_tail_workspace_bytes", "mkgnn_tail_fused", "mkgnn_tail_flush", "mkgnn_flat_copy")
 
 _lib: Optional[C.CDLL] = None
 TORCH_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libmolkgnn_torch.so")
@@ -201,6 +206,8 @@ def load() -> C.CDLL:
     lib.mkgnn_tail_workspace_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_int64]
     lib.mkgnn_tail_fused.restype = C.c_int
     lib.mkgnn_tail_fused.argtypes = [C.POINTER(TailArgs), C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.mkgnn_flat_copy.restype = C.c_int
+    lib.mkgnn_flat_copy.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.mkgnn_tail_flush.restype = C.c_int
     lib.mkgnn_tail_flush.argtypes = [C.c_void_p]
     lib.mkgnn_rows_presplit.restype = C.c_int

@@ -83,9 +83,61 @@ __global__ void __launch_bounds__(256) adamw_step_kernel(AdamArgs a) {
     }
 }
 
+// Many small tensors into their slots of one flat buffer (or back) in ONE launch: the data-parallel step's gradients into the
+// buffer RCCL sums (dp.FlatGradAllReduce).  torch._foreach_copy_ over the model's ~50 gradients is two multi-tensor launches of
+// 12 us each at the end of every step's backward; this is one of launch-floor length (0.5 MB).
+constexpr int COPY_MAX_ITEMS = 120;
+struct CopyItem { float* dst; const float* src; int32_t n; int32_t pad; };
+struct CopyArgs { CopyItem t[COPY_MAX_ITEMS]; int32_t blk_start[COPY_MAX_ITEMS + 1]; int32_t nt; };
+__global__ void __launch_bounds__(256) flat_copy_kernel(CopyArgs a) {
+    int lo = 0, hi = a.nt - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (a.blk_start[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const CopyItem T = a.t[lo];
+    const int base = ((int)blockIdx.x - a.blk_start[lo]) * ADAM_CHUNK;
+    float v[ADAM_CHUNK / 256];
+#pragma unroll
+    for (int k = 0; k < ADAM_CHUNK / 256; ++k) {
+        const int i = base + 256 * k + (int)threadIdx.x;
+        v[k] = T.src[i < T.n ? i : T.n - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < ADAM_CHUNK / 256; ++k) {
+        const int i = base + 256 * k + (int)threadIdx.x;
+        if (i < T.n) T.dst[i] = v[k];
+    }
+}
+
 }  // namespace mkgnn
 
 using namespace mkgnn;
+
+extern "C" int mkgnn_flat_copy(const mkgnn_copy_item* items, int32_t n_items, void* stream) {
+    if (n_items < 0) return api_fail("mkgnn_flat_copy: %d items", n_items);
+    if (n_items == 0) return 0;
+    if (!items) return api_fail("mkgnn_flat_copy: null pointer");
+    hipStream_t st = (hipStream_t)stream;
+    CopyArgs a{};
+    for (int32_t first = 0; first < n_items; first += COPY_MAX_ITEMS) {
+        const int nt = n_items - first < COPY_MAX_ITEMS ? n_items - first : COPY_MAX_ITEMS;
+        int blocks = 0;
+        for (int i = 0; i < nt; ++i) {
+            const mkgnn_copy_item& s = items[first + i];
+            if (!s.dst || !s.src || s.numel < 1 || s.numel > (1 << 30))
+                return api_fail("mkgnn_flat_copy: item %d: null pointer or numel %lld out of range", first + i, (long long)s.numel);
+            a.t[i] = CopyItem{s.dst, s.src, (int32_t)s.numel, 0};
+            a.blk_start[i] = blocks;
+            blocks += (int)((s.numel + ADAM_CHUNK - 1) / ADAM_CHUNK);
+        }
+        a.blk_start[nt] = blocks;
+        a.nt = nt;
+        flat_copy_kernel<<<blocks, 256, 0, st>>>(a);
+    }
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : api_hip_fail("mkgnn_flat_copy", e);
+}
 
 extern "C" int64_t mkgnn_adamw_state_floats(int64_t numel) {
     return numel < 1 ? 0 : 2 * numel + 3 + (numel + ADAM_CHUNK - 1) / ADAM_CHUNK;

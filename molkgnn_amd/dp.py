@@ -80,6 +80,7 @@ class FlatGradAllReduce:
         self._filled: List[torch.nn.Parameter] = []
         self._flag_cache: dict = {}
         self._zero_cache: dict = {}
+        self._copy_tables: dict = {}             # mkgnn_flat_copy tables, by the pointers they hold
 
     @property
     def nbytes(self) -> int:
@@ -109,8 +110,33 @@ class FlatGradAllReduce:
             if len(self._flag_cache) < 64:
                 self._flag_cache[pattern] = local
         src = [g if g is not None else self._zeros_like(i) for i, g in enumerate(grads)]
-        torch._foreach_copy_(self.views + [self.flags], src + [local])
+        if not self._hip_copy(self.views + [self.flags], src + [local]):
+            torch._foreach_copy_(self.views + [self.flags], src + [local])
         return have
+
+    def _hip_copy(self, dst: List[torch.Tensor], src: List[torch.Tensor]) -> bool:
+        """``mkgnn_flat_copy``: the whole list in one launch (contiguous float32 tensors on one GPU: anything else is left to
+        ``torch._foreach_copy_``, two multi-tensor launches of 12 us each where this is one of 6)."""
+        if not dst or not dst[0].is_cuda:
+            return False
+        dev = dst[0].device
+        for d, s in zip(dst, src):
+            if not (d.is_cuda and s.is_cuda and d.device == dev and s.device == dev and d.dtype == torch.float32
+                    and s.dtype == torch.float32 and d.is_contiguous() and s.is_contiguous() and d.numel() == s.numel()):
+                return False
+        import ctypes as C
+        from . import _lib
+        key = tuple((d.data_ptr(), s.data_ptr(), d.numel()) for d, s in zip(dst, src) if d.numel())
+        table = self._copy_tables.get(key)
+        if table is None:                             # (pointers are stable from step to step: one table per gradient pattern)
+            table = (_lib.CopyItem * len(key))()
+            for e, (dp_, sp_, n) in zip(table, key):
+                e.dst, e.src, e.numel = dp_, sp_, n
+            if len(self._copy_tables) < 64:
+                self._copy_tables[key] = table
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().mkgnn_flat_copy(C.cast(table, C.c_void_p), len(key), _lib.stream_ptr(dev)), "mkgnn_flat_copy")
+        return True
 
     def _zeros_like(self, i: int) -> torch.Tensor:
         z = self._zero_cache.get(i)

@@ -1862,3 +1862,32 @@ def test_deferred_bank_preparation_is_carried_by_the_batch_norm_and_changes_noth
     l1, g1 = step(True)
     l0, g0 = step(False)
     assert l1 == l0 and len(g1) == len(g0) and all(torch.equal(a, c) for a, c in zip(g1, g0))
+
+
+def test_flat_copy_fills_the_gradient_buffer_like_foreach_copy():
+    """``mkgnn_flat_copy`` (ABI v7): ``dp.FlatGradAllReduce._fill`` -- the data-parallel step's gradients (and has-gradient flags) into
+    the flat buffer one collective sums -- as ONE launch; the buffer is bit for bit ``torch._foreach_copy_``'s, tensors of 1 to
+    5 500 elements, a missing gradient filled with zeros."""
+    from molkgnn_amd import dp
+    from molkgnn_amd.train import GNNModel
+    dev = _dev()
+    torch.manual_seed(5)
+    model = GNNModel().to(dev)
+    params = list(model.parameters())
+    red = dp.FlatGradAllReduce(params, dp.NEVER_TRAINED, [n for n, _ in model.named_parameters()])
+    grads = [torch.randn_like(p) for p in red.params]
+    grads[3] = None
+    red.prepare_patterns([grads])
+    used = []
+    orig = red._hip_copy
+    red._hip_copy = lambda d, s: (used.append(1), orig(d, s))[1]
+    red._fill(grads)
+    torch.cuda.synchronize()
+    assert used, "the HIP copy was not taken"
+    got = red._buf.clone()
+    red._buf.zero_()
+    red._hip_copy = lambda d, s: False                    # the PyTorch path
+    red._fill(grads)
+    torch.cuda.synchronize()
+    assert torch.equal(got, red._buf)
+    assert float(red.flags.sum()) == len(grads) - 1
